@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the brickmap traversal path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+A step is one full frame of the workload (all pixels, every ray the shader
+casts for them) at one of the three fixed camera views, cycled V0,V1,V2.  The
+scene is resident in HBM before the timed region.  For N>1 the driver launches
+one process per GPU (torch.distributed, backend nccl = RCCL): the frame is
+sharded by interleaved 16x16 tiles and gathered to rank 0 once per frame.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VIEW_ORDER = ["V0", "V1", "V2"]
+
+
+def cpu_baseline(w, grid, view: str, budget_rows: int):
+    """Oracle (CPU restatement of the reference shader) on the host cores, bounded sample: every
+    k-th 4-row band of one frame.  kind = "port" (the reference itself cannot be built here)."""
+    from oracle import oracle as O
+    from tests.helpers import oracle_scene_from_grid
+    from zig_vulkan_amd import workloads as W
+    cores = os.cpu_count() or 1
+    scene = oracle_scene_from_grid(grid)
+    cam, sun = W.camera_for(w, view), W.sun_for(w)
+    pc = O.push_constants(cam.blob(), sun.blob())
+    # sample: rows [y, y+4) for y in range(0, H, stride) -> about budget_rows rows, spread over the frame
+    stride = max(4, (w.height // max(budget_rows, 4)) * 4)
+    import ctypes as C
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    L = O.lib()
+    bands = [(y, min(y + 4, w.height)) for y in range(0, w.height, stride)]
+    f32 = np.zeros((w.height, w.width, 4), dtype=np.float32)
+    groups = [bands[i::cores] for i in range(cores)]
+
+    def work(group):
+        c = O.Counters()
+        for a, b in group:
+            L.oracle_render_rows(C.byref(scene.c), pc.ctypes.data, a, b, f32.ctypes.data, None, C.byref(c))
+        return c.rays
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        rays = sum(ex.map(work, groups))
+    dt = time.perf_counter() - t0
+    rows = sum(b - a for a, b in bands)
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{rows} of {w.height} rows (every {stride}th 4-row band) of view {view}, {rays} rays in {dt:.2f} s; "
+                      f"oracle/vrt_oracle.c -O2, {cores} threads"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=540)
+    ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from zig_vulkan_amd import workloads as W
+    from zig_vulkan_amd.dist import FrameGather
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the traversal path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1 or "RANK" in os.environ:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    w = W.WORKLOADS[args.workload or W.HEADLINE]
+    grid = W.build_grid(w)
+    sharded = world > 1 or args.force_gather
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- rays and algorithmic bytes per view: counted by a counters build of the kernel (untimed) ----
+    per_view = {}
+    if rank == 0:
+        rtc = W.make_renderer(w, grid, enable_counters=True, device_id=local_rank, kernel_variant=args.variant)
+        for v in VIEW_ORDER:
+            W.set_view(rtc, v)
+            rtc.draw()
+            c = rtc.counters()
+            per_view[v] = {"rays": c["rays"],
+                           "bytes": 4 * c["status_loads"] + 4 * c["bricks_entered"] + c["voxel_steps"] + 25 * c["hits"]
+                           + 4 * w.width * w.height,
+                           "counters": c}
+        rtc.deinit()
+    if dist is not None and world > 1:
+        obj = [per_view]
+        dist.broadcast_object_list(obj, src=0)
+        per_view = obj[0]
+
+    # ---- the timed renderer ----
+    fg = None
+    if sharded:
+        fg = FrameGather(w.width, w.height, rank, world, torch.device("cuda", local_rank))
+        rt = W.make_renderer(w, grid, device_id=local_rank, shard_rank=rank, shard_count=world, stream=stream,
+                             external_target_rgba8=fg.shard.data_ptr(), kernel_variant=args.variant)
+    else:
+        rt = W.make_renderer(w, grid, device_id=local_rank, stream=stream, kernel_variant=args.variant)
+    rt.wait()
+
+    cams = {}
+    for v in VIEW_ORDER:
+        W.set_view(rt, v)
+        cams[v] = bytes(rt.camera.d_camera)
+
+    import ctypes as C
+    from zig_vulkan_amd import _lib as L
+
+    def step(i: int) -> None:
+        v = VIEW_ORDER[i % len(VIEW_ORDER)]
+        C.memmove(C.byref(rt.camera.d_camera), cams[v], 96)
+        rt.draw()
+        if sharded:
+            fg.gather()
+            fg.assemble(rt)
+
+    def barrier() -> None:
+        if dist is not None and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    rt.wait()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None and world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- dominant-kernel duration with HIP events on the kernel's own stream (N=1 only) ----
+    roofline = None
+    kernel_ms_view = {}
+    if rank == 0 and not sharded:
+        reps = max(5, args.steps // len(VIEW_ORDER))
+        for v in VIEW_ORDER:
+            C.memmove(C.byref(rt.camera.d_camera), cams[v], 96)
+            rt.draw(frames=reps)
+            kernel_ms_view[v] = rt.last_kernel_ms()
+        avg_ms = sum(kernel_ms_view.values()) / len(kernel_ms_view)
+        avg_bytes = sum(per_view[v]["bytes"] for v in VIEW_ORDER) / len(VIEW_ORDER)
+        achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                    "traffic": None, "kernel": rt.kernel_name(), "kernel_ms_avg": avg_ms,
+                    "kernel_ms_per_view": kernel_ms_view, "algorithmic_bytes_per_launch": avg_bytes}
+
+    if rank == 0:
+        total_rays = sum(per_view[VIEW_ORDER[i % len(VIEW_ORDER)]]["rays"] for i in range(args.steps))
+        out = {
+            "metric": "Mrays/s at 1920x1080 on 512^3 brickmap; achieved % of HBM roofline",
+            "value": total_rays / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": w.name, "frame": f"{w.width}x{w.height}", "grid": f"{w.voxels}^3 voxels, {w.brick_dimension}^3 bricks",
+                       "rays": "primary + shadow" if w.sun_enabled else "primary", "spp": w.spp, "max_bounce": w.max_bounce,
+                       "views": VIEW_ORDER, "rays_per_frame": {v: per_view[v]["rays"] for v in VIEW_ORDER},
+                       "parallelism": f"image tiles 16x16 interleaved over {world} GPU(s), 1 RCCL gather/frame" if sharded else "1 GPU, whole frame"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, grid, "V2", args.cpu_rows)
+        print(json.dumps(out))
+    rt.deinit()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,288 @@
+/*
+ * vrt_hip.h — C ABI of the MI355X-native brickmap ray tracer (libvrt_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of Avokadoen/zig_vulkan: the
+ * vkCmdDispatch of assets/shaders/brick_raytracer.comp
+ * (src/modules/voxel_rt/ComputePipeline.zig:550) together with the buffer
+ * creation and the seven uploads that feed it.  Every entry point cites the
+ * reference interface it replaces.  Plain pointers and sizes only; no C++ or
+ * torch types cross this boundary; nothing here throws or aborts.
+ *
+ * Threading: one vrt_ctx is used from one thread at a time (as the reference
+ * uses its ComputePipeline from the main thread, src/main.zig:156-195).
+ * Ownership: every pointer argument is borrowed for the duration of the call.
+ */
+#ifndef VRT_HIP_H
+#define VRT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRT_ABI_VERSION 1u
+
+/* ---- status codes (replace Zig error unions, e.g. StagingRamp.zig:320-325) */
+enum {
+    VRT_OK = 0,
+    VRT_E_INVALID_ARG = -1,
+    VRT_E_OOM = -2,
+    VRT_E_OUT_OF_RANGE = -3,
+    VRT_E_HIP = -4,
+    VRT_E_NO_DEVICE = -5,
+    VRT_E_STATE = -6
+};
+
+/* ---- buffer ids: same order as shader bindings 1..7
+ * (assets/shaders/brick_raytracer.comp:79,105,112,117,124,128,132) and as
+ * Pipeline.transfer{GridState,Materials,BrickStatuses,BrickIndices,
+ * BrickOccupancy,BrickStartIndex,MaterialIndices} (Pipeline.zig:560-652). */
+typedef enum vrt_buffer_id {
+    VRT_BUF_GRID_STATE = 0,        /* State.Device, 64 B (State.zig:60-79)        */
+    VRT_BUF_MATERIALS = 1,         /* gpu_types.Material[], 20 B each             */
+    VRT_BUF_BRICK_STATUS = 2,      /* BrickStatusMask[] u32, 1 bit / grid cell    */
+    VRT_BUF_BRICK_INDEX = 3,       /* IndexToBrick[] u32                          */
+    VRT_BUF_BRICK_OCCUPANCY = 4,   /* u8[], b^3/8 bytes per brick                 */
+    VRT_BUF_BRICK_START_INDEX = 5, /* Brick.StartIndex[] u32 (u31 value + u1 type) */
+    VRT_BUF_MATERIAL_INDEX = 6,    /* u8[], b^3 per brick                         */
+    VRT_BUF_COUNT = 7
+} vrt_buffer_id;
+
+/* ---- data contract structs (byte-for-byte the reference's extern structs) */
+
+/* State.Device (State.zig:60-79) == BrickGridState UBO (comp:79-95). 64 bytes. */
+typedef struct vrt_grid_state {
+    uint32_t voxel_dim_x, voxel_dim_y, voxel_dim_z;
+    uint32_t dim_x, dim_y, dim_z;
+    uint32_t padding1, padding2;
+    float min_point_base_t[4];
+    float max_point_scale[4];
+} vrt_grid_state;
+
+/* gpu_types.Material (gpu_types.zig:16-32) == comp:97-104. 20 bytes. */
+typedef struct vrt_material {
+    uint32_t type; /* 0 lambertian, 1 metal, 2 dielectric */
+    float albedo_r, albedo_g, albedo_b;
+    float type_data;
+} vrt_material;
+
+/* Camera.Device (Camera.zig:183-193), 96 bytes; Zig @Vector(3,f32) is 16-byte
+ * sized and aligned, hence the explicit pads.  Push-constant bytes 0..95. */
+typedef struct vrt_camera_device {
+    uint32_t image_width, image_height;
+    uint32_t _pad0[2];
+    float horizontal[3];
+    float _pad1;
+    float vertical[3];
+    float _pad2;
+    float lower_left_corner[3];
+    float _pad3;
+    float origin[3];
+    float _pad4;
+    int32_t samples_per_pixel;
+    int32_t max_bounce; /* device value = Config.max_bounce + 1 (Camera.zig:74) */
+    uint32_t _pad5[2];
+} vrt_camera_device;
+
+/* Sun.Device (Sun.zig:13-18), 32 bytes.  Push-constant bytes 96..127. */
+typedef struct vrt_sun_device {
+    float position[3];
+    uint32_t enabled;
+    float color[3];
+    float radius;
+} vrt_sun_device;
+
+/* ---- creation ------------------------------------------------------------
+ * Replaces ComputePipeline.init(allocator, ctx, target_image_info,
+ * StateConfigs{uniform_sizes, storage_sizes}, specialization_constants)
+ * (ComputePipeline.zig:67-73) as called from Pipeline.init
+ * (Pipeline.zig:272-316): image size, buffer sizes (derived here from the grid
+ * dimensions exactly as Pipeline.zig:273-283 derives them from the State slice
+ * lengths), and the specialization constants (brick_dimension -> brick_bits,
+ * brick_bytes, brick_voxel_scale; Pipeline.zig:293-315). */
+typedef struct vrt_config {
+    uint32_t struct_size;       /* = sizeof(vrt_config)                          */
+    uint32_t abi_version;       /* = VRT_ABI_VERSION                             */
+    uint32_t width, height;     /* target image (Pipeline.zig:103-126)           */
+    uint32_t brick_dimension;   /* 4 (reference, State.zig:5) or 8               */
+    uint32_t dim_x, dim_y, dim_z; /* bricks per axis (Grid.zig:36)               */
+    uint64_t brick_alloc;       /* 0 => dim_x*dim_y*dim_z (Grid.zig:51)          */
+    uint32_t material_capacity; /* 0 => 256 (Pipeline.zig:30)                    */
+    int32_t device_id;          /* HIP device; -1 => current device              */
+    uint32_t want_float_output; /* also keep an RGBA32F target (parity checks)   */
+    uint32_t enable_counters;   /* traversal counters (S,K,V,H,rays); slower     */
+    /* image-tile sharding across processes (one process per GPU).  The frame is
+     * cut into tile_w x tile_h tiles, numbered row-major; this context renders
+     * tiles t with t % shard_count == shard_rank into a packed tile-major
+     * buffer (see vrt_shard_info).  shard_count <= 1 => whole frame, row-major. */
+    uint32_t shard_rank, shard_count;
+    uint32_t tile_w, tile_h;    /* 0 => 16 x 16; multiples of 8                  */
+    /* optional caller-owned device memory / stream (the reference pipeline does
+     * not own its target image either, ComputePipeline.zig:64-66).  0 => owned. */
+    void *external_target_rgba8;
+    void *external_target_rgba32f;
+    void *stream;               /* hipStream_t; 0 => a stream owned by the ctx   */
+    uint32_t kernel_variant;    /* 0 => default; see DESIGN.md "kernel variants" */
+    uint32_t _reserved[7];
+} vrt_config;
+
+typedef struct vrt_ctx vrt_ctx;
+
+int vrt_create(const vrt_config *cfg, vrt_ctx **out);
+
+/* ComputePipeline.deinit (ComputePipeline.zig:385-415): waits, then frees. */
+void vrt_destroy(vrt_ctx *ctx);
+
+/* ---- uploads --------------------------------------------------------------
+ * Replaces the seven Pipeline.transfer* (Pipeline.zig:560-652).  byte_offset =
+ * element offset * element size of the reference call.  The bytes are copied
+ * out of `src` before the call returns (the caller keeps ownership, as
+ * BrickGrid keeps its slices, Grid.zig:117-126) and the device copy is ordered
+ * before the next vrt_dispatch.  Out-of-range => VRT_E_OUT_OF_RANGE (the
+ * reference's DestOutOfDeviceMemory, StagingRamp.zig:320-325). */
+int vrt_upload(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, const void *src, uint64_t nbytes);
+
+/* Size in bytes of device buffer `id` (Pipeline.zig:273-283). */
+uint64_t vrt_buffer_size(const vrt_ctx *ctx, vrt_buffer_id id);
+
+/* Device-to-device variant of vrt_upload for sources already in HBM. */
+int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, const void *dev_src, uint64_t nbytes);
+
+/* ---- dispatch -------------------------------------------------------------
+ * Replaces ComputePipeline.dispatch(ctx, workgroup_size, camera, sun)
+ * (ComputePipeline.zig:417-463): waits for the previous frame like the fence
+ * wait at :423-434, passes the 96+32 bytes the reference pushes as push
+ * constants (:488-505) and launches ceil(w/wg) x ceil(h/wg) workgroups
+ * (:547-550).  Asynchronous; vrt_wait() plays the role of the returned
+ * semaphore/fence. */
+int vrt_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun);
+int vrt_wait(vrt_ctx *ctx);
+
+/* Same launch repeated `frames` times back-to-back on the ctx stream without
+ * host round trips (benchmarking; every frame is a full render). */
+int vrt_dispatch_repeat(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames);
+
+/* ---- results --------------------------------------------------------------
+ * Stand in for handing the storage image to the graphics pass
+ * (Pipeline.zig:494-517); layout is what Texture.copyToHost (Texture.zig:185-237)
+ * yields: rows top to bottom, tightly packed, 4 bytes (or 4 floats) per pixel.
+ * For a sharded ctx these return the packed tile-major shard instead. */
+int vrt_read_rgba8(vrt_ctx *ctx, void *dst, uint64_t nbytes);
+int vrt_read_rgba32f(vrt_ctx *ctx, void *dst, uint64_t nbytes);
+void *vrt_device_target_rgba8(vrt_ctx *ctx);   /* device pointer of the target */
+void *vrt_device_target_rgba32f(vrt_ctx *ctx);
+uint64_t vrt_target_bytes_rgba8(const vrt_ctx *ctx);
+
+/* Shard geometry.  tiles_x*tiles_y tiles in the frame; this ctx owns
+ * owned_tiles of them; every shard buffer is padded to tiles_per_rank tiles of
+ * tile_w*tile_h pixels so that a gather has equal counts. */
+typedef struct vrt_shard_info {
+    uint32_t tiles_x, tiles_y, tile_w, tile_h;
+    uint32_t shard_rank, shard_count;
+    uint32_t owned_tiles, tiles_per_rank;
+} vrt_shard_info;
+int vrt_get_shard_info(const vrt_ctx *ctx, vrt_shard_info *out);
+
+/* Root-side un-swizzle after the per-frame gather: `gathered` holds
+ * shard_count consecutive packed shards (rank-major) of bytes_per_pixel-sized
+ * pixels in device memory; writes the row-major frame to `dst_frame` (device).
+ * Runs on the ctx stream. */
+int vrt_assemble_frame(vrt_ctx *ctx, const void *gathered, void *dst_frame, uint32_t bytes_per_pixel);
+
+/* ---- measurement ---------------------------------------------------------- */
+/* hipEvent time of the most recent vrt_dispatch / average per frame of the
+ * most recent vrt_dispatch_repeat, in milliseconds; <0 if none completed. */
+double vrt_last_kernel_ms(vrt_ctx *ctx);
+
+/* Traversal counters of the last dispatch (enable_counters=1):
+ * rays = GridHit invocations, S = status-word loads (comp:323-326),
+ * K = occupied bricks entered (comp:337), V = voxel steps (comp:415),
+ * H = hits (comp:422-427), grid_steps = brick-level DDA iterations. */
+typedef struct vrt_counters {
+    uint64_t rays, status_loads, bricks_entered, voxel_steps, hits, grid_steps;
+} vrt_counters;
+int vrt_get_counters(vrt_ctx *ctx, vrt_counters *out);
+
+const char *vrt_last_error(const vrt_ctx *ctx); /* ctx may be NULL: create errors */
+uint32_t vrt_abi_version(void);
+const char *vrt_kernel_name(const vrt_ctx *ctx); /* mangled name of the traversal kernel in use */
+
+/* =========================================================================
+ * Host-side scene objects (CPU only; usable without a GPU).  C view of the
+ * C++ mirror of the reference's "side" modules so that other hosts (the Zig
+ * app, Python tests) can build the exact byte contract.
+ * ========================================================================= */
+
+/* ---- BrickGrid: Grid.zig:36-211 + State.zig + MaterialAllocator.zig ------- */
+typedef struct vrt_grid vrt_grid;
+
+typedef struct vrt_grid_config {       /* Grid.zig:13-20 */
+    uint64_t brick_alloc;              /* 0 => all bricks                        */
+    float base_t;                      /* default 0.01                           */
+    float min_point[3];
+    float scale;                       /* default 1.0                            */
+    uint32_t brick_dimension;          /* 0 => 4 (State.zig:5); 4 or 8           */
+} vrt_grid_config;
+
+int vrt_grid_create(uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, const vrt_grid_config *cfg, vrt_grid **out);
+void vrt_grid_destroy(vrt_grid *g);
+/* BrickGrid.insert (Grid.zig:129-194), including the Y flip and delta tracking.
+ * Returns VRT_E_OUT_OF_RANGE where the reference would trip its asserts. */
+int vrt_grid_insert(vrt_grid *g, uint64_t x, uint64_t y, uint64_t z, uint8_t material_index);
+/* Bulk form: n records of {x,y,z} u32 triples + material byte. */
+int vrt_grid_insert_many(vrt_grid *g, const uint32_t *xyz, const uint8_t *materials, uint64_t n);
+const vrt_grid_state *vrt_grid_device_state(const vrt_grid *g);
+/* Borrowed pointer + byte size of host array `id` (GRID_STATE..MATERIAL_INDEX;
+ * MATERIALS is not part of the grid => NULL). */
+const void *vrt_grid_data(const vrt_grid *g, vrt_buffer_id id, uint64_t *nbytes);
+uint32_t vrt_grid_active_bricks(const vrt_grid *g);
+uint32_t vrt_grid_brick_dimension(const vrt_grid *g);
+/* DeviceDataDelta (State.zig:14-57): dirty element range [from,to) of array
+ * `id`; returns 1 if active, 0 if inactive. */
+int vrt_grid_delta(const vrt_grid *g, vrt_buffer_id id, uint64_t *from, uint64_t *to);
+void vrt_grid_reset_delta(vrt_grid *g, vrt_buffer_id id);
+
+/* VoxelRT.init's transferGridState (VoxelRT.zig:62) + a full upload of the five
+ * arrays (what the first updateGridDelta amounts to after scene build). */
+int vrt_upload_grid(vrt_ctx *ctx, vrt_grid *g);
+/* VoxelRT.updateGridDelta (VoxelRT.zig:107-172): uploads only the dirty
+ * [from,to) of each of the 5 arrays, then resets the deltas. */
+int vrt_update_grid_delta(vrt_ctx *ctx, vrt_grid *g);
+
+/* ---- Camera (Camera.zig:36-77,162-180) and Sun (Sun.zig:35-63) ----------- */
+typedef struct vrt_camera_config {     /* Camera.zig:5-14 (render-relevant part) */
+    float viewport_height;             /* default 2                              */
+    float origin[3];
+    int32_t samples_per_pixel;         /* default 2                              */
+    int32_t max_bounce;                /* default 2 (device gets +1)             */
+} vrt_camera_config;
+/* Camera.init(vertical_fov, w, h, config): identity orientation, forward (0,0,1). */
+int vrt_camera_init(float vertical_fov_deg, uint32_t image_width, uint32_t image_height,
+                    const vrt_camera_config *cfg, vrt_camera_device *out);
+/* propogatePitchChange for a given unit forward vector (Camera.zig:167-180):
+ * recomputes horizontal / vertical / lower_left_corner in place. */
+int vrt_camera_set_forward(vrt_camera_device *cam, float vertical_fov_deg, float viewport_height,
+                           const float forward[3]);
+
+typedef struct vrt_sun_config {        /* Sun.zig:4-11 (render-relevant part)    */
+    uint32_t enabled;                  /* default 1                              */
+    float color[3];                    /* default 1, 1.1, 1                      */
+    float radius;                      /* default 5                              */
+    float sun_distance;                /* default 1000                           */
+} vrt_sun_config;
+int vrt_sun_init(const vrt_sun_config *cfg, vrt_sun_device *out);
+
+/* The reference's default material table (terrain.zig:130-196), 8 entries. */
+uint32_t vrt_default_materials(vrt_material *out, uint32_t capacity);
+
+/* ---- deterministic synthetic scenes (bench/test input) --- */
+/* Value-noise terrain shell + water inserted through vrt_grid_insert. */
+int vrt_synth_terrain(vrt_grid *g, uint64_t seed);
+/* Sparse field of solid spheres; fraction ~p of 32-voxel blocks occupied. */
+int vrt_synth_sparse(vrt_grid *g, uint64_t seed, float p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRT_HIP_H */

@@ -1,0 +1,191 @@
+"""ctypes binding of libvrt_hip.so — the C ABI declared in include/vrt_hip.h.
+
+This is the only place the shared library is loaded.  There is no fallback: if
+the library is missing or a symbol is absent, importing fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvrt_hip.so")
+
+VRT_ABI_VERSION = 1
+
+VRT_OK = 0
+VRT_E_INVALID_ARG = -1
+VRT_E_OOM = -2
+VRT_E_OUT_OF_RANGE = -3
+VRT_E_HIP = -4
+VRT_E_NO_DEVICE = -5
+VRT_E_STATE = -6
+
+ERROR_NAMES = {
+    VRT_E_INVALID_ARG: "VRT_E_INVALID_ARG",
+    VRT_E_OOM: "VRT_E_OOM",
+    VRT_E_OUT_OF_RANGE: "VRT_E_OUT_OF_RANGE",
+    VRT_E_HIP: "VRT_E_HIP",
+    VRT_E_NO_DEVICE: "VRT_E_NO_DEVICE",
+    VRT_E_STATE: "VRT_E_STATE",
+}
+
+# vrt_buffer_id — shader bindings 1..7
+BUF_GRID_STATE, BUF_MATERIALS, BUF_BRICK_STATUS, BUF_BRICK_INDEX, BUF_BRICK_OCCUPANCY, BUF_BRICK_START_INDEX, BUF_MATERIAL_INDEX = range(7)
+BUF_COUNT = 7
+
+
+class VrtError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class GridState(C.Structure):  # State.Device, State.zig:60-79
+    _fields_ = [
+        ("voxel_dim_x", C.c_uint32), ("voxel_dim_y", C.c_uint32), ("voxel_dim_z", C.c_uint32),
+        ("dim_x", C.c_uint32), ("dim_y", C.c_uint32), ("dim_z", C.c_uint32),
+        ("padding1", C.c_uint32), ("padding2", C.c_uint32),
+        ("min_point_base_t", C.c_float * 4),
+        ("max_point_scale", C.c_float * 4),
+    ]
+
+
+class Material(C.Structure):  # gpu_types.Material, gpu_types.zig:16-32
+    _fields_ = [("type", C.c_uint32), ("albedo_r", C.c_float), ("albedo_g", C.c_float), ("albedo_b", C.c_float),
+                ("type_data", C.c_float)]
+
+
+class CameraDevice(C.Structure):  # Camera.Device, Camera.zig:183-193 (96 bytes)
+    _fields_ = [
+        ("image_width", C.c_uint32), ("image_height", C.c_uint32), ("_pad0", C.c_uint32 * 2),
+        ("horizontal", C.c_float * 3), ("_pad1", C.c_float),
+        ("vertical", C.c_float * 3), ("_pad2", C.c_float),
+        ("lower_left_corner", C.c_float * 3), ("_pad3", C.c_float),
+        ("origin", C.c_float * 3), ("_pad4", C.c_float),
+        ("samples_per_pixel", C.c_int32), ("max_bounce", C.c_int32), ("_pad5", C.c_uint32 * 2),
+    ]
+
+
+class SunDevice(C.Structure):  # Sun.Device, Sun.zig:13-18 (32 bytes)
+    _fields_ = [("position", C.c_float * 3), ("enabled", C.c_uint32), ("color", C.c_float * 3), ("radius", C.c_float)]
+
+
+class Config(C.Structure):  # vrt_config
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
+        ("width", C.c_uint32), ("height", C.c_uint32),
+        ("brick_dimension", C.c_uint32),
+        ("dim_x", C.c_uint32), ("dim_y", C.c_uint32), ("dim_z", C.c_uint32),
+        ("brick_alloc", C.c_uint64),
+        ("material_capacity", C.c_uint32),
+        ("device_id", C.c_int32),
+        ("want_float_output", C.c_uint32),
+        ("enable_counters", C.c_uint32),
+        ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32),
+        ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
+        ("external_target_rgba8", C.c_void_p),
+        ("external_target_rgba32f", C.c_void_p),
+        ("stream", C.c_void_p),
+        ("kernel_variant", C.c_uint32),
+        ("_reserved", C.c_uint32 * 7),
+    ]
+
+
+class ShardInfo(C.Structure):
+    _fields_ = [("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
+                ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("owned_tiles", C.c_uint32),
+                ("tiles_per_rank", C.c_uint32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("status_loads", C.c_uint64), ("bricks_entered", C.c_uint64),
+                ("voxel_steps", C.c_uint64), ("hits", C.c_uint64), ("grid_steps", C.c_uint64)]
+
+
+class GridConfig(C.Structure):  # Grid.zig:13-20
+    _fields_ = [("brick_alloc", C.c_uint64), ("base_t", C.c_float), ("min_point", C.c_float * 3), ("scale", C.c_float),
+                ("brick_dimension", C.c_uint32)]
+
+
+class CameraConfig(C.Structure):  # Camera.zig:5-14
+    _fields_ = [("viewport_height", C.c_float), ("origin", C.c_float * 3), ("samples_per_pixel", C.c_int32),
+                ("max_bounce", C.c_int32)]
+
+
+class SunConfig(C.Structure):  # Sun.zig:4-11
+    _fields_ = [("enabled", C.c_uint32), ("color", C.c_float * 3), ("radius", C.c_float), ("sun_distance", C.c_float)]
+
+
+assert C.sizeof(GridState) == 64 and C.sizeof(Material) == 20
+assert C.sizeof(CameraDevice) == 96 and C.sizeof(SunDevice) == 32
+
+_P = C.POINTER
+_ctx = C.c_void_p
+_grid = C.c_void_p
+
+# name -> (restype, argtypes).  Every function declared in include/vrt_hip.h.
+SIGNATURES = {
+    "vrt_abi_version": (C.c_uint32, []),
+    "vrt_last_error": (C.c_char_p, [_ctx]),
+    "vrt_kernel_name": (C.c_char_p, [_ctx]),
+    "vrt_create": (C.c_int, [_P(Config), _P(_ctx)]),
+    "vrt_destroy": (None, [_ctx]),
+    "vrt_upload": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "vrt_upload_device": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "vrt_buffer_size": (C.c_uint64, [_ctx, C.c_int]),
+    "vrt_dispatch": (C.c_int, [_ctx, _P(CameraDevice), _P(SunDevice)]),
+    "vrt_dispatch_repeat": (C.c_int, [_ctx, _P(CameraDevice), _P(SunDevice), C.c_uint32]),
+    "vrt_wait": (C.c_int, [_ctx]),
+    "vrt_read_rgba8": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
+    "vrt_read_rgba32f": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
+    "vrt_device_target_rgba8": (C.c_void_p, [_ctx]),
+    "vrt_device_target_rgba32f": (C.c_void_p, [_ctx]),
+    "vrt_target_bytes_rgba8": (C.c_uint64, [_ctx]),
+    "vrt_get_shard_info": (C.c_int, [_ctx, _P(ShardInfo)]),
+    "vrt_assemble_frame": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "vrt_last_kernel_ms": (C.c_double, [_ctx]),
+    "vrt_get_counters": (C.c_int, [_ctx, _P(Counters)]),
+    "vrt_grid_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _P(GridConfig), _P(_grid)]),
+    "vrt_grid_destroy": (None, [_grid]),
+    "vrt_grid_insert": (C.c_int, [_grid, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint8]),
+    "vrt_grid_insert_many": (C.c_int, [_grid, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "vrt_grid_device_state": (_P(GridState), [_grid]),
+    "vrt_grid_data": (C.c_void_p, [_grid, C.c_int, _P(C.c_uint64)]),
+    "vrt_grid_active_bricks": (C.c_uint32, [_grid]),
+    "vrt_grid_brick_dimension": (C.c_uint32, [_grid]),
+    "vrt_grid_delta": (C.c_int, [_grid, C.c_int, _P(C.c_uint64), _P(C.c_uint64)]),
+    "vrt_grid_reset_delta": (None, [_grid, C.c_int]),
+    "vrt_upload_grid": (C.c_int, [_ctx, _grid]),
+    "vrt_update_grid_delta": (C.c_int, [_ctx, _grid]),
+    "vrt_camera_init": (C.c_int, [C.c_float, C.c_uint32, C.c_uint32, _P(CameraConfig), _P(CameraDevice)]),
+    "vrt_camera_set_forward": (C.c_int, [_P(CameraDevice), C.c_float, C.c_float, _P(C.c_float * 3)]),
+    "vrt_sun_init": (C.c_int, [_P(SunConfig), _P(SunDevice)]),
+    "vrt_default_materials": (C.c_uint32, [_P(Material), C.c_uint32]),
+    "vrt_synth_terrain": (C.c_int, [_grid, C.c_uint64]),
+    "vrt_synth_sparse": (C.c_int, [_grid, C.c_uint64, C.c_float]),
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C zig_vulkan_amd/csrc` (or __graft_entry__.build()). "
+            "zig_vulkan_amd has no non-HIP implementation of the traversal path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.vrt_abi_version() != VRT_ABI_VERSION:
+        raise ImportError("libvrt_hip.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, ctx=None) -> None:
+    if rc != VRT_OK:
+        msg = lib.vrt_last_error(ctx)
+        raise VrtError(rc, msg.decode() if msg else "")

@@ -1,0 +1,477 @@
+// vrt_api.hip — implementation of the C ABI in include/vrt_hip.h: context
+// (device buffers, stream, events), stream-ordered uploads through a pinned
+// staging ring, dispatch of the traversal kernel, read-back, timing.
+//
+// Replaces src/modules/voxel_rt/ComputePipeline.zig (init / dispatch / deinit)
+// and the Pipeline.transfer* family (Pipeline.zig:560-652) with its StagingRamp
+// (render/StagingRamp.zig) for this one path.  There is no CPU fallback: without
+// a HIP device vrt_create fails with VRT_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include "host_brick_grid.hpp"
+#include "vrt_internal.h"
+
+namespace vrt {
+using KernelFn = void (*)(const TraceParams);
+KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant);
+hipError_t launch_trace(KernelFn fn, const TraceParams &p, hipStream_t stream);
+hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per_pixel, uint32_t width, uint32_t height, uint32_t tiles_x,
+                           uint32_t shard_count, uint32_t tiles_per_rank, hipStream_t stream);
+} // namespace vrt
+
+namespace {
+thread_local std::string g_create_error;
+
+constexpr size_t kStagingSlotBytes = 32u << 20; // pinned staging slot
+constexpr int kStagingSlots = 2;
+} // namespace
+
+struct vrt_ctx {
+    vrt_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void *dbuf[VRT_BUF_COUNT] = {};
+    uint64_t dsize[VRT_BUF_COUNT] = {};
+    uint8_t *target8 = nullptr;
+    float *target32f = nullptr;
+    bool own_t8 = false, own_t32 = false;
+    uint64_t target_pixels = 0; // pixels in the (possibly sharded, padded) target
+    vrt::DeviceCounters *d_counters = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool in_flight = false;
+    bool timing_valid = false;
+    uint32_t timed_frames = 0;
+    double last_ms = -1.0;
+    void *staging[kStagingSlots] = {};
+    hipEvent_t staging_ev[kStagingSlots] = {};
+    bool staging_busy[kStagingSlots] = {};
+    int staging_next = 0;
+    vrt::TraceParams params{};
+    vrt::KernelFn kernel = nullptr;
+    vrt_shard_info shard{};
+    std::string err;
+    std::string kernel_name;
+};
+
+namespace {
+
+int fail(vrt_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+int hip_fail(vrt_ctx *ctx, hipError_t e, const char *what) {
+    return fail(ctx, e == hipErrorOutOfMemory ? VRT_E_OOM : VRT_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define VRT_HIP(ctx, call)                                  \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+void free_ctx(vrt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < VRT_BUF_COUNT; i++)
+        if (c->dbuf[i]) (void)hipFree(c->dbuf[i]);
+    if (c->own_t8 && c->target8) (void)hipFree(c->target8);
+    if (c->own_t32 && c->target32f) (void)hipFree(c->target32f);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    for (int i = 0; i < kStagingSlots; i++) {
+        if (c->staging[i]) (void)hipHostFree(c->staging[i]);
+        if (c->staging_ev[i]) (void)hipEventDestroy(c->staging_ev[i]);
+    }
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// wait for the frame in flight (the fence wait of ComputePipeline.zig:423-434)
+int finish_frame(vrt_ctx *c) {
+    if (!c->in_flight) return VRT_OK;
+    VRT_HIP(c, hipEventSynchronize(c->ev_stop));
+    float ms = 0.0f;
+    VRT_HIP(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+    c->last_ms = (double)ms / (double)(c->timed_frames ? c->timed_frames : 1u);
+    c->timing_valid = true;
+    c->in_flight = false;
+    return VRT_OK;
+}
+
+int copy_h2d(vrt_ctx *c, void *dst, const void *src, uint64_t nbytes) {
+    const uint8_t *s = static_cast<const uint8_t *>(src);
+    uint8_t *d = static_cast<uint8_t *>(dst);
+    while (nbytes) {
+        const int slot = c->staging_next;
+        c->staging_next = (slot + 1) % kStagingSlots;
+        if (c->staging_busy[slot]) {
+            VRT_HIP(c, hipEventSynchronize(c->staging_ev[slot]));
+            c->staging_busy[slot] = false;
+        }
+        const size_t n = nbytes < kStagingSlotBytes ? (size_t)nbytes : kStagingSlotBytes;
+        std::memcpy(c->staging[slot], s, n);
+        VRT_HIP(c, hipMemcpyAsync(d, c->staging[slot], n, hipMemcpyHostToDevice, c->stream));
+        VRT_HIP(c, hipEventRecord(c->staging_ev[slot], c->stream));
+        c->staging_busy[slot] = true;
+        s += n;
+        d += n;
+        nbytes -= n;
+    }
+    return VRT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t vrt_abi_version(void) { return VRT_ABI_VERSION; }
+
+const char *vrt_last_error(const vrt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+const char *vrt_kernel_name(const vrt_ctx *ctx) { return ctx ? ctx->kernel_name.c_str() : ""; }
+
+int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
+    if (!out) return fail(nullptr, VRT_E_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!cfg) return fail(nullptr, VRT_E_INVALID_ARG, "cfg is NULL");
+    if (cfg->struct_size != sizeof(vrt_config) || cfg->abi_version != VRT_ABI_VERSION)
+        return fail(nullptr, VRT_E_INVALID_ARG, "vrt_config size/ABI version mismatch");
+    if (cfg->width == 0 || cfg->height == 0) return fail(nullptr, VRT_E_INVALID_ARG, "zero image size");
+    if (cfg->brick_dimension != 4 && cfg->brick_dimension != 8) return fail(nullptr, VRT_E_INVALID_ARG, "brick_dimension must be 4 or 8");
+    const uint64_t cells = (uint64_t)cfg->dim_x * cfg->dim_y * cfg->dim_z;
+    if (cells == 0) return fail(nullptr, VRT_E_INVALID_ARG, "zero grid dimension");
+    if (cells > 0xFFFFFFFFull) return fail(nullptr, VRT_E_OUT_OF_RANGE, "grid has more than 2^32-1 cells (u32 grid index, comp:318)");
+    const uint64_t brick_alloc = cfg->brick_alloc ? cfg->brick_alloc : cells;
+    const uint64_t bits = (uint64_t)cfg->brick_dimension * cfg->brick_dimension * cfg->brick_dimension;
+    if (brick_alloc * bits > 0x80000000ull)
+        return fail(nullptr, VRT_E_OUT_OF_RANGE, "brick_alloc * brick_bits exceeds the u31 start index (State.zig:117-120)");
+    if ((cfg->tile_w && cfg->tile_w != (uint32_t)vrt::kTileW) || (cfg->tile_h && cfg->tile_h != (uint32_t)vrt::kTileH))
+        return fail(nullptr, VRT_E_INVALID_ARG, "tile size must be 16x16 (or 0)");
+    const uint32_t shard_count = cfg->shard_count ? cfg->shard_count : 1u;
+    if (cfg->shard_rank >= shard_count) return fail(nullptr, VRT_E_INVALID_ARG, "shard_rank >= shard_count");
+    if (cfg->kernel_variant >= vrt::kVariantCount) return fail(nullptr, VRT_E_INVALID_ARG, "unknown kernel_variant");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, VRT_E_NO_DEVICE, "no HIP device: libvrt_hip has no CPU path");
+    int device = cfg->device_id;
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) return fail(nullptr, VRT_E_HIP, "hipGetDevice failed");
+    }
+    if (device >= ndev) return fail(nullptr, VRT_E_INVALID_ARG, "device_id out of range");
+
+    vrt_ctx *c = new (std::nothrow) vrt_ctx();
+    if (!c) return fail(nullptr, VRT_E_OOM, "host allocation failed");
+    c->cfg = *cfg;
+    c->cfg.shard_count = shard_count;
+    c->cfg.brick_alloc = brick_alloc;
+    c->cfg.material_capacity = cfg->material_capacity ? cfg->material_capacity : 256u;
+    c->device = device;
+
+#define VRT_CREATE_HIP(call)                                                                   \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            const int rc_ = fail(nullptr, e_ == hipErrorOutOfMemory ? VRT_E_OOM : VRT_E_HIP,   \
+                                 std::string(#call) + ": " + hipGetErrorString(e_));           \
+            free_ctx(c);                                                                       \
+            return rc_;                                                                        \
+        }                                                                                      \
+    } while (0)
+
+    VRT_CREATE_HIP(hipSetDevice(device));
+    if (cfg->stream) {
+        c->stream = static_cast<hipStream_t>(cfg->stream);
+    } else {
+        VRT_CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    VRT_CREATE_HIP(hipEventCreate(&c->ev_start));
+    VRT_CREATE_HIP(hipEventCreate(&c->ev_stop));
+
+    // buffer sizes as Pipeline.zig:273-283 derives them from the State slices
+    c->dsize[VRT_BUF_GRID_STATE] = sizeof(vrt_grid_state);
+    c->dsize[VRT_BUF_MATERIALS] = (uint64_t)sizeof(vrt_material) * c->cfg.material_capacity;
+    c->dsize[VRT_BUF_BRICK_STATUS] = ((cells + 31u) / 32u) * 4u;
+    c->dsize[VRT_BUF_BRICK_INDEX] = cells * 4u;
+    c->dsize[VRT_BUF_BRICK_OCCUPANCY] = brick_alloc * (bits / 8u);
+    c->dsize[VRT_BUF_BRICK_START_INDEX] = brick_alloc * 4u;
+    c->dsize[VRT_BUF_MATERIAL_INDEX] = brick_alloc * bits;
+    for (int i = 0; i < VRT_BUF_COUNT; i++) {
+        // +16: the kernel reads occupancy as aligned 64-bit words; keep slack at the tail
+        VRT_CREATE_HIP(hipMalloc(&c->dbuf[i], c->dsize[i] + 16u));
+        VRT_CREATE_HIP(hipMemsetAsync(c->dbuf[i], 0, c->dsize[i] + 16u, c->stream));
+    }
+
+    // target image (Pipeline.zig:103-126), whole frame or this rank's packed tiles
+    vrt_shard_info &sh = c->shard;
+    sh.tile_w = vrt::kTileW;
+    sh.tile_h = vrt::kTileH;
+    sh.tiles_x = (cfg->width + vrt::kTileW - 1) / vrt::kTileW;
+    sh.tiles_y = (cfg->height + vrt::kTileH - 1) / vrt::kTileH;
+    sh.shard_rank = cfg->shard_rank;
+    sh.shard_count = shard_count;
+    const uint32_t total_tiles = sh.tiles_x * sh.tiles_y;
+    sh.owned_tiles = (total_tiles > cfg->shard_rank) ? (total_tiles - cfg->shard_rank + shard_count - 1u) / shard_count : 0u;
+    sh.tiles_per_rank = (total_tiles + shard_count - 1u) / shard_count;
+    c->target_pixels = (shard_count > 1u) ? (uint64_t)sh.tiles_per_rank * vrt::kTileW * vrt::kTileH : (uint64_t)cfg->width * cfg->height;
+
+    if (cfg->external_target_rgba8) {
+        c->target8 = static_cast<uint8_t *>(cfg->external_target_rgba8);
+    } else {
+        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->target8), c->target_pixels * 4u));
+        c->own_t8 = true;
+        VRT_CREATE_HIP(hipMemsetAsync(c->target8, 0, c->target_pixels * 4u, c->stream));
+    }
+    if (cfg->external_target_rgba32f) {
+        c->target32f = static_cast<float *>(cfg->external_target_rgba32f);
+    } else if (cfg->want_float_output) {
+        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->target32f), c->target_pixels * 16u));
+        c->own_t32 = true;
+        VRT_CREATE_HIP(hipMemsetAsync(c->target32f, 0, c->target_pixels * 16u, c->stream));
+    }
+    if (cfg->enable_counters) {
+        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_counters), sizeof(vrt::DeviceCounters)));
+        VRT_CREATE_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(vrt::DeviceCounters), c->stream));
+    }
+    for (int i = 0; i < kStagingSlots; i++) {
+        VRT_CREATE_HIP(hipHostMalloc(&c->staging[i], kStagingSlotBytes, hipHostMallocDefault));
+        VRT_CREATE_HIP(hipEventCreateWithFlags(&c->staging_ev[i], hipEventDisableTiming));
+    }
+
+    c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant);
+    if (!c->kernel) {
+        free_ctx(c);
+        return fail(nullptr, VRT_E_INVALID_ARG, "no kernel for this configuration");
+    }
+    {
+        char buf[96];
+        std::snprintf(buf, sizeof buf, "vrt_trace_kernel<B=%u,COUNT=%d,VARIANT=%u>", cfg->brick_dimension, cfg->enable_counters ? 1 : 0,
+                      cfg->kernel_variant == vrt::kVariantLiteral ? (unsigned)vrt::kVariantLiteral : (unsigned)vrt::kVariantSplit);
+        c->kernel_name = buf;
+    }
+
+    vrt::TraceParams &p = c->params;
+    std::memset(&p, 0, sizeof p);
+    p.materials = static_cast<const vrt_material *>(c->dbuf[VRT_BUF_MATERIALS]);
+    p.brick_status = static_cast<const uint32_t *>(c->dbuf[VRT_BUF_BRICK_STATUS]);
+    p.brick_index = static_cast<const uint32_t *>(c->dbuf[VRT_BUF_BRICK_INDEX]);
+    p.brick_occupancy = static_cast<const uint8_t *>(c->dbuf[VRT_BUF_BRICK_OCCUPANCY]);
+    p.brick_start_index = static_cast<const uint32_t *>(c->dbuf[VRT_BUF_BRICK_START_INDEX]);
+    p.material_index = static_cast<const uint8_t *>(c->dbuf[VRT_BUF_MATERIAL_INDEX]);
+    p.target_rgba8 = c->target8;
+    p.target_rgba32f = c->target32f;
+    p.counters = c->d_counters;
+    p.width = cfg->width;
+    p.height = cfg->height;
+    p.tiles_x = sh.tiles_x;
+    p.tiles_y = sh.tiles_y;
+    p.shard_rank = sh.shard_rank;
+    p.shard_count = sh.shard_count;
+    p.owned_tiles = sh.owned_tiles;
+    p.status_words = (uint32_t)((cells + 31u) / 32u);
+    // the grid-state UBO mirror starts zeroed; dim 0 => every ray misses until GRID_STATE is uploaded
+#undef VRT_CREATE_HIP
+    *out = c;
+    return VRT_OK;
+}
+
+void vrt_destroy(vrt_ctx *ctx) { free_ctx(ctx); }
+
+uint64_t vrt_buffer_size(const vrt_ctx *ctx, vrt_buffer_id id) {
+    if (!ctx || (int)id < 0 || id >= VRT_BUF_COUNT) return 0;
+    return ctx->dsize[id];
+}
+
+static int check_range(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, const void *src, uint64_t nbytes) {
+    if (!ctx) return VRT_E_INVALID_ARG;
+    if ((int)id < 0 || id >= VRT_BUF_COUNT) return fail(ctx, VRT_E_INVALID_ARG, "bad buffer id");
+    if (nbytes && !src) return fail(ctx, VRT_E_INVALID_ARG, "src is NULL");
+    if (byte_offset > ctx->dsize[id] || nbytes > ctx->dsize[id] - byte_offset)
+        return fail(ctx, VRT_E_OUT_OF_RANGE, "upload exceeds device buffer (DestOutOfDeviceMemory)");
+    return VRT_OK;
+}
+
+int vrt_upload(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, const void *src, uint64_t nbytes) {
+    const int rc = check_range(ctx, id, byte_offset, src, nbytes);
+    if (rc != VRT_OK || nbytes == 0) return rc;
+    DeviceGuard dg(ctx->device);
+    if (id == VRT_BUF_GRID_STATE) {
+        // the kernel takes the UBO through its argument block; keep the host mirror current
+        std::memcpy(reinterpret_cast<uint8_t *>(&ctx->params.grid) + byte_offset, src, (size_t)nbytes);
+    }
+    return copy_h2d(ctx, static_cast<uint8_t *>(ctx->dbuf[id]) + byte_offset, src, nbytes);
+}
+
+int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, const void *dev_src, uint64_t nbytes) {
+    const int rc = check_range(ctx, id, byte_offset, dev_src, nbytes);
+    if (rc != VRT_OK || nbytes == 0) return rc;
+    DeviceGuard dg(ctx->device);
+    if (id == VRT_BUF_GRID_STATE) {
+        VRT_HIP(ctx, hipMemcpyAsync(reinterpret_cast<uint8_t *>(&ctx->params.grid) + byte_offset, dev_src, nbytes, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    VRT_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->dbuf[id]) + byte_offset, dev_src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return VRT_OK;
+}
+
+static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames) {
+    if (!ctx || !camera || !sun || frames == 0) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL camera/sun or zero frames") : VRT_E_INVALID_ARG;
+    if (camera->image_width != ctx->cfg.width || camera->image_height != ctx->cfg.height)
+        return fail(ctx, VRT_E_INVALID_ARG, "camera image size differs from the target image");
+    DeviceGuard dg(ctx->device);
+    // The reference blocks here on the previous frame's fence because it re-records its one
+    // command buffer (ComputePipeline.zig:423-436).  Launches are stream-ordered and carry their
+    // arguments by value, so frames may queue; vrt_wait / vrt_read_* are the synchronisation points.
+    ctx->in_flight = false;
+    ctx->params.pc.cam = *camera;
+    ctx->params.pc.sun = *sun;
+    if (ctx->d_counters) VRT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(vrt::DeviceCounters), ctx->stream));
+    VRT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    for (uint32_t f = 0; f < frames; f++) VRT_HIP(ctx, vrt::launch_trace(ctx->kernel, ctx->params, ctx->stream));
+    VRT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timed_frames = frames;
+    ctx->in_flight = true;
+    return VRT_OK;
+}
+
+int vrt_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun) { return do_dispatch(ctx, camera, sun, 1); }
+
+int vrt_dispatch_repeat(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames) {
+    return do_dispatch(ctx, camera, sun, frames);
+}
+
+int vrt_wait(vrt_ctx *ctx) {
+    if (!ctx) return VRT_E_INVALID_ARG;
+    DeviceGuard dg(ctx->device);
+    const int rc = finish_frame(ctx);
+    if (rc != VRT_OK) return rc;
+    VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VRT_OK;
+}
+
+double vrt_last_kernel_ms(vrt_ctx *ctx) {
+    if (!ctx) return -1.0;
+    DeviceGuard dg(ctx->device);
+    if (finish_frame(ctx) != VRT_OK) return -1.0;
+    return ctx->timing_valid ? ctx->last_ms : -1.0;
+}
+
+static int read_back(vrt_ctx *ctx, void *dst, uint64_t nbytes, const void *src, uint64_t avail) {
+    if (!ctx || !dst) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "dst is NULL") : VRT_E_INVALID_ARG;
+    if (!src) return fail(ctx, VRT_E_STATE, "target not allocated (want_float_output = 0?)");
+    if (nbytes > avail) return fail(ctx, VRT_E_OUT_OF_RANGE, "read exceeds the target image");
+    DeviceGuard dg(ctx->device);
+    const int rc = finish_frame(ctx);
+    if (rc != VRT_OK) return rc;
+    VRT_HIP(ctx, hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VRT_OK;
+}
+
+int vrt_read_rgba8(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
+    return read_back(ctx, dst, nbytes, ctx ? ctx->target8 : nullptr, ctx ? ctx->target_pixels * 4u : 0);
+}
+int vrt_read_rgba32f(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
+    return read_back(ctx, dst, nbytes, ctx ? ctx->target32f : nullptr, ctx ? ctx->target_pixels * 16u : 0);
+}
+void *vrt_device_target_rgba8(vrt_ctx *ctx) { return ctx ? ctx->target8 : nullptr; }
+void *vrt_device_target_rgba32f(vrt_ctx *ctx) { return ctx ? ctx->target32f : nullptr; }
+uint64_t vrt_target_bytes_rgba8(const vrt_ctx *ctx) { return ctx ? ctx->target_pixels * 4u : 0; }
+
+int vrt_get_shard_info(const vrt_ctx *ctx, vrt_shard_info *out) {
+    if (!ctx || !out) return VRT_E_INVALID_ARG;
+    *out = ctx->shard;
+    return VRT_OK;
+}
+
+int vrt_assemble_frame(vrt_ctx *ctx, const void *gathered, void *dst_frame, uint32_t bytes_per_pixel) {
+    if (!ctx || !gathered || !dst_frame) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL buffer") : VRT_E_INVALID_ARG;
+    if (bytes_per_pixel != 4 && bytes_per_pixel != 16) return fail(ctx, VRT_E_INVALID_ARG, "bytes_per_pixel must be 4 or 16");
+    DeviceGuard dg(ctx->device);
+    VRT_HIP(ctx, vrt::launch_assemble(gathered, dst_frame, bytes_per_pixel, ctx->cfg.width, ctx->cfg.height, ctx->shard.tiles_x,
+                                      ctx->shard.shard_count, ctx->shard.tiles_per_rank, ctx->stream));
+    return VRT_OK;
+}
+
+int vrt_get_counters(vrt_ctx *ctx, vrt_counters *out) {
+    if (!ctx || !out) return VRT_E_INVALID_ARG;
+    if (!ctx->d_counters) return fail(ctx, VRT_E_STATE, "context created with enable_counters = 0");
+    DeviceGuard dg(ctx->device);
+    const int rc = finish_frame(ctx);
+    if (rc != VRT_OK) return rc;
+    vrt::DeviceCounters h;
+    VRT_HIP(ctx, hipMemcpyAsync(&h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->rays = h.rays;
+    out->status_loads = h.status_loads;
+    out->bricks_entered = h.bricks_entered;
+    out->voxel_steps = h.voxel_steps;
+    out->hits = h.hits;
+    out->grid_steps = h.grid_steps;
+    return VRT_OK;
+}
+
+// VoxelRT.init's transferGridState (VoxelRT.zig:62) plus the five arrays in full.
+int vrt_upload_grid(vrt_ctx *ctx, vrt_grid *gh) {
+    if (!ctx || !gh) return VRT_E_INVALID_ARG;
+    vrt::BrickGrid *g = reinterpret_cast<vrt::BrickGrid *>(gh);
+    if (g->brickDimension() != ctx->cfg.brick_dimension) return fail(ctx, VRT_E_INVALID_ARG, "grid brick_dimension differs from the context");
+    static const vrt_buffer_id ids[6] = {VRT_BUF_GRID_STATE,      VRT_BUF_BRICK_STATUS,      VRT_BUF_BRICK_INDEX,
+                                         VRT_BUF_BRICK_OCCUPANCY, VRT_BUF_BRICK_START_INDEX, VRT_BUF_MATERIAL_INDEX};
+    for (vrt_buffer_id id : ids) {
+        uint64_t n = 0;
+        const void *ptr = g->dataFor(id, &n);
+        if (n != ctx->dsize[id]) return fail(ctx, VRT_E_INVALID_ARG, "grid array size differs from the context's buffer");
+        const int rc = vrt_upload(ctx, id, 0, ptr, n);
+        if (rc != VRT_OK) return rc;
+        if (vrt::DeviceDataDelta *d = g->deltaFor(id)) {
+            std::lock_guard<std::mutex> lk(d->mutex);
+            d->resetDelta();
+        }
+    }
+    return VRT_OK;
+}
+
+// VoxelRT.updateGridDelta, VoxelRT.zig:107-172
+int vrt_update_grid_delta(vrt_ctx *ctx, vrt_grid *gh) {
+    if (!ctx || !gh) return VRT_E_INVALID_ARG;
+    vrt::BrickGrid *g = reinterpret_cast<vrt::BrickGrid *>(gh);
+    static const vrt_buffer_id ids[5] = {VRT_BUF_BRICK_STATUS, VRT_BUF_BRICK_INDEX, VRT_BUF_BRICK_OCCUPANCY, VRT_BUF_BRICK_START_INDEX,
+                                         VRT_BUF_MATERIAL_INDEX};
+    for (vrt_buffer_id id : ids) {
+        vrt::DeviceDataDelta *d = g->deltaFor(id);
+        std::lock_guard<std::mutex> lk(d->mutex);
+        if (d->state != vrt::DeviceDataDelta::DeltaState::active) continue;
+        uint64_t n = 0;
+        const uint8_t *base = static_cast<const uint8_t *>(g->dataFor(id, &n));
+        const size_t es = g->elementSize(id);
+        const int rc = vrt_upload(ctx, id, (uint64_t)d->from * es, base + d->from * es, (uint64_t)(d->to - d->from) * es);
+        if (rc != VRT_OK) return rc;
+        d->resetDelta();
+    }
+    return VRT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,56 @@
+// vrt_internal.h — types shared by the C-ABI implementation and the kernels.
+#pragma once
+#include <stdint.h>
+#include "../../include/vrt_hip.h"
+
+namespace vrt {
+
+// push constants as one 128-byte block (brick_raytracer.comp:58-75)
+struct PushConstants {
+    vrt_camera_device cam; // bytes 0..95
+    vrt_sun_device sun;    // bytes 96..127
+};
+static_assert(sizeof(vrt_camera_device) == 96, "Camera.Device is 96 bytes (Camera.zig:183-193)");
+static_assert(sizeof(vrt_sun_device) == 32, "Sun.Device is 32 bytes (Sun.zig:13-18)");
+static_assert(sizeof(PushConstants) == 128, "push constant range is 128 bytes (ComputePipeline.zig:258-272)");
+static_assert(sizeof(vrt_grid_state) == 64, "State.Device is 64 bytes (State.zig:60-79)");
+static_assert(sizeof(vrt_material) == 20, "Material is 20 bytes (gpu_types.zig:16-32)");
+
+struct DeviceCounters {
+    unsigned long long rays, status_loads, bricks_entered, voxel_steps, hits, grid_steps;
+};
+
+// Kernel argument block.  Passed by value: lives in the kernarg segment and is
+// read through the scalar cache, like the reference's UBO + push constants.
+struct TraceParams {
+    vrt_grid_state grid;                 // binding 1
+    PushConstants pc;                    // push constants
+    const vrt_material *materials;       // binding 2
+    const uint32_t *brick_status;        // binding 3
+    const uint32_t *brick_index;         // binding 4
+    const uint8_t *brick_occupancy;      // binding 5
+    const uint32_t *brick_start_index;   // binding 6
+    const uint8_t *material_index;       // binding 7
+    uint8_t *target_rgba8;               // binding 0 (Rgba8 storage image)
+    float *target_rgba32f;               // optional float twin of the target
+    DeviceCounters *counters;            // optional
+    uint32_t width, height;              // imageSize(img_output)
+    // tile geometry / sharding
+    uint32_t tiles_x, tiles_y;           // 16x16-pixel workgroup tiles in the frame
+    uint32_t shard_rank, shard_count;    // this ctx renders tiles t % count == rank
+    uint32_t owned_tiles;                // number of tiles (= workgroups) launched
+    uint32_t status_words;               // length of brick_status in u32 words
+};
+
+constexpr int kTileW = 16;
+constexpr int kTileH = 16;
+
+// kernel variants (vrt_config.kernel_variant)
+enum : uint32_t {
+    kVariantDefault = 0,  // best known
+    kVariantLiteral = 1,  // literal nested loops, byte loads (reference structure)
+    kVariantSplit = 2,    // grid-walk / brick-walk phase split, 64-bit occupancy words
+    kVariantCount
+};
+
+} // namespace vrt

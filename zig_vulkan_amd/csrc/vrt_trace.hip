@@ -1,0 +1,585 @@
+// vrt_trace.hip — brickmap traversal kernels for gfx950 (MI355X), wave64.
+//
+// Replaces the dispatch of assets/shaders/brick_raytracer.comp
+// (src/modules/voxel_rt/ComputePipeline.zig:550).  One lane = one pixel, one
+// wave = an 8x8 pixel block (coherent rays), one 256-thread workgroup = a
+// 16x16 tile.  Arithmetic follows vrt_math.h's contract operation by
+// operation; what differs from the shader is only how memory is touched and how
+// the loops are arranged for a 64-wide wave:
+//   * occupancy is read as one 64-bit word per brick (4^3) or per y-layer (8^3)
+//     and bit-tested in registers, instead of one byte load per voxel step
+//     (comp:415);
+//   * the brick-level walk and the voxel-level walk run as two separate wave
+//     phases: all lanes first advance their grid DDA to the next occupied cell
+//     (empty-space skipping under one exec mask), then all lanes that found one
+//     walk their brick together; the shader's nested form makes the whole wave
+//     wait on every lane's inner loop at a different outer iteration;
+//   * blockIdx is remapped so that each XCD (block b runs on XCD b % 8) gets a
+//     contiguous band of image tiles and its L2 holds one region of the grid.
+#include <hip/hip_runtime.h>
+#include "vrt_internal.h"
+#include "vrt_math.h"
+
+namespace vrt {
+
+constexpr uint32_t MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_NONE = 3;
+
+struct Ray {
+    f3 origin, direction;
+    float internal_reflection;
+    uint32_t ignore_type_material;
+};
+
+struct Hit {
+    f3 point, normal;
+    float t;
+    uint32_t index;
+};
+
+template <bool COUNT>
+struct Cnt {
+    uint32_t rays = 0, status_loads = 0, bricks_entered = 0, voxel_steps = 0, hits = 0, grid_steps = 0;
+};
+template <>
+struct Cnt<false> {};
+
+#define VRT_COUNT(field)          \
+    if constexpr (COUNT) {        \
+        c.field++;                \
+    }
+
+// comp:180-184
+VRT_DI Ray create_ray(f3 origin, f3 direction) { return Ray{origin, normalize3(direction), 1.0f, MAT_NONE}; }
+// comp:192-195
+VRT_DI f3 ray_at(const Ray &r, float t) { return fma3(splat3(t), r.direction, r.origin); }
+// comp:267
+VRT_DI float safe_inverse(float x) { return (x == 0.0f) ? 1e12f : (1.0f / x); }
+
+// DDA walker state shared by the two levels.  `axis` records which face the
+// last step crossed (3 = none yet: the slab-entry normal applies), from which
+// hit.normal is rebuilt only when a voxel is actually hit (comp:350,356,364,370).
+struct Walk {
+    f3 side_dist;
+    int x, y, z;
+    float t_value;
+};
+
+// comp:345-372 / comp:440-467: branchy min-axis step, as selects.
+VRT_DI void dda_step(Walk &w, const f3 &ray_delta, int sx, int sy, int sz, float scale, int &axis) {
+    const bool x_lt_y = w.side_dist.x < w.side_dist.y;
+    const bool x_lt_z = w.side_dist.x < w.side_dist.z;
+    const bool y_lt_z = w.side_dist.y < w.side_dist.z;
+    const int a = x_lt_y ? (x_lt_z ? 0 : 2) : (y_lt_z ? 1 : 2);
+    const float sd = (a == 0) ? w.side_dist.x : ((a == 1) ? w.side_dist.y : w.side_dist.z);
+    w.t_value = sd * scale;
+    if (a == 0) {
+        w.side_dist.x += ray_delta.x;
+        w.x += sx;
+    } else if (a == 1) {
+        w.side_dist.y += ray_delta.y;
+        w.y += sy;
+    } else {
+        w.side_dist.z += ray_delta.z;
+        w.z += sz;
+    }
+    axis = a;
+}
+
+// comp:298 / comp:395
+VRT_DI f3 initial_side_dist(f3 fstep, f3 fposition, f3 ray_delta) {
+    const f3 intersection_delta = floor3(fposition) - fposition;
+    return fma3(fstep, intersection_delta, fstep * 0.5f + splat3(0.5f)) * ray_delta;
+}
+
+struct RaySetup {
+    f3 ray_delta, fstep, entry_normal;
+    int sx, sy, sz;
+    float grid_t_min, grid_t_max;
+};
+
+// comp:522-536 with comp:278 (slab test against the grid box)
+VRT_DI bool grid_slab(const TraceParams &p, const Ray &r, float t_min, float t_max, RaySetup &s) {
+    const f3 g_min = mk3(p.grid.min_point_base_t[0], p.grid.min_point_base_t[1], p.grid.min_point_base_t[2]);
+    const f3 g_max = mk3(p.grid.max_point_scale[0], p.grid.max_point_scale[1], p.grid.max_point_scale[2]);
+    const f3 inv = mk3(safe_inverse(r.direction.x), safe_inverse(r.direction.y), safe_inverse(r.direction.z));
+    const f3 t_lower = (g_min - r.origin) * inv;
+    const f3 t_upper = (g_max - r.origin) * inv;
+    const f3 t_mins = mk3(gl_min(t_lower.x, t_upper.x), gl_min(t_lower.y, t_upper.y), gl_min(t_lower.z, t_upper.z));
+    const f3 t_maxes = mk3(gl_max(t_lower.x, t_upper.x), gl_max(t_lower.y, t_upper.y), gl_max(t_lower.z, t_upper.z));
+    // indexOfMaxComponent, comp:501-503 (ties resolve to 0)
+    const int i = (int)(t_mins.y > t_mins.x && t_mins.y > t_mins.z) + (int)(t_mins.z > t_mins.x && t_mins.z > t_mins.y) * 2;
+    const float sg = sign1(pick3(inv, i));
+    s.entry_normal = mk3(i == 0 ? sg : 0.0f, i == 1 ? sg : 0.0f, i == 2 ? sg : 0.0f);
+    s.grid_t_min = gl_max(t_min, pick3(t_mins, i));
+    s.grid_t_max = gl_min(t_max, gl_min(gl_min(t_maxes.x, t_maxes.y), t_maxes.z));
+    s.ray_delta = abs3(inv);
+    s.sx = (int)sign1(r.direction.x);
+    s.sy = (int)sign1(r.direction.y);
+    s.sz = (int)sign1(r.direction.z);
+    s.fstep = mk3((float)s.sx, (float)s.sy, (float)s.sz);
+    return s.grid_t_min <= s.grid_t_max;
+}
+
+VRT_DI f3 axis_normal(const RaySetup &s, int axis) {
+    if (axis == 3) return s.entry_normal;
+    // normal_axis, comp:304-308: (step < 0) ? 1 : -1 on the crossed axis
+    const float nx = (s.sx < 0) ? 1.0f : -1.0f, ny = (s.sy < 0) ? 1.0f : -1.0f, nz = (s.sz < 0) ? 1.0f : -1.0f;
+    return mk3(axis == 0 ? nx : 0.0f, axis == 1 ? ny : 0.0f, axis == 2 ? nz : 0.0f);
+}
+
+// ---- occupancy access -----------------------------------------------------
+// brick_occupancy bit v%8 of byte brick*(B^3/8) + v/8 (Grid.zig:180-182) read
+// as little-endian 64-bit words: word y of a brick holds voxels
+// v = x + B*z + 64*y' ... for B=4 the whole brick is one word; for B=8 word
+// index == y layer (v = x + 8*(z + 8*y)).
+template <int B>
+struct OccCache {
+    unsigned long long word;
+    int layer; // B==8: y layer held in `word`, -1 = none
+};
+
+template <int B>
+VRT_DI bool voxel_solid(const TraceParams &p, uint32_t brick_index, int vx, int vy, int vz, OccCache<B> &oc) {
+    if constexpr (B == 4) {
+        const int v = vx + 4 * (vz + 4 * vy);
+        return (oc.word >> v) & 1ull;
+    } else {
+        if (oc.layer != vy) {
+            const unsigned long long *base = reinterpret_cast<const unsigned long long *>(p.brick_occupancy) + (size_t)brick_index * 8u;
+            oc.word = base[vy];
+            oc.layer = vy;
+        }
+        return (oc.word >> (vx + 8 * vz)) & 1ull;
+    }
+}
+
+// comp:378-471.  Returns true on a (non-ignored) voxel hit and fills `hit`.
+template <int B, bool COUNT>
+VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t brick_index,
+                       f3 brick_min, Hit &hit, int &axis, Cnt<COUNT> &c) {
+    const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
+    const float voxel_scale = g_scale * brick_voxel_scale;
+    const f3 fposition = (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
+    Walk w;
+    w.side_dist = initial_side_dist(s.fstep, fposition, s.ray_delta);
+    w.x = f2i_sat(__builtin_floorf(fposition.x + 0.f));
+    w.y = f2i_sat(__builtin_floorf(fposition.y + 0.f));
+    w.z = f2i_sat(__builtin_floorf(fposition.z + 0.f));
+    w.t_value = 0;
+    const float local_t_max = s.grid_t_max - hit.t;
+
+    OccCache<B> oc;
+    oc.layer = -1;
+    if constexpr (B == 4) {
+        oc.word = reinterpret_cast<const unsigned long long *>(p.brick_occupancy)[brick_index];
+    } else {
+        oc.word = 0;
+    }
+
+    int guard = 3 * B + 8;
+    while ((unsigned)w.x < (unsigned)B && (unsigned)w.y < (unsigned)B && (unsigned)w.z < (unsigned)B && w.t_value <= local_t_max) {
+        if (guard-- <= 0) break;
+        VRT_COUNT(voxel_steps);
+        if (voxel_solid<B>(p, brick_index, w.x, w.y, w.z, oc)) {
+            VRT_COUNT(hits);
+            const int voxel_index = w.x + B * (w.z + B * w.y);
+            const uint32_t brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu; // comp:422
+            const uint32_t mi = p.material_index[brick_material_index + (uint32_t)voxel_index];
+            const vrt_material *m = p.materials + mi;
+            const uint32_t mtype = m->type;
+            const float mdata = m->type_data;
+            const bool ignore_brick = (mtype == r.ignore_type_material) && (r.internal_reflection == mdata); // comp:427
+            if (!ignore_brick) {
+                hit.index = mi;
+                const float t_offset = voxel_scale * 0.05f;
+                hit.t += w.t_value - t_offset;
+                hit.normal = axis_normal(s, axis);
+                hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
+                return true;
+            }
+        }
+        dda_step(w, s.ray_delta, s.sx, s.sy, s.sz, voxel_scale, axis);
+    }
+    return false;
+}
+
+// comp:271-376 in two wave phases.  t_min = 1e-5, t_max = +inf at every call
+// site (comp:218,247).
+template <int B, bool COUNT>
+VRT_DI bool grid_hit(const TraceParams &p, const Ray &r, Hit &hit, Cnt<COUNT> &c) {
+    const float t_min = 0.00001f;
+    const float t_max = __builtin_inff();
+    VRT_COUNT(rays);
+    RaySetup s;
+    if (!grid_slab(p, r, t_min, t_max, s)) return false;
+
+    const f3 g_min = mk3(p.grid.min_point_base_t[0], p.grid.min_point_base_t[1], p.grid.min_point_base_t[2]);
+    const float g_scale = p.grid.max_point_scale[3];
+    const int dx = (int)p.grid.dim_x, dy = (int)p.grid.dim_y, dz = (int)p.grid.dim_z;
+
+    float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
+    const f3 hit_point = ray_at(r, global_t_value);
+    const f3 fposition = (hit_point - g_min) / splat3(g_scale);
+    Walk w;
+    w.side_dist = initial_side_dist(s.fstep, fposition, s.ray_delta);
+    w.x = f2i_sat(__builtin_floorf(fposition.x + 0.f));
+    w.y = f2i_sat(__builtin_floorf(fposition.y + 0.f));
+    w.z = f2i_sat(__builtin_floorf(fposition.z + 0.f));
+    w.t_value = 0;
+
+    uint32_t word_index = ~0u; // comp:301
+    uint32_t word_bits = 0;
+    int axis = 3;
+    int guard = dx + dy + dz + 8;
+
+    for (;;) {
+        // phase A: skip empty cells
+        bool found = false;
+        uint32_t grid_index = 0;
+        while ((unsigned)w.x < (unsigned)dx && (unsigned)w.y < (unsigned)dy && (unsigned)w.z < (unsigned)dz && global_t_value <= t_max) {
+            if (guard-- <= 0) break;
+            VRT_COUNT(grid_steps);
+            grid_index = (uint32_t)(w.x + dx * (w.z + dz * w.y)); // comp:318
+            const uint32_t wi = grid_index >> 5;
+            if (wi != word_index) { // comp:323-326
+                word_bits = p.brick_status[wi];
+                word_index = wi;
+                VRT_COUNT(status_loads);
+            }
+            if ((word_bits >> (grid_index & 31u)) & 1u) {
+                found = true;
+                break;
+            }
+            dda_step(w, s.ray_delta, s.sx, s.sy, s.sz, g_scale, axis);
+        }
+        if (!found) return false;
+
+        // phase B: walk the brick
+        const f3 brick_min = fma3(mk3((float)w.x, (float)w.y, (float)w.z), splat3(g_scale), g_min); // comp:331
+        global_t_value = w.t_value + s.grid_t_min + 0.01f * g_scale;                               // comp:332
+        hit.t = global_t_value;
+        const uint32_t brick_index = p.brick_index[grid_index]; // comp:337
+        VRT_COUNT(bricks_entered);
+        if (brick_walk<B, COUNT>(p, r, s, g_scale, brick_index, brick_min, hit, axis, c)) return true;
+        dda_step(w, s.ray_delta, s.sx, s.sy, s.sz, g_scale, axis);
+    }
+}
+
+// ---- literal variant: the shader's own loop nest and byte loads -----------
+template <int B, bool COUNT>
+VRT_DI bool grid_hit_literal(const TraceParams &p, const Ray &r, Hit &hit, Cnt<COUNT> &c) {
+    const float t_min = 0.00001f;
+    const float t_max = __builtin_inff();
+    VRT_COUNT(rays);
+    RaySetup s;
+    if (!grid_slab(p, r, t_min, t_max, s)) return false;
+    const f3 g_min = mk3(p.grid.min_point_base_t[0], p.grid.min_point_base_t[1], p.grid.min_point_base_t[2]);
+    const float g_scale = p.grid.max_point_scale[3];
+    const int dx = (int)p.grid.dim_x, dy = (int)p.grid.dim_y, dz = (int)p.grid.dim_z;
+    float global_t_value = s.grid_t_min + 0.0001f * g_scale;
+    const f3 fposition = (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
+    Walk w;
+    w.side_dist = initial_side_dist(s.fstep, fposition, s.ray_delta);
+    w.x = f2i_sat(__builtin_floorf(fposition.x + 0.f));
+    w.y = f2i_sat(__builtin_floorf(fposition.y + 0.f));
+    w.z = f2i_sat(__builtin_floorf(fposition.z + 0.f));
+    w.t_value = 0;
+    uint32_t word_index = ~0u, word_bits = 0;
+    int axis = 3;
+    int guard = dx + dy + dz + 8;
+    while ((unsigned)w.x < (unsigned)dx && (unsigned)w.y < (unsigned)dy && (unsigned)w.z < (unsigned)dz && global_t_value <= t_max) {
+        if (guard-- <= 0) break;
+        VRT_COUNT(grid_steps);
+        const uint32_t grid_index = (uint32_t)(w.x + dx * (w.z + dz * w.y));
+        const uint32_t wi = grid_index >> 5;
+        if (wi != word_index) {
+            word_bits = p.brick_status[wi];
+            word_index = wi;
+            VRT_COUNT(status_loads);
+        }
+        if ((word_bits >> (grid_index & 31u)) & 1u) {
+            const f3 brick_min = fma3(mk3((float)w.x, (float)w.y, (float)w.z), splat3(g_scale), g_min);
+            global_t_value = w.t_value + s.grid_t_min + 0.01f * g_scale;
+            hit.t = global_t_value;
+            const uint32_t brick_index = p.brick_index[grid_index];
+            VRT_COUNT(bricks_entered);
+            // BrickHit, byte loads as comp:415
+            const float voxel_scale = g_scale * (1.0f / (float)B);
+            const f3 bpos = (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
+            Walk v;
+            v.side_dist = initial_side_dist(s.fstep, bpos, s.ray_delta);
+            v.x = f2i_sat(__builtin_floorf(bpos.x + 0.f));
+            v.y = f2i_sat(__builtin_floorf(bpos.y + 0.f));
+            v.z = f2i_sat(__builtin_floorf(bpos.z + 0.f));
+            v.t_value = 0;
+            const float local_t_max = s.grid_t_max - hit.t;
+            const uint32_t base = brick_index * (uint32_t)(B * B * B / 8);
+            int bguard = 3 * B + 8;
+            while ((unsigned)v.x < (unsigned)B && (unsigned)v.y < (unsigned)B && (unsigned)v.z < (unsigned)B && v.t_value <= local_t_max) {
+                if (bguard-- <= 0) break;
+                VRT_COUNT(voxel_steps);
+                const int voxel_index = v.x + B * (v.z + B * v.y);
+                const uint32_t byte = p.brick_occupancy[base + (uint32_t)(voxel_index >> 3)];
+                if ((byte >> (voxel_index & 7)) & 1u) {
+                    VRT_COUNT(hits);
+                    const uint32_t bmi = p.brick_start_index[brick_index] & 0x7FFFFFFFu;
+                    const uint32_t mi = p.material_index[bmi + (uint32_t)voxel_index];
+                    const vrt_material *m = p.materials + mi;
+                    const bool ignore_brick = (m->type == r.ignore_type_material) && (r.internal_reflection == m->type_data);
+                    if (!ignore_brick) {
+                        hit.index = mi;
+                        const float t_offset = voxel_scale * 0.05f;
+                        hit.t += v.t_value - t_offset;
+                        hit.normal = axis_normal(s, axis);
+                        hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
+                        return true;
+                    }
+                }
+                dda_step(v, s.ray_delta, s.sx, s.sy, s.sz, voxel_scale, axis);
+            }
+        }
+        dda_step(w, s.ray_delta, s.sx, s.sy, s.sz, g_scale, axis);
+    }
+    return false;
+}
+
+template <int B, bool COUNT, uint32_t VARIANT>
+VRT_DI bool trace_ray(const TraceParams &p, const Ray &r, Hit &hit, Cnt<COUNT> &c) {
+    if constexpr (VARIANT == kVariantLiteral) {
+        return grid_hit_literal<B, COUNT>(p, r, hit, c);
+    } else {
+        return grid_hit<B, COUNT>(p, r, hit, c);
+    }
+}
+
+// ---- scatter functions (comp:539-596) -------------------------------------
+VRT_DI bool scatter_lambertian(const Hit &hit, Ray &scattered) {
+    const f3 rv = rand_vec3_range(hit.point.x + hit.point.z, hit.point.y + hit.point.z, -0.4f, 0.4f);
+    scattered = create_ray(hit.point, normalize3(hit.normal + rv));
+    return true;
+}
+VRT_DI bool scatter_metal(float fuzz, const Ray &r_in, const Hit &hit, Ray &scattered) {
+    const f3 reflected = reflect3(r_in.direction, hit.normal);
+    const f3 rv = rand_vec3_range(hit.point.x + hit.point.z, hit.point.y + hit.point.z, -fuzz, fuzz);
+    scattered = create_ray(hit.point, reflected + rv);
+    return dot3(scattered.direction, hit.normal) > 0;
+}
+VRT_DI bool transmission_direction(float n1, float n2, f3 ray_dir, f3 normal, f3 &refrac_dir) {
+    const float eta = n1 / n2;
+    const float c1 = -dot3(ray_dir, normal);
+    const float w = eta * c1;
+    const float c2m = (w - eta) * (w + eta);
+    if (c2m < -1.0f) return false;
+    refrac_dir = fma3(splat3(eta), ray_dir, normal * (w - __builtin_sqrtf(1.0f + c2m)));
+    return true;
+}
+VRT_DI bool scatter_dielectric(float ir, const Ray &r_in, const Hit &hit, Ray &scattered) {
+    const f3 rv = rand_vec3_range(hit.point.x + hit.point.z, hit.point.y + hit.point.z, -0.05f, 0.05f);
+    const f3 normal = normalize3(hit.normal + rv);
+    f3 direction = mk3(0, 0, 0);
+    const bool should_refract = transmission_direction(ir, r_in.internal_reflection, r_in.direction, normal, direction);
+    if (should_refract && rand_3(hit.point) > 0.5f) {
+        scattered = create_ray(hit.point, direction);
+        scattered.ignore_type_material = MAT_DIELECTRIC;
+        scattered.internal_reflection = ir;
+    } else {
+        direction = reflect3(r_in.direction, normal);
+        scattered = create_ray(hit.point, direction);
+    }
+    return true;
+}
+
+// comp:203-265
+template <int B, bool COUNT, uint32_t VARIANT>
+VRT_DI f3 ray_color(const TraceParams &p, Ray current_ray, Cnt<COUNT> &c) {
+    const bool sun_enabled = p.pc.sun.enabled > 0;
+    const f3 sun_color = mk3(p.pc.sun.color[0], p.pc.sun.color[1], p.pc.sun.color[2]);
+    const f3 sun_position = mk3(p.pc.sun.position[0], p.pc.sun.position[1], p.pc.sun.position[2]);
+    const int max_bounce = p.pc.cam.max_bounce;
+    Hit hit;
+    hit.point = mk3(0, 0, 0);
+    hit.normal = mk3(0, 0, 0);
+    hit.t = 0;
+    hit.index = 0;
+    int loop_count = 0;
+    f3 color = mk3(0, 0, 0);
+
+    while (loop_count < max_bounce && trace_ray<B, COUNT, VARIANT>(p, current_ray, hit, c)) {
+        loop_count += 1;
+        Ray scattered = current_ray;
+        bool result = false;
+        const vrt_material *m = p.materials + hit.index;
+        const uint32_t mtype = m->type;
+        const f3 attenuation = mk3(m->albedo_r, m->albedo_g, m->albedo_b);
+        const float mdata = m->type_data;
+        switch (mtype) {
+            case MAT_LAMBERTIAN: result = scatter_lambertian(hit, scattered); break;
+            case MAT_METAL: result = scatter_metal(mdata, current_ray, hit, scattered); break;
+            case MAT_DIELECTRIC: result = scatter_dielectric(mdata, current_ray, hit, scattered); break;
+            default:
+                loop_count -= 1;
+                result = false;
+                break;
+        }
+        if (sun_enabled) {
+            const f3 rv = rand_vec3_range(current_ray.direction.x + current_ray.direction.z,
+                                          current_ray.direction.y + current_ray.direction.z, -p.pc.sun.radius, p.pc.sun.radius);
+            const f3 sun_sample_position = sun_position + rv;
+            const f3 shadow_ray_dir = sun_sample_position - hit.point;
+            // CreateShadowRay, comp:186-190: sun_enabled > 0 here, so ignore type is MAT_NONE
+            Ray shadow_ray = create_ray(hit.point, shadow_ray_dir);
+            Hit shadow_hit;
+            if (!trace_ray<B, COUNT, VARIANT>(p, shadow_ray, shadow_hit, c)) {
+                color = color + attenuation * sun_color;
+            }
+        } else {
+            color = color + attenuation;
+        }
+        if (!result) break;
+        current_ray = scattered;
+    }
+    if (loop_count == 0) {
+        // BackgroundColor, comp:197-201
+        const float t = 0.5f * (current_ray.direction.y + 1.0f);
+        const f3 bg = fma3(splat3(1.0f - t), splat3(1.0f), mk3(0.5f, 0.7f, 1.0f) * t);
+        color = color + bg * (sun_enabled ? sun_color : splat3(1.0f));
+    }
+    return color / (color + splat3(1.0f));
+}
+
+VRT_DI uint32_t unorm8(float c) {
+    c = (c > 0.0f) ? c : 0.0f; // NaN -> 0
+    c = (c > 1.0f) ? 1.0f : c;
+    return (uint32_t)__builtin_rintf(c * 255.0f);
+}
+
+// Workgroup -> image tile.  Block b executes on XCD b % 8; give XCD k the k-th
+// contiguous slice of this context's tile list.
+VRT_DI uint32_t xcd_slice_index(uint32_t b, uint32_t n) {
+    const uint32_t q = n >> 3, rem = n & 7u;
+    const uint32_t xcd = b & 7u, i = b >> 3;
+    return (xcd < rem) ? xcd * (q + 1u) + i : rem * (q + 1u) + (xcd - rem) * q + i;
+}
+
+// comp:153-178
+template <int B, bool COUNT, uint32_t VARIANT>
+__global__ __launch_bounds__(256) void vrt_trace_kernel(const TraceParams p) {
+    const uint32_t owned = xcd_slice_index(blockIdx.x, p.owned_tiles);
+    const uint32_t tile = owned * p.shard_count + p.shard_rank;
+    const uint32_t tile_x = tile % p.tiles_x, tile_y = tile / p.tiles_x;
+    // lane -> pixel: wave w of the block covers the 8x8 quadrant (w&1, w>>1)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t in_x = (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t in_y = (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t px = tile_x * kTileW + in_x;
+    const uint32_t py = tile_y * kTileH + in_y;
+
+    Cnt<COUNT> c;
+    const bool inside = (px < p.width) && (py < p.height); // comp:155-159
+    if (inside) {
+        f3 color = mk3(0, 0, 0);
+        const int spp = p.pc.cam.samples_per_pixel;
+        const float x = (float)px, y = (float)py;
+        for (int sample_i = 0; sample_i < spp; sample_i++) {
+            const float flag = (sample_i > 0) ? 1.0f : 0.0f;
+            const float noise_x = hash_12(((x + (float)sample_i) * 0.2f) * flag, (y * 0.2f) * flag);
+            const float u = (x + noise_x) / (float)(p.pc.cam.image_width - 1u);
+            const float noise_y = hash_12((x * 0.2f) * flag, ((y + (float)sample_i) * 0.2f) * flag);
+            const float v = (y + noise_y) / (float)(p.pc.cam.image_height - 1u);
+            // CameraGetRay, comp:474-477
+            const f3 horizontal = mk3(p.pc.cam.horizontal[0], p.pc.cam.horizontal[1], p.pc.cam.horizontal[2]);
+            const f3 vertical = mk3(p.pc.cam.vertical[0], p.pc.cam.vertical[1], p.pc.cam.vertical[2]);
+            const f3 llc = mk3(p.pc.cam.lower_left_corner[0], p.pc.cam.lower_left_corner[1], p.pc.cam.lower_left_corner[2]);
+            const f3 origin = mk3(p.pc.cam.origin[0], p.pc.cam.origin[1], p.pc.cam.origin[2]);
+            const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
+            color = color + ray_color<B, COUNT, VARIANT>(p, create_ray(origin, ray_dir), c);
+        }
+        const float fspp = (float)spp;
+        color = mk3(__builtin_sqrtf(color.x / fspp), __builtin_sqrtf(color.y / fspp), __builtin_sqrtf(color.z / fspp));
+
+        size_t o;
+        if (p.shard_count > 1u) {
+            o = (size_t)owned * (kTileW * kTileH) + in_y * kTileW + in_x; // packed tile-major shard
+        } else {
+            o = (size_t)py * p.width + px; // row-major frame
+        }
+        const uint32_t rgba = unorm8(color.x) | (unorm8(color.y) << 8) | (unorm8(color.z) << 16) | (255u << 24);
+        reinterpret_cast<uint32_t *>(p.target_rgba8)[o] = rgba;
+        if (p.target_rgba32f) {
+            reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(color.x, color.y, color.z, 1.0f);
+        }
+    }
+    if constexpr (COUNT) {
+        // wave-level reduction, then one atomic per wave per counter
+        unsigned long long v[6] = {c.rays, c.status_loads, c.bricks_entered, c.voxel_steps, c.hits, c.grid_steps};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            unsigned long long s = v[k];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            v[k] = s;
+        }
+        if (lane == 0) {
+            atomicAdd(&p.counters->rays, v[0]);
+            atomicAdd(&p.counters->status_loads, v[1]);
+            atomicAdd(&p.counters->bricks_entered, v[2]);
+            atomicAdd(&p.counters->voxel_steps, v[3]);
+            atomicAdd(&p.counters->hits, v[4]);
+            atomicAdd(&p.counters->grid_steps, v[5]);
+        }
+    }
+}
+
+// Root-side un-swizzle of gathered shards (rank-major, tile-major) into a
+// row-major frame.  One thread per pixel.
+template <typename PIX>
+__global__ __launch_bounds__(256) void vrt_assemble_kernel(const PIX *__restrict__ gathered, PIX *__restrict__ frame, uint32_t width,
+                                                           uint32_t height, uint32_t tiles_x, uint32_t shard_count,
+                                                           uint32_t tiles_per_rank) {
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= width || y >= height) return;
+    const uint32_t t = (y / kTileH) * tiles_x + (x / kTileW);
+    const uint32_t r = t % shard_count, i = t / shard_count;
+    const size_t src = ((size_t)r * tiles_per_rank + i) * (kTileW * kTileH) + (y % kTileH) * kTileW + (x % kTileW);
+    frame[(size_t)y * width + x] = gathered[src];
+}
+
+// ---- launchers (called from vrt_api.cpp; same translation unit set) --------
+using KernelFn = void (*)(const TraceParams);
+
+template <int B, bool COUNT>
+static KernelFn pick_variant(uint32_t variant) {
+    switch (variant) {
+        case kVariantLiteral: return vrt_trace_kernel<B, COUNT, kVariantLiteral>;
+        default: return vrt_trace_kernel<B, COUNT, kVariantSplit>;
+    }
+}
+
+KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant) {
+    if (brick_dimension == 4) return counters ? pick_variant<4, true>(variant) : pick_variant<4, false>(variant);
+    if (brick_dimension == 8) return counters ? pick_variant<8, true>(variant) : pick_variant<8, false>(variant);
+    return nullptr;
+}
+
+hipError_t launch_trace(KernelFn fn, const TraceParams &p, hipStream_t stream) {
+    if (p.owned_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(fn, dim3(p.owned_tiles), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per_pixel, uint32_t width, uint32_t height,
+                           uint32_t tiles_x, uint32_t shard_count, uint32_t tiles_per_rank, hipStream_t stream) {
+    const dim3 grid((width + 63u) / 64u, (height + 3u) / 4u);
+    if (bytes_per_pixel == 4) {
+        hipLaunchKernelGGL(vrt_assemble_kernel<uint32_t>, grid, dim3(256), 0, stream, (const uint32_t *)gathered, (uint32_t *)frame, width,
+                           height, tiles_x, shard_count, tiles_per_rank);
+    } else if (bytes_per_pixel == 16) {
+        hipLaunchKernelGGL(vrt_assemble_kernel<float4>, grid, dim3(256), 0, stream, (const float4 *)gathered, (float4 *)frame, width, height,
+                           tiles_x, shard_count, tiles_per_rank);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+} // namespace vrt

@@ -1,0 +1,92 @@
+"""Multi-GPU frame sharding: one process per GPU, image tiles interleaved across
+ranks, ONE gather of RGBA8 tiles to rank 0 per frame (RCCL over xGMI through
+torch.distributed's "nccl" backend), then a device-side un-swizzle on rank 0.
+
+The scene is replicated (each rank uploads the same grid); pixels are
+independent, so there is no other exchange step.
+
+Tile ownership (must match the kernel and vrt_assemble_frame): tiles are
+16x16 pixels, numbered row-major; tile t belongs to rank t % R and is the
+(t // R)-th tile of that rank's packed shard; every shard is padded to
+tiles_per_rank = ceil(T / R) tiles so the gather has equal counts.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+TILE = 16
+
+
+def shard_geometry(width: int, height: int, rank: int, world: int) -> dict:
+    tiles_x = (width + TILE - 1) // TILE
+    tiles_y = (height + TILE - 1) // TILE
+    total = tiles_x * tiles_y
+    owned = (total - rank + world - 1) // world if total > rank else 0
+    return {"tiles_x": tiles_x, "tiles_y": tiles_y, "total_tiles": total, "owned_tiles": owned,
+            "tiles_per_rank": (total + world - 1) // world}
+
+
+def owned_tile_ids(width: int, height: int, rank: int, world: int) -> np.ndarray:
+    g = shard_geometry(width, height, rank, world)
+    return np.arange(rank, g["total_tiles"], world, dtype=np.int64)
+
+
+def assemble_reference(gathered: np.ndarray, width: int, height: int, world: int) -> np.ndarray:
+    """Host restatement of vrt_assemble_frame for checking (numpy).  gathered: [world, tiles_per_rank, 16, 16, C]."""
+    g = shard_geometry(width, height, 0, world)
+    c = gathered.shape[-1]
+    gathered = gathered.reshape(world, g["tiles_per_rank"], TILE, TILE, c)
+    frame = np.zeros((g["tiles_y"] * TILE, g["tiles_x"] * TILE, c), dtype=gathered.dtype)
+    for t in range(g["total_tiles"]):
+        ty, tx = divmod(t, g["tiles_x"])
+        frame[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE] = gathered[t % world, t // world]
+    return frame[:height, :width]
+
+
+class FrameGather:
+    """Owns the per-rank packed tile buffer and (on rank 0) the gathered buffer and the final
+    frame; performs the per-frame collective.  Works with any torch.distributed backend: "nccl"
+    (RCCL) on GPUs, "gloo" on CPU tensors in the world_size-2 tests."""
+
+    def __init__(self, width: int, height: int, rank: int, world: int, device, bytes_per_pixel: int = 4):
+        import torch
+        self.torch = torch
+        self.width, self.height, self.rank, self.world = width, height, rank, world
+        self.geom = shard_geometry(width, height, rank, world)
+        self.bpp = bytes_per_pixel
+        self.shard_bytes = self.geom["tiles_per_rank"] * TILE * TILE * bytes_per_pixel
+        self.device = device
+        self.shard = torch.zeros(self.shard_bytes, dtype=torch.uint8, device=device)
+        self.gathered: Optional["torch.Tensor"] = None
+        self.frame: Optional["torch.Tensor"] = None
+        if rank == 0:
+            self.gathered = torch.zeros(world * self.shard_bytes, dtype=torch.uint8, device=device)
+            self.frame = torch.zeros(height * width * bytes_per_pixel, dtype=torch.uint8, device=device)
+            self._recv_views = list(self.gathered.view(world, self.shard_bytes).unbind(0))
+
+    def gather(self) -> None:
+        """The one collective of the frame: every rank's packed shard -> rank 0, rank-major."""
+        import torch.distributed as dist
+        if self.world == 1:
+            self.gathered.copy_(self.shard)
+            return
+        dist.gather(self.shard, gather_list=self._recv_views if self.rank == 0 else None, dst=0)
+
+    def assemble(self, renderer=None) -> None:
+        """Rank 0: un-swizzle gathered shards into the row-major frame (device kernel when a renderer
+        context is given, numpy restatement otherwise — CPU tests only)."""
+        if self.rank != 0:
+            return
+        if renderer is not None:
+            renderer.assemble_frame(self.gathered.data_ptr(), self.frame.data_ptr(), self.bpp)
+        else:
+            g = self.gathered.cpu().numpy().reshape(self.world, -1)
+            px = g.reshape(self.world, self.geom["tiles_per_rank"], TILE, TILE, self.bpp)
+            out = assemble_reference(px, self.width, self.height, self.world)
+            self.frame.copy_(self.torch.from_numpy(np.ascontiguousarray(out).reshape(-1)))
+
+    def frame_numpy(self) -> np.ndarray:
+        assert self.rank == 0
+        return self.frame.cpu().numpy().reshape(self.height, self.width, self.bpp)

@@ -1,0 +1,321 @@
+"""Host-side mirror of the reference's scene / camera / renderer API for the
+traversal path, on top of the C ABI (include/vrt_hip.h).
+
+Names follow the reference so tests read like its call sites:
+  BrickGrid.init / insert            src/modules/voxel_rt/brick/Grid.zig:36,129
+  Camera.init                        src/modules/voxel_rt/Camera.zig:36
+  Sun.init                           src/modules/voxel_rt/Sun.zig:35
+  VoxelRT.init / push_materials / update_grid_delta / draw
+                                     src/modules/VoxelRT.zig:39,85,107,76
+All computation happens inside libvrt_hip.so (C++ host code + HIP kernels);
+this module only marshals arguments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import lib, check
+
+_GRID_ARRAY_DTYPES = {
+    L.BUF_BRICK_STATUS: np.uint32,
+    L.BUF_BRICK_INDEX: np.uint32,
+    L.BUF_BRICK_OCCUPANCY: np.uint8,
+    L.BUF_BRICK_START_INDEX: np.uint32,
+    L.BUF_MATERIAL_INDEX: np.uint8,
+}
+
+
+class BrickGrid:
+    """BrickGrid (Grid.zig).  `init` arguments are Grid.zig:36 + Grid.Config (Grid.zig:13-20),
+    plus brick_dimension (4 in the reference, State.zig:5)."""
+
+    def __init__(self, dim_x: int, dim_y: int, dim_z: int, *, brick_alloc: Optional[int] = None, base_t: float = 0.01,
+                 min_point: Sequence[float] = (0.0, 0.0, 0.0), scale: float = 1.0, brick_dimension: int = 4):
+        cfg = L.GridConfig()
+        cfg.brick_alloc = int(brick_alloc or 0)
+        cfg.base_t = base_t
+        cfg.min_point[:] = list(min_point)
+        cfg.scale = scale
+        cfg.brick_dimension = brick_dimension
+        h = C.c_void_p()
+        check(lib.vrt_grid_create(dim_x, dim_y, dim_z, C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.brick_dimension = brick_dimension
+        self.dim = (dim_x, dim_y, dim_z)
+        self.brick_alloc = int(brick_alloc) if brick_alloc else dim_x * dim_y * dim_z
+
+    init = classmethod(lambda cls, *a, **k: cls(*a, **k))
+
+    def deinit(self) -> None:
+        if self._h:
+            lib.vrt_grid_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.deinit()
+        except Exception:
+            pass
+
+    def insert(self, x: int, y: int, z: int, material_index: int) -> None:
+        check(lib.vrt_grid_insert(self._h, x, y, z, material_index))
+
+    def insert_many(self, xyz: np.ndarray, materials: np.ndarray) -> None:
+        xyz = np.ascontiguousarray(xyz, dtype=np.uint32).reshape(-1, 3)
+        materials = np.ascontiguousarray(materials, dtype=np.uint8).reshape(-1)
+        assert xyz.shape[0] == materials.shape[0]
+        check(lib.vrt_grid_insert_many(self._h, xyz.ctypes.data, materials.ctypes.data, xyz.shape[0]))
+
+    @property
+    def device_state(self) -> L.GridState:
+        return lib.vrt_grid_device_state(self._h).contents
+
+    @property
+    def active_bricks(self) -> int:
+        return lib.vrt_grid_active_bricks(self._h)
+
+    def array(self, buf_id: int) -> np.ndarray:
+        """Copy of host array `buf_id` (BUF_BRICK_STATUS .. BUF_MATERIAL_INDEX)."""
+        n = C.c_uint64()
+        ptr = lib.vrt_grid_data(self._h, buf_id, C.byref(n))
+        raw = (C.c_uint8 * n.value).from_address(ptr)
+        return np.frombuffer(bytes(raw), dtype=_GRID_ARRAY_DTYPES[buf_id]).copy()
+
+    def array_view(self, buf_id: int) -> np.ndarray:
+        """Zero-copy view (valid while the grid lives and is not resized)."""
+        n = C.c_uint64()
+        ptr = lib.vrt_grid_data(self._h, buf_id, C.byref(n))
+        raw = (C.c_uint8 * n.value).from_address(ptr)
+        return np.frombuffer(raw, dtype=_GRID_ARRAY_DTYPES[buf_id])
+
+    def delta(self, buf_id: int) -> Tuple[bool, int, int]:
+        a, b = C.c_uint64(), C.c_uint64()
+        active = lib.vrt_grid_delta(self._h, buf_id, C.byref(a), C.byref(b))
+        return bool(active), a.value, b.value
+
+    def reset_delta(self, buf_id: int) -> None:
+        lib.vrt_grid_reset_delta(self._h, buf_id)
+
+    def synth_terrain(self, seed: int = 420) -> None:
+        check(lib.vrt_synth_terrain(self._h, seed))
+
+    def synth_sparse(self, seed: int = 420, p: float = 0.05) -> None:
+        check(lib.vrt_synth_sparse(self._h, seed, p))
+
+
+@dataclass
+class CameraConfig:  # Camera.zig:5-14
+    viewport_height: float = 2.0
+    origin: Sequence[float] = (0.0, 0.0, 0.0)
+    samples_per_pixel: int = 2
+    max_bounce: int = 2
+
+
+class Camera:
+    def __init__(self, vertical_fov: float, image_width: int, image_height: int, config: Optional[CameraConfig] = None):
+        config = config or CameraConfig()
+        cc = L.CameraConfig()
+        cc.viewport_height = config.viewport_height
+        cc.origin[:] = list(config.origin)
+        cc.samples_per_pixel = config.samples_per_pixel
+        cc.max_bounce = config.max_bounce
+        self.vertical_fov = vertical_fov
+        self.viewport_height_cfg = config.viewport_height
+        self.d_camera = L.CameraDevice()
+        check(lib.vrt_camera_init(vertical_fov, image_width, image_height, C.byref(cc), C.byref(self.d_camera)))
+        self._forward = (0.0, 0.0, 1.0)
+
+    init = classmethod(lambda cls, *a, **k: cls(*a, **k))
+
+    def set_forward(self, forward: Sequence[float]) -> None:
+        f = (C.c_float * 3)(*forward)
+        check(lib.vrt_camera_set_forward(C.byref(self.d_camera), self.vertical_fov, self.viewport_height_cfg, C.byref(f)))
+        self._forward = tuple(forward)
+
+    def set_origin(self, origin: Sequence[float]) -> None:  # Camera.setOrigin, Camera.zig:89-92
+        self.d_camera.origin[:] = list(origin)
+        self.set_forward(self._forward)
+
+    def look_at(self, origin: Sequence[float], target: Sequence[float]) -> None:
+        """Place the camera at `origin` viewing `target`.  Rays leave along -forward
+        (lower_left_corner = origin - h/2 - v/2 - forward, Camera.zig:177-180)."""
+        self.d_camera.origin[:] = list(origin)
+        self.set_forward([o - t for o, t in zip(origin, target)])
+
+    def blob(self) -> bytes:
+        return bytes(self.d_camera)
+
+
+@dataclass
+class SunConfig:  # Sun.zig:4-11
+    enabled: bool = True
+    color: Sequence[float] = (1.0, 1.1, 1.0)
+    radius: float = 5.0
+    sun_distance: float = 1000.0
+
+
+class Sun:
+    def __init__(self, config: Optional[SunConfig] = None):
+        config = config or SunConfig()
+        sc = L.SunConfig()
+        sc.enabled = 1 if config.enabled else 0
+        sc.color[:] = list(config.color)
+        sc.radius = config.radius
+        sc.sun_distance = config.sun_distance
+        self.device_data = L.SunDevice()
+        check(lib.vrt_sun_init(C.byref(sc), C.byref(self.device_data)))
+
+    init = classmethod(lambda cls, *a, **k: cls(*a, **k))
+
+    def blob(self) -> bytes:
+        return bytes(self.device_data)
+
+
+def default_materials(capacity: int = 256) -> np.ndarray:
+    """The reference's terrain material table (terrain.zig:130-196) padded to `capacity`
+    20-byte records; returned as a (capacity, 5) uint32 view-compatible structured array."""
+    arr = (L.Material * capacity)()
+    lib.vrt_default_materials(arr, capacity)
+    return np.frombuffer(bytes(arr), dtype=MATERIAL_DTYPE).copy()
+
+
+MATERIAL_DTYPE = np.dtype([("type", np.uint32), ("albedo_r", np.float32), ("albedo_g", np.float32),
+                           ("albedo_b", np.float32), ("type_data", np.float32)])
+assert MATERIAL_DTYPE.itemsize == 20
+
+
+@dataclass
+class Config:  # VoxelRT.Config, VoxelRT.zig:22-28 (+ the knobs of this implementation)
+    internal_resolution_width: int = 1280
+    internal_resolution_height: int = 720
+    camera: CameraConfig = field(default_factory=CameraConfig)
+    sun: SunConfig = field(default_factory=SunConfig)
+    material_buffer: int = 256  # Pipeline.Config.material_buffer, Pipeline.zig:30
+    want_float_output: bool = False
+    enable_counters: bool = False
+    device_id: int = -1
+    shard_rank: int = 0
+    shard_count: int = 1
+    kernel_variant: int = 0
+    stream: int = 0
+    external_target_rgba8: int = 0
+    external_target_rgba32f: int = 0
+
+
+class VoxelRT:
+    """VoxelRT (src/modules/VoxelRT.zig): owns camera, sun and the device pipeline for one grid."""
+
+    def __init__(self, brick_grid: BrickGrid, config: Optional[Config] = None, upload_grid: bool = True):
+        config = config or Config()
+        self.config = config
+        self.brick_grid = brick_grid
+        self.camera = Camera(75.0, config.internal_resolution_width, config.internal_resolution_height, config.camera)  # VoxelRT.zig:42
+        self.sun = Sun(config.sun)
+        cfg = L.Config()
+        cfg.struct_size = C.sizeof(L.Config)
+        cfg.abi_version = L.VRT_ABI_VERSION
+        cfg.width = config.internal_resolution_width
+        cfg.height = config.internal_resolution_height
+        cfg.brick_dimension = brick_grid.brick_dimension
+        cfg.dim_x, cfg.dim_y, cfg.dim_z = brick_grid.dim
+        cfg.brick_alloc = brick_grid.brick_alloc
+        cfg.material_capacity = config.material_buffer
+        cfg.device_id = config.device_id
+        cfg.want_float_output = 1 if config.want_float_output else 0
+        cfg.enable_counters = 1 if config.enable_counters else 0
+        cfg.shard_rank = config.shard_rank
+        cfg.shard_count = config.shard_count
+        cfg.kernel_variant = config.kernel_variant
+        cfg.stream = config.stream or None
+        cfg.external_target_rgba8 = config.external_target_rgba8 or None
+        cfg.external_target_rgba32f = config.external_target_rgba32f or None
+        h = C.c_void_p()
+        check(lib.vrt_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.width, self.height = cfg.width, cfg.height
+        if upload_grid:
+            check(lib.vrt_upload_grid(self._h, brick_grid._h), self._h)  # VoxelRT.zig:62 (+ first full delta)
+
+    init = classmethod(lambda cls, *a, **k: cls(*a, **k))
+
+    def deinit(self) -> None:
+        if getattr(self, "_h", None):
+            lib.vrt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.deinit()
+        except Exception:
+            pass
+
+    # -- uploads ------------------------------------------------------------
+    def push_materials(self, materials: np.ndarray) -> None:  # VoxelRT.zig:85-87
+        materials = np.ascontiguousarray(materials)
+        check(lib.vrt_upload(self._h, L.BUF_MATERIALS, 0, materials.ctypes.data, materials.nbytes), self._h)
+
+    def update_grid_delta(self) -> None:  # VoxelRT.zig:107-172
+        check(lib.vrt_update_grid_delta(self._h, self.brick_grid._h), self._h)
+
+    def upload(self, buf_id: int, byte_offset: int, data: np.ndarray) -> None:  # Pipeline.transfer*, Pipeline.zig:560-652
+        data = np.ascontiguousarray(data)
+        check(lib.vrt_upload(self._h, buf_id, byte_offset, data.ctypes.data, data.nbytes), self._h)
+
+    def buffer_size(self, buf_id: int) -> int:
+        return lib.vrt_buffer_size(self._h, buf_id)
+
+    # -- frame --------------------------------------------------------------
+    def draw(self, frames: int = 1) -> None:  # VoxelRT.draw -> Pipeline.draw -> compute dispatch (Pipeline.zig:441)
+        if frames == 1:
+            check(lib.vrt_dispatch(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data)), self._h)
+        else:
+            check(lib.vrt_dispatch_repeat(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data), frames), self._h)
+
+    def wait(self) -> None:
+        check(lib.vrt_wait(self._h), self._h)
+
+    def last_kernel_ms(self) -> float:
+        return lib.vrt_last_kernel_ms(self._h)
+
+    def shard_info(self) -> L.ShardInfo:
+        s = L.ShardInfo()
+        check(lib.vrt_get_shard_info(self._h, C.byref(s)), self._h)
+        return s
+
+    def target_bytes_rgba8(self) -> int:
+        return lib.vrt_target_bytes_rgba8(self._h)
+
+    def read_rgba8(self) -> np.ndarray:
+        n = self.target_bytes_rgba8()
+        out = np.empty(n, dtype=np.uint8)
+        check(lib.vrt_read_rgba8(self._h, out.ctypes.data, n), self._h)
+        if self.config.shard_count <= 1:
+            return out.reshape(self.height, self.width, 4)
+        return out.reshape(-1, 16, 16, 4)
+
+    def read_rgba32f(self) -> np.ndarray:
+        n = self.target_bytes_rgba8() * 4
+        out = np.empty(n // 4, dtype=np.float32)
+        check(lib.vrt_read_rgba32f(self._h, out.ctypes.data, n), self._h)
+        if self.config.shard_count <= 1:
+            return out.reshape(self.height, self.width, 4)
+        return out.reshape(-1, 16, 16, 4)
+
+    def device_target_rgba8(self) -> int:
+        return lib.vrt_device_target_rgba8(self._h)
+
+    def assemble_frame(self, gathered_ptr: int, dst_ptr: int, bytes_per_pixel: int = 4) -> None:
+        check(lib.vrt_assemble_frame(self._h, gathered_ptr, dst_ptr, bytes_per_pixel), self._h)
+
+    def counters(self) -> dict:
+        c = L.Counters()
+        check(lib.vrt_get_counters(self._h, C.byref(c)), self._h)
+        return {k: getattr(c, k) for k, _ in L.Counters._fields_}
+
+    def kernel_name(self) -> str:
+        return lib.vrt_kernel_name(self._h).decode()
