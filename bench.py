@@ -195,6 +195,7 @@ def main() -> None:
             "config": {"workload": w.name, "frame": f"{w.width}x{w.height}", "grid": f"{w.voxels}^3 voxels, {w.brick_dimension}^3 bricks",
                        "rays": "primary + shadow" if w.sun_enabled else "primary", "spp": w.spp, "max_bounce": w.max_bounce,
                        "views": VIEW_ORDER, "rays_per_frame": {v: per_view[v]["rays"] for v in VIEW_ORDER},
+                       "counters_per_frame": {v: per_view[v]["counters"] for v in VIEW_ORDER},
                        "parallelism": f"image tiles 16x16 interleaved over {world} GPU(s), 1 RCCL gather/frame" if sharded else "1 GPU, whole frame"},
             "roofline": roofline,
         }

@@ -168,6 +168,13 @@ SIGNATURES = {
 
 
 def _load() -> C.CDLL:
+    # torch bundles its own libamdhip64.so.7; whichever HIP runtime is mapped first serves the whole
+    # process.  Load torch's first so libvrt_hip.so (NEEDED libamdhip64.so.7) shares it — the other
+    # order leaves torch with "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C zig_vulkan_amd/csrc` (or __graft_entry__.build()). "
