@@ -68,7 +68,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--workload", default=None)
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--variant", type=lambda x: int(x, 0), default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=540)
     ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")

@@ -27,8 +27,8 @@
  *                             reduction + fixed polynomial, specified below
  *                             (GLSL.std.450 Sin precision is implementation
  *                             defined; libm/ocml sinf differ from each other)
- *   - int(x), uint8(x)     -> saturating conversion vrt_f2i (what v_cvt_i32_f32
- *                             does; C's conversion is UB out of range)
+ *   - int(x)               -> (int)clamp(x, -2^31, 2147483520) (vrt_f2i; GLSL leaves the
+ *                             out-of-range conversion undefined, C makes it UB)
  *   - Rgba8 imageStore     -> rintf(clamp(c,0,1)*255)
  * Hang guard: both DDA loops carry an iteration cap that a well-formed DDA can
  * never reach (each iteration moves one cell along one axis); the reference
@@ -134,12 +134,10 @@ static inline float vidx(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.
 static inline float gmin(float x, float y) { return (y < x) ? y : x; }
 static inline float gmax(float x, float y) { return (x < y) ? y : x; }
 
-/* saturating float -> int32 (NaN -> 0), as v_cvt_i32_f32 */
+/* float -> int32 by clamping first (GLSL leaves out-of-range int(x) undefined); NaN takes the
+ * lower bound (fmaxf returns the non-NaN operand). */
 static inline int32_t vrt_f2i(float x) {
-    if (x != x) return 0;
-    if (x >= 2147483648.0f) return INT32_MAX;
-    if (x <= -2147483648.0f) return INT32_MIN;
-    return (int32_t)x;
+    return (int32_t)fminf(fmaxf(x, -2147483648.0f), 2147483520.0f);
 }
 
 /* sin(x) by specification: k = rint(x*2/pi) in double, r = x - k*pi/2 with a

@@ -1,34 +1,38 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output dirs (stats + pmc passes) into a small text summary for profiles/."""
-import csv
+"""Condense rocprofv3 (rocpd sqlite) output dirs — one kernel-trace/stats run plus PMC passes — into a
+small text summary to commit under profiles/.  usage: summarize_prof.py <dir>"""
 import glob
 import os
+import sqlite3
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-print(f"# rocprofv3 summary of {os.path.basename(out)}")
-for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
-    print(f"\n## kernel stats ({os.path.relpath(f, out)})")
-    with open(f) as fh:
-        for row in csv.DictReader(fh):
-            print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+print(f"# rocprofv3 summary of {os.path.basename(out.rstrip('/'))}")
+for f in sorted(glob.glob(os.path.join(out, "stats", "**", "*.db"), recursive=True)):
+    db = sqlite3.connect(f)
+    print(f"\n## kernel stats (--kernel-trace --stats)  [{os.path.relpath(f, out)}]")
+    print(f"{'kernel':70s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'%':>7s}")
+    for name, calls, total, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        print(f"{name[:70]:70s} {calls:6d} {total:12.1f} {avg:10.2f} {pct:7.2f}")
+    rows = list(db.execute("select name, min(duration), max(duration), avg(duration), count(*), vgpr_count, accum_vgpr_count, sgpr_count, "
+                           "scratch_size, lds_size, grid_x, workgroup_x from kernels where name like '%vrt_%' group by name"))
+    for r in rows:
+        print(f"   {r[0][:60]}: n={r[4]} min={r[1] / 1e3:.1f}us max={r[2] / 1e3:.1f}us avg={r[3] / 1e3:.1f}us vgpr={r[5]} agpr={r[6]} sgpr={r[7]} "
+              f"scratch={r[8]} lds={r[9]} grid={r[10]} wg={r[11]}")
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for f in sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)):
+        db = sqlite3.connect(f)
         agg = defaultdict(lambda: defaultdict(float))
-        calls = defaultdict(set)
-        with open(f) as fh:
-            for row in csv.DictReader(fh):
-                k = row.get("Kernel_Name", "?")
-                if "vrt_" not in k:
-                    continue
-                agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
-                calls[k].add(row.get("Dispatch_Id"))
-        print(f"\n## {os.path.relpath(f, out)}")
+        disp = defaultdict(set)
+        for k, c, v, did in db.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection where kernel_name like '%vrt_%'"):
+            agg[k][c] += v
+            disp[k].add(did)
+        print(f"\n## PMC pass [{os.path.relpath(f, out)}]")
         for k, cs in agg.items():
-            n = max(1, len(calls[k]))
-            print(f"kernel {k[:90]}  dispatches={n}")
+            n = max(1, len(disp[k]))
+            print(f"kernel {k[:80]}  dispatches={n}")
             for c, v in sorted(cs.items()):
-                print(f"   {c:32s} total={v:.6g}  per_dispatch={v / n:.6g}")
+                print(f"   {c:34s} per_dispatch={v / n:.6g}")

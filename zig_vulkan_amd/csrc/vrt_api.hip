@@ -18,7 +18,10 @@
 namespace vrt {
 using KernelFn = void (*)(const TraceParams);
 KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant);
-hipError_t launch_trace(KernelFn fn, const TraceParams &p, hipStream_t stream);
+uint32_t resolve_variant(uint32_t variant);
+size_t trace_lds_bytes(const TraceParams &p, uint32_t variant);
+hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per_pixel, uint32_t width, uint32_t height, uint32_t tiles_x,
                            uint32_t shard_count, uint32_t tiles_per_rank, hipStream_t stream);
 } // namespace vrt
@@ -42,6 +45,9 @@ struct vrt_ctx {
     bool own_t8 = false, own_t32 = false;
     uint64_t target_pixels = 0; // pixels in the (possibly sharded, padded) target
     vrt::DeviceCounters *d_counters = nullptr;
+    void *d_status_blocks = nullptr; // derived: 4x4x4 block words + block filter (vrt_trace.hip)
+    bool status_dirty = true;        // brick_status changed since the derived copy was built
+    size_t lds_bytes = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool in_flight = false;
     bool timing_valid = false;
@@ -96,6 +102,7 @@ void free_ctx(vrt_ctx *c) {
     if (c->own_t8 && c->target8) (void)hipFree(c->target8);
     if (c->own_t32 && c->target32f) (void)hipFree(c->target32f);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_status_blocks) (void)hipFree(c->d_status_blocks);
     for (int i = 0; i < kStagingSlots; i++) {
         if (c->staging[i]) (void)hipHostFree(c->staging[i]);
         if (c->staging_ev[i]) (void)hipEventDestroy(c->staging_ev[i]);
@@ -169,7 +176,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         return fail(nullptr, VRT_E_INVALID_ARG, "tile size must be 16x16 (or 0)");
     const uint32_t shard_count = cfg->shard_count ? cfg->shard_count : 1u;
     if (cfg->shard_rank >= shard_count) return fail(nullptr, VRT_E_INVALID_ARG, "shard_rank >= shard_count");
-    if (cfg->kernel_variant >= vrt::kVariantCount) return fail(nullptr, VRT_E_INVALID_ARG, "unknown kernel_variant");
+    if ((cfg->kernel_variant & 0xFFu) >= vrt::kVariantCount || (cfg->kernel_variant >> 16)) return fail(nullptr, VRT_E_INVALID_ARG, "unknown kernel_variant");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -254,6 +261,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_counters), sizeof(vrt::DeviceCounters)));
         VRT_CREATE_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(vrt::DeviceCounters), c->stream));
     }
+    const uint32_t nbx = (cfg->dim_x + 3u) / 4u, nby = (cfg->dim_y + 3u) / 4u, nbz = (cfg->dim_z + 3u) / 4u;
+    const size_t nblocks = (size_t)nbx * nby * nbz;
+    const size_t status_blocks_bytes = nblocks * 8u + ((nblocks + 31u) / 32u) * 4u + 16u;
+    VRT_CREATE_HIP(hipMalloc(&c->d_status_blocks, status_blocks_bytes));
+    VRT_CREATE_HIP(hipMemsetAsync(c->d_status_blocks, 0, status_blocks_bytes, c->stream));
     for (int i = 0; i < kStagingSlots; i++) {
         VRT_CREATE_HIP(hipHostMalloc(&c->staging[i], kStagingSlotBytes, hipHostMallocDefault));
         VRT_CREATE_HIP(hipEventCreateWithFlags(&c->staging_ev[i], hipEventDisableTiming));
@@ -266,8 +278,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     }
     {
         char buf[96];
-        std::snprintf(buf, sizeof buf, "vrt_trace_kernel<B=%u,COUNT=%d,VARIANT=%u>", cfg->brick_dimension, cfg->enable_counters ? 1 : 0,
-                      cfg->kernel_variant == vrt::kVariantLiteral ? (unsigned)vrt::kVariantLiteral : (unsigned)vrt::kVariantSplit);
+        static const char *const mode_names[] = {"?", "linear-status(literal)", "blocked-status", "blocked-status+lds-filter"};
+        const uint32_t rv = vrt::resolve_variant(cfg->kernel_variant);
+        std::snprintf(buf, sizeof buf, "vrt_trace_kernel<B=%u,COUNT=%d,%s,minwaves=%u>", cfg->brick_dimension, cfg->enable_counters ? 1 : 0,
+                      mode_names[rv & 0xFFu], (rv >> 8) ? (rv >> 8) : 4u);
         c->kernel_name = buf;
     }
 
@@ -290,6 +304,18 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.shard_count = sh.shard_count;
     p.owned_tiles = sh.owned_tiles;
     p.status_words = (uint32_t)((cells + 31u) / 32u);
+    p.status_blocks = static_cast<const uint2 *>(c->d_status_blocks);
+    p.nbx = nbx;
+    p.nby = nby;
+    p.nbz = nbz;
+    c->lds_bytes = vrt::trace_lds_bytes(p, cfg->kernel_variant);
+    if (c->lds_bytes > 64u * 1024u) {
+        // the block filter of a very large grid does not fit the LDS budget: read block words directly
+        c->cfg.kernel_variant = (cfg->kernel_variant & ~0xFFu) | vrt::kVariantBlocked;
+        c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant);
+        c->lds_bytes = 0;
+        c->kernel_name += "[filter>64KiB: blocked-status]";
+    }
     // the grid-state UBO mirror starts zeroed; dim 0 => every ray misses until GRID_STATE is uploaded
 #undef VRT_CREATE_HIP
     *out = c;
@@ -320,6 +346,7 @@ int vrt_upload(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, const void 
         // the kernel takes the UBO through its argument block; keep the host mirror current
         std::memcpy(reinterpret_cast<uint8_t *>(&ctx->params.grid) + byte_offset, src, (size_t)nbytes);
     }
+    if (id == VRT_BUF_BRICK_STATUS) ctx->status_dirty = true;
     return copy_h2d(ctx, static_cast<uint8_t *>(ctx->dbuf[id]) + byte_offset, src, nbytes);
 }
 
@@ -332,6 +359,7 @@ int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, cons
                                     ctx->stream));
         VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    if (id == VRT_BUF_BRICK_STATUS) ctx->status_dirty = true;
     VRT_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->dbuf[id]) + byte_offset, dev_src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
     return VRT_OK;
 }
@@ -347,9 +375,17 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     ctx->in_flight = false;
     ctx->params.pc.cam = *camera;
     ctx->params.pc.sun = *sun;
+    const vrt_grid_state &g = ctx->params.grid;
+    if (g.dim_x != 0 && (g.dim_x != ctx->cfg.dim_x || g.dim_y != ctx->cfg.dim_y || g.dim_z != ctx->cfg.dim_z))
+        return fail(ctx, VRT_E_INVALID_ARG, "uploaded grid state has other brick dimensions than the context was created with");
     if (ctx->d_counters) VRT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(vrt::DeviceCounters), ctx->stream));
+    if (ctx->status_dirty) {
+        // refresh the derived block words / filter from the uploaded status bits (stream-ordered after the uploads)
+        VRT_HIP(ctx, vrt::launch_build_status_blocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
+        ctx->status_dirty = false;
+    }
     VRT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-    for (uint32_t f = 0; f < frames; f++) VRT_HIP(ctx, vrt::launch_trace(ctx->kernel, ctx->params, ctx->stream));
+    for (uint32_t f = 0; f < frames; f++) VRT_HIP(ctx, vrt::launch_trace(ctx->kernel, ctx->params, ctx->lds_bytes, ctx->stream));
     VRT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->timed_frames = frames;
     ctx->in_flight = true;

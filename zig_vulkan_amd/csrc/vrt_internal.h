@@ -1,5 +1,6 @@
 // vrt_internal.h — types shared by the C-ABI implementation and the kernels.
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/vrt_hip.h"
 
@@ -38,8 +39,14 @@ struct TraceParams {
     // tile geometry / sharding
     uint32_t tiles_x, tiles_y;           // 16x16-pixel workgroup tiles in the frame
     uint32_t shard_rank, shard_count;    // this ctx renders tiles t % count == rank
-    uint32_t owned_tiles;                // number of tiles (= workgroups) launched
+    uint32_t owned_tiles;                // number of tiles this context renders
     uint32_t status_words;               // length of brick_status in u32 words
+    // derived, device-built copy of brick_status: one 64-bit word per 4x4x4 block of grid cells,
+    // block index bx + nbx*(bz + nbz*by), bit (x&3) + 4*(z&3) + 16*(y&3)  (x, z, y order as comp:318)
+    const uint2 *status_blocks;
+    uint32_t nbx, nby, nbz;
+    uint32_t *tile_counters;             // persistent-workgroup work queue: 2 sets x 8 XCD slices
+    uint32_t frame_parity;               // which counter set this launch consumes
 };
 
 constexpr int kTileW = 16;
@@ -47,9 +54,10 @@ constexpr int kTileH = 16;
 
 // kernel variants (vrt_config.kernel_variant)
 enum : uint32_t {
-    kVariantDefault = 0,  // best known
-    kVariantLiteral = 1,  // literal nested loops, byte loads (reference structure)
-    kVariantSplit = 2,    // grid-walk / brick-walk phase split, 64-bit occupancy words
+    kVariantDefault = 0,    // best known (see vrt_trace.hip select_trace_kernel)
+    kVariantLiteral = 1,    // the shader's memory behaviour: linear status words, byte occupancy loads
+    kVariantBlocked = 2,    // blocked 4^3 status words + 64-bit occupancy words, read from global memory
+    kVariantBlockedLds = 3, // same, status blocks staged in LDS by persistent workgroups
     kVariantCount
 };
 

@@ -10,7 +10,7 @@
 //   fract(x)      = x - floor(x)
 //   reflect(I,N)  = I - (2*dot(N,I))*N
 //   sin(x)        = vrt_sin (f64 Cody-Waite reduction + fixed f64 polynomial)
-//   int(x)        = saturating convert (v_cvt_i32_f32 semantics)
+//   int(x)        = (int)clamp(x, -2^31, 2147483520)  (f2i_clamp)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,18 +43,15 @@ VRT_DI float sign1(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0
 VRT_DI float fract1(float x) { return x - __builtin_floorf(x); }
 VRT_DI float gl_min(float x, float y) { return (y < x) ? y : x; }
 VRT_DI float gl_max(float x, float y) { return (x < y) ? y : x; }
-VRT_DI float pick3(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 VRT_DI f3 reflect3(f3 I, f3 N) {
     const float k = 2.0f * dot3(N, I);
     return I - N * k;
 }
 
-// float -> int32, saturating, NaN -> 0
-VRT_DI int f2i_sat(float x) {
-    if (x != x) return 0;
-    if (x >= 2147483648.0f) return 2147483647;
-    if (x <= -2147483648.0f) return (-2147483647 - 1);
-    return (int)x;
+// float -> int32 by clamping first (GLSL leaves out-of-range int(x) undefined): two VALU ops, no
+// branches.  NaN takes the lower bound (maxNum semantics of v_max_f32 / fmaxf).
+VRT_DI int f2i_clamp(float x) {
+    return (int)__builtin_fminf(__builtin_fmaxf(x, -2147483648.0f), 2147483520.0f);
 }
 
 // sin by specification (same sequence as the parity oracle's restatement).

@@ -4,18 +4,19 @@
 // (src/modules/voxel_rt/ComputePipeline.zig:550).  One lane = one pixel, one
 // wave = an 8x8 pixel block (coherent rays), one 256-thread workgroup = a
 // 16x16 tile.  Arithmetic follows vrt_math.h's contract operation by
-// operation; what differs from the shader is only how memory is touched and how
-// the loops are arranged for a 64-wide wave:
+// operation; what differs from the shader is only how memory is touched:
+//   * brick status is read from a device-built blocked copy: one 64-bit word
+//     per 4x4x4 block of grid cells, so a ray loads a new word every ~4 steps
+//     in any direction (the shader's linear words only serve rays moving along
+//     x, comp:318-326);
+//   * an LDS-resident filter (1 bit per 4x4x4 block: "some cell occupied")
+//     lets lanes crossing empty space skip the global load altogether;
 //   * occupancy is read as one 64-bit word per brick (4^3) or per y-layer (8^3)
 //     and bit-tested in registers, instead of one byte load per voxel step
 //     (comp:415);
-//   * the brick-level walk and the voxel-level walk run as two separate wave
-//     phases: all lanes first advance their grid DDA to the next occupied cell
-//     (empty-space skipping under one exec mask), then all lanes that found one
-//     walk their brick together; the shader's nested form makes the whole wave
-//     wait on every lane's inner loop at a different outer iteration;
 //   * blockIdx is remapped so that each XCD (block b runs on XCD b % 8) gets a
-//     contiguous band of image tiles and its L2 holds one region of the grid.
+//     contiguous band of image tiles and its L2 holds one region of the grid;
+//   * DDA steps are branch-free selects (no exec-mask churn on the scalar unit).
 #include <hip/hip_runtime.h>
 #include "vrt_internal.h"
 #include "vrt_math.h"
@@ -43,9 +44,9 @@ struct Cnt {
 template <>
 struct Cnt<false> {};
 
-#define VRT_COUNT(field)          \
-    if constexpr (COUNT) {        \
-        c.field++;                \
+#define VRT_COUNT(field)   \
+    if constexpr (COUNT) { \
+        c.field++;         \
     }
 
 // comp:180-184
@@ -55,34 +56,36 @@ VRT_DI f3 ray_at(const Ray &r, float t) { return fma3(splat3(t), r.direction, r.
 // comp:267
 VRT_DI float safe_inverse(float x) { return (x == 0.0f) ? 1e12f : (1.0f / x); }
 
-// DDA walker state shared by the two levels.  `axis` records which face the
-// last step crossed (3 = none yet: the slab-entry normal applies), from which
-// hit.normal is rebuilt only when a voxel is actually hit (comp:350,356,364,370).
+// DDA walker state shared by the two levels.
 struct Walk {
     f3 side_dist;
     int x, y, z;
     float t_value;
 };
 
-// comp:345-372 / comp:440-467: branchy min-axis step, as selects.
+// comp:345-372 / comp:440-467: the branchy min-axis step as selects.
+//   x<y ? (x<z ? X : Z) : (y<z ? Y : Z)
+// `axis` records the face crossed; hit.normal (comp:350,356,364,370) is rebuilt from it
+// only when a voxel is actually hit.
 VRT_DI void dda_step(Walk &w, const f3 &ray_delta, int sx, int sy, int sz, float scale, int &axis) {
     const bool x_lt_y = w.side_dist.x < w.side_dist.y;
     const bool x_lt_z = w.side_dist.x < w.side_dist.z;
     const bool y_lt_z = w.side_dist.y < w.side_dist.z;
-    const int a = x_lt_y ? (x_lt_z ? 0 : 2) : (y_lt_z ? 1 : 2);
-    const float sd = (a == 0) ? w.side_dist.x : ((a == 1) ? w.side_dist.y : w.side_dist.z);
+    const bool ax = x_lt_y && x_lt_z;
+    const bool ay = !x_lt_y && y_lt_z;
+    const bool az = !(ax || ay);
+    const float sd = ax ? w.side_dist.x : (ay ? w.side_dist.y : w.side_dist.z);
     w.t_value = sd * scale;
-    if (a == 0) {
-        w.side_dist.x += ray_delta.x;
-        w.x += sx;
-    } else if (a == 1) {
-        w.side_dist.y += ray_delta.y;
-        w.y += sy;
-    } else {
-        w.side_dist.z += ray_delta.z;
-        w.z += sz;
-    }
-    axis = a;
+    const float nx = w.side_dist.x + ray_delta.x;
+    const float ny = w.side_dist.y + ray_delta.y;
+    const float nz = w.side_dist.z + ray_delta.z;
+    w.side_dist.x = ax ? nx : w.side_dist.x;
+    w.side_dist.y = ay ? ny : w.side_dist.y;
+    w.side_dist.z = az ? nz : w.side_dist.z;
+    w.x += ax ? sx : 0;
+    w.y += ay ? sy : 0;
+    w.z += az ? sz : 0;
+    axis = ax ? 0 : (ay ? 1 : 2);
 }
 
 // comp:298 / comp:395
@@ -107,10 +110,14 @@ VRT_DI bool grid_slab(const TraceParams &p, const Ray &r, float t_min, float t_m
     const f3 t_mins = mk3(gl_min(t_lower.x, t_upper.x), gl_min(t_lower.y, t_upper.y), gl_min(t_lower.z, t_upper.z));
     const f3 t_maxes = mk3(gl_max(t_lower.x, t_upper.x), gl_max(t_lower.y, t_upper.y), gl_max(t_lower.z, t_upper.z));
     // indexOfMaxComponent, comp:501-503 (ties resolve to 0)
-    const int i = (int)(t_mins.y > t_mins.x && t_mins.y > t_mins.z) + (int)(t_mins.z > t_mins.x && t_mins.z > t_mins.y) * 2;
-    const float sg = sign1(pick3(inv, i));
-    s.entry_normal = mk3(i == 0 ? sg : 0.0f, i == 1 ? sg : 0.0f, i == 2 ? sg : 0.0f);
-    s.grid_t_min = gl_max(t_min, pick3(t_mins, i));
+    const bool iy = (t_mins.y > t_mins.x) && (t_mins.y > t_mins.z);
+    const bool iz = (t_mins.z > t_mins.x) && (t_mins.z > t_mins.y);
+    // iy and iz cannot both hold; index = iy + 2*iz
+    const float inv_i = iz ? inv.z : (iy ? inv.y : inv.x);
+    const float tmin_i = iz ? t_mins.z : (iy ? t_mins.y : t_mins.x);
+    const float sg = sign1(inv_i);
+    s.entry_normal = mk3((!iy && !iz) ? sg : 0.0f, iy ? sg : 0.0f, iz ? sg : 0.0f);
+    s.grid_t_min = gl_max(t_min, tmin_i);
     s.grid_t_max = gl_min(t_max, gl_min(gl_min(t_maxes.x, t_maxes.y), t_maxes.z));
     s.ray_delta = abs3(inv);
     s.sx = (int)sign1(r.direction.x);
@@ -121,68 +128,60 @@ VRT_DI bool grid_slab(const TraceParams &p, const Ray &r, float t_min, float t_m
 }
 
 VRT_DI f3 axis_normal(const RaySetup &s, int axis) {
-    if (axis == 3) return s.entry_normal;
-    // normal_axis, comp:304-308: (step < 0) ? 1 : -1 on the crossed axis
+    // normal_axis, comp:304-308: (step < 0) ? 1 : -1 on the crossed axis; axis 3 = slab-entry normal
     const float nx = (s.sx < 0) ? 1.0f : -1.0f, ny = (s.sy < 0) ? 1.0f : -1.0f, nz = (s.sz < 0) ? 1.0f : -1.0f;
-    return mk3(axis == 0 ? nx : 0.0f, axis == 1 ? ny : 0.0f, axis == 2 ? nz : 0.0f);
+    return mk3(axis == 0 ? nx : (axis == 3 ? s.entry_normal.x : 0.0f), axis == 1 ? ny : (axis == 3 ? s.entry_normal.y : 0.0f),
+               axis == 2 ? nz : (axis == 3 ? s.entry_normal.z : 0.0f));
 }
 
-// ---- occupancy access -----------------------------------------------------
-// brick_occupancy bit v%8 of byte brick*(B^3/8) + v/8 (Grid.zig:180-182) read
-// as little-endian 64-bit words: word y of a brick holds voxels
-// v = x + B*z + 64*y' ... for B=4 the whole brick is one word; for B=8 word
-// index == y layer (v = x + 8*(z + 8*y)).
-template <int B>
-struct OccCache {
-    unsigned long long word;
-    int layer; // B==8: y layer held in `word`, -1 = none
-};
-
-template <int B>
-VRT_DI bool voxel_solid(const TraceParams &p, uint32_t brick_index, int vx, int vy, int vz, OccCache<B> &oc) {
-    if constexpr (B == 4) {
-        const int v = vx + 4 * (vz + 4 * vy);
-        return (oc.word >> v) & 1ull;
-    } else {
-        if (oc.layer != vy) {
-            const unsigned long long *base = reinterpret_cast<const unsigned long long *>(p.brick_occupancy) + (size_t)brick_index * 8u;
-            oc.word = base[vy];
-            oc.layer = vy;
-        }
-        return (oc.word >> (vx + 8 * vz)) & 1ull;
-    }
+VRT_DI bool bit64(uint2 w, uint32_t bit) { // bit 0..63 of a 64-bit word held as two dwords
+    const uint32_t half = (bit & 32u) ? w.y : w.x;
+    return (half >> (bit & 31u)) & 1u;
 }
 
 // comp:378-471.  Returns true on a (non-ignored) voxel hit and fills `hit`.
-template <int B, bool COUNT>
-VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t brick_index,
-                       f3 brick_min, Hit &hit, int &axis, Cnt<COUNT> &c) {
+// LITERAL: one byte load per voxel step (comp:415); otherwise 64-bit occupancy words:
+// brick_occupancy bit v%8 of byte brick*(B^3/8) + v/8 (Grid.zig:180-182) read as little-endian
+// 64-bit words — the whole brick for B=4, one y-layer (v = x + 8*(z + 8*y)) for B=8.
+template <int B, bool COUNT, bool LITERAL>
+VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t brick_index, f3 brick_min, Hit &hit,
+                       int &axis, Cnt<COUNT> &c) {
     const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
     const float voxel_scale = g_scale * brick_voxel_scale;
     const f3 fposition = (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
     Walk w;
     w.side_dist = initial_side_dist(s.fstep, fposition, s.ray_delta);
-    w.x = f2i_sat(__builtin_floorf(fposition.x + 0.f));
-    w.y = f2i_sat(__builtin_floorf(fposition.y + 0.f));
-    w.z = f2i_sat(__builtin_floorf(fposition.z + 0.f));
+    w.x = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
+    w.y = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
+    w.z = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
     w.t_value = 0;
     const float local_t_max = s.grid_t_max - hit.t;
 
-    OccCache<B> oc;
-    oc.layer = -1;
-    if constexpr (B == 4) {
-        oc.word = reinterpret_cast<const unsigned long long *>(p.brick_occupancy)[brick_index];
-    } else {
-        oc.word = 0;
-    }
+    uint2 occ = make_uint2(0u, 0u);
+    int occ_layer = -1;
+    const uint2 *occ_words = reinterpret_cast<const uint2 *>(p.brick_occupancy);
+    if constexpr (!LITERAL && B == 4) occ = occ_words[brick_index];
 
     int guard = 3 * B + 8;
     while ((unsigned)w.x < (unsigned)B && (unsigned)w.y < (unsigned)B && (unsigned)w.z < (unsigned)B && w.t_value <= local_t_max) {
         if (guard-- <= 0) break;
         VRT_COUNT(voxel_steps);
-        if (voxel_solid<B>(p, brick_index, w.x, w.y, w.z, oc)) {
+        const int voxel_index = w.x + B * (w.z + B * w.y);
+        bool solid;
+        if constexpr (LITERAL) {
+            const uint32_t byte = p.brick_occupancy[brick_index * (uint32_t)(B * B * B / 8) + (uint32_t)(voxel_index >> 3)];
+            solid = (byte >> (voxel_index & 7)) & 1u;
+        } else if constexpr (B == 4) {
+            solid = bit64(occ, (uint32_t)voxel_index);
+        } else {
+            if (occ_layer != w.y) {
+                occ = occ_words[(size_t)brick_index * 8u + (uint32_t)w.y];
+                occ_layer = w.y;
+            }
+            solid = bit64(occ, (uint32_t)(w.x + 8 * w.z));
+        }
+        if (solid) {
             VRT_COUNT(hits);
-            const int voxel_index = w.x + B * (w.z + B * w.y);
             const uint32_t brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu; // comp:422
             const uint32_t mi = p.material_index[brick_material_index + (uint32_t)voxel_index];
             const vrt_material *m = p.materials + mi;
@@ -203,10 +202,16 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
     return false;
 }
 
-// comp:271-376 in two wave phases.  t_min = 1e-5, t_max = +inf at every call
-// site (comp:218,247).
-template <int B, bool COUNT>
-VRT_DI bool grid_hit(const TraceParams &p, const Ray &r, Hit &hit, Cnt<COUNT> &c) {
+// How the brick-level walk learns whether a grid cell is occupied.
+enum StatusMode : int {
+    kStatusLinear = 0,     // the shader's own words: bit i%32 of word i/32, cached per lane (comp:318-328)
+    kStatusBlocked = 1,    // device-built 4x4x4 block words from global memory, cached per lane
+    kStatusBlockedLds = 2  // same, behind an LDS-resident 1-bit-per-block "non-empty" filter
+};
+
+// comp:271-376.  t_min = 1e-5, t_max = +inf at every call site (comp:218,247).
+template <int B, bool COUNT, int MODE>
+VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray &r, Hit &hit, Cnt<COUNT> &c) {
     const float t_min = 0.00001f;
     const float t_max = __builtin_inff();
     VRT_COUNT(rays);
@@ -218,138 +223,65 @@ VRT_DI bool grid_hit(const TraceParams &p, const Ray &r, Hit &hit, Cnt<COUNT> &c
     const int dx = (int)p.grid.dim_x, dy = (int)p.grid.dim_y, dz = (int)p.grid.dim_z;
 
     float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
-    const f3 hit_point = ray_at(r, global_t_value);
-    const f3 fposition = (hit_point - g_min) / splat3(g_scale);
+    const f3 fposition = (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
     Walk w;
     w.side_dist = initial_side_dist(s.fstep, fposition, s.ray_delta);
-    w.x = f2i_sat(__builtin_floorf(fposition.x + 0.f));
-    w.y = f2i_sat(__builtin_floorf(fposition.y + 0.f));
-    w.z = f2i_sat(__builtin_floorf(fposition.z + 0.f));
+    w.x = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
+    w.y = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
+    w.z = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
     w.t_value = 0;
 
     uint32_t word_index = ~0u; // comp:301
     uint32_t word_bits = 0;
+    uint32_t block_index = ~0u;
+    uint2 block_bits = make_uint2(0u, 0u);
     int axis = 3;
     int guard = dx + dy + dz + 8;
 
-    for (;;) {
-        // phase A: skip empty cells
-        bool found = false;
-        uint32_t grid_index = 0;
-        while ((unsigned)w.x < (unsigned)dx && (unsigned)w.y < (unsigned)dy && (unsigned)w.z < (unsigned)dz && global_t_value <= t_max) {
-            if (guard-- <= 0) break;
-            VRT_COUNT(grid_steps);
-            grid_index = (uint32_t)(w.x + dx * (w.z + dz * w.y)); // comp:318
+    while ((unsigned)w.x < (unsigned)dx && (unsigned)w.y < (unsigned)dy && (unsigned)w.z < (unsigned)dz && global_t_value <= t_max) {
+        if (guard-- <= 0) break;
+        VRT_COUNT(grid_steps);
+        const uint32_t grid_index = (uint32_t)(w.x + dx * (w.z + dz * w.y)); // comp:318
+        bool occupied;
+        if constexpr (MODE == kStatusLinear) {
             const uint32_t wi = grid_index >> 5;
             if (wi != word_index) { // comp:323-326
                 word_bits = p.brick_status[wi];
                 word_index = wi;
                 VRT_COUNT(status_loads);
             }
-            if ((word_bits >> (grid_index & 31u)) & 1u) {
-                found = true;
-                break;
-            }
-            dda_step(w, s.ray_delta, s.sx, s.sy, s.sz, g_scale, axis);
-        }
-        if (!found) return false;
-
-        // phase B: walk the brick
-        const f3 brick_min = fma3(mk3((float)w.x, (float)w.y, (float)w.z), splat3(g_scale), g_min); // comp:331
-        global_t_value = w.t_value + s.grid_t_min + 0.01f * g_scale;                               // comp:332
-        hit.t = global_t_value;
-        const uint32_t brick_index = p.brick_index[grid_index]; // comp:337
-        VRT_COUNT(bricks_entered);
-        if (brick_walk<B, COUNT>(p, r, s, g_scale, brick_index, brick_min, hit, axis, c)) return true;
-        dda_step(w, s.ray_delta, s.sx, s.sy, s.sz, g_scale, axis);
-    }
-}
-
-// ---- literal variant: the shader's own loop nest and byte loads -----------
-template <int B, bool COUNT>
-VRT_DI bool grid_hit_literal(const TraceParams &p, const Ray &r, Hit &hit, Cnt<COUNT> &c) {
-    const float t_min = 0.00001f;
-    const float t_max = __builtin_inff();
-    VRT_COUNT(rays);
-    RaySetup s;
-    if (!grid_slab(p, r, t_min, t_max, s)) return false;
-    const f3 g_min = mk3(p.grid.min_point_base_t[0], p.grid.min_point_base_t[1], p.grid.min_point_base_t[2]);
-    const float g_scale = p.grid.max_point_scale[3];
-    const int dx = (int)p.grid.dim_x, dy = (int)p.grid.dim_y, dz = (int)p.grid.dim_z;
-    float global_t_value = s.grid_t_min + 0.0001f * g_scale;
-    const f3 fposition = (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
-    Walk w;
-    w.side_dist = initial_side_dist(s.fstep, fposition, s.ray_delta);
-    w.x = f2i_sat(__builtin_floorf(fposition.x + 0.f));
-    w.y = f2i_sat(__builtin_floorf(fposition.y + 0.f));
-    w.z = f2i_sat(__builtin_floorf(fposition.z + 0.f));
-    w.t_value = 0;
-    uint32_t word_index = ~0u, word_bits = 0;
-    int axis = 3;
-    int guard = dx + dy + dz + 8;
-    while ((unsigned)w.x < (unsigned)dx && (unsigned)w.y < (unsigned)dy && (unsigned)w.z < (unsigned)dz && global_t_value <= t_max) {
-        if (guard-- <= 0) break;
-        VRT_COUNT(grid_steps);
-        const uint32_t grid_index = (uint32_t)(w.x + dx * (w.z + dz * w.y));
-        const uint32_t wi = grid_index >> 5;
-        if (wi != word_index) {
-            word_bits = p.brick_status[wi];
-            word_index = wi;
-            VRT_COUNT(status_loads);
-        }
-        if ((word_bits >> (grid_index & 31u)) & 1u) {
-            const f3 brick_min = fma3(mk3((float)w.x, (float)w.y, (float)w.z), splat3(g_scale), g_min);
-            global_t_value = w.t_value + s.grid_t_min + 0.01f * g_scale;
-            hit.t = global_t_value;
-            const uint32_t brick_index = p.brick_index[grid_index];
-            VRT_COUNT(bricks_entered);
-            // BrickHit, byte loads as comp:415
-            const float voxel_scale = g_scale * (1.0f / (float)B);
-            const f3 bpos = (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
-            Walk v;
-            v.side_dist = initial_side_dist(s.fstep, bpos, s.ray_delta);
-            v.x = f2i_sat(__builtin_floorf(bpos.x + 0.f));
-            v.y = f2i_sat(__builtin_floorf(bpos.y + 0.f));
-            v.z = f2i_sat(__builtin_floorf(bpos.z + 0.f));
-            v.t_value = 0;
-            const float local_t_max = s.grid_t_max - hit.t;
-            const uint32_t base = brick_index * (uint32_t)(B * B * B / 8);
-            int bguard = 3 * B + 8;
-            while ((unsigned)v.x < (unsigned)B && (unsigned)v.y < (unsigned)B && (unsigned)v.z < (unsigned)B && v.t_value <= local_t_max) {
-                if (bguard-- <= 0) break;
-                VRT_COUNT(voxel_steps);
-                const int voxel_index = v.x + B * (v.z + B * v.y);
-                const uint32_t byte = p.brick_occupancy[base + (uint32_t)(voxel_index >> 3)];
-                if ((byte >> (voxel_index & 7)) & 1u) {
-                    VRT_COUNT(hits);
-                    const uint32_t bmi = p.brick_start_index[brick_index] & 0x7FFFFFFFu;
-                    const uint32_t mi = p.material_index[bmi + (uint32_t)voxel_index];
-                    const vrt_material *m = p.materials + mi;
-                    const bool ignore_brick = (m->type == r.ignore_type_material) && (r.internal_reflection == m->type_data);
-                    if (!ignore_brick) {
-                        hit.index = mi;
-                        const float t_offset = voxel_scale * 0.05f;
-                        hit.t += v.t_value - t_offset;
-                        hit.normal = axis_normal(s, axis);
-                        hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
-                        return true;
-                    }
+            occupied = (word_bits >> (grid_index & 31u)) & 1u;
+        } else {
+            if constexpr (COUNT) { // the algorithmic count follows the reference's word rule
+                const uint32_t wi = grid_index >> 5;
+                if (wi != word_index) {
+                    word_index = wi;
+                    c.status_loads++;
                 }
-                dda_step(v, s.ray_delta, s.sx, s.sy, s.sz, voxel_scale, axis);
             }
+            const uint32_t bi = (uint32_t)(w.x >> 2) + p.nbx * ((uint32_t)(w.z >> 2) + p.nbz * (uint32_t)(w.y >> 2));
+            if (bi != block_index) {
+                block_index = bi;
+                if constexpr (MODE == kStatusBlockedLds) {
+                    const uint32_t fw = lds_filter[bi >> 5];
+                    block_bits = ((fw >> (bi & 31u)) & 1u) ? p.status_blocks[bi] : make_uint2(0u, 0u);
+                } else {
+                    block_bits = p.status_blocks[bi];
+                }
+            }
+            occupied = bit64(block_bits, (uint32_t)((w.x & 3) | ((w.z & 3) << 2) | ((w.y & 3) << 4)));
+        }
+        if (occupied) {
+            const f3 brick_min = fma3(mk3((float)w.x, (float)w.y, (float)w.z), splat3(g_scale), g_min); // comp:331
+            global_t_value = w.t_value + s.grid_t_min + 0.01f * g_scale;                               // comp:332
+            hit.t = global_t_value;
+            const uint32_t brick_index = p.brick_index[grid_index]; // comp:337
+            VRT_COUNT(bricks_entered);
+            if (brick_walk<B, COUNT, MODE == kStatusLinear>(p, r, s, g_scale, brick_index, brick_min, hit, axis, c)) return true;
         }
         dda_step(w, s.ray_delta, s.sx, s.sy, s.sz, g_scale, axis);
     }
     return false;
-}
-
-template <int B, bool COUNT, uint32_t VARIANT>
-VRT_DI bool trace_ray(const TraceParams &p, const Ray &r, Hit &hit, Cnt<COUNT> &c) {
-    if constexpr (VARIANT == kVariantLiteral) {
-        return grid_hit_literal<B, COUNT>(p, r, hit, c);
-    } else {
-        return grid_hit<B, COUNT>(p, r, hit, c);
-    }
 }
 
 // ---- scatter functions (comp:539-596) -------------------------------------
@@ -390,8 +322,8 @@ VRT_DI bool scatter_dielectric(float ir, const Ray &r_in, const Hit &hit, Ray &s
 }
 
 // comp:203-265
-template <int B, bool COUNT, uint32_t VARIANT>
-VRT_DI f3 ray_color(const TraceParams &p, Ray current_ray, Cnt<COUNT> &c) {
+template <int B, bool COUNT, int MODE>
+VRT_DI f3 ray_color(const TraceParams &p, const uint32_t *lds_filter, Ray current_ray, Cnt<COUNT> &c) {
     const bool sun_enabled = p.pc.sun.enabled > 0;
     const f3 sun_color = mk3(p.pc.sun.color[0], p.pc.sun.color[1], p.pc.sun.color[2]);
     const f3 sun_position = mk3(p.pc.sun.position[0], p.pc.sun.position[1], p.pc.sun.position[2]);
@@ -404,7 +336,7 @@ VRT_DI f3 ray_color(const TraceParams &p, Ray current_ray, Cnt<COUNT> &c) {
     int loop_count = 0;
     f3 color = mk3(0, 0, 0);
 
-    while (loop_count < max_bounce && trace_ray<B, COUNT, VARIANT>(p, current_ray, hit, c)) {
+    while (loop_count < max_bounce && grid_hit<B, COUNT, MODE>(p, lds_filter, current_ray, hit, c)) {
         loop_count += 1;
         Ray scattered = current_ray;
         bool result = false;
@@ -426,10 +358,10 @@ VRT_DI f3 ray_color(const TraceParams &p, Ray current_ray, Cnt<COUNT> &c) {
                                           current_ray.direction.y + current_ray.direction.z, -p.pc.sun.radius, p.pc.sun.radius);
             const f3 sun_sample_position = sun_position + rv;
             const f3 shadow_ray_dir = sun_sample_position - hit.point;
-            // CreateShadowRay, comp:186-190: sun_enabled > 0 here, so ignore type is MAT_NONE
+            // CreateShadowRay, comp:186-190: sun_enabled > 0 here, so the ignore type is MAT_NONE
             Ray shadow_ray = create_ray(hit.point, shadow_ray_dir);
             Hit shadow_hit;
-            if (!trace_ray<B, COUNT, VARIANT>(p, shadow_ray, shadow_hit, c)) {
+            if (!grid_hit<B, COUNT, MODE>(p, lds_filter, shadow_ray, shadow_hit, c)) {
                 color = color + attenuation * sun_color;
             }
         } else {
@@ -462,8 +394,16 @@ VRT_DI uint32_t xcd_slice_index(uint32_t b, uint32_t n) {
 }
 
 // comp:153-178
-template <int B, bool COUNT, uint32_t VARIANT>
-__global__ __launch_bounds__(256) void vrt_trace_kernel(const TraceParams p) {
+template <int B, bool COUNT, int MODE, int MIN_WAVES>
+__global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TraceParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_filter[];
+    if constexpr (MODE == kStatusBlockedLds) {
+        // stage the block filter (1 bit per 4x4x4 block of cells) once per workgroup
+        const uint32_t nwords = (p.nbx * p.nby * p.nbz + 31u) >> 5;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.status_blocks + (size_t)p.nbx * p.nby * p.nbz);
+        for (uint32_t i = threadIdx.x; i < nwords; i += 256u) lds_filter[i] = src[i];
+        __syncthreads();
+    }
     const uint32_t owned = xcd_slice_index(blockIdx.x, p.owned_tiles);
     const uint32_t tile = owned * p.shard_count + p.shard_rank;
     const uint32_t tile_x = tile % p.tiles_x, tile_y = tile / p.tiles_x;
@@ -492,7 +432,7 @@ __global__ __launch_bounds__(256) void vrt_trace_kernel(const TraceParams p) {
             const f3 llc = mk3(p.pc.cam.lower_left_corner[0], p.pc.cam.lower_left_corner[1], p.pc.cam.lower_left_corner[2]);
             const f3 origin = mk3(p.pc.cam.origin[0], p.pc.cam.origin[1], p.pc.cam.origin[2]);
             const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
-            color = color + ray_color<B, COUNT, VARIANT>(p, create_ray(origin, ray_dir), c);
+            color = color + ray_color<B, COUNT, MODE>(p, lds_filter, create_ray(origin, ray_dir), c);
         }
         const float fspp = (float)spp;
         color = mk3(__builtin_sqrtf(color.x / fspp), __builtin_sqrtf(color.y / fspp), __builtin_sqrtf(color.z / fspp));
@@ -529,6 +469,40 @@ __global__ __launch_bounds__(256) void vrt_trace_kernel(const TraceParams p) {
     }
 }
 
+// Builds the derived status structures from the uploaded brick_status words (binding 3):
+// out[0 .. nblocks)            one uint2 per 4x4x4 block of cells
+// out[nblocks ..) as u32 words  filter: bit b set iff block b has any occupied cell
+// One thread per block; the filter words are produced by a wave ballot (32 blocks per word).
+__global__ __launch_bounds__(256) void vrt_build_status_blocks(const uint32_t *__restrict__ status, uint2 *__restrict__ out, uint32_t dim_x,
+                                                               uint32_t dim_y, uint32_t dim_z, uint32_t nbx, uint32_t nby, uint32_t nbz) {
+    const uint32_t nblocks = nbx * nby * nbz;
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    uint2 word = make_uint2(0u, 0u);
+    if (b < nblocks) {
+        const uint32_t bx = b % nbx, bz = (b / nbx) % nbz, by = b / (nbx * nbz);
+        for (uint32_t yy = 0; yy < 4u; yy++)
+            for (uint32_t zz = 0; zz < 4u; zz++)
+                for (uint32_t xx = 0; xx < 4u; xx++) {
+                    const uint32_t x = bx * 4u + xx, y = by * 4u + yy, z = bz * 4u + zz;
+                    if (x < dim_x && y < dim_y && z < dim_z) {
+                        const uint32_t gi = x + dim_x * (z + dim_z * y);
+                        const uint32_t bit = (status[gi >> 5] >> (gi & 31u)) & 1u;
+                        const uint32_t pos = xx + 4u * zz + 16u * yy;
+                        if (pos < 32u) word.x |= bit << pos;
+                        else word.y |= bit << (pos - 32u);
+                    }
+                }
+        out[b] = word;
+    }
+    const unsigned long long nonempty = __ballot((word.x | word.y) != 0u);
+    uint32_t *filter = reinterpret_cast<uint32_t *>(out + nblocks);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t base_word = (blockIdx.x * 256u + (threadIdx.x & ~63u)) >> 5; // first filter word of this wave
+    const uint32_t nwords = (nblocks + 31u) >> 5;
+    if (lane == 0 && base_word < nwords) filter[base_word] = (uint32_t)(nonempty & 0xFFFFFFFFull);
+    if (lane == 32 && base_word + 1u < nwords) filter[base_word + 1u] = (uint32_t)(nonempty >> 32);
+}
+
 // Root-side un-swizzle of gathered shards (rank-major, tile-major) into a
 // row-major frame.  One thread per pixel.
 template <typename PIX>
@@ -544,26 +518,64 @@ __global__ __launch_bounds__(256) void vrt_assemble_kernel(const PIX *__restrict
     frame[(size_t)y * width + x] = gathered[src];
 }
 
-// ---- launchers (called from vrt_api.cpp; same translation unit set) --------
+// ---- launchers (called from vrt_api.hip) ------------------------------------
 using KernelFn = void (*)(const TraceParams);
 
-template <int B, bool COUNT>
-static KernelFn pick_variant(uint32_t variant) {
-    switch (variant) {
-        case kVariantLiteral: return vrt_trace_kernel<B, COUNT, kVariantLiteral>;
-        default: return vrt_trace_kernel<B, COUNT, kVariantSplit>;
+constexpr int kDefaultMinWaves = 4; // waves per SIMD the register allocator must leave room for
+
+// kernel_variant = mode | (min_waves << 8); min_waves 0 => kDefaultMinWaves.  The occupancy knob
+// exists for tuning runs (bench.py --variant 0x603 ...).
+template <int B, bool COUNT, int MW>
+static KernelFn pick_mode(uint32_t mode) {
+    switch (mode) {
+        case kVariantLiteral: return vrt_trace_kernel<B, COUNT, kStatusLinear, MW>;
+        case kVariantBlocked: return vrt_trace_kernel<B, COUNT, kStatusBlocked, MW>;
+        case kVariantBlockedLds: return vrt_trace_kernel<B, COUNT, kStatusBlockedLds, MW>;
+        default: return nullptr;
     }
 }
 
+template <int B, bool COUNT>
+static KernelFn pick_variant(uint32_t variant) {
+    const uint32_t mode = variant & 0xFFu, mw = (variant >> 8) & 0xFFu;
+    switch (mw) {
+        case 0:
+        case kDefaultMinWaves: return pick_mode<B, COUNT, kDefaultMinWaves>(mode);
+        case 5: return pick_mode<B, COUNT, 5>(mode);
+        case 6: return pick_mode<B, COUNT, 6>(mode);
+        case 8: return pick_mode<B, COUNT, 8>(mode);
+        default: return nullptr;
+    }
+}
+
+uint32_t resolve_variant(uint32_t variant) {
+    return (variant & 0xFFu) == kVariantDefault ? ((variant & ~0xFFu) | (uint32_t)kVariantBlockedLds) : variant;
+}
+
 KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant) {
+    variant = resolve_variant(variant);
     if (brick_dimension == 4) return counters ? pick_variant<4, true>(variant) : pick_variant<4, false>(variant);
     if (brick_dimension == 8) return counters ? pick_variant<8, true>(variant) : pick_variant<8, false>(variant);
     return nullptr;
 }
 
-hipError_t launch_trace(KernelFn fn, const TraceParams &p, hipStream_t stream) {
+// bytes of dynamic LDS the variant needs for this grid
+size_t trace_lds_bytes(const TraceParams &p, uint32_t variant) {
+    if ((resolve_variant(variant) & 0xFFu) != kVariantBlockedLds) return 0;
+    const size_t nwords = ((size_t)p.nbx * p.nby * p.nbz + 31u) >> 5;
+    return (nwords * 4u + 15u) & ~(size_t)15u;
+}
+
+hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream) {
     if (p.owned_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(fn, dim3(p.owned_tiles), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(fn, dim3(p.owned_tiles), dim3(256), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
+    const uint32_t nblocks = p.nbx * p.nby * p.nbz;
+    hipLaunchKernelGGL(vrt_build_status_blocks, dim3((nblocks + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
+                       const_cast<uint2 *>(p.status_blocks), dim_x, dim_y, dim_z, p.nbx, p.nby, p.nbz);
     return hipGetLastError();
 }
 
