@@ -176,7 +176,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         return fail(nullptr, VRT_E_INVALID_ARG, "tile size must be 16x16 (or 0)");
     const uint32_t shard_count = cfg->shard_count ? cfg->shard_count : 1u;
     if (cfg->shard_rank >= shard_count) return fail(nullptr, VRT_E_INVALID_ARG, "shard_rank >= shard_count");
-    if ((cfg->kernel_variant & 0xFFu) >= vrt::kVariantCount || (cfg->kernel_variant >> 16)) return fail(nullptr, VRT_E_INVALID_ARG, "unknown kernel_variant");
+    if ((cfg->kernel_variant & 0xFFu) >= vrt::kVariantCount || (cfg->kernel_variant >> 20)) return fail(nullptr, VRT_E_INVALID_ARG, "unknown kernel_variant");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -305,6 +305,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.owned_tiles = sh.owned_tiles;
     p.status_words = (uint32_t)((cells + 31u) / 32u);
     p.status_blocks = static_cast<const uint2 *>(c->d_status_blocks);
+    p.tile_order = (cfg->kernel_variant >> 16) & 0xFu;
     p.nbx = nbx;
     p.nby = nby;
     p.nbz = nbz;

@@ -47,6 +47,7 @@ struct TraceParams {
     uint32_t nbx, nby, nbz;
     uint32_t *tile_counters;             // persistent-workgroup work queue: 2 sets x 8 XCD slices
     uint32_t frame_parity;               // which counter set this launch consumes
+    uint32_t tile_order;                 // workgroup -> tile mapping (tuning): 0 row bands per XCD, 1 round-robin, 2 column bands
 };
 
 constexpr int kTileW = 16;

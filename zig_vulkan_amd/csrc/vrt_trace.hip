@@ -404,7 +404,17 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TracePa
         for (uint32_t i = threadIdx.x; i < nwords; i += 256u) lds_filter[i] = src[i];
         __syncthreads();
     }
-    const uint32_t owned = xcd_slice_index(blockIdx.x, p.owned_tiles);
+    uint32_t owned;
+    if (p.tile_order == 1u) {
+        owned = blockIdx.x; // round-robin over XCDs
+    } else if (p.tile_order == 2u) {
+        // XCD k gets a band of tile columns: slice index runs column-major over the tile grid
+        const uint32_t cm = xcd_slice_index(blockIdx.x, p.owned_tiles);
+        const uint32_t col = cm / p.tiles_y, row = cm % p.tiles_y;
+        owned = row * p.tiles_x + col;
+    } else {
+        owned = xcd_slice_index(blockIdx.x, p.owned_tiles);
+    }
     const uint32_t tile = owned * p.shard_count + p.shard_rank;
     const uint32_t tile_x = tile % p.tiles_x, tile_y = tile / p.tiles_x;
     // lane -> pixel: wave w of the block covers the 8x8 quadrant (w&1, w>>1)
