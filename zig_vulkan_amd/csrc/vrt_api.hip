@@ -17,7 +17,7 @@
 
 namespace vrt {
 using KernelFn = void (*)(const TraceParams);
-KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant);
+KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, bool single_bounce);
 uint32_t resolve_variant(uint32_t variant);
 size_t trace_lds_bytes(const TraceParams &p, uint32_t variant);
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream);
@@ -58,7 +58,8 @@ struct vrt_ctx {
     bool staging_busy[kStagingSlots] = {};
     int staging_next = 0;
     vrt::TraceParams params{};
-    vrt::KernelFn kernel = nullptr;
+    vrt::KernelFn kernel = nullptr;        // general bounce loop
+    vrt::KernelFn kernel_single = nullptr; // specialisation for max_bounce <= 1
     vrt_shard_info shard{};
     std::string err;
     std::string kernel_name;
@@ -176,7 +177,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         return fail(nullptr, VRT_E_INVALID_ARG, "tile size must be 16x16 (or 0)");
     const uint32_t shard_count = cfg->shard_count ? cfg->shard_count : 1u;
     if (cfg->shard_rank >= shard_count) return fail(nullptr, VRT_E_INVALID_ARG, "shard_rank >= shard_count");
-    if ((cfg->kernel_variant & 0xFFu) >= vrt::kVariantCount || (cfg->kernel_variant >> 20)) return fail(nullptr, VRT_E_INVALID_ARG, "unknown kernel_variant");
+    if ((cfg->kernel_variant & 0xFFu) >= vrt::kVariantCount || (cfg->kernel_variant >> 24)) return fail(nullptr, VRT_E_INVALID_ARG, "unknown kernel_variant");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -271,14 +272,15 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         VRT_CREATE_HIP(hipEventCreateWithFlags(&c->staging_ev[i], hipEventDisableTiming));
     }
 
-    c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant);
-    if (!c->kernel) {
+    c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant, false);
+    c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant, true);
+    if (!c->kernel || !c->kernel_single) {
         free_ctx(c);
         return fail(nullptr, VRT_E_INVALID_ARG, "no kernel for this configuration");
     }
     {
         char buf[96];
-        static const char *const mode_names[] = {"?", "linear-status(literal)", "blocked-status", "blocked-status+lds-filter"};
+        static const char *const mode_names[] = {"?", "linear-status+byte-occupancy", "blocked-status", "blocked-status+lds-filter", "linear-status+wide-occupancy"};
         const uint32_t rv = vrt::resolve_variant(cfg->kernel_variant);
         std::snprintf(buf, sizeof buf, "vrt_trace_kernel<B=%u,COUNT=%d,%s,minwaves=%u>", cfg->brick_dimension, cfg->enable_counters ? 1 : 0,
                       mode_names[rv & 0xFFu], (rv >> 8) ? (rv >> 8) : 4u);
@@ -306,6 +308,15 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.status_words = (uint32_t)((cells + 31u) / 32u);
     p.status_blocks = static_cast<const uint2 *>(c->d_status_blocks);
     p.tile_order = (cfg->kernel_variant >> 16) & 0xFu;
+    p.wave_groups = (cfg->kernel_variant >> 20) & 0x1u;
+    {
+        // a stride near owned_tiles * 0.618 that is coprime to owned_tiles
+        auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+        uint32_t st = (uint32_t)((double)sh.owned_tiles * 0.6180339887) | 1u;
+        while (sh.owned_tiles > 1u && gcd(st, sh.owned_tiles) != 1u) st += 2u;
+        p.tile_stride = sh.owned_tiles > 1u ? st % sh.owned_tiles : 0u;
+        if (sh.owned_tiles > 1u && p.tile_stride == 0u) p.tile_stride = 1u;
+    }
     p.nbx = nbx;
     p.nby = nby;
     p.nbz = nbz;
@@ -313,7 +324,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (c->lds_bytes > 64u * 1024u) {
         // the block filter of a very large grid does not fit the LDS budget: read block words directly
         c->cfg.kernel_variant = (cfg->kernel_variant & ~0xFFu) | vrt::kVariantBlocked;
-        c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant);
+        c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, false);
+        c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, true);
         c->lds_bytes = 0;
         c->kernel_name += "[filter>64KiB: blocked-status]";
     }
@@ -386,7 +398,9 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         ctx->status_dirty = false;
     }
     VRT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-    for (uint32_t f = 0; f < frames; f++) VRT_HIP(ctx, vrt::launch_trace(ctx->kernel, ctx->params, ctx->lds_bytes, ctx->stream));
+    // max_bounce <= 1 ("only primary ray" + its shadow ray): the bounce loop runs at most once
+    const vrt::KernelFn fn = (camera->max_bounce <= 1) ? ctx->kernel_single : ctx->kernel;
+    for (uint32_t f = 0; f < frames; f++) VRT_HIP(ctx, vrt::launch_trace(fn, ctx->params, ctx->lds_bytes, ctx->stream));
     VRT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->timed_frames = frames;
     ctx->in_flight = true;

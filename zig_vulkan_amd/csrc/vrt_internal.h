@@ -47,7 +47,9 @@ struct TraceParams {
     uint32_t nbx, nby, nbz;
     uint32_t *tile_counters;             // persistent-workgroup work queue: 2 sets x 8 XCD slices
     uint32_t frame_parity;               // which counter set this launch consumes
-    uint32_t tile_order;                 // workgroup -> tile mapping (tuning): 0 row bands per XCD, 1 round-robin, 2 column bands
+    uint32_t tile_stride;                // tile_order 4: multiplier coprime to owned_tiles
+    uint32_t wave_groups;                // 1: launch one 64-thread workgroup per 8x8 block instead of 256 per 16x16 tile
+    uint32_t tile_order;                 // workgroup -> tile mapping: 0 round-robin over XCDs (default), 1 row bands per XCD, 2 column bands
 };
 
 constexpr int kTileW = 16;
@@ -58,7 +60,8 @@ enum : uint32_t {
     kVariantDefault = 0,    // best known (see vrt_trace.hip select_trace_kernel)
     kVariantLiteral = 1,    // the shader's memory behaviour: linear status words, byte occupancy loads
     kVariantBlocked = 2,    // blocked 4^3 status words + 64-bit occupancy words, read from global memory
-    kVariantBlockedLds = 3, // same, status blocks staged in LDS by persistent workgroups
+    kVariantBlockedLds = 3, // same, behind an LDS-resident block filter
+    kVariantLinearWide = 4, // linear status words (as the shader) + 64-bit occupancy words
     kVariantCount
 };
 

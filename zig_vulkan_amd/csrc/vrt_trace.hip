@@ -88,6 +88,32 @@ VRT_DI void dda_step(Walk &w, const f3 &ray_delta, int sx, int sy, int sz, float
     axis = ax ? 0 : (ay ? 1 : 2);
 }
 
+// Same step for the brick-level walk, also advancing the linear cell index
+// x + dim_x*(z + dim_z*y) (comp:318) by the stride of the crossed axis instead of recomputing it
+// with two 32-bit multiplies (v_mad_u64_u32 on gfx950, quarter rate).  Exact in modular u32 arithmetic.
+VRT_DI void dda_step_cell(Walk &w, const f3 &ray_delta, int sx, int sy, int sz, float scale, int &axis, uint32_t &cell, uint32_t stride_x,
+                          uint32_t stride_y, uint32_t stride_z) {
+    const bool x_lt_y = w.side_dist.x < w.side_dist.y;
+    const bool x_lt_z = w.side_dist.x < w.side_dist.z;
+    const bool y_lt_z = w.side_dist.y < w.side_dist.z;
+    const bool ax = x_lt_y && x_lt_z;
+    const bool ay = !x_lt_y && y_lt_z;
+    const bool az = !(ax || ay);
+    const float sd = ax ? w.side_dist.x : (ay ? w.side_dist.y : w.side_dist.z);
+    w.t_value = sd * scale;
+    const float nx = w.side_dist.x + ray_delta.x;
+    const float ny = w.side_dist.y + ray_delta.y;
+    const float nz = w.side_dist.z + ray_delta.z;
+    w.side_dist.x = ax ? nx : w.side_dist.x;
+    w.side_dist.y = ay ? ny : w.side_dist.y;
+    w.side_dist.z = az ? nz : w.side_dist.z;
+    w.x += ax ? sx : 0;
+    w.y += ay ? sy : 0;
+    w.z += az ? sz : 0;
+    cell += ax ? stride_x : (ay ? stride_y : stride_z);
+    axis = ax ? 0 : (ay ? 1 : 2);
+}
+
 // comp:298 / comp:395
 VRT_DI f3 initial_side_dist(f3 fstep, f3 fposition, f3 ray_delta) {
     const f3 intersection_delta = floor3(fposition) - fposition;
@@ -162,9 +188,12 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
     const uint2 *occ_words = reinterpret_cast<const uint2 *>(p.brick_occupancy);
     if constexpr (!LITERAL && B == 4) occ = occ_words[brick_index];
 
+    // Single-exit loop (one back-edge condition, no return inside): the structurizer then needs one
+    // exec update per iteration instead of a chain of exit-flag merges on the scalar unit.
     int guard = 3 * B + 8;
-    while ((unsigned)w.x < (unsigned)B && (unsigned)w.y < (unsigned)B && (unsigned)w.z < (unsigned)B && w.t_value <= local_t_max) {
-        if (guard-- <= 0) break;
+    bool found = false;
+    bool more = (unsigned)w.x < (unsigned)B && (unsigned)w.y < (unsigned)B && (unsigned)w.z < (unsigned)B && w.t_value <= local_t_max;
+    while (more) {
         VRT_COUNT(voxel_steps);
         const int voxel_index = w.x + B * (w.z + B * w.y);
         bool solid;
@@ -194,19 +223,24 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
                 hit.t += w.t_value - t_offset;
                 hit.normal = axis_normal(s, axis);
                 hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
-                return true;
+                found = true;
             }
         }
+        // (after a hit this step is dead work, once per ray; its results are never read)
         dda_step(w, s.ray_delta, s.sx, s.sy, s.sz, voxel_scale, axis);
+        guard--;
+        more = !found && guard > 0 && (unsigned)w.x < (unsigned)B && (unsigned)w.y < (unsigned)B && (unsigned)w.z < (unsigned)B &&
+               w.t_value <= local_t_max;
     }
-    return false;
+    return found;
 }
 
 // How the brick-level walk learns whether a grid cell is occupied.
 enum StatusMode : int {
     kStatusLinear = 0,     // the shader's own words: bit i%32 of word i/32, cached per lane (comp:318-328)
     kStatusBlocked = 1,    // device-built 4x4x4 block words from global memory, cached per lane
-    kStatusBlockedLds = 2  // same, behind an LDS-resident 1-bit-per-block "non-empty" filter
+    kStatusBlockedLds = 2, // same, behind an LDS-resident 1-bit-per-block "non-empty" filter
+    kStatusLinearWide = 3  // linear words for status, 64-bit words for occupancy
 };
 
 // comp:271-376.  t_min = 1e-5, t_max = +inf at every call site (comp:218,247).
@@ -238,12 +272,19 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     int axis = 3;
     int guard = dx + dy + dz + 8;
 
-    while ((unsigned)w.x < (unsigned)dx && (unsigned)w.y < (unsigned)dy && (unsigned)w.z < (unsigned)dz && global_t_value <= t_max) {
-        if (guard-- <= 0) break;
+    // `global_t_value <= t_max` (comp:316) with t_max = +inf only fails for a NaN t, and t only
+    // changes when a brick is entered: test it there instead of on every step.
+    if (!(global_t_value <= t_max)) return false;
+    // comp:318, kept current by dda_step_cell; meaningless (and unused) while the position is outside
+    uint32_t grid_index = (uint32_t)w.x + (uint32_t)dx * ((uint32_t)w.z + (uint32_t)dz * (uint32_t)w.y);
+    const uint32_t stride_x = (uint32_t)s.sx, stride_y = (uint32_t)s.sy * (uint32_t)dx * (uint32_t)dz, stride_z = (uint32_t)s.sz * (uint32_t)dx;
+
+    bool found = false;
+    bool more = (unsigned)w.x < (unsigned)dx && (unsigned)w.y < (unsigned)dy && (unsigned)w.z < (unsigned)dz;
+    while (more) { // single-exit loop, see brick_walk
         VRT_COUNT(grid_steps);
-        const uint32_t grid_index = (uint32_t)(w.x + dx * (w.z + dz * w.y)); // comp:318
         bool occupied;
-        if constexpr (MODE == kStatusLinear) {
+        if constexpr (MODE == kStatusLinear || MODE == kStatusLinearWide) {
             const uint32_t wi = grid_index >> 5;
             if (wi != word_index) { // comp:323-326
                 word_bits = p.brick_status[wi];
@@ -271,17 +312,21 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
             }
             occupied = bit64(block_bits, (uint32_t)((w.x & 3) | ((w.z & 3) << 2) | ((w.y & 3) << 4)));
         }
+        bool t_is_nan = false;
         if (occupied) {
             const f3 brick_min = fma3(mk3((float)w.x, (float)w.y, (float)w.z), splat3(g_scale), g_min); // comp:331
             global_t_value = w.t_value + s.grid_t_min + 0.01f * g_scale;                               // comp:332
             hit.t = global_t_value;
             const uint32_t brick_index = p.brick_index[grid_index]; // comp:337
             VRT_COUNT(bricks_entered);
-            if (brick_walk<B, COUNT, MODE == kStatusLinear>(p, r, s, g_scale, brick_index, brick_min, hit, axis, c)) return true;
+            found = brick_walk<B, COUNT, MODE == kStatusLinear>(p, r, s, g_scale, brick_index, brick_min, hit, axis, c);
+            t_is_nan = !(global_t_value <= t_max);
         }
-        dda_step(w, s.ray_delta, s.sx, s.sy, s.sz, g_scale, axis);
+        dda_step_cell(w, s.ray_delta, s.sx, s.sy, s.sz, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
+        guard--;
+        more = !found && !t_is_nan && guard > 0 && (unsigned)w.x < (unsigned)dx && (unsigned)w.y < (unsigned)dy && (unsigned)w.z < (unsigned)dz;
     }
-    return false;
+    return found;
 }
 
 // ---- scatter functions (comp:539-596) -------------------------------------
@@ -319,6 +364,40 @@ VRT_DI bool scatter_dielectric(float ir, const Ray &r_in, const Hit &hit, Ray &s
         scattered = create_ray(hit.point, direction);
     }
     return true;
+}
+
+// comp:203-265 when push_constant.max_bounce <= 1 (Camera.Config.max_bounce = 0: "only primary
+// ray", Camera.zig:74).  The bounce loop then runs at most once, so the scatter functions — whose only
+// products are the next ray and the continue flag — have no observable effect and are not evaluated.
+template <int B, bool COUNT, int MODE>
+VRT_DI f3 ray_color_single(const TraceParams &p, const uint32_t *lds_filter, const Ray &ray, Cnt<COUNT> &c) {
+    const bool sun_enabled = p.pc.sun.enabled > 0;
+    const f3 sun_color = mk3(p.pc.sun.color[0], p.pc.sun.color[1], p.pc.sun.color[2]);
+    f3 color = mk3(0, 0, 0);
+    int loop_count = 0;
+    Hit hit;
+    if (p.pc.cam.max_bounce > 0 && grid_hit<B, COUNT, MODE>(p, lds_filter, ray, hit, c)) {
+        const vrt_material *m = p.materials + hit.index;
+        const uint32_t mtype = m->type;
+        const f3 attenuation = mk3(m->albedo_r, m->albedo_g, m->albedo_b);
+        loop_count = (mtype <= MAT_DIELECTRIC) ? 1 : 0; // unknown type: loop_count -= 1 (comp:235-238)
+        if (sun_enabled) {
+            const f3 sun_position = mk3(p.pc.sun.position[0], p.pc.sun.position[1], p.pc.sun.position[2]);
+            const f3 rv = rand_vec3_range(ray.direction.x + ray.direction.z, ray.direction.y + ray.direction.z, -p.pc.sun.radius,
+                                          p.pc.sun.radius);
+            const Ray shadow_ray = create_ray(hit.point, (sun_position + rv) - hit.point);
+            Hit shadow_hit;
+            if (!grid_hit<B, COUNT, MODE>(p, lds_filter, shadow_ray, shadow_hit, c)) color = color + attenuation * sun_color;
+        } else {
+            color = color + attenuation;
+        }
+    }
+    if (loop_count == 0) {
+        const float t = 0.5f * (ray.direction.y + 1.0f);
+        const f3 bg = fma3(splat3(1.0f - t), splat3(1.0f), mk3(0.5f, 0.7f, 1.0f) * t);
+        color = color + bg * (sun_enabled ? sun_color : splat3(1.0f));
+    }
+    return color / (color + splat3(1.0f));
 }
 
 // comp:203-265
@@ -394,31 +473,43 @@ VRT_DI uint32_t xcd_slice_index(uint32_t b, uint32_t n) {
 }
 
 // comp:153-178
-template <int B, bool COUNT, int MODE, int MIN_WAVES>
+template <int B, bool COUNT, int MODE, int MIN_WAVES, bool SINGLE>
 __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TraceParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_filter[];
     if constexpr (MODE == kStatusBlockedLds) {
         // stage the block filter (1 bit per 4x4x4 block of cells) once per workgroup
         const uint32_t nwords = (p.nbx * p.nby * p.nbz + 31u) >> 5;
         const uint32_t *src = reinterpret_cast<const uint32_t *>(p.status_blocks + (size_t)p.nbx * p.nby * p.nbz);
-        for (uint32_t i = threadIdx.x; i < nwords; i += 256u) lds_filter[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) lds_filter[i] = src[i];
         __syncthreads();
     }
+    // One wave = one 8x8 pixel block.  wave_groups: the workgroup IS one wave (64 threads), so the
+    // hardware dispatcher hands 8x8 blocks to whichever SIMD frees a slot (dynamic load balance at
+    // wave granularity); otherwise a 256-thread workgroup covers one 16x16 tile with four waves.
+    const uint32_t unit = p.wave_groups ? (blockIdx.x >> 2) : blockIdx.x;
+    const uint32_t wave = p.wave_groups ? (blockIdx.x & 3u) : (threadIdx.x >> 6);
     uint32_t owned;
-    if (p.tile_order == 1u) {
-        owned = blockIdx.x; // round-robin over XCDs
+    if (p.tile_order == 0u) {
+        // consecutive tiles go to consecutive XCDs: every XCD samples the whole image, which balances
+        // sky against terrain (contiguous bands per XCD measured 22-28 % slower on the headline frame)
+        owned = unit;
+    } else if (p.tile_order == 3u) {
+        owned = p.owned_tiles - 1u - unit; // reverse raster: bottom of the image first
+    } else if (p.tile_order == 4u) {
+        // strided permutation: consecutive launches sample the whole image (stride coprime to the count)
+        owned = (uint32_t)(((unsigned long long)unit * p.tile_stride) % p.owned_tiles);
     } else if (p.tile_order == 2u) {
         // XCD k gets a band of tile columns: slice index runs column-major over the tile grid
-        const uint32_t cm = xcd_slice_index(blockIdx.x, p.owned_tiles);
+        const uint32_t cm = xcd_slice_index(unit, p.owned_tiles);
         const uint32_t col = cm / p.tiles_y, row = cm % p.tiles_y;
         owned = row * p.tiles_x + col;
     } else {
-        owned = xcd_slice_index(blockIdx.x, p.owned_tiles);
+        owned = xcd_slice_index(unit, p.owned_tiles);
     }
     const uint32_t tile = owned * p.shard_count + p.shard_rank;
     const uint32_t tile_x = tile % p.tiles_x, tile_y = tile / p.tiles_x;
-    // lane -> pixel: wave w of the block covers the 8x8 quadrant (w&1, w>>1)
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // lane -> pixel: wave w of the tile covers the 8x8 quadrant (w&1, w>>1)
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t in_x = (wave & 1u) * 8u + (lane & 7u);
     const uint32_t in_y = (wave >> 1) * 8u + (lane >> 3);
     const uint32_t px = tile_x * kTileW + in_x;
@@ -442,7 +533,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TracePa
             const f3 llc = mk3(p.pc.cam.lower_left_corner[0], p.pc.cam.lower_left_corner[1], p.pc.cam.lower_left_corner[2]);
             const f3 origin = mk3(p.pc.cam.origin[0], p.pc.cam.origin[1], p.pc.cam.origin[2]);
             const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
-            color = color + ray_color<B, COUNT, MODE>(p, lds_filter, create_ray(origin, ray_dir), c);
+            if constexpr (SINGLE) color = color + ray_color_single<B, COUNT, MODE>(p, lds_filter, create_ray(origin, ray_dir), c);
+            else color = color + ray_color<B, COUNT, MODE>(p, lds_filter, create_ray(origin, ray_dir), c);
         }
         const float fspp = (float)spp;
         color = mk3(__builtin_sqrtf(color.x / fspp), __builtin_sqrtf(color.y / fspp), __builtin_sqrtf(color.z / fspp));
@@ -535,37 +627,43 @@ constexpr int kDefaultMinWaves = 4; // waves per SIMD the register allocator mus
 
 // kernel_variant = mode | (min_waves << 8); min_waves 0 => kDefaultMinWaves.  The occupancy knob
 // exists for tuning runs (bench.py --variant 0x603 ...).
-template <int B, bool COUNT, int MW>
+template <int B, bool COUNT, int MW, bool SINGLE>
 static KernelFn pick_mode(uint32_t mode) {
     switch (mode) {
-        case kVariantLiteral: return vrt_trace_kernel<B, COUNT, kStatusLinear, MW>;
-        case kVariantBlocked: return vrt_trace_kernel<B, COUNT, kStatusBlocked, MW>;
-        case kVariantBlockedLds: return vrt_trace_kernel<B, COUNT, kStatusBlockedLds, MW>;
+        case kVariantLiteral: return vrt_trace_kernel<B, COUNT, kStatusLinear, MW, SINGLE>;
+        case kVariantBlocked: return vrt_trace_kernel<B, COUNT, kStatusBlocked, MW, SINGLE>;
+        case kVariantBlockedLds: return vrt_trace_kernel<B, COUNT, kStatusBlockedLds, MW, SINGLE>;
+        case kVariantLinearWide: return vrt_trace_kernel<B, COUNT, kStatusLinearWide, MW, SINGLE>;
         default: return nullptr;
     }
 }
 
-template <int B, bool COUNT>
+template <int B, bool COUNT, bool SINGLE>
 static KernelFn pick_variant(uint32_t variant) {
     const uint32_t mode = variant & 0xFFu, mw = (variant >> 8) & 0xFFu;
     switch (mw) {
         case 0:
-        case kDefaultMinWaves: return pick_mode<B, COUNT, kDefaultMinWaves>(mode);
-        case 5: return pick_mode<B, COUNT, 5>(mode);
-        case 6: return pick_mode<B, COUNT, 6>(mode);
-        case 8: return pick_mode<B, COUNT, 8>(mode);
+        case kDefaultMinWaves: return pick_mode<B, COUNT, kDefaultMinWaves, SINGLE>(mode);
+        case 5: return pick_mode<B, COUNT, 5, SINGLE>(mode);
+        case 6: return pick_mode<B, COUNT, 6, SINGLE>(mode);
+        case 8: return pick_mode<B, COUNT, 8, SINGLE>(mode);
         default: return nullptr;
     }
 }
 
 uint32_t resolve_variant(uint32_t variant) {
-    return (variant & 0xFFu) == kVariantDefault ? ((variant & ~0xFFu) | (uint32_t)kVariantBlockedLds) : variant;
+    return (variant & 0xFFu) == kVariantDefault ? ((variant & ~0xFFu) | (uint32_t)kVariantLiteral) : variant;
 }
 
-KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant) {
+// single_bounce: the specialisation for push_constant.max_bounce <= 1 (no scatter evaluation)
+KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, bool single_bounce) {
     variant = resolve_variant(variant);
-    if (brick_dimension == 4) return counters ? pick_variant<4, true>(variant) : pick_variant<4, false>(variant);
-    if (brick_dimension == 8) return counters ? pick_variant<8, true>(variant) : pick_variant<8, false>(variant);
+#define VRT_PICK(BD)                                                                                                          \
+    (counters ? (single_bounce ? pick_variant<BD, true, true>(variant) : pick_variant<BD, true, false>(variant))               \
+              : (single_bounce ? pick_variant<BD, false, true>(variant) : pick_variant<BD, false, false>(variant)))
+    if (brick_dimension == 4) return VRT_PICK(4);
+    if (brick_dimension == 8) return VRT_PICK(8);
+#undef VRT_PICK
     return nullptr;
 }
 
@@ -578,7 +676,8 @@ size_t trace_lds_bytes(const TraceParams &p, uint32_t variant) {
 
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream) {
     if (p.owned_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(fn, dim3(p.owned_tiles), dim3(256), lds_bytes, stream, p);
+    if (p.wave_groups) hipLaunchKernelGGL(fn, dim3(p.owned_tiles * 4u), dim3(64), lds_bytes, stream, p);
+    else hipLaunchKernelGGL(fn, dim3(p.owned_tiles), dim3(256), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
