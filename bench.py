@@ -26,40 +26,55 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VIEW_ORDER = ["V0", "V1", "V2"]
 
 
-def cpu_baseline(w, grid, view: str, budget_rows: int):
-    """Oracle (CPU restatement of the reference shader) on the host cores, bounded sample: every
-    k-th 4-row band of one frame.  kind = "port" (the reference itself cannot be built here)."""
+def cpu_baseline(w, grid, min_wall_s: float):
+    """Oracle (CPU restatement of the reference shader, oracle/vrt_oracle.c) on the host cores of this
+    box.  Bounded sample: whole frames of the workload, views cycled V0,V1,V2, until `min_wall_s` of
+    wall time has passed (at least one frame per view); rows are handed to the threads one at a time.
+    kind = "port": the reference itself cannot be built here (no zig / GLSL compiler / Vulkan ICD)."""
+    import ctypes as C
+    import threading
+
+    import numpy as np
     from oracle import oracle as O
     from tests.helpers import oracle_scene_from_grid
     from zig_vulkan_amd import workloads as W
     cores = os.cpu_count() or 1
     scene = oracle_scene_from_grid(grid)
-    cam, sun = W.camera_for(w, view), W.sun_for(w)
-    pc = O.push_constants(cam.blob(), sun.blob())
-    # sample: rows [y, y+4) for y in range(0, H, stride) -> about budget_rows rows, spread over the frame
-    stride = max(4, (w.height // max(budget_rows, 4)) * 4)
-    import ctypes as C
-    import numpy as np
-    from concurrent.futures import ThreadPoolExecutor
     L = O.lib()
-    bands = [(y, min(y + 4, w.height)) for y in range(0, w.height, stride)]
+    pcs = [O.push_constants(W.camera_for(w, v).blob(), W.sun_for(w).blob()) for v in VIEW_ORDER]
     f32 = np.zeros((w.height, w.width, 4), dtype=np.float32)
-    groups = [bands[i::cores] for i in range(cores)]
-
-    def work(group):
-        c = O.Counters()
-        for a, b in group:
-            L.oracle_render_rows(C.byref(scene.c), pc.ctypes.data, a, b, f32.ctypes.data, None, C.byref(c))
-        return c.rays
-
+    lock = threading.Lock()
+    state = {"next": 0, "frames": 0, "stop": False}
+    rays_total = [0] * cores
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        rays = sum(ex.map(work, groups))
+
+    def worker(tid: int) -> None:
+        c = O.Counters()
+        while True:
+            with lock:
+                if state["stop"]:
+                    break
+                i = state["next"]
+                state["next"] += 1
+                frame, row = divmod(i, w.height)
+                if row == 0 and frame >= len(VIEW_ORDER) and time.perf_counter() - t0 >= min_wall_s:
+                    state["stop"] = True
+                    state["frames"] = frame
+                    break
+            pc = pcs[frame % len(VIEW_ORDER)]
+            L.oracle_render_rows(C.byref(scene.c), pc.ctypes.data, row, row + 1, f32.ctypes.data, None, C.byref(c))
+        rays_total[tid] = c.rays
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(cores)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
     dt = time.perf_counter() - t0
-    rows = sum(b - a for a, b in bands)
+    rays = sum(rays_total)
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{rows} of {w.height} rows (every {stride}th 4-row band) of view {view}, {rays} rays in {dt:.2f} s; "
-                      f"oracle/vrt_oracle.c -O2, {cores} threads"}
+            "sample": f"{state['frames']} whole frames of {w.name} (views {'/'.join(VIEW_ORDER)} cycled), {rays} rays in {dt:.2f} s wall "
+                      f"= {dt * cores:.0f} core-seconds; oracle/vrt_oracle.c gcc -O2, {cores} threads, rows handed out one at a time"}
 
 
 def main() -> None:
@@ -70,7 +85,7 @@ def main() -> None:
     ap.add_argument("--workload", default=None)
     ap.add_argument("--variant", type=lambda x: int(x, 0), default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=540)
+    ap.add_argument("--cpu-seconds", type=float, default=2.0, help="minimum wall time of the CPU baseline sample")
     ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")
     args = ap.parse_args()
 
@@ -200,7 +215,7 @@ def main() -> None:
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, grid, "V2", args.cpu_rows)
+            out["cpu_baseline"] = cpu_baseline(w, grid, args.cpu_seconds)
         print(json.dumps(out))
     rt.deinit()
     if dist is not None:

@@ -31,8 +31,8 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
             agg[k][c] += v
             disp[k].add(did)
         print(f"\n## PMC pass [{os.path.relpath(f, out)}]")
-        for k, cs in agg.items():
+        for k, cs in sorted(agg.items()):
             n = max(1, len(disp[k]))
-            print(f"kernel {k[:80]}  dispatches={n}")
+            print(f"kernel {k}  dispatches={n}")
             for c, v in sorted(cs.items()):
                 print(f"   {c:34s} per_dispatch={v / n:.6g}")
