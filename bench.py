@@ -4,7 +4,8 @@
   python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
 A step is one full frame of the workload (all pixels, every ray the shader
-casts for them) at one of the three fixed camera views, cycled V0,V1,V2.  The
+casts for them) at one of the three fixed camera views: the first third of the
+steps renders V0, the second third V1, the last third V2.  The
 scene is resident in HBM before the timed region.  For N>1 the driver launches
 one process per GPU (torch.distributed, backend nccl = RCCL): the frame is
 sharded by interleaved 16x16 tiles and gathered to rank 0 once per frame.
@@ -149,8 +150,13 @@ def main() -> None:
     import ctypes as C
     from zig_vulkan_amd import _lib as L
 
-    def step(i: int) -> None:
-        v = VIEW_ORDER[i % len(VIEW_ORDER)]
+    def view_of(i: int, n: int) -> str:
+        # frames of one view are consecutive (a camera moves smoothly; the tile schedule feeds on the
+        # previous frame): first third V0, second third V1, last third V2
+        return VIEW_ORDER[min(len(VIEW_ORDER) - 1, (i * len(VIEW_ORDER)) // max(n, 1))]
+
+    def step(i: int, n: int) -> None:
+        v = view_of(i, n)
         C.memmove(C.byref(rt.camera.d_camera), cams[v], 96)
         rt.draw()
         if sharded:
@@ -163,11 +169,11 @@ def main() -> None:
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(i)
+        step(i, args.warmup)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, args.steps)
     rt.wait()
     barrier()
     dt = time.perf_counter() - t0
@@ -183,6 +189,7 @@ def main() -> None:
         reps = max(5, args.steps // len(VIEW_ORDER))
         for v in VIEW_ORDER:
             C.memmove(C.byref(rt.camera.d_camera), cams[v], 96)
+            rt.draw()  # one frame of this view first: the tile schedule is built from the previous frame
             rt.draw(frames=reps)
             kernel_ms_view[v] = rt.last_kernel_ms()
         avg_ms = sum(kernel_ms_view.values()) / len(kernel_ms_view)
@@ -193,7 +200,7 @@ def main() -> None:
                     "kernel_ms_per_view": kernel_ms_view, "algorithmic_bytes_per_launch": avg_bytes}
 
     if rank == 0:
-        total_rays = sum(per_view[VIEW_ORDER[i % len(VIEW_ORDER)]]["rays"] for i in range(args.steps))
+        total_rays = sum(per_view[view_of(i, args.steps)]["rays"] for i in range(args.steps))
         out = {
             "metric": "Mrays/s at 1920x1080 on 512^3 brickmap; achieved % of HBM roofline",
             "value": total_rays / dt / 1e6,

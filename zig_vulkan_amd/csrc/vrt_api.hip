@@ -8,6 +8,7 @@
 // a HIP device vrt_create fails with VRT_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -21,6 +22,7 @@ KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t varian
 uint32_t resolve_variant(uint32_t variant);
 size_t trace_lds_bytes(const TraceParams &p, uint32_t variant);
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_schedule(uint32_t *cost, uint32_t *order, uint32_t n, hipStream_t stream);
 hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per_pixel, uint32_t width, uint32_t height, uint32_t tiles_x,
                            uint32_t shard_count, uint32_t tiles_per_rank, hipStream_t stream);
@@ -45,6 +47,7 @@ struct vrt_ctx {
     bool own_t8 = false, own_t32 = false;
     uint64_t target_pixels = 0; // pixels in the (possibly sharded, padded) target
     vrt::DeviceCounters *d_counters = nullptr;
+    uint32_t *d_tile_cost = nullptr, *d_tile_schedule = nullptr; // cost-feedback tile schedule
     void *d_status_blocks = nullptr; // derived: 4x4x4 block words + block filter (vrt_trace.hip)
     bool status_dirty = true;        // brick_status changed since the derived copy was built
     size_t lds_bytes = 0;
@@ -104,6 +107,8 @@ void free_ctx(vrt_ctx *c) {
     if (c->own_t32 && c->target32f) (void)hipFree(c->target32f);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_status_blocks) (void)hipFree(c->d_status_blocks);
+    if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
+    if (c->d_tile_schedule) (void)hipFree(c->d_tile_schedule);
     for (int i = 0; i < kStagingSlots; i++) {
         if (c->staging[i]) (void)hipHostFree(c->staging[i]);
         if (c->staging_ev[i]) (void)hipEventDestroy(c->staging_ev[i]);
@@ -267,6 +272,22 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     const size_t status_blocks_bytes = nblocks * 8u + ((nblocks + 31u) / 32u) * 4u + 16u;
     VRT_CREATE_HIP(hipMalloc(&c->d_status_blocks, status_blocks_bytes));
     VRT_CREATE_HIP(hipMemsetAsync(c->d_status_blocks, 0, status_blocks_bytes, c->stream));
+    {
+        // tile schedule starts as reverse raster (bottom rows first); the feedback kernel refines it
+        const uint32_t n = sh.owned_tiles ? sh.owned_tiles : 1u;
+        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_tile_cost), n * 4u));
+        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_tile_schedule), n * 4u));
+        VRT_CREATE_HIP(hipMemsetAsync(c->d_tile_cost, 0, n * 4u, c->stream));
+        uint32_t *init = static_cast<uint32_t *>(std::malloc(n * 4u));
+        if (!init) {
+            free_ctx(c);
+            return fail(nullptr, VRT_E_OOM, "host allocation failed");
+        }
+        for (uint32_t i = 0; i < n; i++) init[i] = n - 1u - i;
+        const hipError_t e = hipMemcpy(c->d_tile_schedule, init, n * 4u, hipMemcpyHostToDevice);
+        std::free(init);
+        VRT_CREATE_HIP(e);
+    }
     for (int i = 0; i < kStagingSlots; i++) {
         VRT_CREATE_HIP(hipHostMalloc(&c->staging[i], kStagingSlotBytes, hipHostMallocDefault));
         VRT_CREATE_HIP(hipEventCreateWithFlags(&c->staging_ev[i], hipEventDisableTiming));
@@ -308,6 +329,9 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.status_words = (uint32_t)((cells + 31u) / 32u);
     p.status_blocks = static_cast<const uint2 *>(c->d_status_blocks);
     p.tile_order = (cfg->kernel_variant >> 16) & 0xFu;
+    if (p.tile_order == 0u) p.tile_order = 3u; // default: reverse raster (see DESIGN.md §4 for the measured alternatives)
+    p.tile_cost = c->d_tile_cost;
+    p.tile_schedule = c->d_tile_schedule;
     p.wave_groups = (cfg->kernel_variant >> 20) & 0x1u;
     {
         // a stride near owned_tiles * 0.618 that is coprime to owned_tiles
@@ -398,6 +422,10 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         ctx->status_dirty = false;
     }
     VRT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    if (ctx->params.tile_order == 5u && ctx->shard.owned_tiles > 1u) {
+        // re-sort the tile list by last frame's measured cost (inside the timed region: it is per-frame work)
+        VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule, ctx->shard.owned_tiles, ctx->stream));
+    }
     // max_bounce <= 1 ("only primary ray" + its shadow ray): the bounce loop runs at most once
     const vrt::KernelFn fn = (camera->max_bounce <= 1) ? ctx->kernel_single : ctx->kernel;
     for (uint32_t f = 0; f < frames; f++) VRT_HIP(ctx, vrt::launch_trace(fn, ctx->params, ctx->lds_bytes, ctx->stream));

@@ -45,11 +45,14 @@ struct TraceParams {
     // block index bx + nbx*(bz + nbz*by), bit (x&3) + 4*(z&3) + 16*(y&3)  (x, z, y order as comp:318)
     const uint2 *status_blocks;
     uint32_t nbx, nby, nbz;
-    uint32_t *tile_counters;             // persistent-workgroup work queue: 2 sets x 8 XCD slices
-    uint32_t frame_parity;               // which counter set this launch consumes
+    // cost-feedback schedule (tile_order 5): tile_cost[i] accumulates the wave-cycles the i-th owned
+    // tile took in the previous frame(s); tile_schedule[k] is the owned tile the k-th workgroup renders
+    uint32_t *tile_cost;
+    const uint32_t *tile_schedule;
     uint32_t tile_stride;                // tile_order 4: multiplier coprime to owned_tiles
     uint32_t wave_groups;                // 1: launch one 64-thread workgroup per 8x8 block instead of 256 per 16x16 tile
-    uint32_t tile_order;                 // workgroup -> tile mapping: 0 round-robin over XCDs (default), 1 row bands per XCD, 2 column bands
+    uint32_t tile_order;                 // workgroup -> tile mapping: 0 default (= 3), 1 row bands per XCD, 2 column bands per XCD,
+                                         // 3 reverse raster, 4 strided, 5 cost-feedback schedule, 6 raster
 };
 
 constexpr int kTileW = 16;

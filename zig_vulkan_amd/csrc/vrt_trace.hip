@@ -489,12 +489,19 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TracePa
     const uint32_t unit = p.wave_groups ? (blockIdx.x >> 2) : blockIdx.x;
     const uint32_t wave = p.wave_groups ? (blockIdx.x & 3u) : (threadIdx.x >> 6);
     uint32_t owned;
-    if (p.tile_order == 0u) {
-        // consecutive tiles go to consecutive XCDs: every XCD samples the whole image, which balances
-        // sky against terrain (contiguous bands per XCD measured 22-28 % slower on the headline frame)
+    if (p.tile_order == 5u) {
+        // cost-feedback schedule: tiles sorted by the time they took last frame, heaviest first, so the
+        // kernel's tail is made of cheap tiles (longest-processing-time-first list scheduling).  Launch
+        // order also spreads consecutive tiles over XCDs (block b runs on XCD b % 8).
+        owned = p.tile_schedule[unit];
+    } else if (p.tile_order == 6u) {
+        // raster order; consecutive tiles go to consecutive XCDs: every XCD samples the whole image
+        // (a contiguous band per XCD measured 22-28 % slower on the headline frame: sky bands idle)
         owned = unit;
     } else if (p.tile_order == 3u) {
-        owned = p.owned_tiles - 1u - unit; // reverse raster: bottom of the image first
+        // reverse raster, consecutive tiles on consecutive XCDs: every XCD samples the whole image, and
+        // the rows that usually hold the ground (long rays) start first so that sky tiles fill the tail
+        owned = p.owned_tiles - 1u - unit;
     } else if (p.tile_order == 4u) {
         // strided permutation: consecutive launches sample the whole image (stride coprime to the count)
         owned = (uint32_t)(((unsigned long long)unit * p.tile_stride) % p.owned_tiles);
@@ -515,6 +522,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TracePa
     const uint32_t px = tile_x * kTileW + in_x;
     const uint32_t py = tile_y * kTileH + in_y;
 
+    const unsigned long long t_begin = (p.tile_order == 5u) ? __builtin_readcyclecounter() : 0ull;
     Cnt<COUNT> c;
     const bool inside = (px < p.width) && (py < p.height); // comp:155-159
     if (inside) {
@@ -550,6 +558,11 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TracePa
         if (p.target_rgba32f) {
             reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(color.x, color.y, color.z, 1.0f);
         }
+    }
+    if (p.tile_order == 5u) {
+        // one relaxed add per wave: the tile's cost for the next frame's schedule
+        const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
+        if (lane == 0) atomicAdd(&p.tile_cost[owned], (uint32_t)(dt >> 6));
     }
     if constexpr (COUNT) {
         // wave-level reduction, then one atomic per wave per counter
@@ -603,6 +616,42 @@ __global__ __launch_bounds__(256) void vrt_build_status_blocks(const uint32_t *_
     const uint32_t nwords = (nblocks + 31u) >> 5;
     if (lane == 0 && base_word < nwords) filter[base_word] = (uint32_t)(nonempty & 0xFFFFFFFFull);
     if (lane == 32 && base_word + 1u < nwords) filter[base_word + 1u] = (uint32_t)(nonempty >> 32);
+}
+
+// Cost-feedback schedule: order[] = owned tile ids sorted by cost (previous frame's wave-cycles),
+// heaviest first, by a 256-bucket counting sort; cost[] is cleared for the next frame.  One workgroup.
+// The order inside a bucket is whatever the atomics give: it affects timing only, never pixels.
+__global__ __launch_bounds__(1024) void vrt_schedule_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n) {
+    __shared__ uint32_t s_max;
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t start[256];
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_max = 0u;
+    if (tid < 256u) hist[tid] = 0u;
+    __syncthreads();
+    uint32_t m = 0u;
+    for (uint32_t i = tid; i < n; i += 1024u) m = max(m, cost[i]);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down(m, off, 64));
+    if ((tid & 63u) == 0u) atomicMax(&s_max, m);
+    __syncthreads();
+    const uint32_t mx = s_max;
+    if (mx == 0u) return; // no measurement yet (first frame): keep the current order
+    const float scale = 255.0f / (float)mx;
+    for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[(uint32_t)((float)cost[i] * scale)], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0u;
+        for (int b = 255; b >= 0; b--) { // heaviest bucket first
+            start[b] = acc;
+            acc += hist[b];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024u) {
+        const uint32_t b = (uint32_t)((float)cost[i] * scale);
+        order[atomicAdd(&start[b], 1u)] = i;
+        cost[i] = 0u;
+    }
 }
 
 // Root-side un-swizzle of gathered shards (rank-major, tile-major) into a
@@ -678,6 +727,11 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
     if (p.owned_tiles == 0) return hipSuccess;
     if (p.wave_groups) hipLaunchKernelGGL(fn, dim3(p.owned_tiles * 4u), dim3(64), lds_bytes, stream, p);
     else hipLaunchKernelGGL(fn, dim3(p.owned_tiles), dim3(256), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_schedule(uint32_t *cost, uint32_t *order, uint32_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(vrt_schedule_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
     return hipGetLastError();
 }
 
