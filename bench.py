@@ -155,13 +155,26 @@ def main() -> None:
         # previous frame): first third V0, second third V1, last third V2
         return VIEW_ORDER[min(len(VIEW_ORDER) - 1, (i * len(VIEW_ORDER)) // max(n, 1))]
 
+    frame_no = [0]  # frames submitted so far (warm-up included): the gather pipeline's slot counter
+
     def step(i: int, n: int) -> None:
         v = view_of(i, n)
         C.memmove(C.byref(rt.camera.d_camera), cams[v], 96)
-        rt.draw()
-        if sharded:
-            fg.gather()
-            fg.assemble(rt)
+        if not sharded:
+            rt.draw()
+            return
+        f = frame_no[0]
+        frame_no[0] += 1
+        fg.begin_frame(f)                       # buffer f%2 is free once frame f-2's gather is done
+        rt.set_target(fg.shard_for(f).data_ptr())
+        rt.draw()                               # this rank's tiles of frame f
+        fg.gather_async(f)                      # ONE collective per frame, overlapped with frame f+1's kernel
+        if f >= 1:
+            fg.complete(f - 1, rt)              # rank 0: un-swizzle the previous frame
+
+    def drain() -> None:
+        if sharded and frame_no[0] >= 1:
+            fg.complete(frame_no[0] - 1, rt)
 
     def barrier() -> None:
         if dist is not None and world > 1:
@@ -170,10 +183,12 @@ def main() -> None:
 
     for i in range(args.warmup):
         step(i, args.warmup)
+    drain()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, args.steps)
+    drain()  # the last frame's gather + un-swizzle belong to the timed region
     rt.wait()
     barrier()
     dt = time.perf_counter() - t0

@@ -170,6 +170,10 @@ int vrt_dispatch_repeat(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
  * For a sharded ctx these return the packed tile-major shard instead. */
 int vrt_read_rgba8(vrt_ctx *ctx, void *dst, uint64_t nbytes);
 int vrt_read_rgba32f(vrt_ctx *ctx, void *dst, uint64_t nbytes);
+/* Re-point the context at other caller-owned target images (device memory, same size as
+ * vrt_target_bytes_rgba8 / x4 for the float twin; rgba32f may be NULL).  Takes effect for the next
+ * dispatch; lets a caller double-buffer the image a gather or a present pass is still reading. */
+int vrt_set_target(vrt_ctx *ctx, void *rgba8, void *rgba32f);
 void *vrt_device_target_rgba8(vrt_ctx *ctx);   /* device pointer of the target */
 void *vrt_device_target_rgba32f(vrt_ctx *ctx);
 uint64_t vrt_target_bytes_rgba8(const vrt_ctx *ctx);

@@ -33,25 +33,43 @@ def _worker(rank: int, world: int, port: int, out_path: str):
         w = W.Workload("t", 200, 120, 64, 4, 1, 0, True, 0.0)  # ragged: 200x120 is not a multiple of 16
         grid = W.build_grid(w)  # replicated scene: every rank builds the same deterministic grid
         scene = oracle_scene_from_grid(grid)
-        pc = push_for(W.camera_for(w, "V2"), W.sun_for(w))
         fg = FrameGather(w.width, w.height, rank, world, torch.device("cpu"))
         geom = shard_geometry(w.width, w.height, rank, world)
-        shard = np.zeros((geom["tiles_per_rank"], TILE, TILE, 4), dtype=np.uint8)
-        for i, t in enumerate(owned_tile_ids(w.width, w.height, rank, world)):
-            ty, tx = divmod(int(t), geom["tiles_x"])
-            ys, xs = np.mgrid[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE]
-            inside = (xs < w.width) & (ys < w.height)
-            xy = np.stack([xs[inside], ys[inside]], axis=-1)
-            _, u8, _ = O.render_pixels(scene, pc, xy)
-            tile = np.zeros((TILE, TILE, 4), dtype=np.uint8)
-            tile[inside] = u8
-            shard[i] = tile
-        fg.shard.copy_(torch.from_numpy(shard.reshape(-1)))
-        fg.gather()          # the one collective per frame
-        fg.assemble(None)    # numpy restatement of vrt_assemble_frame
+
+        def render_shard(view):
+            pc = push_for(W.camera_for(w, view), W.sun_for(w))
+            shard = np.zeros((geom["tiles_per_rank"], TILE, TILE, 4), dtype=np.uint8)
+            for i, t in enumerate(owned_tile_ids(w.width, w.height, rank, world)):
+                ty, tx = divmod(int(t), geom["tiles_x"])
+                ys, xs = np.mgrid[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE]
+                inside = (xs < w.width) & (ys < w.height)
+                xy = np.stack([xs[inside], ys[inside]], axis=-1)
+                _, u8, _ = O.render_pixels(scene, pc, xy)
+                tile = np.zeros((TILE, TILE, 4), dtype=np.uint8)
+                tile[inside] = u8
+                shard[i] = tile
+            return pc, shard
+
+        # the pipelined loop of bench.py: 5 frames over 3 views through 2 buffers
+        views = ["V2", "V1", "V0", "V2", "V1"]
+        ok = 1
+        pcs = []
+        for f, view in enumerate(views):
+            pc, shard = render_shard(view)
+            pcs.append(pc)
+            fg.begin_frame(f)
+            fg.shard_for(f).copy_(torch.from_numpy(shard.reshape(-1)))
+            fg.gather_async(f)   # the one collective per frame
+            if f >= 1:
+                fg.complete(f - 1, None)  # numpy restatement of vrt_assemble_frame
+                if rank == 0:
+                    _, full, _ = O.render(scene, pcs[f - 1])
+                    ok &= int(np.array_equal(fg.frame_numpy(), full))
+        fg.complete(len(views) - 1, None)
         if rank == 0:
-            _, full, _ = O.render(scene, pc)
-            np.save(out_path, np.array([int(np.array_equal(fg.frame_numpy(), full)), geom["total_tiles"]]))
+            _, full, _ = O.render(scene, pcs[-1])
+            ok &= int(np.array_equal(fg.frame_numpy(), full))
+            np.save(out_path, np.array([ok, geom["total_tiles"]]))
     finally:
         dist.destroy_process_group()
 

@@ -139,6 +139,7 @@ SIGNATURES = {
     "vrt_wait": (C.c_int, [_ctx]),
     "vrt_read_rgba8": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
     "vrt_read_rgba32f": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
+    "vrt_set_target": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
     "vrt_device_target_rgba8": (C.c_void_p, [_ctx]),
     "vrt_device_target_rgba32f": (C.c_void_p, [_ctx]),
     "vrt_target_bytes_rgba8": (C.c_uint64, [_ctx]),

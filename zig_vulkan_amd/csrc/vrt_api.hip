@@ -475,6 +475,26 @@ int vrt_read_rgba8(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
 int vrt_read_rgba32f(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
     return read_back(ctx, dst, nbytes, ctx ? ctx->target32f : nullptr, ctx ? ctx->target_pixels * 16u : 0);
 }
+int vrt_set_target(vrt_ctx *ctx, void *rgba8, void *rgba32f) {
+    if (!ctx) return VRT_E_INVALID_ARG;
+    if (!rgba8) return fail(ctx, VRT_E_INVALID_ARG, "rgba8 target is NULL");
+    DeviceGuard dg(ctx->device);
+    if (ctx->own_t8 && ctx->target8) {
+        VRT_HIP(ctx, hipStreamSynchronize(ctx->stream)); // frames in flight still write the owned image
+        (void)hipFree(ctx->target8);
+        ctx->own_t8 = false;
+    }
+    if (ctx->own_t32 && ctx->target32f) {
+        VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->target32f);
+        ctx->own_t32 = false;
+    }
+    ctx->target8 = static_cast<uint8_t *>(rgba8);
+    ctx->target32f = static_cast<float *>(rgba32f);
+    ctx->params.target_rgba8 = ctx->target8;
+    ctx->params.target_rgba32f = ctx->target32f;
+    return VRT_OK;
+}
 void *vrt_device_target_rgba8(vrt_ctx *ctx) { return ctx ? ctx->target8 : nullptr; }
 void *vrt_device_target_rgba32f(vrt_ctx *ctx) { return ctx ? ctx->target32f : nullptr; }
 uint64_t vrt_target_bytes_rgba8(const vrt_ctx *ctx) { return ctx ? ctx->target_pixels * 4u : 0; }

@@ -46,46 +46,82 @@ def assemble_reference(gathered: np.ndarray, width: int, height: int, world: int
 
 
 class FrameGather:
-    """Owns the per-rank packed tile buffer and (on rank 0) the gathered buffer and the final
-    frame; performs the per-frame collective.  Works with any torch.distributed backend: "nccl"
-    (RCCL) on GPUs, "gloo" on CPU tensors in the world_size-2 tests."""
+    """Per-frame collective of the sharded renderer, pipelined over `depth` frames.
 
-    def __init__(self, width: int, height: int, rank: int, world: int, device, bytes_per_pixel: int = 4):
+    Each rank owns `depth` packed tile buffers; frame f renders into buffer f % depth and its gather
+    is started asynchronously, so the traversal kernel of frame f+1 overlaps the gather of frame f
+    (RCCL runs on its own stream; the only ordering points are: a buffer is not rewritten before the
+    gather that reads it has finished, and rank 0 un-swizzles a frame after its gather).  Works with
+    any torch.distributed backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" on CPU tensors in the
+    world_size-2 tests.  One gather per frame; no other data-path collective."""
+
+    def __init__(self, width: int, height: int, rank: int, world: int, device, bytes_per_pixel: int = 4, depth: int = 2):
         import torch
         self.torch = torch
-        self.width, self.height, self.rank, self.world = width, height, rank, world
+        self.width, self.height, self.rank, self.world, self.depth = width, height, rank, world, depth
         self.geom = shard_geometry(width, height, rank, world)
         self.bpp = bytes_per_pixel
         self.shard_bytes = self.geom["tiles_per_rank"] * TILE * TILE * bytes_per_pixel
         self.device = device
-        self.shard = torch.zeros(self.shard_bytes, dtype=torch.uint8, device=device)
-        self.gathered: Optional["torch.Tensor"] = None
-        self.frame: Optional["torch.Tensor"] = None
+        self.shards = [torch.zeros(self.shard_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.work = [None] * depth
+        self.gathered = None
+        self.frame = None
         if rank == 0:
-            self.gathered = torch.zeros(world * self.shard_bytes, dtype=torch.uint8, device=device)
+            self.gathered = [torch.zeros(world * self.shard_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
             self.frame = torch.zeros(height * width * bytes_per_pixel, dtype=torch.uint8, device=device)
-            self._recv_views = list(self.gathered.view(world, self.shard_bytes).unbind(0))
+            self._recv_views = [list(g.view(world, self.shard_bytes).unbind(0)) for g in self.gathered]
 
-    def gather(self) -> None:
-        """The one collective of the frame: every rank's packed shard -> rank 0, rank-major."""
+    @property
+    def shard(self):  # buffer of frame 0 (single-frame use)
+        return self.shards[0]
+
+    def shard_for(self, f: int):
+        """Buffer frame f renders into.  Call begin_frame(f) first."""
+        return self.shards[f % self.depth]
+
+    def begin_frame(self, f: int) -> None:
+        """Order the rewrite of buffer f % depth after the gather of frame f - depth that read it."""
+        slot = f % self.depth
+        w = self.work[slot]
+        if w is not None:
+            w.wait()  # nccl: the current stream waits (no host block); gloo: host waits
+            self.work[slot] = None
+
+    def gather_async(self, f: int) -> None:
+        """Start the one collective of frame f: every rank's packed shard -> rank 0, rank-major."""
         import torch.distributed as dist
+        slot = f % self.depth
         if self.world == 1:
-            self.gathered.copy_(self.shard)
+            self.gathered[slot].copy_(self.shards[slot])
             return
-        dist.gather(self.shard, gather_list=self._recv_views if self.rank == 0 else None, dst=0)
+        self.work[slot] = dist.gather(self.shards[slot], gather_list=self._recv_views[slot] if self.rank == 0 else None, dst=0,
+                                      async_op=True)
 
-    def assemble(self, renderer=None) -> None:
-        """Rank 0: un-swizzle gathered shards into the row-major frame (device kernel when a renderer
-        context is given, numpy restatement otherwise — CPU tests only)."""
+    def complete(self, f: int, renderer=None) -> None:
+        """Rank 0: wait for frame f's gather and un-swizzle it into the row-major frame (device kernel
+        when a renderer context is given; numpy restatement otherwise — CPU tests only)."""
+        slot = f % self.depth
+        w = self.work[slot]
+        if w is not None:
+            w.wait()
+            self.work[slot] = None
         if self.rank != 0:
             return
         if renderer is not None:
-            renderer.assemble_frame(self.gathered.data_ptr(), self.frame.data_ptr(), self.bpp)
+            renderer.assemble_frame(self.gathered[slot].data_ptr(), self.frame.data_ptr(), self.bpp)
         else:
-            g = self.gathered.cpu().numpy().reshape(self.world, -1)
+            g = self.gathered[slot].cpu().numpy().reshape(self.world, -1)
             px = g.reshape(self.world, self.geom["tiles_per_rank"], TILE, TILE, self.bpp)
             out = assemble_reference(px, self.width, self.height, self.world)
             self.frame.copy_(self.torch.from_numpy(np.ascontiguousarray(out).reshape(-1)))
+
+    # single-frame convenience (tests)
+    def gather(self) -> None:
+        self.gather_async(0)
+
+    def assemble(self, renderer=None) -> None:
+        self.complete(0, renderer)
 
     def frame_numpy(self) -> np.ndarray:
         assert self.rank == 0

@@ -306,6 +306,9 @@ class VoxelRT:
             return out.reshape(self.height, self.width, 4)
         return out.reshape(-1, 16, 16, 4)
 
+    def set_target(self, rgba8_ptr: int, rgba32f_ptr: int = 0) -> None:
+        check(lib.vrt_set_target(self._h, rgba8_ptr, rgba32f_ptr or None), self._h)
+
     def device_target_rgba8(self) -> int:
         return lib.vrt_device_target_rgba8(self._h)
 
