@@ -30,9 +30,13 @@
  *   - int(x)               -> (int)clamp(x, -2^31, 2147483520) (vrt_f2i; GLSL leaves the
  *                             out-of-range conversion undefined, C makes it UB)
  *   - Rgba8 imageStore     -> rintf(clamp(c,0,1)*255)
- * Hang guard: both DDA loops carry an iteration cap that a well-formed DDA can
- * never reach (each iteration moves one cell along one axis); the reference
- * has no cap and would spin forever on a degenerate (NaN/zero-step) ray.
+ * Hang guard: a DDA step along an axis whose ray_step is 0 does not move the
+ * position, so a degenerate ray (NaN side distances with a zero step) would spin
+ * forever in the reference's loops.  Both loops here allow such a zero-step
+ * axis to be selected at most G times (G = dx+dy+dz+8 for the brick-level walk,
+ * 3*b+8 for the voxel-level walk) and end the loop on the next selection.  A
+ * well-formed ray never selects a zero-step axis (its side distance is 5e11),
+ * so the guard is unobservable on valid input.
  */
 #include <math.h>
 #include <stdint.h>
@@ -286,9 +290,8 @@ static int BrickHit(const Env *e, const Ray *r, float t_min, float t_max, v3 ray
     const float local_t_max = t_max - hit->t;
     (void)t_min; /* local_t_min is computed but never read in the shader (comp:404) */
     float t_value = 0;
-    int guard = 3 * bd + 8;
+    int zero_budget[3] = {3 * bd + 8, 3 * bd + 8, 3 * bd + 8}; /* hang guard, see header */
     while (lx >= 0 && ly >= 0 && lz >= 0 && lx < bd && ly < bd && lz < bd && t_value <= local_t_max) {
-        if (guard-- <= 0) break;
         const int voxel_index = lx + bd * (lz + bd * ly);
         const uint8_t mask_index = (uint8_t)(voxel_index / 8);
         const uint8_t mask_offset = (uint8_t)(voxel_index % 8);
@@ -308,23 +311,25 @@ static int BrickHit(const Env *e, const Ray *r, float t_min, float t_max, v3 ray
                 return 1;
             }
         }
+        int axis;
         if (side_dist.x < side_dist.y) {
             if (side_dist.x < side_dist.z) {
                 t_value = side_dist.x * voxel_scale.x; side_dist.x += ray_delta.x; lx += ray_step[0];
-                hit->normal = V3(normal_axis.x, 0, 0);
+                hit->normal = V3(normal_axis.x, 0, 0); axis = 0;
             } else {
                 t_value = side_dist.z * voxel_scale.z; side_dist.z += ray_delta.z; lz += ray_step[2];
-                hit->normal = V3(0, 0, normal_axis.z);
+                hit->normal = V3(0, 0, normal_axis.z); axis = 2;
             }
         } else {
             if (side_dist.y < side_dist.z) {
                 t_value = side_dist.y * voxel_scale.y; side_dist.y += ray_delta.y; ly += ray_step[1];
-                hit->normal = V3(0, normal_axis.y, 0);
+                hit->normal = V3(0, normal_axis.y, 0); axis = 1;
             } else {
                 t_value = side_dist.z * voxel_scale.z; side_dist.z += ray_delta.z; lz += ray_step[2];
-                hit->normal = V3(0, 0, normal_axis.z);
+                hit->normal = V3(0, 0, normal_axis.z); axis = 2;
             }
         }
+        if (ray_step[axis] == 0 && --zero_budget[axis] < 0) break; /* hang guard */
     }
     return 0;
 }
@@ -362,9 +367,8 @@ static int GridHit(const Env *e, const Ray *r, float t_min, float t_max, v3 *hit
 
     float t_value = 0;
     int lx = vrt_f2i(floorf(fposition.x + 0.f)), ly = vrt_f2i(floorf(fposition.y + 0.f)), lz = vrt_f2i(floorf(fposition.z + 0.f));
-    int guard = dx + dy + dz + 8;
+    int zero_budget[3] = {dx + dy + dz + 8, dx + dy + dz + 8, dx + dy + dz + 8}; /* hang guard, see header */
     while (lx >= 0 && ly >= 0 && lz >= 0 && lx < dx && ly < dy && lz < dz && global_t_value <= t_max) {
-        if (guard-- <= 0) break;
         if (e->c) e->c->grid_steps++;
         const uint32_t grid_index = (uint32_t)(lx + dx * (lz + dz * ly));
         const uint32_t new_brick_type_index = grid_index / 32;
@@ -386,23 +390,25 @@ static int GridHit(const Env *e, const Ray *r, float t_min, float t_max, v3 *hit
                 return 1;
             }
         }
+        int axis;
         if (side_dist.x < side_dist.y) {
             if (side_dist.x < side_dist.z) {
                 t_value = side_dist.x * g_scale.x; side_dist.x += ray_delta.x; lx += ray_step[0];
-                hit->normal = V3(normal_axis.x, 0, 0);
+                hit->normal = V3(normal_axis.x, 0, 0); axis = 0;
             } else {
                 t_value = side_dist.z * g_scale.z; side_dist.z += ray_delta.z; lz += ray_step[2];
-                hit->normal = V3(0, 0, normal_axis.z);
+                hit->normal = V3(0, 0, normal_axis.z); axis = 2;
             }
         } else {
             if (side_dist.y < side_dist.z) {
                 t_value = side_dist.y * g_scale.y; side_dist.y += ray_delta.y; ly += ray_step[1];
-                hit->normal = V3(0, normal_axis.y, 0);
+                hit->normal = V3(0, normal_axis.y, 0); axis = 1;
             } else {
                 t_value = side_dist.z * g_scale.z; side_dist.z += ray_delta.z; lz += ray_step[2];
-                hit->normal = V3(0, 0, normal_axis.z);
+                hit->normal = V3(0, 0, normal_axis.z); axis = 2;
             }
         }
+        if (ray_step[axis] == 0 && --zero_budget[axis] < 0) break; /* hang guard */
     }
     return 0;
 }

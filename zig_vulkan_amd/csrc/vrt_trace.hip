@@ -56,43 +56,34 @@ VRT_DI f3 ray_at(const Ray &r, float t) { return fma3(splat3(t), r.direction, r.
 // comp:267
 VRT_DI float safe_inverse(float x) { return (x == 0.0f) ? 1e12f : (1.0f / x); }
 
-// DDA walker state shared by the two levels.
+// DDA walker state shared by the two levels.  Instead of the cell position the walker keeps, per
+// axis, how many more steps it may take before it leaves the box through the face it is moving
+// towards (rem = dim-1-pos for step +1, pos for step -1): stepping decrements one counter and "still
+// inside" is min3(rem) >= 0 — two VALU ops and no lane-mask merging on the scalar unit, against
+// three compares and their s_and/s_or chain on positions.  An axis with step 0 never moves; its
+// counter holds the hang-guard budget instead (see the oracle's header: same definition).  The
+// position, needed only when a brick is entered, is base - step*rem.
 struct Walk {
     f3 side_dist;
-    int x, y, z;
+    int rx, ry, rz;
     float t_value;
 };
 
-// comp:345-372 / comp:440-467: the branchy min-axis step as selects.
-//   x<y ? (x<z ? X : Z) : (y<z ? Y : Z)
-// `axis` records the face crossed; hit.normal (comp:350,356,364,370) is rebuilt from it
-// only when a voxel is actually hit.
-VRT_DI void dda_step(Walk &w, const f3 &ray_delta, int sx, int sy, int sz, float scale, int &axis) {
-    const bool x_lt_y = w.side_dist.x < w.side_dist.y;
-    const bool x_lt_z = w.side_dist.x < w.side_dist.z;
-    const bool y_lt_z = w.side_dist.y < w.side_dist.z;
-    const bool ax = x_lt_y && x_lt_z;
-    const bool ay = !x_lt_y && y_lt_z;
-    const bool az = !(ax || ay);
-    const float sd = ax ? w.side_dist.x : (ay ? w.side_dist.y : w.side_dist.z);
-    w.t_value = sd * scale;
-    const float nx = w.side_dist.x + ray_delta.x;
-    const float ny = w.side_dist.y + ray_delta.y;
-    const float nz = w.side_dist.z + ray_delta.z;
-    w.side_dist.x = ax ? nx : w.side_dist.x;
-    w.side_dist.y = ay ? ny : w.side_dist.y;
-    w.side_dist.z = az ? nz : w.side_dist.z;
-    w.x += ax ? sx : 0;
-    w.y += ay ? sy : 0;
-    w.z += az ? sz : 0;
-    axis = ax ? 0 : (ay ? 1 : 2);
+VRT_DI int steps_left(int step, int pos, int dim, int zero_budget) {
+    // (pos may be any int when the start lies outside the box; wrap instead of overflowing)
+    return step > 0 ? (int)((uint32_t)(dim - 1) - (uint32_t)pos) : (step < 0 ? pos : zero_budget);
 }
+VRT_DI int walk_base(int step, int pos, int dim) { return step > 0 ? dim - 1 : (step < 0 ? 0 : pos); }
+VRT_DI int min3i(int a, int b, int c) { return min(min(a, b), c); }
 
-// Same step for the brick-level walk, also advancing the linear cell index
-// x + dim_x*(z + dim_z*y) (comp:318) by the stride of the crossed axis instead of recomputing it
-// with two 32-bit multiplies (v_mad_u64_u32 on gfx950, quarter rate).  Exact in modular u32 arithmetic.
-VRT_DI void dda_step_cell(Walk &w, const f3 &ray_delta, int sx, int sy, int sz, float scale, int &axis, uint32_t &cell, uint32_t stride_x,
-                          uint32_t stride_y, uint32_t stride_z) {
+// comp:345-372 / comp:440-467: the branchy min-axis step as selects,
+//   x<y ? (x<z ? X : Z) : (y<z ? Y : Z)
+// also advancing a linear index (cell index x + dim_x*(z + dim_z*y), comp:318, or voxel index,
+// comp:412) by the stride of the crossed axis instead of recomputing it with two 32-bit multiplies
+// (v_mad_u64_u32 on gfx950, quarter rate); exact in modular u32 arithmetic.  `axis` records the face
+// crossed; hit.normal (comp:350,356,364,370) is rebuilt from it only when a voxel is actually hit.
+VRT_DI void dda_step(Walk &w, const f3 &ray_delta, float scale, int &axis, uint32_t &index, uint32_t stride_x, uint32_t stride_y,
+                     uint32_t stride_z) {
     const bool x_lt_y = w.side_dist.x < w.side_dist.y;
     const bool x_lt_z = w.side_dist.x < w.side_dist.z;
     const bool y_lt_z = w.side_dist.y < w.side_dist.z;
@@ -107,10 +98,10 @@ VRT_DI void dda_step_cell(Walk &w, const f3 &ray_delta, int sx, int sy, int sz, 
     w.side_dist.x = ax ? nx : w.side_dist.x;
     w.side_dist.y = ay ? ny : w.side_dist.y;
     w.side_dist.z = az ? nz : w.side_dist.z;
-    w.x += ax ? sx : 0;
-    w.y += ay ? sy : 0;
-    w.z += az ? sz : 0;
-    cell += ax ? stride_x : (ay ? stride_y : stride_z);
+    w.rx -= ax ? 1 : 0;
+    w.ry -= ay ? 1 : 0;
+    w.rz -= az ? 1 : 0;
+    index += ax ? stride_x : (ay ? stride_y : stride_z);
     axis = ax ? 0 : (ay ? 1 : 2);
 }
 
@@ -177,42 +168,47 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
     const f3 fposition = (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
     Walk w;
     w.side_dist = initial_side_dist(s.fstep, fposition, s.ray_delta);
-    w.x = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
-    w.y = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
-    w.z = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
+    const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
+    const int py = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
+    const int pz = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
+    constexpr int kZeroBudget = 3 * B + 8;
+    w.rx = steps_left(s.sx, px, B, kZeroBudget);
+    w.ry = steps_left(s.sy, py, B, kZeroBudget);
+    w.rz = steps_left(s.sz, pz, B, kZeroBudget);
     w.t_value = 0;
     const float local_t_max = s.grid_t_max - hit.t;
+    uint32_t voxel_index = (uint32_t)px + (uint32_t)B * ((uint32_t)pz + (uint32_t)B * (uint32_t)py); // comp:412, kept current by dda_step
+    const uint32_t stride_x = (uint32_t)s.sx, stride_y = (uint32_t)(s.sy * (B * B)), stride_z = (uint32_t)(s.sz * B);
 
     uint2 occ = make_uint2(0u, 0u);
-    int occ_layer = -1;
+    uint32_t occ_layer = ~0u;
     const uint2 *occ_words = reinterpret_cast<const uint2 *>(p.brick_occupancy);
     if constexpr (!LITERAL && B == 4) occ = occ_words[brick_index];
 
     // Single-exit loop (one back-edge condition, no return inside): the structurizer then needs one
     // exec update per iteration instead of a chain of exit-flag merges on the scalar unit.
-    int guard = 3 * B + 8;
     bool found = false;
-    bool more = (unsigned)w.x < (unsigned)B && (unsigned)w.y < (unsigned)B && (unsigned)w.z < (unsigned)B && w.t_value <= local_t_max;
+    bool more = (unsigned)px < (unsigned)B && (unsigned)py < (unsigned)B && (unsigned)pz < (unsigned)B && w.t_value <= local_t_max;
     while (more) {
         VRT_COUNT(voxel_steps);
-        const int voxel_index = w.x + B * (w.z + B * w.y);
         bool solid;
         if constexpr (LITERAL) {
-            const uint32_t byte = p.brick_occupancy[brick_index * (uint32_t)(B * B * B / 8) + (uint32_t)(voxel_index >> 3)];
-            solid = (byte >> (voxel_index & 7)) & 1u;
+            const uint32_t byte = p.brick_occupancy[brick_index * (uint32_t)(B * B * B / 8) + (voxel_index >> 3)];
+            solid = (byte >> (voxel_index & 7u)) & 1u;
         } else if constexpr (B == 4) {
-            solid = bit64(occ, (uint32_t)voxel_index);
+            solid = bit64(occ, voxel_index);
         } else {
-            if (occ_layer != w.y) {
-                occ = occ_words[(size_t)brick_index * 8u + (uint32_t)w.y];
-                occ_layer = w.y;
+            const uint32_t layer = voxel_index >> 6; // y
+            if (occ_layer != layer) {
+                occ = occ_words[(size_t)brick_index * 8u + layer];
+                occ_layer = layer;
             }
-            solid = bit64(occ, (uint32_t)(w.x + 8 * w.z));
+            solid = bit64(occ, voxel_index & 63u);
         }
         if (solid) {
             VRT_COUNT(hits);
             const uint32_t brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu; // comp:422
-            const uint32_t mi = p.material_index[brick_material_index + (uint32_t)voxel_index];
+            const uint32_t mi = p.material_index[brick_material_index + voxel_index];
             const vrt_material *m = p.materials + mi;
             const uint32_t mtype = m->type;
             const float mdata = m->type_data;
@@ -227,10 +223,8 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
             }
         }
         // (after a hit this step is dead work, once per ray; its results are never read)
-        dda_step(w, s.ray_delta, s.sx, s.sy, s.sz, voxel_scale, axis);
-        guard--;
-        more = !found && guard > 0 && (unsigned)w.x < (unsigned)B && (unsigned)w.y < (unsigned)B && (unsigned)w.z < (unsigned)B &&
-               w.t_value <= local_t_max;
+        dda_step(w, s.ray_delta, voxel_scale, axis, voxel_index, stride_x, stride_y, stride_z);
+        more = !found && min3i(w.rx, w.ry, w.rz) >= 0 && w.t_value <= local_t_max;
     }
     return found;
 }
@@ -260,9 +254,14 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     const f3 fposition = (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
     Walk w;
     w.side_dist = initial_side_dist(s.fstep, fposition, s.ray_delta);
-    w.x = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
-    w.y = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
-    w.z = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
+    const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
+    const int py = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
+    const int pz = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
+    const int zero_budget = dx + dy + dz + 8;
+    w.rx = steps_left(s.sx, px, dx, zero_budget);
+    w.ry = steps_left(s.sy, py, dy, zero_budget);
+    w.rz = steps_left(s.sz, pz, dz, zero_budget);
+    const int base_x = walk_base(s.sx, px, dx), base_y = walk_base(s.sy, py, dy), base_z = walk_base(s.sz, pz, dz);
     w.t_value = 0;
 
     uint32_t word_index = ~0u; // comp:301
@@ -270,17 +269,18 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     uint32_t block_index = ~0u;
     uint2 block_bits = make_uint2(0u, 0u);
     int axis = 3;
-    int guard = dx + dy + dz + 8;
 
     // `global_t_value <= t_max` (comp:316) with t_max = +inf only fails for a NaN t, and t only
     // changes when a brick is entered: test it there instead of on every step.
     if (!(global_t_value <= t_max)) return false;
-    // comp:318, kept current by dda_step_cell; meaningless (and unused) while the position is outside
-    uint32_t grid_index = (uint32_t)w.x + (uint32_t)dx * ((uint32_t)w.z + (uint32_t)dz * (uint32_t)w.y);
+    // comp:318, kept current by dda_step; meaningless (and unused) while the position is outside
+    uint32_t grid_index = (uint32_t)px + (uint32_t)dx * ((uint32_t)pz + (uint32_t)dz * (uint32_t)py);
     const uint32_t stride_x = (uint32_t)s.sx, stride_y = (uint32_t)s.sy * (uint32_t)dx * (uint32_t)dz, stride_z = (uint32_t)s.sz * (uint32_t)dx;
 
-    bool found = false;
-    bool more = (unsigned)w.x < (unsigned)dx && (unsigned)w.y < (unsigned)dy && (unsigned)w.z < (unsigned)dz;
+    // stop: 0 keep walking, -1 voxel hit, -2 t became NaN; negative values end the loop through the
+    // same integer test as the box exit
+    int stop = 0;
+    bool more = (unsigned)px < (unsigned)dx && (unsigned)py < (unsigned)dy && (unsigned)pz < (unsigned)dz;
     while (more) { // single-exit loop, see brick_walk
         VRT_COUNT(grid_steps);
         bool occupied;
@@ -300,7 +300,8 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
                     c.status_loads++;
                 }
             }
-            const uint32_t bi = (uint32_t)(w.x >> 2) + p.nbx * ((uint32_t)(w.z >> 2) + p.nbz * (uint32_t)(w.y >> 2));
+            const int cx = base_x - s.sx * w.rx, cy = base_y - s.sy * w.ry, cz = base_z - s.sz * w.rz;
+            const uint32_t bi = (uint32_t)(cx >> 2) + p.nbx * ((uint32_t)(cz >> 2) + p.nbz * (uint32_t)(cy >> 2));
             if (bi != block_index) {
                 block_index = bi;
                 if constexpr (MODE == kStatusBlockedLds) {
@@ -310,23 +311,22 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
                     block_bits = p.status_blocks[bi];
                 }
             }
-            occupied = bit64(block_bits, (uint32_t)((w.x & 3) | ((w.z & 3) << 2) | ((w.y & 3) << 4)));
+            occupied = bit64(block_bits, (uint32_t)((cx & 3) | ((cz & 3) << 2) | ((cy & 3) << 4)));
         }
-        bool t_is_nan = false;
         if (occupied) {
-            const f3 brick_min = fma3(mk3((float)w.x, (float)w.y, (float)w.z), splat3(g_scale), g_min); // comp:331
-            global_t_value = w.t_value + s.grid_t_min + 0.01f * g_scale;                               // comp:332
+            const int cx = base_x - s.sx * w.rx, cy = base_y - s.sy * w.ry, cz = base_z - s.sz * w.rz; // cell position
+            const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min);  // comp:331
+            global_t_value = w.t_value + s.grid_t_min + 0.01f * g_scale;                             // comp:332
             hit.t = global_t_value;
             const uint32_t brick_index = p.brick_index[grid_index]; // comp:337
             VRT_COUNT(bricks_entered);
-            found = brick_walk<B, COUNT, MODE == kStatusLinear>(p, r, s, g_scale, brick_index, brick_min, hit, axis, c);
-            t_is_nan = !(global_t_value <= t_max);
+            const bool found = brick_walk<B, COUNT, MODE == kStatusLinear>(p, r, s, g_scale, brick_index, brick_min, hit, axis, c);
+            stop = found ? -1 : ((global_t_value <= t_max) ? 0 : -2);
         }
-        dda_step_cell(w, s.ray_delta, s.sx, s.sy, s.sz, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
-        guard--;
-        more = !found && !t_is_nan && guard > 0 && (unsigned)w.x < (unsigned)dx && (unsigned)w.y < (unsigned)dy && (unsigned)w.z < (unsigned)dz;
+        dda_step(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
+        more = (min3i(w.rx, w.ry, w.rz) | stop) >= 0;
     }
-    return found;
+    return stop == -1;
 }
 
 // ---- scatter functions (comp:539-596) -------------------------------------
