@@ -301,7 +301,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     }
     {
         char buf[96];
-        static const char *const mode_names[] = {"?", "linear-status+byte-occupancy", "blocked-status", "blocked-status+lds-filter", "linear-status+wide-occupancy"};
+        static const char *const mode_names[] = {"?", "linear-status+byte-occupancy", "blocked-status", "blocked-status+lds-filter", "linear-status+wide-occupancy", "linear-status-uncached", "linear-status-in-lds"};
         const uint32_t rv = vrt::resolve_variant(cfg->kernel_variant);
         std::snprintf(buf, sizeof buf, "vrt_trace_kernel<B=%u,COUNT=%d,%s,minwaves=%u>", cfg->brick_dimension, cfg->enable_counters ? 1 : 0,
                       mode_names[rv & 0xFFu], (rv >> 8) ? (rv >> 8) : 4u);
@@ -346,14 +346,16 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.nbz = nbz;
     c->lds_bytes = vrt::trace_lds_bytes(p, cfg->kernel_variant);
     if (c->lds_bytes > 64u * 1024u) {
-        // the block filter of a very large grid does not fit the LDS budget: read block words directly
-        c->cfg.kernel_variant = (cfg->kernel_variant & ~0xFFu) | vrt::kVariantBlocked;
+        // the LDS-staged structure of a very large grid does not fit the LDS budget: read from global memory
+        const uint32_t mode = vrt::resolve_variant(cfg->kernel_variant) & 0xFFu;
+        const uint32_t fallback = (mode == vrt::kVariantLinearLds) ? vrt::kVariantLinearAlways : vrt::kVariantBlocked;
+        c->cfg.kernel_variant = (cfg->kernel_variant & ~0xFFu) | fallback;
         c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, false);
         c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, true);
         c->lds_bytes = 0;
-        c->kernel_name += "[filter>64KiB: blocked-status]";
+        c->kernel_name += "[LDS structure > 64 KiB: global-memory variant]";
     }
-    // the grid-state UBO mirror starts zeroed; dim 0 => every ray misses until GRID_STATE is uploaded
+    // the status bitmap is read 16 bytes at a time by the LDS-staging variant: the +16 slack of dbuf covers the tail
 #undef VRT_CREATE_HIP
     *out = c;
     return VRT_OK;

@@ -65,6 +65,8 @@ enum : uint32_t {
     kVariantBlocked = 2,    // blocked 4^3 status words + 64-bit occupancy words, read from global memory
     kVariantBlockedLds = 3, // same, behind an LDS-resident block filter
     kVariantLinearWide = 4, // linear status words (as the shader) + 64-bit occupancy words
+    kVariantLinearAlways = 5, // linear status word loaded on every step (no per-lane cache / branch)
+    kVariantLinearLds = 6,    // linear status bitmap staged in LDS per workgroup (grids whose bitmap fits)
     kVariantCount
 };
 

@@ -87,9 +87,10 @@ VRT_DI void dda_step(Walk &w, const f3 &ray_delta, float scale, int &axis, uint3
     const bool x_lt_y = w.side_dist.x < w.side_dist.y;
     const bool x_lt_z = w.side_dist.x < w.side_dist.z;
     const bool y_lt_z = w.side_dist.y < w.side_dist.z;
-    const bool ax = x_lt_y && x_lt_z;
-    const bool ay = !x_lt_y && y_lt_z;
-    const bool az = !(ax || ay);
+    // lane masks combined with bitwise operators: one s_and / s_andn2 / s_or each on the scalar unit
+    const bool ax = x_lt_y & x_lt_z;
+    const bool ay = (!x_lt_y) & y_lt_z;
+    const bool axy = ax | ay; // z is crossed when neither x nor y is
     const float sd = ax ? w.side_dist.x : (ay ? w.side_dist.y : w.side_dist.z);
     w.t_value = sd * scale;
     const float nx = w.side_dist.x + ray_delta.x;
@@ -97,10 +98,10 @@ VRT_DI void dda_step(Walk &w, const f3 &ray_delta, float scale, int &axis, uint3
     const float nz = w.side_dist.z + ray_delta.z;
     w.side_dist.x = ax ? nx : w.side_dist.x;
     w.side_dist.y = ay ? ny : w.side_dist.y;
-    w.side_dist.z = az ? nz : w.side_dist.z;
+    w.side_dist.z = axy ? w.side_dist.z : nz;
     w.rx -= ax ? 1 : 0;
     w.ry -= ay ? 1 : 0;
-    w.rz -= az ? 1 : 0;
+    w.rz -= axy ? 0 : 1;
     index += ax ? stride_x : (ay ? stride_y : stride_z);
     axis = ax ? 0 : (ay ? 1 : 2);
 }
@@ -234,7 +235,9 @@ enum StatusMode : int {
     kStatusLinear = 0,     // the shader's own words: bit i%32 of word i/32, cached per lane (comp:318-328)
     kStatusBlocked = 1,    // device-built 4x4x4 block words from global memory, cached per lane
     kStatusBlockedLds = 2, // same, behind an LDS-resident 1-bit-per-block "non-empty" filter
-    kStatusLinearWide = 3  // linear words for status, 64-bit words for occupancy
+    kStatusLinearWide = 3, // linear words for status, 64-bit words for occupancy
+    kStatusLinearAlways = 4, // linear words, loaded on every step (no per-lane word cache, no branch)
+    kStatusLinearLds = 5     // the whole linear status bitmap staged in LDS per workgroup, read on every step
 };
 
 // comp:271-376.  t_min = 1e-5, t_max = +inf at every call site (comp:218,247).
@@ -284,7 +287,25 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     while (more) { // single-exit loop, see brick_walk
         VRT_COUNT(grid_steps);
         bool occupied;
-        if constexpr (MODE == kStatusLinear || MODE == kStatusLinearWide) {
+        if constexpr (MODE == kStatusLinearLds) {
+            if constexpr (COUNT) {
+                const uint32_t wi = grid_index >> 5;
+                if (wi != word_index) {
+                    word_index = wi;
+                    c.status_loads++;
+                }
+            }
+            occupied = (lds_filter[grid_index >> 5] >> (grid_index & 31u)) & 1u; // ds_read_b32
+        } else if constexpr (MODE == kStatusLinearAlways) {
+            if constexpr (COUNT) {
+                const uint32_t wi = grid_index >> 5;
+                if (wi != word_index) {
+                    word_index = wi;
+                    c.status_loads++;
+                }
+            }
+            occupied = (p.brick_status[grid_index >> 5] >> (grid_index & 31u)) & 1u;
+        } else if constexpr (MODE == kStatusLinear || MODE == kStatusLinearWide) {
             const uint32_t wi = grid_index >> 5;
             if (wi != word_index) { // comp:323-326
                 word_bits = p.brick_status[wi];
@@ -314,13 +335,13 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
             occupied = bit64(block_bits, (uint32_t)((cx & 3) | ((cz & 3) << 2) | ((cy & 3) << 4)));
         }
         if (occupied) {
-            const int cx = base_x - s.sx * w.rx, cy = base_y - s.sy * w.ry, cz = base_z - s.sz * w.rz; // cell position
+            const int cx = base_x - __mul24(s.sx, w.rx), cy = base_y - __mul24(s.sy, w.ry), cz = base_z - __mul24(s.sz, w.rz); // cell position
             const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min);  // comp:331
             global_t_value = w.t_value + s.grid_t_min + 0.01f * g_scale;                             // comp:332
             hit.t = global_t_value;
             const uint32_t brick_index = p.brick_index[grid_index]; // comp:337
             VRT_COUNT(bricks_entered);
-            const bool found = brick_walk<B, COUNT, MODE == kStatusLinear>(p, r, s, g_scale, brick_index, brick_min, hit, axis, c);
+            const bool found = brick_walk<B, COUNT, MODE == kStatusLinear || MODE == kStatusLinearAlways || MODE == kStatusLinearLds>(p, r, s, g_scale, brick_index, brick_min, hit, axis, c);
             stop = found ? -1 : ((global_t_value <= t_max) ? 0 : -2);
         }
         dda_step(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
@@ -476,6 +497,14 @@ VRT_DI uint32_t xcd_slice_index(uint32_t b, uint32_t n) {
 template <int B, bool COUNT, int MODE, int MIN_WAVES, bool SINGLE>
 __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TraceParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_filter[];
+    if constexpr (MODE == kStatusLinearLds) {
+        // stage the brick-status bitmap (binding 3) in LDS: 16 bytes per lane per trip
+        const uint32_t nvec = (p.status_words + 3u) >> 2;
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.brick_status);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_filter);
+        for (uint32_t i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
     if constexpr (MODE == kStatusBlockedLds) {
         // stage the block filter (1 bit per 4x4x4 block of cells) once per workgroup
         const uint32_t nwords = (p.nbx * p.nby * p.nbz + 31u) >> 5;
@@ -683,6 +712,8 @@ static KernelFn pick_mode(uint32_t mode) {
         case kVariantBlocked: return vrt_trace_kernel<B, COUNT, kStatusBlocked, MW, SINGLE>;
         case kVariantBlockedLds: return vrt_trace_kernel<B, COUNT, kStatusBlockedLds, MW, SINGLE>;
         case kVariantLinearWide: return vrt_trace_kernel<B, COUNT, kStatusLinearWide, MW, SINGLE>;
+        case kVariantLinearAlways: return vrt_trace_kernel<B, COUNT, kStatusLinearAlways, MW, SINGLE>;
+        case kVariantLinearLds: return vrt_trace_kernel<B, COUNT, kStatusLinearLds, MW, SINGLE>;
         default: return nullptr;
     }
 }
@@ -718,9 +749,13 @@ KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t varian
 
 // bytes of dynamic LDS the variant needs for this grid
 size_t trace_lds_bytes(const TraceParams &p, uint32_t variant) {
-    if ((resolve_variant(variant) & 0xFFu) != kVariantBlockedLds) return 0;
-    const size_t nwords = ((size_t)p.nbx * p.nby * p.nbz + 31u) >> 5;
-    return (nwords * 4u + 15u) & ~(size_t)15u;
+    const uint32_t mode = resolve_variant(variant) & 0xFFu;
+    if (mode == kVariantBlockedLds) {
+        const size_t nwords = ((size_t)p.nbx * p.nby * p.nbz + 31u) >> 5;
+        return (nwords * 4u + 15u) & ~(size_t)15u;
+    }
+    if (mode == kVariantLinearLds) return (((size_t)p.status_words + 3u) & ~(size_t)3u) * 4u;
+    return 0;
 }
 
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream) {
