@@ -87,6 +87,7 @@ def main() -> None:
     ap.add_argument("--variant", type=lambda x: int(x, 0), default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=2.0, help="minimum wall time of the CPU baseline sample")
+    ap.add_argument("--frames-in-flight", type=int, default=2, help="1: frames strictly one after another; 2: two frames in flight")
     ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")
     args = ap.parse_args()
 
@@ -139,7 +140,7 @@ def main() -> None:
         rt = W.make_renderer(w, grid, device_id=local_rank, shard_rank=rank, shard_count=world, stream=stream,
                              external_target_rgba8=fg.shard.data_ptr(), kernel_variant=args.variant)
     else:
-        rt = W.make_renderer(w, grid, device_id=local_rank, stream=stream, kernel_variant=args.variant)
+        rt = W.make_renderer(w, grid, device_id=local_rank, kernel_variant=args.variant, frames_in_flight=args.frames_in_flight)
     rt.wait()
 
     cams = {}
@@ -233,7 +234,8 @@ def main() -> None:
                        "rays": "primary + shadow" if w.sun_enabled else "primary", "spp": w.spp, "max_bounce": w.max_bounce,
                        "views": VIEW_ORDER, "rays_per_frame": {v: per_view[v]["rays"] for v in VIEW_ORDER},
                        "counters_per_frame": {v: per_view[v]["counters"] for v in VIEW_ORDER},
-                       "parallelism": f"image tiles 16x16 interleaved over {world} GPU(s), 1 RCCL gather/frame" if sharded else "1 GPU, whole frame"},
+                       "parallelism": f"image tiles 16x16 interleaved over {world} GPU(s), 1 RCCL gather/frame, gather of frame f overlaps kernel of f+1"
+                       if sharded else f"1 GPU, whole frame, {args.frames_in_flight} frame(s) in flight"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

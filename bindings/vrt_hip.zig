@@ -54,7 +54,8 @@ pub const Config = extern struct {
     external_target_rgba32f: ?*anyopaque = null,
     stream: ?*anyopaque = null,
     kernel_variant: u32 = 0,
-    _reserved: [7]u32 = [_]u32{0} ** 7,
+    frames_in_flight: u32 = 1,
+    _reserved: [6]u32 = [_]u32{0} ** 6,
 };
 
 pub extern fn vrt_create(cfg: *const Config, out: *?*Ctx) c_int;

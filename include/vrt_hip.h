@@ -124,7 +124,12 @@ typedef struct vrt_config {
     void *external_target_rgba32f;
     void *stream;               /* hipStream_t; 0 => a stream owned by the ctx   */
     uint32_t kernel_variant;    /* 0 => default; see DESIGN.md "kernel variants" */
-    uint32_t _reserved[7];
+    /* 1 (or 0): frames execute one after another on the context's stream.  2: vrt_dispatch alternates
+     * between two internal streams, each with its own target image, so the tail of one frame overlaps
+     * the start of the next (two frames in flight, as a swapchain would have).  Ignored (1) when a
+     * caller stream / external target or counters are in use. */
+    uint32_t frames_in_flight;
+    uint32_t _reserved[6];
 } vrt_config;
 
 typedef struct vrt_ctx vrt_ctx;
@@ -207,6 +212,12 @@ typedef struct vrt_counters {
     uint64_t rays, status_loads, bricks_entered, voxel_steps, hits, grid_steps;
 } vrt_counters;
 int vrt_get_counters(vrt_ctx *ctx, vrt_counters *out);
+
+/* Measurement aid: render one frame with per-wave begin/end timestamps (100 MHz wall clock) and copy
+ * them to `out` as pairs, `capacity_pairs` >= waves launched (4 per owned tile).  Returns the number of
+ * pairs written through *n_pairs.  Not part of the reference's interface. */
+int vrt_trace_wave_timeline(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint64_t *out,
+                            uint64_t capacity_pairs, uint64_t *n_pairs);
 
 const char *vrt_last_error(const vrt_ctx *ctx); /* ctx may be NULL: create errors */
 uint32_t vrt_abi_version(void);

@@ -119,3 +119,37 @@ def test_sharded_tiles_reassemble_to_full_frame():
     torch.cuda.synchronize()
     rt.deinit()
     assert np.array_equal(out.cpu().numpy().reshape(w.height, w.width, 4), u_full)
+
+
+def test_two_frames_in_flight_give_the_same_frames_and_respect_uploads():
+    """frames_in_flight = 2: frames alternate between two streams/targets; every frame still equals
+    the single-stream result, and a grid edit between frames is seen by the next frame on either stream."""
+    w = W.Workload("t", 320, 200, 64, 4, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    ref = {}
+    for view in ["V0", "V1", "V2"]:
+        _, ref[view], _, _ = _run_hip(w, grid, view, counters=False)
+    rt = W.make_renderer(w, grid, frames_in_flight=2)
+    seq = ["V0", "V1", "V2", "V1", "V0", "V2", "V2"]
+    for view in seq:  # queue without reading: frames overlap
+        W.set_view(rt, view)
+        rt.draw()
+    assert np.array_equal(rt.read_rgba8(), ref[seq[-1]])
+    for view in seq:  # read every frame
+        W.set_view(rt, view)
+        rt.draw()
+        assert np.array_equal(rt.read_rgba8(), ref[view])
+    # edit the grid between frames: both slots must see it
+    for y in range(20, 60):
+        grid.insert(31, y, 31, 7)
+        grid.insert(32, y, 31, 7)
+    rt.update_grid_delta()
+    W.set_view(rt, "V1")
+    rt.draw()
+    a = rt.read_rgba8().copy()
+    rt.draw()
+    b = rt.read_rgba8().copy()
+    rt.deinit()
+    _, want, _, _ = _run_hip(w, grid, "V1", counters=False)
+    assert np.array_equal(a, want) and np.array_equal(b, want)
+    assert not np.array_equal(want, ref["V1"])

@@ -88,7 +88,8 @@ class Config(C.Structure):  # vrt_config
         ("external_target_rgba32f", C.c_void_p),
         ("stream", C.c_void_p),
         ("kernel_variant", C.c_uint32),
-        ("_reserved", C.c_uint32 * 7),
+        ("frames_in_flight", C.c_uint32),
+        ("_reserved", C.c_uint32 * 6),
     ]
 
 
@@ -147,6 +148,7 @@ SIGNATURES = {
     "vrt_assemble_frame": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_uint32]),
     "vrt_last_kernel_ms": (C.c_double, [_ctx]),
     "vrt_get_counters": (C.c_int, [_ctx, _P(Counters)]),
+    "vrt_trace_wave_timeline": (C.c_int, [_ctx, _P(CameraDevice), _P(SunDevice), C.c_void_p, C.c_uint64, _P(C.c_uint64)]),
     "vrt_grid_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _P(GridConfig), _P(_grid)]),
     "vrt_grid_destroy": (None, [_grid]),
     "vrt_grid_insert": (C.c_int, [_grid, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint8]),

@@ -40,6 +40,16 @@ struct vrt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // second frame slot (frames_in_flight == 2): own stream + own target images
+    uint32_t frames_in_flight = 1;
+    hipStream_t stream_b = nullptr;
+    uint8_t *target8_b = nullptr;
+    float *target32f_b = nullptr;
+    hipEvent_t ev_b_done = nullptr, ev_upload = nullptr;
+    bool b_pending = false;          // stream_b has frames the primary stream has not been ordered after
+    uint64_t upload_seq = 0, b_seen_upload = 0;
+    uint32_t frame_seq = 0;
+    int last_slot = 0;
     void *dbuf[VRT_BUF_COUNT] = {};
     uint64_t dsize[VRT_BUF_COUNT] = {};
     uint8_t *target8 = nullptr;
@@ -115,6 +125,14 @@ void free_ctx(vrt_ctx *c) {
     }
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->stream_b) {
+        (void)hipStreamSynchronize(c->stream_b);
+        (void)hipStreamDestroy(c->stream_b);
+    }
+    if (c->target8_b) (void)hipFree(c->target8_b);
+    if (c->target32f_b) (void)hipFree(c->target32f_b);
+    if (c->ev_b_done) (void)hipEventDestroy(c->ev_b_done);
+    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -131,9 +149,28 @@ int finish_frame(vrt_ctx *c) {
     return VRT_OK;
 }
 
+// Scene writes happen on the primary stream.  With two frames in flight they must not overtake a frame
+// that is still reading the scene on stream_b, and later frames on stream_b must see them.
+int begin_scene_write(vrt_ctx *c) {
+    if (c->stream_b && c->b_pending) {
+        VRT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_b_done, 0));
+        c->b_pending = false;
+    }
+    return VRT_OK;
+}
+int end_scene_write(vrt_ctx *c) {
+    if (c->stream_b) {
+        VRT_HIP(c, hipEventRecord(c->ev_upload, c->stream));
+        c->upload_seq++;
+    }
+    return VRT_OK;
+}
+
 int copy_h2d(vrt_ctx *c, void *dst, const void *src, uint64_t nbytes) {
     const uint8_t *s = static_cast<const uint8_t *>(src);
     uint8_t *d = static_cast<uint8_t *>(dst);
+    int rc0 = begin_scene_write(c);
+    if (rc0 != VRT_OK) return rc0;
     while (nbytes) {
         const int slot = c->staging_next;
         c->staging_next = (slot + 1) % kStagingSlots;
@@ -150,7 +187,7 @@ int copy_h2d(vrt_ctx *c, void *dst, const void *src, uint64_t nbytes) {
         d += n;
         nbytes -= n;
     }
-    return VRT_OK;
+    return end_scene_write(c);
 }
 
 } // namespace
@@ -263,6 +300,21 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         c->own_t32 = true;
         VRT_CREATE_HIP(hipMemsetAsync(c->target32f, 0, c->target_pixels * 16u, c->stream));
     }
+    if (cfg->frames_in_flight == 2 && !cfg->stream && !cfg->external_target_rgba8 && !cfg->external_target_rgba32f && !cfg->enable_counters) {
+        c->frames_in_flight = 2;
+        VRT_CREATE_HIP(hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+        VRT_CREATE_HIP(hipEventCreateWithFlags(&c->ev_b_done, hipEventDisableTiming));
+        VRT_CREATE_HIP(hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->target8_b), c->target_pixels * 4u));
+        VRT_CREATE_HIP(hipMemsetAsync(c->target8_b, 0, c->target_pixels * 4u, c->stream));
+        if (c->target32f) {
+            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->target32f_b), c->target_pixels * 16u));
+            VRT_CREATE_HIP(hipMemsetAsync(c->target32f_b, 0, c->target_pixels * 16u, c->stream));
+        }
+    } else if (cfg->frames_in_flight > 2) {
+        free_ctx(c);
+        return fail(nullptr, VRT_E_INVALID_ARG, "frames_in_flight must be 0, 1 or 2");
+    }
     if (cfg->enable_counters) {
         VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_counters), sizeof(vrt::DeviceCounters)));
         VRT_CREATE_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(vrt::DeviceCounters), c->stream));
@@ -356,6 +408,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         c->kernel_name += "[LDS structure > 64 KiB: global-memory variant]";
     }
     // the status bitmap is read 16 bytes at a time by the LDS-staging variant: the +16 slack of dbuf covers the tail
+    if (c->stream_b) {
+        // everything enqueued on the primary stream so far (clears) precedes the first frame on stream_b
+        VRT_CREATE_HIP(hipEventRecord(c->ev_upload, c->stream));
+        c->upload_seq = 1;
+    }
 #undef VRT_CREATE_HIP
     *out = c;
     return VRT_OK;
@@ -399,11 +456,13 @@ int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, cons
         VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (id == VRT_BUF_BRICK_STATUS) ctx->status_dirty = true;
+    const int rcb = begin_scene_write(ctx);
+    if (rcb != VRT_OK) return rcb;
     VRT_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->dbuf[id]) + byte_offset, dev_src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
-    return VRT_OK;
+    return end_scene_write(ctx);
 }
 
-static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames) {
+static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames, bool primary_only = false) {
     if (!ctx || !camera || !sun || frames == 0) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL camera/sun or zero frames") : VRT_E_INVALID_ARG;
     if (camera->image_width != ctx->cfg.width || camera->image_height != ctx->cfg.height)
         return fail(ctx, VRT_E_INVALID_ARG, "camera image size differs from the target image");
@@ -420,20 +479,49 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     if (ctx->d_counters) VRT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(vrt::DeviceCounters), ctx->stream));
     if (ctx->status_dirty) {
         // refresh the derived block words / filter from the uploaded status bits (stream-ordered after the uploads)
+        int rcw = begin_scene_write(ctx);
+        if (rcw != VRT_OK) return rcw;
         VRT_HIP(ctx, vrt::launch_build_status_blocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
+        rcw = end_scene_write(ctx);
+        if (rcw != VRT_OK) return rcw;
         ctx->status_dirty = false;
+    }
+    // max_bounce <= 1 ("only primary ray" + its shadow ray): the bounce loop runs at most once
+    const vrt::KernelFn fn = (camera->max_bounce <= 1) ? ctx->kernel_single : ctx->kernel;
+
+    const bool slot_b = ctx->stream_b && frames == 1 && !primary_only && (ctx->frame_seq & 1u);
+    if (slot_b) {
+        // second frame slot: its own stream and target; ordered after every scene write so far
+        if (ctx->b_seen_upload != ctx->upload_seq) {
+            VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->ev_upload, 0));
+            ctx->b_seen_upload = ctx->upload_seq;
+        }
+        vrt::TraceParams pb = ctx->params;
+        pb.target_rgba8 = ctx->target8_b;
+        pb.target_rgba32f = ctx->target32f_b;
+        VRT_HIP(ctx, vrt::launch_trace(fn, pb, ctx->lds_bytes, ctx->stream_b));
+        VRT_HIP(ctx, hipEventRecord(ctx->ev_b_done, ctx->stream_b));
+        ctx->b_pending = true;
+        ctx->frame_seq++;
+        ctx->last_slot = 1;
+        return VRT_OK;
+    }
+    if (ctx->stream_b && (frames > 1 || primary_only) && ctx->b_pending) {
+        // timed back-to-back launches: do not let a frame on the other stream run underneath them
+        VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_b_done, 0));
+        ctx->b_pending = false;
     }
     VRT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     if (ctx->params.tile_order == 5u && ctx->shard.owned_tiles > 1u) {
         // re-sort the tile list by last frame's measured cost (inside the timed region: it is per-frame work)
         VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule, ctx->shard.owned_tiles, ctx->stream));
     }
-    // max_bounce <= 1 ("only primary ray" + its shadow ray): the bounce loop runs at most once
-    const vrt::KernelFn fn = (camera->max_bounce <= 1) ? ctx->kernel_single : ctx->kernel;
     for (uint32_t f = 0; f < frames; f++) VRT_HIP(ctx, vrt::launch_trace(fn, ctx->params, ctx->lds_bytes, ctx->stream));
     VRT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->timed_frames = frames;
     ctx->in_flight = true;
+    ctx->frame_seq++;
+    ctx->last_slot = 0;
     return VRT_OK;
 }
 
@@ -449,6 +537,10 @@ int vrt_wait(vrt_ctx *ctx) {
     const int rc = finish_frame(ctx);
     if (rc != VRT_OK) return rc;
     VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream_b) {
+        VRT_HIP(ctx, hipStreamSynchronize(ctx->stream_b));
+        ctx->b_pending = false;
+    }
     return VRT_OK;
 }
 
@@ -466,20 +558,23 @@ static int read_back(vrt_ctx *ctx, void *dst, uint64_t nbytes, const void *src, 
     DeviceGuard dg(ctx->device);
     const int rc = finish_frame(ctx);
     if (rc != VRT_OK) return rc;
-    VRT_HIP(ctx, hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
-    VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const hipStream_t s = (ctx->last_slot == 1) ? ctx->stream_b : ctx->stream; // the stream that rendered the most recent frame
+    VRT_HIP(ctx, hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, s));
+    VRT_HIP(ctx, hipStreamSynchronize(s));
     return VRT_OK;
 }
 
 int vrt_read_rgba8(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
-    return read_back(ctx, dst, nbytes, ctx ? ctx->target8 : nullptr, ctx ? ctx->target_pixels * 4u : 0);
+    return read_back(ctx, dst, nbytes, ctx ? (ctx->last_slot == 1 ? ctx->target8_b : ctx->target8) : nullptr, ctx ? ctx->target_pixels * 4u : 0);
 }
 int vrt_read_rgba32f(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
-    return read_back(ctx, dst, nbytes, ctx ? ctx->target32f : nullptr, ctx ? ctx->target_pixels * 16u : 0);
+    return read_back(ctx, dst, nbytes, ctx ? (ctx->last_slot == 1 ? ctx->target32f_b : ctx->target32f) : nullptr,
+                     ctx ? ctx->target_pixels * 16u : 0);
 }
 int vrt_set_target(vrt_ctx *ctx, void *rgba8, void *rgba32f) {
     if (!ctx) return VRT_E_INVALID_ARG;
     if (!rgba8) return fail(ctx, VRT_E_INVALID_ARG, "rgba8 target is NULL");
+    if (ctx->stream_b) return fail(ctx, VRT_E_STATE, "vrt_set_target needs frames_in_flight = 1");
     DeviceGuard dg(ctx->device);
     if (ctx->own_t8 && ctx->target8) {
         VRT_HIP(ctx, hipStreamSynchronize(ctx->stream)); // frames in flight still write the owned image
@@ -497,8 +592,8 @@ int vrt_set_target(vrt_ctx *ctx, void *rgba8, void *rgba32f) {
     ctx->params.target_rgba32f = ctx->target32f;
     return VRT_OK;
 }
-void *vrt_device_target_rgba8(vrt_ctx *ctx) { return ctx ? ctx->target8 : nullptr; }
-void *vrt_device_target_rgba32f(vrt_ctx *ctx) { return ctx ? ctx->target32f : nullptr; }
+void *vrt_device_target_rgba8(vrt_ctx *ctx) { return ctx ? (ctx->last_slot == 1 ? ctx->target8_b : ctx->target8) : nullptr; }
+void *vrt_device_target_rgba32f(vrt_ctx *ctx) { return ctx ? (ctx->last_slot == 1 ? ctx->target32f_b : ctx->target32f) : nullptr; }
 uint64_t vrt_target_bytes_rgba8(const vrt_ctx *ctx) { return ctx ? ctx->target_pixels * 4u : 0; }
 
 int vrt_get_shard_info(const vrt_ctx *ctx, vrt_shard_info *out) {
@@ -513,6 +608,29 @@ int vrt_assemble_frame(vrt_ctx *ctx, const void *gathered, void *dst_frame, uint
     DeviceGuard dg(ctx->device);
     VRT_HIP(ctx, vrt::launch_assemble(gathered, dst_frame, bytes_per_pixel, ctx->cfg.width, ctx->cfg.height, ctx->shard.tiles_x,
                                       ctx->shard.shard_count, ctx->shard.tiles_per_rank, ctx->stream));
+    return VRT_OK;
+}
+
+int vrt_trace_wave_timeline(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint64_t *out, uint64_t capacity_pairs,
+                            uint64_t *n_pairs) {
+    if (!ctx || !out || !n_pairs) return VRT_E_INVALID_ARG;
+    const uint64_t waves = (uint64_t)ctx->shard.owned_tiles * 4u;
+    if (capacity_pairs < waves) return fail(ctx, VRT_E_OUT_OF_RANGE, "timeline buffer too small");
+    DeviceGuard dg(ctx->device);
+    unsigned long long *d = nullptr;
+    VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), waves * 16u));
+    VRT_HIP(ctx, hipMemsetAsync(d, 0, waves * 16u, ctx->stream));
+    ctx->params.wave_timeline = d;
+    const int rc = do_dispatch(ctx, camera, sun, 1, true);
+    ctx->params.wave_timeline = nullptr;
+    if (rc != VRT_OK) {
+        (void)hipFree(d);
+        return rc;
+    }
+    VRT_HIP(ctx, hipMemcpyAsync(out, d, waves * 16u, hipMemcpyDeviceToHost, ctx->stream));
+    VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d);
+    *n_pairs = waves;
     return VRT_OK;
 }
 

@@ -48,6 +48,7 @@ struct TraceParams {
     // cost-feedback schedule (tile_order 5): tile_cost[i] accumulates the wave-cycles the i-th owned
     // tile took in the previous frame(s); tile_schedule[k] is the owned tile the k-th workgroup renders
     uint32_t *tile_cost;
+    unsigned long long *wave_timeline;   // optional (measurement): [begin,end] wall-clock ticks per wave, 2 u64 each
     const uint32_t *tile_schedule;
     uint32_t tile_stride;                // tile_order 4: multiplier coprime to owned_tiles
     uint32_t wave_groups;                // 1: launch one 64-thread workgroup per 8x8 block instead of 256 per 16x16 tile

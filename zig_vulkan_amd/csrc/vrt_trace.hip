@@ -552,6 +552,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TracePa
     const uint32_t py = tile_y * kTileH + in_y;
 
     const unsigned long long t_begin = (p.tile_order == 5u) ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long wall_begin = p.wave_timeline ? wall_clock64() : 0ull;
     Cnt<COUNT> c;
     const bool inside = (px < p.width) && (py < p.height); // comp:155-159
     if (inside) {
@@ -587,6 +588,11 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TracePa
         if (p.target_rgba32f) {
             reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(color.x, color.y, color.z, 1.0f);
         }
+    }
+    if (p.wave_timeline && lane == 0) {
+        const size_t w_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        p.wave_timeline[2 * w_id] = wall_begin;
+        p.wave_timeline[2 * w_id + 1] = wall_clock64();
     }
     if (p.tile_order == 5u) {
         // one relaxed add per wave: the tile's cost for the next frame's schedule
@@ -732,7 +738,7 @@ static KernelFn pick_variant(uint32_t variant) {
 }
 
 uint32_t resolve_variant(uint32_t variant) {
-    return (variant & 0xFFu) == kVariantDefault ? ((variant & ~0xFFu) | (uint32_t)kVariantLiteral) : variant;
+    return (variant & 0xFFu) == kVariantDefault ? ((variant & ~0xFFu) | (uint32_t)kVariantLinearLds) : variant;
 }
 
 // single_bounce: the specialisation for push_constant.max_bounce <= 1 (no scatter evaluation)

@@ -202,6 +202,7 @@ class Config:  # VoxelRT.Config, VoxelRT.zig:22-28 (+ the knobs of this implemen
     shard_rank: int = 0
     shard_count: int = 1
     kernel_variant: int = 0
+    frames_in_flight: int = 1
     stream: int = 0
     external_target_rgba8: int = 0
     external_target_rgba32f: int = 0
@@ -231,6 +232,7 @@ class VoxelRT:
         cfg.shard_rank = config.shard_rank
         cfg.shard_count = config.shard_count
         cfg.kernel_variant = config.kernel_variant
+        cfg.frames_in_flight = config.frames_in_flight
         cfg.stream = config.stream or None
         cfg.external_target_rgba8 = config.external_target_rgba8 or None
         cfg.external_target_rgba32f = config.external_target_rgba32f or None
@@ -319,6 +321,15 @@ class VoxelRT:
         c = L.Counters()
         check(lib.vrt_get_counters(self._h, C.byref(c)), self._h)
         return {k: getattr(c, k) for k, _ in L.Counters._fields_}
+
+    def wave_timeline(self) -> np.ndarray:
+        """One frame with per-wave [begin, end] wall-clock ticks (100 MHz); shape (waves, 2)."""
+        n = self.shard_info().owned_tiles * 4
+        out = np.zeros((n, 2), dtype=np.uint64)
+        got = C.c_uint64()
+        check(lib.vrt_trace_wave_timeline(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data), out.ctypes.data, n,
+                                          C.byref(got)), self._h)
+        return out[:got.value]
 
     def kernel_name(self) -> str:
         return lib.vrt_kernel_name(self._h).decode()
