@@ -212,6 +212,10 @@ typedef struct vrt_counters {
     uint64_t rays, status_loads, bricks_entered, voxel_steps, hits, grid_steps;
 } vrt_counters;
 int vrt_get_counters(vrt_ctx *ctx, vrt_counters *out);
+/* Wave-level execution counts of the last dispatch (enable_counters=1), a tuning aid: out[0] = trips
+ * of the brick-level loop, out[1] = executions of the voxel-level walk, out[2] = trips of the
+ * voxel-level loop, each counted once per wave however many lanes took part. */
+int vrt_get_wave_counters(vrt_ctx *ctx, uint64_t out[3]);
 
 /* Measurement aid: render one frame with per-wave begin/end timestamps (100 MHz wall clock) and copy
  * them to `out` as pairs, `capacity_pairs` >= waves launched (4 per owned tile).  Returns the number of

@@ -148,6 +148,7 @@ SIGNATURES = {
     "vrt_assemble_frame": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_uint32]),
     "vrt_last_kernel_ms": (C.c_double, [_ctx]),
     "vrt_get_counters": (C.c_int, [_ctx, _P(Counters)]),
+    "vrt_get_wave_counters": (C.c_int, [_ctx, _P(C.c_uint64 * 3)]),
     "vrt_trace_wave_timeline": (C.c_int, [_ctx, _P(CameraDevice), _P(SunDevice), C.c_void_p, C.c_uint64, _P(C.c_uint64)]),
     "vrt_grid_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _P(GridConfig), _P(_grid)]),
     "vrt_grid_destroy": (None, [_grid]),

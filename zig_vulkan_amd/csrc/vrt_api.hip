@@ -652,6 +652,21 @@ int vrt_get_counters(vrt_ctx *ctx, vrt_counters *out) {
     return VRT_OK;
 }
 
+int vrt_get_wave_counters(vrt_ctx *ctx, uint64_t out[3]) {
+    if (!ctx || !out) return VRT_E_INVALID_ARG;
+    if (!ctx->d_counters) return fail(ctx, VRT_E_STATE, "context created with enable_counters = 0");
+    DeviceGuard dg(ctx->device);
+    const int rc = finish_frame(ctx);
+    if (rc != VRT_OK) return rc;
+    vrt::DeviceCounters h;
+    VRT_HIP(ctx, hipMemcpyAsync(&h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out[0] = h.wave_grid_iters;
+    out[1] = h.wave_brick_walks;
+    out[2] = h.wave_voxel_iters;
+    return VRT_OK;
+}
+
 // VoxelRT.init's transferGridState (VoxelRT.zig:62) plus the five arrays in full.
 int vrt_upload_grid(vrt_ctx *ctx, vrt_grid *gh) {
     if (!ctx || !gh) return VRT_E_INVALID_ARG;

@@ -19,6 +19,8 @@ static_assert(sizeof(vrt_material) == 20, "Material is 20 bytes (gpu_types.zig:1
 
 struct DeviceCounters {
     unsigned long long rays, status_loads, bricks_entered, voxel_steps, hits, grid_steps;
+    // wave-level executions (one count per wave per trip, whatever the number of active lanes)
+    unsigned long long wave_grid_iters, wave_brick_walks, wave_voxel_iters;
 };
 
 // Kernel argument block.  Passed by value: lives in the kernarg segment and is

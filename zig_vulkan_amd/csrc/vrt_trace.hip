@@ -40,6 +40,7 @@ struct Hit {
 template <bool COUNT>
 struct Cnt {
     uint32_t rays = 0, status_loads = 0, bricks_entered = 0, voxel_steps = 0, hits = 0, grid_steps = 0;
+    uint32_t wave_grid_iters = 0, wave_brick_walks = 0, wave_voxel_iters = 0;
 };
 template <>
 struct Cnt<false> {};
@@ -47,6 +48,11 @@ struct Cnt<false> {};
 #define VRT_COUNT(field)   \
     if constexpr (COUNT) { \
         c.field++;         \
+    }
+// counts once per wave per execution: only the first active lane increments
+#define VRT_COUNT_WAVE(field)                                                              \
+    if constexpr (COUNT) {                                                                 \
+        if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) c.field++; \
     }
 
 // comp:180-184
@@ -192,6 +198,7 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
     bool more = (unsigned)px < (unsigned)B && (unsigned)py < (unsigned)B && (unsigned)pz < (unsigned)B && w.t_value <= local_t_max;
     while (more) {
         VRT_COUNT(voxel_steps);
+        VRT_COUNT_WAVE(wave_voxel_iters);
         bool solid;
         if constexpr (LITERAL) {
             const uint32_t byte = p.brick_occupancy[brick_index * (uint32_t)(B * B * B / 8) + (voxel_index >> 3)];
@@ -286,6 +293,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     bool more = (unsigned)px < (unsigned)dx && (unsigned)py < (unsigned)dy && (unsigned)pz < (unsigned)dz;
     while (more) { // single-exit loop, see brick_walk
         VRT_COUNT(grid_steps);
+        VRT_COUNT_WAVE(wave_grid_iters);
         bool occupied;
         if constexpr (MODE == kStatusLinearLds) {
             if constexpr (COUNT) {
@@ -341,6 +349,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
             hit.t = global_t_value;
             const uint32_t brick_index = p.brick_index[grid_index]; // comp:337
             VRT_COUNT(bricks_entered);
+            VRT_COUNT_WAVE(wave_brick_walks);
             const bool found = brick_walk<B, COUNT, MODE == kStatusLinear || MODE == kStatusLinearAlways || MODE == kStatusLinearLds>(p, r, s, g_scale, brick_index, brick_min, hit, axis, c);
             stop = found ? -1 : ((global_t_value <= t_max) ? 0 : -2);
         }
@@ -601,9 +610,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TracePa
     }
     if constexpr (COUNT) {
         // wave-level reduction, then one atomic per wave per counter
-        unsigned long long v[6] = {c.rays, c.status_loads, c.bricks_entered, c.voxel_steps, c.hits, c.grid_steps};
+        unsigned long long v[9] = {c.rays, c.status_loads, c.bricks_entered, c.voxel_steps, c.hits, c.grid_steps,
+                                   c.wave_grid_iters, c.wave_brick_walks, c.wave_voxel_iters};
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
+        for (int k = 0; k < 9; k++) {
             unsigned long long s = v[k];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             v[k] = s;
@@ -615,6 +625,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TracePa
             atomicAdd(&p.counters->voxel_steps, v[3]);
             atomicAdd(&p.counters->hits, v[4]);
             atomicAdd(&p.counters->grid_steps, v[5]);
+            atomicAdd(&p.counters->wave_grid_iters, v[6]);
+            atomicAdd(&p.counters->wave_brick_walks, v[7]);
+            atomicAdd(&p.counters->wave_voxel_iters, v[8]);
         }
     }
 }

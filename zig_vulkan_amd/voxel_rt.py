@@ -331,5 +331,10 @@ class VoxelRT:
                                           C.byref(got)), self._h)
         return out[:got.value]
 
+    def wave_counters(self) -> dict:
+        out = (C.c_uint64 * 3)()
+        check(lib.vrt_get_wave_counters(self._h, C.byref(out)), self._h)
+        return {"wave_grid_iters": out[0], "wave_brick_walks": out[1], "wave_voxel_iters": out[2]}
+
     def kernel_name(self) -> str:
         return lib.vrt_kernel_name(self._h).decode()
