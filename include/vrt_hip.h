@@ -301,6 +301,42 @@ int vrt_synth_terrain(vrt_grid *g, uint64_t seed);
 /* Sparse field of solid spheres; fraction ~p of 32-voxel blocks occupied. */
 int vrt_synth_sparse(vrt_grid *g, uint64_t seed, float p);
 
+/* ---- MagicaVoxel .vox input --------------------------------------------
+ * Host-side parser with the reference's semantics (src/modules/voxel_rt/vox/loader.zig:41-229,
+ * types.zig): MAIN, optional PACK, per model SIZE + XYZI, then an optional RGBA chunk; unknown
+ * chunks are skipped 4 bytes at a time; without RGBA the default palette applies.  Unlike the
+ * reference (loader.zig:90 "TODO: pos will cause out of bounds easily") every read is bounds
+ * checked and a truncated file is VRT_VOX_E_INVALID_FILE_CONTENT. */
+enum { /* loader.zig:33-41 ParseError */
+    VRT_VOX_E_INVALID_ID = -100,
+    VRT_VOX_E_EXPECTED_SIZE_HEADER = -101,
+    VRT_VOX_E_EXPECTED_XYZI_HEADER = -102,
+    VRT_VOX_E_EXPECTED_RGBA_HEADER = -103,
+    VRT_VOX_E_UNEXPECTED_VERSION = -104,
+    VRT_VOX_E_INVALID_FILE_CONTENT = -105,
+    VRT_VOX_E_MULTIPLE_PACK_CHUNKS = -106
+};
+typedef struct vrt_vox vrt_vox;
+typedef struct vrt_vox_xyzi { uint8_t x, y, z, color_index; } vrt_vox_xyzi; /* types.zig Chunk.XyziElement */
+typedef struct vrt_vox_rgba { uint8_t r, g, b, a; } vrt_vox_rgba;           /* types.zig Chunk.RgbaElement */
+/* validateHeader (loader.zig:231-245): "VOX ", version byte 150, "MAIN" at offset 8. */
+int vrt_vox_validate_header(const void *buffer, uint64_t nbytes);
+/* parseBuffer(strict, allocator, buffer) (loader.zig:41). */
+int vrt_vox_parse(const void *buffer, uint64_t nbytes, int strict, vrt_vox **out);
+void vrt_vox_destroy(vrt_vox *v);
+uint32_t vrt_vox_num_models(const vrt_vox *v);
+int vrt_vox_model_size(const vrt_vox *v, uint32_t model, int32_t size_xyz[3]);
+const vrt_vox_xyzi *vrt_vox_model_voxels(const vrt_vox *v, uint32_t model, uint64_t *count);
+const vrt_vox_rgba *vrt_vox_palette(const vrt_vox *v); /* 256 entries */
+/* Palette -> materials as the reference app maps them (src/main.zig:93-106): alpha/255 < 0.8 =>
+ * dielectric with index 1.52, else lambertian; albedo = rgb/255.  Writes palette entries
+ * [0, count) to out[0..count). */
+int vrt_vox_materials(const vrt_vox *v, vrt_material *out, uint32_t count);
+/* Insert one model into a grid as the reference app does (src/main.zig:109-117): voxel (x,y,z) goes to
+ * grid (x + off_x, z + off_y, y + off_z) — .vox is z-up — with material color_index + material_offset. */
+int vrt_vox_insert(vrt_grid *g, const vrt_vox *v, uint32_t model, uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                   uint32_t material_offset);
+
 #ifdef __cplusplus
 }
 #endif

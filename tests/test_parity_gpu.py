@@ -153,3 +153,35 @@ def test_two_frames_in_flight_give_the_same_frames_and_respect_uploads():
     _, want, _, _ = _run_hip(w, grid, "V1", counters=False)
     assert np.array_equal(a, want) and np.array_equal(b, want)
     assert not np.array_equal(want, ref["V1"])
+
+
+def test_vox_model_scene_like_main_zig():
+    """The reference app's scene build (src/main.zig:84-138): a .vox model inserted into the grid at an
+    offset, its palette appended after the 8 terrain materials, then terrain — rendered with the
+    reference defaults (spp 2, max_bounce 2, sun) and compared with the oracle."""
+    import struct
+    from tests.test_vox import make_vox
+    from zig_vulkan_amd import BrickGrid, default_materials, vox
+    voxels = [(x, y, z, 1 + ((x + 2 * y + 3 * z) % 5)) for x in range(12) for y in range(12) for z in range(20)
+              if (x - 6) ** 2 + (y - 6) ** 2 + ((z - 10) * 0.6) ** 2 < 30]
+    rgba = bytearray(1024)
+    for i, (r, g, b, a) in enumerate([(200, 30, 30, 255), (30, 200, 30, 255), (40, 40, 220, 120), (250, 250, 60, 255), (90, 90, 90, 255)]):
+        rgba[4 * i:4 * i + 4] = bytes([r, g, b, a])  # file colour i -> palette entry i+1
+    model = vox.parse_buffer(make_vox([((12, 12, 20), voxels)], rgba=bytes(rgba)))
+    grid = BrickGrid(16, 16, 16, min_point=(-32, -32, -32), scale=4.0, brick_dimension=4)
+    model.insert_into(grid, 0, offset=(26, 34, 26), material_offset=8)
+    grid.synth_terrain(420)
+    materials = default_materials(256)
+    pal = model.materials(248)
+    materials[8:] = pal[:248]
+    w = W.Workload("t", 256, 160, 64, 4, 2, 2, True, 5.0)
+    rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True)
+    rt.push_materials(materials)
+    W.set_view(rt, "V2")
+    rt.draw()
+    f, u, c = rt.read_rgba32f(), rt.read_rgba8(), rt.counters()
+    pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+    rt.deinit()
+    fo, uo, co = O.render(oracle_scene_from_grid(grid, materials), pc)
+    _compare(f, u, c, fo, uo, co)
+    assert (materials["type"][8:14] == [0, 0, 0, 2, 0, 0]).all()  # palette entry 3 (alpha 120) is glass

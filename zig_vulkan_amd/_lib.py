@@ -168,7 +168,24 @@ SIGNATURES = {
     "vrt_default_materials": (C.c_uint32, [_P(Material), C.c_uint32]),
     "vrt_synth_terrain": (C.c_int, [_grid, C.c_uint64]),
     "vrt_synth_sparse": (C.c_int, [_grid, C.c_uint64, C.c_float]),
+    "vrt_vox_validate_header": (C.c_int, [C.c_char_p, C.c_uint64]),
+    "vrt_vox_parse": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int, _P(C.c_void_p)]),
+    "vrt_vox_destroy": (None, [C.c_void_p]),
+    "vrt_vox_num_models": (C.c_uint32, [C.c_void_p]),
+    "vrt_vox_model_size": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_int32 * 3)]),
+    "vrt_vox_model_voxels": (C.c_void_p, [C.c_void_p, C.c_uint32, _P(C.c_uint64)]),
+    "vrt_vox_palette": (C.c_void_p, [C.c_void_p]),
+    "vrt_vox_materials": (C.c_int, [C.c_void_p, _P(Material), C.c_uint32]),
+    "vrt_vox_insert": (C.c_int, [_grid, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
 }
+
+# loader.zig:33-41 ParseError
+VOX_E_INVALID_ID, VOX_E_EXPECTED_SIZE_HEADER, VOX_E_EXPECTED_XYZI_HEADER, VOX_E_EXPECTED_RGBA_HEADER = -100, -101, -102, -103
+VOX_E_UNEXPECTED_VERSION, VOX_E_INVALID_FILE_CONTENT, VOX_E_MULTIPLE_PACK_CHUNKS = -104, -105, -106
+ERROR_NAMES.update({VOX_E_INVALID_ID: "InvalidId", VOX_E_EXPECTED_SIZE_HEADER: "ExpectedSizeHeader",
+                    VOX_E_EXPECTED_XYZI_HEADER: "ExpectedXyziHeader", VOX_E_EXPECTED_RGBA_HEADER: "ExpectedRgbaHeader",
+                    VOX_E_UNEXPECTED_VERSION: "UnexpectedVersion", VOX_E_INVALID_FILE_CONTENT: "InvalidFileContent",
+                    VOX_E_MULTIPLE_PACK_CHUNKS: "MultiplePackChunks"})
 
 
 def _load() -> C.CDLL:
