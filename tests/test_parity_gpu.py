@@ -184,4 +184,5 @@ def test_vox_model_scene_like_main_zig():
     rt.deinit()
     fo, uo, co = O.render(oracle_scene_from_grid(grid, materials), pc)
     _compare(f, u, c, fo, uo, co)
-    assert (materials["type"][8:14] == [0, 0, 0, 2, 0, 0]).all()  # palette entry 3 (alpha 120) is glass
+    # palette entry 0 is (0,0,0,1) (alpha 1/255: glass, loader.zig:169-174); entry 3 has alpha 120: glass
+    assert (materials["type"][8:14] == [2, 0, 0, 2, 0, 0]).all()
