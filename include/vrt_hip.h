@@ -301,6 +301,22 @@ int vrt_synth_terrain(vrt_grid *g, uint64_t seed);
 /* Sparse field of solid spheres; fraction ~p of 32-voxel blocks occupied. */
 int vrt_synth_sparse(vrt_grid *g, uint64_t seed, float p);
 
+/* ---- present / denoise pass ------------------------------------------------
+ * The step after the path: the reference samples the traced image in a fullscreen-quad fragment pass
+ * with the "sirBird" denoiser (assets/shaders/image.frag:18-78; parameters GraphicsPipeline.Config,
+ * GraphicsPipeline.zig:34-39: samples 20, bias 0.6, multiplier 1.5, inverse hue tolerance 20) at the
+ * window resolution.  vrt_denoise runs that pass as a HIP kernel over the most recent frame of the
+ * context into a context-owned out_w x out_h image; unsharded contexts only. */
+typedef struct vrt_denoise_config {
+    int32_t samples;
+    float distribution_bias, pixel_multiplier, inverse_hue_tolerance;
+} vrt_denoise_config;
+int vrt_denoise(vrt_ctx *ctx, const vrt_denoise_config *cfg /* NULL => reference defaults */, uint32_t out_w, uint32_t out_h,
+                uint32_t want_float);
+int vrt_read_denoised_rgba8(vrt_ctx *ctx, void *dst, uint64_t nbytes);
+int vrt_read_denoised_rgba32f(vrt_ctx *ctx, void *dst, uint64_t nbytes);
+void *vrt_device_denoised_rgba8(vrt_ctx *ctx);
+
 /* ---- MagicaVoxel .vox input --------------------------------------------
  * Host-side parser with the reference's semantics (src/modules/voxel_rt/vox/loader.zig:41-229,
  * types.zig): MAIN, optional PACK, per model SIZE + XYZI, then an optional RGBA chunk; unknown

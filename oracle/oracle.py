@@ -19,8 +19,8 @@ LIB_PATH = os.path.join(_HERE, "libvrt_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "vrt_oracle.c")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("vrt_oracle.c", "denoise_oracle.c")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return LIB_PATH
 
@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
         L.oracle_adv_norm_intersect.restype = C.c_int
         L.oracle_adv_norm_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.oracle_denoise_rows.restype = None
+        L.oracle_denoise_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -179,3 +181,22 @@ def algorithmic_bytes(counters: dict, pixels: int) -> int:
     """4*S + 4*K + 1*V + 25*H per ray, summed, + 4 B per pixel stored."""
     return (4 * counters["status_loads"] + 4 * counters["bricks_entered"] + counters["voxel_steps"] + 25 * counters["hits"]
             + 4 * pixels)
+
+
+def denoise(image_rgba8: np.ndarray, out_w: int, out_h: int, samples=20, distribution_bias=0.6, pixel_multiplier=1.5,
+            inverse_hue_tolerance=20.0):
+    """image.frag over an out_w x out_h target (defaults: GraphicsPipeline.Config, GraphicsPipeline.zig:34-39).
+    Returns (rgba32f, rgba8)."""
+    L = lib()
+    img = np.ascontiguousarray(image_rgba8, dtype=np.uint8)
+    h, w = img.shape[:2]
+    pc = np.zeros(1, dtype=np.dtype([("samples", np.int32), ("b", np.float32), ("m", np.float32), ("t", np.float32)]))
+    pc[0] = (samples, distribution_bias, pixel_multiplier, inverse_hue_tolerance)
+    f32 = np.zeros((out_h, out_w, 4), dtype=np.float32)
+    u8 = np.zeros((out_h, out_w, 4), dtype=np.uint8)
+    threads = os.cpu_count() or 1
+    bands = [(y, min(y + 8, out_h)) for y in range(0, out_h, 8)]
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(lambda ab: L.oracle_denoise_rows(img.ctypes.data, w, h, pc.ctypes.data, out_w, out_h, ab[0], ab[1], f32.ctypes.data,
+                                                     u8.ctypes.data), bands))
+    return f32, u8

@@ -104,6 +104,11 @@ class Counters(C.Structure):
                 ("voxel_steps", C.c_uint64), ("hits", C.c_uint64), ("grid_steps", C.c_uint64)]
 
 
+class DenoiseConfig(C.Structure):  # GraphicsPipeline.PushConstant / Config, GraphicsPipeline.zig:27-39
+    _fields_ = [("samples", C.c_int32), ("distribution_bias", C.c_float), ("pixel_multiplier", C.c_float),
+                ("inverse_hue_tolerance", C.c_float)]
+
+
 class GridConfig(C.Structure):  # Grid.zig:13-20
     _fields_ = [("brick_alloc", C.c_uint64), ("base_t", C.c_float), ("min_point", C.c_float * 3), ("scale", C.c_float),
                 ("brick_dimension", C.c_uint32)]
@@ -144,6 +149,10 @@ SIGNATURES = {
     "vrt_device_target_rgba8": (C.c_void_p, [_ctx]),
     "vrt_device_target_rgba32f": (C.c_void_p, [_ctx]),
     "vrt_target_bytes_rgba8": (C.c_uint64, [_ctx]),
+    "vrt_denoise": (C.c_int, [_ctx, _P(DenoiseConfig), C.c_uint32, C.c_uint32, C.c_uint32]),
+    "vrt_read_denoised_rgba8": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
+    "vrt_read_denoised_rgba32f": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
+    "vrt_device_denoised_rgba8": (C.c_void_p, [_ctx]),
     "vrt_get_shard_info": (C.c_int, [_ctx, _P(ShardInfo)]),
     "vrt_assemble_frame": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_uint32]),
     "vrt_last_kernel_ms": (C.c_double, [_ctx]),

@@ -24,6 +24,8 @@ size_t trace_lds_bytes(const TraceParams &p, uint32_t variant);
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_schedule(uint32_t *cost, uint32_t *order, uint32_t n, hipStream_t stream);
 hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
+hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
+                          void *out_f32, hipStream_t stream);
 hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per_pixel, uint32_t width, uint32_t height, uint32_t tiles_x,
                            uint32_t shard_count, uint32_t tiles_per_rank, hipStream_t stream);
 } // namespace vrt
@@ -58,6 +60,9 @@ struct vrt_ctx {
     uint64_t target_pixels = 0; // pixels in the (possibly sharded, padded) target
     vrt::DeviceCounters *d_counters = nullptr;
     uint32_t *d_tile_cost = nullptr, *d_tile_schedule = nullptr; // cost-feedback tile schedule
+    void *d_denoised8 = nullptr, *d_denoised32f = nullptr;       // output of the present/denoise pass
+    uint32_t denoised_w = 0, denoised_h = 0;
+    hipStream_t denoised_stream = nullptr;
     void *d_status_blocks = nullptr; // derived: 4x4x4 block words + block filter (vrt_trace.hip)
     bool status_dirty = true;        // brick_status changed since the derived copy was built
     size_t lds_bytes = 0;
@@ -117,6 +122,8 @@ void free_ctx(vrt_ctx *c) {
     if (c->own_t32 && c->target32f) (void)hipFree(c->target32f);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_status_blocks) (void)hipFree(c->d_status_blocks);
+    if (c->d_denoised8) (void)hipFree(c->d_denoised8);
+    if (c->d_denoised32f) (void)hipFree(c->d_denoised32f);
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_schedule) (void)hipFree(c->d_tile_schedule);
     for (int i = 0; i < kStagingSlots; i++) {
@@ -595,6 +602,50 @@ int vrt_set_target(vrt_ctx *ctx, void *rgba8, void *rgba32f) {
 void *vrt_device_target_rgba8(vrt_ctx *ctx) { return ctx ? (ctx->last_slot == 1 ? ctx->target8_b : ctx->target8) : nullptr; }
 void *vrt_device_target_rgba32f(vrt_ctx *ctx) { return ctx ? (ctx->last_slot == 1 ? ctx->target32f_b : ctx->target32f) : nullptr; }
 uint64_t vrt_target_bytes_rgba8(const vrt_ctx *ctx) { return ctx ? ctx->target_pixels * 4u : 0; }
+
+int vrt_denoise(vrt_ctx *ctx, const vrt_denoise_config *cfg, uint32_t out_w, uint32_t out_h, uint32_t want_float) {
+    if (!ctx || out_w == 0 || out_h == 0) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "zero output size") : VRT_E_INVALID_ARG;
+    if (ctx->shard.shard_count > 1u) return fail(ctx, VRT_E_STATE, "vrt_denoise needs the whole frame (unsharded context)");
+    vrt_denoise_config c{20, 0.6f, 1.5f, 20.0f}; // GraphicsPipeline.Config, GraphicsPipeline.zig:34-39
+    if (cfg) c = *cfg;
+    if (c.samples < 0 || c.samples > 4096) return fail(ctx, VRT_E_INVALID_ARG, "samples out of range");
+    DeviceGuard dg(ctx->device);
+    // runs on the stream that rendered the most recent frame, so it is ordered after that frame
+    const hipStream_t s = (ctx->last_slot == 1) ? ctx->stream_b : ctx->stream;
+    if (ctx->denoised_w != out_w || ctx->denoised_h != out_h || (want_float && !ctx->d_denoised32f)) {
+        VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->stream_b) VRT_HIP(ctx, hipStreamSynchronize(ctx->stream_b));
+        if (ctx->d_denoised8) (void)hipFree(ctx->d_denoised8);
+        if (ctx->d_denoised32f) (void)hipFree(ctx->d_denoised32f);
+        ctx->d_denoised8 = ctx->d_denoised32f = nullptr;
+        VRT_HIP(ctx, hipMalloc(&ctx->d_denoised8, (size_t)out_w * out_h * 4u));
+        if (want_float) VRT_HIP(ctx, hipMalloc(&ctx->d_denoised32f, (size_t)out_w * out_h * 16u));
+        ctx->denoised_w = out_w;
+        ctx->denoised_h = out_h;
+    }
+    const void *img = (ctx->last_slot == 1) ? ctx->target8_b : ctx->target8;
+    VRT_HIP(ctx, vrt::launch_denoise(img, (int)ctx->cfg.width, (int)ctx->cfg.height, c.samples, c.distribution_bias, c.pixel_multiplier,
+                                     c.inverse_hue_tolerance, (int)out_w, (int)out_h, ctx->d_denoised8, want_float ? ctx->d_denoised32f : nullptr, s));
+    ctx->denoised_stream = s;
+    return VRT_OK;
+}
+
+static int read_denoised(vrt_ctx *ctx, void *dst, uint64_t nbytes, const void *src, uint64_t avail) {
+    if (!ctx || !dst) return VRT_E_INVALID_ARG;
+    if (!src) return fail(ctx, VRT_E_STATE, "no denoised image (call vrt_denoise first; want_float for the float image)");
+    if (nbytes > avail) return fail(ctx, VRT_E_OUT_OF_RANGE, "read exceeds the denoised image");
+    DeviceGuard dg(ctx->device);
+    VRT_HIP(ctx, hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx->denoised_stream));
+    VRT_HIP(ctx, hipStreamSynchronize(ctx->denoised_stream));
+    return VRT_OK;
+}
+int vrt_read_denoised_rgba8(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
+    return read_denoised(ctx, dst, nbytes, ctx ? ctx->d_denoised8 : nullptr, ctx ? (uint64_t)ctx->denoised_w * ctx->denoised_h * 4u : 0);
+}
+int vrt_read_denoised_rgba32f(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
+    return read_denoised(ctx, dst, nbytes, ctx ? ctx->d_denoised32f : nullptr, ctx ? (uint64_t)ctx->denoised_w * ctx->denoised_h * 16u : 0);
+}
+void *vrt_device_denoised_rgba8(vrt_ctx *ctx) { return ctx ? ctx->d_denoised8 : nullptr; }
 
 int vrt_get_shard_info(const vrt_ctx *ctx, vrt_shard_info *out) {
     if (!ctx || !out) return VRT_E_INVALID_ARG;

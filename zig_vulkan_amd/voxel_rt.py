@@ -311,6 +311,19 @@ class VoxelRT:
     def set_target(self, rgba8_ptr: int, rgba32f_ptr: int = 0) -> None:
         check(lib.vrt_set_target(self._h, rgba8_ptr, rgba32f_ptr or None), self._h)
 
+    def denoise(self, out_w: int, out_h: int, *, samples: int = 20, distribution_bias: float = 0.6, pixel_multiplier: float = 1.5,
+                inverse_hue_tolerance: float = 20.0, want_float: bool = False):
+        """The present/denoise pass (image.frag) over the most recent frame; returns rgba8 (and rgba32f)."""
+        dc = L.DenoiseConfig(samples, distribution_bias, pixel_multiplier, inverse_hue_tolerance)
+        check(lib.vrt_denoise(self._h, C.byref(dc), out_w, out_h, 1 if want_float else 0), self._h)
+        u8 = np.empty((out_h, out_w, 4), dtype=np.uint8)
+        check(lib.vrt_read_denoised_rgba8(self._h, u8.ctypes.data, u8.nbytes), self._h)
+        if not want_float:
+            return u8
+        f32 = np.empty((out_h, out_w, 4), dtype=np.float32)
+        check(lib.vrt_read_denoised_rgba32f(self._h, f32.ctypes.data, f32.nbytes), self._h)
+        return u8, f32
+
     def device_target_rgba8(self) -> int:
         return lib.vrt_device_target_rgba8(self._h)
 
