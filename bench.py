@@ -78,6 +78,27 @@ def cpu_baseline(w, grid, min_wall_s: float):
                       f"= {dt * cores:.0f} core-seconds; oracle/vrt_oracle.c gcc -O2, {cores} threads, rows handed out one at a time"}
 
 
+def hbm_traffic_from_profile(brick_dimension: int):
+    """HBM bytes per launch of the traversal kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/*_pmc.json, written by tools/summarize_prof.py; bench.py cannot run rocprofv3 on
+    itself).  FETCH_SIZE and WRITE_SIZE are in KiB, collected in separate passes.  WRITE_SIZE equals the
+    RGBA8 frame exactly (8100 KiB at 1080p); FETCH_SIZE on gfx950 reads half of a wide coalesced stream
+    (MI355X_MICROARCH.md) and is uncalibrated for this dword-gather pattern, so both the raw and the
+    doubled fetch are given and `traffic` uses the doubled (upper) figure."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None, "no profiles/*_pmc.json"
+    with open(files[-1]) as fh:
+        data = json.load(fh)
+    for name, c in data.items():
+        if "vrt_trace_kernel<%d, false" % brick_dimension in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            fetch, write = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
+            return 2.0 * fetch + write, (f"{os.path.basename(files[-1])}: FETCH_SIZE {fetch / 1e6:.2f} MB raw (x2 = {2 * fetch / 1e6:.2f} MB), "
+                                         f"WRITE_SIZE {write / 1e6:.2f} MB per launch; the touched scene data lives in L2/MALL")
+    return None, "traversal kernel not found in " + os.path.basename(files[-1])
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,8 +232,9 @@ def main() -> None:
         avg_ms = sum(kernel_ms_view.values()) / len(kernel_ms_view)
         avg_bytes = sum(per_view[v]["bytes"] for v in VIEW_ORDER) / len(VIEW_ORDER)
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_note = hbm_traffic_from_profile(w.brick_dimension)
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                    "traffic": None, "kernel": rt.kernel_name(), "kernel_ms_avg": avg_ms,
+                    "traffic": traffic, "traffic_note": traffic_note, "kernel": rt.kernel_name(), "kernel_ms_avg": avg_ms,
                     "kernel_ms_per_view": kernel_ms_view, "algorithmic_bytes_per_launch": avg_bytes}
 
     if rank == 0:

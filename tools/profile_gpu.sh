@@ -18,5 +18,5 @@ for PMC in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM 
   rocprofv3 --kernel-trace --pmc $PMC -d $OUT/pmc$i -o pmc -- $BENCH > $OUT/pmc$i.log 2>&1
 done
 cd $ROOT
-python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+python tools/summarize_prof.py $OUT $OUT/pmc.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -36,3 +36,22 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
             print(f"kernel {k}  dispatches={n}")
             for c, v in sorted(cs.items()):
                 print(f"   {c:34s} per_dispatch={v / n:.6g}")
+
+# machine-readable per-kernel counters (bench.py reads the HBM traffic of the traversal kernel from here)
+if len(sys.argv) > 2:
+    import json
+    result = {}
+    for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
+        for f in sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)):
+            db = sqlite3.connect(f)
+            for k, c, v, n in db.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                                         "where kernel_name like '%vrt_%' group by kernel_name, counter_name"):
+                result.setdefault(k, {})[c] = v
+    for f in sorted(glob.glob(os.path.join(out, "stats", "**", "*.db"), recursive=True)):
+        db = sqlite3.connect(f)
+        for name, calls, total, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+            if "vrt_" in name:
+                result.setdefault(name, {})["kernel_trace_avg_us"] = avg
+                result[name]["kernel_trace_calls"] = calls
+    with open(sys.argv[2], "w") as fh:
+        json.dump(result, fh, indent=1, sort_keys=True)
