@@ -186,3 +186,49 @@ def test_vox_model_scene_like_main_zig():
     _compare(f, u, c, fo, uo, co)
     # palette entry 0 is (0,0,0,1) (alpha 1/255: glass, loader.zig:169-174); entry 3 has alpha 120: glass
     assert (materials["type"][8:14] == [2, 0, 0, 2, 0, 0]).all()
+
+
+def test_reference_app_default_scene_shape_non_cubic_grid():
+    """The reference app's own defaults (src/main.zig:77-81,122-135): 128x64x128 bricks of 4^3 at
+    min (-32,-16,-32), scale 0.5, 1024x576, spp 2, max_bounce 2, sun on — a non-cubic grid whose status
+    bitmap (128 KiB) does not fit the LDS budget, so the global-memory variant is selected."""
+    from zig_vulkan_amd import BrickGrid, Config, CameraConfig, SunConfig, VoxelRT, default_materials
+    grid = BrickGrid(128, 64, 128, min_point=(-32.0, -16.0, -32.0), scale=0.5, brick_dimension=4)
+    grid.synth_terrain(420)
+    rt = VoxelRT(grid, Config(internal_resolution_width=1024, internal_resolution_height=576, camera=CameraConfig(samples_per_pixel=2, max_bounce=2),
+                              sun=SunConfig(enabled=True), want_float_output=True, enable_counters=True))
+    rt.push_materials(default_materials(256))
+    assert "global-memory variant" in rt.kernel_name()
+    rt.camera.set_origin((0.0, 0.0, 0.0))  # Camera.Config default origin, looking -Z
+    rt.draw()
+    f, u, c = rt.read_rgba32f(), rt.read_rgba8(), rt.counters()
+    pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+    rt.deinit()
+    rng = np.random.default_rng(5)
+    xy = np.stack([rng.integers(0, 1024, 20000), rng.integers(0, 576, 20000)], axis=-1).astype(np.int32)
+    fo, uo, _ = O.render_pixels(oracle_scene_from_grid(grid), pc, xy)
+    assert np.array_equal(f[xy[:, 1], xy[:, 0]].view(np.uint32), fo.view(np.uint32))
+    assert np.array_equal(u[xy[:, 1], xy[:, 0]], uo)
+    assert c["hits"] > 0
+
+
+@pytest.mark.parametrize("dims", [(5, 3, 7), (1, 1, 1), (2, 9, 2)])
+def test_odd_grid_dimensions(dims):
+    """Grids whose dimensions are not multiples of the 4x4x4 status blocks (and a single-cell grid)."""
+    from zig_vulkan_amd import BrickGrid
+    w = W.Workload("t", 160, 100, 64, 4, 1, 0, True, 0.0)
+    grid = BrickGrid(*dims, min_point=(-10.0, -6.0, -14.0), scale=4.0, brick_dimension=4)
+    rng = np.random.default_rng(sum(dims))
+    n = 40 * dims[0] * dims[1] * dims[2]
+    xyz = np.stack([rng.integers(0, 4 * d, n) for d in dims], axis=-1)
+    grid.insert_many(xyz, rng.integers(0, 8, n))
+    for variant in (0, 1, 2, 3, 5):
+        rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, kernel_variant=variant)
+        rt.camera.look_at((30.0, -25.0, 40.0), (0.0, 5.0, 0.0))
+        rt.draw()
+        f, u, c = rt.read_rgba32f(), rt.read_rgba8(), rt.counters()
+        pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+        rt.deinit()
+        fo, uo, co = O.render(oracle_scene_from_grid(grid), pc)
+        _compare(f, u, c, fo, uo, co)
+    assert co["hits"] > 0
