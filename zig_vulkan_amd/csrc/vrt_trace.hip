@@ -88,6 +88,9 @@ VRT_DI int min3i(int a, int b, int c) { return min(min(a, b), c); }
 // comp:412) by the stride of the crossed axis instead of recomputing it with two 32-bit multiplies
 // (v_mad_u64_u32 on gfx950, quarter rate); exact in modular u32 arithmetic.  `axis` records the face
 // crossed; hit.normal (comp:350,356,364,370) is rebuilt from it only when a voxel is actually hit.
+// DEFER_T: leave t_value unscaled (the crossed side distance itself); the brick-level walk only needs
+// `t_value = side_dist * scale` (comp:347) when a brick is entered, so it multiplies there.
+template <bool DEFER_T>
 VRT_DI void dda_step(Walk &w, const f3 &ray_delta, float scale, int &axis, uint32_t &index, uint32_t stride_x, uint32_t stride_y,
                      uint32_t stride_z) {
     const bool x_lt_y = w.side_dist.x < w.side_dist.y;
@@ -98,7 +101,7 @@ VRT_DI void dda_step(Walk &w, const f3 &ray_delta, float scale, int &axis, uint3
     const bool ay = (!x_lt_y) & y_lt_z;
     const bool axy = ax | ay; // z is crossed when neither x nor y is
     const float sd = ax ? w.side_dist.x : (ay ? w.side_dist.y : w.side_dist.z);
-    w.t_value = sd * scale;
+    w.t_value = DEFER_T ? sd : sd * scale;
     const float nx = w.side_dist.x + ray_delta.x;
     const float ny = w.side_dist.y + ray_delta.y;
     const float nz = w.side_dist.z + ray_delta.z;
@@ -156,6 +159,22 @@ VRT_DI f3 axis_normal(const RaySetup &s, int axis) {
     const float nx = (s.sx < 0) ? 1.0f : -1.0f, ny = (s.sy < 0) ? 1.0f : -1.0f, nz = (s.sz < 0) ? 1.0f : -1.0f;
     return mk3(axis == 0 ? nx : (axis == 3 ? s.entry_normal.x : 0.0f), axis == 1 ? ny : (axis == 3 ? s.entry_normal.y : 0.0f),
                axis == 2 ? nz : (axis == 3 ? s.entry_normal.z : 0.0f));
+}
+
+// bit (index % 32) of a status word.  v_bfe_u32 takes the offset from the low five bits of its operand,
+// so no separate `index & 31`; written as asm because the compiler does not drop the mask by itself.
+VRT_DI bool status_bit(uint32_t word, uint32_t index) {
+    uint32_t r;
+    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(r) : "v"(word), "v"(index));
+    return r != 0u;
+}
+
+// Word i of the dynamic LDS region.  The traversal kernel declares no static LDS, so its dynamic region
+// starts at LDS address 0 (MI355X guide, G17); addressing it as address-space-3 offset 0 saves the
+// per-access add of a link-time base the compiler cannot fold.
+VRT_DI uint32_t lds_word0(uint32_t i) {
+    typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+    return reinterpret_cast<lds_u32 *>(0)[i];
 }
 
 VRT_DI bool bit64(uint2 w, uint32_t bit) { // bit 0..63 of a 64-bit word held as two dwords
@@ -231,7 +250,7 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
             }
         }
         // (after a hit this step is dead work, once per ray; its results are never read)
-        dda_step(w, s.ray_delta, voxel_scale, axis, voxel_index, stride_x, stride_y, stride_z);
+        dda_step<false>(w, s.ray_delta, voxel_scale, axis, voxel_index, stride_x, stride_y, stride_z);
         more = !found && min3i(w.rx, w.ry, w.rz) >= 0 && w.t_value <= local_t_max;
     }
     return found;
@@ -303,7 +322,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
                     c.status_loads++;
                 }
             }
-            occupied = (lds_filter[grid_index >> 5] >> (grid_index & 31u)) & 1u; // ds_read_b32
+            occupied = status_bit(lds_word0(grid_index >> 5), grid_index); // ds_read_b32 + v_bfe_u32
         } else if constexpr (MODE == kStatusLinearAlways) {
             if constexpr (COUNT) {
                 const uint32_t wi = grid_index >> 5;
@@ -312,7 +331,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
                     c.status_loads++;
                 }
             }
-            occupied = (p.brick_status[grid_index >> 5] >> (grid_index & 31u)) & 1u;
+            occupied = status_bit(p.brick_status[grid_index >> 5], grid_index);
         } else if constexpr (MODE == kStatusLinear || MODE == kStatusLinearWide) {
             const uint32_t wi = grid_index >> 5;
             if (wi != word_index) { // comp:323-326
@@ -345,7 +364,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         if (occupied) {
             const int cx = base_x - __mul24(s.sx, w.rx), cy = base_y - __mul24(s.sy, w.ry), cz = base_z - __mul24(s.sz, w.rz); // cell position
             const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min);  // comp:331
-            global_t_value = w.t_value + s.grid_t_min + 0.01f * g_scale;                             // comp:332
+            global_t_value = w.t_value * g_scale + s.grid_t_min + 0.01f * g_scale;                   // comp:347 (deferred) + comp:332
             hit.t = global_t_value;
             const uint32_t brick_index = p.brick_index[grid_index]; // comp:337
             VRT_COUNT(bricks_entered);
@@ -353,7 +372,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
             const bool found = brick_walk<B, COUNT, MODE == kStatusLinear || MODE == kStatusLinearAlways || MODE == kStatusLinearLds>(p, r, s, g_scale, brick_index, brick_min, hit, axis, c);
             stop = found ? -1 : ((global_t_value <= t_max) ? 0 : -2);
         }
-        dda_step(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
+        dda_step<true>(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
         more = (min3i(w.rx, w.ry, w.rz) | stop) >= 0;
     }
     return stop == -1;
