@@ -18,7 +18,7 @@
 
 namespace vrt {
 using KernelFn = void (*)(const TraceParams);
-KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, bool single_bounce);
+KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, int shade);
 uint32_t resolve_variant(uint32_t variant);
 size_t trace_lds_bytes(const TraceParams &p, uint32_t variant);
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream);
@@ -78,6 +78,7 @@ struct vrt_ctx {
     vrt::TraceParams params{};
     vrt::KernelFn kernel = nullptr;        // general bounce loop
     vrt::KernelFn kernel_single = nullptr; // specialisation for max_bounce <= 1
+    vrt::KernelFn kernel_single1 = nullptr; // ... and samples_per_pixel == 1
     vrt_shard_info shard{};
     std::string err;
     std::string kernel_name;
@@ -352,9 +353,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         VRT_CREATE_HIP(hipEventCreateWithFlags(&c->staging_ev[i], hipEventDisableTiming));
     }
 
-    c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant, false);
-    c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant, true);
-    if (!c->kernel || !c->kernel_single) {
+    c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant, 0);
+    c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant, 1);
+    c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant, 2);
+    if (!c->kernel || !c->kernel_single || !c->kernel_single1) {
         free_ctx(c);
         return fail(nullptr, VRT_E_INVALID_ARG, "no kernel for this configuration");
     }
@@ -409,8 +411,9 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         const uint32_t mode = vrt::resolve_variant(cfg->kernel_variant) & 0xFFu;
         const uint32_t fallback = (mode == vrt::kVariantLinearLds) ? vrt::kVariantLinearAlways : vrt::kVariantBlocked;
         c->cfg.kernel_variant = (cfg->kernel_variant & ~0xFFu) | fallback;
-        c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, false);
-        c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, true);
+        c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 0);
+        c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 1);
+        c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 2);
         c->lds_bytes = 0;
         c->kernel_name += "[LDS structure > 64 KiB: global-memory variant]";
     }
@@ -494,7 +497,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         ctx->status_dirty = false;
     }
     // max_bounce <= 1 ("only primary ray" + its shadow ray): the bounce loop runs at most once
-    const vrt::KernelFn fn = (camera->max_bounce <= 1) ? ctx->kernel_single : ctx->kernel;
+    const vrt::KernelFn fn = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? ctx->kernel_single1 : ctx->kernel_single) : ctx->kernel;
 
     const bool slot_b = ctx->stream_b && frames == 1 && !primary_only && (ctx->frame_seq & 1u);
     if (slot_b) {

@@ -122,7 +122,8 @@ VRT_DI f3 initial_side_dist(f3 fstep, f3 fposition, f3 ray_delta) {
 }
 
 struct RaySetup {
-    f3 ray_delta, fstep, entry_normal;
+    f3 ray_delta;
+    int entry_code; // slab-entry normal (comp:529-531): axis index | sign bits, see entry_normal()
     int sx, sy, sz;
     float grid_t_min, grid_t_max;
 };
@@ -143,22 +144,24 @@ VRT_DI bool grid_slab(const TraceParams &p, const Ray &r, float t_min, float t_m
     const float inv_i = iz ? inv.z : (iy ? inv.y : inv.x);
     const float tmin_i = iz ? t_mins.z : (iy ? t_mins.y : t_mins.x);
     const float sg = sign1(inv_i);
-    s.entry_normal = mk3((!iy && !iz) ? sg : 0.0f, iy ? sg : 0.0f, iz ? sg : 0.0f);
+    // packed: bits 0-1 axis (0,1,2), bit 2 = negative, bit 3 = zero (sign(inv) is never 0 in practice: safeInverse)
+    s.entry_code = (iz ? 2 : (iy ? 1 : 0)) | (sg < 0.0f ? 4 : 0) | (sg == 0.0f ? 8 : 0);
     s.grid_t_min = gl_max(t_min, tmin_i);
     s.grid_t_max = gl_min(t_max, gl_min(gl_min(t_maxes.x, t_maxes.y), t_maxes.z));
     s.ray_delta = abs3(inv);
     s.sx = (int)sign1(r.direction.x);
     s.sy = (int)sign1(r.direction.y);
     s.sz = (int)sign1(r.direction.z);
-    s.fstep = mk3((float)s.sx, (float)s.sy, (float)s.sz);
     return s.grid_t_min <= s.grid_t_max;
 }
 
 VRT_DI f3 axis_normal(const RaySetup &s, int axis) {
     // normal_axis, comp:304-308: (step < 0) ? 1 : -1 on the crossed axis; axis 3 = slab-entry normal
     const float nx = (s.sx < 0) ? 1.0f : -1.0f, ny = (s.sy < 0) ? 1.0f : -1.0f, nz = (s.sz < 0) ? 1.0f : -1.0f;
-    return mk3(axis == 0 ? nx : (axis == 3 ? s.entry_normal.x : 0.0f), axis == 1 ? ny : (axis == 3 ? s.entry_normal.y : 0.0f),
-               axis == 2 ? nz : (axis == 3 ? s.entry_normal.z : 0.0f));
+    const int ea = s.entry_code & 3;
+    const float ev = (s.entry_code & 8) ? 0.0f : ((s.entry_code & 4) ? -1.0f : 1.0f);
+    return mk3(axis == 0 ? nx : ((axis == 3 && ea == 0) ? ev : 0.0f), axis == 1 ? ny : ((axis == 3 && ea == 1) ? ev : 0.0f),
+               axis == 2 ? nz : ((axis == 3 && ea == 2) ? ev : 0.0f));
 }
 
 // bit (index % 32) of a status word.  v_bfe_u32 takes the offset from the low five bits of its operand,
@@ -193,7 +196,7 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
     const float voxel_scale = g_scale * brick_voxel_scale;
     const f3 fposition = (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
     Walk w;
-    w.side_dist = initial_side_dist(s.fstep, fposition, s.ray_delta);
+    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
     const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
     const int py = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
     const int pz = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
@@ -282,7 +285,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
     const f3 fposition = (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
     Walk w;
-    w.side_dist = initial_side_dist(s.fstep, fposition, s.ray_delta);
+    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
     const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
     const int py = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
     const int pz = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
@@ -522,7 +525,9 @@ VRT_DI uint32_t xcd_slice_index(uint32_t b, uint32_t n) {
 }
 
 // comp:153-178
-template <int B, bool COUNT, int MODE, int MIN_WAVES, bool SINGLE>
+// SHADE: 0 general bounce loop; 1 max_bounce <= 1 (ray_color_single); 2 the same with one sample per
+// pixel (no accumulator kept live across the traversal)
+template <int B, bool COUNT, int MODE, int MIN_WAVES, int SHADE>
 __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TraceParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_filter[];
     if constexpr (MODE == kStatusLinearLds) {
@@ -585,22 +590,30 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TracePa
     const bool inside = (px < p.width) && (py < p.height); // comp:155-159
     if (inside) {
         f3 color = mk3(0, 0, 0);
-        const int spp = p.pc.cam.samples_per_pixel;
+        const int spp = (SHADE == 2) ? 1 : p.pc.cam.samples_per_pixel;
         const float x = (float)px, y = (float)py;
-        for (int sample_i = 0; sample_i < spp; sample_i++) {
-            const float flag = (sample_i > 0) ? 1.0f : 0.0f;
-            const float noise_x = hash_12(((x + (float)sample_i) * 0.2f) * flag, (y * 0.2f) * flag);
-            const float u = (x + noise_x) / (float)(p.pc.cam.image_width - 1u);
-            const float noise_y = hash_12((x * 0.2f) * flag, ((y + (float)sample_i) * 0.2f) * flag);
-            const float v = (y + noise_y) / (float)(p.pc.cam.image_height - 1u);
-            // CameraGetRay, comp:474-477
-            const f3 horizontal = mk3(p.pc.cam.horizontal[0], p.pc.cam.horizontal[1], p.pc.cam.horizontal[2]);
-            const f3 vertical = mk3(p.pc.cam.vertical[0], p.pc.cam.vertical[1], p.pc.cam.vertical[2]);
-            const f3 llc = mk3(p.pc.cam.lower_left_corner[0], p.pc.cam.lower_left_corner[1], p.pc.cam.lower_left_corner[2]);
-            const f3 origin = mk3(p.pc.cam.origin[0], p.pc.cam.origin[1], p.pc.cam.origin[2]);
+        // CameraGetRay operands, comp:474-477
+        const f3 horizontal = mk3(p.pc.cam.horizontal[0], p.pc.cam.horizontal[1], p.pc.cam.horizontal[2]);
+        const f3 vertical = mk3(p.pc.cam.vertical[0], p.pc.cam.vertical[1], p.pc.cam.vertical[2]);
+        const f3 llc = mk3(p.pc.cam.lower_left_corner[0], p.pc.cam.lower_left_corner[1], p.pc.cam.lower_left_corner[2]);
+        const f3 origin = mk3(p.pc.cam.origin[0], p.pc.cam.origin[1], p.pc.cam.origin[2]);
+        if constexpr (SHADE == 2) {
+            // sample 0 is un-jittered: hash12(0) = 0 (comp:167-170)
+            const float u = (x + 0.0f) / (float)(p.pc.cam.image_width - 1u);
+            const float v = (y + 0.0f) / (float)(p.pc.cam.image_height - 1u);
             const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
-            if constexpr (SINGLE) color = color + ray_color_single<B, COUNT, MODE>(p, lds_filter, create_ray(origin, ray_dir), c);
-            else color = color + ray_color<B, COUNT, MODE>(p, lds_filter, create_ray(origin, ray_dir), c);
+            color = mk3(0, 0, 0) + ray_color_single<B, COUNT, MODE>(p, lds_filter, create_ray(origin, ray_dir), c);
+        } else {
+            for (int sample_i = 0; sample_i < spp; sample_i++) {
+                const float flag = (sample_i > 0) ? 1.0f : 0.0f;
+                const float noise_x = hash_12(((x + (float)sample_i) * 0.2f) * flag, (y * 0.2f) * flag);
+                const float u = (x + noise_x) / (float)(p.pc.cam.image_width - 1u);
+                const float noise_y = hash_12((x * 0.2f) * flag, ((y + (float)sample_i) * 0.2f) * flag);
+                const float v = (y + noise_y) / (float)(p.pc.cam.image_height - 1u);
+                const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
+                if constexpr (SHADE == 1) color = color + ray_color_single<B, COUNT, MODE>(p, lds_filter, create_ray(origin, ray_dir), c);
+                else color = color + ray_color<B, COUNT, MODE>(p, lds_filter, create_ray(origin, ray_dir), c);
+            }
         }
         const float fspp = (float)spp;
         color = mk3(__builtin_sqrtf(color.x / fspp), __builtin_sqrtf(color.y / fspp), __builtin_sqrtf(color.z / fspp));
@@ -743,45 +756,43 @@ constexpr int kDefaultMinWaves = 4; // waves per SIMD the register allocator mus
 
 // kernel_variant = mode | (min_waves << 8); min_waves 0 => kDefaultMinWaves.  The occupancy knob
 // exists for tuning runs (bench.py --variant 0x603 ...).
-template <int B, bool COUNT, int MW, bool SINGLE>
+template <int B, bool COUNT, int MW, int SHADE>
 static KernelFn pick_mode(uint32_t mode) {
     switch (mode) {
-        case kVariantLiteral: return vrt_trace_kernel<B, COUNT, kStatusLinear, MW, SINGLE>;
-        case kVariantBlocked: return vrt_trace_kernel<B, COUNT, kStatusBlocked, MW, SINGLE>;
-        case kVariantBlockedLds: return vrt_trace_kernel<B, COUNT, kStatusBlockedLds, MW, SINGLE>;
-        case kVariantLinearWide: return vrt_trace_kernel<B, COUNT, kStatusLinearWide, MW, SINGLE>;
-        case kVariantLinearAlways: return vrt_trace_kernel<B, COUNT, kStatusLinearAlways, MW, SINGLE>;
-        case kVariantLinearLds: return vrt_trace_kernel<B, COUNT, kStatusLinearLds, MW, SINGLE>;
+        case kVariantLiteral: return vrt_trace_kernel<B, COUNT, kStatusLinear, MW, SHADE>;
+        case kVariantBlocked: return vrt_trace_kernel<B, COUNT, kStatusBlocked, MW, SHADE>;
+        case kVariantBlockedLds: return vrt_trace_kernel<B, COUNT, kStatusBlockedLds, MW, SHADE>;
+        case kVariantLinearWide: return vrt_trace_kernel<B, COUNT, kStatusLinearWide, MW, SHADE>;
+        case kVariantLinearAlways: return vrt_trace_kernel<B, COUNT, kStatusLinearAlways, MW, SHADE>;
+        case kVariantLinearLds: return vrt_trace_kernel<B, COUNT, kStatusLinearLds, MW, SHADE>;
         default: return nullptr;
     }
 }
 
-template <int B, bool COUNT, bool SINGLE>
+template <int B, bool COUNT, int SHADE>
 static KernelFn pick_variant(uint32_t variant) {
     const uint32_t mode = variant & 0xFFu, mw = (variant >> 8) & 0xFFu;
     switch (mw) {
         case 0:
-        case kDefaultMinWaves: return pick_mode<B, COUNT, kDefaultMinWaves, SINGLE>(mode);
-        case 5: return pick_mode<B, COUNT, 5, SINGLE>(mode);
-        case 6: return pick_mode<B, COUNT, 6, SINGLE>(mode);
-        case 8: return pick_mode<B, COUNT, 8, SINGLE>(mode);
+        case kDefaultMinWaves: return pick_mode<B, COUNT, kDefaultMinWaves, SHADE>(mode);
+        case 5: return pick_mode<B, COUNT, 5, SHADE>(mode);
+        case 7: return pick_mode<B, COUNT, 7, SHADE>(mode);
+        case 8: return pick_mode<B, COUNT, 8, SHADE>(mode);
         default: return nullptr;
     }
 }
 
 uint32_t resolve_variant(uint32_t variant) {
-    return (variant & 0xFFu) == kVariantDefault ? ((variant & ~0xFFu) | (uint32_t)kVariantLinearLds) : variant;
+    return (variant & 0xFFu) == kVariantDefault ? ((variant & ~0xFFu) | (uint32_t)kVariantLinearAlways) : variant;
 }
 
-// single_bounce: the specialisation for push_constant.max_bounce <= 1 (no scatter evaluation)
-KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, bool single_bounce) {
+// shade: 0 general, 1 max_bounce <= 1 (no scatter evaluation), 2 the same with samples_per_pixel == 1
+KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, int shade) {
     variant = resolve_variant(variant);
-#define VRT_PICK(BD)                                                                                                          \
-    (counters ? (single_bounce ? pick_variant<BD, true, true>(variant) : pick_variant<BD, true, false>(variant))               \
-              : (single_bounce ? pick_variant<BD, false, true>(variant) : pick_variant<BD, false, false>(variant)))
-    if (brick_dimension == 4) return VRT_PICK(4);
-    if (brick_dimension == 8) return VRT_PICK(8);
-#undef VRT_PICK
+#define VRT_PICK3(BD, CNT) (shade == 2 ? pick_variant<BD, CNT, 2>(variant) : (shade == 1 ? pick_variant<BD, CNT, 1>(variant) : pick_variant<BD, CNT, 0>(variant)))
+    if (brick_dimension == 4) return counters ? VRT_PICK3(4, true) : VRT_PICK3(4, false);
+    if (brick_dimension == 8) return counters ? VRT_PICK3(8, true) : VRT_PICK3(8, false);
+#undef VRT_PICK3
     return nullptr;
 }
 
