@@ -362,7 +362,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     }
     {
         char buf[96];
-        static const char *const mode_names[] = {"?", "linear-status+byte-occupancy", "blocked-status", "blocked-status+lds-filter", "linear-status+wide-occupancy", "linear-status-uncached", "linear-status-in-lds"};
+        static const char *const mode_names[] = {"?", "linear-status+byte-occupancy", "blocked-status", "blocked-status+lds-filter", "linear-status+wide-occupancy", "linear-status-uncached", "linear-status-in-lds", "linear-status-in-lds(512-thread groups)"};
         const uint32_t rv = vrt::resolve_variant(cfg->kernel_variant);
         std::snprintf(buf, sizeof buf, "vrt_trace_kernel<B=%u,COUNT=%d,%s,minwaves=%u>", cfg->brick_dimension, cfg->enable_counters ? 1 : 0,
                       mode_names[rv & 0xFFu], (rv >> 8) ? (rv >> 8) : 4u);
@@ -394,6 +394,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.tile_cost = c->d_tile_cost;
     p.tile_schedule = c->d_tile_schedule;
     p.wave_groups = (cfg->kernel_variant >> 20) & 0x1u;
+    p.block_threads = ((vrt::resolve_variant(cfg->kernel_variant) & 0xFFu) == vrt::kVariantLinearLds512) ? 512u : 256u;
     {
         // a stride near owned_tiles * 0.618 that is coprime to owned_tiles
         auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
@@ -409,12 +410,13 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (c->lds_bytes > 64u * 1024u) {
         // the LDS-staged structure of a very large grid does not fit the LDS budget: read from global memory
         const uint32_t mode = vrt::resolve_variant(cfg->kernel_variant) & 0xFFu;
-        const uint32_t fallback = (mode == vrt::kVariantLinearLds) ? vrt::kVariantLinearAlways : vrt::kVariantBlocked;
+        const uint32_t fallback = (mode == vrt::kVariantLinearLds || mode == vrt::kVariantLinearLds512) ? vrt::kVariantLinearAlways : vrt::kVariantBlocked;
         c->cfg.kernel_variant = (cfg->kernel_variant & ~0xFFu) | fallback;
         c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 0);
         c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 1);
         c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 2);
         c->lds_bytes = 0;
+        p.block_threads = 256u;
         c->kernel_name += "[LDS structure > 64 KiB: global-memory variant]";
     }
     // the status bitmap is read 16 bytes at a time by the LDS-staging variant: the +16 slack of dbuf covers the tail

@@ -527,8 +527,8 @@ VRT_DI uint32_t xcd_slice_index(uint32_t b, uint32_t n) {
 // comp:153-178
 // SHADE: 0 general bounce loop; 1 max_bounce <= 1 (ray_color_single); 2 the same with one sample per
 // pixel (no accumulator kept live across the traversal)
-template <int B, bool COUNT, int MODE, int MIN_WAVES, int SHADE>
-__global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TraceParams p) {
+template <int B, bool COUNT, int MODE, int MIN_WAVES, int SHADE, int BLOCK = 256>
+__global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const TraceParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_filter[];
     if constexpr (MODE == kStatusLinearLds) {
         // stage the brick-status bitmap (binding 3) in LDS: 16 bytes per lane per trip
@@ -548,8 +548,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_trace_kernel(const TracePa
     // One wave = one 8x8 pixel block.  wave_groups: the workgroup IS one wave (64 threads), so the
     // hardware dispatcher hands 8x8 blocks to whichever SIMD frees a slot (dynamic load balance at
     // wave granularity); otherwise a 256-thread workgroup covers one 16x16 tile with four waves.
-    const uint32_t unit = p.wave_groups ? (blockIdx.x >> 2) : blockIdx.x;
-    const uint32_t wave = p.wave_groups ? (blockIdx.x & 3u) : (threadIdx.x >> 6);
+    // BLOCK 512: two 16x16 tiles per workgroup share one LDS copy of the status bitmap
+    const uint32_t unit = p.wave_groups ? (blockIdx.x >> 2) : (BLOCK == 512 ? blockIdx.x * 2u + (threadIdx.x >> 8) : blockIdx.x);
+    const uint32_t wave = p.wave_groups ? (blockIdx.x & 3u) : ((threadIdx.x >> 6) & 3u);
+    if (BLOCK == 512 && unit >= p.owned_tiles) return; // odd tile count: the last workgroup's second half is idle
     uint32_t owned;
     if (p.tile_order == 5u) {
         // cost-feedback schedule: tiles sorted by the time they took last frame, heaviest first, so the
@@ -765,6 +767,7 @@ static KernelFn pick_mode(uint32_t mode) {
         case kVariantLinearWide: return vrt_trace_kernel<B, COUNT, kStatusLinearWide, MW, SHADE>;
         case kVariantLinearAlways: return vrt_trace_kernel<B, COUNT, kStatusLinearAlways, MW, SHADE>;
         case kVariantLinearLds: return vrt_trace_kernel<B, COUNT, kStatusLinearLds, MW, SHADE>;
+        case kVariantLinearLds512: return vrt_trace_kernel<B, COUNT, kStatusLinearLds, MW, SHADE, 512>;
         default: return nullptr;
     }
 }
@@ -803,13 +806,14 @@ size_t trace_lds_bytes(const TraceParams &p, uint32_t variant) {
         const size_t nwords = ((size_t)p.nbx * p.nby * p.nbz + 31u) >> 5;
         return (nwords * 4u + 15u) & ~(size_t)15u;
     }
-    if (mode == kVariantLinearLds) return (((size_t)p.status_words + 3u) & ~(size_t)3u) * 4u;
+    if (mode == kVariantLinearLds || mode == kVariantLinearLds512) return (((size_t)p.status_words + 3u) & ~(size_t)3u) * 4u;
     return 0;
 }
 
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream) {
     if (p.owned_tiles == 0) return hipSuccess;
-    if (p.wave_groups) hipLaunchKernelGGL(fn, dim3(p.owned_tiles * 4u), dim3(64), lds_bytes, stream, p);
+    if (p.block_threads == 512u) hipLaunchKernelGGL(fn, dim3((p.owned_tiles + 1u) / 2u), dim3(512), lds_bytes, stream, p);
+    else if (p.wave_groups) hipLaunchKernelGGL(fn, dim3(p.owned_tiles * 4u), dim3(64), lds_bytes, stream, p);
     else hipLaunchKernelGGL(fn, dim3(p.owned_tiles), dim3(256), lds_bytes, stream, p);
     return hipGetLastError();
 }
