@@ -353,6 +353,17 @@ int vrt_vox_materials(const vrt_vox *v, vrt_material *out, uint32_t count);
 int vrt_vox_insert(vrt_grid *g, const vrt_vox *v, uint32_t model, uint32_t off_x, uint32_t off_y, uint32_t off_z,
                    uint32_t material_offset);
 
+/* ---- scripted benchmark fly-through ----------------------------------------
+ * Benchmark.init / update / Report of src/modules/voxel_rt/Benchmark.zig:22-136 with its path
+ * (Benchmark.zig:141-172): 60 s, 11 positions and 11 orientations, linearly interpolated.  The caller
+ * advances it by the frame time it measured (the reference passes the app's delta time) and renders
+ * with the updated camera. */
+typedef struct vrt_benchmark vrt_benchmark;
+int vrt_benchmark_create(vrt_camera_device *cam, float vertical_fov_deg, float viewport_height, vrt_benchmark **out);
+void vrt_benchmark_destroy(vrt_benchmark *b);
+int vrt_benchmark_update(vrt_benchmark *b, float dt_seconds, vrt_camera_device *cam); /* 1 = path complete */
+int vrt_benchmark_report(const vrt_benchmark *b, float *min_ms, float *max_ms, float *avg_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,6 +177,10 @@ SIGNATURES = {
     "vrt_default_materials": (C.c_uint32, [_P(Material), C.c_uint32]),
     "vrt_synth_terrain": (C.c_int, [_grid, C.c_uint64]),
     "vrt_synth_sparse": (C.c_int, [_grid, C.c_uint64, C.c_float]),
+    "vrt_benchmark_create": (C.c_int, [_P(CameraDevice), C.c_float, C.c_float, _P(C.c_void_p)]),
+    "vrt_benchmark_destroy": (None, [C.c_void_p]),
+    "vrt_benchmark_update": (C.c_int, [C.c_void_p, C.c_float, _P(CameraDevice)]),
+    "vrt_benchmark_report": (C.c_int, [C.c_void_p, _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "vrt_vox_validate_header": (C.c_int, [C.c_char_p, C.c_uint64]),
     "vrt_vox_parse": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int, _P(C.c_void_p)]),
     "vrt_vox_destroy": (None, [C.c_void_p]),

@@ -189,6 +189,32 @@ MATERIAL_DTYPE = np.dtype([("type", np.uint32), ("albedo_r", np.float32), ("albe
 assert MATERIAL_DTYPE.itemsize == 20
 
 
+class Benchmark:
+    """Benchmark (src/modules/voxel_rt/Benchmark.zig): scripted 60 s fly-through driving a Camera."""
+
+    def __init__(self, camera: Camera):
+        self.camera = camera
+        h = C.c_void_p()
+        check(lib.vrt_benchmark_create(C.byref(camera.d_camera), camera.vertical_fov, camera.viewport_height_cfg, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.vrt_benchmark_destroy(self._h)
+            self._h = None
+
+    def update(self, dt: float) -> bool:
+        rc = lib.vrt_benchmark_update(self._h, dt, C.byref(self.camera.d_camera))
+        if rc < 0:
+            check(rc)
+        return rc == 1
+
+    def report(self) -> dict:
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        check(lib.vrt_benchmark_report(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"min_frame_ms": a.value, "max_frame_ms": b.value, "avg_frame_ms": c.value}
+
+
 @dataclass
 class Config:  # VoxelRT.Config, VoxelRT.zig:22-28 (+ the knobs of this implementation)
     internal_resolution_width: int = 1280
@@ -348,6 +374,9 @@ class VoxelRT:
         out = (C.c_uint64 * 3)()
         check(lib.vrt_get_wave_counters(self._h, C.byref(out)), self._h)
         return {"wave_grid_iters": out[0], "wave_brick_walks": out[1], "wave_voxel_iters": out[2]}
+
+    def create_benchmark(self) -> "Benchmark":  # VoxelRT.createBenchmark, VoxelRT.zig:72-74
+        return Benchmark(self.camera)
 
     def kernel_name(self) -> str:
         return lib.vrt_kernel_name(self._h).decode()
