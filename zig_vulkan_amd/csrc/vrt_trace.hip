@@ -525,6 +525,13 @@ VRT_DI uint32_t xcd_slice_index(uint32_t b, uint32_t n) {
 }
 
 // comp:153-178
+// A wave-uniform float the optimiser may not move out of a loop (empty asm pinned to an SGPR).
+VRT_DI float opaque_uniform(float v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+VRT_DI f3 opaque_uniform3(const float (&v)[3]) { return mk3(opaque_uniform(v[0]), opaque_uniform(v[1]), opaque_uniform(v[2])); }
+
 // SHADE: 0 general bounce loop; 1 max_bounce <= 1 (ray_color_single); 2 the same with one sample per
 // pixel (no accumulator kept live across the traversal)
 template <int B, bool COUNT, int MODE, int MIN_WAVES, int SHADE, int BLOCK = 256>
@@ -607,6 +614,13 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
             color = mk3(0, 0, 0) + ray_color_single<B, COUNT, MODE>(p, lds_filter, create_ray(origin, ray_dir), c);
         } else {
             for (int sample_i = 0; sample_i < spp; sample_i++) {
+                // Re-derive the camera vectors from their SGPRs in every trip: a VALU op takes a single scalar
+                // operand, so the compiler copies them to VGPRs — hoisted out of this loop, twelve copies would
+                // stay live across the whole traversal and cost a wave per SIMD.
+                const f3 horizontal = opaque_uniform3(p.pc.cam.horizontal);
+                const f3 vertical = opaque_uniform3(p.pc.cam.vertical);
+                const f3 llc = opaque_uniform3(p.pc.cam.lower_left_corner);
+                const f3 origin = opaque_uniform3(p.pc.cam.origin);
                 const float flag = (sample_i > 0) ? 1.0f : 0.0f;
                 const float noise_x = hash_12(((x + (float)sample_i) * 0.2f) * flag, (y * 0.2f) * flag);
                 const float u = (x + noise_x) / (float)(p.pc.cam.image_width - 1u);
