@@ -227,7 +227,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         return fail(nullptr, VRT_E_INVALID_ARG, "tile size must be 16x16 (or 0)");
     const uint32_t shard_count = cfg->shard_count ? cfg->shard_count : 1u;
     if (cfg->shard_rank >= shard_count) return fail(nullptr, VRT_E_INVALID_ARG, "shard_rank >= shard_count");
-    if ((cfg->kernel_variant & 0xFFu) >= vrt::kVariantCount || (cfg->kernel_variant >> 24)) return fail(nullptr, VRT_E_INVALID_ARG, "unknown kernel_variant");
+    if ((cfg->kernel_variant & 0xFFu) >= vrt::kVariantCount || (cfg->kernel_variant >> 28)) return fail(nullptr, VRT_E_INVALID_ARG, "unknown kernel_variant");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -394,6 +394,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.tile_cost = c->d_tile_cost;
     p.tile_schedule = c->d_tile_schedule;
     p.wave_groups = (cfg->kernel_variant >> 20) & 0x1u;
+    p.brick_batch = (cfg->kernel_variant >> 24) & 0xFu ? ((cfg->kernel_variant >> 24) & 0xFu) * 4u : 4u; // tuning knob: units of 4 lanes
     p.block_threads = ((vrt::resolve_variant(cfg->kernel_variant) & 0xFFu) == vrt::kVariantLinearLds512) ? 512u : 256u;
     {
         // a stride near owned_tiles * 0.618 that is coprime to owned_tiles
