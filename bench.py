@@ -109,6 +109,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=2.0, help="minimum wall time of the CPU baseline sample")
     ap.add_argument("--frames-in-flight", type=int, default=2, help="1: frames strictly one after another; 2: two frames in flight")
+    ap.add_argument("--dist", choices=["native", "torch"], default="native",
+                    help="N>1 frame gather: native = RCCL send/recv inside libvrt_hip.so (pipelined, 4 frames in flight); "
+                         "torch = torch.distributed.gather from Python (fallback)")
+    ap.add_argument("--dist-frames", type=int, default=4, help="frames in flight per rank of the native multi-GPU pipeline")
     ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")
     args = ap.parse_args()
 
@@ -156,13 +160,40 @@ def main() -> None:
 
     # ---- the timed renderer ----
     fg = None
-    if sharded:
+    native = False
+    if sharded and args.dist == "native":
+        # RCCL inside libvrt_hip.so: kernel -> grouped send/recv to rank 0 -> un-swizzle, several frames in flight
+        from zig_vulkan_amd import VoxelRT
+        ok = 1
+        rt = None
+        try:
+            uid = [VoxelRT.dist_unique_id() if rank == 0 else None]
+            if dist is not None and world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            rt = W.make_renderer(w, grid, device_id=local_rank, shard_rank=rank, shard_count=world, kernel_variant=args.variant)
+            rt.dist_init(uid[0], rank, world, args.dist_frames)
+            if world == 1:
+                rt.dist_selftest()
+        except Exception as e:  # noqa: BLE001 - any failure means "use the torch path"
+            print(f"[bench rank {rank}] native RCCL pipeline unavailable: {e}", file=sys.stderr)
+            ok = 0
+        if dist is not None and world > 1:  # every rank must take the same path
+            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        native = bool(ok)
+        if not native and rt is not None:
+            rt.deinit()
+    if sharded and not native:
         fg = FrameGather(w.width, w.height, rank, world, torch.device("cuda", local_rank))
         rt = W.make_renderer(w, grid, device_id=local_rank, shard_rank=rank, shard_count=world, stream=stream,
                              external_target_rgba8=fg.shard.data_ptr(), kernel_variant=args.variant)
-    else:
+    elif not sharded:
         rt = W.make_renderer(w, grid, device_id=local_rank, kernel_variant=args.variant, frames_in_flight=args.frames_in_flight)
-    rt.wait()
+    if native:
+        rt.dist_wait()
+    else:
+        rt.wait()
 
     cams = {}
     for v in VIEW_ORDER:
@@ -185,6 +216,9 @@ def main() -> None:
         if not sharded:
             rt.draw()
             return
+        if native:
+            rt.dist_frame()                     # kernel -> one RCCL gather -> un-swizzle, on this frame's stream
+            return
         f = frame_no[0]
         frame_no[0] += 1
         fg.begin_frame(f)                       # buffer f%2 is free once frame f-2's gather is done
@@ -195,7 +229,9 @@ def main() -> None:
             fg.complete(f - 1, rt)              # rank 0: un-swizzle the previous frame
 
     def drain() -> None:
-        if sharded and frame_no[0] >= 1:
+        if native:
+            rt.dist_wait()
+        elif sharded and frame_no[0] >= 1:
             fg.complete(frame_no[0] - 1, rt)
 
     def barrier() -> None:
@@ -211,7 +247,8 @@ def main() -> None:
     for i in range(args.steps):
         step(i, args.steps)
     drain()  # the last frame's gather + un-swizzle belong to the timed region
-    rt.wait()
+    if not native:
+        rt.wait()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None and world > 1:
@@ -256,7 +293,8 @@ def main() -> None:
                        "rays": "primary + shadow" if w.sun_enabled else "primary", "spp": w.spp, "max_bounce": w.max_bounce,
                        "views": VIEW_ORDER, "rays_per_frame": {v: per_view[v]["rays"] for v in VIEW_ORDER},
                        "counters_per_frame": {v: per_view[v]["counters"] for v in VIEW_ORDER},
-                       "parallelism": f"image tiles 16x16 interleaved over {world} GPU(s), 1 RCCL gather/frame, gather of frame f overlaps kernel of f+1"
+                       "parallelism": (f"image tiles 16x16 interleaved over {world} GPU(s), 1 RCCL gather/frame to rank 0, "
+                                       + (f"native pipeline with {args.dist_frames} frames in flight" if native else "torch.distributed gather, frame f overlaps kernel of f+1"))
                        if sharded else f"1 GPU, whole frame, {args.frames_in_flight} frame(s) in flight"},
             "roofline": roofline,
         }

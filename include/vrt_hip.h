@@ -31,7 +31,8 @@ enum {
     VRT_E_OUT_OF_RANGE = -3,
     VRT_E_HIP = -4,
     VRT_E_NO_DEVICE = -5,
-    VRT_E_STATE = -6
+    VRT_E_STATE = -6,
+    VRT_E_RCCL = -7
 };
 
 /* ---- buffer ids: same order as shader bindings 1..7
@@ -198,6 +199,24 @@ int vrt_get_shard_info(const vrt_ctx *ctx, vrt_shard_info *out);
  * pixels in device memory; writes the row-major frame to `dst_frame` (device).
  * Runs on the ctx stream. */
 int vrt_assemble_frame(vrt_ctx *ctx, const void *gathered, void *dst_frame, uint32_t bytes_per_pixel);
+
+/* ---- multi-GPU frame pipeline (RCCL over xGMI, one process per GPU) -----------------------------
+ * The reference is single-GPU; this is the north-star's image-tile sharding.  A context created with
+ * shard_rank / shard_count = this process's rank / world size renders its interleaved 16x16 tiles and
+ * ONE gather per frame (grouped ncclSend / ncclRecv) brings the packed RGBA8 shards to rank 0, which
+ * un-swizzles them into the row-major frame.  Up to 8 frames are in flight, each on its own stream
+ * (kernel -> gather -> un-swizzle), so a frame's collective overlaps the next frames' kernels.
+ * RCCL is reached through dlopen(rccl_path) — pass the library the process already uses (PyTorch's
+ * bundled librccl.so) so that there is one RCCL in the address space; libvrt_hip.so does not link it.
+ * Rank 0 makes the 128-byte id with vrt_dist_unique_id and the host distributes it to every rank. */
+int vrt_dist_unique_id(const char *rccl_path, void *out_id128);
+int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight);
+int vrt_dist_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun);
+int vrt_dist_wait(vrt_ctx *ctx);
+/* rank 0: the most recently submitted frame, row-major RGBA8 (waits for it) */
+int vrt_dist_read_frame(vrt_ctx *ctx, void *dst, uint64_t nbytes);
+/* ncclSend + ncclRecv of one shard to this rank itself: checks the RCCL binding on a single GPU */
+int vrt_dist_selftest(vrt_ctx *ctx);
 
 /* ---- measurement ---------------------------------------------------------- */
 /* hipEvent time of the most recent vrt_dispatch / average per frame of the

@@ -232,3 +232,39 @@ def test_odd_grid_dimensions(dims):
         fo, uo, co = O.render(oracle_scene_from_grid(grid), pc)
         _compare(f, u, c, fo, uo, co)
     assert co["hits"] > 0
+
+
+def test_native_rccl_pipeline_single_rank():
+    """vrt_dist_* on one GPU (world = 1): RCCL bound through dlopen of PyTorch's librccl, communicator
+    created, a shard sent to and received from this rank itself, then the pipelined frame loop (4 frames
+    in flight, packed tile-major targets, un-swizzle) must reproduce the plain frames — also across a
+    grid edit.  Peers other than self cannot be exercised on a one-GPU box."""
+    from zig_vulkan_amd import VoxelRT
+    w = W.Workload("t", 330, 210, 64, 4, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    ref = {}
+    for view in ["V0", "V1", "V2"]:
+        _, ref[view], _, _ = _run_hip(w, grid, view, counters=False)
+    rt = W.make_renderer(w, grid, shard_rank=0, shard_count=1)
+    rt.dist_init(VoxelRT.dist_unique_id(), 0, 1, frames_in_flight=4)
+    rt.dist_selftest()
+    seq = ["V0", "V1", "V2", "V2", "V1", "V0", "V1"]
+    for view in seq:
+        W.set_view(rt, view)
+        rt.dist_frame()
+    assert np.array_equal(rt.dist_read_frame(), ref[seq[-1]])
+    for view in seq:
+        W.set_view(rt, view)
+        rt.dist_frame()
+        assert np.array_equal(rt.dist_read_frame(), ref[view])
+    for y in range(20, 60):
+        grid.insert(31, y, 31, 7)
+    rt.update_grid_delta()
+    W.set_view(rt, "V1")
+    for _ in range(5):
+        rt.dist_frame()
+    got = rt.dist_read_frame()
+    rt.dist_wait()
+    rt.deinit()
+    _, want, _, _ = _run_hip(w, grid, "V1", counters=False)
+    assert np.array_equal(got, want) and not np.array_equal(want, ref["V1"])

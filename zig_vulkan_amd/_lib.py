@@ -20,6 +20,7 @@ VRT_E_OUT_OF_RANGE = -3
 VRT_E_HIP = -4
 VRT_E_NO_DEVICE = -5
 VRT_E_STATE = -6
+VRT_E_RCCL = -7
 
 ERROR_NAMES = {
     VRT_E_INVALID_ARG: "VRT_E_INVALID_ARG",
@@ -28,6 +29,7 @@ ERROR_NAMES = {
     VRT_E_HIP: "VRT_E_HIP",
     VRT_E_NO_DEVICE: "VRT_E_NO_DEVICE",
     VRT_E_STATE: "VRT_E_STATE",
+    VRT_E_RCCL: "VRT_E_RCCL",
 }
 
 # vrt_buffer_id — shader bindings 1..7
@@ -155,6 +157,12 @@ SIGNATURES = {
     "vrt_device_denoised_rgba8": (C.c_void_p, [_ctx]),
     "vrt_get_shard_info": (C.c_int, [_ctx, _P(ShardInfo)]),
     "vrt_assemble_frame": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "vrt_dist_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "vrt_dist_init": (C.c_int, [_ctx, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32]),
+    "vrt_dist_frame": (C.c_int, [_ctx, _P(CameraDevice), _P(SunDevice)]),
+    "vrt_dist_wait": (C.c_int, [_ctx]),
+    "vrt_dist_read_frame": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
+    "vrt_dist_selftest": (C.c_int, [_ctx]),
     "vrt_last_kernel_ms": (C.c_double, [_ctx]),
     "vrt_get_counters": (C.c_int, [_ctx, _P(Counters)]),
     "vrt_get_wave_counters": (C.c_int, [_ctx, _P(C.c_uint64 * 3)]),
@@ -224,6 +232,13 @@ def _load() -> C.CDLL:
 
 
 lib = _load()
+
+
+def rccl_library_path() -> str:
+    """The RCCL the process already uses: PyTorch's bundled librccl.so (backend "nccl" on ROCm)."""
+    import torch
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return path if os.path.exists(path) else "librccl.so"
 
 
 def check(rc: int, ctx=None) -> None:

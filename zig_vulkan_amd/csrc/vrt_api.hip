@@ -7,6 +7,8 @@
 // (render/StagingRamp.zig) for this one path.  There is no CPU fallback: without
 // a HIP device vrt_create fails with VRT_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and prototypes only: the library is reached through dlopen, not linked
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -37,6 +39,66 @@ constexpr size_t kStagingSlotBytes = 32u << 20; // pinned staging slot
 constexpr int kStagingSlots = 2;
 } // namespace
 
+// RCCL entry points resolved with dlsym from the library the host process already uses.
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool load(const char *path, std::string &err) {
+        lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) {
+            err = std::string("dlopen(") + (path ? path : "NULL") + "): " + dlerror();
+            return false;
+        }
+#define VRT_RCCL_SYM(field, name)                                   \
+        field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); \
+        if (!field) {                                                \
+            err = std::string("dlsym ") + name + " failed";         \
+            return false;                                            \
+        }
+        VRT_RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+        VRT_RCCL_SYM(CommInitRank, "ncclCommInitRank")
+        VRT_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+        VRT_RCCL_SYM(GroupStart, "ncclGroupStart")
+        VRT_RCCL_SYM(GroupEnd, "ncclGroupEnd")
+        VRT_RCCL_SYM(Send, "ncclSend")
+        VRT_RCCL_SYM(Recv, "ncclRecv")
+        VRT_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef VRT_RCCL_SYM
+        return true;
+    }
+};
+
+constexpr uint32_t kMaxDistSlots = 8;
+
+// One frame in flight of the multi-GPU pipeline: its stream carries kernel -> gather -> un-swizzle.
+struct DistSlot {
+    hipStream_t stream = nullptr;
+    uint8_t *shard = nullptr;    // this rank's packed tiles (on rank 0: the first shard of `gathered`)
+    uint8_t *gathered = nullptr; // rank 0: world x shard_bytes, rank-major
+    uint8_t *frame = nullptr;    // rank 0: row-major RGBA8 frame
+    hipEvent_t done = nullptr;
+    uint64_t seen_upload = 0;
+    bool used = false;
+};
+
+struct Dist {
+    RcclApi api;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    uint32_t nslots = 0;
+    DistSlot slots[kMaxDistSlots];
+    uint64_t frame_no = 0;
+    int last_slot = -1;
+    size_t shard_bytes = 0;
+};
+
 struct vrt_ctx {
     vrt_config cfg{};
     int device = 0;
@@ -61,6 +123,7 @@ struct vrt_ctx {
     vrt::DeviceCounters *d_counters = nullptr;
     uint32_t *d_tile_cost = nullptr, *d_tile_schedule = nullptr; // cost-feedback tile schedule
     void *d_denoised8 = nullptr, *d_denoised32f = nullptr;       // output of the present/denoise pass
+    struct Dist *dist = nullptr;                                 // multi-GPU frame pipeline (vrt_dist_*)
     uint32_t denoised_w = 0, denoised_h = 0;
     hipStream_t denoised_stream = nullptr;
     void *d_status_blocks = nullptr; // derived: 4x4x4 block words + block filter (vrt_trace.hip)
@@ -123,6 +186,23 @@ void free_ctx(vrt_ctx *c) {
     if (c->own_t32 && c->target32f) (void)hipFree(c->target32f);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_status_blocks) (void)hipFree(c->d_status_blocks);
+    if (c->dist) {
+        Dist *d = c->dist;
+        for (uint32_t i = 0; i < d->nslots; i++) {
+            DistSlot &sl = d->slots[i];
+            if (sl.stream) {
+                (void)hipStreamSynchronize(sl.stream);
+                (void)hipStreamDestroy(sl.stream);
+            }
+            if (sl.gathered) (void)hipFree(sl.gathered);
+            else if (sl.shard) (void)hipFree(sl.shard);
+            if (sl.frame) (void)hipFree(sl.frame);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+        }
+        if (d->comm && d->api.CommDestroy) (void)d->api.CommDestroy(d->comm);
+        delete d;
+        c->dist = nullptr;
+    }
     if (c->d_denoised8) (void)hipFree(c->d_denoised8);
     if (c->d_denoised32f) (void)hipFree(c->d_denoised32f);
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
@@ -164,10 +244,14 @@ int begin_scene_write(vrt_ctx *c) {
         VRT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_b_done, 0));
         c->b_pending = false;
     }
+    if (c->dist) {
+        for (uint32_t i = 0; i < c->dist->nslots; i++)
+            if (c->dist->slots[i].used) VRT_HIP(c, hipStreamWaitEvent(c->stream, c->dist->slots[i].done, 0));
+    }
     return VRT_OK;
 }
 int end_scene_write(vrt_ctx *c) {
-    if (c->stream_b) {
+    if (c->stream_b || c->dist) {
         VRT_HIP(c, hipEventRecord(c->ev_upload, c->stream));
         c->upload_seq++;
     }
@@ -475,11 +559,12 @@ int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, cons
     return end_scene_write(ctx);
 }
 
-static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames, bool primary_only = false) {
-    if (!ctx || !camera || !sun || frames == 0) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL camera/sun or zero frames") : VRT_E_INVALID_ARG;
+// Common front part of a frame: argument checks, push constants, derived-structure refresh.  Leaves the
+// kernel to launch in *fn.  Runs on the primary stream.
+static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, vrt::KernelFn *fn) {
+    if (!ctx || !camera || !sun) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL camera/sun") : VRT_E_INVALID_ARG;
     if (camera->image_width != ctx->cfg.width || camera->image_height != ctx->cfg.height)
         return fail(ctx, VRT_E_INVALID_ARG, "camera image size differs from the target image");
-    DeviceGuard dg(ctx->device);
     // The reference blocks here on the previous frame's fence because it re-records its one
     // command buffer (ComputePipeline.zig:423-436).  Launches are stream-ordered and carry their
     // arguments by value, so frames may queue; vrt_wait / vrt_read_* are the synchronisation points.
@@ -500,7 +585,17 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         ctx->status_dirty = false;
     }
     // max_bounce <= 1 ("only primary ray" + its shadow ray): the bounce loop runs at most once
-    const vrt::KernelFn fn = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? ctx->kernel_single1 : ctx->kernel_single) : ctx->kernel;
+    *fn = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? ctx->kernel_single1 : ctx->kernel_single) : ctx->kernel;
+    return VRT_OK;
+}
+
+static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames, bool primary_only = false) {
+    if (frames == 0) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "zero frames") : VRT_E_INVALID_ARG;
+    if (ctx && ctx->dist) return fail(ctx, VRT_E_STATE, "this context runs the multi-GPU pipeline: use vrt_dist_frame");
+    DeviceGuard dg(ctx ? ctx->device : 0);
+    vrt::KernelFn fn = nullptr;
+    const int rcp = pre_dispatch(ctx, camera, sun, &fn);
+    if (rcp != VRT_OK) return rcp;
 
     const bool slot_b = ctx->stream_b && frames == 1 && !primary_only && (ctx->frame_seq & 1u);
     if (slot_b) {
@@ -689,6 +784,172 @@ int vrt_trace_wave_timeline(vrt_ctx *ctx, const vrt_camera_device *camera, const
     (void)hipFree(d);
     *n_pairs = waves;
     return VRT_OK;
+}
+
+// ---- multi-GPU frame pipeline ------------------------------------------------------------------------
+#define VRT_NCCL(ctx, d, call)                                                                               \
+    do {                                                                                                     \
+        const ncclResult_t r_ = (call);                                                                      \
+        if (r_ != ncclSuccess) return fail(ctx, VRT_E_RCCL, std::string(#call) + ": " + (d)->api.GetErrorString(r_)); \
+    } while (0)
+
+int vrt_dist_unique_id(const char *rccl_path, void *out_id128) {
+    if (!rccl_path || !out_id128) return VRT_E_INVALID_ARG;
+    RcclApi api;
+    std::string err;
+    if (!api.load(rccl_path, err)) return fail(nullptr, VRT_E_RCCL, err);
+    ncclUniqueId id;
+    const ncclResult_t r = api.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, VRT_E_RCCL, std::string("ncclGetUniqueId: ") + api.GetErrorString(r));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(out_id128, &id, sizeof id);
+    return VRT_OK;
+}
+
+int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight) {
+    if (!ctx || !rccl_path || !id128) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL argument") : VRT_E_INVALID_ARG;
+    if (ctx->dist) return fail(ctx, VRT_E_STATE, "vrt_dist_init called twice");
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, VRT_E_INVALID_ARG, "bad rank / world");
+    if ((uint32_t)world != ctx->shard.shard_count || (uint32_t)rank != ctx->shard.shard_rank)
+        return fail(ctx, VRT_E_INVALID_ARG, "context was not created with shard_rank / shard_count = rank / world");
+    if (ctx->stream_b || ctx->cfg.stream || ctx->cfg.external_target_rgba8 || ctx->d_counters)
+        return fail(ctx, VRT_E_STATE, "the multi-GPU pipeline owns its streams and targets (no frames_in_flight=2, caller stream/target or counters)");
+    if (frames_in_flight == 0) frames_in_flight = 4;
+    if (frames_in_flight > kMaxDistSlots) return fail(ctx, VRT_E_INVALID_ARG, "at most 8 frames in flight");
+    DeviceGuard dg(ctx->device);
+    Dist *d = new (std::nothrow) Dist();
+    if (!d) return fail(ctx, VRT_E_OOM, "host allocation failed");
+    std::string err;
+    if (!d->api.load(rccl_path, err)) {
+        delete d;
+        return fail(ctx, VRT_E_RCCL, err);
+    }
+    d->rank = rank;
+    d->world = world;
+    d->nslots = frames_in_flight;
+    d->shard_bytes = (size_t)ctx->shard.tiles_per_rank * vrt::kTileW * vrt::kTileH * 4u;
+    ctx->dist = d; // from here free_ctx cleans up
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    VRT_NCCL(ctx, d, d->api.CommInitRank(&d->comm, world, id, rank));
+    for (uint32_t i = 0; i < d->nslots; i++) {
+        DistSlot &sl = d->slots[i];
+        VRT_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        VRT_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        if (rank == 0) {
+            VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&sl.gathered), d->shard_bytes * (size_t)world));
+            VRT_HIP(ctx, hipMemsetAsync(sl.gathered, 0, d->shard_bytes * (size_t)world, ctx->stream));
+            sl.shard = sl.gathered; // rank 0's own tiles are shard 0 of the gathered buffer: no copy
+            VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&sl.frame), (size_t)ctx->cfg.width * ctx->cfg.height * 4u));
+        } else {
+            VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&sl.shard), d->shard_bytes));
+            VRT_HIP(ctx, hipMemsetAsync(sl.shard, 0, d->shard_bytes, ctx->stream));
+        }
+    }
+    if (!ctx->ev_upload) VRT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
+    // everything enqueued on the primary stream so far (scene uploads, clears) precedes the first frame of every slot
+    VRT_HIP(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
+    ctx->upload_seq++;
+    return VRT_OK;
+}
+
+int vrt_dist_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun) {
+    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
+    Dist *d = ctx->dist;
+    DeviceGuard dg(ctx->device);
+    vrt::KernelFn fn = nullptr;
+    const int rcp = pre_dispatch(ctx, camera, sun, &fn);
+    if (rcp != VRT_OK) return rcp;
+    const int k = (int)(d->frame_no % d->nslots);
+    DistSlot &sl = d->slots[k];
+    if (sl.seen_upload != ctx->upload_seq) { // scene writes happen on the primary stream
+        VRT_HIP(ctx, hipStreamWaitEvent(sl.stream, ctx->ev_upload, 0));
+        sl.seen_upload = ctx->upload_seq;
+    }
+    // 1. this rank's tiles, packed tile-major, straight into the buffer RCCL sends (rank 0: into shard 0 of `gathered`)
+    vrt::TraceParams pk = ctx->params;
+    pk.target_rgba8 = sl.shard;
+    pk.target_rgba32f = nullptr;
+    pk.packed_tiles = 1u;
+    VRT_HIP(ctx, vrt::launch_trace(fn, pk, ctx->lds_bytes, sl.stream));
+    // 2. the one collective of the frame: every rank's shard -> rank 0 (grouped point-to-point = gather)
+    if (d->world > 1) {
+        VRT_NCCL(ctx, d, d->api.GroupStart());
+        if (d->rank == 0) {
+            for (int r = 1; r < d->world; r++)
+                VRT_NCCL(ctx, d, d->api.Recv(sl.gathered + (size_t)r * d->shard_bytes, d->shard_bytes, ncclUint8, r, d->comm, sl.stream));
+        } else {
+            VRT_NCCL(ctx, d, d->api.Send(sl.shard, d->shard_bytes, ncclUint8, 0, d->comm, sl.stream));
+        }
+        VRT_NCCL(ctx, d, d->api.GroupEnd());
+    }
+    // 3. rank 0: tile-major shards -> row-major frame
+    if (d->rank == 0)
+        VRT_HIP(ctx, vrt::launch_assemble(sl.gathered, sl.frame, 4, ctx->cfg.width, ctx->cfg.height, ctx->shard.tiles_x, (uint32_t)d->world,
+                                          ctx->shard.tiles_per_rank, sl.stream));
+    VRT_HIP(ctx, hipEventRecord(sl.done, sl.stream));
+    sl.used = true;
+    d->last_slot = k;
+    d->frame_no++;
+    return VRT_OK;
+}
+
+int vrt_dist_wait(vrt_ctx *ctx) {
+    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
+    DeviceGuard dg(ctx->device);
+    for (uint32_t i = 0; i < ctx->dist->nslots; i++) VRT_HIP(ctx, hipStreamSynchronize(ctx->dist->slots[i].stream));
+    VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VRT_OK;
+}
+
+int vrt_dist_read_frame(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
+    if (!ctx || !ctx->dist || !dst) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called / dst NULL") : VRT_E_INVALID_ARG;
+    Dist *d = ctx->dist;
+    if (d->rank != 0) return fail(ctx, VRT_E_STATE, "only rank 0 holds the assembled frame");
+    if (d->last_slot < 0) return fail(ctx, VRT_E_STATE, "no frame submitted yet");
+    if (nbytes > (uint64_t)ctx->cfg.width * ctx->cfg.height * 4u) return fail(ctx, VRT_E_OUT_OF_RANGE, "read exceeds the frame");
+    DeviceGuard dg(ctx->device);
+    DistSlot &sl = d->slots[d->last_slot];
+    VRT_HIP(ctx, hipMemcpyAsync(dst, sl.frame, nbytes, hipMemcpyDeviceToHost, sl.stream));
+    VRT_HIP(ctx, hipStreamSynchronize(sl.stream));
+    return VRT_OK;
+}
+
+int vrt_dist_selftest(vrt_ctx *ctx) {
+    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
+    Dist *d = ctx->dist;
+    DeviceGuard dg(ctx->device);
+    const size_t n = d->shard_bytes;
+    uint8_t *a = nullptr, *b = nullptr;
+    VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a), n));
+    VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&b), n));
+    std::string host(n, '\0'), back(n, '\0');
+    for (size_t i = 0; i < n; i++) host[i] = (char)((i * 131u + 7u) & 0xFFu);
+    hipStream_t s = d->slots[0].stream;
+    int rc = VRT_OK;
+    do {
+        if (hipMemcpyAsync(a, host.data(), n, hipMemcpyHostToDevice, s) != hipSuccess || hipMemsetAsync(b, 0, n, s) != hipSuccess) {
+            rc = fail(ctx, VRT_E_HIP, "selftest copy failed");
+            break;
+        }
+        ncclResult_t r = d->api.GroupStart();
+        if (r == ncclSuccess) r = d->api.Send(a, n, ncclUint8, d->rank, d->comm, s);
+        if (r == ncclSuccess) r = d->api.Recv(b, n, ncclUint8, d->rank, d->comm, s);
+        const ncclResult_t r2 = d->api.GroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) {
+            rc = fail(ctx, VRT_E_RCCL, std::string("self send/recv: ") + d->api.GetErrorString(r));
+            break;
+        }
+        if (hipMemcpyAsync(&back[0], b, n, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(ctx, VRT_E_HIP, "selftest read-back failed");
+            break;
+        }
+        if (back != host) rc = fail(ctx, VRT_E_RCCL, "self send/recv returned different bytes");
+    } while (0);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return rc;
 }
 
 int vrt_get_counters(vrt_ctx *ctx, vrt_counters *out) {

@@ -669,7 +669,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         color = mk3(__builtin_sqrtf(color.x / fspp), __builtin_sqrtf(color.y / fspp), __builtin_sqrtf(color.z / fspp));
 
         size_t o;
-        if (p.shard_count > 1u) {
+        if (p.shard_count > 1u || p.packed_tiles) {
             o = (size_t)owned * (kTileW * kTileH) + in_y * kTileW + in_x; // packed tile-major shard
         } else {
             o = (size_t)py * p.width + px; // row-major frame

@@ -375,6 +375,32 @@ class VoxelRT:
         check(lib.vrt_get_wave_counters(self._h, C.byref(out)), self._h)
         return {"wave_grid_iters": out[0], "wave_brick_walks": out[1], "wave_voxel_iters": out[2]}
 
+    # -- multi-GPU frame pipeline (native RCCL; see include/vrt_hip.h vrt_dist_*) --------------------
+    @staticmethod
+    def dist_unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        check(lib.vrt_dist_unique_id(L.rccl_library_path().encode(), buf))
+        return bytes(buf)
+
+    def dist_init(self, unique_id: bytes, rank: int, world: int, frames_in_flight: int = 4) -> None:
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(lib.vrt_dist_init(self._h, L.rccl_library_path().encode(), buf, rank, world, frames_in_flight), self._h)
+
+    def dist_frame(self) -> None:
+        check(lib.vrt_dist_frame(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data)), self._h)
+
+    def dist_wait(self) -> None:
+        check(lib.vrt_dist_wait(self._h), self._h)
+
+    def dist_read_frame(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        check(lib.vrt_dist_read_frame(self._h, out.ctypes.data, out.nbytes), self._h)
+        return out
+
+    def dist_selftest(self) -> None:
+        check(lib.vrt_dist_selftest(self._h), self._h)
+
     def create_benchmark(self) -> "Benchmark":  # VoxelRT.createBenchmark, VoxelRT.zig:72-74
         return Benchmark(self.camera)
 
