@@ -1,0 +1,114 @@
+"""Boundary behaviour on a real device: error codes instead of aborts, upload semantics (caller keeps
+ownership, ranges, device-to-device), buffer sizes as Pipeline.zig:273-283 derives them."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.helpers import O, oracle_scene_from_grid
+from zig_vulkan_amd import BrickGrid, Config, VoxelRT, default_materials
+from zig_vulkan_amd import _lib as L
+from zig_vulkan_amd import workloads as W
+from zig_vulkan_amd._lib import VrtError, lib
+
+pytestmark = pytest.mark.gpu
+
+
+def test_buffer_sizes_follow_the_grid():
+    g = BrickGrid(6, 5, 4, brick_dimension=8, brick_alloc=50)
+    rt = VoxelRT(g, Config(internal_resolution_width=64, internal_resolution_height=48))
+    cells = 6 * 5 * 4
+    assert rt.buffer_size(L.BUF_GRID_STATE) == 64
+    assert rt.buffer_size(L.BUF_MATERIALS) == 256 * 20
+    assert rt.buffer_size(L.BUF_BRICK_STATUS) == ((cells + 31) // 32) * 4
+    assert rt.buffer_size(L.BUF_BRICK_INDEX) == cells * 4
+    assert rt.buffer_size(L.BUF_BRICK_OCCUPANCY) == 50 * 64
+    assert rt.buffer_size(L.BUF_BRICK_START_INDEX) == 50 * 4
+    assert rt.buffer_size(L.BUF_MATERIAL_INDEX) == 50 * 512
+    rt.deinit()
+
+
+def test_errors_are_codes_not_aborts():
+    g = BrickGrid(4, 4, 4)
+    rt = VoxelRT(g, Config(internal_resolution_width=64, internal_resolution_height=48))
+    data = np.zeros(64, dtype=np.uint8)
+    with pytest.raises(VrtError) as e:  # DestOutOfDeviceMemory, StagingRamp.zig:320-325
+        rt.upload(L.BUF_BRICK_STATUS, rt.buffer_size(L.BUF_BRICK_STATUS) - 8, data)
+    assert e.value.code == L.VRT_E_OUT_OF_RANGE and "exceeds" in str(e.value)
+    with pytest.raises(VrtError) as e:
+        rt.upload(99, 0, data)
+    assert e.value.code == L.VRT_E_INVALID_ARG
+    other = W.Camera(75.0, 32, 32)  # camera for another image size
+    assert lib.vrt_dispatch(rt._h, C.byref(other.d_camera), C.byref(rt.sun.device_data)) == L.VRT_E_INVALID_ARG
+    assert lib.vrt_dispatch(rt._h, None, None) == L.VRT_E_INVALID_ARG
+    assert lib.vrt_read_rgba32f(rt._h, data.ctypes.data, 16) == L.VRT_E_STATE  # want_float_output was 0
+    c = L.Counters()
+    assert lib.vrt_get_counters(rt._h, C.byref(c)) == L.VRT_E_STATE
+    big = np.zeros(64 * 48 * 4 + 4, dtype=np.uint8)
+    assert lib.vrt_read_rgba8(rt._h, big.ctypes.data, big.nbytes) == L.VRT_E_OUT_OF_RANGE
+    # a grid state whose brick dimensions contradict the context is refused at dispatch
+    bad = bytearray(bytes(g.device_state))
+    bad[12:16] = (5).to_bytes(4, "little")  # dim_x = 5
+    rt.upload(L.BUF_GRID_STATE, 0, np.frombuffer(bytes(bad), dtype=np.uint8))
+    with pytest.raises(VrtError) as e:
+        rt.draw()
+    assert e.value.code == L.VRT_E_INVALID_ARG
+    rt.deinit()
+
+
+def test_upload_copies_before_returning_and_partial_ranges():
+    """The caller keeps ownership of the source (Grid.zig:117-126): overwriting it right after the call
+    must not change the frame; partial uploads land at their byte offset."""
+    w = W.Workload("t", 160, 100, 64, 4, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    from zig_vulkan_amd.voxel_rt import CameraConfig, SunConfig
+    rt = VoxelRT(grid, Config(internal_resolution_width=160, internal_resolution_height=100, camera=CameraConfig(samples_per_pixel=1, max_bounce=0),
+                              sun=SunConfig(enabled=True, radius=0.0)), upload_grid=False)
+    rt.push_materials(default_materials(256))
+    rt.upload(L.BUF_GRID_STATE, 0, np.frombuffer(bytes(grid.device_state), dtype=np.uint8))
+    for bid in (L.BUF_BRICK_STATUS, L.BUF_BRICK_INDEX, L.BUF_BRICK_OCCUPANCY, L.BUF_BRICK_START_INDEX, L.BUF_MATERIAL_INDEX):
+        src = grid.array(bid)
+        raw = src.view(np.uint8)
+        half = (raw.size // 2) & ~3
+        scratch = raw[:half].copy()
+        rt.upload(bid, 0, scratch)
+        scratch[:] = 0xEE  # scribble over the source immediately
+        tail = raw[half:].copy()
+        rt.upload(bid, half, tail)
+        tail[:] = 0x11
+    W.set_view(rt, "V1")
+    rt.draw()
+    u = rt.read_rgba8()
+    pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+    rt.deinit()
+    _, uo, _ = O.render(oracle_scene_from_grid(grid), pc)
+    assert np.array_equal(u, uo)
+
+
+def test_device_to_device_upload_and_caller_stream():
+    import torch
+    w = W.Workload("t", 160, 100, 64, 4, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    stream = torch.cuda.Stream()
+    target = torch.zeros(100 * 160 * 4, dtype=torch.uint8, device="cuda")
+    from zig_vulkan_amd.voxel_rt import CameraConfig, SunConfig
+    rt = VoxelRT(grid, Config(internal_resolution_width=160, internal_resolution_height=100, camera=CameraConfig(samples_per_pixel=1, max_bounce=0),
+                              sun=SunConfig(enabled=True, radius=0.0), stream=stream.cuda_stream, external_target_rgba8=target.data_ptr()),
+                 upload_grid=False)
+    rt.push_materials(default_materials(256))
+    rt.upload(L.BUF_GRID_STATE, 0, np.frombuffer(bytes(grid.device_state), dtype=np.uint8))
+    keep = []
+    for bid in (L.BUF_BRICK_STATUS, L.BUF_BRICK_INDEX, L.BUF_BRICK_OCCUPANCY, L.BUF_BRICK_START_INDEX, L.BUF_MATERIAL_INDEX):
+        dev = torch.from_numpy(grid.array(bid).view(np.uint8).copy()).cuda()
+        keep.append(dev)
+        torch.cuda.synchronize()
+        L.check(lib.vrt_upload_device(rt._h, bid, 0, dev.data_ptr(), dev.numel()), rt._h)
+    W.set_view(rt, "V2")
+    rt.draw()
+    rt.wait()
+    stream.synchronize()
+    u = target.cpu().numpy().reshape(100, 160, 4)  # the caller-owned image was written
+    pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+    rt.deinit()
+    _, uo, _ = O.render(oracle_scene_from_grid(grid), pc)
+    assert np.array_equal(u, uo)
