@@ -268,3 +268,87 @@ def test_native_rccl_pipeline_single_rank():
     rt.deinit()
     _, want, _, _ = _run_hip(w, grid, "V1", counters=False)
     assert np.array_equal(got, want) and not np.array_equal(want, ref["V1"])
+
+
+def _parity_for(grid, w, view_setup, materials=None, counters=True):
+    rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=counters)
+    if materials is not None:
+        rt.push_materials(materials)
+    view_setup(rt)
+    rt.draw()
+    f, u = rt.read_rgba32f(), rt.read_rgba8()
+    c = rt.counters() if counters else None
+    pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+    rt.deinit()
+    fo, uo, co = O.render(oracle_scene_from_grid(grid, materials), pc)
+    return f, u, c, fo, uo, co
+
+
+def test_quirk_unknown_material_type_and_glass_and_metal():
+    """SURVEY.md §8 quirks 7-8 and the scatter paths: a scene of glass, metal and an out-of-enum material
+    type (loop_count -= 1, comp:235-238), traced with bounces."""
+    from zig_vulkan_amd import BrickGrid, default_materials
+    mats = default_materials(256)
+    mats[9] = (7, 0.9, 0.2, 0.9, 1.0)      # unknown type 7
+    mats[10] = (3, 0.3, 0.9, 0.3, 1.0)     # type == MAT_NONE with type_data == 1: the ignore test of comp:427 matches it
+    mats[11] = (2, 0.9, 0.9, 1.0, 1.52)    # glass
+    mats[12] = (1, 0.8, 0.8, 0.8, 0.05)    # polished metal
+    grid = BrickGrid(16, 16, 16, min_point=(-32, -32, -32), scale=4.0, brick_dimension=4)
+    rng = np.random.default_rng(11)
+    for cx, cz, m in [(12, 12, 9), (30, 14, 10), (48, 12, 11), (14, 40, 12), (34, 40, 0), (50, 44, 7)]:
+        for x in range(cx - 5, cx + 6):
+            for z in range(cz - 5, cz + 6):
+                for y in range(24, 40):
+                    if (x - cx) ** 2 + (z - cz) ** 2 <= 30 or y < 27:
+                        grid.insert(x, y, z, m)
+    for x in range(64):
+        for z in range(64):
+            grid.insert(x, 20, z, 1 + int(rng.integers(0, 6)))
+    w = W.Workload("t", 240, 160, 64, 4, 2, 3, True, 5.0)
+    f, u, c, fo, uo, co = _parity_for(grid, w, lambda rt: rt.camera.look_at((10.0, -14.0, 36.0), (0.0, 4.0, 0.0)), mats)
+    _compare(f, u, c, fo, uo, co)
+    assert co["hits"] > 0 and co["rays"] > 240 * 160 * 2
+
+
+def test_camera_inside_solid_and_axis_aligned_rays():
+    """Rays that start inside an occupied brick / voxel, and a camera whose centre column and row hold
+    rays with exactly zero direction components (safeInverse(0) = 1e12, sign(0) = 0)."""
+    from zig_vulkan_amd import BrickGrid
+    grid = BrickGrid(8, 8, 8, min_point=(-16, -16, -16), scale=4.0, brick_dimension=8)
+    for x in range(20, 44):
+        for y in range(20, 44):
+            for z in range(20, 44):
+                if (x + y + z) % 3:
+                    grid.insert(x, y, z, 1 + (x % 6))
+    w = W.Workload("t", 129, 97, 64, 8, 1, 0, True, 0.0)  # odd sizes: pixel (64,48) is the exact image centre
+    f, u, c, fo, uo, co = _parity_for(grid, w, lambda rt: rt.camera.set_origin((0.3, 0.2, 0.1)))  # inside the block, looking -Z
+    _compare(f, u, c, fo, uo, co)
+    f, u, c, fo, uo, co = _parity_for(grid, w, lambda rt: rt.camera.set_origin((0.0, 0.0, 40.0)))  # outside, centre ray = (0,0,-1)
+    _compare(f, u, c, fo, uo, co)
+    assert co["hits"] > 0
+
+
+def test_degenerate_one_pixel_image_nan_rays():
+    """image_width - 1 == 0 makes u = 0/0 (comp:168): every ray direction is NaN.  The shader then misses
+    the slab test and the colour is NaN, stored as 0; kernel and oracle must agree on that too."""
+    from zig_vulkan_amd import BrickGrid
+    grid = BrickGrid(4, 4, 4, min_point=(-8, -8, -8), scale=4.0)
+    grid.insert(8, 8, 8, 1)
+    w = W.Workload("t", 1, 1, 16, 4, 1, 0, True, 0.0)
+    f, u, c, fo, uo, co = _parity_for(grid, w, lambda rt: rt.camera.set_origin((0.0, 0.0, 20.0)))
+    assert np.array_equal(np.isnan(f), np.isnan(fo)) and np.isnan(fo[0, 0, :3]).all()
+    assert np.array_equal(u, uo) and u[0, 0].tolist() == [0, 0, 0, 255]
+    assert c == co and co["rays"] == 1
+
+
+def test_sparse_allocation_fewer_slots_than_cells():
+    """brick_alloc below the cell count (the 2048^3 configuration's case): slots are handed out in
+    insertion order, unset start indices stay 0xFFFFFFFF for unused slots."""
+    from zig_vulkan_amd import BrickGrid
+    grid = BrickGrid(32, 32, 32, min_point=(-32, -32, -32), scale=2.0, brick_dimension=8, brick_alloc=6000)
+    grid.synth_sparse(420, 0.08)
+    assert 0 < grid.active_bricks <= 6000 < 32 ** 3
+    w = W.Workload("t", 200, 150, 256, 8, 1, 1, True, 5.0, "sparse", 0.08, 6000)
+    f, u, c, fo, uo, co = _parity_for(grid, w, lambda rt: W.set_view(rt, "V2"))
+    _compare(f, u, c, fo, uo, co)
+    assert co["hits"] > 0
