@@ -71,6 +71,19 @@ pub extern fn vrt_device_target_rgba8(ctx: *Ctx) ?*anyopaque;
 pub extern fn vrt_last_kernel_ms(ctx: *Ctx) f64;
 pub extern fn vrt_last_error(ctx: ?*const Ctx) [*:0]const u8;
 
+// the step after the path: image.frag's denoiser as a HIP kernel (GraphicsPipeline.Config defaults when cfg == null)
+pub const DenoiseConfig = extern struct { samples: i32 = 20, distribution_bias: f32 = 0.6, pixel_multiplier: f32 = 1.5, inverse_hue_tolerance: f32 = 20 };
+pub extern fn vrt_denoise(ctx: *Ctx, cfg: ?*const DenoiseConfig, out_w: u32, out_h: u32, want_float: u32) c_int;
+pub extern fn vrt_read_denoised_rgba8(ctx: *Ctx, dst: *anyopaque, nbytes: u64) c_int;
+pub extern fn vrt_device_denoised_rgba8(ctx: *Ctx) ?*anyopaque;
+
+// multi-GPU frame pipeline (one process per GPU; rank 0 owns the assembled frame)
+pub extern fn vrt_dist_unique_id(rccl_path: [*:0]const u8, out_id128: *[128]u8) c_int;
+pub extern fn vrt_dist_init(ctx: *Ctx, rccl_path: [*:0]const u8, id128: *const [128]u8, rank: c_int, world: c_int, frames_in_flight: u32) c_int;
+pub extern fn vrt_dist_frame(ctx: *Ctx, camera: *const anyopaque, sun: *const anyopaque) c_int;
+pub extern fn vrt_dist_wait(ctx: *Ctx) c_int;
+pub extern fn vrt_dist_read_frame(ctx: *Ctx, dst: *anyopaque, nbytes: u64) c_int;
+
 fn check(rc: c_int) !void {
     return switch (@as(Status, @enumFromInt(rc))) {
         .ok => {},
