@@ -38,7 +38,7 @@ def _compare(f, u, c, fo, uo, co):
 
 
 @pytest.mark.parametrize("view", ["V0", "V1", "V2"])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 0x10002, 0x20003, 0x30001, 0x60001, 0x140001])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 0x10002, 0x20003, 0x30001, 0x60001, 0x140001])
 def test_config0_primary_rays(view, variant):
     w = W.WORKLOADS["cfg0_256x256_64c_b4"]
     grid = W.build_grid(w)
@@ -222,7 +222,7 @@ def test_odd_grid_dimensions(dims):
     n = 40 * dims[0] * dims[1] * dims[2]
     xyz = np.stack([rng.integers(0, 4 * d, n) for d in dims], axis=-1)
     grid.insert_many(xyz, rng.integers(0, 8, n))
-    for variant in (0, 1, 2, 3, 5, 6, 7):
+    for variant in (0, 1, 2, 3, 5, 6, 7, 8):
         rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, kernel_variant=variant)
         rt.camera.look_at((30.0, -25.0, 40.0), (0.0, 5.0, 0.0))
         rt.draw()

@@ -74,6 +74,7 @@ enum : uint32_t {
     kVariantLinearAlways = 5, // linear status word loaded on every step (no per-lane cache / branch)
     kVariantLinearLds = 6,    // linear status bitmap staged in LDS per workgroup (grids whose bitmap fits)
     kVariantLinearLds512 = 7, // the same with 512-thread workgroups (two tiles share one LDS copy)
+    kVariantLinearAhead = 8,  // uncached status word, software-pipelined one cell ahead
     kVariantCount
 };
 

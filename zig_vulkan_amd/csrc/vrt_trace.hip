@@ -266,7 +266,8 @@ enum StatusMode : int {
     kStatusBlockedLds = 2, // same, behind an LDS-resident 1-bit-per-block "non-empty" filter
     kStatusLinearWide = 3, // linear words for status, 64-bit words for occupancy
     kStatusLinearAlways = 4, // linear words, loaded on every step (no per-lane word cache, no branch)
-    kStatusLinearLds = 5     // the whole linear status bitmap staged in LDS per workgroup, read on every step
+    kStatusLinearLds = 5,    // the whole linear status bitmap staged in LDS per workgroup, read on every step
+    kStatusLinearAhead = 6   // as kStatusLinearAlways, software-pipelined: the next cell's word is requested before the current cell is tested
 };
 
 // comp:271-376.  t_min = 1e-5, t_max = +inf at every call site (comp:218,247).
@@ -372,17 +373,20 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
             return bit64(block_bits, (uint32_t)((cx & 3) | ((cz & 3) << 2) | ((cy & 3) << 4)));
         }
     };
-    auto enter_brick = [&]() {
-        const int cx = base_x - __mul24(s.sx, w.rx), cy = base_y - __mul24(s.sy, w.ry), cz = base_z - __mul24(s.sz, w.rz); // cell position
+    // walk the brick of the cell reached with steps-left (rx,ry,rz), crossed-distance t and linear index `cell`
+    auto enter_brick_at = [&](int rx, int ry, int rz, float t_cross, uint32_t cell, int &brick_axis) {
+        const int cx = base_x - __mul24(s.sx, rx), cy = base_y - __mul24(s.sy, ry), cz = base_z - __mul24(s.sz, rz); // cell position
         const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min);  // comp:331
-        global_t_value = w.t_value * g_scale + s.grid_t_min + 0.01f * g_scale;                   // comp:347 (deferred) + comp:332
+        global_t_value = t_cross * g_scale + s.grid_t_min + 0.01f * g_scale;                     // comp:347 (deferred) + comp:332
         hit.t = global_t_value;
-        const uint32_t brick_index = p.brick_index[grid_index]; // comp:337
+        const uint32_t brick_index = p.brick_index[cell]; // comp:337
         VRT_COUNT(bricks_entered);
         VRT_COUNT_WAVE(wave_brick_walks);
-        const bool found = brick_walk<B, COUNT, MODE == kStatusLinear || MODE == kStatusLinearAlways || MODE == kStatusLinearLds>(p, r, s, g_scale, brick_index, brick_min, hit, axis, c);
+        const bool found = brick_walk<B, COUNT, MODE == kStatusLinear || MODE == kStatusLinearAlways || MODE == kStatusLinearLds || MODE == kStatusLinearAhead>(
+            p, r, s, g_scale, brick_index, brick_min, hit, brick_axis, c);
         stop = found ? -1 : ((global_t_value <= t_max) ? 0 : -2);
     };
+    auto enter_brick = [&]() { enter_brick_at(w.rx, w.ry, w.rz, w.t_value, grid_index, axis); };
 
     if constexpr (BATCH) {
         // lane state: 0 at a cell (test it), 1 waiting to walk a brick, 2 finished, 3 take the DDA step
@@ -403,6 +407,36 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
                 dda_step<true>(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
                 state = (min3i(w.rx, w.ry, w.rz) >= 0) ? 0 : 2;
             }
+        }
+        return stop == -1;
+    } else if constexpr (MODE == kStatusLinearAhead) {
+        // Software-pipelined walk.  The DDA step does not depend on the cell test, so it is taken first and
+        // the status word of the NEXT cell is requested right away; the current cell is tested while that load
+        // is in flight (its latency otherwise sits between every two steps).  If the current cell is occupied
+        // its brick is walked with the pre-step state, rebuilt from the post-step state and the crossed axis.
+        uint32_t word = more ? p.brick_status[grid_index >> 5] : 0u;
+        while (more) {
+            VRT_COUNT(grid_steps);
+            VRT_COUNT_WAVE(wave_grid_iters);
+            if constexpr (COUNT) {
+                const uint32_t wi = grid_index >> 5;
+                if (wi != word_index) {
+                    word_index = wi;
+                    c.status_loads++;
+                }
+            }
+            const bool occupied = status_bit(word, grid_index);
+            const float t_here = w.t_value; // crossed distance of the step INTO the current cell
+            int axis_here = axis;
+            dda_step<true>(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
+            const bool inside = min3i(w.rx, w.ry, w.rz) >= 0;
+            word = inside ? p.brick_status[grid_index >> 5] : 0u;
+            if (occupied) {
+                const int a = axis; // the step just taken left the current cell through this axis
+                enter_brick_at(w.rx + (a == 0 ? 1 : 0), w.ry + (a == 1 ? 1 : 0), w.rz + (a == 2 ? 1 : 0), t_here,
+                               grid_index - (a == 0 ? stride_x : (a == 1 ? stride_y : stride_z)), axis_here);
+            }
+            more = ((inside ? 0 : -1) | stop) >= 0;
         }
         return stop == -1;
     } else {
@@ -816,6 +850,7 @@ static KernelFn pick_mode(uint32_t mode) {
         case kVariantLinearAlways: return vrt_trace_kernel<B, COUNT, kStatusLinearAlways, MW, SHADE>;
         case kVariantLinearLds: return vrt_trace_kernel<B, COUNT, kStatusLinearLds, MW, SHADE>;
         case kVariantLinearLds512: return vrt_trace_kernel<B, COUNT, kStatusLinearLds, MW, SHADE, 512>;
+        case kVariantLinearAhead: return vrt_trace_kernel<B, COUNT, kStatusLinearAhead, MW, SHADE>;
         default: return nullptr;
     }
 }
