@@ -115,6 +115,46 @@ VRT_DI void dda_step(Walk &w, const f3 &ray_delta, float scale, int &axis, uint3
     axis = ax ? 0 : (ay ? 1 : 2);
 }
 
+// The brick-level step, hand-scheduled for gfx950: the same operations as dda_step<true> in 22 VALU and 3
+// SALU instructions (hipcc's version: 27 + 7 — it re-compares for !(x<y), widens the z counter update to
+// cndmask+sub and shuffles lane masks through VALU).  Lane masks stay in SGPR pairs and feed v_cndmask /
+// v_subbrev / v_addc directly; the ray's |1/dir| comes in as an |abs| source modifier on the signed
+// inverse.  t_value is left unscaled (DEFER_T).  Comparison semantics are the shader's: `!(x<y)` is
+// s_andn2 of the x<y mask, so NaN operands take the same branches as comp:345-372.
+VRT_DI void dda_step_gfx950(Walk &w, const f3 &inv_dir, int &axis, uint32_t &index, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z) {
+    unsigned long long m_ax, m_ay, m_axy, carry;
+    float nx, ny, nz, tsel;
+    int ax_out;
+    asm("v_cmp_lt_f32_e64 %[mx], %[sdx], %[sdy]\n\t"
+        "v_cmp_lt_f32_e64 %[mxy], %[sdx], %[sdz]\n\t"
+        "v_cmp_lt_f32_e64 %[my], %[sdy], %[sdz]\n\t"
+        "v_add_f32_e64 %[nx], %[sdx], |%[ix]|\n\t"
+        "v_add_f32_e64 %[ny], %[sdy], |%[iy]|\n\t"
+        "v_add_f32_e64 %[nz], %[sdz], |%[iz]|\n\t"
+        "s_andn2_b64 %[my], %[my], %[mx]\n\t"   // y crossed: (y<z) & !(x<y)
+        "s_and_b64 %[mx], %[mx], %[mxy]\n\t"    // x crossed: (x<y) & (x<z)
+        "s_or_b64 %[mxy], %[mx], %[my]\n\t"     // x or y crossed; z otherwise
+        "v_cndmask_b32_e64 %[ts], %[sdz], %[sdy], %[my]\n\t"
+        "v_cndmask_b32_e64 %[ts], %[ts], %[sdx], %[mx]\n\t"
+        "v_cndmask_b32_e64 %[sdx], %[sdx], %[nx], %[mx]\n\t"
+        "v_cndmask_b32_e64 %[sdy], %[sdy], %[ny], %[my]\n\t"
+        "v_cndmask_b32_e64 %[sdz], %[nz], %[sdz], %[mxy]\n\t"
+        "v_subbrev_co_u32_e64 %[rx], %[cc], 0, %[rx], %[mx]\n\t"
+        "v_subbrev_co_u32_e64 %[ry], %[cc], 0, %[ry], %[my]\n\t"
+        "v_addc_co_u32_e64 %[rz], %[cc], -1, %[rz], %[mxy]\n\t" // rz - 1 + (x or y crossed)
+        "v_cndmask_b32_e64 %[nx], %[stz], %[sty], %[my]\n\t"
+        "v_cndmask_b32_e64 %[nx], %[nx], %[stx], %[mx]\n\t"
+        "v_add_u32_e32 %[idx], %[idx], %[nx]\n\t"
+        "v_cndmask_b32_e64 %[ax], 2, 1, %[my]\n\t"
+        "v_cndmask_b32_e64 %[ax], %[ax], 0, %[mx]"
+        : [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),
+          [idx] "+v"(index), [ts] "=&v"(tsel), [ax] "=&v"(ax_out), [nx] "=&v"(nx), [ny] "=&v"(ny), [nz] "=&v"(nz), [mx] "=&s"(m_ax),
+          [my] "=&s"(m_ay), [mxy] "=&s"(m_axy), [cc] "=&s"(carry)
+        : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z));
+    w.t_value = tsel;
+    axis = ax_out;
+}
+
 // comp:298 / comp:395
 VRT_DI f3 initial_side_dist(f3 fstep, f3 fposition, f3 ray_delta) {
     const f3 intersection_delta = floor3(fposition) - fposition;
@@ -122,7 +162,8 @@ VRT_DI f3 initial_side_dist(f3 fstep, f3 fposition, f3 ray_delta) {
 }
 
 struct RaySetup {
-    f3 ray_delta;
+    f3 ray_delta; // |1/dir|
+    f3 inv_dir;   // 1/dir (safeInverse), kept for the |abs|-modifier form of the hand-scheduled step
     int entry_code; // slab-entry normal (comp:529-531): axis index | sign bits, see entry_normal()
     int sx, sy, sz;
     float grid_t_min, grid_t_max;
@@ -149,6 +190,7 @@ VRT_DI bool grid_slab(const TraceParams &p, const Ray &r, float t_min, float t_m
     s.grid_t_min = gl_max(t_min, tmin_i);
     s.grid_t_max = gl_min(t_max, gl_min(gl_min(t_maxes.x, t_maxes.y), t_maxes.z));
     s.ray_delta = abs3(inv);
+    s.inv_dir = inv;
     s.sx = (int)sign1(r.direction.x);
     s.sy = (int)sign1(r.direction.y);
     s.sz = (int)sign1(r.direction.z);
@@ -442,7 +484,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     } else {
         while (more) { // single-exit loop, see brick_walk
             if (cell_occupied()) enter_brick();
-            dda_step<true>(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
+            dda_step_gfx950(w, s.inv_dir, axis, grid_index, stride_x, stride_y, stride_z);
             more = (min3i(w.rx, w.ry, w.rz) | stop) >= 0;
         }
         return stop == -1;
