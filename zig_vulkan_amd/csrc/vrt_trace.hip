@@ -155,6 +155,51 @@ VRT_DI void dda_step_gfx950(Walk &w, const f3 &inv_dir, int &axis, uint32_t &ind
     axis = ax_out;
 }
 
+// The brick-level step as three EXEC regions (the shipped default).  Every lane crosses exactly one axis per
+// step, so instead of computing all three candidates and selecting (v_cndmask per value), the wave runs the
+// x-, y- and z-updates under EXEC = the lanes crossing that axis: side_dist += |1/dir|, steps-left -= 1,
+// index += stride — 3 VALU per region, 14 VALU + 10 SALU per step against 22 + 3 for the select form (the
+// kernel is VALU-issue bound, the scalar unit has slack).  The borrow of the steps-left decrement IS the
+// box-exit test (a counter at 0 is decremented exactly when the lane leaves through that face), so the loop
+// condition needs no VALU at all: `exit` comes back as a lane mask in an SGPR pair.  A VOP3 carry-out writes
+// zero for lanes outside EXEC (tools/isa_probe.hip checks this on the hardware).  The crossed-axis masks are
+// returned so that the axis (hit normal) is materialised only when a brick is entered; t_value stays
+// unscaled (DEFER_T).  Same comparison semantics as dda_step (comp:345-372), same float operations per lane.
+VRT_DI void dda_step_regions(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
+                             unsigned long long &m_ax, unsigned long long &m_ay, unsigned long long &exit_mask) {
+    unsigned long long m_axy, save, by, bz;
+    float tsel;
+    asm("v_cmp_lt_f32_e64 %[mx], %[sdx], %[sdy]\n\t"
+        "v_cmp_lt_f32_e64 %[mxy], %[sdx], %[sdz]\n\t"
+        "v_cmp_lt_f32_e64 %[my], %[sdy], %[sdz]\n\t"
+        "s_mov_b64 %[save], exec\n\t"
+        "s_andn2_b64 %[my], %[my], %[mx]\n\t"   // y crossed: (y<z) & !(x<y)
+        "s_and_b64 %[mx], %[mx], %[mxy]\n\t"    // x crossed: (x<y) & (x<z)
+        "s_or_b64 %[mxy], %[mx], %[my]\n\t"     // x or y crossed; z otherwise
+        "v_cndmask_b32_e64 %[ts], %[sdz], %[sdy], %[my]\n\t"
+        "v_cndmask_b32_e64 %[ts], %[ts], %[sdx], %[mx]\n\t"
+        "s_mov_b64 exec, %[mx]\n\t"
+        "v_add_f32_e64 %[sdx], %[sdx], |%[ix]|\n\t"
+        "v_sub_co_u32_e64 %[rx], %[ex], %[rx], 1\n\t"
+        "v_add_u32_e32 %[idx], %[idx], %[stx]\n\t"
+        "s_mov_b64 exec, %[my]\n\t"
+        "v_add_f32_e64 %[sdy], %[sdy], |%[iy]|\n\t"
+        "v_sub_co_u32_e64 %[ry], %[by], %[ry], 1\n\t"
+        "v_add_u32_e32 %[idx], %[idx], %[sty]\n\t"
+        "s_andn2_b64 exec, %[save], %[mxy]\n\t"
+        "v_add_f32_e64 %[sdz], %[sdz], |%[iz]|\n\t"
+        "v_sub_co_u32_e64 %[rz], %[bz], %[rz], 1\n\t"
+        "v_add_u32_e32 %[idx], %[idx], %[stz]\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        "s_or_b64 %[ex], %[ex], %[by]\n\t"
+        "s_or_b64 %[ex], %[ex], %[bz]"
+        : [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),
+          [idx] "+v"(index), [ts] "=&v"(tsel), [mx] "=&s"(m_ax), [my] "=&s"(m_ay), [mxy] "=&s"(m_axy), [save] "=&s"(save), [ex] "=&s"(exit_mask),
+          [by] "=&s"(by), [bz] "=&s"(bz)
+        : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z));
+    w.t_value = tsel;
+}
+
 // comp:298 / comp:395
 VRT_DI f3 initial_side_dist(f3 fstep, f3 fposition, f3 ray_delta) {
     const f3 intersection_delta = floor3(fposition) - fposition;
@@ -482,10 +527,49 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         }
         return stop == -1;
     } else {
+        // Software-pipelined walk over the region step.  The step does not depend on the cell test, so it is
+        // taken first and the status word of the NEXT cell is requested at once; the current cell's bit is
+        // tested while that load is in flight.  Everything a brick entry needs from before the step is
+        // rebuilt, in the rare taken path only, from the post-step state and the two sets of crossed-axis lane
+        // masks (c_*: the step INTO the current cell, n_*: the step just taken OUT of it).  The rare path sits
+        // behind a wave-uniform branch so that "some lane stopped" can live in an SGPR pair as well: the loop
+        // condition is scalar work only.  Status words are fetched through a buffer resource: a lane that
+        // has left the grid carries an arbitrary index and reads 0 instead of faulting.
+        const __amdgpu_buffer_rsrc_t status_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.brick_status), 0, (int)(p.status_words * 4u), 0x00020000);
+        unsigned long long c_ax = 0ull, c_ay = 0ull, stop_mask = 0ull;
+        int have_axis = 0; // wave-uniform: all lanes of a wave take their first trip together
+        uint32_t word = __builtin_amdgcn_raw_buffer_load_b32(status_rsrc, (grid_index >> 3) & ~3u, 0, 0);
         while (more) { // single-exit loop, see brick_walk
-            if (cell_occupied()) enter_brick();
-            dda_step_gfx950(w, s.inv_dir, axis, grid_index, stride_x, stride_y, stride_z);
-            more = (min3i(w.rx, w.ry, w.rz) | stop) >= 0;
+            VRT_COUNT(grid_steps);
+            VRT_COUNT_WAVE(wave_grid_iters);
+            if constexpr (COUNT) {
+                const uint32_t wi = grid_index >> 5;
+                if (wi != word_index) {
+                    word_index = wi;
+                    c.status_loads++;
+                }
+            }
+            const bool occupied = status_bit(word, grid_index);
+            const float t_here = w.t_value; // crossed distance of the step INTO the current cell
+            unsigned long long n_ax, n_ay, exit_mask;
+            dda_step_regions(w, s.inv_dir, grid_index, stride_x, stride_y, stride_z, n_ax, n_ay, exit_mask);
+            word = __builtin_amdgcn_raw_buffer_load_b32(status_rsrc, (grid_index >> 3) & ~3u, 0, 0);
+            if (__builtin_amdgcn_ballot_w64(occupied) != 0ull) {
+                if (occupied) {
+                    int a = have_axis ? (__builtin_amdgcn_inverse_ballot_w64(c_ax) ? 0 : (__builtin_amdgcn_inverse_ballot_w64(c_ay) ? 1 : 2)) : 3;
+                    const bool out_x = __builtin_amdgcn_inverse_ballot_w64(n_ax), out_y = __builtin_amdgcn_inverse_ballot_w64(n_ay);
+                    enter_brick_at(w.rx + (out_x ? 1 : 0), w.ry + (out_y ? 1 : 0), w.rz + ((out_x | out_y) ? 0 : 1), t_here,
+                                   grid_index - (out_x ? stride_x : (out_y ? stride_y : stride_z)), a);
+                }
+                stop_mask = __builtin_amdgcn_ballot_w64(stop != 0);
+            }
+            c_ax = n_ax;
+            c_ay = n_ay;
+            have_axis = 1;
+            unsigned long long leave; // (as asm: the compiler would otherwise do this OR on the vector unit)
+            asm("s_or_b64 %0, %1, %2" : "=s"(leave) : "s"(exit_mask), "s"(stop_mask));
+            more = !__builtin_amdgcn_inverse_ballot_w64(leave);
         }
         return stop == -1;
     }
