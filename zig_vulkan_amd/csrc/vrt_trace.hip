@@ -115,90 +115,128 @@ VRT_DI void dda_step(Walk &w, const f3 &ray_delta, float scale, int &axis, uint3
     axis = ax ? 0 : (ay ? 1 : 2);
 }
 
-// The brick-level step, hand-scheduled for gfx950: the same operations as dda_step<true> in 22 VALU and 3
-// SALU instructions (hipcc's version: 27 + 7 — it re-compares for !(x<y), widens the z counter update to
-// cndmask+sub and shuffles lane masks through VALU).  Lane masks stay in SGPR pairs and feed v_cndmask /
-// v_subbrev / v_addc directly; the ray's |1/dir| comes in as an |abs| source modifier on the signed
-// inverse.  t_value is left unscaled (DEFER_T).  Comparison semantics are the shader's: `!(x<y)` is
-// s_andn2 of the x<y mask, so NaN operands take the same branches as comp:345-372.
-VRT_DI void dda_step_gfx950(Walk &w, const f3 &inv_dir, int &axis, uint32_t &index, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z) {
-    unsigned long long m_ax, m_ay, m_axy, carry;
-    float nx, ny, nz, tsel;
-    int ax_out;
-    asm("v_cmp_lt_f32_e64 %[mx], %[sdx], %[sdy]\n\t"
-        "v_cmp_lt_f32_e64 %[mxy], %[sdx], %[sdz]\n\t"
-        "v_cmp_lt_f32_e64 %[my], %[sdy], %[sdz]\n\t"
-        "v_add_f32_e64 %[nx], %[sdx], |%[ix]|\n\t"
-        "v_add_f32_e64 %[ny], %[sdy], |%[iy]|\n\t"
-        "v_add_f32_e64 %[nz], %[sdz], |%[iz]|\n\t"
-        "s_andn2_b64 %[my], %[my], %[mx]\n\t"   // y crossed: (y<z) & !(x<y)
-        "s_and_b64 %[mx], %[mx], %[mxy]\n\t"    // x crossed: (x<y) & (x<z)
-        "s_or_b64 %[mxy], %[mx], %[my]\n\t"     // x or y crossed; z otherwise
-        "v_cndmask_b32_e64 %[ts], %[sdz], %[sdy], %[my]\n\t"
-        "v_cndmask_b32_e64 %[ts], %[ts], %[sdx], %[mx]\n\t"
-        "v_cndmask_b32_e64 %[sdx], %[sdx], %[nx], %[mx]\n\t"
-        "v_cndmask_b32_e64 %[sdy], %[sdy], %[ny], %[my]\n\t"
-        "v_cndmask_b32_e64 %[sdz], %[nz], %[sdz], %[mxy]\n\t"
-        "v_subbrev_co_u32_e64 %[rx], %[cc], 0, %[rx], %[mx]\n\t"
-        "v_subbrev_co_u32_e64 %[ry], %[cc], 0, %[ry], %[my]\n\t"
-        "v_addc_co_u32_e64 %[rz], %[cc], -1, %[rz], %[mxy]\n\t" // rz - 1 + (x or y crossed)
-        "v_cndmask_b32_e64 %[nx], %[stz], %[sty], %[my]\n\t"
-        "v_cndmask_b32_e64 %[nx], %[nx], %[stx], %[mx]\n\t"
-        "v_add_u32_e32 %[idx], %[idx], %[nx]\n\t"
-        "v_cndmask_b32_e64 %[ax], 2, 1, %[my]\n\t"
-        "v_cndmask_b32_e64 %[ax], %[ax], 0, %[mx]"
-        : [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),
-          [idx] "+v"(index), [ts] "=&v"(tsel), [ax] "=&v"(ax_out), [nx] "=&v"(nx), [ny] "=&v"(ny), [nz] "=&v"(nz), [mx] "=&s"(m_ax),
-          [my] "=&s"(m_ay), [mxy] "=&s"(m_axy), [cc] "=&s"(carry)
-        : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z));
-    w.t_value = tsel;
-    axis = ax_out;
-}
+// ---- the brick-level walk loop, hand-written for gfx950 -------------------------------------------------
+// Measured model (tools/ubench/step_bench.hip): a SIMD issues about one instruction per cycle in total —
+// vector, scalar and branch alike — and a wave on its own needs >= 4 cycles per instruction, more across a
+// VALU -> SGPR -> SALU -> VALU hand-over.  So the loop is written for the smallest TOTAL instruction count with
+// short dependency chains, and everything the compiler adds around an inline-asm step (copies of loop-carried
+// lane masks, exit-flag merging on the scalar unit, s_nop padding at the asm boundary) is avoided by keeping the
+// whole loop inside one asm block: 30 instructions per trip (18 VALU, 8 SALU, 1 VMEM, 1 waitcnt, 2 branches)
+// against 41 for the compiler's loop around the same step.
+//
+// One trip = take the DDA step out of the current cell (dda_step<true> as selects; comp:345-372 semantics,
+// `!(x<y)` is s_andn2 of the x<y mask so NaNs take the shader's branches), request the next cell's status word,
+// and only then test the bit of the cell just left, whose word was requested one trip earlier and has had a
+// whole step to arrive (s_waitcnt vmcnt(1)).  The steps-left counters are decremented with the crossed-
+// axis lane mask as borrow-in; their borrow-OUT is the box-exit test (a counter at 0 is decremented exactly
+// when the lane leaves through that face), so leaving lanes are dropped from EXEC with scalar work only.  The
+// loop is unrolled twice with the roles of two register sets swapped (A/B: crossed distance and crossed-axis
+// masks of the last and of the previous step), so nothing is copied between trips.  It runs until some lane
+// meets an occupied cell or every lane has left the grid; the caller walks the bricks (rare: about once per
+// wave per ray) and calls again.  Status words come through a stride-4 buffer resource: a lane outside the grid
+// carries an arbitrary index and reads 0 instead of faulting (tools/isa_probe.hip checks this and the
+// carry-out-under-partial-EXEC behaviour on the hardware).
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-// The brick-level step as three EXEC regions (the shipped default).  Every lane crosses exactly one axis per
-// step, so instead of computing all three candidates and selecting (v_cndmask per value), the wave runs the
-// x-, y- and z-updates under EXEC = the lanes crossing that axis: side_dist += |1/dir|, steps-left -= 1,
-// index += stride — 3 VALU per region, 14 VALU + 10 SALU per step against 22 + 3 for the select form (the
-// kernel is VALU-issue bound, the scalar unit has slack).  The borrow of the steps-left decrement IS the
-// box-exit test (a counter at 0 is decremented exactly when the lane leaves through that face), so the loop
-// condition needs no VALU at all: `exit` comes back as a lane mask in an SGPR pair.  A VOP3 carry-out writes
-// zero for lanes outside EXEC (tools/isa_probe.hip checks this on the hardware).  The crossed-axis masks are
-// returned so that the axis (hit normal) is materialised only when a brick is entered; t_value stays
-// unscaled (DEFER_T).  Same comparison semantics as dda_step (comp:345-372), same float operations per lane.
-VRT_DI void dda_step_regions(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
-                             unsigned long long &m_ax, unsigned long long &m_ay, unsigned long long &exit_mask) {
-    unsigned long long m_axy, save, by, bz;
-    float tsel;
-    asm("v_cmp_lt_f32_e64 %[mx], %[sdx], %[sdy]\n\t"
-        "v_cmp_lt_f32_e64 %[mxy], %[sdx], %[sdz]\n\t"
-        "v_cmp_lt_f32_e64 %[my], %[sdy], %[sdz]\n\t"
-        "s_mov_b64 %[save], exec\n\t"
-        "s_andn2_b64 %[my], %[my], %[mx]\n\t"   // y crossed: (y<z) & !(x<y)
-        "s_and_b64 %[mx], %[mx], %[mxy]\n\t"    // x crossed: (x<y) & (x<z)
-        "s_or_b64 %[mxy], %[mx], %[my]\n\t"     // x or y crossed; z otherwise
-        "v_cndmask_b32_e64 %[ts], %[sdz], %[sdy], %[my]\n\t"
-        "v_cndmask_b32_e64 %[ts], %[ts], %[sdx], %[mx]\n\t"
-        "s_mov_b64 exec, %[mx]\n\t"
-        "v_add_f32_e64 %[sdx], %[sdx], |%[ix]|\n\t"
-        "v_sub_co_u32_e64 %[rx], %[ex], %[rx], 1\n\t"
-        "v_add_u32_e32 %[idx], %[idx], %[stx]\n\t"
-        "s_mov_b64 exec, %[my]\n\t"
-        "v_add_f32_e64 %[sdy], %[sdy], |%[iy]|\n\t"
-        "v_sub_co_u32_e64 %[ry], %[by], %[ry], 1\n\t"
-        "v_add_u32_e32 %[idx], %[idx], %[sty]\n\t"
-        "s_andn2_b64 exec, %[save], %[mxy]\n\t"
-        "v_add_f32_e64 %[sdz], %[sdz], |%[iz]|\n\t"
-        "v_sub_co_u32_e64 %[rz], %[bz], %[rz], 1\n\t"
-        "v_add_u32_e32 %[idx], %[idx], %[stz]\n\t"
-        "s_mov_b64 exec, %[save]\n\t"
-        "s_or_b64 %[ex], %[ex], %[by]\n\t"
-        "s_or_b64 %[ex], %[ex], %[bz]"
-        : [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),
-          [idx] "+v"(index), [ts] "=&v"(tsel), [mx] "=&s"(m_ax), [my] "=&s"(m_ay), [mxy] "=&s"(m_axy), [save] "=&s"(save), [ex] "=&s"(exit_mask),
-          [by] "=&s"(by), [bz] "=&s"(bz)
-        : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z));
-    w.t_value = tsel;
+struct GridWalkRegs {
+    unsigned long long alive;        // in/out: lanes still walking the grid
+    unsigned long long occ;          // out: lanes whose cell BEFORE their last step is occupied (0: every lane has left)
+    unsigned long long out_x, out_y; // in/out: crossed-x / crossed-y lanes of the last step taken
+    unsigned long long in_x, in_y;   // out: the same for the step before it (the step INTO the tested cell)
+    float t_out, t_in;               // crossed distance of the last step (in/out) and of the one before it (out)
+    uint32_t stub;                   // out: 0 the call ended in its first trip, 1/2 in a later trip, 3 every lane left
+};
+
+#define VRT_TRIP(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, OUT)            \
+    "v_cmp_lt_f32_e64 %[" MX "], %[sdx], %[sdy]\n\t"                      \
+    "v_cmp_lt_f32_e64 %[" MXY "], %[sdx], %[sdz]\n\t"                     \
+    "v_cmp_lt_f32_e64 %[" MY "], %[sdy], %[sdz]\n\t"                      \
+    "v_add_f32_e64 %[t0], %[sdx], |%[ix]|\n\t"                            \
+    "v_add_f32_e64 %[t1], %[sdy], |%[iy]|\n\t"                            \
+    "v_add_f32_e64 %[t2], %[sdz], |%[iz]|\n\t"                            \
+    "s_andn2_b64 %[" MY "], %[" MY "], %[" MX "]\n\t"                     \
+    "s_and_b64 %[" MX "], %[" MX "], %[" MXY "]\n\t"                      \
+    "s_or_b64 %[" MXY "], %[" MX "], %[" MY "]\n\t"                       \
+    "v_cndmask_b32_e64 %[" TS "], %[sdz], %[sdy], %[" MY "]\n\t"          \
+    "v_cndmask_b32_e64 %[" TS "], %[" TS "], %[sdx], %[" MX "]\n\t"       \
+    "v_cndmask_b32_e64 %[sdx], %[sdx], %[t0], %[" MX "]\n\t"              \
+    "v_cndmask_b32_e64 %[sdy], %[sdy], %[t1], %[" MY "]\n\t"              \
+    "v_cndmask_b32_e64 %[sdz], %[t2], %[sdz], %[" MXY "]\n\t"             \
+    "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[" MY "]\n\t"              \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[" MX "]\n\t"               \
+    "v_add_u32_e32 %[" IDXN "], %[" IDX "], %[t0]\n\t"                    \
+    "v_lshrrev_b32_e32 %[t2], 5, %[" IDXN "]\n\t"                         \
+    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"         \
+    "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[" MX "]\n\t"          \
+    "v_subbrev_co_u32_e64 %[ry], %[by], 0, %[ry], %[" MY "]\n\t"          \
+    "v_addc_co_u32_e64 %[rz], %[cz], -1, %[rz], %[" MXY "]\n\t"           \
+    "s_or_b64 %[ex], %[ex], %[by]\n\t"                                    \
+    "s_orn2_b64 %[ex], %[ex], %[cz]\n\t" /* z: carry-out 0 = borrow */    \
+    "s_waitcnt vmcnt(1)\n\t" /* the word of the cell being left; the next cell's stays in flight */ \
+    "v_bfe_u32 %[t1], %[" WORD "], %[" IDX "], 1\n\t"                     \
+    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"                                  \
+    "s_andn2_b64 exec, exec, %[ex]\n\t"                                   \
+    "s_cbranch_vccnz " OUT "\n\t"
+
+VRT_DI void grid_walk_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
+                             uint32_t &word, u32x4 rsrc, GridWalkRegs &g) {
+    unsigned long long mxya, mxyb, ex, by, cz, save;
+    float t0, t1, t2;
+    uint32_t wordb;
+    // Register sets: an A trip leaves cell idxa (status word worda), writes {tsa, mxa, mya} and produces idxb and
+    // the request for wordb; a B trip the other way round.  A call starts with an A trip.  On exit the B set holds
+    // the last step and the A set the one before it, idxa/worda the current cell and idxb the cell just left:
+    // a call that ends in an A trip swaps the sets on its way out.
+    asm volatile("s_mov_b64 %[save], exec\n\t"
+                 "s_mov_b64 exec, %[alive]\n\t"
+                 VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", "1f")
+                 "0:\n\t"
+                 VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", "2f")
+                 VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", "3f")
+                 "s_cbranch_execnz 0b\n\t"
+                 "s_mov_b32 %[stub], 3\n\t"
+                 "s_branch 4f\n\t"
+                 "1:\n\t"
+                 "s_mov_b32 %[stub], 0\n\t"
+                 "s_branch 4f\n\t"
+                 "3:\n\t"
+                 "s_mov_b32 %[stub], 2\n\t"
+                 "4:\n\t"
+                 "s_mov_b64 %[occ], vcc\n\t"
+                 "s_mov_b64 %[alive], exec\n\t"
+                 "s_mov_b64 exec, %[save]\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_mov_b64 %[ex], %[mxa]\n\t"
+                 "s_mov_b64 %[mxa], %[mxb]\n\t"
+                 "s_mov_b64 %[mxb], %[ex]\n\t"
+                 "s_mov_b64 %[ex], %[mya]\n\t"
+                 "s_mov_b64 %[mya], %[myb]\n\t"
+                 "s_mov_b64 %[myb], %[ex]\n\t"
+                 "v_mov_b32_e32 %[t0], %[tsa]\n\t"
+                 "v_mov_b32_e32 %[tsa], %[tsb]\n\t"
+                 "v_mov_b32_e32 %[tsb], %[t0]\n\t"
+                 "v_mov_b32_e32 %[t0], %[idxa]\n\t"
+                 "v_mov_b32_e32 %[idxa], %[idxb]\n\t"
+                 "v_mov_b32_e32 %[idxb], %[t0]\n\t"
+                 "v_mov_b32_e32 %[worda], %[wordb]\n\t"
+                 "s_branch 6f\n\t"
+                 "2:\n\t"
+                 "s_mov_b32 %[stub], 1\n\t"
+                 "s_mov_b64 %[occ], vcc\n\t"
+                 "s_mov_b64 %[alive], exec\n\t"
+                 "s_mov_b64 exec, %[save]\n\t"
+                 "s_waitcnt vmcnt(0)\n\t" // the compiler may move `word`: no load may be in flight outside
+                 "6:"
+                 : [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),
+                   [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(word), [wordb] "=&v"(wordb), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in),
+                   [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive),
+                   [mxa] "=&s"(g.in_x), [mya] "=&s"(g.in_y), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz),
+                   [save] "=&s"(save), [occ] "=&s"(g.occ), [stub] "=&s"(g.stub)
+                 : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z),
+                   [rsrc] "s"(rsrc)
+                 : "vcc", "scc");
 }
+#undef VRT_TRIP
 
 // comp:298 / comp:395
 VRT_DI f3 initial_side_dist(f3 fstep, f3 fposition, f3 ray_delta) {
@@ -526,50 +564,44 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
             more = ((inside ? 0 : -1) | stop) >= 0;
         }
         return stop == -1;
+    } else if constexpr (MODE == kStatusLinearAlways && !COUNT) {
+        // The shipped default: grid_walk_gfx950 runs trips until some lane stands on an occupied cell (or all
+        // lanes have left); the bricks are walked here, with the state from BEFORE the lane's last step rebuilt
+        // from the post-step state and the crossed-axis lane masks, and the walk is resumed.
+        const unsigned long long status_addr = (unsigned long long)p.brick_status;
+        u32x4 rsrc;
+        rsrc.x = (uint32_t)status_addr;
+        rsrc.y = (uint32_t)(status_addr >> 32) | (4u << 16); // stride 4: one record per status word
+        rsrc.z = p.status_words;
+        rsrc.w = 0x00020000u;
+        uint32_t word = p.brick_status[more ? (grid_index >> 5) : 0u];
+        GridWalkRegs g;
+        g.alive = __builtin_amdgcn_ballot_w64(more);
+        g.out_x = 0ull;
+        g.out_y = 0ull;
+        g.t_out = 0.0f;
+        bool first = true; // wave-uniform
+        while (g.alive != 0ull) {
+            uint32_t cell; // the cell each lane stood on before its last step
+            grid_walk_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
+            if (g.occ == 0ull) break; // every lane has left the grid
+            if (__builtin_amdgcn_inverse_ballot_w64(g.occ)) {
+                // axis 3: the first cell of the walk was entered through the slab test, not by a step
+                int a = (first && g.stub == 0u) ? 3
+                                                : (__builtin_amdgcn_inverse_ballot_w64(g.in_x) ? 0 : (__builtin_amdgcn_inverse_ballot_w64(g.in_y) ? 1 : 2));
+                const bool out_x = __builtin_amdgcn_inverse_ballot_w64(g.out_x), out_y = __builtin_amdgcn_inverse_ballot_w64(g.out_y);
+                enter_brick_at(w.rx + (out_x ? 1 : 0), w.ry + (out_y ? 1 : 0), w.rz + ((out_x | out_y) ? 0 : 1), g.t_in, cell, a);
+            }
+            // (as asm: the compiler would do this on the vector unit and could not hand the result back to an SGPR operand)
+            asm("s_andn2_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(stop != 0)) : "scc");
+            first = false;
+        }
+        return stop == -1;
     } else {
-        // Software-pipelined walk over the region step.  The step does not depend on the cell test, so it is
-        // taken first and the status word of the NEXT cell is requested at once; the current cell's bit is
-        // tested while that load is in flight.  Everything a brick entry needs from before the step is
-        // rebuilt, in the rare taken path only, from the post-step state and the two sets of crossed-axis lane
-        // masks (c_*: the step INTO the current cell, n_*: the step just taken OUT of it).  The rare path sits
-        // behind a wave-uniform branch so that "some lane stopped" can live in an SGPR pair as well: the loop
-        // condition is scalar work only.  Status words are fetched through a buffer resource: a lane that
-        // has left the grid carries an arbitrary index and reads 0 instead of faulting.
-        const __amdgpu_buffer_rsrc_t status_rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.brick_status), 0, (int)(p.status_words * 4u), 0x00020000);
-        unsigned long long c_ax = 0ull, c_ay = 0ull, stop_mask = 0ull;
-        int have_axis = 0; // wave-uniform: all lanes of a wave take their first trip together
-        uint32_t word = __builtin_amdgcn_raw_buffer_load_b32(status_rsrc, (grid_index >> 3) & ~3u, 0, 0);
         while (more) { // single-exit loop, see brick_walk
-            VRT_COUNT(grid_steps);
-            VRT_COUNT_WAVE(wave_grid_iters);
-            if constexpr (COUNT) {
-                const uint32_t wi = grid_index >> 5;
-                if (wi != word_index) {
-                    word_index = wi;
-                    c.status_loads++;
-                }
-            }
-            const bool occupied = status_bit(word, grid_index);
-            const float t_here = w.t_value; // crossed distance of the step INTO the current cell
-            unsigned long long n_ax, n_ay, exit_mask;
-            dda_step_regions(w, s.inv_dir, grid_index, stride_x, stride_y, stride_z, n_ax, n_ay, exit_mask);
-            word = __builtin_amdgcn_raw_buffer_load_b32(status_rsrc, (grid_index >> 3) & ~3u, 0, 0);
-            if (__builtin_amdgcn_ballot_w64(occupied) != 0ull) {
-                if (occupied) {
-                    int a = have_axis ? (__builtin_amdgcn_inverse_ballot_w64(c_ax) ? 0 : (__builtin_amdgcn_inverse_ballot_w64(c_ay) ? 1 : 2)) : 3;
-                    const bool out_x = __builtin_amdgcn_inverse_ballot_w64(n_ax), out_y = __builtin_amdgcn_inverse_ballot_w64(n_ay);
-                    enter_brick_at(w.rx + (out_x ? 1 : 0), w.ry + (out_y ? 1 : 0), w.rz + ((out_x | out_y) ? 0 : 1), t_here,
-                                   grid_index - (out_x ? stride_x : (out_y ? stride_y : stride_z)), a);
-                }
-                stop_mask = __builtin_amdgcn_ballot_w64(stop != 0);
-            }
-            c_ax = n_ax;
-            c_ay = n_ay;
-            have_axis = 1;
-            unsigned long long leave; // (as asm: the compiler would otherwise do this OR on the vector unit)
-            asm("s_or_b64 %0, %1, %2" : "=s"(leave) : "s"(exit_mask), "s"(stop_mask));
-            more = !__builtin_amdgcn_inverse_ballot_w64(leave);
+            if (cell_occupied()) enter_brick();
+            dda_step<true>(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
+            more = (min3i(w.rx, w.ry, w.rz) | stop) >= 0;
         }
         return stop == -1;
     }
