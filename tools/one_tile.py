@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zig_vulkan_amd import workloads as W
 
 view, tx, ty = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-variants = [int(v, 0) for v in sys.argv[4:]] or [0]
+profile = "--profile" in sys.argv
+variants = [int(v, 0) for v in sys.argv[4:] if v != "--profile"] or [0]
 w = W.WORKLOADS[W.HEADLINE]
 grid = W.build_grid(w)
 tiles_x, tiles_y = (w.width + 15) // 16, (w.height + 15) // 16
@@ -20,4 +21,8 @@ for variant in variants:
     c, wc = rc.counters(), rc.wave_counters()
     print(f"variant {variant:#x} {rt.kernel_name()}: tile ({tx},{ty}) alone {rt.last_kernel_ms()*1000:.1f} us; 4 waves: grid trips {wc['wave_grid_iters']} brick walks {wc['wave_brick_walks']} "
           f"voxel trips {wc['wave_voxel_iters']}; lanes: grid steps {c['grid_steps']} bricks {c['bricks_entered']} voxel steps {c['voxel_steps']} hits {c['hits']} rays {c['rays']}")
+    if profile:  # library built with make EXTRA=-DVRT_DEV_PROFILE: core-clock cycles per phase, summed over the 4 waves
+        pr = rt.wave_timeline().reshape(-1)[:8]
+        names = ["grid loop", "brick walks (all)", "voxel loops", "grid_hit setup", "-", "-", "-", "whole wave"]
+        print("   cycles summed over 4 waves:", ", ".join(f"{n} {int(v)}" for n, v in zip(names, pr) if n != "-"))
     rt.deinit(); rc.deinit()

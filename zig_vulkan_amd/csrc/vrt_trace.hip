@@ -62,6 +62,23 @@ VRT_DI f3 ray_at(const Ray &r, float t) { return fma3(splat3(t), r.direction, r.
 // comp:267
 VRT_DI float safe_inverse(float x) { return (x == 0.0f) ? 1e12f : (1.0f / x); }
 
+// Development-only phase profile (make EXTRA=-DVRT_DEV_PROFILE; tools/one_tile.py --profile): core-clock
+// cycles per phase, summed over the waves of a workgroup in LDS and written to the wave-timeline buffer.
+#ifdef VRT_DEV_PROFILE
+__shared__ unsigned long long vrt_prof[8];
+VRT_DI unsigned long long prof_now() { return __builtin_readcyclecounter(); }
+VRT_DI void prof_add(int k, unsigned long long t0) {
+    const unsigned long long dt = __builtin_readcyclecounter() - t0;
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+    if ((threadIdx.x & 63u) == (uint32_t)(__builtin_ctzll(act))) atomicAdd(&vrt_prof[k], dt);
+}
+#define VRT_PROF_BEGIN(t) const unsigned long long t = prof_now()
+#define VRT_PROF_END(k, t) prof_add(k, t)
+#else
+#define VRT_PROF_BEGIN(t)
+#define VRT_PROF_END(k, t)
+#endif
+
 // DDA walker state shared by the two levels.  Instead of the cell position the walker keeps, per
 // axis, how many more steps it may take before it leaves the box through the face it is moving
 // towards (rem = dim-1-pos for step +1, pos for step -1): stepping decrements one counter and "still
@@ -147,7 +164,7 @@ struct GridWalkRegs {
     uint32_t stub;                   // out: 0 the call ended in its first trip, 1/2 in a later trip, 3 every lane left
 };
 
-#define VRT_TRIP(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, OUT)            \
+#define VRT_TRIP(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, OUT)     \
     "v_cmp_lt_f32_e64 %[" MX "], %[sdx], %[sdy]\n\t"                      \
     "v_cmp_lt_f32_e64 %[" MXY "], %[sdx], %[sdz]\n\t"                     \
     "v_cmp_lt_f32_e64 %[" MY "], %[sdy], %[sdz]\n\t"                      \
@@ -170,6 +187,7 @@ struct GridWalkRegs {
     "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[" MX "]\n\t"          \
     "v_subbrev_co_u32_e64 %[ry], %[by], 0, %[ry], %[" MY "]\n\t"          \
     "v_addc_co_u32_e64 %[rz], %[cz], -1, %[rz], %[" MXY "]\n\t"           \
+    LIMIT(TS, MXY)                                                        \
     "s_or_b64 %[ex], %[ex], %[by]\n\t"                                    \
     "s_orn2_b64 %[ex], %[ex], %[cz]\n\t" /* z: carry-out 0 = borrow */    \
     "s_waitcnt vmcnt(1)\n\t" /* the word of the cell being left; the next cell's stays in flight */ \
@@ -178,64 +196,92 @@ struct GridWalkRegs {
     "s_andn2_b64 exec, exec, %[ex]\n\t"                                   \
     "s_cbranch_vccnz " OUT "\n\t"
 
+// voxel level only (comp:469): the lane also leaves when the crossed distance, scaled to world units, is not
+// <= the distance left inside the grid box (NaN leaves, as `!(t <= max)` does)
+#define VRT_NO_LIMIT(TS, MXY)
+#define VRT_T_LIMIT(TS, MXY) /* (the x|y mask of this trip is dead by now: its register takes the compare) */ \
+    "v_mul_f32_e32 %[t1], %[scale], %[" TS "]\n\t"                        \
+    "v_cmp_nle_f32_e64 %[" MXY "], %[t1], %[tmax]\n\t"                    \
+    "s_or_b64 %[ex], %[ex], %[" MXY "]\n\t"
+
+// Register sets: an A trip leaves cell idxa (word worda), writes {tsa, mxa, mya} and produces idxb and the
+// request for wordb; a B trip the other way round.  A call starts with an A trip.  On exit the B set holds the
+// last step and the A set the one before it, idxa/worda the current cell and idxb the cell just left: a call
+// that ends in an A trip swaps the sets on its way out.
+#define VRT_WALK_ASM(LIMIT)                                                                              \
+    "s_mov_b64 %[save], exec\n\t"                                                                         \
+    "s_mov_b64 exec, %[alive]\n\t"                                                                        \
+    VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, "1f")                  \
+    "0:\n\t"                                                                                              \
+    VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, "2f")                  \
+    VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, "3f")                  \
+    "s_cbranch_execnz 0b\n\t"                                                                             \
+    "s_mov_b32 %[stub], 3\n\t"                                                                            \
+    "s_branch 4f\n\t"                                                                                     \
+    "1:\n\t"                                                                                              \
+    "s_mov_b32 %[stub], 0\n\t"                                                                            \
+    "s_branch 4f\n\t"                                                                                     \
+    "3:\n\t"                                                                                              \
+    "s_mov_b32 %[stub], 2\n\t"                                                                            \
+    "4:\n\t"                                                                                              \
+    "s_mov_b64 %[occ], vcc\n\t"                                                                           \
+    "s_mov_b64 %[alive], exec\n\t"                                                                        \
+    "s_mov_b64 exec, %[save]\n\t"                                                                         \
+    "s_waitcnt vmcnt(0)\n\t"                                                                              \
+    "s_mov_b64 %[ex], %[mxa]\n\t"                                                                         \
+    "s_mov_b64 %[mxa], %[mxb]\n\t"                                                                        \
+    "s_mov_b64 %[mxb], %[ex]\n\t"                                                                         \
+    "s_mov_b64 %[ex], %[mya]\n\t"                                                                         \
+    "s_mov_b64 %[mya], %[myb]\n\t"                                                                        \
+    "s_mov_b64 %[myb], %[ex]\n\t"                                                                         \
+    "v_mov_b32_e32 %[t0], %[tsa]\n\t"                                                                     \
+    "v_mov_b32_e32 %[tsa], %[tsb]\n\t"                                                                    \
+    "v_mov_b32_e32 %[tsb], %[t0]\n\t"                                                                     \
+    "v_mov_b32_e32 %[t0], %[idxa]\n\t"                                                                    \
+    "v_mov_b32_e32 %[idxa], %[idxb]\n\t"                                                                  \
+    "v_mov_b32_e32 %[idxb], %[t0]\n\t"                                                                    \
+    "v_mov_b32_e32 %[worda], %[wordb]\n\t"                                                                \
+    "s_branch 6f\n\t"                                                                                     \
+    "2:\n\t"                                                                                              \
+    "s_mov_b32 %[stub], 1\n\t"                                                                            \
+    "s_mov_b64 %[occ], vcc\n\t"                                                                           \
+    "s_mov_b64 %[alive], exec\n\t"                                                                        \
+    "s_mov_b64 exec, %[save]\n\t"                                                                         \
+    "s_waitcnt vmcnt(0)\n\t" /* the compiler may move `word`: no load may be in flight outside */         \
+    "6:"
+
+#define VRT_WALK_OUTPUTS                                                                                                                        \
+    [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),          \
+        [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(word), [wordb] "=&v"(wordb), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in),              \
+        [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive), [mxa] "=&s"(g.in_x),    \
+        [mya] "=&s"(g.in_y), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz), [save] "=&s"(save),         \
+        [occ] "=&s"(g.occ), [stub] "=&s"(g.stub)
+#define VRT_WALK_INPUTS \
+    [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z), [rsrc] "s"(rsrc)
+
+// brick level (comp:314-375): cells of the grid, bits of brick_status
 VRT_DI void grid_walk_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
                              uint32_t &word, u32x4 rsrc, GridWalkRegs &g) {
     unsigned long long mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb;
-    // Register sets: an A trip leaves cell idxa (status word worda), writes {tsa, mxa, mya} and produces idxb and
-    // the request for wordb; a B trip the other way round.  A call starts with an A trip.  On exit the B set holds
-    // the last step and the A set the one before it, idxa/worda the current cell and idxb the cell just left:
-    // a call that ends in an A trip swaps the sets on its way out.
-    asm volatile("s_mov_b64 %[save], exec\n\t"
-                 "s_mov_b64 exec, %[alive]\n\t"
-                 VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", "1f")
-                 "0:\n\t"
-                 VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", "2f")
-                 VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", "3f")
-                 "s_cbranch_execnz 0b\n\t"
-                 "s_mov_b32 %[stub], 3\n\t"
-                 "s_branch 4f\n\t"
-                 "1:\n\t"
-                 "s_mov_b32 %[stub], 0\n\t"
-                 "s_branch 4f\n\t"
-                 "3:\n\t"
-                 "s_mov_b32 %[stub], 2\n\t"
-                 "4:\n\t"
-                 "s_mov_b64 %[occ], vcc\n\t"
-                 "s_mov_b64 %[alive], exec\n\t"
-                 "s_mov_b64 exec, %[save]\n\t"
-                 "s_waitcnt vmcnt(0)\n\t"
-                 "s_mov_b64 %[ex], %[mxa]\n\t"
-                 "s_mov_b64 %[mxa], %[mxb]\n\t"
-                 "s_mov_b64 %[mxb], %[ex]\n\t"
-                 "s_mov_b64 %[ex], %[mya]\n\t"
-                 "s_mov_b64 %[mya], %[myb]\n\t"
-                 "s_mov_b64 %[myb], %[ex]\n\t"
-                 "v_mov_b32_e32 %[t0], %[tsa]\n\t"
-                 "v_mov_b32_e32 %[tsa], %[tsb]\n\t"
-                 "v_mov_b32_e32 %[tsb], %[t0]\n\t"
-                 "v_mov_b32_e32 %[t0], %[idxa]\n\t"
-                 "v_mov_b32_e32 %[idxa], %[idxb]\n\t"
-                 "v_mov_b32_e32 %[idxb], %[t0]\n\t"
-                 "v_mov_b32_e32 %[worda], %[wordb]\n\t"
-                 "s_branch 6f\n\t"
-                 "2:\n\t"
-                 "s_mov_b32 %[stub], 1\n\t"
-                 "s_mov_b64 %[occ], vcc\n\t"
-                 "s_mov_b64 %[alive], exec\n\t"
-                 "s_mov_b64 exec, %[save]\n\t"
-                 "s_waitcnt vmcnt(0)\n\t" // the compiler may move `word`: no load may be in flight outside
-                 "6:"
-                 : [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),
-                   [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(word), [wordb] "=&v"(wordb), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in),
-                   [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive),
-                   [mxa] "=&s"(g.in_x), [mya] "=&s"(g.in_y), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz),
-                   [save] "=&s"(save), [occ] "=&s"(g.occ), [stub] "=&s"(g.stub)
-                 : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z),
-                   [rsrc] "s"(rsrc)
-                 : "vcc", "scc");
+    asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
 }
+
+// voxel level (comp:409-470): voxels of one brick, bits of brick_occupancy addressed by the global bit index
+// brick * B^3 + voxel; `scale` and `t_max` as in the loop condition comp:469
+VRT_DI void voxel_walk_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
+                              uint32_t &word, u32x4 rsrc, GridWalkRegs &g, float scale, float t_max) {
+    unsigned long long mxya, mxyb, ex, by, cz, save;
+    float t0, t1, t2;
+    uint32_t wordb;
+    asm volatile(VRT_WALK_ASM(VRT_T_LIMIT) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS, [scale] "v"(scale), [tmax] "v"(t_max) : "vcc", "scc");
+}
+#undef VRT_WALK_ASM
+#undef VRT_WALK_OUTPUTS
+#undef VRT_WALK_INPUTS
+#undef VRT_T_LIMIT
+#undef VRT_NO_LIMIT
 #undef VRT_TRIP
 
 // comp:298 / comp:395
@@ -310,6 +356,8 @@ VRT_DI bool bit64(uint2 w, uint32_t bit) { // bit 0..63 of a 64-bit word held as
     return (half >> (bit & 31u)) & 1u;
 }
 
+VRT_DI bool more_init(int px, int py, int pz, int dim) { return (unsigned)px < (unsigned)dim && (unsigned)py < (unsigned)dim && (unsigned)pz < (unsigned)dim; }
+
 // comp:378-471.  Returns true on a (non-ignored) voxel hit and fills `hit`.
 // LITERAL: one byte load per voxel step (comp:415); otherwise 64-bit occupancy words:
 // brick_occupancy bit v%8 of byte brick*(B^3/8) + v/8 (Grid.zig:180-182) read as little-endian
@@ -338,11 +386,28 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
     uint32_t occ_layer = ~0u;
     const uint2 *occ_words = reinterpret_cast<const uint2 *>(p.brick_occupancy);
     if constexpr (!LITERAL && B == 4) occ = occ_words[brick_index];
+    // B == 8: one 64-bit word per y-layer.  The walk moves through the layers in one direction (sy), so the
+    // word of the layer after the current one is requested a layer early: a walk then waits for memory once,
+    // not once per layer (these dependent loads are what a wave with many brick walks spends its time on).
+    uint2 occ_ahead = make_uint2(0u, 0u);
+    [[maybe_unused]] const uint2 *brick_layers = occ_words + (size_t)brick_index * 8u;
+    [[maybe_unused]] auto layer_ahead = [&](uint32_t layer) -> uint2 {
+        const uint32_t next = layer + (uint32_t)s.sy; // sy == 0: the layer never changes, any valid word will do
+        return brick_layers[next < 8u ? next : layer];
+    };
+    if constexpr (!LITERAL && B == 8) {
+        if (more_init(px, py, pz, B)) {
+            occ_layer = (uint32_t)py;
+            occ = brick_layers[occ_layer];
+            occ_ahead = layer_ahead(occ_layer);
+        }
+    }
 
     // Single-exit loop (one back-edge condition, no return inside): the structurizer then needs one
     // exec update per iteration instead of a chain of exit-flag merges on the scalar unit.
     bool found = false;
     bool more = (unsigned)px < (unsigned)B && (unsigned)py < (unsigned)B && (unsigned)pz < (unsigned)B && w.t_value <= local_t_max;
+    VRT_PROF_BEGIN(tp2);
     while (more) {
         VRT_COUNT(voxel_steps);
         VRT_COUNT_WAVE(wave_voxel_iters);
@@ -354,9 +419,10 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
             solid = bit64(occ, voxel_index);
         } else {
             const uint32_t layer = voxel_index >> 6; // y
-            if (occ_layer != layer) {
-                occ = occ_words[(size_t)brick_index * 8u + layer];
+            if (occ_layer != layer) { // crossed into the next layer: its word was requested a layer ago
+                occ = occ_ahead;
                 occ_layer = layer;
+                occ_ahead = layer_ahead(layer);
             }
             solid = bit64(occ, voxel_index & 63u);
         }
@@ -380,6 +446,78 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
         // (after a hit this step is dead work, once per ray; its results are never read)
         dda_step<false>(w, s.ray_delta, voxel_scale, axis, voxel_index, stride_x, stride_y, stride_z);
         more = !found && min3i(w.rx, w.ry, w.rz) >= 0 && w.t_value <= local_t_max;
+    }
+    VRT_PROF_END(2, tp2);
+    return found;
+}
+
+// comp:378-471 on the hand-written voxel loop (voxel_walk_gfx950): same operations per lane as brick_walk.
+// The loop returns when some lane has left a solid voxel behind; the material test (comp:422-427) and the hit
+// record are done here, and lanes whose voxel is to be ignored walk on.  `axis_in`: the face through which the
+// brick was entered (the brick-level walk's crossed axis), used when the very first voxel is the hit.
+template <int B>
+VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t brick_index, f3 brick_min, Hit &hit,
+                              int axis_in) {
+    const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
+    const float voxel_scale = g_scale * brick_voxel_scale;
+    const f3 fposition = (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
+    Walk w;
+    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
+    const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
+    const int py = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
+    const int pz = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
+    constexpr int kZeroBudget = 3 * B + 8;
+    w.rx = steps_left(s.sx, px, B, kZeroBudget);
+    w.ry = steps_left(s.sy, py, B, kZeroBudget);
+    w.rz = steps_left(s.sz, pz, B, kZeroBudget);
+    w.t_value = 0;
+    const float local_t_max = s.grid_t_max - hit.t;
+    // global bit index of the voxel in brick_occupancy: brick * B^3 + voxel index (comp:412-415)
+    const uint32_t base = brick_index * (uint32_t)(B * B * B);
+    uint32_t bit_index = base + ((uint32_t)px + (uint32_t)B * ((uint32_t)pz + (uint32_t)B * (uint32_t)py));
+    const uint32_t stride_x = (uint32_t)s.sx, stride_y = (uint32_t)(s.sy * (B * B)), stride_z = (uint32_t)(s.sz * B);
+    const bool more = more_init(px, py, pz, B) && (0.0f <= local_t_max); // comp:409 with t_value = 0
+
+    const unsigned long long occ_addr = (unsigned long long)p.brick_occupancy;
+    u32x4 rsrc;
+    rsrc.x = (uint32_t)occ_addr;
+    rsrc.y = (uint32_t)(occ_addr >> 32) | (4u << 16);
+    rsrc.z = p.occupancy_words;
+    rsrc.w = 0x00020000u;
+    uint32_t word = reinterpret_cast<const uint32_t *>(p.brick_occupancy)[more ? (bit_index >> 5) : 0u];
+    GridWalkRegs g;
+    g.alive = __builtin_amdgcn_ballot_w64(more);
+    g.out_x = 0ull;
+    g.out_y = 0ull;
+    g.t_out = 0.0f;
+    bool first = true; // wave-uniform
+    bool found = false;
+    while (g.alive != 0ull) {
+        uint32_t solid_bit; // bit index of the voxel each lane stood on before its last step
+        voxel_walk_gfx950(w, s.inv_dir, bit_index, solid_bit, stride_x, stride_y, stride_z, word, rsrc, g, voxel_scale, local_t_max);
+        if (g.occ == 0ull) break; // every lane has left the brick (or the grid box)
+        if (__builtin_amdgcn_inverse_ballot_w64(g.occ)) {
+            const uint32_t voxel_index = solid_bit - base;
+            const uint32_t brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu; // comp:422
+            const uint32_t mi = p.material_index[brick_material_index + voxel_index];
+            const vrt_material *m = p.materials + mi;
+            const uint32_t mtype = m->type;
+            const float mdata = m->type_data;
+            const bool ignore_brick = (mtype == r.ignore_type_material) && (r.internal_reflection == mdata); // comp:427
+            if (!ignore_brick) {
+                const int a = (first && g.stub == 0u)
+                                  ? axis_in
+                                  : (__builtin_amdgcn_inverse_ballot_w64(g.in_x) ? 0 : (__builtin_amdgcn_inverse_ballot_w64(g.in_y) ? 1 : 2));
+                hit.index = mi;
+                const float t_offset = voxel_scale * 0.05f;
+                hit.t += g.t_in * voxel_scale - t_offset; // t_value of the step into this voxel (comp:442), 0 for the first
+                hit.normal = axis_normal(s, a);
+                hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
+                found = true;
+            }
+        }
+        asm("s_andn2_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(found)) : "scc");
+        first = false;
     }
     return found;
 }
@@ -408,6 +546,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     const float t_min = 0.00001f;
     const float t_max = __builtin_inff();
     VRT_COUNT(rays);
+    VRT_PROF_BEGIN(tp3);
     RaySetup s;
     if (!grid_slab(p, r, t_min, t_max, s)) return false;
 
@@ -507,8 +646,13 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         const uint32_t brick_index = p.brick_index[cell]; // comp:337
         VRT_COUNT(bricks_entered);
         VRT_COUNT_WAVE(wave_brick_walks);
-        const bool found = brick_walk<B, COUNT, MODE == kStatusLinear || MODE == kStatusLinearAlways || MODE == kStatusLinearLds || MODE == kStatusLinearAhead>(
-            p, r, s, g_scale, brick_index, brick_min, hit, brick_axis, c);
+        bool found;
+        if constexpr (MODE == kStatusLinearAlways && !COUNT) {
+            found = brick_walk_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, brick_axis);
+        } else {
+            found = brick_walk<B, COUNT, MODE == kStatusLinear || MODE == kStatusLinearLds || MODE == kStatusLinearAhead>(
+                p, r, s, g_scale, brick_index, brick_min, hit, brick_axis, c);
+        }
         stop = found ? -1 : ((global_t_value <= t_max) ? 0 : -2);
     };
     auto enter_brick = [&]() { enter_brick_at(w.rx, w.ry, w.rz, w.t_value, grid_index, axis); };
@@ -581,16 +725,21 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         g.out_y = 0ull;
         g.t_out = 0.0f;
         bool first = true; // wave-uniform
+        VRT_PROF_END(3, tp3);
         while (g.alive != 0ull) {
             uint32_t cell; // the cell each lane stood on before its last step
+            VRT_PROF_BEGIN(tp0);
             grid_walk_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
+            VRT_PROF_END(0, tp0);
             if (g.occ == 0ull) break; // every lane has left the grid
             if (__builtin_amdgcn_inverse_ballot_w64(g.occ)) {
                 // axis 3: the first cell of the walk was entered through the slab test, not by a step
                 int a = (first && g.stub == 0u) ? 3
                                                 : (__builtin_amdgcn_inverse_ballot_w64(g.in_x) ? 0 : (__builtin_amdgcn_inverse_ballot_w64(g.in_y) ? 1 : 2));
                 const bool out_x = __builtin_amdgcn_inverse_ballot_w64(g.out_x), out_y = __builtin_amdgcn_inverse_ballot_w64(g.out_y);
+                VRT_PROF_BEGIN(tp1);
                 enter_brick_at(w.rx + (out_x ? 1 : 0), w.ry + (out_y ? 1 : 0), w.rz + ((out_x | out_y) ? 0 : 1), g.t_in, cell, a);
+                VRT_PROF_END(1, tp1);
             }
             // (as asm: the compiler would do this on the vector unit and could not hand the result back to an SGPR operand)
             asm("s_andn2_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(stop != 0)) : "scc");
@@ -819,6 +968,11 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const uint32_t px = tile_x * kTileW + in_x;
     const uint32_t py = tile_y * kTileH + in_y;
 
+#ifdef VRT_DEV_PROFILE
+    if (threadIdx.x < 8) vrt_prof[threadIdx.x] = 0ull;
+    __syncthreads();
+#endif
+    VRT_PROF_BEGIN(tp7);
     const unsigned long long t_begin = (p.tile_order == 5u) ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long wall_begin = p.wave_timeline ? wall_clock64() : 0ull;
     Cnt<COUNT> c;
@@ -872,11 +1026,17 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
             reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(color.x, color.y, color.z, 1.0f);
         }
     }
+#ifdef VRT_DEV_PROFILE
+    VRT_PROF_END(7, tp7);
+    __syncthreads();
+    if (p.wave_timeline && threadIdx.x < 8) p.wave_timeline[(size_t)blockIdx.x * 8 + threadIdx.x] = vrt_prof[threadIdx.x];
+#else
     if (p.wave_timeline && lane == 0) {
         const size_t w_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         p.wave_timeline[2 * w_id] = wall_begin;
         p.wave_timeline[2 * w_id + 1] = wall_clock64();
     }
+#endif
     if (p.tile_order == 5u) {
         // one relaxed add per wave: the tile's cost for the next frame's schedule
         const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
