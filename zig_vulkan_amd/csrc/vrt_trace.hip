@@ -275,7 +275,7 @@ VRT_DI void voxel_walk_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint3
     unsigned long long mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb;
-    asm volatile(VRT_WALK_ASM(VRT_T_LIMIT) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS, [scale] "v"(scale), [tmax] "v"(t_max) : "vcc", "scc");
+    asm volatile(VRT_WALK_ASM(VRT_T_LIMIT) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
 }
 #undef VRT_WALK_ASM
 #undef VRT_WALK_OUTPUTS
@@ -457,7 +457,7 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
 // brick was entered (the brick-level walk's crossed axis), used when the very first voxel is the hit.
 template <int B>
 VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t brick_index, f3 brick_min, Hit &hit,
-                              int axis_in) {
+                              int axis_in, int &hit_axis) {
     const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
     const float voxel_scale = g_scale * brick_voxel_scale;
     const f3 fposition = (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
@@ -508,11 +508,12 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
                 const int a = (first && g.stub == 0u)
                                   ? axis_in
                                   : (__builtin_amdgcn_inverse_ballot_w64(g.in_x) ? 0 : (__builtin_amdgcn_inverse_ballot_w64(g.in_y) ? 1 : 2));
+                // (hit.normal and hit.point are derived from hit_axis and hit.t once the walk is over: six registers
+                // less to carry through both loops)
                 hit.index = mi;
                 const float t_offset = voxel_scale * 0.05f;
                 hit.t += g.t_in * voxel_scale - t_offset; // t_value of the step into this voxel (comp:442), 0 for the first
-                hit.normal = axis_normal(s, a);
-                hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
+                hit_axis = a;
                 found = true;
             }
         }
@@ -573,6 +574,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     uint32_t block_index = ~0u;
     uint2 block_bits = make_uint2(0u, 0u);
     int axis = 3;
+    [[maybe_unused]] int hit_axis = 0; // default kernel: the face of the voxel hit, turned into hit.normal / hit.point after the walk
 
     // `global_t_value <= t_max` (comp:316) with t_max = +inf only fails for a NaN t, and t only
     // changes when a brick is entered: test it there instead of on every step.
@@ -648,7 +650,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         VRT_COUNT_WAVE(wave_brick_walks);
         bool found;
         if constexpr (MODE == kStatusLinearAlways && !COUNT) {
-            found = brick_walk_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, brick_axis);
+            found = brick_walk_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, brick_axis, hit_axis);
         } else {
             found = brick_walk<B, COUNT, MODE == kStatusLinear || MODE == kStatusLinearLds || MODE == kStatusLinearAhead>(
                 p, r, s, g_scale, brick_index, brick_min, hit, brick_axis, c);
@@ -744,6 +746,11 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
             // (as asm: the compiler would do this on the vector unit and could not hand the result back to an SGPR operand)
             asm("s_andn2_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(stop != 0)) : "scc");
             first = false;
+        }
+        if (stop == -1) { // comp:433-436, from the values recorded at the hit
+            const float t_offset = (g_scale * (1.0f / (float)B)) * 0.05f;
+            hit.normal = axis_normal(s, hit_axis);
+            hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
         }
         return stop == -1;
     } else {
