@@ -23,6 +23,6 @@ for variant in variants:
           f"voxel trips {wc['wave_voxel_iters']}; lanes: grid steps {c['grid_steps']} bricks {c['bricks_entered']} voxel steps {c['voxel_steps']} hits {c['hits']} rays {c['rays']}")
     if profile:  # library built with make EXTRA=-DVRT_DEV_PROFILE: core-clock cycles per phase, summed over the 4 waves
         pr = rt.wave_timeline().reshape(-1)[:8]
-        names = ["grid loop", "brick walks (all)", "voxel loops", "grid_hit setup", "-", "-", "-", "whole wave"]
+        names = ["grid loop", "brick walks (all)", "voxel loops", "grid_hit setup", "material test", "-", "-", "whole wave"]
         print("   cycles summed over 4 waves:", ", ".join(f"{n} {int(v)}" for n, v in zip(names, pr) if n != "-"))
     rt.deinit(); rc.deinit()

@@ -184,15 +184,15 @@ struct GridWalkRegs {
     "v_add_u32_e32 %[" IDXN "], %[" IDX "], %[t0]\n\t"                    \
     "v_lshrrev_b32_e32 %[t2], 5, %[" IDXN "]\n\t"                         \
     "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"         \
+    "s_waitcnt vmcnt(1)\n\t" /* the word of the cell being left (requested a trip ago); the next cell's stays in flight */ \
+    "v_bfe_u32 %[t1], %[" WORD "], %[" IDX "], 1\n\t"                     \
+    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"                                  \
     "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[" MX "]\n\t"          \
     "v_subbrev_co_u32_e64 %[ry], %[by], 0, %[ry], %[" MY "]\n\t"          \
     "v_addc_co_u32_e64 %[rz], %[cz], -1, %[rz], %[" MXY "]\n\t"           \
     LIMIT(TS, MXY)                                                        \
     "s_or_b64 %[ex], %[ex], %[by]\n\t"                                    \
     "s_orn2_b64 %[ex], %[ex], %[cz]\n\t" /* z: carry-out 0 = borrow */    \
-    "s_waitcnt vmcnt(1)\n\t" /* the word of the cell being left; the next cell's stays in flight */ \
-    "v_bfe_u32 %[t1], %[" WORD "], %[" IDX "], 1\n\t"                     \
-    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"                                  \
     "s_andn2_b64 exec, exec, %[ex]\n\t"                                   \
     "s_cbranch_vccnz " OUT "\n\t"
 
@@ -213,6 +213,8 @@ struct GridWalkRegs {
     "s_mov_b64 exec, %[alive]\n\t"                                                                        \
     VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, "1f")                  \
     "0:\n\t"                                                                                              \
+    VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, "2f")                  \
+    VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, "3f")                  \
     VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, "2f")                  \
     VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, "3f")                  \
     "s_cbranch_execnz 0b\n\t"                                                                             \
@@ -485,6 +487,8 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
     rsrc.z = p.occupancy_words;
     rsrc.w = 0x00020000u;
     uint32_t word = reinterpret_cast<const uint32_t *>(p.brick_occupancy)[more ? (bit_index >> 5) : 0u];
+    // comp:422, requested before the walk so that a solid voxel's material test starts one dependent load later
+    const uint32_t brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu;
     GridWalkRegs g;
     g.alive = __builtin_amdgcn_ballot_w64(more);
     g.out_x = 0ull;
@@ -494,11 +498,13 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
     bool found = false;
     while (g.alive != 0ull) {
         uint32_t solid_bit; // bit index of the voxel each lane stood on before its last step
+        VRT_PROF_BEGIN(tp2);
         voxel_walk_gfx950(w, s.inv_dir, bit_index, solid_bit, stride_x, stride_y, stride_z, word, rsrc, g, voxel_scale, local_t_max);
+        VRT_PROF_END(2, tp2);
         if (g.occ == 0ull) break; // every lane has left the brick (or the grid box)
         if (__builtin_amdgcn_inverse_ballot_w64(g.occ)) {
+            VRT_PROF_BEGIN(tp4);
             const uint32_t voxel_index = solid_bit - base;
-            const uint32_t brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu; // comp:422
             const uint32_t mi = p.material_index[brick_material_index + voxel_index];
             const vrt_material *m = p.materials + mi;
             const uint32_t mtype = m->type;
@@ -516,6 +522,7 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
                 hit_axis = a;
                 found = true;
             }
+            VRT_PROF_END(4, tp4);
         }
         asm("s_andn2_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(found)) : "scc");
         first = false;
