@@ -194,6 +194,95 @@ __global__ void k_chain_load(const State *in, float *out, unsigned long long *cy
     STORE_STATE
 }
 
+// The shipped trip (vrt_trace.hip VRT_TRIP, brick level) on an all-empty bitmap, four trips per back edge.
+typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+#define TRIP(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN)                      \
+    "v_cmp_lt_f32_e64 %[" MX "], %[sdx], %[sdy]\n\t"                      \
+    "v_cmp_lt_f32_e64 %[" MXY "], %[sdx], %[sdz]\n\t"                     \
+    "v_cmp_lt_f32_e64 %[" MY "], %[sdy], %[sdz]\n\t"                      \
+    "v_add_f32_e64 %[t0], %[sdx], |%[ix]|\n\t"                            \
+    "v_add_f32_e64 %[t1], %[sdy], |%[iy]|\n\t"                            \
+    "v_add_f32_e64 %[t2], %[sdz], |%[iz]|\n\t"                            \
+    "s_andn2_b64 %[" MY "], %[" MY "], %[" MX "]\n\t"                     \
+    "s_and_b64 %[" MX "], %[" MX "], %[" MXY "]\n\t"                      \
+    "s_or_b64 %[" MXY "], %[" MX "], %[" MY "]\n\t"                       \
+    "v_cndmask_b32_e64 %[" TS "], %[sdz], %[sdy], %[" MY "]\n\t"          \
+    "v_cndmask_b32_e64 %[" TS "], %[" TS "], %[sdx], %[" MX "]\n\t"       \
+    "v_cndmask_b32_e64 %[sdx], %[sdx], %[t0], %[" MX "]\n\t"              \
+    "v_cndmask_b32_e64 %[sdy], %[sdy], %[t1], %[" MY "]\n\t"              \
+    "v_cndmask_b32_e64 %[sdz], %[t2], %[sdz], %[" MXY "]\n\t"             \
+    "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[" MY "]\n\t"              \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[" MX "]\n\t"               \
+    "v_add_u32_e32 %[" IDXN "], %[" IDX "], %[t0]\n\t"                    \
+    "v_lshrrev_b32_e32 %[t2], 5, %[" IDXN "]\n\t"                         \
+    LOADPART(WORDN)                                                       \
+    "v_bfe_u32 %[t1], %[" WORD "], %[" IDX "], 1\n\t"                     \
+    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"                                  \
+    "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[" MX "]\n\t"          \
+    "v_subbrev_co_u32_e64 %[ry], %[by], 0, %[ry], %[" MY "]\n\t"          \
+    "v_addc_co_u32_e64 %[rz], %[cz], -1, %[rz], %[" MXY "]\n\t"           \
+    "s_or_b64 %[ex], %[ex], %[by]\n\t"                                    \
+    "s_orn2_b64 %[ex], %[ex], %[cz]\n\t"                                  \
+    EXECPART                                                              \
+    BRANCHPART
+#define KFULL(NAME) \
+__global__ void NAME(const State *in, float *out, unsigned long long *cyc, int iters, const uint32_t *bitmap, uint32_t nwords) { \
+    LOAD_STATE \
+    const unsigned long long a = (unsigned long long)bitmap; \
+    u4 rsrc; rsrc.x = (uint32_t)a; rsrc.y = (uint32_t)(a >> 32) | (4u << 16); rsrc.z = nwords; rsrc.w = 0x00020000u; \
+    uint32_t idxa = idx & 0xFFFFu, idxb = 0, worda = 0, wordb = 0; float tsa = 0, tsb = 0, t0, t1, t2; \
+    unsigned long long mxa, mya, mxya, mxb, myb, mxyb, cz; \
+    int n = iters / 4; \
+    unsigned long long w0 = wall_clock64(); unsigned long long tt0 = clock64(); \
+    asm volatile("s_mov_b64 %[save], exec\n\t" \
+        "buffer_load_dword %[worda], %[idxa], %[rsrc], 0 idxen\n\t" \
+        "0:\n\t" \
+        TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb") \
+        TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda") \
+        TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb") \
+        TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda") \
+        "s_sub_u32 %[n], %[n], 1\n\t" \
+        "s_cmp_lg_u32 %[n], 0\n\t" \
+        "s_cbranch_scc1 0b\n\t" \
+        "9:\n\t" \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "s_mov_b64 exec, %[save]" \
+        : [sdx] "+v"(sx), [sdy] "+v"(sy), [sdz] "+v"(sz), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz), [idxa] "+v"(idxa), [idxb] "+v"(idxb), \
+          [worda] "+v"(worda), [wordb] "+v"(wordb), [tsa] "+v"(tsa), [tsb] "+v"(tsb), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), \
+          [mxa] "=&s"(mxa), [mya] "=&s"(mya), [mxya] "=&s"(mxya), [mxb] "=&s"(mxb), [myb] "=&s"(myb), [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), \
+          [cz] "=&s"(cz), [save] "=&s"(save), [n] "+s"(n) \
+        : [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), [stx] "v"(stx), [sty] "v"(sty), [stz] "v"(stz), [rsrc] "s"(rsrc) \
+        : "vcc", "scc"); \
+    unsigned long long t1c = clock64(); unsigned long long w1 = wall_clock64(); \
+    ts = tsa + tsb; idx = idxa + idxb + worda + wordb; \
+    unsigned long long t0c = tt0; \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sx + sy + sz + ts + (float)(rx + ry + rz) + (float)idx; \
+    if (threadIdx.x == 0) { cyc[blockIdx.x * 2] = t1c - t0c; cyc[blockIdx.x * 2 + 1] = w1 - w0; } \
+}
+
+#define LOADPART(WORDN) "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t" "s_waitcnt vmcnt(1)\n\t"
+#define EXECPART "s_andn2_b64 exec, exec, %[ex]\n\t"
+#define BRANCHPART "s_cbranch_vccnz 9f\n\t"
+KFULL(k_full)
+#undef LOADPART
+#define LOADPART(WORDN)
+KFULL(k_full_noload)
+#undef LOADPART
+#define LOADPART(WORDN) "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t" "s_waitcnt vmcnt(1)\n\t"
+#undef EXECPART
+#define EXECPART
+KFULL(k_full_noexec)
+#undef EXECPART
+#define EXECPART "s_andn2_b64 exec, exec, %[ex]\n\t"
+#undef BRANCHPART
+#define BRANCHPART
+KFULL(k_full_nobranch)
+#undef LOADPART
+#define LOADPART(WORDN)
+#undef EXECPART
+#define EXECPART
+KFULL(k_full_bare)
+
 typedef void (*kern_t)(const State *, float *, unsigned long long *, int);
 
 int main() {
@@ -235,6 +324,45 @@ int main() {
         hipMemcpy(c.data(), d_cyc, 16 * blocks, hipMemcpyDeviceToHost);
         double cyc = 0, wall = 0; for (int b = 0; b < blocks; ++b) { cyc += c[2 * b]; wall += c[2 * b + 1]; }
         printf("%-44s %-18s clock64 %.1f /trip  wall %.2f ns/trip\n", "dependent L1-hit global_load chain", mode == 0 ? "1 wave alone" : "8 waves/SIMD full", cyc / blocks / iters, wall / blocks * 10.0 / iters);
+    }
+    {
+        // address pattern of the trip's load: scattered (default state), every lane the same word, 8x8 block of neighbouring cells
+        std::vector<State> h2(64), h3(64);
+        for (int i = 0; i < 64; ++i) { h2[i] = h[i]; h2[i].stx = h2[i].sty = h2[i].stz = 0; h2[i].idx = 4096; }
+        for (int i = 0; i < 64; ++i) { h3[i] = h[i]; h3[i].stx = h3[i].sty = h3[i].stz = 0; h3[i].idx = 64 * 64 * 8 + (i & 7) * 64 + (i >> 3) * 4096 + 17; } // 8 z-rows x 8 y-layers
+        State *d_in2, *d_in3; hipMalloc(&d_in2, sizeof(State) * 64); hipMalloc(&d_in3, sizeof(State) * 64);
+        hipMemcpy(d_in2, h2.data(), sizeof(State) * 64, hipMemcpyHostToDevice); hipMemcpy(d_in3, h3.data(), sizeof(State) * 64, hipMemcpyHostToDevice);
+        uint32_t *d_bm2; hipMalloc(&d_bm2, 8192 * 4); hipMemset(d_bm2, 0, 8192 * 4);
+        const State *ins[3] = {d_in, d_in2, d_in3}; const char *pn[3] = {"scattered/out of range", "all lanes one word", "8 z-rows x 8 y-layers (16 lines)"};
+        for (int q = 0; q < 3; ++q) {
+            k_full<<<256 * 6, 256>>>(ins[q], d_out, d_cyc, 16, d_bm2, 8192); hipDeviceSynchronize();
+            k_full<<<256 * 6, 256>>>(ins[q], d_out, d_cyc, iters, d_bm2, 8192); hipDeviceSynchronize();
+            const int blocks = 256 * 6; std::vector<unsigned long long> c(2 * blocks);
+            hipMemcpy(c.data(), d_cyc, 16 * blocks, hipMemcpyDeviceToHost);
+            double cyc = 0; for (int b = 0; b < blocks; ++b) cyc += c[2 * b];
+            printf("shipped trip, 6 waves/SIMD, load pattern %-34s -> %.1f cycles per trip per SIMD\n", pn[q], cyc / blocks / iters / 6);
+        }
+    }
+    {
+        uint32_t *d_bm; const uint32_t nwords = 8192; hipMalloc(&d_bm, nwords * 4); hipMemset(d_bm, 0, nwords * 4);
+        // strides small so the index stays inside the bitmap for a while, then reads 0 out of range
+        const int cfgs[4][2] = {{1, 64}, {256 * 4, 256}, {256 * 6, 256}, {256 * 8, 256}};
+        const char *names[4] = {"1 wave alone", "4 waves/SIMD", "6 waves/SIMD", "8 waves/SIMD"};
+        typedef void (*kf_t)(const State *, float *, unsigned long long *, int, const uint32_t *, uint32_t);
+        struct { const char *name; kf_t k; } fam[] = {{"shipped brick-level trip (29 instr)", k_full}, {"  without load+waitcnt", k_full_noload}, {"  without exec update", k_full_noexec},
+                                                       {"  without vccnz branch", k_full_nobranch}, {"  without load, exec update, branch", k_full_bare}};
+        for (auto &f : fam)
+        for (int m = 0; m < 4; m += (m == 0 ? 2 : 1)) {
+            f.k<<<cfgs[m][0], cfgs[m][1]>>>(d_in, d_out, d_cyc, 16, d_bm, nwords); hipDeviceSynchronize();
+            f.k<<<cfgs[m][0], cfgs[m][1]>>>(d_in, d_out, d_cyc, iters, d_bm, nwords); hipDeviceSynchronize();
+            const int blocks = cfgs[m][0];
+            std::vector<unsigned long long> c(2 * blocks);
+            hipMemcpy(c.data(), d_cyc, 16 * blocks, hipMemcpyDeviceToHost);
+            double cyc = 0, wall = 0; for (int b = 0; b < blocks; ++b) { cyc += c[2 * b]; wall += c[2 * b + 1]; }
+            const int waves_per_simd = m == 0 ? 1 : (m == 1 ? 4 : (m == 2 ? 6 : 8));
+            printf("%-44s %-14s clock64 %.1f /trip/wave -> %.1f cycles, %.2f ns per trip per SIMD\n", f.name, names[m],
+                   cyc / blocks / iters, cyc / blocks / iters / waves_per_simd, wall / blocks * 10.0 / iters / waves_per_simd);
+        }
     }
     return 0;
 }

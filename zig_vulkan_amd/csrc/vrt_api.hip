@@ -532,12 +532,16 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         p.block_threads = 256u;
         c->kernel_name += "[LDS structure > 64 KiB: global-memory variant]";
     }
-    if (p.occupancy_words == 0u && (vrt::resolve_variant(c->cfg.kernel_variant) & 0xFFu) == vrt::kVariantLinearAlways) {
+    const uint32_t resolved_mode = vrt::resolve_variant(c->cfg.kernel_variant) & 0xFFu;
+    if (p.occupancy_words == 0u &&
+        (resolved_mode == vrt::kVariantLinearAlways || resolved_mode == vrt::kVariantLinearLds || resolved_mode == vrt::kVariantLinearLds512)) {
         // more than 2^32 voxel bits: the default kernel's 32-bit bit index does not reach; 64-bit occupancy words instead
         c->cfg.kernel_variant = (c->cfg.kernel_variant & ~0xFFu) | vrt::kVariantLinearWide;
         c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 0);
         c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 1);
         c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 2);
+        c->lds_bytes = 0;
+        p.block_threads = 256u;
         c->kernel_name += "[> 2^32 voxel bits: wide-occupancy variant]";
     }
     // the status bitmap is read 16 bytes at a time by the LDS-staging variant: the +16 slack of dbuf covers the tail

@@ -164,7 +164,7 @@ struct GridWalkRegs {
     uint32_t stub;                   // out: 0 the call ended in its first trip, 1/2 in a later trip, 3 every lane left
 };
 
-#define VRT_TRIP(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, OUT)     \
+#define VRT_TRIP(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, OUT) \
     "v_cmp_lt_f32_e64 %[" MX "], %[sdx], %[sdy]\n\t"                      \
     "v_cmp_lt_f32_e64 %[" MXY "], %[sdx], %[sdz]\n\t"                     \
     "v_cmp_lt_f32_e64 %[" MY "], %[sdy], %[sdz]\n\t"                      \
@@ -182,9 +182,7 @@ struct GridWalkRegs {
     "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[" MY "]\n\t"              \
     "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[" MX "]\n\t"               \
     "v_add_u32_e32 %[" IDXN "], %[" IDX "], %[t0]\n\t"                    \
-    "v_lshrrev_b32_e32 %[t2], 5, %[" IDXN "]\n\t"                         \
-    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"         \
-    "s_waitcnt vmcnt(1)\n\t" /* the word of the cell being left (requested a trip ago); the next cell's stays in flight */ \
+    LOAD(IDXN, WORDN) /* request the next cell's word; wait for the one requested a trip ago */ \
     "v_bfe_u32 %[t1], %[" WORD "], %[" IDX "], 1\n\t"                     \
     "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"                                  \
     "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[" MX "]\n\t"          \
@@ -195,6 +193,23 @@ struct GridWalkRegs {
     "s_orn2_b64 %[ex], %[ex], %[cz]\n\t" /* z: carry-out 0 = borrow */    \
     "s_andn2_b64 exec, exec, %[ex]\n\t"                                   \
     "s_cbranch_vccnz " OUT "\n\t"
+
+// Where the bitmap words come from.  Global memory: a stride-4 buffer resource indexed by the word index (an
+// index outside the buffer reads 0).  LDS (brick level, grids whose status bitmap fits): the bitmap staged at
+// LDS address 0, byte address masked into the power-of-two allocation.  The vector memory pipeline takes
+// one wave-wide scattered dword request per ~16 cycles per CU (tools/ubench/step_bench.hip: the trip runs at 63
+// cycles per SIMD with the buffer load, 40-44 without); LDS serves the same request several times faster.
+#define VRT_LOAD_BUFFER(IDXN, WORDN)                                      \
+    "v_lshrrev_b32_e32 %[t2], 5, %[" IDXN "]\n\t"                         \
+    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"         \
+    "s_waitcnt vmcnt(1)\n\t"
+#define VRT_WAIT_BUFFER "s_waitcnt vmcnt(0)\n\t"
+#define VRT_LOAD_LDS(IDXN, WORDN)                                         \
+    "v_lshrrev_b32_e32 %[t2], 3, %[" IDXN "]\n\t"                         \
+    "v_and_b32_e32 %[t2], %[rsrc], %[t2]\n\t"                             \
+    "ds_read_b32 %[" WORDN "], %[t2]\n\t"                                 \
+    "s_waitcnt lgkmcnt(1)\n\t"
+#define VRT_WAIT_LDS "s_waitcnt lgkmcnt(0)\n\t"
 
 // voxel level only (comp:469): the lane also leaves when the crossed distance, scaled to world units, is not
 // <= the distance left inside the grid box (NaN leaves, as `!(t <= max)` does)
@@ -208,15 +223,15 @@ struct GridWalkRegs {
 // request for wordb; a B trip the other way round.  A call starts with an A trip.  On exit the B set holds the
 // last step and the A set the one before it, idxa/worda the current cell and idxb the cell just left: a call
 // that ends in an A trip swaps the sets on its way out.
-#define VRT_WALK_ASM(LIMIT)                                                                              \
+#define VRT_WALK_ASM(LIMIT, LOAD, WAITALL)                                                                            \
     "s_mov_b64 %[save], exec\n\t"                                                                         \
     "s_mov_b64 exec, %[alive]\n\t"                                                                        \
-    VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, "1f")                  \
+    VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, "1f")                  \
     "0:\n\t"                                                                                              \
-    VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, "2f")                  \
-    VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, "3f")                  \
-    VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, "2f")                  \
-    VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, "3f")                  \
+    VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, "2f")                  \
+    VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, "3f")                  \
+    VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, "2f")                  \
+    VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, "3f")                  \
     "s_cbranch_execnz 0b\n\t"                                                                             \
     "s_mov_b32 %[stub], 3\n\t"                                                                            \
     "s_branch 4f\n\t"                                                                                     \
@@ -229,7 +244,7 @@ struct GridWalkRegs {
     "s_mov_b64 %[occ], vcc\n\t"                                                                           \
     "s_mov_b64 %[alive], exec\n\t"                                                                        \
     "s_mov_b64 exec, %[save]\n\t"                                                                         \
-    "s_waitcnt vmcnt(0)\n\t"                                                                              \
+    WAITALL                                                                                               \
     "s_mov_b64 %[ex], %[mxa]\n\t"                                                                         \
     "s_mov_b64 %[mxa], %[mxb]\n\t"                                                                        \
     "s_mov_b64 %[mxb], %[ex]\n\t"                                                                         \
@@ -249,7 +264,7 @@ struct GridWalkRegs {
     "s_mov_b64 %[occ], vcc\n\t"                                                                           \
     "s_mov_b64 %[alive], exec\n\t"                                                                        \
     "s_mov_b64 exec, %[save]\n\t"                                                                         \
-    "s_waitcnt vmcnt(0)\n\t" /* the compiler may move `word`: no load may be in flight outside */         \
+    WAITALL /* the compiler may move `word`: no load may be in flight outside */                          \
     "6:"
 
 #define VRT_WALK_OUTPUTS                                                                                                                        \
@@ -267,7 +282,16 @@ VRT_DI void grid_walk_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32
     unsigned long long mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb;
-    asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
+    asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_BUFFER, VRT_WAIT_BUFFER) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
+}
+
+// brick level with the status bitmap in LDS; `rsrc` is the byte-address mask (allocation size - 4)
+VRT_DI void grid_walk_lds_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
+                                 uint32_t &word, uint32_t rsrc, GridWalkRegs &g) {
+    unsigned long long mxya, mxyb, ex, by, cz, save;
+    float t0, t1, t2;
+    uint32_t wordb;
+    asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_LDS, VRT_WAIT_LDS) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
 }
 
 // voxel level (comp:409-470): voxels of one brick, bits of brick_occupancy addressed by the global bit index
@@ -277,7 +301,7 @@ VRT_DI void voxel_walk_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint3
     unsigned long long mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb;
-    asm volatile(VRT_WALK_ASM(VRT_T_LIMIT) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
+    asm volatile(VRT_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_BUFFER, VRT_WAIT_BUFFER) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
 }
 #undef VRT_WALK_ASM
 #undef VRT_WALK_OUTPUTS
@@ -656,7 +680,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         VRT_COUNT(bricks_entered);
         VRT_COUNT_WAVE(wave_brick_walks);
         bool found;
-        if constexpr (MODE == kStatusLinearAlways && !COUNT) {
+        if constexpr ((MODE == kStatusLinearAlways || MODE == kStatusLinearLds) && !COUNT) {
             found = brick_walk_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, brick_axis, hit_axis);
         } else {
             found = brick_walk<B, COUNT, MODE == kStatusLinear || MODE == kStatusLinearLds || MODE == kStatusLinearAhead>(
@@ -717,7 +741,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
             more = ((inside ? 0 : -1) | stop) >= 0;
         }
         return stop == -1;
-    } else if constexpr (MODE == kStatusLinearAlways && !COUNT) {
+    } else if constexpr ((MODE == kStatusLinearAlways || MODE == kStatusLinearLds) && !COUNT) {
         // The shipped default: grid_walk_gfx950 runs trips until some lane stands on an occupied cell (or all
         // lanes have left); the bricks are walked here, with the state from BEFORE the lane's last step rebuilt
         // from the post-step state and the crossed-axis lane masks, and the walk is resumed.
@@ -727,7 +751,11 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         rsrc.y = (uint32_t)(status_addr >> 32) | (4u << 16); // stride 4: one record per status word
         rsrc.z = p.status_words;
         rsrc.w = 0x00020000u;
-        uint32_t word = p.brick_status[more ? (grid_index >> 5) : 0u];
+        // LDS variant: byte-address mask of the power-of-two LDS allocation holding the bitmap (trace_lds_bytes)
+        [[maybe_unused]] const uint32_t lds_mask = (0xFFFFFFFFu >> __builtin_clz(p.status_words * 4u - 1u)) & ~3u;
+        uint32_t word;
+        if constexpr (MODE == kStatusLinearLds) word = lds_word0(more ? (grid_index >> 5) : 0u);
+        else word = p.brick_status[more ? (grid_index >> 5) : 0u];
         GridWalkRegs g;
         g.alive = __builtin_amdgcn_ballot_w64(more);
         g.out_x = 0ull;
@@ -738,7 +766,8 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         while (g.alive != 0ull) {
             uint32_t cell; // the cell each lane stood on before its last step
             VRT_PROF_BEGIN(tp0);
-            grid_walk_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
+            if constexpr (MODE == kStatusLinearLds) grid_walk_lds_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, lds_mask, g);
+            else grid_walk_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
             VRT_PROF_END(0, tp0);
             if (g.occ == 0ull) break; // every lane has left the grid
             if (__builtin_amdgcn_inverse_ballot_w64(g.occ)) {
@@ -1221,7 +1250,11 @@ size_t trace_lds_bytes(const TraceParams &p, uint32_t variant) {
         const size_t nwords = ((size_t)p.nbx * p.nby * p.nbz + 31u) >> 5;
         return (nwords * 4u + 15u) & ~(size_t)15u;
     }
-    if (mode == kVariantLinearLds || mode == kVariantLinearLds512) return (((size_t)p.status_words + 3u) & ~(size_t)3u) * 4u;
+    if (mode == kVariantLinearLds || mode == kVariantLinearLds512) {
+        size_t bytes = 16; // power of two: the hand-written loop masks byte addresses into the allocation
+        while (bytes < (size_t)p.status_words * 4u) bytes <<= 1;
+        return bytes;
+    }
     return 0;
 }
 
