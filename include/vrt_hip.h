@@ -112,7 +112,8 @@ typedef struct vrt_config {
     uint32_t material_capacity; /* 0 => 256 (Pipeline.zig:30)                    */
     int32_t device_id;          /* HIP device; -1 => current device              */
     uint32_t want_float_output; /* also keep an RGBA32F target (parity checks)   */
-    uint32_t enable_counters;   /* traversal counters (S,K,V,H,rays); slower     */
+    uint32_t enable_counters;   /* traversal counters (S,K,V,H,rays): a counting build of the kernel runs
+                                   before the product kernel, which still renders the frame read back */
     /* image-tile sharding across processes (one process per GPU).  The frame is
      * cut into tile_w x tile_h tiles, numbered row-major; this context renders
      * tiles t with t % shard_count == shard_rank into a packed tile-major

@@ -212,6 +212,28 @@ def test_reference_app_default_scene_shape_non_cubic_grid():
     assert c["hits"] > 0
 
 
+@pytest.mark.parametrize("b", [4, 8])
+@pytest.mark.parametrize("scale", [0.3, 3.0, 0.5])
+def test_grid_scale_not_a_power_of_two(b, scale):
+    """The kernel replaces `x / scale` by `x * (1 / scale)` when the grid and voxel scales are powers of two
+    (exact); any other scale must take the IEEE divisions of the shader (comp:288,392)."""
+    from zig_vulkan_amd import BrickGrid
+    w = W.Workload("t", 200, 120, 16 * b, b, 1, 0, True, 2.0)
+    n = 16
+    grid = BrickGrid(n, n, n, min_point=(-0.5 * n * scale, -0.5 * n * scale, -0.5 * n * scale), scale=scale, brick_dimension=b)
+    grid.synth_terrain(420)
+    for variant in (0, 4):
+        rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, kernel_variant=variant)
+        rt.camera.look_at((0.9 * n * scale, -0.8 * n * scale, 1.1 * n * scale), (0.0, 0.1 * n * scale, 0.0))
+        rt.draw()
+        f, u, c = rt.read_rgba32f(), rt.read_rgba8(), rt.counters()
+        pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+        rt.deinit()
+        fo, uo, co = O.render(oracle_scene_from_grid(grid), pc)
+        _compare(f, u, c, fo, uo, co)
+    assert co["hits"] > 0 and co["rays"] > 200 * 120
+
+
 @pytest.mark.parametrize("dims", [(5, 3, 7), (1, 1, 1), (2, 9, 2)])
 def test_odd_grid_dimensions(dims):
     """Grids whose dimensions are not multiples of the 4x4x4 status blocks (and a single-cell grid)."""

@@ -612,6 +612,20 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
     ctx->params.pc.cam = *camera;
     ctx->params.pc.sun = *sun;
     const vrt_grid_state &g = ctx->params.grid;
+    {
+        auto pow2_with_normal_reciprocal = [](float v) {
+            uint32_t b;
+            std::memcpy(&b, &v, 4);
+            const uint32_t e = (b >> 23) & 0xFFu;
+            return (b & 0x7FFFFFu) == 0u && e >= 2u && e <= 252u;
+        };
+        const float gs = g.max_point_scale[3];
+        const float vs = gs * (1.0f / (float)ctx->cfg.brick_dimension); // as the kernel forms it (Pipeline.zig:313)
+        const bool ok = pow2_with_normal_reciprocal(gs) && pow2_with_normal_reciprocal(vs);
+        ctx->params.scale_pow2 = ok ? 1u : 0u;
+        ctx->params.inv_grid_scale = ok ? 1.0f / gs : 0.0f;
+        ctx->params.inv_voxel_scale = ok ? 1.0f / vs : 0.0f;
+    }
     if (g.dim_x != 0 && (g.dim_x != ctx->cfg.dim_x || g.dim_y != ctx->cfg.dim_y || g.dim_z != ctx->cfg.dim_z))
         return fail(ctx, VRT_E_INVALID_ARG, "uploaded grid state has other brick dimensions than the context was created with");
     if (ctx->d_counters) VRT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(vrt::DeviceCounters), ctx->stream));
@@ -637,6 +651,16 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     const int rcp = pre_dispatch(ctx, camera, sun, &fn);
     if (rcp != VRT_OK) return rcp;
 
+    // With counters enabled the counting build of the kernel (compiler-generated loops, per-lane counters) runs
+    // first and fills the counters; the frame that is read back is then rendered by the product kernel itself,
+    // so that every parity check made on a counting context checks the shipped code path.
+    vrt::KernelFn product_fn = nullptr;
+    if (ctx->d_counters) {
+        const int shade = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? 2 : 1) : 0;
+        product_fn = vrt::select_trace_kernel((int)ctx->cfg.brick_dimension, false, ctx->cfg.kernel_variant, shade);
+        if (!product_fn) return fail(ctx, VRT_E_STATE, "no product kernel for this configuration");
+    }
+
     const bool slot_b = ctx->stream_b && frames == 1 && !primary_only && (ctx->frame_seq & 1u);
     if (slot_b) {
         // second frame slot: its own stream and target; ordered after every scene write so far
@@ -648,6 +672,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         pb.target_rgba8 = ctx->target8_b;
         pb.target_rgba32f = ctx->target32f_b;
         VRT_HIP(ctx, vrt::launch_trace(fn, pb, ctx->lds_bytes, ctx->stream_b));
+        if (product_fn) VRT_HIP(ctx, vrt::launch_trace(product_fn, pb, ctx->lds_bytes, ctx->stream_b));
         VRT_HIP(ctx, hipEventRecord(ctx->ev_b_done, ctx->stream_b));
         ctx->b_pending = true;
         ctx->frame_seq++;
@@ -665,6 +690,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule, ctx->shard.owned_tiles, ctx->stream));
     }
     for (uint32_t f = 0; f < frames; f++) VRT_HIP(ctx, vrt::launch_trace(fn, ctx->params, ctx->lds_bytes, ctx->stream));
+    if (product_fn) VRT_HIP(ctx, vrt::launch_trace(product_fn, ctx->params, ctx->lds_bytes, ctx->stream));
     VRT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->timed_frames = frames;
     ctx->in_flight = true;

@@ -43,6 +43,11 @@ struct TraceParams {
     uint32_t shard_rank, shard_count;    // this ctx renders tiles t % count == rank
     uint32_t owned_tiles;                // number of tiles this context renders
     uint32_t status_words;               // length of brick_status in u32 words
+    // x / grid scale and x / voxel scale as multiplications when both scales are powers of two (set per dispatch from
+    // binding 1): the exact reciprocal gives the same correctly rounded quotient in one instruction instead of the
+    // ~10 of an IEEE division (six divisions per ray, three per brick entered)
+    uint32_t scale_pow2;
+    float inv_grid_scale, inv_voxel_scale;
     uint32_t occupancy_words;            // length of brick_occupancy in u32 words (0: too many voxels for a 32-bit bit index)
     // derived, device-built copy of brick_status: one 64-bit word per 4x4x4 block of grid cells,
     // block index bx + nbx*(bz + nbz*by), bit (x&3) + 4*(z&3) + 16*(y&3)  (x, z, y order as comp:318)

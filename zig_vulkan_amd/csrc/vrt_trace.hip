@@ -393,7 +393,7 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
                        int &axis, Cnt<COUNT> &c) {
     const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
     const float voxel_scale = g_scale * brick_voxel_scale;
-    const f3 fposition = (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
+    const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
     Walk w;
     w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
     const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
@@ -486,7 +486,7 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
                               int axis_in, int &hit_axis) {
     const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
     const float voxel_scale = g_scale * brick_voxel_scale;
-    const f3 fposition = (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
+    const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
     Walk w;
     w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
     const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
@@ -587,7 +587,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     const int dx = (int)p.grid.dim_x, dy = (int)p.grid.dim_y, dz = (int)p.grid.dim_z;
 
     float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
-    const f3 fposition = (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
+    const f3 fposition = p.scale_pow2 ? (ray_at(r, global_t_value) - g_min) * p.inv_grid_scale : (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
     Walk w;
     w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
     const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
@@ -689,6 +689,16 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         stop = found ? -1 : ((global_t_value <= t_max) ? 0 : -2);
     };
     auto enter_brick = [&]() { enter_brick_at(w.rx, w.ry, w.rz, w.t_value, grid_index, axis); };
+    // brick_walk_gfx950 records a hit as distance + material + face; comp:433-436 from those, once the walk is over
+    auto finish_hit = [&]() {
+        if constexpr ((MODE == kStatusLinearAlways || MODE == kStatusLinearLds) && !COUNT) {
+            if (stop == -1) {
+                const float t_offset = (g_scale * (1.0f / (float)B)) * 0.05f;
+                hit.normal = axis_normal(s, hit_axis);
+                hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
+            }
+        }
+    };
 
     if constexpr (BATCH) {
         // lane state: 0 at a cell (test it), 1 waiting to walk a brick, 2 finished, 3 take the DDA step
@@ -710,6 +720,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
                 state = (min3i(w.rx, w.ry, w.rz) >= 0) ? 0 : 2;
             }
         }
+        finish_hit();
         return stop == -1;
     } else if constexpr (MODE == kStatusLinearAhead) {
         // Software-pipelined walk.  The DDA step does not depend on the cell test, so it is taken first and
@@ -783,11 +794,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
             asm("s_andn2_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(stop != 0)) : "scc");
             first = false;
         }
-        if (stop == -1) { // comp:433-436, from the values recorded at the hit
-            const float t_offset = (g_scale * (1.0f / (float)B)) * 0.05f;
-            hit.normal = axis_normal(s, hit_axis);
-            hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
-        }
+        finish_hit();
         return stop == -1;
     } else {
         while (more) { // single-exit loop, see brick_walk
