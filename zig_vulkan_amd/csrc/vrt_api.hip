@@ -506,7 +506,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.tile_cost = c->d_tile_cost;
     p.tile_schedule = c->d_tile_schedule;
     p.wave_groups = (cfg->kernel_variant >> 20) & 0x1u;
-    p.brick_batch = (cfg->kernel_variant >> 24) & 0xFu ? ((cfg->kernel_variant >> 24) & 0xFu) * 4u : 4u; // tuning knob: units of 4 lanes
+    p.brick_batch = (cfg->kernel_variant >> 24) & 0xFu ? ((cfg->kernel_variant >> 24) & 0xFu) * 4u : 8u; // tuning knob: units of 4 lanes
     p.block_threads = ((vrt::resolve_variant(cfg->kernel_variant) & 0xFFu) == vrt::kVariantLinearLds512) ? 512u : 256u;
     {
         // a stride near owned_tiles * 0.618 that is coprime to owned_tiles

@@ -306,6 +306,103 @@ VRT_DI void voxel_walk_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint3
 #undef VRT_WALK_ASM
 #undef VRT_WALK_OUTPUTS
 #undef VRT_WALK_INPUTS
+
+// ---- the same loop with parking, for frames with bounces ----------------------------------------------------
+// Secondary rays are incoherent: the lanes of a wave meet their bricks at different trips, and walking each
+// brick at once (the shader's order) runs the long voxel-level code for a few lanes at a time.  Here a lane
+// whose trip left an occupied cell behind is PARKED: dropped from EXEC with, per lane, tsa = the distance into
+// that cell, tsb = the distance of the step out of it, idxb = the cell, idxa = the cell it now stands on and the
+// two crossed axes in `code` (an A trip swaps the two register sets for the parked lanes to get there).  The
+// other lanes keep walking until `batch` lanes are parked or nobody is moving; then the call returns and the
+// caller walks all parked bricks in ONE execution.  Per lane the sequence of operations is unchanged.  The
+// in-axis of a lane's FIRST trip in a call comes from code bits 4-5 (its last step may be many trips old); later
+// trips read it from the other set's crossed-axis masks.  On exit the sets are swapped for the still-moving
+// lanes as well if the last trip was an A trip, so that set B / idxa / worda are "last step / current cell /
+// its status word" for every lane.  (Measured on the 2048^3 path-trace config: 325 -> 220 ms per frame against
+// the per-trip state machine this replaces; on primary + shadow frames the plain loop above is 3 % faster.)
+struct GridParkRegs {
+    unsigned long long alive;        // in: lanes to walk; out: lanes still moving when the call ended
+    unsigned long long parked;       // out: lanes that left an occupied cell behind (0: every lane has left)
+    unsigned long long out_x, out_y; // in/out: crossed-x / crossed-y lanes of the last trip (moving lanes: their last step)
+    float t_out, t_in;               // per lane: crossed distance of the lane's last step (in/out) and of the step before it (out)
+    // per lane.  in: bits 4-5 = axis crossed by the lane's last step before this call (3: none, the slab entry).
+    // out, parked lanes: bits 0-1 axis INTO the occupied cell, bits 2-3 axis OUT of it
+    uint32_t code;
+    uint32_t batch;                  // in: the call returns once this many lanes are parked (or nobody is moving)
+};
+
+#define VRT_PARK(LABEL, IN_AXIS, OUT_MX, OUT_MY, SWAP, NEXT, EXIT)                                       \
+    LABEL ":\n\t"                                                                                         \
+    "s_mov_b64 %[ex], exec\n\t"                                                                           \
+    "s_mov_b64 exec, vcc\n\t"                                                                             \
+    IN_AXIS                                                                                               \
+    "v_cndmask_b32_e64 %[t1], 2, 1, %[" OUT_MY "]\n\t"                                                    \
+    "v_cndmask_b32_e64 %[t1], %[t1], 0, %[" OUT_MX "]\n\t"                                                \
+    "v_lshl_or_b32 %[code], %[t1], 2, %[t0]\n\t"                                                          \
+    SWAP                                                                                                  \
+    "s_or_b64 %[parked], %[parked], vcc\n\t"                                                              \
+    "s_andn2_b64 exec, %[ex], vcc\n\t"                                                                    \
+    "s_bcnt1_i32_b64 %[n], %[parked]\n\t"                                                                 \
+    "s_cmp_ge_u32 %[n], %[batch]\n\t"                                                                     \
+    "s_cbranch_scc1 " EXIT "\n\t"                                                                         \
+    "s_cbranch_execnz " NEXT "\n\t"                                                                       \
+    "s_branch " EXIT "\n\t"
+#define VRT_IN_FROM_CODE "v_bfe_u32 %[t0], %[code], 4, 2\n\t"
+#define VRT_IN_FROM(MX, MY) "v_cndmask_b32_e64 %[t0], 2, 1, %[" MY "]\n\t" "v_cndmask_b32_e64 %[t0], %[t0], 0, %[" MX "]\n\t"
+#define VRT_SWAP_SETS "v_swap_b32 %[tsa], %[tsb]\n\t" "v_swap_b32 %[idxa], %[idxb]\n\t"
+
+VRT_DI void grid_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
+                                  uint32_t &word, u32x4 rsrc, GridParkRegs &g) {
+    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
+    float t0, t1, t2;
+    uint32_t wordb, n;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "s_mov_b64 exec, %[alive]\n\t"
+        "s_mov_b64 %[parked], 0\n\t"
+        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", VRT_NO_LIMIT, VRT_LOAD_BUFFER, "10f")
+        "0:\n\t"
+        VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", VRT_NO_LIMIT, VRT_LOAD_BUFFER, "11f")
+        "21:\n\t"
+        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", VRT_NO_LIMIT, VRT_LOAD_BUFFER, "12f")
+        "22:\n\t"
+        VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", VRT_NO_LIMIT, VRT_LOAD_BUFFER, "13f")
+        "23:\n\t"
+        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", VRT_NO_LIMIT, VRT_LOAD_BUFFER, "14f")
+        "24:\n\t"
+        "s_cbranch_execnz 0b\n\t"
+        "s_branch 31f\n\t"
+        VRT_PARK("10", VRT_IN_FROM_CODE, "mxa", "mya", VRT_SWAP_SETS, "0b", "30f")
+        VRT_PARK("11", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "21b", "31f")
+        VRT_PARK("12", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "22b", "30f")
+        VRT_PARK("13", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "23b", "31f")
+        VRT_PARK("14", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "24b", "30f")
+        "30:\n\t" /* the last trip was an A trip: swap the sets of the lanes still moving */
+        "s_mov_b64 %[alive], exec\n\t"
+        VRT_WAIT_BUFFER
+        VRT_SWAP_SETS
+        "v_mov_b32_e32 %[worda], %[wordb]\n\t"
+        "s_mov_b64 %[mxb], %[mxa]\n\t"
+        "s_mov_b64 %[myb], %[mya]\n\t"
+        "s_branch 32f\n\t"
+        "31:\n\t"
+        "s_mov_b64 %[alive], exec\n\t"
+        VRT_WAIT_BUFFER /* the compiler may move `word`: no load may be in flight outside */
+        "32:\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),
+          [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(word), [wordb] "=&v"(wordb), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in),
+          [code] "+v"(g.code), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive),
+          [mxa] "=&s"(mxa), [mya] "=&s"(mya), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz),
+          [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n)
+        : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z), [rsrc] "s"(rsrc),
+          [batch] "s"(g.batch)
+        : "vcc", "scc");
+}
+#undef VRT_PARK
+#undef VRT_IN_FROM_CODE
+#undef VRT_IN_FROM
+#undef VRT_SWAP_SETS
 #undef VRT_T_LIMIT
 #undef VRT_NO_LIMIT
 #undef VRT_TRIP
@@ -700,7 +797,45 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         }
     };
 
-    if constexpr (BATCH) {
+    if constexpr (BATCH && MODE == kStatusLinearAlways && !COUNT) {
+        // frames with bounces on the default kernel: the hand-written loop with parking (grid_walk_park_gfx950)
+        const unsigned long long status_addr = (unsigned long long)p.brick_status;
+        u32x4 rsrc;
+        rsrc.x = (uint32_t)status_addr;
+        rsrc.y = (uint32_t)(status_addr >> 32) | (4u << 16); // stride 4: one record per status word
+        rsrc.z = p.status_words;
+        rsrc.w = 0x00020000u;
+        uint32_t word = p.brick_status[more ? (grid_index >> 5) : 0u];
+        GridParkRegs g;
+        g.alive = __builtin_amdgcn_ballot_w64(more);
+        g.out_x = 0ull;
+        g.out_y = 0ull;
+        g.t_out = 0.0f;
+        g.code = 3u << 4; // the first cell of the walk was entered through the slab test, not by a step
+        g.batch = p.brick_batch;
+        while (g.alive != 0ull) {
+            uint32_t cell; // the occupied cell each parked lane stood on before its last step
+            grid_walk_park_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
+            if (g.parked == 0ull) break; // every lane has left the grid
+            const bool parked = __builtin_amdgcn_inverse_ballot_w64(g.parked);
+            bool resume = false;
+            if (parked) {
+                int a = (int)(g.code & 3u);
+                const uint32_t out = (g.code >> 2) & 3u;
+                // the counters as they were on the occupied cell: undo the decrement of the step out of it
+                enter_brick_at(w.rx + (out == 0u ? 1 : 0), w.ry + (out == 1u ? 1 : 0), w.rz + (out == 2u ? 1 : 0), g.t_in, cell, a);
+                resume = (stop == 0) && min3i(w.rx, w.ry, w.rz) >= 0;
+            }
+            // every lane: the axis of its last step, for its first trip in the next call
+            g.code = parked ? ((g.code >> 2) & 3u) << 4
+                            : (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
+            if (resume) word = p.brick_status[grid_index >> 5]; // (an A-trip park left the lane's word in the other register set)
+            // (as asm: the compiler would do this on the vector unit and could not hand the result back to an SGPR operand)
+            asm("s_or_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(resume)) : "scc");
+        }
+        finish_hit();
+        return stop == -1;
+    } else if constexpr (BATCH) {
         // lane state: 0 at a cell (test it), 1 waiting to walk a brick, 2 finished, 3 take the DDA step
         int state = more ? 0 : 2;
         while (__any(state != 2)) {
