@@ -116,6 +116,13 @@ def main() -> None:
     ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio (flushed at exit, i.e.
+    # after anything Python printed), so everything else written to fd 1 by any library is sent to stderr and the
+    # JSON line goes to a private copy of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     from zig_vulkan_amd import workloads as W
@@ -300,7 +307,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, grid, args.cpu_seconds)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     rt.deinit()
     if dist is not None:
         dist.destroy_process_group()
