@@ -121,15 +121,17 @@ def test_sharded_tiles_reassemble_to_full_frame():
     assert np.array_equal(out.cpu().numpy().reshape(w.height, w.width, 4), u_full)
 
 
-def test_two_frames_in_flight_give_the_same_frames_and_respect_uploads():
+@pytest.mark.parametrize("variant", [0, 0x50000, 0x100000])
+def test_two_frames_in_flight_give_the_same_frames_and_respect_uploads(variant):
     """frames_in_flight = 2: frames alternate between two streams/targets; every frame still equals
-    the single-stream result, and a grid edit between frames is seen by the next frame on either stream."""
+    the single-stream result, and a grid edit between frames is seen by the next frame on either stream.
+    (0x50000: the cost-feedback tile schedule, which is re-sorted before every frame; 0x100000: one wave per workgroup.)"""
     w = W.Workload("t", 320, 200, 64, 4, 1, 0, True, 0.0)
     grid = W.build_grid(w)
     ref = {}
     for view in ["V0", "V1", "V2"]:
         _, ref[view], _, _ = _run_hip(w, grid, view, counters=False)
-    rt = W.make_renderer(w, grid, frames_in_flight=2)
+    rt = W.make_renderer(w, grid, frames_in_flight=2, kernel_variant=variant)
     seq = ["V0", "V1", "V2", "V1", "V0", "V2", "V2"]
     for view in seq:  # queue without reading: frames overlap
         W.set_view(rt, view)

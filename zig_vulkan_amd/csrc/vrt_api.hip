@@ -661,7 +661,9 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         if (!product_fn) return fail(ctx, VRT_E_STATE, "no product kernel for this configuration");
     }
 
-    const bool slot_b = ctx->stream_b && frames == 1 && !primary_only && (ctx->frame_seq & 1u);
+    // (the cost-feedback tile schedule is re-sorted in place before every frame on the primary stream: a frame
+    // running on the second stream would read it while it is being rewritten, so that tile order runs one frame at a time)
+    const bool slot_b = ctx->stream_b && frames == 1 && !primary_only && (ctx->frame_seq & 1u) && ctx->params.tile_order != 5u;
     if (slot_b) {
         // second frame slot: its own stream and target; ordered after every scene write so far
         if (ctx->b_seen_upload != ctx->upload_seq) {
