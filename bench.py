@@ -86,9 +86,10 @@ def hbm_traffic_from_profile(brick_dimension: int):
     (MI355X_MICROARCH.md) and is uncalibrated for this dword-gather pattern, so both the raw and the
     doubled fetch are given and `traffic` uses the doubled (upper) figure."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    # the shipped kernel's passes are r<round>_final_pmc.json (latest round last); other *_pmc.json files are earlier kernels
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_pmc.json")))
     if not files:
-        return None, "no profiles/*_pmc.json"
+        return None, "no profiles/r*_final_pmc.json"
     with open(files[-1]) as fh:
         data = json.load(fh)
     for name, c in data.items():
