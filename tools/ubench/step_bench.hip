@@ -333,8 +333,20 @@ int main() {
         State *d_in2, *d_in3; hipMalloc(&d_in2, sizeof(State) * 64); hipMalloc(&d_in3, sizeof(State) * 64);
         hipMemcpy(d_in2, h2.data(), sizeof(State) * 64, hipMemcpyHostToDevice); hipMemcpy(d_in3, h3.data(), sizeof(State) * 64, hipMemcpyHostToDevice);
         uint32_t *d_bm2; hipMalloc(&d_bm2, 8192 * 4); hipMemset(d_bm2, 0, 8192 * 4);
-        const State *ins[3] = {d_in, d_in2, d_in3}; const char *pn[3] = {"scattered/out of range", "all lanes one word", "8 z-rows x 8 y-layers (16 lines)"};
-        for (int q = 0; q < 3; ++q) {
+        // more patterns inside ONE y-layer: 2 / 8 / 32 distinct words of the same 128-byte line, and 2 y-layers x 2 words
+        State *d_more[4]; const int nw[4] = {2, 8, 32, 4};
+        for (int m = 0; m < 4; ++m) {
+            std::vector<State> hm(64);
+            for (int i = 0; i < 64; ++i) {
+                hm[i] = h[i]; hm[i].stx = hm[i].sty = hm[i].stz = 0;
+                hm[i].idx = (m < 3) ? 64 * 64 * 8 + (i % nw[m]) * 32 + 5 : 64 * 64 * 8 + (i & 1) * 64 + ((i >> 1) & 1) * 4096 + 5;
+            }
+            hipMalloc(&d_more[m], sizeof(State) * 64); hipMemcpy(d_more[m], hm.data(), sizeof(State) * 64, hipMemcpyHostToDevice);
+        }
+        const State *ins[7] = {d_in, d_in2, d_in3, d_more[0], d_more[1], d_more[2], d_more[3]};
+        const char *pn[7] = {"scattered/out of range", "all lanes one word", "8 z-rows x 8 y-layers (8 lines)", "2 words of one line", "8 words of one line",
+                             "32 words of one line", "2 y-layers x 2 z-rows (2 lines)"};
+        for (int q = 0; q < 7; ++q) {
             k_full<<<256 * 6, 256>>>(ins[q], d_out, d_cyc, 16, d_bm2, 8192); hipDeviceSynchronize();
             k_full<<<256 * 6, 256>>>(ins[q], d_out, d_cyc, iters, d_bm2, 8192); hipDeviceSynchronize();
             const int blocks = 256 * 6; std::vector<unsigned long long> c(2 * blocks);
