@@ -495,11 +495,9 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.shard_count = sh.shard_count;
     p.owned_tiles = sh.owned_tiles;
     p.status_words = (uint32_t)((cells + 31u) / 32u);
-    {
-        // the hand-written voxel-level loop addresses brick_occupancy by a 32-bit global bit index
-        const uint64_t occ_bits = c->dsize[VRT_BUF_BRICK_OCCUPANCY] * 8u;
-        p.occupancy_words = occ_bits <= 0xFFFFFFFFull ? (uint32_t)(c->dsize[VRT_BUF_BRICK_OCCUPANCY] / 4u) : 0u;
-    }
+    // the hand-written voxel-level loop addresses brick_occupancy by a 32-bit global bit index: brick_alloc * B^3 <= 2^31
+    // (the u31 start-index check above), so it always reaches
+    p.occupancy_words = (uint32_t)(c->dsize[VRT_BUF_BRICK_OCCUPANCY] / 4u);
     p.status_blocks = static_cast<const uint2 *>(c->d_status_blocks);
     p.tile_order = (cfg->kernel_variant >> 16) & 0xFu;
     if (p.tile_order == 0u) p.tile_order = 3u; // default: reverse raster (see DESIGN.md §4 for the measured alternatives)
@@ -531,18 +529,6 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         c->lds_bytes = 0;
         p.block_threads = 256u;
         c->kernel_name += "[LDS structure > 64 KiB: global-memory variant]";
-    }
-    const uint32_t resolved_mode = vrt::resolve_variant(c->cfg.kernel_variant) & 0xFFu;
-    if (p.occupancy_words == 0u &&
-        (resolved_mode == vrt::kVariantLinearAlways || resolved_mode == vrt::kVariantLinearLds || resolved_mode == vrt::kVariantLinearLds512)) {
-        // more than 2^32 voxel bits: the default kernel's 32-bit bit index does not reach; 64-bit occupancy words instead
-        c->cfg.kernel_variant = (c->cfg.kernel_variant & ~0xFFu) | vrt::kVariantLinearWide;
-        c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 0);
-        c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 1);
-        c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 2);
-        c->lds_bytes = 0;
-        p.block_threads = 256u;
-        c->kernel_name += "[> 2^32 voxel bits: wide-occupancy variant]";
     }
     // the status bitmap is read 16 bytes at a time by the LDS-staging variant: the +16 slack of dbuf covers the tail
     if (c->stream_b) {

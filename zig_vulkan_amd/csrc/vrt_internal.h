@@ -48,7 +48,7 @@ struct TraceParams {
     // ~10 of an IEEE division (six divisions per ray, three per brick entered)
     uint32_t scale_pow2;
     float inv_grid_scale, inv_voxel_scale;
-    uint32_t occupancy_words;            // length of brick_occupancy in u32 words (0: too many voxels for a 32-bit bit index)
+    uint32_t occupancy_words;            // length of brick_occupancy in u32 words
     // derived, device-built copy of brick_status: one 64-bit word per 4x4x4 block of grid cells,
     // block index bx + nbx*(bz + nbz*by), bit (x&3) + 4*(z&3) + 16*(y&3)  (x, z, y order as comp:318)
     const uint2 *status_blocks;
