@@ -82,3 +82,24 @@ def test_grid_edits_reach_the_next_dispatch():
     assert not np.array_equal(u, before)
     fo, uo, co = O.render(oracle_scene_from_grid(grid), pc)
     assert np.array_equal(f.view(np.uint32), fo.view(np.uint32)) and np.array_equal(u, uo) and c == co
+
+
+def test_headline_frames_are_deterministic_with_two_in_flight():
+    """90 frames of the headline workload, two in flight, views cycled: every frame's bytes equal the first frame of
+    its view (a timing-dependent fault in the hand-written loops would show up as a differing frame;
+    tools/soak.py runs the same for thousands of frames)."""
+    import hashlib
+    w = W.WORKLOADS[W.HEADLINE]
+    grid = W.build_grid(w)
+    rt = W.make_renderer(w, grid, frames_in_flight=2)
+    ref = {}
+    for i in range(90):
+        view = ["V0", "V1", "V2"][i % 3]
+        W.set_view(rt, view)
+        rt.draw()
+        if i % 2 == 1:
+            rt.draw()
+        h = hashlib.sha1(rt.read_rgba8().tobytes()).hexdigest()
+        assert ref.setdefault(view, h) == h, f"frame {i} ({view}) differs"
+    rt.deinit()
+    assert len(set(ref.values())) == 3
