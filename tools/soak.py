@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Determinism soak: many frames of the headline workload (two in flight), every frame's bytes must equal the first
+"""Determinism soak (usage: soak.py [frames] [workload]): many frames of a workload (two in flight), every frame's bytes must equal the first
 frame of its view.  A timing-dependent fault in the hand-written loops (a missed hazard, a stale wait count)
 would show up here as a differing frame."""
 import os, sys, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zig_vulkan_amd import workloads as W
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-w = W.WORKLOADS[W.HEADLINE]
+w = W.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 else W.HEADLINE]
 grid = W.build_grid(w)
 rt = W.make_renderer(w, grid, frames_in_flight=2)
 ref, bad = {}, 0
