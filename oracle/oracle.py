@@ -62,6 +62,9 @@ def lib() -> C.CDLL:
         L.oracle_grid_hit.restype = C.c_int
         L.oracle_grid_hit.argtypes = [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p]
+        L.oracle_grid_hit_raw.restype = C.c_int
+        L.oracle_grid_hit_raw.argtypes = [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p]
         L.oracle_sinf.restype = C.c_float
         L.oracle_sinf.argtypes = [C.c_float]
         L.oracle_hash12.restype = C.c_float
@@ -175,6 +178,21 @@ def grid_hit(scene: OracleScene, pc: np.ndarray, origin, direction):
     ok = L.oracle_grid_hit(C.byref(scene.c), pc.ctypes.data, o.ctypes.data, d.ctypes.data, point.ctypes.data, normal.ctypes.data,
                            C.byref(t), C.byref(idx), C.byref(c))
     return bool(ok), point, normal, float(t.value), int(idx.value), c.as_dict()
+
+
+def grid_hit_raw(scene: OracleScene, pc: np.ndarray, origin, direction, ignore_type_material: int = 3, internal_reflection: float = 1.0):
+    """GridHit (comp:271) for a ray used as given (direction NOT normalised).  Returns (hit, point, normal, t, material_index)."""
+    L = lib()
+    o = np.asarray(origin, dtype=np.float32)
+    d = np.asarray(direction, dtype=np.float32)
+    point = np.zeros(3, dtype=np.float32)
+    normal = np.zeros(3, dtype=np.float32)
+    t = C.c_float()
+    idx = C.c_uint32()
+    c = Counters()
+    ok = L.oracle_grid_hit_raw(C.byref(scene.c), pc.ctypes.data, o.ctypes.data, d.ctypes.data, int(ignore_type_material),
+                               float(internal_reflection), point.ctypes.data, normal.ctypes.data, C.byref(t), C.byref(idx), C.byref(c))
+    return bool(ok), point, normal, np.float32(t.value), int(idx.value)
 
 
 def algorithmic_bytes(counters: dict, pixels: int) -> int:

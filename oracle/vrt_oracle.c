@@ -582,3 +582,24 @@ int oracle_grid_hit(const oracle_scene *scene, const oracle_push *pc, const floa
     *out_t = hit.t; *out_index = hit.index;
     return ok;
 }
+
+/* The same probe with the ray given as is (no CreateRay: the direction is used unnormalised, and the two
+ * fields of comp:427's ignore test are the caller's).  For the cross-check against the independent literal
+ * restatement in tests/literal_port.py. */
+int oracle_grid_hit_raw(const oracle_scene *scene, const oracle_push *pc, const float origin[3], const float dir[3],
+                        uint32_t ignore_type_material, float internal_reflection, float out_point[3], float out_normal[3],
+                        float *out_t, uint32_t *out_index, oracle_counters *counters) {
+    Env e = {scene, pc, counters};
+    Ray r;
+    r.origin = V3(origin[0], origin[1], origin[2]);
+    r.direction = V3(dir[0], dir[1], dir[2]);
+    r.internal_reflection = internal_reflection;
+    r.ignore_type_material = ignore_type_material;
+    HitRecord hit; memset(&hit, 0, sizeof hit);
+    v3 hmin = V3(0, 0, 0);
+    const int ok = GridHit(&e, &r, 0.00001f, INFINITY, &hmin, &hit);
+    out_point[0] = hit.point.x; out_point[1] = hit.point.y; out_point[2] = hit.point.z;
+    out_normal[0] = hit.normal.x; out_normal[1] = hit.normal.y; out_normal[2] = hit.normal.z;
+    *out_t = hit.t; *out_index = hit.index;
+    return ok;
+}
