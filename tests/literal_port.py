@@ -200,3 +200,52 @@ def grid_hit(sc: Scene, origin, direction, ignore_type=3, internal_reflection=1.
                 return True, hit
         t_value, hit["normal"] = _dda_step(side, delta, step, pos, sc.scale, normal_axis)
     return False, hit
+
+
+# ---- one pixel of a deterministic frame (samples_per_pixel 1, device max_bounce <= 1, sun radius 0) -----------------
+# main :153-178, CameraGetRay :474-477, CreateRay/CreateShadowRay :180-190, BackgroundColor :197-201, RayColor :203-265.
+# With one sample the jitter is hash12(0) = 0; with sun radius 0 RandVec3 is the zero vector; with max_bounce <= 1 the
+# scatter functions' only products (the next ray, the continue flag) are never read.  normalize(v) = v * (1 / sqrt(dot))
+# with dot as the fma chain z*z + (y*y + x*x): the contract of DESIGN.md §3.
+
+def normalize(v):
+    d = fma(v[2], v[2], fma(v[1], v[1], v[0] * v[0]))
+    inv = f32(1.0) / f32(np.sqrt(d))
+    return [c * inv for c in v]
+
+
+def pixel(sc: Scene, cam: dict, sun: dict, px: int, py: int):
+    """cam: image_width, image_height, horizontal, vertical, lower_left_corner, origin (lists of float32), max_bounce;
+    sun: position, enabled, color.  Returns (rgb float32 list, rgba8 list)."""
+    u = f32(px) / f32(cam["image_width"] - 1)
+    v = f32(py) / f32(cam["image_height"] - 1)
+    ray_dir = [fma(cam["horizontal"][i], u, cam["lower_left_corner"][i]) + fma(v, cam["vertical"][i], -cam["origin"][i]) for i in range(3)]
+    origin, direction = cam["origin"], normalize(ray_dir)
+    sun_on = sun["enabled"] > 0
+    color = [f32(0.0)] * 3
+    loop_count = 0
+    if cam["max_bounce"] > 0:
+        ok, hit = grid_hit(sc, origin, direction, 3, 1.0)
+        if ok:
+            loop_count = 1
+            m = sc.materials[hit["index"]]
+            attenuation = [f32(m["albedo_r"]), f32(m["albedo_g"]), f32(m["albedo_b"])]
+            if int(m["type"]) > 2:
+                loop_count = 0
+            if sun_on:
+                shadow_dir = normalize([f32(sun["position"][i]) - hit["point"][i] for i in range(3)])
+                shadowed, _ = grid_hit(sc, hit["point"], shadow_dir, 3, 1.0)
+                if not shadowed:
+                    color = [color[i] + attenuation[i] * f32(sun["color"][i]) for i in range(3)]
+            else:
+                color = [color[i] + attenuation[i] for i in range(3)]
+    if loop_count == 0:
+        t = f32(0.5) * (direction[1] + f32(1.0))
+        bg = [fma(f32(1.0) - t, f32(1.0), t * c) for c in (f32(0.5), f32(0.7), f32(1.0))]
+        k = [f32(c) for c in sun["color"]] if sun_on else [f32(1.0)] * 3
+        color = [color[i] + bg[i] * k[i] for i in range(3)]
+    color = [c / (c + f32(1.0)) for c in color]
+    color = [f32(np.sqrt(c / f32(1.0))) for c in color]
+    # RGBA8 UNORM store: round-to-nearest-even of clamp(c, 0, 1) * 255 in float32 (NaN -> 0), SURVEY.md §8 quirk 10
+    rgba8 = [int(np.rint(f32(min(c, f32(1.0))) * f32(255.0))) if c > 0 else 0 for c in color] + [255]
+    return color, rgba8

@@ -81,3 +81,30 @@ def test_c_oracle_equals_literal_restatement(case):
             assert np.array_equal(normal_c, np.array(rec["normal"], dtype=np.float32)), f"ray {k}: normal"
             assert index_c == rec["index"], f"ray {k}: material index"
     assert hits > 40
+
+
+@pytest.mark.parametrize("sun_on", [True, False])
+def test_c_oracle_pixels_equal_literal_restatement(sun_on):
+    """Whole deterministic pixels (ray generation, primary + shadow traversal, background, tone-map, gamma, UNORM8)."""
+    from zig_vulkan_amd import CameraConfig, SunConfig
+    grid, mats, rng = list(_scenes())[0]
+    mats[9] = (7, 0.9, 0.2, 0.9, 1.0)  # an unknown material type: background is added on top (comp:235-238)
+    scene = oracle_scene_from_grid(grid, mats)
+    w, h = 48, 30
+    cam = Camera(75.0, w, h, CameraConfig(samples_per_pixel=1, max_bounce=0))
+    cam.look_at((2.6, -2.4, 3.4), (0.0, 0.2, 0.0))
+    sun = Sun(SunConfig(enabled=sun_on, radius=0.0))
+    pc = push_for(cam, sun)
+    d, sd = cam.d_camera, sun.device_data
+    cam_fields = {"image_width": d.image_width, "image_height": d.image_height, "max_bounce": d.max_bounce,
+                  "horizontal": [np.float32(x) for x in d.horizontal[:3]], "vertical": [np.float32(x) for x in d.vertical[:3]],
+                  "lower_left_corner": [np.float32(x) for x in d.lower_left_corner[:3]], "origin": [np.float32(x) for x in d.origin[:3]]}
+    sun_fields = {"position": list(sd.position[:3]), "enabled": sd.enabled, "color": list(sd.color[:3])}
+    lit = _literal_scene(grid, mats)
+    xy = np.stack([rng.integers(0, w, 160), rng.integers(0, h, 160)], axis=-1).astype(np.int32)
+    fo, uo, co = O.render_pixels(scene, pc, xy)
+    for k, (x, y) in enumerate(xy):
+        rgb, rgba8 = LP.pixel(lit, cam_fields, sun_fields, int(x), int(y))
+        assert np.array_equal(np.array(rgb, dtype=np.float32).view(np.uint32), fo[k, :3].view(np.uint32)), f"pixel {x},{y}: {rgb} vs {fo[k]}"
+        assert rgba8 == [int(c) for c in uo[k]], f"pixel {x},{y}"
+    assert co["hits"] > 20
