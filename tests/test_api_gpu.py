@@ -112,3 +112,15 @@ def test_device_to_device_upload_and_caller_stream():
     rt.deinit()
     _, uo, _ = O.render(oracle_scene_from_grid(grid), pc)
     assert np.array_equal(u, uo)
+
+
+def test_hardware_assumptions_of_the_hand_written_loops():
+    """tools/isa_probe (built by __graft_entry__.build): a VOP3 carry-out under a partial EXEC mask writes 0 for the
+    inactive lanes, and an `idxen` buffer load beyond num_records returns 0 — what the asm walk loops rely on."""
+    import os
+    import subprocess
+    probe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "isa_probe")
+    if not os.path.exists(probe):
+        pytest.skip("tools/isa_probe not built (run __graft_entry__.build())")
+    out = subprocess.run([probe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "ISA_PROBE_OK" in out.stdout, out.stdout + out.stderr
