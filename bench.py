@@ -103,8 +103,8 @@ def hbm_traffic_from_profile(brick_dimension: int):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default=None)
     ap.add_argument("--variant", type=lambda x: int(x, 0), default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
