@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 30 --warmup 3 --no-cpu-baseline $*"
+BENCH="python $ROOT/bench.py --steps 300 --warmup 30 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 # PMC passes, each in its own run, kernel-trace only
 i=0
