@@ -113,7 +113,7 @@ def main() -> None:
     ap.add_argument("--dist", choices=["native", "torch"], default="native",
                     help="N>1 frame gather: native = RCCL send/recv inside libvrt_hip.so (pipelined, 4 frames in flight); "
                          "torch = torch.distributed.gather from Python (fallback)")
-    ap.add_argument("--dist-frames", type=int, default=4, help="frames in flight per rank of the native multi-GPU pipeline")
+    ap.add_argument("--dist-frames", type=int, default=8, help="frames in flight per rank of the native multi-GPU pipeline")
     ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")
     args = ap.parse_args()
 
