@@ -196,6 +196,9 @@ __global__ void k_chain_load(const State *in, float *out, unsigned long long *cy
 
 // The shipped trip (vrt_trace.hip VRT_TRIP, brick level) on an all-empty bitmap, four trips per back edge.
 typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+#define TSFULL(TS, MX, MY) "v_cndmask_b32_e64 %[" TS "], %[sdz], %[sdy], %[" MY "]\n\t" "v_cndmask_b32_e64 %[" TS "], %[" TS "], %[sdx], %[" MX "]\n\t"
+#define TSNONE(TS, MX, MY)
+#define TSPART TSFULL
 #define TRIP(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN)                      \
     "v_cmp_lt_f32_e64 %[" MX "], %[sdx], %[sdy]\n\t"                      \
     "v_cmp_lt_f32_e64 %[" MXY "], %[sdx], %[sdz]\n\t"                     \
@@ -206,8 +209,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u4;
     "s_andn2_b64 %[" MY "], %[" MY "], %[" MX "]\n\t"                     \
     "s_and_b64 %[" MX "], %[" MX "], %[" MXY "]\n\t"                      \
     "s_or_b64 %[" MXY "], %[" MX "], %[" MY "]\n\t"                       \
-    "v_cndmask_b32_e64 %[" TS "], %[sdz], %[sdy], %[" MY "]\n\t"          \
-    "v_cndmask_b32_e64 %[" TS "], %[" TS "], %[sdx], %[" MX "]\n\t"       \
+    TSPART(TS, MX, MY)                                                    \
     "v_cndmask_b32_e64 %[sdx], %[sdx], %[t0], %[" MX "]\n\t"              \
     "v_cndmask_b32_e64 %[sdy], %[sdy], %[t1], %[" MY "]\n\t"              \
     "v_cndmask_b32_e64 %[sdz], %[t2], %[sdz], %[" MXY "]\n\t"             \
@@ -282,6 +284,17 @@ KFULL(k_full_nobranch)
 #undef EXECPART
 #define EXECPART
 KFULL(k_full_bare)
+#undef LOADPART
+#undef EXECPART
+#undef BRANCHPART
+#define LOADPART(WORDN) "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t" "s_waitcnt vmcnt(1)\n\t"
+#define EXECPART "s_andn2_b64 exec, exec, %[ex]\n\t"
+#define BRANCHPART "s_cbranch_vccnz 9f\n\t"
+#undef TSPART
+#define TSPART TSNONE
+KFULL(k_full_nots)
+#undef TSPART
+#define TSPART TSFULL
 
 typedef void (*kern_t)(const State *, float *, unsigned long long *, int);
 
@@ -362,7 +375,7 @@ int main() {
         const char *names[4] = {"1 wave alone", "4 waves/SIMD", "6 waves/SIMD", "8 waves/SIMD"};
         typedef void (*kf_t)(const State *, float *, unsigned long long *, int, const uint32_t *, uint32_t);
         struct { const char *name; kf_t k; } fam[] = {{"shipped brick-level trip (29 instr)", k_full}, {"  without load+waitcnt", k_full_noload}, {"  without exec update", k_full_noexec},
-                                                       {"  without vccnz branch", k_full_nobranch}, {"  without load, exec update, branch", k_full_bare}};
+                                                       {"  without vccnz branch", k_full_nobranch}, {"  without load, exec update, branch", k_full_bare}, {"  full trip without the two t-select instructions", k_full_nots}};
         for (auto &f : fam)
         for (int m = 0; m < 4; m += (m == 0 ? 2 : 1)) {
             f.k<<<cfgs[m][0], cfgs[m][1]>>>(d_in, d_out, d_cyc, 16, d_bm, nwords); hipDeviceSynchronize();
