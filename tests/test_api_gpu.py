@@ -124,3 +124,29 @@ def test_hardware_assumptions_of_the_hand_written_loops():
         pytest.skip("tools/isa_probe not built (run __graft_entry__.build())")
     out = subprocess.run([probe], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "ISA_PROBE_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_compiled_host_on_the_c_abi_renders_the_same_frame(tmp_path):
+    """examples/render_ppm (C++, links libvrt_hip.so only — no Python, no PyTorch in that process) builds the terrain
+    scene, renders view V2 and prints a digest of the RGBA8 frame; the Python host must produce the same bytes."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "render_ppm")
+    if not os.path.exists(exe):
+        pytest.skip("examples/render_ppm not built (run __graft_entry__.build())")
+    out = subprocess.run([exe, str(tmp_path / "frame.ppm"), "640", "360", "128", "8"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    digest = out.stdout.strip().splitlines()[-1]
+    w = W.Workload("t", 640, 360, 128, 8, 1, 0, True, 5.0)
+    grid = W.build_grid(w)
+    rt = W.make_renderer(w, grid)
+    W.set_view(rt, "V2")
+    rt.draw()
+    frame = rt.read_rgba8()
+    rt.deinit()
+    h = 1469598103934665603
+    for v in frame.tobytes():
+        h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert digest == f"{h:016x}"
+    ppm = (tmp_path / "frame.ppm").read_bytes()
+    assert ppm.startswith(b"P6\n640 360\n255\n") and len(ppm) == len(b"P6\n640 360\n255\n") + 640 * 360 * 3
