@@ -376,3 +376,15 @@ def test_sparse_allocation_fewer_slots_than_cells():
     f, u, c, fo, uo, co = _parity_for(grid, w, lambda rt: W.set_view(rt, "V2"))
     _compare(f, u, c, fo, uo, co)
     assert co["hits"] > 0
+
+
+def test_random_scenes_fuzz_slice():
+    """A fixed slice of tools/fuzz_parity.py (60 random scenes / cameras / ray budgets, seed 5): whole frames of the product
+    kernel against the oracle, bit for bit."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py")
+    spec = importlib.util.spec_from_file_location("fuzz_parity", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.fuzz(60, 5, verbose=False) == 0

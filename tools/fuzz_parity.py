@@ -10,54 +10,60 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from zig_vulkan_amd import BrickGrid, Config, CameraConfig, SunConfig, VoxelRT, default_materials
 from helpers import O, oracle_scene_from_grid
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-big = len(sys.argv) > 3 and sys.argv[3] == "big"  # larger grids and frames, LDS variant mixed in
-bad = 0
-for case in range(cases):
-    b = int(rng.choice([4, 8]))
-    dims = [int(rng.integers(1, 25 if big else 9)) for _ in range(3)]
-    scale = float(rng.choice([0.5, 1.0, 2.0, 0.3, 1.7, 4.0]))
-    min_point = [float(-0.5 * d * scale + rng.normal() * 0.3) for d in dims]
-    cells = dims[0] * dims[1] * dims[2]
-    grid = BrickGrid(*dims, min_point=min_point, scale=scale, brick_dimension=b)
-    n = int(rng.integers(1, max(2, int(0.2 * cells * b ** 3))))
-    xyz = np.stack([rng.integers(0, b * d, n) for d in dims], axis=-1)
-    if rng.random() < 0.5:  # clumps: whole columns
-        xyz[:, 1] = rng.integers(0, b * dims[1], n) // 2 * 2
-    grid.insert_many(xyz, rng.integers(0, 14, n))
-    mats = default_materials(256)
-    mats[8] = (2, 0.9, 0.95, 1.0, 1.52)
-    mats[9] = (7, 0.9, 0.2, 0.9, 1.0)
-    mats[10] = (3, 0.3, 0.9, 0.3, 1.0)
-    mats[11] = (1, 0.8, 0.8, 0.8, 0.05)
-    mats[12] = (2, 0.9, 0.9, 1.0, 1.0)
-    mats[13] = (1, 0.7, 0.6, 0.5, 0.6)
-    w, h = int(rng.integers(1, 400 if big else 90)), int(rng.integers(1, 260 if big else 70))
-    spp, bounce = int(rng.integers(1, 4)), int(rng.integers(0, 3))
-    sun_on, radius = bool(rng.random() < 0.7), float(rng.choice([0.0, 5.0, 40.0]))
-    rt = VoxelRT(grid, Config(internal_resolution_width=w, internal_resolution_height=h, camera=CameraConfig(samples_per_pixel=spp, max_bounce=bounce),
-                              sun=SunConfig(enabled=sun_on, radius=radius), want_float_output=True,
-                              kernel_variant=int(rng.choice([0, 0, 6, 1])) if big else 0))
-    rt.push_materials(mats)
-    size = np.array(dims) * scale
-    centre = np.array(min_point) + 0.5 * size
-    origin = centre + (rng.random(3) - 0.5) * size * (3.0 if rng.random() < 0.7 else 0.9)
-    rt.camera.look_at(origin.tolist(), (centre + (rng.random(3) - 0.5) * size * 0.5).tolist())
-    rt.draw()
-    f, u = rt.read_rgba32f(), rt.read_rgba8()
-    pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
-    name = rt.kernel_name()
-    rt.deinit()
-    fo, uo, co = O.render(oracle_scene_from_grid(grid, mats), pc)
-    # bit for bit, except that any NaN equals any NaN (a 1-pixel-wide image divides 0 by 0 in comp:168-170; the sign and
-    # payload of the resulting NaN differ between x86 and gfx950, its RGBA8 value 0 does not)
-    both_nan = np.isnan(f) & np.isnan(fo)
-    ok = np.array_equal(f.view(np.uint32)[~both_nan], fo.view(np.uint32)[~both_nan]) and np.array_equal(u, uo)
-    if not ok:
-        bad += 1
-        print(f"case {case}: MISMATCH  b={b} dims={dims} scale={scale} {w}x{h} spp={spp} bounce={bounce} sun={sun_on}/{radius}  {np.count_nonzero(f != fo)} floats differ")
-    elif case % 10 == 0:
-        print(f"case {case}: ok  b={b} dims={dims} scale={scale} {w}x{h} spp={spp} bounce={bounce} sun={sun_on}/{radius} rays={co['rays']} hits={co['hits']}")
-print(f"{cases} cases, {bad} mismatching")
-sys.exit(1 if bad else 0)
+def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True) -> int:
+    """Returns the number of mismatching cases."""
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for case in range(cases):
+        b = int(rng.choice([4, 8]))
+        dims = [int(rng.integers(1, 25 if big else 9)) for _ in range(3)]
+        scale = float(rng.choice([0.5, 1.0, 2.0, 0.3, 1.7, 4.0]))
+        min_point = [float(-0.5 * d * scale + rng.normal() * 0.3) for d in dims]
+        cells = dims[0] * dims[1] * dims[2]
+        grid = BrickGrid(*dims, min_point=min_point, scale=scale, brick_dimension=b)
+        n = int(rng.integers(1, max(2, int(0.2 * cells * b ** 3))))
+        xyz = np.stack([rng.integers(0, b * d, n) for d in dims], axis=-1)
+        if rng.random() < 0.5:  # clumps: whole columns
+            xyz[:, 1] = rng.integers(0, b * dims[1], n) // 2 * 2
+        grid.insert_many(xyz, rng.integers(0, 14, n))
+        mats = default_materials(256)
+        mats[8] = (2, 0.9, 0.95, 1.0, 1.52)
+        mats[9] = (7, 0.9, 0.2, 0.9, 1.0)
+        mats[10] = (3, 0.3, 0.9, 0.3, 1.0)
+        mats[11] = (1, 0.8, 0.8, 0.8, 0.05)
+        mats[12] = (2, 0.9, 0.9, 1.0, 1.0)
+        mats[13] = (1, 0.7, 0.6, 0.5, 0.6)
+        w, h = int(rng.integers(1, 400 if big else 90)), int(rng.integers(1, 260 if big else 70))
+        spp, bounce = int(rng.integers(1, 4)), int(rng.integers(0, 3))
+        sun_on, radius = bool(rng.random() < 0.7), float(rng.choice([0.0, 5.0, 40.0]))
+        rt = VoxelRT(grid, Config(internal_resolution_width=w, internal_resolution_height=h, camera=CameraConfig(samples_per_pixel=spp, max_bounce=bounce),
+                                  sun=SunConfig(enabled=sun_on, radius=radius), want_float_output=True,
+                                  kernel_variant=int(rng.choice([0, 0, 6, 1])) if big else 0))
+        rt.push_materials(mats)
+        size = np.array(dims) * scale
+        centre = np.array(min_point) + 0.5 * size
+        origin = centre + (rng.random(3) - 0.5) * size * (3.0 if rng.random() < 0.7 else 0.9)
+        rt.camera.look_at(origin.tolist(), (centre + (rng.random(3) - 0.5) * size * 0.5).tolist())
+        rt.draw()
+        f, u = rt.read_rgba32f(), rt.read_rgba8()
+        pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+        name = rt.kernel_name()
+        rt.deinit()
+        fo, uo, co = O.render(oracle_scene_from_grid(grid, mats), pc)
+        # bit for bit, except that any NaN equals any NaN (a 1-pixel-wide image divides 0 by 0 in comp:168-170; the sign and
+        # payload of the resulting NaN differ between x86 and gfx950, its RGBA8 value 0 does not)
+        both_nan = np.isnan(f) & np.isnan(fo)
+        ok = np.array_equal(f.view(np.uint32)[~both_nan], fo.view(np.uint32)[~both_nan]) and np.array_equal(u, uo)
+        if not ok:
+            bad += 1
+            print(f"case {case}: MISMATCH  b={b} dims={dims} scale={scale} {w}x{h} spp={spp} bounce={bounce} sun={sun_on}/{radius}  {np.count_nonzero(f != fo)} floats differ")
+        elif verbose and case % 10 == 0:
+            print(f"case {case}: ok  b={b} dims={dims} scale={scale} {w}x{h} spp={spp} bounce={bounce} sun={sun_on}/{radius} rays={co['rays']} hits={co['hits']}")
+    if verbose:
+        print(f"{cases} cases, {bad} mismatching")
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if fuzz(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 7,
+                       len(sys.argv) > 3 and sys.argv[3] == "big") else 0)
