@@ -147,8 +147,8 @@ VRT_DI void dda_step(Walk &w, const f3 &ray_delta, float scale, int &axis, uint3
 // whole step to arrive (s_waitcnt vmcnt(1)).  The steps-left counters are decremented with the crossed-
 // axis lane mask as borrow-in; their borrow-OUT is the box-exit test (a counter at 0 is decremented exactly
 // when the lane leaves through that face), so leaving lanes are dropped from EXEC with scalar work only.  The
-// loop is unrolled twice with the roles of two register sets swapped (A/B: crossed distance and crossed-axis
-// masks of the last and of the previous step), so nothing is copied between trips.  It runs until some lane
+// loop is unrolled (four trips per back edge) with the roles of two register sets alternating (A/B: crossed distance
+// and crossed-axis masks of the last and of the previous step), so nothing is copied between trips.  It runs until some lane
 // meets an occupied cell or every lane has left the grid; the caller walks the bricks (rare: about once per
 // wave per ray) and calls again.  Status words come through a stride-4 buffer resource: a lane outside the grid
 // carries an arbitrary index and reads 0 instead of faulting (tools/isa_probe.hip checks this and the
