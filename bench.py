@@ -82,9 +82,10 @@ def hbm_traffic_from_profile(brick_dimension: int):
     """HBM bytes per launch of the traversal kernel from the committed rocprofv3 PMC passes of this same
     command (profiles/*_pmc.json, written by tools/summarize_prof.py; bench.py cannot run rocprofv3 on
     itself).  FETCH_SIZE and WRITE_SIZE are in KiB, collected in separate passes.  WRITE_SIZE equals the
-    RGBA8 frame exactly (8100 KiB at 1080p); FETCH_SIZE on gfx950 reads half of a wide coalesced stream
-    (MI355X_MICROARCH.md) and is uncalibrated for this dword-gather pattern, so both the raw and the
-    doubled fetch are given and `traffic` uses the doubled (upper) figure."""
+    RGBA8 frame exactly (8100 KiB at 1080p); FETCH_SIZE on gfx950 reports half of the bytes fetched
+    (MI355X_MICROARCH.md) — for scattered dword loads as well: tools/ubench/fetch_calib.hip reads a 2 GiB buffer
+    with one dword per 128-byte line and gets 1.00 GiB, memory being fetched in whole lines and tallied at 64 bytes
+    per line — so `traffic` uses the doubled figure (the raw one is quoted beside it)."""
     import glob
     # the shipped kernel's passes are r<round>_final_pmc.json (latest round last); other *_pmc.json files are earlier kernels
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_pmc.json")))
