@@ -1,0 +1,65 @@
+"""The multi-rank branch of the native frame pipeline (vrt_dist_frame: kernel -> grouped recv on rank 0 / send
+elsewhere -> un-swizzle, several frames in flight) with R ranks as R contexts of this process on the one GPU of the
+box, bound to tests/fake_rccl/libfake_rccl.so instead of RCCL (which refuses two ranks on one device).  Everything
+of the pipeline except RCCL itself runs: packed tile-major shards of every rank, slot streams and events, frame
+ordering across ranks, the gathered layout, the un-swizzle.  Each rank is driven from its own thread, like a process."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from zig_vulkan_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+FAKE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "libfake_rccl.so")
+
+
+@pytest.mark.parametrize("world,frames_in_flight", [(2, 2), (3, 4), (8, 8), (8, 1)])
+def test_native_pipeline_with_many_ranks_on_one_gpu(world, frames_in_flight):
+    if not os.path.exists(FAKE):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
+    w = W.Workload("t", 330, 210, 64, 4, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    views = ["V0", "V1", "V2", "V1", "V2", "V0", "V0", "V2", "V1", "V1", "V0"]
+    plain = W.make_renderer(w, grid)
+    ref = {}
+    for v in set(views):
+        W.set_view(plain, v)
+        plain.draw()
+        ref[v] = plain.read_rgba8().copy()
+    plain.deinit()
+
+    uid = b"fake-rccl-test" + bytes([world, frames_in_flight]) + os.urandom(16) + bytes(128 - 32)
+    ranks = [W.make_renderer(w, grid, shard_rank=r, shard_count=world) for r in range(world)]
+    for r, rt in enumerate(ranks):
+        rt.dist_init(uid, r, world, frames_in_flight=frames_in_flight, rccl_path=FAKE)
+    got, errors = [], []
+
+    def drive(r):
+        try:
+            rt = ranks[r]
+            for i, v in enumerate(views):
+                W.set_view(rt, v)
+                rt.dist_frame()
+                if r == 0 and i % 3 == 2:  # read some frames mid-stream, the rest stay in flight
+                    got.append((v, rt.dist_read_frame().copy()))
+            rt.dist_wait()
+            if r == 0:
+                got.append((views[-1], rt.dist_read_frame().copy()))
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    assert not errors, errors
+    for rt in ranks:
+        rt.deinit()
+    assert len(got) == len(views) // 3 + 1
+    for v, frame in got:
+        assert np.array_equal(frame, ref[v]), f"assembled frame of view {v} differs from the single-context frame"
