@@ -114,7 +114,9 @@ def main() -> None:
     ap.add_argument("--dist", choices=["native", "torch"], default="native",
                     help="N>1 frame gather: native = RCCL send/recv inside libvrt_hip.so (pipelined, 4 frames in flight); "
                          "torch = torch.distributed.gather from Python (fallback)")
-    ap.add_argument("--dist-frames", type=int, default=8, help="frames in flight per rank of the native multi-GPU pipeline")
+    ap.add_argument("--dist-frames", type=int, default=4, help="launches in flight per rank of the native multi-GPU pipeline")
+    ap.add_argument("--dist-batch", type=int, default=8,
+                    help="frames traced by one launch and gathered by one collective when world > 1 (a rank owns 1/world of the tiles)")
     ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")
     args = ap.parse_args()
 
@@ -180,7 +182,7 @@ def main() -> None:
             if dist is not None and world > 1:
                 dist.broadcast_object_list(uid, src=0)
             rt = W.make_renderer(w, grid, device_id=local_rank, shard_rank=rank, shard_count=world, kernel_variant=args.variant)
-            rt.dist_init(uid[0], rank, world, args.dist_frames)
+            rt.dist_init(uid[0], rank, world, args.dist_frames, frames_per_launch=(args.dist_batch if world > 1 else 1))
             if world == 1:
                 rt.dist_selftest()
         except Exception as e:  # noqa: BLE001 - any failure means "use the torch path"
@@ -302,8 +304,8 @@ def main() -> None:
                        "rays": "primary + shadow" if w.sun_enabled else "primary", "spp": w.spp, "max_bounce": w.max_bounce,
                        "views": VIEW_ORDER, "rays_per_frame": {v: per_view[v]["rays"] for v in VIEW_ORDER},
                        "counters_per_frame": {v: per_view[v]["counters"] for v in VIEW_ORDER},
-                       "parallelism": (f"image tiles 16x16 interleaved over {world} GPU(s), 1 RCCL gather/frame to rank 0, "
-                                       + (f"native pipeline with {args.dist_frames} frames in flight" if native else "torch.distributed gather, frame f overlaps kernel of f+1"))
+                       "parallelism": (f"image tiles 16x16 interleaved over {world} GPU(s), 1 RCCL gather per launch to rank 0, "
+                                       + (f"native pipeline, {args.dist_batch if world > 1 else 1} frame(s) per launch, {args.dist_frames} launches in flight" if native else "torch.distributed gather, frame f overlaps kernel of f+1"))
                        if sharded else f"1 GPU, whole frame, {args.frames_in_flight} frame(s) in flight"},
             "roofline": roofline,
         }

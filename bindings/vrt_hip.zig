@@ -80,6 +80,7 @@ pub extern fn vrt_device_denoised_rgba8(ctx: *Ctx) ?*anyopaque;
 // multi-GPU frame pipeline (one process per GPU; rank 0 owns the assembled frame)
 pub extern fn vrt_dist_unique_id(rccl_path: [*:0]const u8, out_id128: *[128]u8) c_int;
 pub extern fn vrt_dist_init(ctx: *Ctx, rccl_path: [*:0]const u8, id128: *const [128]u8, rank: c_int, world: c_int, frames_in_flight: u32) c_int;
+pub extern fn vrt_dist_init_batched(ctx: *Ctx, rccl_path: [*:0]const u8, id128: *const [128]u8, rank: c_int, world: c_int, frames_in_flight: u32, frames_per_launch: u32) c_int;
 pub extern fn vrt_dist_frame(ctx: *Ctx, camera: *const anyopaque, sun: *const anyopaque) c_int;
 pub extern fn vrt_dist_wait(ctx: *Ctx) c_int;
 pub extern fn vrt_dist_read_frame(ctx: *Ctx, dst: *anyopaque, nbytes: u64) c_int;

@@ -212,9 +212,18 @@ int vrt_assemble_frame(vrt_ctx *ctx, const void *gathered, void *dst_frame, uint
  * Rank 0 makes the 128-byte id with vrt_dist_unique_id and the host distributes it to every rank. */
 int vrt_dist_unique_id(const char *rccl_path, void *out_id128);
 int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight);
+/* The same with frames_per_launch (1..8) consecutive frames traced by ONE kernel launch and gathered by ONE collective:
+ * a rank owns only 1/world of the tiles — too few waves to fill a GPU, and a launch is never shorter than its
+ * longest wave — so single-frame launches leave most of the machine idle.  vrt_dist_frame then
+ * queues; a full queue, vrt_dist_wait or a scene upload launches what is queued — events that every rank sees at the same
+ * frame, as every launch carries a collective.
+ * frames_in_flight counts launches. */
+int vrt_dist_init_batched(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight,
+                          uint32_t frames_per_launch);
 int vrt_dist_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun);
 int vrt_dist_wait(vrt_ctx *ctx);
-/* rank 0: the most recently submitted frame, row-major RGBA8 (waits for it) */
+/* rank 0: the most recently submitted frame, row-major RGBA8 (waits for it).  With frames_per_launch > 1 the queue must
+ * be empty (full batch just launched, or after vrt_dist_wait): a launch carries a collective, every rank launches together. */
 int vrt_dist_read_frame(vrt_ctx *ctx, void *dst, uint64_t nbytes);
 /* ncclSend + ncclRecv of one shard to this rank itself: checks the RCCL binding on a single GPU */
 int vrt_dist_selftest(vrt_ctx *ctx);

@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 FAKE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "libfake_rccl.so")
 
 
-@pytest.mark.parametrize("world,frames_in_flight", [(2, 2), (3, 4), (8, 8), (8, 1)])
-def test_native_pipeline_with_many_ranks_on_one_gpu(world, frames_in_flight):
+@pytest.mark.parametrize("world,frames_in_flight,frames_per_launch", [(2, 2, 1), (3, 4, 1), (8, 8, 1), (8, 1, 1), (2, 2, 3), (8, 3, 8), (5, 2, 4), (8, 1, 2)])
+def test_native_pipeline_with_many_ranks_on_one_gpu(world, frames_in_flight, frames_per_launch):
     if not os.path.exists(FAKE):
         pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
     w = W.Workload("t", 330, 210, 64, 4, 1, 0, True, 0.0)
@@ -32,9 +32,10 @@ def test_native_pipeline_with_many_ranks_on_one_gpu(world, frames_in_flight):
     plain.deinit()
 
     uid = b"fake-rccl-test" + bytes([world, frames_in_flight]) + os.urandom(16) + bytes(128 - 32)
+    reads = [i for i in range(len(views)) if (i + 1) % frames_per_launch == 0 and i % 3 == 2]  # only where the queue has just been launched
     ranks = [W.make_renderer(w, grid, shard_rank=r, shard_count=world) for r in range(world)]
     for r, rt in enumerate(ranks):
-        rt.dist_init(uid, r, world, frames_in_flight=frames_in_flight, rccl_path=FAKE)
+        rt.dist_init(uid, r, world, frames_in_flight=frames_in_flight, rccl_path=FAKE, frames_per_launch=frames_per_launch)
     got, errors = [], []
 
     def drive(r):
@@ -43,7 +44,7 @@ def test_native_pipeline_with_many_ranks_on_one_gpu(world, frames_in_flight):
             for i, v in enumerate(views):
                 W.set_view(rt, v)
                 rt.dist_frame()
-                if r == 0 and i % 3 == 2:  # read some frames mid-stream, the rest stay in flight
+                if r == 0 and i in reads:  # read some frames mid-stream, the rest stay in flight
                     got.append((v, rt.dist_read_frame().copy()))
             rt.dist_wait()
             if r == 0:
@@ -60,6 +61,6 @@ def test_native_pipeline_with_many_ranks_on_one_gpu(world, frames_in_flight):
     assert not errors, errors
     for rt in ranks:
         rt.deinit()
-    assert len(got) == len(views) // 3 + 1
+    assert len(got) == len(reads) + 1
     for v, frame in got:
         assert np.array_equal(frame, ref[v]), f"assembled frame of view {v} differs from the single-context frame"

@@ -159,6 +159,7 @@ SIGNATURES = {
     "vrt_assemble_frame": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_uint32]),
     "vrt_dist_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),
     "vrt_dist_init": (C.c_int, [_ctx, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32]),
+    "vrt_dist_init_batched": (C.c_int, [_ctx, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32]),
     "vrt_dist_frame": (C.c_int, [_ctx, _P(CameraDevice), _P(SunDevice)]),
     "vrt_dist_wait": (C.c_int, [_ctx]),
     "vrt_dist_read_frame": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),

@@ -24,7 +24,7 @@ using KernelFn = void (*)(const TraceParams);
 KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, int shade);
 uint32_t resolve_variant(uint32_t variant);
 size_t trace_lds_bytes(const TraceParams &p, uint32_t variant);
-hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream, uint32_t frames = 1);
 hipError_t launch_schedule(uint32_t *cost, uint32_t *order, uint32_t n, hipStream_t stream);
 hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
@@ -78,14 +78,16 @@ struct RcclApi {
 
 constexpr uint32_t kMaxDistSlots = 8;
 
-// One frame in flight of the multi-GPU pipeline: its stream carries kernel -> gather -> un-swizzle.
+// One launch in flight of the multi-GPU pipeline: its stream carries kernel -> gather -> un-swizzle for a batch of up to
+// `batch` consecutive frames (see Dist).
 struct DistSlot {
     hipStream_t stream = nullptr;
-    uint8_t *shard = nullptr;    // this rank's packed tiles (on rank 0: the first shard of `gathered`)
-    uint8_t *gathered = nullptr; // rank 0: world x shard_bytes, rank-major
-    uint8_t *frame = nullptr;    // rank 0: row-major RGBA8 frame
+    uint8_t *shard = nullptr;    // this rank's packed tiles, frame-major: batch x shard_bytes (on rank 0: region 0 of `gathered`)
+    uint8_t *gathered = nullptr; // rank 0: world x batch x shard_bytes, rank-major then frame-major
+    uint8_t *frame = nullptr;    // rank 0: batch row-major RGBA8 frames
     hipEvent_t done = nullptr;
     uint64_t seen_upload = 0;
+    uint32_t frames = 0;         // frames of the batch this slot holds
     bool used = false;
 };
 
@@ -95,9 +97,18 @@ struct Dist {
     int rank = 0, world = 1;
     uint32_t nslots = 0;
     DistSlot slots[kMaxDistSlots];
-    uint64_t frame_no = 0;
+    uint64_t frame_no = 0;       // batches launched so far (slot = frame_no % nslots)
     int last_slot = -1;
     size_t shard_bytes = 0;
+    // Frames are traced `batch` to a launch (grid.y): a rank owns 1/world of the tiles, too few waves to fill the GPU
+    // and no shorter than the frame's longest wave, so single-frame launches leave most of the machine idle
+    // (tools/shard_streams.py: 19-31 us per 1/8 frame with eight single-frame launches in flight, against 8-18 us for
+    // an eighth of a whole-frame launch).  vrt_dist_frame queues; a full queue, vrt_dist_wait, vrt_dist_read_frame or a
+    // scene upload launches what is queued.
+    uint32_t batch = 1;
+    uint32_t npend = 0;
+    vrt::PushConstants pend[vrt::kMaxBatchFrames];
+    vrt::KernelFn pend_fn = nullptr;
 };
 
 struct vrt_ctx {
@@ -240,7 +251,12 @@ int finish_frame(vrt_ctx *c) {
 
 // Scene writes happen on the primary stream.  With two frames in flight they must not overtake a frame
 // that is still reading the scene on stream_b, and later frames on stream_b must see them.
+int dist_flush(vrt_ctx *ctx);
 int begin_scene_write(vrt_ctx *c) {
+    if (c->dist && c->dist->npend) { // frames queued before this write must see the scene as it was
+        const int rcf = dist_flush(c);
+        if (rcf != VRT_OK) return rcf;
+    }
     if (c->stream_b && c->b_pending) {
         VRT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_b_done, 0));
         c->b_pending = false;
@@ -595,8 +611,8 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
     // command buffer (ComputePipeline.zig:423-436).  Launches are stream-ordered and carry their
     // arguments by value, so frames may queue; vrt_wait / vrt_read_* are the synchronisation points.
     ctx->in_flight = false;
-    ctx->params.pc.cam = *camera;
-    ctx->params.pc.sun = *sun;
+    ctx->params.pcs[0].cam = *camera;
+    ctx->params.pcs[0].sun = *sun;
     const vrt_grid_state &g = ctx->params.grid;
     {
         auto pow2_with_normal_reciprocal = [](float v) {
@@ -860,7 +876,8 @@ int vrt_dist_unique_id(const char *rccl_path, void *out_id128) {
     return VRT_OK;
 }
 
-int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight) {
+int vrt_dist_init_batched(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight,
+                          uint32_t frames_per_launch) {
     if (!ctx || !rccl_path || !id128) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL argument") : VRT_E_INVALID_ARG;
     if (ctx->dist) return fail(ctx, VRT_E_STATE, "vrt_dist_init called twice");
     if (world < 1 || rank < 0 || rank >= world) return fail(ctx, VRT_E_INVALID_ARG, "bad rank / world");
@@ -869,7 +886,9 @@ int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int ra
     if (ctx->stream_b || ctx->cfg.stream || ctx->cfg.external_target_rgba8 || ctx->d_counters)
         return fail(ctx, VRT_E_STATE, "the multi-GPU pipeline owns its streams and targets (no frames_in_flight=2, caller stream/target or counters)");
     if (frames_in_flight == 0) frames_in_flight = 4;
-    if (frames_in_flight > kMaxDistSlots) return fail(ctx, VRT_E_INVALID_ARG, "at most 8 frames in flight");
+    if (frames_in_flight > kMaxDistSlots) return fail(ctx, VRT_E_INVALID_ARG, "at most 8 launches in flight");
+    if (frames_per_launch == 0) frames_per_launch = 1;
+    if (frames_per_launch > (uint32_t)vrt::kMaxBatchFrames) return fail(ctx, VRT_E_INVALID_ARG, "at most 8 frames per launch");
     DeviceGuard dg(ctx->device);
     Dist *d = new (std::nothrow) Dist();
     if (!d) return fail(ctx, VRT_E_OOM, "host allocation failed");
@@ -881,23 +900,25 @@ int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int ra
     d->rank = rank;
     d->world = world;
     d->nslots = frames_in_flight;
+    d->batch = frames_per_launch;
     d->shard_bytes = (size_t)ctx->shard.tiles_per_rank * vrt::kTileW * vrt::kTileH * 4u;
     ctx->dist = d; // from here free_ctx cleans up
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
     VRT_NCCL(ctx, d, d->api.CommInitRank(&d->comm, world, id, rank));
+    const size_t region = d->shard_bytes * d->batch; // one rank's shards of a batch, frame-major
     for (uint32_t i = 0; i < d->nslots; i++) {
         DistSlot &sl = d->slots[i];
         VRT_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
         VRT_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         if (rank == 0) {
-            VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&sl.gathered), d->shard_bytes * (size_t)world));
-            VRT_HIP(ctx, hipMemsetAsync(sl.gathered, 0, d->shard_bytes * (size_t)world, ctx->stream));
-            sl.shard = sl.gathered; // rank 0's own tiles are shard 0 of the gathered buffer: no copy
-            VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&sl.frame), (size_t)ctx->cfg.width * ctx->cfg.height * 4u));
+            VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&sl.gathered), region * (size_t)world));
+            VRT_HIP(ctx, hipMemsetAsync(sl.gathered, 0, region * (size_t)world, ctx->stream));
+            sl.shard = sl.gathered; // rank 0's own tiles are region 0 of the gathered buffer: no copy
+            VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&sl.frame), (size_t)ctx->cfg.width * ctx->cfg.height * 4u * d->batch));
         } else {
-            VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&sl.shard), d->shard_bytes));
-            VRT_HIP(ctx, hipMemsetAsync(sl.shard, 0, d->shard_bytes, ctx->stream));
+            VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&sl.shard), region));
+            VRT_HIP(ctx, hipMemsetAsync(sl.shard, 0, region, ctx->stream));
         }
     }
     if (!ctx->ev_upload) VRT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
@@ -907,50 +928,88 @@ int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int ra
     return VRT_OK;
 }
 
+int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight) {
+    return vrt_dist_init_batched(ctx, rccl_path, id128, rank, world, frames_in_flight, 1);
+}
+
 int vrt_dist_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun) {
     if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
     Dist *d = ctx->dist;
     DeviceGuard dg(ctx->device);
     vrt::KernelFn fn = nullptr;
-    const int rcp = pre_dispatch(ctx, camera, sun, &fn);
+    const int rcp = pre_dispatch(ctx, camera, sun, &fn); // (a scene write it may have to do launches the queued frames first)
     if (rcp != VRT_OK) return rcp;
+    if (d->npend > 0 && d->pend_fn != fn) { // another kernel specialisation (bounces / samples changed): not in the same launch
+        const int rcf = dist_flush(ctx);
+        if (rcf != VRT_OK) return rcf;
+    }
+    d->pend[d->npend].cam = *camera;
+    d->pend[d->npend].sun = *sun;
+    d->pend_fn = fn;
+    d->npend++;
+    return d->npend >= d->batch ? dist_flush(ctx) : VRT_OK;
+}
+
+} // extern "C"
+
+namespace {
+// Launch the queued frames: one kernel over (tiles of this rank) x (frames), ONE collective, one un-swizzle per frame.
+int dist_flush(vrt_ctx *ctx) {
+    Dist *d = ctx->dist;
+    const uint32_t n = d->npend;
+    if (n == 0) return VRT_OK;
+    d->npend = 0; // (also on failure: the frames are dropped, not retried)
     const int k = (int)(d->frame_no % d->nslots);
     DistSlot &sl = d->slots[k];
     if (sl.seen_upload != ctx->upload_seq) { // scene writes happen on the primary stream
         VRT_HIP(ctx, hipStreamWaitEvent(sl.stream, ctx->ev_upload, 0));
         sl.seen_upload = ctx->upload_seq;
     }
-    // 1. this rank's tiles, packed tile-major, straight into the buffer RCCL sends (rank 0: into shard 0 of `gathered`)
+    // 1. this rank's tiles of the n frames, packed tile-major, frame after frame, straight into the buffer RCCL sends
+    //    (rank 0: into region 0 of `gathered`)
     vrt::TraceParams pk = ctx->params;
+    for (uint32_t f = 0; f < n; f++) pk.pcs[f] = d->pend[f];
     pk.target_rgba8 = sl.shard;
     pk.target_rgba32f = nullptr;
     pk.packed_tiles = 1u;
-    VRT_HIP(ctx, vrt::launch_trace(fn, pk, ctx->lds_bytes, sl.stream));
-    // 2. the one collective of the frame: every rank's shard -> rank 0 (grouped point-to-point = gather)
+    pk.batch_target_stride = (uint32_t)d->shard_bytes;
+    VRT_HIP(ctx, vrt::launch_trace(d->pend_fn, pk, ctx->lds_bytes, sl.stream, n));
+    // 2. the one collective of the batch: every rank's shards -> rank 0 (grouped point-to-point = gather)
+    const size_t region = d->shard_bytes * d->batch;
     if (d->world > 1) {
         VRT_NCCL(ctx, d, d->api.GroupStart());
         if (d->rank == 0) {
             for (int r = 1; r < d->world; r++)
-                VRT_NCCL(ctx, d, d->api.Recv(sl.gathered + (size_t)r * d->shard_bytes, d->shard_bytes, ncclUint8, r, d->comm, sl.stream));
+                VRT_NCCL(ctx, d, d->api.Recv(sl.gathered + (size_t)r * region, d->shard_bytes * n, ncclUint8, r, d->comm, sl.stream));
         } else {
-            VRT_NCCL(ctx, d, d->api.Send(sl.shard, d->shard_bytes, ncclUint8, 0, d->comm, sl.stream));
+            VRT_NCCL(ctx, d, d->api.Send(sl.shard, d->shard_bytes * n, ncclUint8, 0, d->comm, sl.stream));
         }
         VRT_NCCL(ctx, d, d->api.GroupEnd());
     }
-    // 3. rank 0: tile-major shards -> row-major frame
-    if (d->rank == 0)
-        VRT_HIP(ctx, vrt::launch_assemble(sl.gathered, sl.frame, 4, ctx->cfg.width, ctx->cfg.height, ctx->shard.tiles_x, (uint32_t)d->world,
-                                          ctx->shard.tiles_per_rank, sl.stream));
+    // 3. rank 0: tile-major shards -> row-major frames
+    if (d->rank == 0) {
+        const size_t frame_bytes = (size_t)ctx->cfg.width * ctx->cfg.height * 4u;
+        for (uint32_t f = 0; f < n; f++)
+            VRT_HIP(ctx, vrt::launch_assemble(sl.gathered + (size_t)f * d->shard_bytes, sl.frame + (size_t)f * frame_bytes, 4, ctx->cfg.width,
+                                              ctx->cfg.height, ctx->shard.tiles_x, (uint32_t)d->world, ctx->shard.tiles_per_rank * d->batch,
+                                              sl.stream));
+    }
     VRT_HIP(ctx, hipEventRecord(sl.done, sl.stream));
     sl.used = true;
+    sl.frames = n;
     d->last_slot = k;
     d->frame_no++;
     return VRT_OK;
 }
+} // namespace
+
+extern "C" {
 
 int vrt_dist_wait(vrt_ctx *ctx) {
     if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
     DeviceGuard dg(ctx->device);
+    const int rcf = dist_flush(ctx);
+    if (rcf != VRT_OK) return rcf;
     for (uint32_t i = 0; i < ctx->dist->nslots; i++) VRT_HIP(ctx, hipStreamSynchronize(ctx->dist->slots[i].stream));
     VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VRT_OK;
@@ -960,11 +1019,15 @@ int vrt_dist_read_frame(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
     if (!ctx || !ctx->dist || !dst) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called / dst NULL") : VRT_E_INVALID_ARG;
     Dist *d = ctx->dist;
     if (d->rank != 0) return fail(ctx, VRT_E_STATE, "only rank 0 holds the assembled frame");
-    if (d->last_slot < 0) return fail(ctx, VRT_E_STATE, "no frame submitted yet");
     if (nbytes > (uint64_t)ctx->cfg.width * ctx->cfg.height * 4u) return fail(ctx, VRT_E_OUT_OF_RANGE, "read exceeds the frame");
     DeviceGuard dg(ctx->device);
+    // A launch carries a collective, so every rank must launch the same frames together: rank 0 cannot launch a partial
+    // queue on its own.  Queues empty themselves when full and in vrt_dist_wait, which every rank calls.
+    if (d->npend) return fail(ctx, VRT_E_STATE, "frames are still queued for the next launch: call vrt_dist_wait on every rank first");
+    if (d->last_slot < 0) return fail(ctx, VRT_E_STATE, "no frame submitted yet");
     DistSlot &sl = d->slots[d->last_slot];
-    VRT_HIP(ctx, hipMemcpyAsync(dst, sl.frame, nbytes, hipMemcpyDeviceToHost, sl.stream));
+    const size_t frame_bytes = (size_t)ctx->cfg.width * ctx->cfg.height * 4u;
+    VRT_HIP(ctx, hipMemcpyAsync(dst, sl.frame + (size_t)(sl.frames - 1u) * frame_bytes, nbytes, hipMemcpyDeviceToHost, sl.stream));
     VRT_HIP(ctx, hipStreamSynchronize(sl.stream));
     return VRT_OK;
 }

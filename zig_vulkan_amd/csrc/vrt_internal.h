@@ -27,7 +27,11 @@ struct DeviceCounters {
 // read through the scalar cache, like the reference's UBO + push constants.
 struct TraceParams {
     vrt_grid_state grid;                 // binding 1
-    PushConstants pc;                    // push constants
+    // push constants of the frames of this launch.  A launch renders blockIdx.y = 0 .. frames-1 frames of the same
+    // scene, frame f with pcs[f] into target + f * batch_target_stride: one rank of a multi-GPU run owns only 1/R
+    // of the tiles, too few waves to fill the GPU and no shorter than the frame's longest wave, so its frames
+    // are traced several to a launch (vrt_dist_*).  A plain dispatch is a batch of one.
+    PushConstants pcs[8];
     const vrt_material *materials;       // binding 2
     const uint32_t *brick_status;        // binding 3
     const uint32_t *brick_index;         // binding 4
@@ -38,6 +42,7 @@ struct TraceParams {
     float *target_rgba32f;               // optional float twin of the target
     DeviceCounters *counters;            // optional
     uint32_t width, height;              // imageSize(img_output)
+    uint32_t batch_target_stride;        // bytes between the RGBA8 targets of consecutive frames of a launch
     // tile geometry / sharding
     uint32_t tiles_x, tiles_y;           // 16x16-pixel workgroup tiles in the frame
     uint32_t shard_rank, shard_count;    // this ctx renders tiles t % count == rank
@@ -67,6 +72,7 @@ struct TraceParams {
                                          // 3 reverse raster, 4 strided, 5 cost-feedback schedule, 6 raster
 };
 
+constexpr int kMaxBatchFrames = 8;
 constexpr int kTileW = 16;
 constexpr int kTileH = 16;
 

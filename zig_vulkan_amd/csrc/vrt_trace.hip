@@ -982,21 +982,21 @@ VRT_DI bool scatter_dielectric(float ir, const Ray &r_in, const Hit &hit, Ray &s
 // ray", Camera.zig:74).  The bounce loop then runs at most once, so the scatter functions — whose only
 // products are the next ray and the continue flag — have no observable effect and are not evaluated.
 template <int B, bool COUNT, int MODE>
-VRT_DI f3 ray_color_single(const TraceParams &p, const uint32_t *lds_filter, const Ray &ray, Cnt<COUNT> &c) {
-    const bool sun_enabled = p.pc.sun.enabled > 0;
-    const f3 sun_color = mk3(p.pc.sun.color[0], p.pc.sun.color[1], p.pc.sun.color[2]);
+VRT_DI f3 ray_color_single(const TraceParams &p, const PushConstants &pc, const uint32_t *lds_filter, const Ray &ray, Cnt<COUNT> &c) {
+    const bool sun_enabled = pc.sun.enabled > 0;
+    const f3 sun_color = mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
     f3 color = mk3(0, 0, 0);
     int loop_count = 0;
     Hit hit;
-    if (p.pc.cam.max_bounce > 0 && grid_hit<B, COUNT, MODE>(p, lds_filter, ray, hit, c)) {
+    if (pc.cam.max_bounce > 0 && grid_hit<B, COUNT, MODE>(p, lds_filter, ray, hit, c)) {
         const vrt_material *m = p.materials + hit.index;
         const uint32_t mtype = m->type;
         const f3 attenuation = mk3(m->albedo_r, m->albedo_g, m->albedo_b);
         loop_count = (mtype <= MAT_DIELECTRIC) ? 1 : 0; // unknown type: loop_count -= 1 (comp:235-238)
         if (sun_enabled) {
-            const f3 sun_position = mk3(p.pc.sun.position[0], p.pc.sun.position[1], p.pc.sun.position[2]);
-            const f3 rv = rand_vec3_range(ray.direction.x + ray.direction.z, ray.direction.y + ray.direction.z, -p.pc.sun.radius,
-                                          p.pc.sun.radius);
+            const f3 sun_position = mk3(pc.sun.position[0], pc.sun.position[1], pc.sun.position[2]);
+            const f3 rv = rand_vec3_range(ray.direction.x + ray.direction.z, ray.direction.y + ray.direction.z, -pc.sun.radius,
+                                          pc.sun.radius);
             const Ray shadow_ray = create_ray(hit.point, (sun_position + rv) - hit.point);
             Hit shadow_hit;
             if (!grid_hit<B, COUNT, MODE>(p, lds_filter, shadow_ray, shadow_hit, c)) color = color + attenuation * sun_color;
@@ -1014,11 +1014,11 @@ VRT_DI f3 ray_color_single(const TraceParams &p, const uint32_t *lds_filter, con
 
 // comp:203-265
 template <int B, bool COUNT, int MODE>
-VRT_DI f3 ray_color(const TraceParams &p, const uint32_t *lds_filter, Ray current_ray, Cnt<COUNT> &c) {
-    const bool sun_enabled = p.pc.sun.enabled > 0;
-    const f3 sun_color = mk3(p.pc.sun.color[0], p.pc.sun.color[1], p.pc.sun.color[2]);
-    const f3 sun_position = mk3(p.pc.sun.position[0], p.pc.sun.position[1], p.pc.sun.position[2]);
-    const int max_bounce = p.pc.cam.max_bounce;
+VRT_DI f3 ray_color(const TraceParams &p, const PushConstants &pc, const uint32_t *lds_filter, Ray current_ray, Cnt<COUNT> &c) {
+    const bool sun_enabled = pc.sun.enabled > 0;
+    const f3 sun_color = mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
+    const f3 sun_position = mk3(pc.sun.position[0], pc.sun.position[1], pc.sun.position[2]);
+    const int max_bounce = pc.cam.max_bounce;
     Hit hit;
     hit.point = mk3(0, 0, 0);
     hit.normal = mk3(0, 0, 0);
@@ -1046,7 +1046,7 @@ VRT_DI f3 ray_color(const TraceParams &p, const uint32_t *lds_filter, Ray curren
         }
         if (sun_enabled) {
             const f3 rv = rand_vec3_range(current_ray.direction.x + current_ray.direction.z,
-                                          current_ray.direction.y + current_ray.direction.z, -p.pc.sun.radius, p.pc.sun.radius);
+                                          current_ray.direction.y + current_ray.direction.z, -pc.sun.radius, pc.sun.radius);
             const f3 sun_sample_position = sun_position + rv;
             const f3 shadow_ray_dir = sun_sample_position - hit.point;
             // CreateShadowRay, comp:186-190: sun_enabled > 0 here, so the ignore type is MAT_NONE
@@ -1148,6 +1148,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const uint32_t tile_x = tile % p.tiles_x, tile_y = tile / p.tiles_x;
     // lane -> pixel: wave w of the tile covers the 8x8 quadrant (w&1, w>>1)
     const uint32_t lane = threadIdx.x & 63u;
+    const PushConstants &pc = p.pcs[blockIdx.y]; // frame blockIdx.y of this launch (kernarg segment, scalar loads)
     const uint32_t in_x = (wave & 1u) * 8u + (lane & 7u);
     const uint32_t in_y = (wave >> 1) * 8u + (lane >> 3);
     const uint32_t px = tile_x * kTileW + in_x;
@@ -1164,36 +1165,36 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const bool inside = (px < p.width) && (py < p.height); // comp:155-159
     if (inside) {
         f3 color = mk3(0, 0, 0);
-        const int spp = (SHADE == 2) ? 1 : p.pc.cam.samples_per_pixel;
+        const int spp = (SHADE == 2) ? 1 : pc.cam.samples_per_pixel;
         const float x = (float)px, y = (float)py;
         // CameraGetRay operands, comp:474-477
-        const f3 horizontal = mk3(p.pc.cam.horizontal[0], p.pc.cam.horizontal[1], p.pc.cam.horizontal[2]);
-        const f3 vertical = mk3(p.pc.cam.vertical[0], p.pc.cam.vertical[1], p.pc.cam.vertical[2]);
-        const f3 llc = mk3(p.pc.cam.lower_left_corner[0], p.pc.cam.lower_left_corner[1], p.pc.cam.lower_left_corner[2]);
-        const f3 origin = mk3(p.pc.cam.origin[0], p.pc.cam.origin[1], p.pc.cam.origin[2]);
+        const f3 horizontal = mk3(pc.cam.horizontal[0], pc.cam.horizontal[1], pc.cam.horizontal[2]);
+        const f3 vertical = mk3(pc.cam.vertical[0], pc.cam.vertical[1], pc.cam.vertical[2]);
+        const f3 llc = mk3(pc.cam.lower_left_corner[0], pc.cam.lower_left_corner[1], pc.cam.lower_left_corner[2]);
+        const f3 origin = mk3(pc.cam.origin[0], pc.cam.origin[1], pc.cam.origin[2]);
         if constexpr (SHADE == 2) {
             // sample 0 is un-jittered: hash12(0) = 0 (comp:167-170)
-            const float u = (x + 0.0f) / (float)(p.pc.cam.image_width - 1u);
-            const float v = (y + 0.0f) / (float)(p.pc.cam.image_height - 1u);
+            const float u = (x + 0.0f) / (float)(pc.cam.image_width - 1u);
+            const float v = (y + 0.0f) / (float)(pc.cam.image_height - 1u);
             const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
-            color = mk3(0, 0, 0) + ray_color_single<B, COUNT, MODE>(p, lds_filter, create_ray(origin, ray_dir), c);
+            color = mk3(0, 0, 0) + ray_color_single<B, COUNT, MODE>(p, pc, lds_filter, create_ray(origin, ray_dir), c);
         } else {
             for (int sample_i = 0; sample_i < spp; sample_i++) {
                 // Re-derive the camera vectors from their SGPRs in every trip: a VALU op takes a single scalar
                 // operand, so the compiler copies them to VGPRs — hoisted out of this loop, twelve copies would
                 // stay live across the whole traversal and cost a wave per SIMD.
-                const f3 horizontal = opaque_uniform3(p.pc.cam.horizontal);
-                const f3 vertical = opaque_uniform3(p.pc.cam.vertical);
-                const f3 llc = opaque_uniform3(p.pc.cam.lower_left_corner);
-                const f3 origin = opaque_uniform3(p.pc.cam.origin);
+                const f3 horizontal = opaque_uniform3(pc.cam.horizontal);
+                const f3 vertical = opaque_uniform3(pc.cam.vertical);
+                const f3 llc = opaque_uniform3(pc.cam.lower_left_corner);
+                const f3 origin = opaque_uniform3(pc.cam.origin);
                 const float flag = (sample_i > 0) ? 1.0f : 0.0f;
                 const float noise_x = hash_12(((x + (float)sample_i) * 0.2f) * flag, (y * 0.2f) * flag);
-                const float u = (x + noise_x) / (float)(p.pc.cam.image_width - 1u);
+                const float u = (x + noise_x) / (float)(pc.cam.image_width - 1u);
                 const float noise_y = hash_12((x * 0.2f) * flag, ((y + (float)sample_i) * 0.2f) * flag);
-                const float v = (y + noise_y) / (float)(p.pc.cam.image_height - 1u);
+                const float v = (y + noise_y) / (float)(pc.cam.image_height - 1u);
                 const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
-                if constexpr (SHADE == 1) color = color + ray_color_single<B, COUNT, MODE>(p, lds_filter, create_ray(origin, ray_dir), c);
-                else color = color + ray_color<B, COUNT, MODE>(p, lds_filter, create_ray(origin, ray_dir), c);
+                if constexpr (SHADE == 1) color = color + ray_color_single<B, COUNT, MODE>(p, pc, lds_filter, create_ray(origin, ray_dir), c);
+                else color = color + ray_color<B, COUNT, MODE>(p, pc, lds_filter, create_ray(origin, ray_dir), c);
             }
         }
         const float fspp = (float)spp;
@@ -1206,7 +1207,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
             o = (size_t)py * p.width + px; // row-major frame
         }
         const uint32_t rgba = unorm8(color.x) | (unorm8(color.y) << 8) | (unorm8(color.z) << 16) | (255u << 24);
-        reinterpret_cast<uint32_t *>(p.target_rgba8)[o] = rgba;
+        reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] = rgba;
         if (p.target_rgba32f) {
             reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(color.x, color.y, color.z, 1.0f);
         }
@@ -1326,7 +1327,7 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(uint32_t *__restrict
 template <typename PIX>
 __global__ __launch_bounds__(256) void vrt_assemble_kernel(const PIX *__restrict__ gathered, PIX *__restrict__ frame, uint32_t width,
                                                            uint32_t height, uint32_t tiles_x, uint32_t shard_count,
-                                                           uint32_t tiles_per_rank) {
+                                                           uint32_t tiles_per_rank /* tiles between the shards of consecutive ranks */) {
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (x >= width || y >= height) return;
@@ -1396,11 +1397,13 @@ size_t trace_lds_bytes(const TraceParams &p, uint32_t variant) {
     return 0;
 }
 
-hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream) {
-    if (p.owned_tiles == 0) return hipSuccess;
-    if (p.block_threads == 512u) hipLaunchKernelGGL(fn, dim3((p.owned_tiles + 1u) / 2u), dim3(512), lds_bytes, stream, p);
-    else if (p.wave_groups) hipLaunchKernelGGL(fn, dim3(p.owned_tiles * 4u), dim3(64), lds_bytes, stream, p);
-    else hipLaunchKernelGGL(fn, dim3(p.owned_tiles), dim3(256), lds_bytes, stream, p);
+hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream, uint32_t frames) {
+    if (p.owned_tiles == 0 || frames == 0) return hipSuccess;
+    // grid.y = the frames of this launch (p.pcs[0 .. frames-1]); workgroups are dispatched x-fastest, so the tiles of
+    // frame 0 start first
+    if (p.block_threads == 512u) hipLaunchKernelGGL(fn, dim3((p.owned_tiles + 1u) / 2u, frames), dim3(512), lds_bytes, stream, p);
+    else if (p.wave_groups) hipLaunchKernelGGL(fn, dim3(p.owned_tiles * 4u, frames), dim3(64), lds_bytes, stream, p);
+    else hipLaunchKernelGGL(fn, dim3(p.owned_tiles, frames), dim3(256), lds_bytes, stream, p);
     return hipGetLastError();
 }
 

@@ -382,11 +382,15 @@ class VoxelRT:
         check(lib.vrt_dist_unique_id(L.rccl_library_path().encode(), buf))
         return bytes(buf)
 
-    def dist_init(self, unique_id: bytes, rank: int, world: int, frames_in_flight: int = 4, rccl_path: Optional[str] = None) -> None:
-        """rccl_path: the library to bind (default: the RCCL PyTorch ships; tests pass a single-process stand-in)."""
+    def dist_init(self, unique_id: bytes, rank: int, world: int, frames_in_flight: int = 4, rccl_path: Optional[str] = None,
+                  frames_per_launch: int = 1) -> None:
+        """frames_in_flight: launches in flight; frames_per_launch: consecutive frames traced by one launch and gathered by
+        one collective (vrt_dist_init_batched).  rccl_path: the library to bind (default: the RCCL PyTorch ships; tests pass
+        a single-process stand-in)."""
         assert len(unique_id) == 128
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
-        check(lib.vrt_dist_init(self._h, (rccl_path or L.rccl_library_path()).encode(), buf, rank, world, frames_in_flight), self._h)
+        check(lib.vrt_dist_init_batched(self._h, (rccl_path or L.rccl_library_path()).encode(), buf, rank, world, frames_in_flight,
+                                        frames_per_launch), self._h)
 
     def dist_frame(self) -> None:
         check(lib.vrt_dist_frame(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data)), self._h)
