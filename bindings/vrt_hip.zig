@@ -55,7 +55,8 @@ pub const Config = extern struct {
     stream: ?*anyopaque = null,
     kernel_variant: u32 = 0,
     frames_in_flight: u32 = 1,
-    _reserved: [6]u32 = [_]u32{0} ** 6,
+    shard_root_weight: u32 = 0,
+    _reserved: [5]u32 = [_]u32{0} ** 5,
 };
 
 pub extern fn vrt_create(cfg: *const Config, out: *?*Ctx) c_int;

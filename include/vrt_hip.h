@@ -131,7 +131,12 @@ typedef struct vrt_config {
      * the start of the next (two frames in flight, as a swapchain would have).  Ignored (1) when a
      * caller stream / external target or counters are in use. */
     uint32_t frames_in_flight;
-    uint32_t _reserved[6];
+    /* Multi-GPU, 2..8 ranks: rank 0's share of the tiles in percent of an equal share (0 or 100: equal; 1..99: rank 0
+     * owns fewer tiles — it also receives every other rank's shards and un-swizzles every frame).  Every rank must pass
+     * the same value.  Tile t then belongs to owner[t % period] of a fixed periodic pattern instead of rank t % count;
+     * vrt_shard_info.owned_tiles / tiles_per_rank describe the result. */
+    uint32_t shard_root_weight;
+    uint32_t _reserved[5];
 } vrt_config;
 
 typedef struct vrt_ctx vrt_ctx;

@@ -33,10 +33,15 @@ struct Posted {
     size_t bytes;
     hipEvent_t ready;
 };
+struct Staging {
+    void *ptr;
+    size_t bytes;
+    hipEvent_t idle; // recorded after the receiver's copy out of it
+};
 struct World {
     int nranks = 0;
     std::map<std::pair<int, int>, std::deque<Posted>> sends; // (src, dst) -> FIFO
-    std::vector<void *> garbage;                             // staging buffers, freed with the last communicator
+    std::vector<Staging> pool;                               // staging buffers, reused once idle; freed with the last communicator
     int live = 0;
 };
 std::mutex g_mu;
@@ -83,7 +88,10 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     World *w = comm->world;
     if (--w->live == 0) {
         (void)hipDeviceSynchronize();
-        for (void *p : w->garbage) (void)hipFree(p);
+        for (Staging &g : w->pool) {
+            (void)hipFree(g.ptr);
+            (void)hipEventDestroy(g.idle);
+        }
         for (auto &q : w->sends)
             for (Posted &s : q.second) {
                 (void)hipFree(s.staging);
@@ -102,7 +110,18 @@ ncclResult_t ncclGroupEnd() { return ncclSuccess; }
 ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t, int peer, ncclComm_t comm, hipStream_t stream) {
     if (!comm || peer < 0 || peer >= comm->world->nranks) return ncclInvalidArgument;
     Posted s{nullptr, count, nullptr};
-    if (hipMalloc(&s.staging, count ? count : 1) != hipSuccess) return ncclUnhandledCudaError;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto &pool = comm->world->pool;
+        for (size_t i = 0; i < pool.size(); i++)
+            if (pool[i].bytes >= count && hipEventQuery(pool[i].idle) == hipSuccess) {
+                s.staging = pool[i].ptr;
+                (void)hipEventDestroy(pool[i].idle);
+                pool.erase(pool.begin() + (long)i);
+                break;
+            }
+    }
+    if (!s.staging && hipMalloc(&s.staging, count ? count : 1) != hipSuccess) return ncclUnhandledCudaError;
     if (hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;
     if (hipMemcpyAsync(s.staging, sendbuff, count, hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
     if (hipEventRecord(s.ready, stream) != hipSuccess) return ncclUnhandledCudaError;
@@ -123,12 +142,17 @@ ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t, int peer, nc
         g_cv.wait(lk, [&] { return !q.empty(); }); // the matching send is posted by another host thread
         s = q.front();
         q.pop_front();
-        comm->world->garbage.push_back(s.staging);
     }
     if (s.bytes != count) return ncclInvalidArgument;
     if (hipStreamWaitEvent(stream, s.ready, 0) != hipSuccess) return ncclUnhandledCudaError;
     if (hipMemcpyAsync(recvbuff, s.staging, count, hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
     (void)hipEventDestroy(s.ready); // (destruction is deferred by the runtime until the wait has been carried out)
+    Staging g{s.staging, s.bytes, nullptr};
+    if (hipEventCreateWithFlags(&g.idle, hipEventDisableTiming) != hipSuccess || hipEventRecord(g.idle, stream) != hipSuccess) return ncclUnhandledCudaError;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        comm->world->pool.push_back(g);
+    }
     return ncclSuccess;
 }
 

@@ -91,7 +91,8 @@ class Config(C.Structure):  # vrt_config
         ("stream", C.c_void_p),
         ("kernel_variant", C.c_uint32),
         ("frames_in_flight", C.c_uint32),
-        ("_reserved", C.c_uint32 * 6),
+        ("shard_root_weight", C.c_uint32),
+        ("_reserved", C.c_uint32 * 5),
     ]
 
 

@@ -30,7 +30,7 @@ hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint
 hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
                           void *out_f32, hipStream_t stream);
 hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per_pixel, uint32_t width, uint32_t height, uint32_t tiles_x,
-                           uint32_t shard_count, uint32_t tiles_per_rank, hipStream_t stream);
+                           uint32_t shard_count, uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream);
 } // namespace vrt
 
 namespace {
@@ -139,6 +139,7 @@ struct vrt_ctx {
     uint32_t denoised_w = 0, denoised_h = 0;
     hipStream_t denoised_stream = nullptr;
     void *d_status_blocks = nullptr; // derived: 4x4x4 block words + block filter (vrt_trace.hip)
+    vrt::TileOwnership own{};        // weighted tile ownership (period 0: tile t belongs to rank t % shard_count)
     bool status_dirty = true;        // brick_status changed since the derived copy was built
     size_t lds_bytes = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -415,6 +416,46 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     const uint32_t total_tiles = sh.tiles_x * sh.tiles_y;
     sh.owned_tiles = (total_tiles > cfg->shard_rank) ? (total_tiles - cfg->shard_rank + shard_count - 1u) / shard_count : 0u;
     sh.tiles_per_rank = (total_tiles + shard_count - 1u) / shard_count;
+    if (cfg->shard_root_weight > 0u && cfg->shard_root_weight < 100u) {
+        if (shard_count < 2u || shard_count > 8u) {
+            free_ctx(c);
+            return fail(nullptr, VRT_E_INVALID_ARG, "shard_root_weight needs 2..8 ranks");
+        }
+        // Periodic pattern: 8 slots per period for every rank but the root, round(8 * weight) >= 1 for the root, laid out
+        // so that each rank's slots are spread evenly over the period (largest deficit first; ties to the lower rank).
+        vrt::TileOwnership &o = c->own;
+        uint32_t want[8];
+        want[0] = (8u * cfg->shard_root_weight + 50u) / 100u;
+        if (want[0] < 1u) want[0] = 1u;
+        for (uint32_t r = 1; r < shard_count; r++) want[r] = 8u;
+        o.ranks = shard_count;
+        o.period = want[0] + 8u * (shard_count - 1u);
+        uint32_t given[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t j = 0; j < o.period; j++) {
+            uint32_t best = 0;
+            int64_t best_deficit = INT64_MIN;
+            for (uint32_t r = 0; r < shard_count; r++) {
+                // deficit of rank r after j+1 slots, scaled by the period
+                const int64_t deficit = (int64_t)want[r] * (int64_t)(j + 1u) - (int64_t)given[r] * (int64_t)o.period;
+                if (given[r] < want[r] && deficit > best_deficit) {
+                    best_deficit = deficit;
+                    best = r;
+                }
+            }
+            o.owner[j] = (uint8_t)best;
+            o.prefix[j] = (uint8_t)given[best];
+            given[best]++;
+        }
+        for (uint32_t r = 0; r < shard_count; r++) o.count[r] = (uint8_t)want[r];
+        auto owned_by = [&](uint32_t r) {
+            uint32_t n = (total_tiles / o.period) * want[r];
+            for (uint32_t j = 0; j < total_tiles % o.period; j++) n += (o.owner[j] == r) ? 1u : 0u;
+            return n;
+        };
+        sh.owned_tiles = owned_by(cfg->shard_rank);
+        sh.tiles_per_rank = 0;
+        for (uint32_t r = 0; r < shard_count; r++) sh.tiles_per_rank = std::max(sh.tiles_per_rank, owned_by(r));
+    }
     c->target_pixels = (shard_count > 1u) ? (uint64_t)sh.tiles_per_rank * vrt::kTileW * vrt::kTileH : (uint64_t)cfg->width * cfg->height;
 
     if (cfg->external_target_rgba8) {
@@ -510,6 +551,13 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.shard_rank = sh.shard_rank;
     p.shard_count = sh.shard_count;
     p.owned_tiles = sh.owned_tiles;
+    if (c->own.period) {
+        p.own_period = c->own.period;
+        p.own_count = c->own.count[sh.shard_rank];
+        uint32_t k = 0;
+        for (uint32_t j = 0; j < c->own.period; j++)
+            if (c->own.owner[j] == sh.shard_rank) p.own_slots[k++] = (uint8_t)j;
+    }
     p.status_words = (uint32_t)((cells + 31u) / 32u);
     // the hand-written voxel-level loop addresses brick_occupancy by a 32-bit global bit index: brick_alloc * B^3 <= 2^31
     // (the u31 start-index check above), so it always reaches
@@ -829,7 +877,7 @@ int vrt_assemble_frame(vrt_ctx *ctx, const void *gathered, void *dst_frame, uint
     if (bytes_per_pixel != 4 && bytes_per_pixel != 16) return fail(ctx, VRT_E_INVALID_ARG, "bytes_per_pixel must be 4 or 16");
     DeviceGuard dg(ctx->device);
     VRT_HIP(ctx, vrt::launch_assemble(gathered, dst_frame, bytes_per_pixel, ctx->cfg.width, ctx->cfg.height, ctx->shard.tiles_x,
-                                      ctx->shard.shard_count, ctx->shard.tiles_per_rank, ctx->stream));
+                                      ctx->shard.shard_count, ctx->shard.tiles_per_rank, ctx->own, ctx->stream));
     return VRT_OK;
 }
 
@@ -992,7 +1040,7 @@ int dist_flush(vrt_ctx *ctx) {
         for (uint32_t f = 0; f < n; f++)
             VRT_HIP(ctx, vrt::launch_assemble(sl.gathered + (size_t)f * d->shard_bytes, sl.frame + (size_t)f * frame_bytes, 4, ctx->cfg.width,
                                               ctx->cfg.height, ctx->shard.tiles_x, (uint32_t)d->world, ctx->shard.tiles_per_rank * d->batch,
-                                              sl.stream));
+                                              ctx->own, sl.stream));
     }
     VRT_HIP(ctx, hipEventRecord(sl.done, sl.stream));
     sl.used = true;

@@ -23,6 +23,18 @@ struct DeviceCounters {
     unsigned long long wave_grid_iters, wave_brick_walks, wave_voxel_iters;
 };
 
+// Which rank owns which 16x16 tile.  Default: tile t belongs to rank t % R (its (t / R)-th tile).  With a root weight
+// (vrt_config.shard_root_weight) the ownership is a periodic pattern instead: tile t belongs to owner[t % period], rank 0
+// holding fewer slots of the period than the others — at 8 GPUs the root also takes in seven ranks' shards and un-swizzles
+// every frame, so it should trace less.  A rank's packed shard holds its tiles in increasing tile order either way.
+struct TileOwnership {
+    uint32_t period;      // 0: the t % R rule
+    uint32_t ranks;
+    uint8_t owner[64];    // slot j of the period -> rank
+    uint8_t prefix[64];   // number of earlier slots of the period held by the same rank
+    uint8_t count[8];     // slots per period of each rank
+};
+
 // Kernel argument block.  Passed by value: lives in the kernarg segment and is
 // read through the scalar cache, like the reference's UBO + push constants.
 struct TraceParams {
@@ -47,6 +59,8 @@ struct TraceParams {
     uint32_t tiles_x, tiles_y;           // 16x16-pixel workgroup tiles in the frame
     uint32_t shard_rank, shard_count;    // this ctx renders tiles t % count == rank
     uint32_t owned_tiles;                // number of tiles this context renders
+    uint32_t own_period, own_count;      // weighted ownership (TileOwnership): period 0 = the t % shard_count rule
+    uint8_t own_slots[16];               // the slots of the period this rank holds, ascending
     uint32_t status_words;               // length of brick_status in u32 words
     // x / grid scale and x / voxel scale as multiplications when both scales are powers of two (set per dispatch from
     // binding 1): the exact reciprocal gives the same correctly rounded quotient in one instruction instead of the

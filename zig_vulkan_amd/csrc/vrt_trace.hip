@@ -1144,7 +1144,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     } else {
         owned = xcd_slice_index(unit, p.owned_tiles);
     }
-    const uint32_t tile = owned * p.shard_count + p.shard_rank;
+    const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
     const uint32_t tile_x = tile % p.tiles_x, tile_y = tile / p.tiles_x;
     // lane -> pixel: wave w of the tile covers the 8x8 quadrant (w&1, w>>1)
     const uint32_t lane = threadIdx.x & 63u;
@@ -1327,12 +1327,21 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(uint32_t *__restrict
 template <typename PIX>
 __global__ __launch_bounds__(256) void vrt_assemble_kernel(const PIX *__restrict__ gathered, PIX *__restrict__ frame, uint32_t width,
                                                            uint32_t height, uint32_t tiles_x, uint32_t shard_count,
-                                                           uint32_t tiles_per_rank /* tiles between the shards of consecutive ranks */) {
+                                                           uint32_t tiles_per_rank /* tiles between the shards of consecutive ranks */,
+                                                           const TileOwnership own) {
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (x >= width || y >= height) return;
     const uint32_t t = (y / kTileH) * tiles_x + (x / kTileW);
-    const uint32_t r = t % shard_count, i = t / shard_count;
+    uint32_t r, i;
+    if (own.period) {
+        const uint32_t q = t / own.period, j = t % own.period;
+        r = own.owner[j];
+        i = q * own.count[r] + own.prefix[j];
+    } else {
+        r = t % shard_count;
+        i = t / shard_count;
+    }
     const size_t src = ((size_t)r * tiles_per_rank + i) * (kTileW * kTileH) + (y % kTileH) * kTileW + (x % kTileW);
     frame[(size_t)y * width + x] = gathered[src];
 }
@@ -1420,14 +1429,14 @@ hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint
 }
 
 hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per_pixel, uint32_t width, uint32_t height,
-                           uint32_t tiles_x, uint32_t shard_count, uint32_t tiles_per_rank, hipStream_t stream) {
+                           uint32_t tiles_x, uint32_t shard_count, uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream) {
     const dim3 grid((width + 63u) / 64u, (height + 3u) / 4u);
     if (bytes_per_pixel == 4) {
         hipLaunchKernelGGL(vrt_assemble_kernel<uint32_t>, grid, dim3(256), 0, stream, (const uint32_t *)gathered, (uint32_t *)frame, width,
-                           height, tiles_x, shard_count, tiles_per_rank);
+                           height, tiles_x, shard_count, tiles_per_rank, own);
     } else if (bytes_per_pixel == 16) {
         hipLaunchKernelGGL(vrt_assemble_kernel<float4>, grid, dim3(256), 0, stream, (const float4 *)gathered, (float4 *)frame, width, height,
-                           tiles_x, shard_count, tiles_per_rank);
+                           tiles_x, shard_count, tiles_per_rank, own);
     } else {
         return hipErrorInvalidValue;
     }

@@ -227,6 +227,7 @@ class Config:  # VoxelRT.Config, VoxelRT.zig:22-28 (+ the knobs of this implemen
     device_id: int = -1
     shard_rank: int = 0
     shard_count: int = 1
+    shard_root_weight: int = 0  # rank 0's share of the tiles in percent of an equal share (0: equal)
     kernel_variant: int = 0
     frames_in_flight: int = 1
     stream: int = 0
@@ -257,6 +258,7 @@ class VoxelRT:
         cfg.enable_counters = 1 if config.enable_counters else 0
         cfg.shard_rank = config.shard_rank
         cfg.shard_count = config.shard_count
+        cfg.shard_root_weight = config.shard_root_weight
         cfg.kernel_variant = config.kernel_variant
         cfg.frames_in_flight = config.frames_in_flight
         cfg.stream = config.stream or None
