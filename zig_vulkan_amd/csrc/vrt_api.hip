@@ -30,7 +30,8 @@ hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint
 hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
                           void *out_f32, hipStream_t stream);
 hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per_pixel, uint32_t width, uint32_t height, uint32_t tiles_x,
-                           uint32_t shard_count, uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream);
+                           uint32_t shard_count, uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream, uint32_t frames = 1,
+                           uint32_t frame_src_stride_pixels = 0);
 } // namespace vrt
 
 namespace {
@@ -1036,11 +1037,9 @@ int dist_flush(vrt_ctx *ctx) {
     }
     // 3. rank 0: tile-major shards -> row-major frames
     if (d->rank == 0) {
-        const size_t frame_bytes = (size_t)ctx->cfg.width * ctx->cfg.height * 4u;
-        for (uint32_t f = 0; f < n; f++)
-            VRT_HIP(ctx, vrt::launch_assemble(sl.gathered + (size_t)f * d->shard_bytes, sl.frame + (size_t)f * frame_bytes, 4, ctx->cfg.width,
-                                              ctx->cfg.height, ctx->shard.tiles_x, (uint32_t)d->world, ctx->shard.tiles_per_rank * d->batch,
-                                              ctx->own, sl.stream));
+        // (one launch for the n frames of the batch: grid.z)
+        VRT_HIP(ctx, vrt::launch_assemble(sl.gathered, sl.frame, 4, ctx->cfg.width, ctx->cfg.height, ctx->shard.tiles_x, (uint32_t)d->world,
+                                          ctx->shard.tiles_per_rank * d->batch, ctx->own, sl.stream, n, (uint32_t)(d->shard_bytes / 4u)));
     }
     VRT_HIP(ctx, hipEventRecord(sl.done, sl.stream));
     sl.used = true;

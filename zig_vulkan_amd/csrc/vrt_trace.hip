@@ -1328,7 +1328,10 @@ template <typename PIX>
 __global__ __launch_bounds__(256) void vrt_assemble_kernel(const PIX *__restrict__ gathered, PIX *__restrict__ frame, uint32_t width,
                                                            uint32_t height, uint32_t tiles_x, uint32_t shard_count,
                                                            uint32_t tiles_per_rank /* tiles between the shards of consecutive ranks */,
-                                                           const TileOwnership own) {
+                                                           const TileOwnership own, uint32_t frame_src_stride /* pixels between the shards of consecutive frames */) {
+    // blockIdx.z: frame of a batch (shards of consecutive frames frame_src_stride pixels apart, frames width*height apart)
+    gathered += (size_t)blockIdx.z * frame_src_stride;
+    frame += (size_t)blockIdx.z * width * height;
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (x >= width || y >= height) return;
@@ -1429,14 +1432,15 @@ hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint
 }
 
 hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per_pixel, uint32_t width, uint32_t height,
-                           uint32_t tiles_x, uint32_t shard_count, uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream) {
-    const dim3 grid((width + 63u) / 64u, (height + 3u) / 4u);
+                           uint32_t tiles_x, uint32_t shard_count, uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream,
+                           uint32_t frames, uint32_t frame_src_stride_pixels) {
+    const dim3 grid((width + 63u) / 64u, (height + 3u) / 4u, frames);
     if (bytes_per_pixel == 4) {
         hipLaunchKernelGGL(vrt_assemble_kernel<uint32_t>, grid, dim3(256), 0, stream, (const uint32_t *)gathered, (uint32_t *)frame, width,
-                           height, tiles_x, shard_count, tiles_per_rank, own);
+                           height, tiles_x, shard_count, tiles_per_rank, own, frame_src_stride_pixels);
     } else if (bytes_per_pixel == 16) {
         hipLaunchKernelGGL(vrt_assemble_kernel<float4>, grid, dim3(256), 0, stream, (const float4 *)gathered, (float4 *)frame, width, height,
-                           tiles_x, shard_count, tiles_per_rank, own);
+                           tiles_x, shard_count, tiles_per_rank, own, frame_src_stride_pixels);
     } else {
         return hipErrorInvalidValue;
     }
