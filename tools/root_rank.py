@@ -19,7 +19,7 @@ for weight in (0, 65, 40):
     uid = b"root-rank" + os.urandom(16) + bytes(128 - 25)
     rt = W.make_renderer(w, grid, shard_rank=0, shard_count=world, shard_root_weight=weight)
     rt.dist_init(uid, 0, world, frames_in_flight=slots, rccl_path=FAKE, frames_per_launch=batch)
-    shard_bytes = rt.shard_info().tiles_per_rank * 256 * 4
+    shard_bytes = rt.shard_info().tiles_per_rank * 256 * 3  # shards travel as RGB
     u = Uid(); C.memmove(C.byref(u), uid, 128)
     comms = []
     for r in range(1, world):

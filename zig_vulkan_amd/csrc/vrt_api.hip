@@ -26,6 +26,8 @@ uint32_t resolve_variant(uint32_t variant);
 size_t trace_lds_bytes(const TraceParams &p, uint32_t variant);
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream, uint32_t frames = 1);
 hipError_t launch_schedule(uint32_t *cost, uint32_t *order, uint32_t n, hipStream_t stream);
+hipError_t launch_assemble_rgb(const void *gathered, void *frame, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t shard_count,
+                               uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream, uint32_t frames, uint32_t frame_src_stride_bytes);
 hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
                           void *out_f32, hipStream_t stream);
@@ -950,7 +952,8 @@ int vrt_dist_init_batched(vrt_ctx *ctx, const char *rccl_path, const void *id128
     d->world = world;
     d->nslots = frames_in_flight;
     d->batch = frames_per_launch;
-    d->shard_bytes = (size_t)ctx->shard.tiles_per_rank * vrt::kTileW * vrt::kTileH * 4u;
+    // shards travel as RGB (the alpha of the RGBA8 target is the constant 255): a quarter less for rank 0's links to take in
+    d->shard_bytes = (size_t)ctx->shard.tiles_per_rank * vrt::kTileW * vrt::kTileH * 3u;
     ctx->dist = d; // from here free_ctx cleans up
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
@@ -1021,6 +1024,7 @@ int dist_flush(vrt_ctx *ctx) {
     pk.target_rgba8 = sl.shard;
     pk.target_rgba32f = nullptr;
     pk.packed_tiles = 1u;
+    pk.packed_rgb = 1u;
     pk.batch_target_stride = (uint32_t)d->shard_bytes;
     VRT_HIP(ctx, vrt::launch_trace(d->pend_fn, pk, ctx->lds_bytes, sl.stream, n));
     // 2. the one collective of the batch: every rank's shards -> rank 0 (grouped point-to-point = gather)
@@ -1038,8 +1042,8 @@ int dist_flush(vrt_ctx *ctx) {
     // 3. rank 0: tile-major shards -> row-major frames
     if (d->rank == 0) {
         // (one launch for the n frames of the batch: grid.z)
-        VRT_HIP(ctx, vrt::launch_assemble(sl.gathered, sl.frame, 4, ctx->cfg.width, ctx->cfg.height, ctx->shard.tiles_x, (uint32_t)d->world,
-                                          ctx->shard.tiles_per_rank * d->batch, ctx->own, sl.stream, n, (uint32_t)(d->shard_bytes / 4u)));
+        VRT_HIP(ctx, vrt::launch_assemble_rgb(sl.gathered, sl.frame, ctx->cfg.width, ctx->cfg.height, ctx->shard.tiles_x, (uint32_t)d->world,
+                                              ctx->shard.tiles_per_rank * d->batch, ctx->own, sl.stream, n, (uint32_t)d->shard_bytes));
     }
     VRT_HIP(ctx, hipEventRecord(sl.done, sl.stream));
     sl.used = true;

@@ -79,6 +79,8 @@ struct TraceParams {
     const uint32_t *tile_schedule;
     uint32_t tile_stride;                // tile_order 4: multiplier coprime to owned_tiles
     uint32_t packed_tiles;               // 1: write the packed tile-major shard layout even when shard_count == 1
+    uint32_t packed_rgb;                 // 1 (with packed_tiles): 3 bytes per pixel in the shard (alpha is the constant 255): a quarter
+                                         // less to gather over xGMI; the un-swizzle on rank 0 puts the alpha back
     uint32_t brick_batch;                // lanes that must be waiting before a batched voxel-level walk runs (bounce frames)
     uint32_t block_threads;              // 256, or 512 for kVariantLinearLds512
     uint32_t wave_groups;                // 1: launch one 64-thread workgroup per 8x8 block instead of 256 per 16x16 tile

@@ -1163,6 +1163,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const unsigned long long wall_begin = p.wave_timeline ? wall_clock64() : 0ull;
     Cnt<COUNT> c;
     const bool inside = (px < p.width) && (py < p.height); // comp:155-159
+    uint32_t rgba = 0u; // this lane's pixel (0 outside the image), also needed after the branch by the RGB shard store
     if (inside) {
         f3 color = mk3(0, 0, 0);
         const int spp = (SHADE == 2) ? 1 : pc.cam.samples_per_pixel;
@@ -1206,11 +1207,24 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         } else {
             o = (size_t)py * p.width + px; // row-major frame
         }
-        const uint32_t rgba = unorm8(color.x) | (unorm8(color.y) << 8) | (unorm8(color.z) << 16) | (255u << 24);
-        reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] = rgba;
+        rgba = unorm8(color.x) | (unorm8(color.y) << 8) | (unorm8(color.z) << 16) | (255u << 24);
+        if (!p.packed_rgb) reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] = rgba;
         if (p.target_rgba32f) {
             reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(color.x, color.y, color.z, 1.0f);
         }
+    }
+    if (p.packed_rgb) {
+        // RGB shard (multi-GPU pipeline): 16x16 tiles of 3-byte pixels, 768 bytes per tile.  The eight lanes of a row of
+        // this wave's 8x8 block hold 24 consecutive bytes = 6 dwords; lane k < 6 of the row assembles dword k from the
+        // two pixels it spans (bytes 4k .. 4k+3; pixel = byte / 3) and stores it.
+        const uint32_t k = lane & 7u;
+        const uint32_t first = k + (k >= 3u ? 1u : 0u); // = 4k / 3 for k < 6
+        const int src = (int)((lane & ~7u) + first);
+        const uint32_t lo = (uint32_t)__shfl((int)rgba, src, 64), hi = (uint32_t)__shfl((int)rgba, src + 1, 64);
+        const uint32_t m = k % 3u;
+        const uint32_t dword = (m == 0u) ? ((lo & 0xFFFFFFu) | (hi << 24)) : ((m == 1u) ? (((lo >> 8) & 0xFFFFu) | (hi << 16)) : (((lo >> 16) & 0xFFu) | (hi << 8)));
+        if (k < 6u)
+            reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[(size_t)owned * 192u + in_y * 12u + (in_x >> 3) * 6u + k] = dword;
     }
 #ifdef VRT_DEV_PROFILE
     VRT_PROF_END(7, tp7);
@@ -1349,6 +1363,29 @@ __global__ __launch_bounds__(256) void vrt_assemble_kernel(const PIX *__restrict
     frame[(size_t)y * width + x] = gathered[src];
 }
 
+// The same from RGB shards (3 bytes per pixel, see TraceParams::packed_rgb) into the RGBA8 frame (alpha 255).
+__global__ __launch_bounds__(256) void vrt_assemble_rgb_kernel(const uint8_t *__restrict__ gathered, uint32_t *__restrict__ frame, uint32_t width,
+                                                               uint32_t height, uint32_t tiles_x, uint32_t shard_count, uint32_t tiles_per_rank,
+                                                               const TileOwnership own, uint32_t frame_src_stride_bytes) {
+    gathered += (size_t)blockIdx.z * frame_src_stride_bytes;
+    frame += (size_t)blockIdx.z * width * height;
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= width || y >= height) return;
+    const uint32_t t = (y / kTileH) * tiles_x + (x / kTileW);
+    uint32_t r, i;
+    if (own.period) {
+        const uint32_t q = t / own.period, j = t % own.period;
+        r = own.owner[j];
+        i = q * own.count[r] + own.prefix[j];
+    } else {
+        r = t % shard_count;
+        i = t / shard_count;
+    }
+    const uint8_t *src = gathered + (((size_t)r * tiles_per_rank + i) * (kTileW * kTileH) + (y % kTileH) * kTileW + (x % kTileW)) * 3u;
+    frame[(size_t)y * width + x] = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | (255u << 24);
+}
+
 // ---- launchers (called from vrt_api.hip) ------------------------------------
 using KernelFn = void (*)(const TraceParams);
 
@@ -1428,6 +1465,14 @@ hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint
     const uint32_t nblocks = p.nbx * p.nby * p.nbz;
     hipLaunchKernelGGL(vrt_build_status_blocks, dim3((nblocks + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
                        const_cast<uint2 *>(p.status_blocks), dim_x, dim_y, dim_z, p.nbx, p.nby, p.nbz);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_rgb(const void *gathered, void *frame, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t shard_count,
+                               uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream, uint32_t frames, uint32_t frame_src_stride_bytes) {
+    const dim3 grid((width + 63u) / 64u, (height + 3u) / 4u, frames);
+    hipLaunchKernelGGL(vrt_assemble_rgb_kernel, grid, dim3(256), 0, stream, (const uint8_t *)gathered, (uint32_t *)frame, width, height, tiles_x,
+                       shard_count, tiles_per_rank, own, frame_src_stride_bytes);
     return hipGetLastError();
 }
 
