@@ -119,7 +119,7 @@ def main() -> None:
                     help="frames traced by one launch and gathered by one collective when world > 1 (a rank owns 1/world of the tiles)")
     ap.add_argument("--root-share", type=int, default=-1,
                     help="native multi-GPU pipeline: rank 0's share of the tiles in percent of an equal share (it also takes in the other "
-                         "ranks' shards and un-swizzles every frame); -1: 100 - 5 per other rank (8 GPUs: 65)")
+                         "ranks' shards and un-swizzles every frame); -1: 100 - 40 (world - 1) / 7, i.e. 60 at 8 GPUs, 83 at 4, 94 at 2")
     ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")
     args = ap.parse_args()
 
@@ -184,7 +184,7 @@ def main() -> None:
             uid = [VoxelRT.dist_unique_id() if rank == 0 else None]
             if dist is not None and world > 1:
                 dist.broadcast_object_list(uid, src=0)
-            root_share = args.root_share if args.root_share >= 0 else max(30, 100 - 5 * (world - 1))
+            root_share = args.root_share if args.root_share >= 0 else max(30, 100 - (40 * (world - 1) + 3) // 7)
             rt = W.make_renderer(w, grid, device_id=local_rank, shard_rank=rank, shard_count=world, kernel_variant=args.variant,
                                  shard_root_weight=(root_share if 2 <= world <= 8 else 0))
             rt.dist_init(uid[0], rank, world, args.dist_frames, frames_per_launch=(args.dist_batch if world > 1 else 1))

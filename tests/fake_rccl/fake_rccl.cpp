@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -110,6 +111,20 @@ ncclResult_t ncclGroupEnd() { return ncclSuccess; }
 ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t, int peer, ncclComm_t comm, hipStream_t stream) {
     if (!comm || peer < 0 || peer >= comm->world->nranks) return ncclInvalidArgument;
     Posted s{nullptr, count, nullptr};
+    static const bool zero_copy = std::getenv("FAKE_RCCL_ZERO_COPY") != nullptr;
+    if (zero_copy) {
+        // measurement aid (tools/root_rank.py): no staging copy, the receiver copies straight out of the send buffer — only
+        // sound when the sender never rewrites that buffer, as the feeder thread of that tool
+        s.staging = const_cast<void *>(sendbuff);
+        if (hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(s.ready, stream) != hipSuccess)
+            return ncclUnhandledCudaError;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            comm->world->sends[{comm->rank, peer}].push_back(s);
+        }
+        g_cv.notify_all();
+        return ncclSuccess;
+    }
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto &pool = comm->world->pool;
@@ -147,6 +162,8 @@ ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t, int peer, nc
     if (hipStreamWaitEvent(stream, s.ready, 0) != hipSuccess) return ncclUnhandledCudaError;
     if (hipMemcpyAsync(recvbuff, s.staging, count, hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
     (void)hipEventDestroy(s.ready); // (destruction is deferred by the runtime until the wait has been carried out)
+    static const bool zero_copy = std::getenv("FAKE_RCCL_ZERO_COPY") != nullptr;
+    if (zero_copy) return ncclSuccess; // (the buffer is the sender's)
     Staging g{s.staging, s.bytes, nullptr};
     if (hipEventCreateWithFlags(&g.idle, hipEventDisableTiming) != hipSuccess || hipEventRecord(g.idle, stream) != hipSuccess) return ncclUnhandledCudaError;
     {

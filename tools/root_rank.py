@@ -3,6 +3,7 @@
 ranks' shards and the un-swizzle of every frame.  Rank 0 of 8 over the test-only RCCL stand-in, the seven peers played by a
 feeder thread that posts ready-made shards (no tracing), so the only GPU work is rank 0's."""
 import ctypes as C, os, sys, threading, time
+os.environ["FAKE_RCCL_ZERO_COPY"] = "1"  # the feeder never rewrites its buffer: let the receives copy straight out of it
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
