@@ -209,9 +209,9 @@ int vrt_assemble_frame(vrt_ctx *ctx, const void *gathered, void *dst_frame, uint
 /* ---- multi-GPU frame pipeline (RCCL over xGMI, one process per GPU) -----------------------------
  * The reference is single-GPU; this is the north-star's image-tile sharding.  A context created with
  * shard_rank / shard_count = this process's rank / world size renders its interleaved 16x16 tiles and
- * ONE gather per frame (grouped ncclSend / ncclRecv) brings the packed RGBA8 shards to rank 0, which
- * un-swizzles them into the row-major frame.  Up to 8 frames are in flight, each on its own stream
- * (kernel -> gather -> un-swizzle), so a frame's collective overlaps the next frames' kernels.
+ * ONE gather per launch (grouped ncclSend / ncclRecv) brings the packed shards (RGB: the alpha of the target is the
+ * constant 255) to rank 0, which un-swizzles them into row-major RGBA8 frames.  Up to 8 launches are in flight, each on
+ * its own stream (kernel -> gather -> un-swizzle), so one launch's collective overlaps the next launches' kernels.
  * RCCL is reached through dlopen(rccl_path) — pass the library the process already uses (PyTorch's
  * bundled librccl.so) so that there is one RCCL in the address space; libvrt_hip.so does not link it.
  * Rank 0 makes the 128-byte id with vrt_dist_unique_id and the host distributes it to every rank. */
