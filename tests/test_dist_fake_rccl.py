@@ -22,7 +22,8 @@ FAKE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "li
 def test_native_pipeline_with_many_ranks_on_one_gpu(world, frames_in_flight, frames_per_launch, root_weight):
     if not os.path.exists(FAKE):
         pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
-    w = W.Workload("t", 330, 210, 64, 4, 1, 0, True, 0.0)
+    # (width 332: the four-pixels-per-thread un-swizzle; 330: the one-pixel one)
+    w = W.Workload("t", 332 if frames_per_launch > 1 else 330, 210, 64, 4, 1, 0, True, 0.0)
     grid = W.build_grid(w)
     views = ["V0", "V1", "V2", "V1", "V2", "V0", "V0", "V2", "V1", "V1", "V0"]
     plain = W.make_renderer(w, grid)

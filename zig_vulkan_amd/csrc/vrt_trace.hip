@@ -1386,6 +1386,32 @@ __global__ __launch_bounds__(256) void vrt_assemble_rgb_kernel(const uint8_t *__
     frame[(size_t)y * width + x] = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | (255u << 24);
 }
 
+// Four pixels per thread (width % 4 == 0): three dwords in, one 16-byte store out.
+__global__ __launch_bounds__(256) void vrt_assemble_rgb4_kernel(const uint8_t *__restrict__ gathered, uint32_t *__restrict__ frame, uint32_t width,
+                                                                uint32_t height, uint32_t tiles_x, uint32_t shard_count, uint32_t tiles_per_rank,
+                                                                const TileOwnership own, uint32_t frame_src_stride_bytes) {
+    gathered += (size_t)blockIdx.z * frame_src_stride_bytes;
+    frame += (size_t)blockIdx.z * width * height;
+    const uint32_t x = (blockIdx.x * 64u + (threadIdx.x & 63u)) * 4u;
+    const uint32_t y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= width || y >= height) return;
+    const uint32_t t = (y / kTileH) * tiles_x + (x / kTileW);
+    uint32_t r, i;
+    if (own.period) {
+        const uint32_t q = t / own.period, j = t % own.period;
+        r = own.owner[j];
+        i = q * own.count[r] + own.prefix[j];
+    } else {
+        r = t % shard_count;
+        i = t / shard_count;
+    }
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(gathered + (((size_t)r * tiles_per_rank + i) * (kTileW * kTileH) + (y % kTileH) * kTileW + (x % kTileW)) * 3u);
+    const uint32_t a = src[0], b = src[1], c = src[2]; // r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+    const uint4 out = make_uint4((a & 0xFFFFFFu) | 0xFF000000u, (a >> 24) | ((b & 0xFFFFu) << 8) | 0xFF000000u,
+                                 (b >> 16) | ((c & 0xFFu) << 16) | 0xFF000000u, (c >> 8) | 0xFF000000u);
+    *reinterpret_cast<uint4 *>(frame + (size_t)y * width + x) = out;
+}
+
 // ---- launchers (called from vrt_api.hip) ------------------------------------
 using KernelFn = void (*)(const TraceParams);
 
@@ -1470,6 +1496,13 @@ hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint
 
 hipError_t launch_assemble_rgb(const void *gathered, void *frame, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t shard_count,
                                uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream, uint32_t frames, uint32_t frame_src_stride_bytes) {
+    if (width % 4u == 0u && (reinterpret_cast<uintptr_t>(frame) & 15u) == 0u && (reinterpret_cast<uintptr_t>(gathered) & 3u) == 0u &&
+        frame_src_stride_bytes % 4u == 0u) {
+        const dim3 grid4((width / 4u + 63u) / 64u, (height + 3u) / 4u, frames);
+        hipLaunchKernelGGL(vrt_assemble_rgb4_kernel, grid4, dim3(256), 0, stream, (const uint8_t *)gathered, (uint32_t *)frame, width, height, tiles_x,
+                           shard_count, tiles_per_rank, own, frame_src_stride_bytes);
+        return hipGetLastError();
+    }
     const dim3 grid((width + 63u) / 64u, (height + 3u) / 4u, frames);
     hipLaunchKernelGGL(vrt_assemble_rgb_kernel, grid, dim3(256), 0, stream, (const uint8_t *)gathered, (uint32_t *)frame, width, height, tiles_x,
                        shard_count, tiles_per_rank, own, frame_src_stride_bytes);
