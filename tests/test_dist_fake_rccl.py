@@ -70,3 +70,45 @@ def test_native_pipeline_with_many_ranks_on_one_gpu(world, frames_in_flight, fra
     assert len(got) == len(reads) + 1
     for v, frame in got:
         assert np.array_equal(frame, ref[v]), f"assembled frame of view {v} differs from the single-context frame"
+
+
+@pytest.mark.parametrize("size,world,root_weight,frames_per_launch", [((40, 24), 8, 60, 8), ((16, 16), 4, 50, 2), ((130, 70), 8, 0, 8), ((1, 1), 2, 90, 1)])
+def test_more_ranks_than_tiles_and_tiny_frames(size, world, root_weight, frames_per_launch):
+    """Frames with fewer tiles than ranks (some ranks, possibly the root, own nothing), with and without the weighted pattern."""
+    if not os.path.exists(FAKE):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
+    w = W.Workload("t", size[0], size[1], 64, 4, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    plain = W.make_renderer(w, grid)
+    W.set_view(plain, "V2")
+    plain.draw()
+    ref = plain.read_rgba8().copy()
+    plain.deinit()
+    uid = b"tiny" + bytes([world, root_weight, frames_per_launch]) + os.urandom(16) + bytes(128 - 23)
+    ranks = [W.make_renderer(w, grid, shard_rank=r, shard_count=world, shard_root_weight=root_weight) for r in range(world)]
+    owned = [rt.shard_info().owned_tiles for rt in ranks]
+    assert sum(owned) == ranks[0].shard_info().tiles_x * ranks[0].shard_info().tiles_y
+    for r, rt in enumerate(ranks):
+        W.set_view(rt, "V2")
+        rt.dist_init(uid, r, world, frames_in_flight=2, rccl_path=FAKE, frames_per_launch=frames_per_launch)
+    errors = []
+
+    def drive(r):
+        try:
+            for _ in range(11):
+                ranks[r].dist_frame()
+            ranks[r].dist_wait()
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads) and not errors, errors
+    got = ranks[0].dist_read_frame()
+    for rt in ranks:
+        rt.deinit()
+    both_nan_free = np.array_equal(got, ref)
+    assert both_nan_free, f"owned tiles per rank {owned}"
