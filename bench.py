@@ -115,7 +115,7 @@ def main() -> None:
                     help="N>1 frame gather: native = RCCL send/recv inside libvrt_hip.so (pipelined, 4 frames in flight); "
                          "torch = torch.distributed.gather from Python (fallback)")
     ap.add_argument("--dist-frames", type=int, default=4, help="launches in flight per rank of the native multi-GPU pipeline")
-    ap.add_argument("--dist-batch", type=int, default=8,
+    ap.add_argument("--dist-batch", type=int, default=4,
                     help="frames traced by one launch and gathered by one collective when world > 1 (a rank owns 1/world of the tiles)")
     ap.add_argument("--root-share", type=int, default=-1,
                     help="native multi-GPU pipeline: rank 0's share of the tiles in percent of an equal share (it also takes in the other "
