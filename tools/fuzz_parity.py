@@ -56,7 +56,11 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True) -> int:
         ok = np.array_equal(f.view(np.uint32)[~both_nan], fo.view(np.uint32)[~both_nan]) and np.array_equal(u, uo)
         if not ok:
             bad += 1
-            print(f"case {case}: MISMATCH  b={b} dims={dims} scale={scale} {w}x{h} spp={spp} bounce={bounce} sun={sun_on}/{radius}  {np.count_nonzero(f != fo)} floats differ")
+            du = np.argwhere(u != uo)
+            db = np.argwhere((f.view(np.uint32) != fo.view(np.uint32)) & ~both_nan)
+            print(f"   float bits differ at {len(db)} places, first {[(i.tolist(), float(f[tuple(i)]), float(fo[tuple(i)]), hex(int(f.view(np.uint32)[tuple(i)])), hex(int(fo.view(np.uint32)[tuple(i)]))) for i in db[:4]]}")
+            print(f"case {case}: MISMATCH  {name} b={b} dims={dims} scale={scale} {w}x{h} spp={spp} bounce={bounce} sun={sun_on}/{radius}  {np.count_nonzero(f != fo)} floats differ, "
+                  f"{len(du)} RGBA8 bytes differ, first {[(i.tolist(), int(u[tuple(i)]), int(uo[tuple(i)])) for i in du[:4]]}")
         elif verbose and case % 10 == 0:
             print(f"case {case}: ok  b={b} dims={dims} scale={scale} {w}x{h} spp={spp} bounce={bounce} sun={sun_on}/{radius} rays={co['rays']} hits={co['hits']}")
     if verbose:
