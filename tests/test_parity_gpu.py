@@ -121,7 +121,33 @@ def test_sharded_tiles_reassemble_to_full_frame():
     assert np.array_equal(out.cpu().numpy().reshape(w.height, w.width, 4), u_full)
 
 
-@pytest.mark.parametrize("variant", [0, 0x50000, 0x100000])
+@pytest.mark.parametrize("frames_in_flight", [1, 2])
+def test_amortised_tile_schedule_keeps_every_frame_identical(frames_in_flight):
+    """kernel_variant 0x70000: tiles ordered by the cost measured over the previous 16 frames, re-sorted into the other of
+    two schedule buffers while frames of the second stream may be running.  The order must never change a pixel: 70
+    overlapping frames (four re-sorts) without a read in between, then every frame of a second sequence is compared."""
+    w = W.Workload("t", 320, 200, 64, 4, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    ref = {}
+    for view in ["V0", "V1", "V2"]:
+        _, ref[view], _, _ = _run_hip(w, grid, view, counters=False)
+    rt = W.make_renderer(w, grid, frames_in_flight=frames_in_flight, kernel_variant=0x70000)
+    for i in range(70):
+        W.set_view(rt, ["V0", "V1", "V2"][(i // 5) % 3])
+        rt.draw()
+    assert np.array_equal(rt.read_rgba8(), ref[["V0", "V1", "V2"][(69 // 5) % 3]])
+    for i in range(40):
+        view = ["V2", "V0", "V1"][i % 3]
+        W.set_view(rt, view)
+        rt.draw()
+        assert np.array_equal(rt.read_rgba8(), ref[view]), (i, view)
+    W.set_view(rt, "V1")
+    rt.draw(frames=40)  # back-to-back launches of one call re-sort inside the loop
+    assert np.array_equal(rt.read_rgba8(), ref["V1"])
+    rt.deinit()
+
+
+@pytest.mark.parametrize("variant", [0, 0x50000, 0x70000, 0x100000])
 def test_two_frames_in_flight_give_the_same_frames_and_respect_uploads(variant):
     """frames_in_flight = 2: frames alternate between two streams/targets; every frame still equals
     the single-stream result, and a grid edit between frames is seen by the next frame on either stream.

@@ -15,6 +15,7 @@ grid = W.build_grid(w)
 rt = W.make_renderer(w, grid, kernel_variant=variant)
 for view in ["V0", "V1", "V2"]:
     W.set_view(rt, view)
+    rt.draw(frames=40)  # lets the cost-feedback tile schedule (default order) settle on this view
     rt.draw(); rt.wait()
     t = rt.wave_timeline().astype(np.int64)
     t0, t1 = t[:, 0].min(), t[:, 1].max()
@@ -26,6 +27,6 @@ for view in ["V0", "V1", "V2"]:
         overlap = np.clip(np.minimum(t[:, 1], b) - np.maximum(t[:, 0], a), 0, None).sum() / (b - a)
         occ.append(overlap)
     print(f"{view}: span {span:.1f} us, waves {len(t)}, wave duration mean {dur.mean():.1f} us p50 {np.median(dur):.1f} p99 {np.percentile(dur, 99):.1f} max {dur.max():.1f}; "
-          f"mean resident waves {dur.sum() / span:.0f} (capacity 4096 at 4 waves/SIMD)")
+          f"mean resident waves {dur.sum() / span:.0f} (capacity 6144 at 6 waves/SIMD)")
     print("   resident waves per 5% slice:", " ".join(f"{o:.0f}" for o in occ))
 rt.deinit()

@@ -1124,7 +1124,8 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         // cost-feedback schedule: tiles sorted by the time they took last frame, heaviest first, so the
         // kernel's tail is made of cheap tiles (longest-processing-time-first list scheduling).  Launch
         // order also spreads consecutive tiles over XCDs (block b runs on XCD b % 8).
-        owned = p.tile_schedule[unit];
+        // (stored XCD-major: workgroup b runs on XCD b % 8, and the eight XCDs read disjoint lines of the list)
+        owned = p.tile_schedule[(unit & 7u) * ((p.owned_tiles + 7u) >> 3) + (unit >> 3)];
     } else if (p.tile_order == 6u) {
         // raster order; consecutive tiles go to consecutive XCDs: every XCD samples the whole image
         // (a contiguous band per XCD measured 22-28 % slower on the headline frame: sky bands idle)
@@ -1238,9 +1239,11 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     }
 #endif
     if (p.tile_order == 5u) {
-        // one relaxed add per wave: the tile's cost for the next frame's schedule
+        // the wave's cycles, one plain store per wave into its own slot: the tile's cost for the next schedule.  (An
+        // atomic add per wave into one word per tile measured 4.5 % of the kernel: the wave's slot is held until the
+        // atomic is acknowledged.)
         const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
-        if (lane == 0) atomicAdd(&p.tile_cost[owned], (uint32_t)(dt >> 6));
+        if (lane == 0) p.tile_cost[owned * 4u + wave] = (uint32_t)(dt >> 6);
     }
     if constexpr (COUNT) {
         // wave-level reduction, then one atomic per wave per counter
@@ -1300,39 +1303,80 @@ __global__ __launch_bounds__(256) void vrt_build_status_blocks(const uint32_t *_
     if (lane == 32 && base_word + 1u < nwords) filter[base_word + 1u] = (uint32_t)(nonempty >> 32);
 }
 
-// Cost-feedback schedule: order[] = owned tile ids sorted by cost (previous frame's wave-cycles),
-// heaviest first, by a 256-bucket counting sort; cost[] is cleared for the next frame.  One workgroup.
-// The order inside a bucket is whatever the atomics give: it affects timing only, never pixels.
-__global__ __launch_bounds__(1024) void vrt_schedule_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n) {
+// Cost-feedback schedule: order[] = owned tile ids in kScheduleBuckets classes of cost (wave-cycles accumulated
+// since the last sort, relative to the maximum), heaviest class first; INSIDE a class the tiles keep the default
+// reverse-raster order, so that consecutive workgroups still render neighbouring tiles (a full sort by cost
+// measured 6-7 % slower on views without outliers: neighbouring tiles share the lines of the bitmaps they walk).
+// One workgroup.  cost[] (four words per tile, one per wave, overwritten by every frame) is summed into snap[]
+// first: frames on another stream may still be writing cost[], and every pass below must see the same values
+// or order[] would not be a permutation.  The order affects timing only, never pixels.
+constexpr uint32_t kScheduleBuckets = 8u;
+__global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ snap,
+                                                            const uint32_t *prev_order, uint32_t *order, uint32_t n) {
     __shared__ uint32_t s_max;
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t start[256];
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t wave_total[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     if (tid == 0) s_max = 0u;
-    if (tid < 256u) hist[tid] = 0u;
     __syncthreads();
     uint32_t m = 0u;
-    for (uint32_t i = tid; i < n; i += 1024u) m = max(m, cost[i]);
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down(m, off, 64));
-    if ((tid & 63u) == 0u) atomicMax(&s_max, m);
-    __syncthreads();
-    const uint32_t mx = s_max;
-    if (mx == 0u) return; // no measurement yet (first frame): keep the current order
-    const float scale = 255.0f / (float)mx;
-    for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[(uint32_t)((float)cost[i] * scale)], 1u);
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t acc = 0u;
-        for (int b = 255; b >= 0; b--) { // heaviest bucket first
-            start[b] = acc;
-            acc += hist[b];
-        }
-    }
-    __syncthreads();
     for (uint32_t i = tid; i < n; i += 1024u) {
-        const uint32_t b = (uint32_t)((float)cost[i] * scale);
-        order[atomicAdd(&start[b], 1u)] = i;
-        cost[i] = 0u;
+        const uint4 w = reinterpret_cast<const uint4 *>(cost)[i]; // the four waves of the tile, most recent frame
+        const uint32_t v = w.x + w.y + w.z + w.w;
+        snap[i] = v;
+        m = max(m, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down(m, off, 64));
+    if (lane == 0u) atomicMax(&s_max, m);
+    __syncthreads(); // (also orders the snap[] writes before the reads of other threads below)
+    const uint32_t mx = s_max;
+    if (mx == 0u) { // no measurement yet: keep the current order
+        if (order != prev_order)
+            for (uint32_t i = tid; i < 8u * ((n + 7u) >> 3); i += 1024u) order[i] = prev_order[i];
+        return;
+    }
+    const float scale = (float)kScheduleBuckets / (float)mx;
+    // thread t owns positions [lo, hi) of the default order (position j = tile n-1-j)
+    const uint32_t chunk = (n + 1023u) / 1024u;
+    const uint32_t lo = min(n, tid * chunk), hi = min(n, lo + chunk);
+    uint32_t cnt[kScheduleBuckets];
+#pragma unroll
+    for (uint32_t b = 0; b < kScheduleBuckets; b++) cnt[b] = 0u;
+    for (uint32_t j = lo; j < hi; j++) {
+        const uint32_t b = min(kScheduleBuckets - 1u, (uint32_t)((float)snap[n - 1u - j] * scale));
+#pragma unroll
+        for (uint32_t k = 0; k < kScheduleBuckets; k++) cnt[k] += (k == b) ? 1u : 0u;
+    }
+    // exclusive scan of every class over the threads, heaviest class first
+    uint32_t base = 0u;
+    uint32_t pos[kScheduleBuckets];
+#pragma unroll
+    for (int b = (int)kScheduleBuckets - 1; b >= 0; b--) {
+        uint32_t incl = cnt[b];
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+            if (lane >= (uint32_t)off) incl += up;
+        }
+        __syncthreads(); // wave_total of the previous class has been read
+        if (lane == 63u) wave_total[wv] = incl;
+        __syncthreads();
+        uint32_t before = 0u, total = 0u;
+        for (uint32_t k = 0; k < 16u; k++) {
+            const uint32_t t = wave_total[k];
+            before += (k < wv) ? t : 0u;
+            total += t;
+        }
+        pos[b] = base + before + incl - cnt[b];
+        base += total;
+    }
+    for (uint32_t j = lo; j < hi; j++) {
+        const uint32_t tile = n - 1u - j;
+        const uint32_t b = min(kScheduleBuckets - 1u, (uint32_t)((float)snap[tile] * scale));
+        uint32_t at = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kScheduleBuckets; k++) {
+            if (k == b) at = pos[k]++;
+        }
+        order[(at & 7u) * ((n + 7u) >> 3) + (at >> 3)] = tile; // XCD-major, see the trace kernel
     }
 }
 
@@ -1482,8 +1526,8 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
     return hipGetLastError();
 }
 
-hipError_t launch_schedule(uint32_t *cost, uint32_t *order, uint32_t n, hipStream_t stream) {
-    hipLaunchKernelGGL(vrt_schedule_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
+hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(vrt_schedule_kernel, dim3(1), dim3(1024), 0, stream, cost, snap, prev_order, order, n);
     return hipGetLastError();
 }
 
