@@ -72,8 +72,9 @@ struct TraceParams {
     // block index bx + nbx*(bz + nbz*by), bit (x&3) + 4*(z&3) + 16*(y&3)  (x, z, y order as comp:318)
     const uint2 *status_blocks;
     uint32_t nbx, nby, nbz;
-    // cost-feedback schedule (tile_order 5): tile_cost[i] accumulates the wave-cycles the i-th owned
-    // tile took in the previous frame(s); tile_schedule[k] is the owned tile the k-th workgroup renders
+    // cost-feedback schedule (tile_order 5): tile_cost[4*i + w] = cycles/64 that wave w of the i-th owned tile took in the
+    // most recent frame; tile_schedule (stored XCD-major: entry of workgroup k at (k % 8) * ceil(n / 8) + k / 8) is the
+    // owned tile the k-th workgroup renders
     uint32_t *tile_cost;
     unsigned long long *wave_timeline;   // optional (measurement): [begin,end] wall-clock ticks per wave, 2 u64 each
     const uint32_t *tile_schedule;
@@ -84,8 +85,9 @@ struct TraceParams {
     uint32_t brick_batch;                // lanes that must be waiting before a batched voxel-level walk runs (bounce frames)
     uint32_t block_threads;              // 256, or 512 for kVariantLinearLds512
     uint32_t wave_groups;                // 1: launch one 64-thread workgroup per 8x8 block instead of 256 per 16x16 tile
-    uint32_t tile_order;                 // workgroup -> tile mapping: 0 default (= 3), 1 row bands per XCD, 2 column bands per XCD,
-                                         // 3 reverse raster, 4 strided, 5 cost-feedback schedule, 6 raster
+    uint32_t tile_order;                 // workgroup -> tile mapping: 1 row bands per XCD, 2 column bands per XCD, 3 reverse raster, 4 strided,
+                                         // 5 cost-feedback schedule, 6 raster.  (kernel_variant: 0 = the library chooses between 3 and the
+                                         // schedule re-sorted every 16 frames, which is 7 there; 5 there re-sorts before every frame)
 };
 
 constexpr int kMaxBatchFrames = 8;
