@@ -582,7 +582,12 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     // default: frames that run one at a time take the amortised cost-feedback schedule (7); frames that alternate between
     // the two streams of a frames_in_flight = 2 context take reverse raster (3), see do_dispatch and DESIGN.md §4
     c->order_auto = (p.tile_order == 0u);
-    if (p.tile_order == 0u) p.tile_order = 7u;
+    if (p.tile_order == 0u) {
+        // a frame whose workgroups are all resident at once (6 per CU at 6 waves per SIMD) has no launch order to speak of
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
+        p.tile_order = (sh.owned_tiles > 6u * (uint32_t)cus) ? 7u : 3u;
+    }
     if (p.tile_order == 7u) {
         // the cost-feedback schedule, re-sorted every 16 frames instead of every frame: the kernel sees order 5
         p.tile_order = 5u;
