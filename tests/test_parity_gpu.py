@@ -123,15 +123,17 @@ def test_sharded_tiles_reassemble_to_full_frame():
 
 @pytest.mark.parametrize("frames_in_flight", [1, 2])
 def test_amortised_tile_schedule_keeps_every_frame_identical(frames_in_flight):
-    """kernel_variant 0x70000: tiles ordered by the cost measured over the previous 16 frames, re-sorted into the other of
-    two schedule buffers while frames of the second stream may be running.  The order must never change a pixel: 70
-    overlapping frames (four re-sorts) without a read in between, then every frame of a second sequence is compared."""
+    """kernel_variant 0x..70000: tiles launched in the order of their measured cost, re-sorted every 8 frames here (0x3 << 28;
+    32 by default) into the other of two schedule buffers while frames of the second stream may be running; the heaviest
+    tiles are split into two half-tile workgroups (on this small frame every re-sort splits as many as it has spare entries
+    for).  Order and splitting must never change a pixel: 70 overlapping frames without a read in between, then every frame
+    of a second sequence is compared."""
     w = W.Workload("t", 320, 200, 64, 4, 1, 0, True, 0.0)
     grid = W.build_grid(w)
     ref = {}
     for view in ["V0", "V1", "V2"]:
         _, ref[view], _, _ = _run_hip(w, grid, view, counters=False)
-    rt = W.make_renderer(w, grid, frames_in_flight=frames_in_flight, kernel_variant=0x70000)
+    rt = W.make_renderer(w, grid, frames_in_flight=frames_in_flight, kernel_variant=0x30070000)
     for i in range(70):
         W.set_view(rt, ["V0", "V1", "V2"][(i // 5) % 3])
         rt.draw()

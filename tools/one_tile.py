@@ -22,7 +22,7 @@ for variant in variants:
     print(f"variant {variant:#x} {rt.kernel_name()}: tile ({tx},{ty}) alone {rt.last_kernel_ms()*1000:.1f} us; 4 waves: grid trips {wc['wave_grid_iters']} brick walks {wc['wave_brick_walks']} "
           f"voxel trips {wc['wave_voxel_iters']}; lanes: grid steps {c['grid_steps']} bricks {c['bricks_entered']} voxel steps {c['voxel_steps']} hits {c['hits']} rays {c['rays']}")
     if profile:  # library built with make EXTRA=-DVRT_DEV_PROFILE: core-clock cycles per phase, summed over the 4 waves
-        pr = rt.wave_timeline().reshape(-1)[:8]
+        pr = rt.wave_timeline(raw=True).reshape(-1)[:8]
         names = ["grid loop", "brick walks (all)", "voxel loops", "grid_hit setup", "material test", "-", "-", "whole wave"]
         print("   cycles summed over 4 waves:", ", ".join(f"{n} {int(v)}" for n, v in zip(names, pr) if n != "-"))
     rt.deinit(); rc.deinit()

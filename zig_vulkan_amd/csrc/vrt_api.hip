@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h> // types and prototypes only: the library is reached through dlopen, not linked
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,7 +26,8 @@ KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t varian
 uint32_t resolve_variant(uint32_t variant);
 size_t trace_lds_bytes(const TraceParams &p, uint32_t variant);
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream, uint32_t frames = 1);
-hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, hipStream_t stream);
+hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra, uint32_t wave_slots,
+                           hipStream_t stream);
 hipError_t launch_assemble_rgb(const void *gathered, void *frame, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t shard_count,
                                uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream, uint32_t frames, uint32_t frame_src_stride_bytes);
 hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
@@ -140,6 +142,7 @@ struct vrt_ctx {
     // amortised cost-feedback schedule (tile_order 7): re-sorted every sched_period frames into the other buffer
     uint32_t sched_period = 0, sched_since = 0, sched_cur = 0;
     bool order_auto = false; // kernel_variant left the tile order to the library
+    uint32_t tile_order = 0, sched_extra = 0, sched_stride = 0, wave_slots = 0;
     uint64_t sched_seq = 0, b_seen_sched = 0;
     hipEvent_t ev_sched = nullptr, ev_b_sched = nullptr;
     bool b_sched_recorded = false;
@@ -510,22 +513,36 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     {
         // tile schedule starts as reverse raster (bottom rows first); the feedback kernel refines it
         const uint32_t n = sh.owned_tiles ? sh.owned_tiles : 1u;
-        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_tile_cost), n * 16u)); // one word per wave of a tile
-        const uint32_t ns = 8u * ((n + 7u) / 8u); // an order buffer is stored XCD-major: 8 rows of ceil(n / 8)
-        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_tile_schedule), 3u * (size_t)ns * 4u)); // order A, order B, snapshot
-        VRT_CREATE_HIP(hipMemsetAsync(c->d_tile_cost, 0, n * 16u, c->stream));
-        uint32_t *init = static_cast<uint32_t *>(std::calloc(ns, 4u));
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
+        c->wave_slots = 24u * (uint32_t)cus; // 4 SIMDs x 6 waves of the trace kernel per CU
+        // default order: frames that run one at a time take the amortised cost-feedback schedule (7) unless all their workgroups
+        // are resident at once (6 per CU: no launch order to speak of); the amortised schedule may split tiles (spare entries)
+        uint32_t order = (cfg->kernel_variant >> 16) & 0xFu;
+        c->order_auto = (order == 0u);
+        if (order == 0u) order = (n > 6u * (uint32_t)cus) ? 7u : 3u;
+        c->tile_order = order;
+        const bool plain_tiles = !((cfg->kernel_variant >> 20) & 0x1u) && (vrt::resolve_variant(cfg->kernel_variant) & 0xFFu) != vrt::kVariantLinearLds512;
+        c->sched_extra = (order == 7u && plain_tiles) ? std::min(1024u, n / 8u) : 0u;
+        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_tile_cost), n * 32u)); // [half][tile][wave]
+        const uint32_t ns = 8u * ((n + c->sched_extra + 7u) / 8u); // an order buffer is stored XCD-major: 8 rows of ceil((n + extra) / 8)
+        c->sched_stride = ns;
+        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_tile_schedule), (2u * (size_t)ns + 2u * (size_t)n) * 4u)); // order A, order B, snapshot + split state
+        VRT_CREATE_HIP(hipMemsetAsync(c->d_tile_cost, 0, n * 32u, c->stream));
+        VRT_CREATE_HIP(hipMemsetAsync(c->d_tile_schedule + 2u * (size_t)ns, 0, 2u * (size_t)n * 4u, c->stream));
+        uint32_t *init = static_cast<uint32_t *>(std::malloc((size_t)ns * 4u));
         if (!init) {
             free_ctx(c);
             return fail(nullptr, VRT_E_OOM, "host allocation failed");
         }
+        std::memset(init, 0xFF, (size_t)ns * 4u); // spare entries: idle workgroups
         for (uint32_t i = 0; i < n; i++) init[(i & 7u) * (ns / 8u) + (i >> 3)] = n - 1u - i;
         const hipError_t e = hipMemcpy(c->d_tile_schedule, init, ns * 4u, hipMemcpyHostToDevice);
         std::free(init);
         VRT_CREATE_HIP(e);
         // first launch of the schedule kernel now (code-object load, about 2 ms, stays out of the frames): with no cost
         // measured yet it copies the initial order into the second buffer
-        if (n > 1u) VRT_CREATE_HIP(vrt::launch_schedule(c->d_tile_cost, c->d_tile_schedule + 2u * (size_t)ns, c->d_tile_schedule, c->d_tile_schedule + ns, n, c->stream));
+        if (n > 1u) VRT_CREATE_HIP(vrt::launch_schedule(c->d_tile_cost, c->d_tile_schedule + 2u * (size_t)ns, c->d_tile_schedule, c->d_tile_schedule + ns, n, c->sched_extra, c->wave_slots, c->stream));
     }
     for (int i = 0; i < kStagingSlots; i++) {
         VRT_CREATE_HIP(hipHostMalloc(&c->staging[i], kStagingSlotBytes, hipHostMallocDefault));
@@ -578,20 +595,14 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     // (the u31 start-index check above), so it always reaches
     p.occupancy_words = (uint32_t)(c->dsize[VRT_BUF_BRICK_OCCUPANCY] / 4u);
     p.status_blocks = static_cast<const uint2 *>(c->d_status_blocks);
-    p.tile_order = (cfg->kernel_variant >> 16) & 0xFu;
-    // default: frames that run one at a time take the amortised cost-feedback schedule (7); frames that alternate between
-    // the two streams of a frames_in_flight = 2 context take reverse raster (3), see do_dispatch and DESIGN.md §4
-    c->order_auto = (p.tile_order == 0u);
-    if (p.tile_order == 0u) {
-        // a frame whose workgroups are all resident at once (6 per CU at 6 waves per SIMD) has no launch order to speak of
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
-        p.tile_order = (sh.owned_tiles > 6u * (uint32_t)cus) ? 7u : 3u;
-    }
+    // (order_auto: frames that alternate between the two streams of a frames_in_flight = 2 context take reverse raster (3)
+    // instead, see do_dispatch and DESIGN.md §4)
+    p.tile_order = c->tile_order;
+    p.sched_extra = c->sched_extra;
     if (p.tile_order == 7u) {
-        // the cost-feedback schedule, re-sorted every 16 frames instead of every frame: the kernel sees order 5
+        // the cost-feedback schedule, re-sorted every 32 frames instead of every frame: the kernel sees order 5
         p.tile_order = 5u;
-        c->sched_period = (cfg->kernel_variant >> 28) ? (1u << (cfg->kernel_variant >> 28)) : 16u; // tuning knob: log2 of the period
+        c->sched_period = (cfg->kernel_variant >> 28) ? (1u << (cfg->kernel_variant >> 28)) : 32u; // tuning knob: log2 of the period
         VRT_CREATE_HIP(hipEventCreateWithFlags(&c->ev_sched, hipEventDisableTiming));
         VRT_CREATE_HIP(hipEventCreateWithFlags(&c->ev_b_sched, hipEventDisableTiming));
     }
@@ -781,10 +792,10 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     }
     VRT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     const uint32_t nt = ctx->shard.owned_tiles;
-    const uint32_t ns = 8u * ((nt + 7u) / 8u); // stride of a schedule buffer
+    const uint32_t ns = ctx->sched_stride; // stride of a schedule buffer
     if (ctx->params.tile_order == 5u && nt > 1u && !ctx->sched_period) {
         // re-sort the tile list by last frame's measured cost (inside the timed region: it is per-frame work)
-        VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule + 2u * (size_t)ns, ctx->d_tile_schedule, ctx->d_tile_schedule, nt, ctx->stream));
+        VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule + 2u * (size_t)ns, ctx->d_tile_schedule, ctx->d_tile_schedule, nt, 0u, ctx->wave_slots, ctx->stream));
     }
     if (ctx->order_auto && ctx->stream_b && frames == 1 && !primary_only) {
         // the even frames of two frames in flight: the other stream fills this frame's tail, and reverse raster keeps
@@ -802,11 +813,14 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     }
     for (uint32_t f = 0; f < frames; f++) {
         if (ctx->sched_period && nt > 1u && ctx->sched_since >= ctx->sched_period) {
-            // amortised re-sort (inside the timed region as well): costs summed over the last sched_period frames order the
-            // tiles into the buffer no frame reads; frames launched from here on read that one
+            // Amortised re-sort, in the frames' own stream (inside the timed region as well): the most recent frame's costs
+            // order the tiles into the buffer no frame reads; frames launched from here on read that one.  A sort costs about
+            // 35 us of the stream's time (18 us of kernel plus the two kernel boundaries).  Measured alternatives: on a second
+            // stream with event waits 80 us per sort; on a second stream with the host polling for its completion nothing, but
+            // then the order lags behind frames that are queued ahead (vrt_dispatch_repeat) by a whole call.
             if (ctx->b_sched_recorded) VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_b_sched, 0)); // (signalled a period ago)
             uint32_t *cur = ctx->d_tile_schedule + (size_t)ctx->sched_cur * ns, *alt = ctx->d_tile_schedule + (size_t)(ctx->sched_cur ^ 1u) * ns;
-            VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule + 2u * (size_t)ns, cur, alt, nt, ctx->stream));
+            VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule + 2u * (size_t)ns, cur, alt, nt, ctx->sched_extra, ctx->wave_slots, ctx->stream));
             VRT_HIP(ctx, hipEventRecord(ctx->ev_sched, ctx->stream));
             ctx->sched_cur ^= 1u;
             ctx->params.tile_schedule = alt;
@@ -958,7 +972,9 @@ int vrt_assemble_frame(vrt_ctx *ctx, const void *gathered, void *dst_frame, uint
 int vrt_trace_wave_timeline(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint64_t *out, uint64_t capacity_pairs,
                             uint64_t *n_pairs) {
     if (!ctx || !out || !n_pairs) return VRT_E_INVALID_ARG;
-    const uint64_t waves = (uint64_t)ctx->shard.owned_tiles * 4u;
+    // (the cost-ordered launch has spare workgroups for the halves of split tiles: their waves are listed too; a workgroup that
+    // stayed idle leaves zeros)
+    const uint64_t waves = ((uint64_t)ctx->shard.owned_tiles + (ctx->params.tile_order == 5u ? ctx->sched_extra : 0u)) * 4u;
     if (capacity_pairs < waves) return fail(ctx, VRT_E_OUT_OF_RANGE, "timeline buffer too small");
     DeviceGuard dg(ctx->device);
     unsigned long long *d = nullptr;

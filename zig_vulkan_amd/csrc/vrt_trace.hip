@@ -1120,12 +1120,21 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const uint32_t wave = p.wave_groups ? (blockIdx.x & 3u) : ((threadIdx.x >> 6) & 3u);
     if (BLOCK == 512 && unit >= p.owned_tiles) return; // odd tile count: the last workgroup's second half is idle
     uint32_t owned;
+    uint32_t split = 0u, half = 0u; // split: this workgroup renders one half of the tile (rows 4*half .. 4*half+3 of each 8x8 block)
     if (p.tile_order == 5u) {
         // cost-feedback schedule: tiles sorted by the time they took last frame, heaviest first, so the
         // kernel's tail is made of cheap tiles (longest-processing-time-first list scheduling).  Launch
         // order also spreads consecutive tiles over XCDs (block b runs on XCD b % 8).
         // (stored XCD-major: workgroup b runs on XCD b % 8, and the eight XCDs read disjoint lines of the list)
-        owned = p.tile_schedule[(unit & 7u) * ((p.owned_tiles + 7u) >> 3) + (unit >> 3)];
+        // An entry with bit 31 renders HALF of its tile (bit 30 says which) on 32 lanes per wave: the schedule kernel
+        // splits the tiles whose slowest wave would otherwise outlast the rest of the frame (the lanes of such a wave
+        // walk their bricks one after the other; half the lanes, fewer separate walks: 88 -> 70 us for the slowest
+        // tile of view V1).  The list has p.sched_extra spare entries for the second halves; unused ones are ~0.
+        const uint32_t entry = p.tile_schedule[(unit & 7u) * ((p.owned_tiles + p.sched_extra + 7u) >> 3) + (unit >> 3)];
+        if (entry == 0xFFFFFFFFu) return; // a spare entry (uniform over the workgroup)
+        owned = entry & 0x3FFFFFFFu;
+        split = entry >> 31;
+        half = (entry >> 30) & 1u;
     } else if (p.tile_order == 6u) {
         // raster order; consecutive tiles go to consecutive XCDs: every XCD samples the whole image
         // (a contiguous band per XCD measured 22-28 % slower on the headline frame: sky bands idle)
@@ -1151,7 +1160,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const uint32_t lane = threadIdx.x & 63u;
     const PushConstants &pc = p.pcs[blockIdx.y]; // frame blockIdx.y of this launch (kernarg segment, scalar loads)
     const uint32_t in_x = (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t in_y = (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t in_y = (wave >> 1) * 8u + (split ? half * 4u + ((lane >> 3) & 3u) : (lane >> 3));
     const uint32_t px = tile_x * kTileW + in_x;
     const uint32_t py = tile_y * kTileH + in_y;
 
@@ -1163,7 +1172,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const unsigned long long t_begin = (p.tile_order == 5u) ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long wall_begin = p.wave_timeline ? wall_clock64() : 0ull;
     Cnt<COUNT> c;
-    const bool inside = (px < p.width) && (py < p.height); // comp:155-159
+    const bool inside = (px < p.width) && (py < p.height) && (!split || lane < 32u); // comp:155-159
     uint32_t rgba = 0u; // this lane's pixel (0 outside the image), also needed after the branch by the RGB shard store
     if (inside) {
         f3 color = mk3(0, 0, 0);
@@ -1243,7 +1252,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         // atomic add per wave into one word per tile measured 4.5 % of the kernel: the wave's slot is held until the
         // atomic is acknowledged.)
         const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
-        if (lane == 0) p.tile_cost[owned * 4u + wave] = (uint32_t)(dt >> 6);
+        if (lane == 0) p.tile_cost[((size_t)half * p.owned_tiles + owned) * 4u + wave] = (uint32_t)(dt >> 6);
     }
     if constexpr (COUNT) {
         // wave-level reduction, then one atomic per wave per counter
@@ -1303,54 +1312,105 @@ __global__ __launch_bounds__(256) void vrt_build_status_blocks(const uint32_t *_
     if (lane == 32 && base_word + 1u < nwords) filter[base_word + 1u] = (uint32_t)(nonempty >> 32);
 }
 
-// Cost-feedback schedule: order[] = owned tile ids in kScheduleBuckets classes of cost (wave-cycles accumulated
-// since the last sort, relative to the maximum), heaviest class first; INSIDE a class the tiles keep the default
+// Cost-feedback schedule: order[] = owned tile ids in kScheduleBuckets classes of cost (wave-cycles of the most
+// recent frame, relative to the maximum), heaviest class first; INSIDE a class the tiles keep the default
 // reverse-raster order, so that consecutive workgroups still render neighbouring tiles (a full sort by cost
 // measured 6-7 % slower on views without outliers: neighbouring tiles share the lines of the bitmaps they walk).
-// One workgroup.  cost[] (four words per tile, one per wave, overwritten by every frame) is summed into snap[]
-// first: frames on another stream may still be writing cost[], and every pass below must see the same values
-// or order[] would not be a permutation.  The order affects timing only, never pixels.
+// With extra > 0 the tiles whose slowest wave would outlast the rest of the frame (longer than 1.25 x the frame's
+// wave-cycles spread over all wave slots) are SPLIT: two entries, each renders half of the tile with 32 lanes per
+// wave, in a class of their own at the front; at most `extra` tiles, unused spare entries are ~0.  snap[n .. 2n)
+// remembers which tiles are split (their measured waves are scaled back up by 1.28 before the test, the measured
+// gain of splitting, so that a split tile does not flip back and forth).
+// One workgroup.  cost[] ([half][tile][wave], overwritten by every frame) is condensed into snap[] first: frames
+// on another stream may still be writing cost[], and every pass below must see the same values or order[] would
+// not be a permutation.  The order affects timing only, never pixels.
 constexpr uint32_t kScheduleBuckets = 8u;
 __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ snap,
-                                                            const uint32_t *prev_order, uint32_t *order, uint32_t n) {
-    __shared__ uint32_t s_max;
+                                                            const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra,
+                                                            uint32_t wave_slots) {
+    __shared__ uint32_t s_max, s_nsplit, s_longest;
+    __shared__ unsigned long long s_total;
     __shared__ uint32_t wave_total[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    if (tid == 0) s_max = 0u;
-    __syncthreads();
-    uint32_t m = 0u;
-    for (uint32_t i = tid; i < n; i += 1024u) {
-        const uint4 w = reinterpret_cast<const uint4 *>(cost)[i]; // the four waves of the tile, most recent frame
-        const uint32_t v = w.x + w.y + w.z + w.w;
-        snap[i] = v;
-        m = max(m, v);
+    uint32_t *state = snap + n;
+    const uint32_t row = (n + extra + 7u) >> 3; // order[] is stored XCD-major: entry k at (k % 8) * row + k / 8
+    if (tid == 0) {
+        s_max = 0u;
+        s_nsplit = 0u;
+        s_longest = 0u;
+        s_total = 0ull;
     }
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down(m, off, 64));
-    if (lane == 0u) atomicMax(&s_max, m);
-    __syncthreads(); // (also orders the snap[] writes before the reads of other threads below)
+    __syncthreads();
+    uint32_t m = 0u, ml = 0u;
+    unsigned long long total = 0ull;
+    const uint4 *cost4 = reinterpret_cast<const uint4 *>(cost);
+    for (uint32_t i = tid; i < n; i += 1024u) {
+        const uint4 w = cost4[i]; // the four waves of the tile, most recent frame
+        uint32_t v = w.x + w.y + w.z + w.w;
+        uint32_t longest = max(max(w.x, w.y), max(w.z, w.w));
+        const uint32_t was_split = extra ? (state[i] & 1u) : 0u;
+        if (was_split) {
+            const uint4 w2 = cost4[n + i]; // the waves of the second half
+            v += w2.x + w2.y + w2.z + w2.w;
+            longest = max(longest, max(max(w2.x, w2.y), max(w2.z, w2.w)));
+            longest += (longest >> 2) + (longest >> 5); // what the wave would take unsplit
+        }
+        snap[i] = v;
+        state[i] = (min(longest, 0x7FFFFFFFu) << 1) | was_split;
+        m = max(m, v);
+        ml = max(ml, longest);
+        total += v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        m = max(m, (uint32_t)__shfl_down(m, off, 64));
+        ml = max(ml, (uint32_t)__shfl_down(ml, off, 64));
+        total += __shfl_down(total, off, 64);
+    }
+    if (lane == 0u) {
+        atomicMax(&s_max, m);
+        atomicMax(&s_longest, ml);
+        atomicAdd(&s_total, total);
+    }
+    __syncthreads(); // (also orders the snap[] / state[] writes before the reads of other threads below)
     const uint32_t mx = s_max;
     if (mx == 0u) { // no measurement yet: keep the current order
         if (order != prev_order)
-            for (uint32_t i = tid; i < 8u * ((n + 7u) >> 3); i += 1024u) order[i] = prev_order[i];
+            for (uint32_t i = tid; i < 8u * row; i += 1024u) order[i] = prev_order[i];
+        for (uint32_t i = tid; i < n; i += 1024u) state[i] &= 1u;
         return;
     }
-    const float scale = (float)kScheduleBuckets / (float)mx;
+    // A frame whose slowest wave is well below the time the frame needs anyway (its wave-cycles spread over all wave
+    // slots) keeps the plain reverse-raster order: there the launch order cannot shorten anything, and any re-ordering
+    // measured 2-3 % slower (view V0).  Otherwise: cost classes, and which tiles to split.
+    const unsigned long long par = s_total / (wave_slots ? wave_slots : 1u);
+    const bool reorder = (unsigned long long)s_longest * 4ull > par * 3ull;
+    const unsigned long long threshold = par + (par >> 2);
+    for (uint32_t i = tid; i < n; i += 1024u) {
+        uint32_t want = (reorder && extra && (unsigned long long)(state[i] >> 1) > threshold) ? 1u : 0u;
+        if (want && atomicAdd(&s_nsplit, 1u) >= extra) want = 0u; // no spare entry left
+        state[i] = want;
+    }
+    __syncthreads();
+    const uint32_t nsplit = min(s_nsplit, extra);
+    const float scale = reorder ? (float)kScheduleBuckets / (float)mx : 0.0f; // (0: one class, i.e. reverse raster)
     // thread t owns positions [lo, hi) of the default order (position j = tile n-1-j)
     const uint32_t chunk = (n + 1023u) / 1024u;
     const uint32_t lo = min(n, tid * chunk), hi = min(n, lo + chunk);
-    uint32_t cnt[kScheduleBuckets];
+    uint32_t cnt[kScheduleBuckets + 1u]; // class kScheduleBuckets: the halves of split tiles
 #pragma unroll
-    for (uint32_t b = 0; b < kScheduleBuckets; b++) cnt[b] = 0u;
+    for (uint32_t b = 0; b <= kScheduleBuckets; b++) cnt[b] = 0u;
     for (uint32_t j = lo; j < hi; j++) {
-        const uint32_t b = min(kScheduleBuckets - 1u, (uint32_t)((float)snap[n - 1u - j] * scale));
+        const uint32_t tile = n - 1u - j;
+        const uint32_t sp = state[tile];
+        const uint32_t b = sp ? kScheduleBuckets : min(kScheduleBuckets - 1u, (uint32_t)((float)snap[tile] * scale));
 #pragma unroll
-        for (uint32_t k = 0; k < kScheduleBuckets; k++) cnt[k] += (k == b) ? 1u : 0u;
+        for (uint32_t k = 0; k <= kScheduleBuckets; k++) cnt[k] += (k == b) ? (1u + sp) : 0u;
     }
     // exclusive scan of every class over the threads, heaviest class first
     uint32_t base = 0u;
-    uint32_t pos[kScheduleBuckets];
+    uint32_t pos[kScheduleBuckets + 1u];
 #pragma unroll
-    for (int b = (int)kScheduleBuckets - 1; b >= 0; b--) {
+    for (int b = (int)kScheduleBuckets; b >= 0; b--) {
         uint32_t incl = cnt[b];
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
@@ -1359,25 +1419,35 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__re
         __syncthreads(); // wave_total of the previous class has been read
         if (lane == 63u) wave_total[wv] = incl;
         __syncthreads();
-        uint32_t before = 0u, total = 0u;
+        uint32_t before = 0u, total_b = 0u;
         for (uint32_t k = 0; k < 16u; k++) {
             const uint32_t t = wave_total[k];
             before += (k < wv) ? t : 0u;
-            total += t;
+            total_b += t;
         }
         pos[b] = base + before + incl - cnt[b];
-        base += total;
+        base += total_b;
     }
     for (uint32_t j = lo; j < hi; j++) {
         const uint32_t tile = n - 1u - j;
-        const uint32_t b = min(kScheduleBuckets - 1u, (uint32_t)((float)snap[tile] * scale));
+        const uint32_t sp = state[tile];
+        const uint32_t b = sp ? kScheduleBuckets : min(kScheduleBuckets - 1u, (uint32_t)((float)snap[tile] * scale));
         uint32_t at = 0u;
 #pragma unroll
-        for (uint32_t k = 0; k < kScheduleBuckets; k++) {
-            if (k == b) at = pos[k]++;
+        for (uint32_t k = 0; k <= kScheduleBuckets; k++) {
+            if (k == b) {
+                at = pos[k];
+                pos[k] += 1u + sp;
+            }
         }
-        order[(at & 7u) * ((n + 7u) >> 3) + (at >> 3)] = tile; // XCD-major, see the trace kernel
+        if (sp) {
+            order[(at & 7u) * row + (at >> 3)] = tile | 0x80000000u;
+            order[((at + 1u) & 7u) * row + ((at + 1u) >> 3)] = tile | 0xC0000000u;
+        } else {
+            order[(at & 7u) * row + (at >> 3)] = tile;
+        }
     }
+    for (uint32_t at = n + nsplit + tid; at < 8u * row; at += 1024u) order[(at & 7u) * row + (at >> 3)] = 0xFFFFFFFFu; // idle workgroups
 }
 
 // Root-side un-swizzle of gathered shards (rank-major, tile-major) into a
@@ -1522,12 +1592,13 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
     // frame 0 start first
     if (p.block_threads == 512u) hipLaunchKernelGGL(fn, dim3((p.owned_tiles + 1u) / 2u, frames), dim3(512), lds_bytes, stream, p);
     else if (p.wave_groups) hipLaunchKernelGGL(fn, dim3(p.owned_tiles * 4u, frames), dim3(64), lds_bytes, stream, p);
-    else hipLaunchKernelGGL(fn, dim3(p.owned_tiles, frames), dim3(256), lds_bytes, stream, p);
+    else hipLaunchKernelGGL(fn, dim3(p.owned_tiles + (p.tile_order == 5u ? p.sched_extra : 0u), frames), dim3(256), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
-hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, hipStream_t stream) {
-    hipLaunchKernelGGL(vrt_schedule_kernel, dim3(1), dim3(1024), 0, stream, cost, snap, prev_order, order, n);
+hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra,
+                           uint32_t wave_slots, hipStream_t stream) {
+    hipLaunchKernelGGL(vrt_schedule_kernel, dim3(1), dim3(1024), 0, stream, cost, snap, prev_order, order, n, extra, wave_slots);
     return hipGetLastError();
 }
 

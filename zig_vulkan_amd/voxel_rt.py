@@ -363,14 +363,16 @@ class VoxelRT:
         check(lib.vrt_get_counters(self._h, C.byref(c)), self._h)
         return {k: getattr(c, k) for k, _ in L.Counters._fields_}
 
-    def wave_timeline(self) -> np.ndarray:
-        """One frame with per-wave [begin, end] wall-clock ticks (100 MHz); shape (waves, 2)."""
-        n = self.shard_info().owned_tiles * 4
+    def wave_timeline(self, raw: bool = False) -> np.ndarray:
+        """One frame with per-wave [begin, end] wall-clock ticks (100 MHz); shape (waves, 2).  The cost-ordered launch has up to
+        1024 spare workgroups (second halves of split tiles); the rows of those that stayed idle are dropped unless raw."""
+        n = (self.shard_info().owned_tiles + 1024) * 4
         out = np.zeros((n, 2), dtype=np.uint64)
         got = C.c_uint64()
         check(lib.vrt_trace_wave_timeline(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data), out.ctypes.data, n,
                                           C.byref(got)), self._h)
-        return out[:got.value]
+        out = out[:got.value]
+        return out if raw else out[out[:, 1] != 0]
 
     def wave_counters(self) -> dict:
         out = (C.c_uint64 * 3)()
