@@ -103,3 +103,31 @@ def test_headline_frames_are_deterministic_with_two_in_flight():
         assert ref.setdefault(view, h) == h, f"frame {i} ({view}) differs"
     rt.deinit()
     assert len(set(ref.values())) == 3
+
+
+def test_headline_cost_ordered_launch_and_split_tiles_keep_the_frame():
+    """One frame at a time (the default tile order of such a context: measured cost, re-sorted every 32 frames, heaviest
+    tiles split into two half-tile workgroups): the first frame of a view (reverse raster, nothing measured yet) and the
+    frame after 70 more are the same bytes, for all three views; on V1 the settled launch really contains split tiles
+    (more waves than 4 per tile)."""
+    import hashlib
+    w = W.WORKLOADS[W.HEADLINE]
+    grid = W.build_grid(w)
+    fresh = {}
+    for view in ["V0", "V1", "V2"]:
+        rt = W.make_renderer(w, grid)
+        W.set_view(rt, view)
+        rt.draw()
+        fresh[view] = hashlib.sha1(rt.read_rgba8().tobytes()).hexdigest()
+        rt.deinit()
+    rt = W.make_renderer(w, grid)
+    tiles = rt.shard_info().owned_tiles
+    for view in ["V1", "V0", "V2", "V1"]:
+        W.set_view(rt, view)
+        rt.draw(frames=70)
+        rt.draw()
+        assert hashlib.sha1(rt.read_rgba8().tobytes()).hexdigest() == fresh[view], view
+    waves = len(rt.wave_timeline())
+    assert waves > tiles * 4, "no tile was split on V1"
+    assert hashlib.sha1(rt.read_rgba8().tobytes()).hexdigest() == fresh["V1"]
+    rt.deinit()
