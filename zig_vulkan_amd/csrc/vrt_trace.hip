@@ -1330,7 +1330,8 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__re
                                                             uint32_t wave_slots) {
     __shared__ uint32_t s_max, s_nsplit, s_longest;
     __shared__ unsigned long long s_total;
-    __shared__ uint32_t wave_total[16];
+    __shared__ uint32_t wave_total[kScheduleBuckets + 1u][16];
+    __shared__ uint32_t class_total[kScheduleBuckets + 1u];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     uint32_t *state = snap + n;
     const uint32_t row = (n + extra + 7u) >> 3; // order[] is stored XCD-major: entry k at (k % 8) * row + k / 8
@@ -1344,6 +1345,7 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__re
     uint32_t m = 0u, ml = 0u;
     unsigned long long total = 0ull;
     const uint4 *cost4 = reinterpret_cast<const uint4 *>(cost);
+#pragma unroll 4
     for (uint32_t i = tid; i < n; i += 1024u) {
         const uint4 w = cost4[i]; // the four waves of the tile, most recent frame
         uint32_t v = w.x + w.y + w.z + w.w;
@@ -1385,6 +1387,7 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__re
     const unsigned long long par = s_total / (wave_slots ? wave_slots : 1u);
     const bool reorder = (unsigned long long)s_longest * 4ull > par * 3ull;
     const unsigned long long threshold = par + (par >> 2);
+#pragma unroll 4
     for (uint32_t i = tid; i < n; i += 1024u) {
         uint32_t want = (reorder && extra && (unsigned long long)(state[i] >> 1) > threshold) ? 1u : 0u;
         if (want && atomicAdd(&s_nsplit, 1u) >= extra) want = 0u; // no spare entry left
@@ -1399,6 +1402,7 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__re
     uint32_t cnt[kScheduleBuckets + 1u]; // class kScheduleBuckets: the halves of split tiles
 #pragma unroll
     for (uint32_t b = 0; b <= kScheduleBuckets; b++) cnt[b] = 0u;
+#pragma unroll 4
     for (uint32_t j = lo; j < hi; j++) {
         const uint32_t tile = n - 1u - j;
         const uint32_t sp = state[tile];
@@ -1406,27 +1410,37 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__re
 #pragma unroll
         for (uint32_t k = 0; k <= kScheduleBuckets; k++) cnt[k] += (k == b) ? (1u + sp) : 0u;
     }
-    // exclusive scan of every class over the threads, heaviest class first
-    uint32_t base = 0u;
+    // exclusive scan of every class over the threads, heaviest class first: inside the wave by shuffles, over the 16 waves
+    // by one thread per class
     uint32_t pos[kScheduleBuckets + 1u];
 #pragma unroll
-    for (int b = (int)kScheduleBuckets; b >= 0; b--) {
+    for (uint32_t b = 0; b <= kScheduleBuckets; b++) {
         uint32_t incl = cnt[b];
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
             if (lane >= (uint32_t)off) incl += up;
         }
-        __syncthreads(); // wave_total of the previous class has been read
-        if (lane == 63u) wave_total[wv] = incl;
-        __syncthreads();
-        uint32_t before = 0u, total_b = 0u;
+        pos[b] = incl - cnt[b]; // exclusive, inside the wave
+        if (lane == 63u) wave_total[b][wv] = incl;
+    }
+    __syncthreads();
+    if (tid <= kScheduleBuckets) {
+        uint32_t acc = 0u;
         for (uint32_t k = 0; k < 16u; k++) {
-            const uint32_t t = wave_total[k];
-            before += (k < wv) ? t : 0u;
-            total_b += t;
+            const uint32_t t = wave_total[tid][k];
+            wave_total[tid][k] = acc; // -> exclusive over the waves
+            acc += t;
         }
-        pos[b] = base + before + incl - cnt[b];
-        base += total_b;
+        class_total[tid] = acc;
+    }
+    __syncthreads();
+    {
+        uint32_t base = 0u;
+#pragma unroll
+        for (int b = (int)kScheduleBuckets; b >= 0; b--) {
+            pos[b] += base + wave_total[b][wv];
+            base += class_total[b];
+        }
     }
     for (uint32_t j = lo; j < hi; j++) {
         const uint32_t tile = n - 1u - j;
