@@ -1357,6 +1357,10 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__re
             longest = max(longest, max(max(w2.x, w2.y), max(w2.z, w2.w)));
             longest += (longest >> 2) + (longest >> 5); // what the wave would take unsplit
         }
+        // (the classes come from the mean of this measurement and the running value: a tile's cycles depend on what
+        // runs beside it, i.e. on the order itself, and an order made from one frame's costs alone keeps changing)
+        const uint32_t prev = snap[i];
+        if (prev) v = (uint32_t)(((unsigned long long)prev + v) >> 1);
         snap[i] = v;
         state[i] = (min(longest, 0x7FFFFFFFu) << 1) | was_split;
         m = max(m, v);
