@@ -1385,11 +1385,11 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__re
         for (uint32_t i = tid; i < n; i += 1024u) state[i] &= 1u;
         return;
     }
-    // A frame whose slowest wave is well below the time the frame needs anyway (its wave-cycles spread over all wave
-    // slots) keeps the plain reverse-raster order: there the launch order cannot shorten anything, and any re-ordering
-    // measured 2-3 % slower (view V0).  Otherwise: cost classes, and which tiles to split.
+    // A frame whose slowest wave is well below (0.6 x) the time the frame needs anyway (its wave-cycles spread over all
+    // wave slots) keeps the plain reverse-raster order: there the launch order cannot shorten anything.  Otherwise: cost
+    // classes, and which tiles to split.
     const unsigned long long par = s_total / (wave_slots ? wave_slots : 1u);
-    const bool reorder = (unsigned long long)s_longest * 4ull > par * 3ull;
+    const bool reorder = (unsigned long long)s_longest * 5ull > par * 3ull;
     const unsigned long long threshold = par + (par >> 2);
 #pragma unroll 4
     for (uint32_t i = tid; i < n; i += 1024u) {
