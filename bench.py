@@ -279,7 +279,9 @@ def main() -> None:
         reps = max(5, args.steps // len(VIEW_ORDER))
         for v in VIEW_ORDER:
             C.memmove(C.byref(rt.camera.d_camera), cams[v], 96)
-            rt.draw()  # one frame of this view first: the tile schedule is built from the previous frame
+            # untimed: the camera has just jumped to this view, and the launch order follows the measured tile costs with
+            # a lag (re-sorted every 32 frames from a running mean): let it settle as it would under a moving camera
+            rt.draw(frames=128)
             rt.draw(frames=reps)
             kernel_ms_view[v] = rt.last_kernel_ms()
         avg_ms = sum(kernel_ms_view.values()) / len(kernel_ms_view)

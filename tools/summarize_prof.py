@@ -20,6 +20,35 @@ for f in sorted(glob.glob(os.path.join(out, "stats", "**", "*.db"), recursive=Tr
     for r in rows:
         print(f"   {r[0][:60]}: n={r[4]} min={r[1] / 1e3:.1f}us max={r[2] / 1e3:.1f}us avg={r[3] / 1e3:.1f}us vgpr={r[5]} agpr={r[6]} sgpr={r[7]} "
               f"scratch={r[8]} lds={r[9]} grid={r[10]} wg={r[11]}")
+# the launches of the traversal kernel by bench.py phase (single-stream runs): the main timed region cuts between
+# the views, and the launch order needs a few dozen frames after a cut; the roofline leg times settled frames
+log = os.path.join(out, "stats.log")
+if os.path.exists(log):
+    import json as _json
+    line = None
+    for ln in open(log, errors="replace"):
+        if ln.startswith("{") and '"roofline"' in ln:
+            line = _json.loads(ln)
+    for f in sorted(glob.glob(os.path.join(out, "stats", "**", "*.db"), recursive=True)):
+        if not line or "1 frame(s) in flight" not in line["config"].get("parallelism", ""):
+            break
+        db = sqlite3.connect(f)
+        d = [r[0] / 1e3 for r in db.execute("select duration from kernels where name like '%vrt_trace_kernel<%, false,%' order by start")]
+        steps, warmup, settle = line["steps"], line["warmup"], 128
+        reps = max(5, steps // 3)
+        nviews = len(line["config"]["views"])
+        d = d[nviews:]  # (first: the product-kernel frames of the counting context, one per view)
+        if len(d) == warmup + steps + nviews * (settle + reps):
+            print(f"\n## {len(d)} launches of the traversal kernel by bench.py phase (us)")
+            print(f"   warm-up + timed region ({warmup} + {steps} launches, views cut at the thirds): avg {sum(d[:warmup + steps]) / (warmup + steps):.2f}")
+            leg = d[warmup + steps:]
+            timed = []
+            for v, name in enumerate(line["config"]["views"]):
+                seg = leg[v * (settle + reps):(v + 1) * (settle + reps)]
+                timed += seg[settle:]
+                print(f"   roofline leg {name}: {settle} settling launches avg {sum(seg[:settle]) / settle:.2f}, {reps} timed launches avg {sum(seg[settle:]) / reps:.2f}")
+            print(f"   timed launches of the roofline leg: avg {sum(timed) / len(timed):.2f}  (bench.py, HIP events around the same launches incl. the "
+                  f"schedule kernels between them: {line['roofline']['kernel_ms_avg'] * 1e3:.2f})")
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     if not os.path.isdir(d):
         continue
