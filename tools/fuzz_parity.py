@@ -38,12 +38,15 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True) -> int:
         sun_on, radius = bool(rng.random() < 0.7), float(rng.choice([0.0, 5.0, 40.0]))
         rt = VoxelRT(grid, Config(internal_resolution_width=w, internal_resolution_height=h, camera=CameraConfig(samples_per_pixel=spp, max_bounce=bounce),
                                   sun=SunConfig(enabled=sun_on, radius=radius), want_float_output=True,
-                                  kernel_variant=int(rng.choice([0, 0, 6, 1])) if big else 0))
+                                  kernel_variant=int(rng.choice([0, 0, 6, 1, 0x10070000, 0x10070000])) if big else 0))
         rt.push_materials(mats)
         size = np.array(dims) * scale
         centre = np.array(min_point) + 0.5 * size
         origin = centre + (rng.random(3) - 0.5) * size * (3.0 if rng.random() < 0.7 else 0.9)
         rt.camera.look_at(origin.tolist(), (centre + (rng.random(3) - 0.5) * size * 0.5).tolist())
+        if (rt.config.kernel_variant >> 16) & 0xF == 7:
+            # cost-ordered launch, re-sorted every 2 frames: the compared frame comes after three re-sorts, with split tiles
+            rt.draw(frames=7)
         rt.draw()
         f, u = rt.read_rgba32f(), rt.read_rgba8()
         pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
