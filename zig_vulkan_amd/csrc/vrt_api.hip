@@ -517,10 +517,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
         c->wave_slots = 24u * (uint32_t)cus; // 4 SIMDs x 6 waves of the trace kernel per CU
         // default order: frames that run one at a time take the amortised cost-feedback schedule (7) unless all their workgroups
-        // are resident at once (6 per CU: no launch order to speak of); the amortised schedule may split tiles (spare entries)
+        // are resident at once (6 per CU: no launch order to speak of) or the frame is many times that (4K: 21 rounds of resident
+        // workgroups, the tail is a small part of it and the schedule measured +1 %); the schedule may split tiles (spare entries)
         uint32_t order = (cfg->kernel_variant >> 16) & 0xFu;
         c->order_auto = (order == 0u);
-        if (order == 0u) order = (n > 6u * (uint32_t)cus) ? 7u : 3u;
+        if (order == 0u) order = (n > 6u * (uint32_t)cus && n <= 64u * (uint32_t)cus) ? 7u : 3u;
         c->tile_order = order;
         const bool plain_tiles = !((cfg->kernel_variant >> 20) & 0x1u) && (vrt::resolve_variant(cfg->kernel_variant) & 0xFFu) != vrt::kVariantLinearLds512;
         c->sched_extra = (order == 7u && plain_tiles) ? std::min(1024u, n / 8u) : 0u;
