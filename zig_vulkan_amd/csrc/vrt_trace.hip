@@ -1572,7 +1572,9 @@ static KernelFn pick_variant(uint32_t variant) {
     // (builds forced to 5, 7 or 8 waves per SIMD through __launch_bounds__ spilled and measured 6-21 % slower; they
     // are no longer instantiated)
     if (mw != 0u && mw != (uint32_t)kDefaultMinWaves) return nullptr;
-    return pick_mode<B, COUNT, kDefaultMinWaves, SHADE>(mode);
+    // (the several-samples-per-pixel kernel, SHADE 1, needs 87 VGPRs left to itself = 5 waves per SIMD; held to 80 it spills
+    // 36 bytes outside the loops and runs at 6: 4K / 1024^3 / 4 rays per pixel 1.215 -> 1.183 ms per frame)
+    return pick_mode<B, COUNT, (SHADE == 1 && !COUNT) ? 6 : kDefaultMinWaves, SHADE>(mode);
 }
 
 uint32_t resolve_variant(uint32_t variant) {
