@@ -1574,7 +1574,10 @@ static KernelFn pick_variant(uint32_t variant) {
     if (mw != 0u && mw != (uint32_t)kDefaultMinWaves) return nullptr;
     // (the several-samples-per-pixel kernel, SHADE 1, needs 87 VGPRs left to itself = 5 waves per SIMD; held to 80 it spills
     // 36 bytes outside the loops and runs at 6: 4K / 1024^3 / 4 rays per pixel 1.215 -> 1.183 ms per frame)
-    return pick_mode<B, COUNT, (SHADE == 1 && !COUNT) ? 6 : kDefaultMinWaves, SHADE>(mode);
+    // (the bounce kernel, SHADE 0, takes 114 VGPRs = 4 waves per SIMD; its incoherent secondary rays wait on memory, not on
+    // issue, and more waves pay for the spills: 4K / 2048^3 path-trace config, ms per frame V1 / V0 at 4, 5, 6, 8 waves per
+    // SIMD: 83.7 / 283, 71.6 / 238, 66.1 / 219, 60.6 / 201)
+    return pick_mode<B, COUNT, (SHADE == 1 && !COUNT) ? 6 : ((SHADE == 0 && !COUNT) ? 8 : kDefaultMinWaves), SHADE>(mode);
 }
 
 uint32_t resolve_variant(uint32_t variant) {
