@@ -142,6 +142,7 @@ struct vrt_ctx {
     // amortised cost-feedback schedule (tile_order 7): re-sorted every sched_period frames into the other buffer
     uint32_t sched_period = 0, sched_since = 0, sched_cur = 0;
     bool order_auto = false; // kernel_variant left the tile order to the library
+    uint32_t bounce_variant = 0; // kernel_variant with the occupancy choice of the bounce kernel filled in
     uint32_t tile_order = 0, sched_extra = 0, sched_stride = 0, wave_slots = 0;
     uint64_t sched_seq = 0, b_seen_sched = 0;
     hipEvent_t ev_sched = nullptr, ev_b_sched = nullptr;
@@ -550,7 +551,13 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         VRT_CREATE_HIP(hipEventCreateWithFlags(&c->staging_ev[i], hipEventDisableTiming));
     }
 
-    c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant, 0);
+    // the bounce kernel comes in a 4- and an 8-waves-per-SIMD build (vrt_trace.hip, pick_variant): the second one for scenes
+    // whose traversal structures (bindings 3-5) exceed what the caches hold
+    c->bounce_variant = cfg->kernel_variant;
+    if (((cfg->kernel_variant >> 8) & 0xFFu) == 0u &&
+        c->dsize[VRT_BUF_BRICK_STATUS] + c->dsize[VRT_BUF_BRICK_INDEX] + c->dsize[VRT_BUF_BRICK_OCCUPANCY] > (192ull << 20))
+        c->bounce_variant |= 8u << 8;
+    c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->bounce_variant, 0);
     c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant, 1);
     c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant, 2);
     if (!c->kernel || !c->kernel_single || !c->kernel_single1) {
@@ -629,7 +636,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         const uint32_t mode = vrt::resolve_variant(cfg->kernel_variant) & 0xFFu;
         const uint32_t fallback = (mode == vrt::kVariantLinearLds || mode == vrt::kVariantLinearLds512) ? vrt::kVariantLinearAlways : vrt::kVariantBlocked;
         c->cfg.kernel_variant = (cfg->kernel_variant & ~0xFFu) | fallback;
-        c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 0);
+        c->bounce_variant = (c->bounce_variant & ~0xFFu) | fallback;
+        c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->bounce_variant, 0);
         c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 1);
         c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 2);
         c->lds_bytes = 0;
@@ -749,7 +757,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     vrt::KernelFn product_fn = nullptr;
     if (ctx->d_counters) {
         const int shade = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? 2 : 1) : 0;
-        product_fn = vrt::select_trace_kernel((int)ctx->cfg.brick_dimension, false, ctx->cfg.kernel_variant, shade);
+        product_fn = vrt::select_trace_kernel((int)ctx->cfg.brick_dimension, false, shade == 0 ? ctx->bounce_variant : ctx->cfg.kernel_variant, shade);
         if (!product_fn) return fail(ctx, VRT_E_STATE, "no product kernel for this configuration");
     }
 

@@ -1571,13 +1571,18 @@ static KernelFn pick_variant(uint32_t variant) {
     const uint32_t mode = variant & 0xFFu, mw = (variant >> 8) & 0xFFu;
     // (builds forced to 5, 7 or 8 waves per SIMD through __launch_bounds__ spilled and measured 6-21 % slower; they
     // are no longer instantiated)
-    if (mw != 0u && mw != (uint32_t)kDefaultMinWaves) return nullptr;
+    if (mw != 0u && mw != (uint32_t)kDefaultMinWaves && mw != 8u) return nullptr;
     // (the several-samples-per-pixel kernel, SHADE 1, needs 87 VGPRs left to itself = 5 waves per SIMD; held to 80 it spills
     // 36 bytes outside the loops and runs at 6: 4K / 1024^3 / 4 rays per pixel 1.215 -> 1.183 ms per frame)
-    // (the bounce kernel, SHADE 0, takes 114 VGPRs = 4 waves per SIMD; its incoherent secondary rays wait on memory, not on
-    // issue, and more waves pay for the spills: 4K / 2048^3 path-trace config, ms per frame V1 / V0 at 4, 5, 6, 8 waves per
-    // SIMD: 83.7 / 283, 71.6 / 238, 66.1 / 219, 60.6 / 201)
-    return pick_mode<B, COUNT, (SHADE == 1 && !COUNT) ? 6 : ((SHADE == 0 && !COUNT) ? 8 : kDefaultMinWaves), SHADE>(mode);
+    // (the bounce kernel, SHADE 0, takes 114 VGPRs = 4 waves per SIMD.  Its incoherent secondary rays wait on memory, and on a
+    // scene that does not stay in the caches more waves pay for the spills: 4K / 2048^3 sparse path-trace config, ms per frame
+    // V1 / V0 at 4, 5, 6, 8 waves per SIMD: 83.7 / 283, 71.6 / 238, 66.1 / 219, 60.6 / 201.  On the 512^3 terrain (17 MiB of
+    // bitmaps) the same build is 16 % SLOWER than the 4-wave one (0.518 against 0.447 ms, 1080p, 2 bounces), so both exist and
+    // vrt_create asks for the 8-wave one (min_waves 8) by the size of bindings 3-5)
+    if constexpr (SHADE == 0 && !COUNT) {
+        if (mw == 8u) return pick_mode<B, COUNT, 8, SHADE>(mode);
+    }
+    return pick_mode<B, COUNT, (SHADE == 1 && !COUNT) ? 6 : kDefaultMinWaves, SHADE>(mode);
 }
 
 uint32_t resolve_variant(uint32_t variant) {
