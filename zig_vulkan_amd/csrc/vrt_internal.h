@@ -88,7 +88,7 @@ struct TraceParams {
     uint32_t wave_groups;                // 1: launch one 64-thread workgroup per 8x8 block instead of 256 per 16x16 tile
     uint32_t tile_order;                 // workgroup -> tile mapping: 1 row bands per XCD, 2 column bands per XCD, 3 reverse raster, 4 strided,
                                          // 5 cost-feedback schedule, 6 raster.  (kernel_variant: 0 = the library chooses between 3 and the
-                                         // schedule re-sorted every 16 frames, which is 7 there; 5 there re-sorts before every frame)
+                                         // schedule re-sorted every 32 frames, which is 7 there; 5 there re-sorts before every frame)
 };
 
 constexpr int kMaxBatchFrames = 8;
