@@ -822,9 +822,9 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     }
     for (uint32_t f = 0; f < frames; f++) {
         if (ctx->sched_period && nt > 1u && ctx->sched_since >= ctx->sched_period) {
-            // Amortised re-sort, in the frames' own stream (inside the timed region as well): the most recent frame's costs
+            // Amortised re-sort, in the frames' own stream (inside the timed region as well): the measured costs (running mean)
             // order the tiles into the buffer no frame reads; frames launched from here on read that one.  A sort costs about
-            // 35 us of the stream's time (18 us of kernel plus the two kernel boundaries).  Measured alternatives: on a second
+            // 35 us of the stream's time (the kernel plus the two kernel boundaries).  Measured alternatives: on a second
             // stream with event waits 80 us per sort; on a second stream with the host polling for its completion nothing, but
             // then the order lags behind frames that are queued ahead (vrt_dispatch_repeat) by a whole call.
             if (ctx->b_sched_recorded) VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_b_sched, 0)); // (signalled a period ago)
