@@ -30,8 +30,9 @@ if os.path.exists(log):
         if ln.startswith("{") and '"roofline"' in ln:
             line = _json.loads(ln)
     for f in sorted(glob.glob(os.path.join(out, "stats", "**", "*.db"), recursive=True)):
-        if not line or "1 frame(s) in flight" not in line["config"].get("parallelism", ""):
+        if not line or "frame(s) in flight" not in line["config"].get("parallelism", ""):
             break
+        overlapped = "1 frame(s) in flight" not in line["config"]["parallelism"]
         db = sqlite3.connect(f)
         d = [r[0] / 1e3 for r in db.execute("select duration from kernels where name like '%vrt_trace_kernel<%, false,%' order by start")]
         steps, warmup, settle = line["steps"], line["warmup"], 128
@@ -40,7 +41,8 @@ if os.path.exists(log):
         d = d[nviews:]  # (first: the product-kernel frames of the counting context, one per view)
         if len(d) == warmup + steps + nviews * (settle + reps):
             print(f"\n## {len(d)} launches of the traversal kernel by bench.py phase (us)")
-            print(f"   warm-up + timed region ({warmup} + {steps} launches, views cut at the thirds): avg {sum(d[:warmup + steps]) / (warmup + steps):.2f}")
+            print(f"   warm-up + timed region ({warmup} + {steps} launches, views cut at the thirds): avg {sum(d[:warmup + steps]) / (warmup + steps):.2f}"
+                  + ("  (frames alternate between two streams there: two kernels share the GPU, a kernel's duration is not a frame's cost)" if overlapped else ""))
             leg = d[warmup + steps:]
             timed = []
             for v, name in enumerate(line["config"]["views"]):
