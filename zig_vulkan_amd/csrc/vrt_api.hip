@@ -31,6 +31,7 @@ hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t 
 hipError_t launch_assemble_rgb(const void *gathered, void *frame, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t shard_count,
                                uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream, uint32_t frames, uint32_t frame_src_stride_bytes);
 hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
+hipError_t launch_build_cell_bounds(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
                           void *out_f32, hipStream_t stream);
 hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per_pixel, uint32_t width, uint32_t height, uint32_t tiles_x,
@@ -152,6 +153,7 @@ struct vrt_ctx {
     uint32_t denoised_w = 0, denoised_h = 0;
     hipStream_t denoised_stream = nullptr;
     void *d_status_blocks = nullptr; // derived: 4x4x4 block words + block filter (vrt_trace.hip)
+    int *d_cell_bounds = nullptr;    // derived: bounding box of the occupied cells (TraceParams::cell_bounds)
     vrt::TileOwnership own{};        // weighted tile ownership (period 0: tile t belongs to rank t % shard_count)
     bool status_dirty = true;        // brick_status changed since the derived copy was built
     size_t lds_bytes = 0;
@@ -212,6 +214,7 @@ void free_ctx(vrt_ctx *c) {
     if (c->own_t32 && c->target32f) (void)hipFree(c->target32f);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_status_blocks) (void)hipFree(c->d_status_blocks);
+    if (c->d_cell_bounds) (void)hipFree(c->d_cell_bounds);
     if (c->dist) {
         Dist *d = c->dist;
         for (uint32_t i = 0; i < d->nslots; i++) {
@@ -511,6 +514,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     const size_t status_blocks_bytes = nblocks * 8u + ((nblocks + 31u) / 32u) * 4u + 16u;
     VRT_CREATE_HIP(hipMalloc(&c->d_status_blocks, status_blocks_bytes));
     VRT_CREATE_HIP(hipMemsetAsync(c->d_status_blocks, 0, status_blocks_bytes, c->stream));
+    VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_cell_bounds), 6 * sizeof(int)));
+    VRT_CREATE_HIP(hipMemsetAsync(c->d_cell_bounds, 0x80, 6 * sizeof(int), c->stream)); // no cell occupied yet
     {
         // tile schedule starts as reverse raster (bottom rows first); the feedback kernel refines it
         const uint32_t n = sh.owned_tiles ? sh.owned_tiles : 1u;
@@ -603,6 +608,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     // (the u31 start-index check above), so it always reaches
     p.occupancy_words = (uint32_t)(c->dsize[VRT_BUF_BRICK_OCCUPANCY] / 4u);
     p.status_blocks = static_cast<const uint2 *>(c->d_status_blocks);
+    p.cell_bounds = c->d_cell_bounds;
     // (order_auto: frames that alternate between the two streams of a frames_in_flight = 2 context take reverse raster (3)
     // instead, see do_dispatch and DESIGN.md §4)
     p.tile_order = c->tile_order;
@@ -734,6 +740,7 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
         int rcw = begin_scene_write(ctx);
         if (rcw != VRT_OK) return rcw;
         VRT_HIP(ctx, vrt::launch_build_status_blocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
+        VRT_HIP(ctx, vrt::launch_build_cell_bounds(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
         rcw = end_scene_write(ctx);
         if (rcw != VRT_OK) return rcw;
         ctx->status_dirty = false;

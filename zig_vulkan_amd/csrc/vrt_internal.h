@@ -68,6 +68,10 @@ struct TraceParams {
     uint32_t scale_pow2;
     float inv_grid_scale, inv_voxel_scale;
     uint32_t occupancy_words;            // length of brick_occupancy in u32 words
+    // derived from binding 3: the bounding box of the occupied grid cells as {-min_x, -min_y, -min_z, max_x, max_y, max_z}
+    // (0x80808080 in all six while no cell is occupied).  A ray that has left this box on the far side of an axis cannot meet an
+    // occupied cell any more, so the brick-level walk of the product kernels ends there instead of at the grid's face.
+    const int *cell_bounds;
     // derived, device-built copy of brick_status: one 64-bit word per 4x4x4 block of grid cells,
     // block index bx + nbx*(bz + nbz*by), bit (x&3) + 4*(z&3) + 16*(y&3)  (x, z, y order as comp:318)
     const uint2 *status_blocks;

@@ -97,6 +97,13 @@ VRT_DI int steps_left(int step, int pos, int dim, int zero_budget) {
     return step > 0 ? (int)((uint32_t)(dim - 1) - (uint32_t)pos) : (step < 0 ? pos : zero_budget);
 }
 VRT_DI int walk_base(int step, int pos, int dim) { return step > 0 ? dim - 1 : (step < 0 ? 0 : pos); }
+// the same against a box [lo, hi] of cells (pos inside the grid): steps that can be taken before the far face of the box is
+// crossed, negative when the position is already beyond it; an axis the ray does not move along gets the hang-guard budget
+// while the position is inside the box's range and -1 outside (the ray never reaches the box)
+VRT_DI int steps_left_box(int step, int pos, int lo, int hi, int zero_budget) {
+    return step > 0 ? hi - pos : (step < 0 ? pos - lo : ((pos >= lo && pos <= hi) ? zero_budget : -1));
+}
+VRT_DI int walk_base_box(int step, int pos, int lo, int hi) { return step > 0 ? hi : (step < 0 ? lo : pos); }
 VRT_DI int min3i(int a, int b, int c) { return min(min(a, b), c); }
 
 // comp:345-372 / comp:440-467: the branchy min-axis step as selects,
@@ -691,10 +698,21 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     const int py = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
     const int pz = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
     const int zero_budget = dx + dy + dz + 8;
-    w.rx = steps_left(s.sx, px, dx, zero_budget);
-    w.ry = steps_left(s.sy, py, dy, zero_budget);
-    w.rz = steps_left(s.sz, pz, dz, zero_budget);
-    const int base_x = walk_base(s.sx, px, dx), base_y = walk_base(s.sy, py, dy), base_z = walk_base(s.sz, pz, dz);
+    // The walk ends where the ray leaves the bounding box of the OCCUPIED cells on the far side of an axis (every cell beyond
+    // is empty, and the ray cannot come back), not only at the grid's face: same hits, same misses, fewer trips -- sky rays of a
+    // camera above the terrain and shadow rays towards the sun stop at the height of the highest brick.  The counting build
+    // walks to the grid's face like the shader, so that its counters stay the reference algorithm's.
+    int lox = 0, loy = 0, loz = 0, hix = dx - 1, hiy = dy - 1, hiz = dz - 1;
+    if constexpr (!COUNT) {
+        if (p.cell_bounds) {
+            lox = -p.cell_bounds[0], loy = -p.cell_bounds[1], loz = -p.cell_bounds[2];
+            hix = p.cell_bounds[3], hiy = p.cell_bounds[4], hiz = p.cell_bounds[5];
+        }
+    }
+    w.rx = steps_left_box(s.sx, px, lox, hix, zero_budget);
+    w.ry = steps_left_box(s.sy, py, loy, hiy, zero_budget);
+    w.rz = steps_left_box(s.sz, pz, loz, hiz, zero_budget);
+    const int base_x = walk_base_box(s.sx, px, lox, hix), base_y = walk_base_box(s.sy, py, loy, hiy), base_z = walk_base_box(s.sz, pz, loz, hiz);
     w.t_value = 0;
 
     uint32_t word_index = ~0u; // comp:301
@@ -714,7 +732,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     // stop: 0 keep walking, -1 voxel hit, -2 t became NaN; negative values end the loop through the
     // same integer test as the box exit
     int stop = 0;
-    bool more = (unsigned)px < (unsigned)dx && (unsigned)py < (unsigned)dy && (unsigned)pz < (unsigned)dz;
+    bool more = (unsigned)px < (unsigned)dx && (unsigned)py < (unsigned)dy && (unsigned)pz < (unsigned)dz && (w.rx | w.ry | w.rz) >= 0;
 
     auto cell_occupied = [&]() -> bool {
         VRT_COUNT(grid_steps);
@@ -1312,6 +1330,28 @@ __global__ __launch_bounds__(256) void vrt_build_status_blocks(const uint32_t *_
     if (lane == 32 && base_word + 1u < nwords) filter[base_word + 1u] = (uint32_t)(nonempty >> 32);
 }
 
+// Bounding box of the occupied grid cells (TraceParams::cell_bounds), from the status bits of binding 3: one thread per
+// status word, six atomic maxima over {-x, -y, -z, x, y, z}; bounds[] starts as 0x80808080 (hipMemsetAsync 0x80).
+__global__ __launch_bounds__(256) void vrt_build_cell_bounds(const uint32_t *__restrict__ status, int *__restrict__ bounds, uint32_t words,
+                                                             uint32_t cells, uint32_t dim_x, uint32_t dim_z) {
+    const uint32_t wi = blockIdx.x * 256u + threadIdx.x;
+    if (wi >= words) return;
+    uint32_t bits = status[wi];
+    if (wi == words - 1u && (cells & 31u)) bits &= (1u << (cells & 31u)) - 1u; // bits beyond the last cell mean nothing
+    if (bits == 0u) return;
+    int m[6] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+    while (bits) {
+        const uint32_t b = (uint32_t)__builtin_ctz(bits);
+        bits &= bits - 1u;
+        const uint32_t i = wi * 32u + b; // x + dim_x * (z + dim_z * y), comp:318
+        const int x = (int)(i % dim_x), z = (int)((i / dim_x) % dim_z), y = (int)(i / (dim_x * dim_z));
+        m[0] = max(m[0], -x), m[1] = max(m[1], -y), m[2] = max(m[2], -z);
+        m[3] = max(m[3], x), m[4] = max(m[4], y), m[5] = max(m[5], z);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) atomicMax(&bounds[k], m[k]);
+}
+
 // Cost-feedback schedule: order[] = owned tile ids in kScheduleBuckets classes of cost (wave-cycles of the most
 // recent frame, relative to the maximum), heaviest class first; INSIDE a class the tiles keep the default
 // reverse-raster order, so that consecutive workgroups still render neighbouring tiles (a full sort by cost
@@ -1627,6 +1667,16 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
 hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra,
                            uint32_t wave_slots, hipStream_t stream) {
     hipLaunchKernelGGL(vrt_schedule_kernel, dim3(1), dim3(1024), 0, stream, cost, snap, prev_order, order, n, extra, wave_slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_cell_bounds(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
+    if (!p.cell_bounds) return hipSuccess;
+    int *bounds = const_cast<int *>(p.cell_bounds);
+    hipError_t e = hipMemsetAsync(bounds, 0x80, 6 * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(vrt_build_cell_bounds, dim3((p.status_words + 255u) / 256u), dim3(256), 0, stream, p.brick_status, bounds, p.status_words,
+                       dim_x * dim_y * dim_z, dim_x, dim_z);
     return hipGetLastError();
 }
 
