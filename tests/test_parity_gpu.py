@@ -416,3 +416,59 @@ def test_random_scenes_fuzz_slice():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.fuzz(60, 5, verbose=False) == 0
+
+
+def test_walk_ends_at_the_bounding_box_of_the_occupied_cells():
+    """The product kernel ends a brick-level walk where the ray leaves the bounding box of the occupied cells (derived from
+    binding 3 on upload) instead of at the grid's face.  Pixels must not change: an island of bricks in a larger empty grid seen
+    from inside the box, from outside it on every side, looking away from it and past it (odd frame size: the centre ray is
+    (nearly) axis-aligned), with shadow rays; an empty grid; and an edit that grows the box, seen by the next frame."""
+    from zig_vulkan_amd import BrickGrid, VoxelRT, Config, CameraConfig, SunConfig, default_materials
+    mats = default_materials(256)
+
+    def island():
+        g = BrickGrid(12, 10, 14, min_point=(-24.0, -20.0, -28.0), scale=4.0, brick_dimension=4)
+        for x in range(20, 29):
+            for y in range(18, 25):
+                for z in range(30, 41):
+                    if (x + y + z) % 3:
+                        g.insert(x, y, z, 1 + (x % 5))
+        return g
+
+    def check(rt, grid, origin, target, what):
+        rt.camera.look_at(list(origin), list(target))
+        rt.draw()
+        f, u = rt.read_rgba32f(), rt.read_rgba8()
+        fo, uo, _ = O.render(oracle_scene_from_grid(grid, mats), O.push_constants(rt.camera.blob(), rt.sun.blob()))
+        assert np.array_equal(f.view(np.uint32), fo.view(np.uint32)) and np.array_equal(u, uo), what
+
+    cfg = Config(internal_resolution_width=161, internal_resolution_height=99, camera=CameraConfig(samples_per_pixel=1, max_bounce=0),
+                 sun=SunConfig(enabled=True, radius=0.0), want_float_output=True)
+    grid = island()
+    rt = VoxelRT(grid, cfg)
+    rt.push_materials(mats)
+    centre = (0.2, -3.0, 3.5)  # inside the island (cells 5..7, 4..6, 7..10 of the grid)
+    check(rt, grid, centre, (5.0, -2.0, 9.0), "from inside the box")
+    for k, off in enumerate([(-20, 0, 0), (22, 1, 0), (0, -15, 0.5), (0.5, 16, 0), (0, 0.5, -24), (1, 0, 26), (-18, -14, -20)]):
+        o = tuple(c + d for c, d in zip(centre, off))
+        check(rt, grid, o, centre, f"towards the box from side {k}")
+        check(rt, grid, o, tuple(2 * a - b for a, b in zip(o, centre)), f"away from the box from side {k}")
+        check(rt, grid, o, (o[0], o[1], o[2] - 10.0), f"along -z past the box from side {k}")
+        check(rt, grid, o, (o[0] + 10.0, o[1], o[2]), f"along +x past the box from side {k}")
+    # an edit that grows the box: one voxel in a far corner of the grid, then one right above the camera's usual spot
+    grid.insert(1, 38, 2, 4)
+    rt.update_grid_delta()
+    check(rt, grid, (-20.0, 14.0, -25.0), (-23.0, 17.5, -27.0), "new corner voxel, seen from nearby")
+    check(rt, grid, centre, (5.0, -2.0, 9.0), "after the edit, from inside")
+    grid.insert(46, 1, 54, 2)
+    rt.update_grid_delta()
+    check(rt, grid, (20.0, -14.0, 25.0), (22.5, -17.5, 27.0), "second corner voxel")
+    check(rt, grid, (-22.0, 18.0, -26.0), (22.5, -17.5, 27.0), "across the whole grid")
+    rt.deinit()
+    # no occupied cell at all
+    empty = BrickGrid(5, 4, 6, min_point=(-10.0, -8.0, -12.0), scale=4.0, brick_dimension=8)
+    rt = VoxelRT(empty, cfg)
+    rt.push_materials(mats)
+    check(rt, empty, (0.0, 0.0, 0.0), (1.0, 0.5, 3.0), "empty grid, camera inside")
+    check(rt, empty, (0.0, -30.0, 0.0), (0.0, 0.0, 0.0), "empty grid, camera outside")
+    rt.deinit()
