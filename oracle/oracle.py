@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY — see the header of vrt_oracle.c.  Imported by tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by zig_vulkan_amd.
-PARITY UNPINNED: the reference holds no golden vectors for this path.
+PARITY PINNED against the reference's own shader run under Mesa llvmpipe (oracle/ref_gl, tests/test_ref_gl.py).
 """
 from __future__ import annotations
 
@@ -16,11 +16,14 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvrt_oracle.so")
+# the same restatement with Mesa llvmpipe's lowering of fma / dot / sin: only ever compared with oracle/_ref
+LIB_PATH_LLVMPIPE = os.path.join(_HERE, "libvrt_oracle_llvmpipe.so")
 
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("vrt_oracle.c", "denoise_oracle.c")]
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
+    if force or any(not os.path.exists(p) or os.path.getmtime(p) < max(os.path.getmtime(s) for s in srcs)
+                    for p in (LIB_PATH, LIB_PATH_LLVMPIPE)):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return LIB_PATH
 
@@ -48,13 +51,15 @@ class Counters(C.Structure):
 
 
 _lib = None
+_libs = {}
 
 
-def lib() -> C.CDLL:
+def lib(lowering: str = "hw") -> C.CDLL:
+    """lowering "hw": the oracle proper.  "llvmpipe": built-ins lowered as Mesa llvmpipe does (see vrt_oracle.c)."""
     global _lib
-    if _lib is None:
+    if lowering not in _libs:
         build()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL({"hw": LIB_PATH, "llvmpipe": LIB_PATH_LLVMPIPE}[lowering])
         L.oracle_render_rows.restype = None
         L.oracle_render_rows.argtypes = [C.POINTER(Scene), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_render_pixels.restype = None
@@ -80,8 +85,10 @@ def lib() -> C.CDLL:
                                                 C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.oracle_denoise_rows.restype = None
         L.oracle_denoise_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        _lib = L
-    return _lib
+        _libs[lowering] = L
+        if lowering == "hw":
+            _lib = L
+    return _libs[lowering]
 
 
 class OracleScene:
@@ -119,10 +126,10 @@ def push_constants(camera_blob: bytes, sun_blob: bytes) -> np.ndarray:
 
 
 def render(scene: OracleScene, pc: np.ndarray, *, rows: Optional[Tuple[int, int]] = None, threads: int = 0,
-           want_counters: bool = True):
+           want_counters: bool = True, lowering: str = "hw"):
     """Render image rows [y0,y1) (default: all) with the oracle.  Returns
     (rgba32f[H,W,4], rgba8[H,W,4], counters dict) — rows outside the range stay zero."""
-    L = lib()
+    L = lib(lowering)
     w, h = np.frombuffer(pc[:8].tobytes(), dtype=np.uint32)
     w, h = int(w), int(h)
     y0, y1 = rows if rows else (0, h)

@@ -1,0 +1,156 @@
+"""ctypes wrapper of oracle/_ref: the reference's compute shader run by Mesa llvmpipe on the host cores.
+
+TEST INFRASTRUCTURE.  Used by tests/ (to pin oracle/vrt_oracle.c against the real shader), by
+tests/golden/make_ref_golden.py (fixtures) and by bench.py's cpu_baseline leg (`kind: "reference"`).
+Never imported by zig_vulkan_amd.  See recipe.py for how oracle/_ref is made and what is edited.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import recipe
+
+_FORMAT_FILE_MAGIC = b"GLRF"
+
+
+class GlRefUnavailable(RuntimeError):
+    pass
+
+
+class GlRef:
+    """One llvmpipe GL 4.5 context per process (thread-affine: use from the thread that made it)."""
+
+    _lib = None
+
+    def __init__(self):
+        if GlRef._lib is None:
+            path = os.path.join(recipe.REF_DIR, "libglref.so")
+            if not os.path.exists(path):
+                try:
+                    recipe.build_runner()
+                except Exception as e:  # noqa: BLE001
+                    raise GlRefUnavailable(f"oracle/_ref/libglref.so missing and not buildable: {e}") from e
+            L = C.CDLL(path)
+            L.glref_last_error.restype = C.c_char_p
+            L.glref_info.restype = C.c_char_p
+            L.glref_compile.argtypes = [C.c_char_p, C.c_int]
+            L.glref_get_binary.restype = C.c_int64
+            L.glref_get_binary.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_uint32)]
+            L.glref_load_binary.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
+            L.glref_delete_program.argtypes = [C.c_int]
+            L.glref_dispatch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                         C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                         C.c_int, C.c_void_p]
+            if L.glref_init() != 0:
+                raise GlRefUnavailable("llvmpipe context: " + L.glref_last_error().decode(errors="replace"))
+            GlRef._lib = L
+        self.L = GlRef._lib
+
+    def info(self) -> str:
+        return self.L.glref_info().decode()
+
+    def _err(self) -> str:
+        return self.L.glref_last_error().decode(errors="replace")
+
+    def compile(self, source: str) -> int:
+        s = source.encode()
+        prog = self.L.glref_compile(s, len(s))
+        if prog <= 0:
+            raise RuntimeError("Mesa GLSL compiler: " + self._err())
+        return prog
+
+    def save_binary(self, prog: int, path: str) -> None:
+        n = self.L.glref_get_binary(prog, None, 0, None)
+        if n <= 0:
+            raise RuntimeError(self._err())
+        buf = (C.c_uint8 * n)()
+        fmt = C.c_uint32()
+        if self.L.glref_get_binary(prog, buf, n, C.byref(fmt)) != n:
+            raise RuntimeError(self._err())
+        with open(path, "wb") as fh:
+            fh.write(_FORMAT_FILE_MAGIC + int(fmt.value).to_bytes(4, "little") + bytes(buf))
+
+    def load_binary(self, path: str) -> int:
+        with open(path, "rb") as fh:
+            blob = fh.read()
+        if blob[:4] != _FORMAT_FILE_MAGIC:
+            raise RuntimeError(f"{path}: not a glref program binary")
+        fmt = int.from_bytes(blob[4:8], "little")
+        body = blob[8:]
+        prog = self.L.glref_load_binary(body, len(body), fmt)
+        if prog <= 0:
+            raise RuntimeError(self._err())
+        return prog
+
+    def delete(self, prog: int) -> None:
+        self.L.glref_delete_program(prog)
+
+    def dispatch(self, prog: int, width: int, height: int, ubos: Dict[int, np.ndarray], ssbos: Dict[int, np.ndarray],
+                 out_float: bool, workgroup: Tuple[int, int] = (recipe.WORKGROUP, recipe.WORKGROUP)) -> np.ndarray:
+        def pack(d):
+            keys = sorted(d)
+            arrs = [np.ascontiguousarray(d[k]) for k in keys]
+            return (len(keys), (C.c_int * len(keys))(*keys), (C.c_void_p * len(keys))(*[a.ctypes.data for a in arrs]),
+                    (C.c_int64 * len(keys))(*[a.nbytes for a in arrs]), arrs)
+        nu, ub, up, un, keep_u = pack(ubos)
+        ns, sb, sp, sn, keep_s = pack(ssbos)
+        out = np.zeros((height, width, 4), dtype=np.float32 if out_float else np.uint8)
+        rc = self.L.glref_dispatch(prog, width, height, workgroup[0], workgroup[1], nu, ub, up, un, ns, sb, sp, sn,
+                                   1 if out_float else 0, out.ctypes.data)
+        del keep_u, keep_s
+        if rc != 0:
+            raise RuntimeError(self._err())
+        return out
+
+
+class ReferenceShader:
+    """brick_raytracer.comp (reference) for one brick dimension, as built by recipe.py.
+
+    render(scene, pc) takes the same inputs as oracle.render: an OracleScene (bindings 1..7) and the 128
+    push-constant bytes; returns (rgba32f or None, rgba8)."""
+
+    def __init__(self, brick_dimension: int, want_float: bool = True):
+        self.gl = GlRef()
+        self.brick_dimension = brick_dimension
+        self.progs = {}
+        for fmt in (("rgba8", "rgba32f") if want_float else ("rgba8",)):
+            path = recipe.binary_path(brick_dimension, fmt)
+            if os.path.exists(path):
+                try:
+                    self.progs[fmt] = self.gl.load_binary(path)
+                    continue
+                except RuntimeError:
+                    if not recipe.reference_available():
+                        raise
+            if not recipe.reference_available():
+                raise GlRefUnavailable(f"{path} missing and /root/reference absent: run `python -m oracle.ref_gl.recipe` "
+                                       "in the build container")
+            self.progs[fmt] = self.gl.compile(recipe.opengl_dialect(brick_dimension, fmt))
+
+    def render(self, scene, pc: np.ndarray, want_float: bool = True, want_u8: bool = True):
+        assert scene.brick_dimension == self.brick_dimension
+        w, h = (int(v) for v in np.frombuffer(pc[:8].tobytes(), dtype=np.uint32))
+        ubos = {0: np.frombuffer(pc.tobytes(), dtype=np.uint8), 1: scene.grid_state}
+        ssbos = {2: scene.materials.view(np.uint8).reshape(-1), 3: scene.brick_status, 4: scene.brick_index,
+                 5: scene.brick_occupancy, 6: scene.brick_start_index, 7: scene.material_index}
+        f = self.gl.dispatch(self.progs["rgba32f"], w, h, ubos, ssbos, True) if want_float else None
+        u = self.gl.dispatch(self.progs["rgba8"], w, h, ubos, ssbos, False) if want_u8 else None
+        return f, u
+
+
+def available() -> Optional[str]:
+    """None when the reference shader can be run here, else the reason."""
+    try:
+        GlRef()
+    except (GlRefUnavailable, OSError) as e:
+        return str(e)
+    if recipe.reference_available():
+        return None
+    missing = [recipe.binary_path(b, f) for b in recipe.BRICK_DIMENSIONS for f in recipe.FORMATS
+               if not os.path.exists(recipe.binary_path(b, f))]
+    return ("missing " + ", ".join(os.path.basename(m) for m in missing)) if missing else None

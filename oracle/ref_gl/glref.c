@@ -1,0 +1,259 @@
+/* glref — runs a GLSL compute shader on Mesa's software rasteriser (llvmpipe) without a display.
+ *
+ * TEST INFRASTRUCTURE (oracle side).  This is the runner of `oracle/_ref`: the reference's own
+ * compute shader, /root/reference/assets/shaders/brick_raytracer.comp, compiled by Mesa's GLSL compiler
+ * and executed by llvmpipe on the host cores.  The shader source is never copied into this repo: the
+ * recipe (oracle/ref_gl/recipe.py) reads it where it lies under /root/reference, applies the dialect
+ * edits listed there in memory, hands the text to glref_compile() and keeps only Mesa's program binary
+ * (serialised NIR, no source text) under oracle/_ref/.
+ *
+ * The image has Mesa 23.2.1 (libglapi.so.0, dri/swrast_dri.so) but no X server, no EGL and no OSMesa,
+ * so the GL context is made through the driver's own DRI "swrast" loader interface
+ * (/usr/include/GL/internal/dri_interface.h): createNewScreen2 -> createContextAttribs(GL 4.5 core) ->
+ * bindContext on a dummy drawable.  GL entry points come from libglapi's _glapi_get_proc_address.
+ *
+ * What it replaces of the reference: vkCmdDispatch of the compute pipeline
+ * (src/modules/voxel_rt/ComputePipeline.zig:547-550) with its descriptor set
+ * (bindings 0..7, ComputePipeline.zig:120-215) and push constants (:488-505).
+ *
+ * One context per process, used from the thread that called glref_init().
+ */
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <GL/gl.h>
+#include <GL/glext.h>
+#include <GL/internal/dri_interface.h>
+
+#define GLREF_API __attribute__((visibility("default")))
+
+/* ---- DRI swrast loader: a drawable nobody looks at ---- */
+static void ld_get_drawable_info(__DRIdrawable *d, int *x, int *y, int *w, int *h, void *p) { (void)d; (void)p; *x = *y = 0; *w = *h = 16; }
+static void ld_put_image(__DRIdrawable *d, int op, int x, int y, int w, int h, char *data, void *p) { (void)d; (void)op; (void)x; (void)y; (void)w; (void)h; (void)data; (void)p; }
+static void ld_get_image(__DRIdrawable *d, int x, int y, int w, int h, char *data, void *p) { (void)d; (void)x; (void)y; (void)w; (void)h; (void)data; (void)p; }
+static void ld_put_image2(__DRIdrawable *d, int op, int x, int y, int w, int h, int stride, char *data, void *p) { (void)d; (void)op; (void)x; (void)y; (void)w; (void)h; (void)stride; (void)data; (void)p; }
+static void ld_get_image2(__DRIdrawable *d, int x, int y, int w, int h, int stride, char *data, void *p) { (void)d; (void)x; (void)y; (void)w; (void)h; (void)stride; (void)data; (void)p; }
+static const __DRIswrastLoaderExtension g_loader = {
+    .base = {__DRI_SWRAST_LOADER, 3},
+    .getDrawableInfo = ld_get_drawable_info, .putImage = ld_put_image, .getImage = ld_get_image,
+    .putImage2 = ld_put_image2, .getImage2 = ld_get_image2,
+};
+static const __DRIextension *g_loader_exts[] = {&g_loader.base, NULL};
+
+static char g_err[4096];
+static int g_ready;
+static const __DRIcoreExtension *g_core;
+static __DRIscreen *g_screen;
+static __DRIcontext *g_ctx;
+static __DRIdrawable *g_draw;
+
+#define GLFN(ret, name, ...) static ret (*p_##name)(__VA_ARGS__)
+GLFN(const GLubyte *, glGetString, GLenum);
+GLFN(void, glGetIntegerv, GLenum, GLint *);
+GLFN(GLenum, glGetError, void);
+GLFN(GLuint, glCreateShader, GLenum);
+GLFN(void, glShaderSource, GLuint, GLsizei, const GLchar *const *, const GLint *);
+GLFN(void, glCompileShader, GLuint);
+GLFN(void, glGetShaderiv, GLuint, GLenum, GLint *);
+GLFN(void, glGetShaderInfoLog, GLuint, GLsizei, GLsizei *, GLchar *);
+GLFN(void, glDeleteShader, GLuint);
+GLFN(GLuint, glCreateProgram, void);
+GLFN(void, glAttachShader, GLuint, GLuint);
+GLFN(void, glLinkProgram, GLuint);
+GLFN(void, glGetProgramiv, GLuint, GLenum, GLint *);
+GLFN(void, glGetProgramInfoLog, GLuint, GLsizei, GLsizei *, GLchar *);
+GLFN(void, glProgramParameteri, GLuint, GLenum, GLint);
+GLFN(void, glGetProgramBinary, GLuint, GLsizei, GLsizei *, GLenum *, void *);
+GLFN(void, glProgramBinary, GLuint, GLenum, const void *, GLsizei);
+GLFN(void, glDeleteProgram, GLuint);
+GLFN(void, glUseProgram, GLuint);
+GLFN(void, glGenBuffers, GLsizei, GLuint *);
+GLFN(void, glDeleteBuffers, GLsizei, const GLuint *);
+GLFN(void, glBindBuffer, GLenum, GLuint);
+GLFN(void, glBufferData, GLenum, GLsizeiptr, const void *, GLenum);
+GLFN(void, glBufferSubData, GLenum, GLintptr, GLsizeiptr, const void *);
+GLFN(void, glGetBufferSubData, GLenum, GLintptr, GLsizeiptr, void *);
+GLFN(void, glBindBufferBase, GLenum, GLuint, GLuint);
+GLFN(void, glGenTextures, GLsizei, GLuint *);
+GLFN(void, glDeleteTextures, GLsizei, const GLuint *);
+GLFN(void, glBindTexture, GLenum, GLuint);
+GLFN(void, glTexStorage2D, GLenum, GLsizei, GLenum, GLsizei, GLsizei);
+GLFN(void, glBindImageTexture, GLuint, GLuint, GLint, GLboolean, GLint, GLenum, GLenum);
+GLFN(void, glGetTexImage, GLenum, GLint, GLenum, GLenum, void *);
+GLFN(void, glPixelStorei, GLenum, GLint);
+GLFN(void, glDispatchCompute, GLuint, GLuint, GLuint);
+GLFN(void, glMemoryBarrier, GLbitfield);
+GLFN(void, glFinish, void);
+
+GLREF_API const char *glref_last_error(void) { return g_err; }
+
+static int fail(const char *fmt, const char *arg) {
+    snprintf(g_err, sizeof g_err, fmt, arg ? arg : "");
+    return -1;
+}
+
+/* Creates the llvmpipe GL 4.5 core context (idempotent).  0 on success. */
+GLREF_API int glref_init(void) {
+    if (g_ready) return 0;
+    const char *paths[] = {"/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so", "swrast_dri.so", NULL};
+    void *drv = NULL;
+    for (int i = 0; paths[i] && !drv; i++) drv = dlopen(paths[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!drv) return fail("dlopen swrast_dri.so: %s", dlerror());
+    const __DRIextension **(*get_exts)(void) = (const __DRIextension **(*)(void))dlsym(drv, "__driDriverGetExtensions_swrast");
+    if (!get_exts) return fail("%s", "no __driDriverGetExtensions_swrast");
+    const __DRIextension **exts = get_exts();
+    const __DRIswrastExtension *sw = NULL;
+    for (int i = 0; exts[i]; i++) {
+        if (!strcmp(exts[i]->name, __DRI_CORE)) g_core = (const __DRIcoreExtension *)exts[i];
+        if (!strcmp(exts[i]->name, __DRI_SWRAST)) sw = (const __DRIswrastExtension *)exts[i];
+    }
+    if (!g_core || !sw || sw->base.version < 4) return fail("%s", "DRI_Core / DRI_SWRast v4 not offered by the driver");
+    const __DRIconfig **configs = NULL;
+    g_screen = sw->createNewScreen2(0, g_loader_exts, exts, &configs, NULL);
+    if (!g_screen || !configs || !configs[0]) return fail("%s", "createNewScreen2 failed");
+    uint32_t attribs[] = {__DRI_CTX_ATTRIB_MAJOR_VERSION, 4, __DRI_CTX_ATTRIB_MINOR_VERSION, 5};
+    unsigned err = 0;
+    g_ctx = sw->createContextAttribs(g_screen, __DRI_API_OPENGL_CORE, configs[0], NULL, 2, attribs, &err, NULL);
+    if (!g_ctx) return fail("%s", "createContextAttribs(GL 4.5 core) failed");
+    g_draw = sw->createNewDrawable(g_screen, configs[0], NULL);
+    if (!g_draw || !g_core->bindContext(g_ctx, g_draw, g_draw)) return fail("%s", "bindContext failed");
+    void *glapi = dlopen("libglapi.so.0", RTLD_NOW | RTLD_GLOBAL);
+    if (!glapi) return fail("dlopen libglapi.so.0: %s", dlerror());
+    void *(*gpa)(const char *) = (void *(*)(const char *))dlsym(glapi, "_glapi_get_proc_address");
+    if (!gpa) return fail("%s", "no _glapi_get_proc_address");
+#define LOAD(name) do { *(void **)&p_##name = gpa(#name); if (!p_##name) return fail("GL entry point missing: %s", #name); } while (0)
+    LOAD(glGetString); LOAD(glGetIntegerv); LOAD(glGetError); LOAD(glCreateShader); LOAD(glShaderSource); LOAD(glCompileShader);
+    LOAD(glGetShaderiv); LOAD(glGetShaderInfoLog); LOAD(glDeleteShader); LOAD(glCreateProgram); LOAD(glAttachShader);
+    LOAD(glLinkProgram); LOAD(glGetProgramiv); LOAD(glGetProgramInfoLog); LOAD(glProgramParameteri); LOAD(glGetProgramBinary);
+    LOAD(glProgramBinary); LOAD(glDeleteProgram); LOAD(glUseProgram); LOAD(glGenBuffers); LOAD(glDeleteBuffers); LOAD(glBindBuffer);
+    LOAD(glBufferData); LOAD(glBufferSubData); LOAD(glGetBufferSubData); LOAD(glBindBufferBase); LOAD(glGenTextures);
+    LOAD(glDeleteTextures); LOAD(glBindTexture); LOAD(glTexStorage2D); LOAD(glBindImageTexture); LOAD(glGetTexImage);
+    LOAD(glPixelStorei); LOAD(glDispatchCompute); LOAD(glMemoryBarrier); LOAD(glFinish);
+#undef LOAD
+    g_ready = 1;
+    return 0;
+}
+
+/* "GL_VERSION | GL_RENDERER | GLSL version" of the context, for the fixtures' provenance record. */
+GLREF_API const char *glref_info(void) {
+    static char s[512];
+    if (!g_ready) return "";
+    snprintf(s, sizeof s, "%s | %s | GLSL %s", (const char *)p_glGetString(GL_VERSION), (const char *)p_glGetString(GL_RENDERER),
+             (const char *)p_glGetString(GL_SHADING_LANGUAGE_VERSION));
+    return s;
+}
+
+/* Compiles + links one compute shader.  Returns the program name (>0) or -1 (log in glref_last_error). */
+GLREF_API int glref_compile(const char *src, int len) {
+    if (!g_ready) return fail("%s", "glref_init not called");
+    GLuint sh = p_glCreateShader(GL_COMPUTE_SHADER);
+    GLint l = len;
+    p_glShaderSource(sh, 1, &src, &l);
+    p_glCompileShader(sh);
+    GLint ok = 0;
+    p_glGetShaderiv(sh, GL_COMPILE_STATUS, &ok);
+    if (!ok) {
+        char log[3800] = {0};
+        p_glGetShaderInfoLog(sh, sizeof log - 1, NULL, log);
+        p_glDeleteShader(sh);
+        return fail("compile: %s", log);
+    }
+    GLuint prog = p_glCreateProgram();
+    p_glProgramParameteri(prog, GL_PROGRAM_BINARY_RETRIEVABLE_HINT, GL_TRUE);
+    p_glAttachShader(prog, sh);
+    p_glLinkProgram(prog);
+    p_glDeleteShader(sh);
+    p_glGetProgramiv(prog, GL_LINK_STATUS, &ok);
+    if (!ok) {
+        char log[3800] = {0};
+        p_glGetProgramInfoLog(prog, sizeof log - 1, NULL, log);
+        p_glDeleteProgram(prog);
+        return fail("link: %s", log);
+    }
+    return (int)prog;
+}
+
+/* Mesa's program binary (serialised NIR + metadata; loadable by the same Mesa build only).
+ * Returns its size; copies it to `dst` when cap is large enough.  `format` receives the binary format enum. */
+GLREF_API int64_t glref_get_binary(int prog, void *dst, int64_t cap, uint32_t *format) {
+    GLint n = 0;
+    p_glGetProgramiv((GLuint)prog, GL_PROGRAM_BINARY_LENGTH, &n);
+    if (n <= 0) return fail("%s", "program has no binary");
+    if (dst && cap >= n) {
+        GLenum fmt = 0;
+        GLsizei got = 0;
+        p_glGetProgramBinary((GLuint)prog, n, &got, &fmt, dst);
+        if (format) *format = fmt;
+        if (got != n) return fail("%s", "glGetProgramBinary returned a short binary");
+    }
+    return n;
+}
+
+GLREF_API int glref_load_binary(const void *bin, int64_t n, uint32_t format) {
+    if (!g_ready) return fail("%s", "glref_init not called");
+    GLuint prog = p_glCreateProgram();
+    p_glProgramBinary(prog, format, bin, (GLsizei)n);
+    GLint ok = 0;
+    p_glGetProgramiv(prog, GL_LINK_STATUS, &ok);
+    if (!ok) {
+        p_glDeleteProgram(prog);
+        return fail("%s", "glProgramBinary rejected the binary (made by a different Mesa build?)");
+    }
+    return (int)prog;
+}
+
+GLREF_API void glref_delete_program(int prog) { if (g_ready && prog > 0) p_glDeleteProgram((GLuint)prog); }
+
+/* One dispatch of a compute program over a width x height image.
+ *   ubo[i]  : nubo uniform blocks   -> UBO binding point ubo_binding[i]
+ *   ssbo[i] : nssbo storage blocks  -> SSBO binding point ssbo_binding[i]   (sizes in bytes; padded to 4 here)
+ *   image unit 0 : a fresh width x height texture, RGBA8 (out_float = 0) or RGBA32F (out_float = 1), write-only
+ *   groups = ceil(width / wg_x) x ceil(height / wg_y) x 1   (ComputePipeline.zig:547-550)
+ * `out` receives the image rows top to bottom (y ascending), 4 or 16 bytes per pixel.  0 on success. */
+GLREF_API int glref_dispatch(int prog, int width, int height, int wg_x, int wg_y, int nubo, const int *ubo_binding,
+                             const void *const *ubo, const int64_t *ubo_bytes, int nssbo, const int *ssbo_binding,
+                             const void *const *ssbo, const int64_t *ssbo_bytes, int out_float, void *out) {
+    if (!g_ready) return fail("%s", "glref_init not called");
+    if (nubo > 8 || nssbo > 16) return fail("%s", "too many buffers");
+    while (p_glGetError() != GL_NO_ERROR) {}
+    GLuint bufs[24];
+    int nb = nubo + nssbo;
+    p_glGenBuffers(nb, bufs);
+    for (int i = 0; i < nubo; i++) {
+        p_glBindBuffer(GL_UNIFORM_BUFFER, bufs[i]);
+        p_glBufferData(GL_UNIFORM_BUFFER, (GLsizeiptr)ubo_bytes[i], ubo[i], GL_STATIC_DRAW);
+        p_glBindBufferBase(GL_UNIFORM_BUFFER, (GLuint)ubo_binding[i], bufs[i]);
+    }
+    for (int i = 0; i < nssbo; i++) {
+        int64_t n = ssbo_bytes[i], padded = (n + 3) & ~(int64_t)3;
+        if (padded == 0) padded = 4;
+        p_glBindBuffer(GL_SHADER_STORAGE_BUFFER, bufs[nubo + i]);
+        p_glBufferData(GL_SHADER_STORAGE_BUFFER, (GLsizeiptr)padded, NULL, GL_STATIC_DRAW);
+        if (n) p_glBufferSubData(GL_SHADER_STORAGE_BUFFER, 0, (GLsizeiptr)n, ssbo[i]);
+        if (padded > n) { const uint32_t z = 0; p_glBufferSubData(GL_SHADER_STORAGE_BUFFER, (GLintptr)n, (GLsizeiptr)(padded - n), &z); }
+        p_glBindBufferBase(GL_SHADER_STORAGE_BUFFER, (GLuint)ssbo_binding[i], bufs[nubo + i]);
+    }
+    GLuint tex = 0;
+    p_glGenTextures(1, &tex);
+    p_glBindTexture(GL_TEXTURE_2D, tex);
+    p_glTexStorage2D(GL_TEXTURE_2D, 1, out_float ? GL_RGBA32F : GL_RGBA8, width, height);
+    p_glBindImageTexture(0, tex, 0, GL_FALSE, 0, GL_WRITE_ONLY, out_float ? GL_RGBA32F : GL_RGBA8);
+    p_glUseProgram((GLuint)prog);
+    p_glDispatchCompute((GLuint)((width + wg_x - 1) / wg_x), (GLuint)((height + wg_y - 1) / wg_y), 1);
+    p_glMemoryBarrier(GL_ALL_BARRIER_BITS);
+    p_glFinish();
+    p_glPixelStorei(GL_PACK_ALIGNMENT, 1);
+    p_glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, out_float ? GL_FLOAT : GL_UNSIGNED_BYTE, out);
+    GLenum e = p_glGetError();
+    p_glUseProgram(0);
+    p_glDeleteTextures(1, &tex);
+    p_glDeleteBuffers(nb, bufs);
+    if (e != GL_NO_ERROR) {
+        snprintf(g_err, sizeof g_err, "GL error 0x%x during dispatch", e);
+        return -1;
+    }
+    return 0;
+}

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ref/*.npz: outputs of the REFERENCE's own compute shader
+(/root/reference/assets/shaders/brick_raytracer.comp), compiled by Mesa 23.2.1's GLSL compiler and executed
+by llvmpipe in this container (oracle/_ref, recipe in oracle/ref_gl/recipe.py).
+
+These are the vectors that pin the oracle: each fixture holds the complete inputs as data (the seven
+buffers of bindings 1..7, the 128 push-constant bytes, the brick dimension the pipeline is specialised with)
+and the frame the reference shader produced for them — RGBA8 exactly as its `Rgba8` image receives it, and the
+float colour of the rgba32f build of the same shader (recipe edit E8).  No shader text is stored.
+
+    python tests/golden/make_ref_golden.py        # needs /root/reference (build container only)
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+from oracle.ref_gl import GlRef, ReferenceShader  # noqa: E402
+from tests.helpers import oracle_scene_from_grid  # noqa: E402
+from zig_vulkan_amd import default_materials  # noqa: E402
+from zig_vulkan_amd import workloads as W  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref")
+
+
+def mixed_materials():
+    """Every material type on the terrain's material ids 0..7: glass, lambertian, metal, unknown (quirk 8)."""
+    m = default_materials(256).copy()
+    m["type"][:8] = [2, 0, 1, 0, 7, 1, 2, 0]
+    m["type_data"][:8] = [1.333, 0.0, 0.3, 0.0, 0.0, 0.05, 1.5, 0.0]
+    return m
+
+
+# name -> (workload, view, materials or None for the reference's default table)
+CASES = {
+    # BASELINE.json configs[0] itself: 256x256, 64^3 dense, 1 primary ray per pixel, on the reference shader
+    "cfg0_V0": (W.WORKLOADS["cfg0_256x256_64c_b4"], "V0", None),
+    "cfg0_V1": (W.WORKLOADS["cfg0_256x256_64c_b4"], "V1", None),
+    "cfg0_V2": (W.WORKLOADS["cfg0_256x256_64c_b4"], "V2", None),
+    # the headline path at fixture size: 8^3 bricks, primary + shadow ray, hard and soft sun
+    "shadow_b8_r0_V0": (W.Workload("shadow_b8_r0", 160, 90, 128, 8, 1, 0, True, 0.0), "V0", None),
+    "shadow_b8_r0_V1": (W.Workload("shadow_b8_r0", 160, 90, 128, 8, 1, 0, True, 0.0), "V1", None),
+    "shadow_b8_r0_V2": (W.Workload("shadow_b8_r0", 160, 90, 128, 8, 1, 0, True, 0.0), "V2", None),
+    "shadow_b8_r5_V2": (W.Workload("shadow_b8_r5", 160, 90, 128, 8, 1, 0, True, 5.0), "V2", None),
+    # several samples per pixel (hash12 jitter), bounces, every scatter function, sin-based RNG
+    "path_b4_spp3_b2_V2": (W.Workload("path_b4", 160, 90, 64, 4, 3, 2, True, 5.0), "V2", None),
+    "path_b8_spp2_b3_mixed_V0": (W.Workload("path_b8", 160, 90, 128, 8, 2, 3, False, 0.0), "V0", "mixed"),
+    "path_b8_spp2_b3_mixed_sun_V1": (W.Workload("path_b8s", 160, 90, 128, 8, 2, 3, True, 5.0), "V1", "mixed"),
+    # sparse allocation (brick_alloc < cells), the shape of configs[4]
+    "sparse_b8_spp4_b2_V2": (W.Workload("sparse_b8", 160, 90, 256, 8, 4, 2, True, 5.0, "sparse", 0.08, 20000), "V2", None),
+}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    info = GlRef().info()
+    refs = {}
+    for name, (w, view, mats) in CASES.items():
+        grid = W.build_grid(w)
+        materials = mixed_materials() if mats == "mixed" else default_materials(256)
+        scene = oracle_scene_from_grid(grid, materials)
+        pc = O.push_constants(W.camera_for(w, view).blob(), W.sun_for(w).blob())
+        ref = refs.setdefault(w.brick_dimension, ReferenceShader(w.brick_dimension))
+        f, u = ref.render(scene, pc)
+        # sanity: the restatement with llvmpipe's lowering must agree (this is what tests/test_ref_gl.py asserts)
+        fo, uo, _ = O.render(scene, pc, lowering="llvmpipe")
+        same = bool(np.array_equal(f.view(np.uint32), fo.view(np.uint32)) and np.array_equal(u, uo))
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"),
+            provenance=np.array(f"brick_raytracer.comp + rand.comp of /root/reference, OpenGL dialect edits E1-E8 of "
+                                f"oracle/ref_gl/recipe.py, {info}"),
+            brick_dimension=np.int32(w.brick_dimension),
+            grid_state=scene.grid_state, materials=scene.materials.view(np.uint8).reshape(-1),
+            brick_status=scene.brick_status, brick_index=scene.brick_index, brick_occupancy=scene.brick_occupancy,
+            brick_start_index=scene.brick_start_index, material_index=scene.material_index,
+            push_constants=pc,
+            rgba8=u, rgb32f=np.ascontiguousarray(f[:, :, :3]),
+            float_sha256=np.array(hashlib.sha256(f.tobytes()).hexdigest()))
+        print(f"{name}: {w.width}x{w.height}, oracle(llvmpipe lowering) bit-equal: {same}")
+
+
+if __name__ == "__main__":
+    main()
