@@ -3,19 +3,20 @@
 
   python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
-A step is one full frame of the workload (all pixels, every ray the shader
-casts for them) at one of the three fixed camera views: the first third of the
-steps renders V0, the second third V1, the last third V2.  The
-scene is resident in HBM before the timed region.  For N>1 the driver launches
-one process per GPU (torch.distributed, backend nccl = RCCL): the frame is
-sharded by interleaved 16x16 tiles and gathered to rank 0 once per frame.
-Rank 0 prints ONE JSON line.
+A step is one full frame of the workload (all pixels, every ray the shader casts for them) at one of the fixed
+camera views: the steps are split evenly over V0, V1, V2 (consecutive frames share a view).  The scene is resident
+in HBM before the timed region.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the frame is
+sharded by interleaved 16x16 tiles and each frame's shards are gathered to rank 0 once.  Launched
+without rank environment (`python bench.py --gpus 8`), the script re-executes itself under
+`python -m torch.distributed.run --standalone --nproc-per-node N`; it never reports fewer ranks than asked.
+Rank 0 prints ONE JSON line (fields: DESIGN.md §6).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,15 +24,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VIEW_ORDER = ["V0", "V1", "V2"]
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VIEW_ORDER = ["V0", "V1", "V2"]          # cycled by the timed region
+EXTRA_VIEWS = ["V1x", "VG"]              # reported per view only: outside-the-box view of round 1, all-ground view
+SETTLE_FRAMES = 128                      # untimed frames after a camera jump (the tile schedule follows with a lag)
 
 
-def cpu_baseline(w, grid, min_wall_s: float):
-    """Oracle (CPU restatement of the reference shader, oracle/vrt_oracle.c) on the host cores of this
-    box.  Bounded sample: whole frames of the workload, views cycled V0,V1,V2, until `min_wall_s` of
-    wall time has passed (at least one frame per view); rows are handed to the threads one at a time.
-    kind = "port": the reference itself cannot be built here (no zig / GLSL compiler / Vulkan ICD)."""
+def metric_name(w) -> str:
+    rays = "primary + shadow" if w.sun_enabled else "primary"
+    if w.max_bounce > 0:
+        rays += f" + {w.max_bounce} bounce(s)"
+    return (f"Mrays/s at {w.width}x{w.height} on {w.voxels}^3 brickmap ({w.brick_dimension}^3 bricks, {rays}, {w.spp} spp); "
+            "achieved % of HBM roofline")
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def cpu_baseline_port(w, grid, min_wall_s: float, per_view):
+    """Oracle (CPU restatement of the reference shader, oracle/vrt_oracle.c) on all host cores of this box.
+    Bounded sample: whole frames, views cycled, until `min_wall_s` of wall time (at least one frame per view)."""
     import ctypes as C
     import threading
 
@@ -78,16 +88,119 @@ def cpu_baseline(w, grid, min_wall_s: float):
                       f"= {dt * cores:.0f} core-seconds; oracle/vrt_oracle.c gcc -O2, {cores} threads, rows handed out one at a time"}
 
 
-def hbm_traffic_from_profile(brick_dimension: int):
-    """HBM bytes per launch of the traversal kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/*_pmc.json, written by tools/summarize_prof.py; bench.py cannot run rocprofv3 on
-    itself).  FETCH_SIZE and WRITE_SIZE are in KiB, collected in separate passes.  WRITE_SIZE equals the
-    RGBA8 frame exactly (8100 KiB at 1080p); FETCH_SIZE on gfx950 reports half of the bytes fetched
-    (MI355X_MICROARCH.md) — for scattered dword loads as well: tools/ubench/fetch_calib.hip reads a 2 GiB buffer
-    with one dword per 128-byte line and gets 1.00 GiB, memory being fetched in whole lines and tallied at 64 bytes
-    per line — so `traffic` uses the doubled figure (the raw one is quoted beside it)."""
+def cpu_baseline_reference(w, grid, min_wall_s: float, per_view):
+    """The reference's own shader (brick_raytracer.comp) compiled by Mesa and run by llvmpipe on this box's host cores
+    (oracle/_ref; north_star's "reference under lavapipe": same gallivm back end, OpenGL instead of Vulkan front end).
+    Scene buffers are uploaded once; each frame pushes the 128 constant bytes and dispatches ceil(W/32) x ceil(H/32)
+    workgroups, timed to glFinish.  Returns (dict, None) or (None, reason)."""
+    try:
+        from oracle import oracle as O
+        from oracle import ref_gl
+        from tests.helpers import oracle_scene_from_grid
+        from zig_vulkan_amd import workloads as W
+        reason = ref_gl.available()
+        if reason is not None:
+            return None, reason
+        ref = ref_gl.ReferenceShader(w.brick_dimension, want_float=False)
+        scene = oracle_scene_from_grid(grid)
+        pcs = [O.push_constants(W.camera_for(w, v).blob(), W.sun_for(w).blob()) for v in VIEW_ORDER]
+        try:
+            ref.bind(scene, pcs[0])
+        except ref_gl.GlRefUnavailable as e:   # a storage block above GL_MAX_SHADER_STORAGE_BLOCK_SIZE (128 MiB)
+            return None, str(e)
+        ref.frame(pcs[0])  # untimed: JIT of the compute variant, page faults
+        t0 = time.perf_counter()
+        frames = 0
+        rays = 0
+        while frames < len(VIEW_ORDER) or time.perf_counter() - t0 < min_wall_s:
+            v = VIEW_ORDER[frames % len(VIEW_ORDER)]
+            ref.frame(pcs[frames % len(VIEW_ORDER)])
+            rays += per_view[v]["rays"]
+            frames += 1
+        dt = time.perf_counter() - t0
+        threads = ref.gl.worker_threads()
+        info = ref.gl.info()
+        ref.unbind()
+        return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "reference",
+                "sample": f"{frames} whole frames of {w.name} (views {'/'.join(VIEW_ORDER)} cycled), {rays} rays in {dt:.2f} s wall; "
+                          f"assets/shaders/brick_raytracer.comp of the reference as Mesa program binary (oracle/_ref), {info}, "
+                          f"{threads} llvmpipe worker threads (Mesa's cap) on a {os.cpu_count()}-core host"}, None
+    except Exception as e:  # noqa: BLE001 - a baseline must never take the bench down
+        return None, f"{type(e).__name__}: {e}"
+
+
+# ------------------------------------------------------------------------------------------------ PMC (rocprofv3)
+PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
+              ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVES",
+               "SQ_BUSY_CYCLES"]]
+
+
+def pmc_child(args) -> None:
+    """Run under `rocprofv3 --pmc`: the product kernel alone, single stream, a few settled frames per view.
+    No torch import (start-up time), nothing printed."""
+    from zig_vulkan_amd import workloads as W
+    w = W.WORKLOADS[args.workload or W.HEADLINE]
+    grid = W.build_grid(w)
+    rt = W.make_renderer(w, grid, kernel_variant=args.variant, frames_in_flight=1)
+    for v in VIEW_ORDER:
+        W.set_view(rt, v)
+        rt.draw(frames=args.pmc_frames)
+        rt.wait()
+    rt.deinit()
+
+
+def _pmc_read(dirs, kernel_substr: str):
     import glob
-    # the shipped kernel's passes are r<round>_final_pmc.json (latest round last); other *_pmc.json files are earlier kernels
+    import sqlite3
+    out = {}
+    for d in dirs:
+        for f in sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)):
+            db = sqlite3.connect(f)
+            for c, v, n in db.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like ? "
+                                      "group by counter_name", (f"%{kernel_substr}%",)):
+                out[c] = v
+                out["_dispatches"] = n
+    return out
+
+
+def pmc_live(args, w):
+    """HBM bytes and instruction counts per launch of the traversal kernel, measured now: one `rocprofv3 --kernel-trace
+    --pmc <group>` pass per counter group over `bench.py --pmc-child` (counters are never combined with other trace
+    domains; FETCH_SIZE and WRITE_SIZE do not fit one pass — MI355X_MICROARCH.md).  Returns (counters, note)."""
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="vrt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    dirs = []
+    t0 = time.perf_counter()
+    try:
+        for i, group in enumerate(PMC_PASSES):
+            d = os.path.join(tmp, f"pmc{i}")
+            cmd = [exe, "--kernel-trace", "--pmc", *group, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--workload", w.name, "--variant", str(args.variant), "--pmc-frames", str(args.pmc_frames)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=args.pmc_timeout)
+            if r.returncode != 0:
+                return None, f"rocprofv3 pass {group} exited {r.returncode}: {r.stdout.decode(errors='replace')[-300:]}"
+            dirs.append(d)
+        c = _pmc_read(dirs, f"vrt_trace_kernel<{w.brick_dimension}, false")
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            return None, "rocprofv3 ran but the traversal kernel's counters were not found"
+        return c, (f"measured in this run: {len(PMC_PASSES)} rocprofv3 --pmc passes over {int(c.get('_dispatches', 0))} launches of the product "
+                   f"kernel ({args.pmc_frames} frames per view, single stream), {time.perf_counter() - t0:.0f} s")
+    except Exception as e:  # noqa: BLE001
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_from_profile(brick_dimension: int):
+    """Fallback: the committed PMC passes of the same command (profiles/r*_final_pmc.json, tools/summarize_prof.py)."""
+    import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_pmc.json")))
     if not files:
         return None, "no profiles/r*_final_pmc.json"
@@ -95,13 +208,82 @@ def hbm_traffic_from_profile(brick_dimension: int):
         data = json.load(fh)
     for name, c in data.items():
         if "vrt_trace_kernel<%d, false" % brick_dimension in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            fetch, write = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
-            return 2.0 * fetch + write, (f"{os.path.basename(files[-1])}: FETCH_SIZE {fetch / 1e6:.2f} MB raw (x2 = {2 * fetch / 1e6:.2f} MB), "
-                                         f"WRITE_SIZE {write / 1e6:.2f} MB per launch; the touched scene data lives in L2/MALL")
+            return c, f"NOT measured in this run: read from the committed {os.path.basename(files[-1])} (an earlier run of this command)"
     return None, "traversal kernel not found in " + os.path.basename(files[-1])
 
 
-def main() -> None:
+# ------------------------------------------------------------------------------------------------ launch plumbing
+def ensure_ranks(args, argv) -> None:
+    """`--gpus N` with N > 1 and no rank environment: re-execute under torch.distributed.run with N ranks on this node.
+    Exits non-zero instead of running on fewer GPUs than asked."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    if not args.stub:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s): refusing to run on fewer")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print(f"[bench] no rank environment: re-executing as {' '.join(cmd)}", file=sys.stderr)
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
+class _StubRT:
+    """TEST ONLY (`--stub`, tests/test_bench_plumbing.py): stands in for the renderer so that the rank plumbing —
+    environment, process group, broadcasts, the native/torch agreement, max-over-ranks timing, the one JSON line —
+    runs at world size 2 over gloo on a box without GPUs.  Renders nothing."""
+
+    def __init__(self, fail_native: bool):
+        import types
+        self.fail_native = fail_native
+        self.camera = types.SimpleNamespace(d_camera=(bytearray(96)))
+        self.frames = 0
+
+    def draw(self, frames: int = 1):
+        self.frames += frames
+        time.sleep(0.0005 * frames)
+
+    def dist_init(self, *a, **k):
+        if self.fail_native:
+            raise RuntimeError("stub: native pipeline unavailable on this rank")
+
+    def dist_frame(self):
+        self.draw()
+
+    def dist_info(self):
+        return {"rank": int(os.environ.get("RANK", "0")), "world": int(os.environ.get("WORLD_SIZE", "1")), "frames_per_launch": 1,
+                "launches_in_flight": 1}
+
+    def set_target(self, *a):
+        pass
+
+    def assemble_frame(self, *a):
+        pass
+
+    def kernel_name(self):
+        return "stub"
+
+    def dist_wait(self):
+        pass
+
+    wait = deinit = dist_selftest = dist_wait
+
+
+def percentiles(ms):
+    import numpy as np
+    a = np.sort(np.asarray(ms, dtype=np.float64))
+    return {"median": float(np.percentile(a, 50)), "p10": float(np.percentile(a, 10)), "p90": float(np.percentile(a, 90)),
+            "mean": float(a.mean()), "n": int(a.size)}
+
+
+def main(argv=None) -> None:
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=600)
@@ -109,19 +291,31 @@ def main() -> None:
     ap.add_argument("--workload", default=None)
     ap.add_argument("--variant", type=lambda x: int(x, 0), default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=2.0, help="minimum wall time of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="minimum wall time of each CPU baseline sample")
     ap.add_argument("--frames-in-flight", type=int, default=2, help="1: frames strictly one after another; 2: two frames in flight")
+    ap.add_argument("--pmc", choices=["auto", "live", "profile", "off"], default="auto",
+                    help="HBM traffic / instruction counters of the roofline object: live = rocprofv3 passes over a child run now; "
+                         "profile = the committed profiles/*_pmc.json; auto = live, falling back to profile")
+    ap.add_argument("--pmc-frames", type=int, default=24, help="frames per view of a PMC child run")
+    ap.add_argument("--pmc-timeout", type=float, default=240.0)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dist", choices=["native", "torch"], default="native",
-                    help="N>1 frame gather: native = RCCL send/recv inside libvrt_hip.so (pipelined, 4 frames in flight); "
-                         "torch = torch.distributed.gather from Python (fallback)")
+                    help="N>1 frame gather: native = RCCL send/recv inside libvrt_hip.so (pipelined); torch = torch.distributed.gather (fallback)")
     ap.add_argument("--dist-frames", type=int, default=4, help="launches in flight per rank of the native multi-GPU pipeline")
     ap.add_argument("--dist-batch", type=int, default=4,
-                    help="frames traced by one launch and gathered by one collective when world > 1 (a rank owns 1/world of the tiles)")
+                    help="frames traced by one launch and carried by one collective when world > 1 (every frame is gathered once; "
+                         "1 = one collective per frame)")
     ap.add_argument("--root-share", type=int, default=-1,
-                    help="native multi-GPU pipeline: rank 0's share of the tiles in percent of an equal share (it also takes in the other "
-                         "ranks' shards and un-swizzles every frame); -1: 100 - 40 (world - 1) / 7, i.e. 60 at 8 GPUs, 83 at 4, 94 at 2")
+                    help="native multi-GPU pipeline: rank 0's share of the tiles in percent of an equal share; -1: 100 - 40 (world - 1) / 7")
     ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")
-    args = ap.parse_args()
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)            # tests/test_bench_plumbing.py
+    ap.add_argument("--stub-fail-native-on", type=int, default=-1, help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
+
+    if args.pmc_child:
+        pmc_child(args)
+        return
+    ensure_ranks(args, argv)
 
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio (flushed at exit, i.e.
     # after anything Python printed), so everything else written to fd 1 by any library is sent to stderr and the
@@ -132,42 +326,80 @@ def main() -> None:
 
     import numpy as np
     import torch
-    from zig_vulkan_amd import workloads as W
-    from zig_vulkan_amd.dist import FrameGather
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    stub = args.stub
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the traversal path has no CPU implementation")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:
-        import torch.distributed as dist
+    if not stub:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if stub:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
+    def sync() -> None:
+        if not stub:
+            torch.cuda.synchronize()
+
+    # every rank announces itself: rank 0 reports who took part
+    ranks_seen = [rank]
+    if use_dist and world > 1:
+        t = torch.zeros(world, dtype=torch.int32, device=dev)
+        t[rank] = 1
+        dist.all_reduce(t)
+        ranks_seen = [i for i in range(world) if int(t[i].item()) == 1]
+        if len(ranks_seen) != world:
+            raise SystemExit(f"bench.py: only ranks {ranks_seen} of {world} answered")
+
+    from zig_vulkan_amd import workloads as W
     w = W.WORKLOADS[args.workload or W.HEADLINE]
-    grid = W.build_grid(w)
+    grid = None if stub else W.build_grid(w)
     sharded = world > 1 or args.force_gather
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = 0 if stub else torch.cuda.current_stream().cuda_stream
+    all_views = VIEW_ORDER + EXTRA_VIEWS
 
-    # ---- rays and algorithmic bytes per view: counted by a counters build of the kernel (untimed) ----
+    # ---- rays and bytes per view, counted by counting builds of the kernel (untimed) ----
     per_view = {}
-    if rank == 0:
-        rtc = W.make_renderer(w, grid, enable_counters=True, device_id=local_rank, kernel_variant=args.variant)
-        for v in VIEW_ORDER:
-            W.set_view(rtc, v)
-            rtc.draw()
-            c = rtc.counters()
-            per_view[v] = {"rays": c["rays"],
-                           "bytes": 4 * c["status_loads"] + 4 * c["bricks_entered"] + c["voxel_steps"] + 25 * c["hits"]
-                           + 4 * w.width * w.height,
-                           "counters": c}
-        rtc.deinit()
-    if dist is not None and world > 1:
+    if rank == 0 and not stub:
+        pixels = w.width * w.height
+        for mode, key in ((1, "counters"), (2, "issued")):
+            rtc = W.make_renderer(w, grid, enable_counters=mode, device_id=local_rank, kernel_variant=args.variant)
+            for v in all_views:
+                W.set_view(rtc, v)
+                rtc.draw()
+                c = rtc.counters()
+                pv = per_view.setdefault(v, {})
+                pv[key] = c
+                if mode == 1:
+                    # the loads of the REFERENCE algorithm (per-lane word cache, walk to the grid's face)
+                    pv["rays"] = c["rays"]
+                    pv["bytes"] = 4 * c["status_loads"] + 4 * c["bricks_entered"] + c["voxel_steps"] + 25 * c["hits"] + 4 * pixels
+                    primaries = pixels * w.spp
+                    if w.max_bounce == 0:
+                        ph = (c["rays"] - primaries) if w.sun_enabled else c["hits"]
+                        pv["primary_hit_fraction"] = ph / primaries
+                    else:
+                        pv["primary_hit_fraction"] = None
+                else:
+                    # what the PRODUCT kernel requests: a status dword per brick-level trip of a walk that ends at
+                    # the occupied-cell box; per brick entered the index, the start index and the first occupancy dword; an
+                    # occupancy dword per voxel trip; per hit the material id and the 20-byte material; the pixel store
+                    pv["issued_bytes"] = (4 * c["grid_steps"] + 12 * c["bricks_entered"] + 4 * c["voxel_steps"] + 21 * c["hits"] + 4 * pixels)
+            rtc.deinit()
+    elif stub:
+        per_view = {v: {"rays": 1000, "bytes": 4000, "issued_bytes": 2000, "counters": {}, "issued": {}, "primary_hit_fraction": 0.5}
+                    for v in all_views}
+    if use_dist and world > 1:
         obj = [per_view]
         dist.broadcast_object_list(obj, src=0)
         per_view = obj[0]
@@ -175,65 +407,89 @@ def main() -> None:
     # ---- the timed renderer ----
     fg = None
     native = False
+    rt = None
+    dist_info = None
     if sharded and args.dist == "native":
-        # RCCL inside libvrt_hip.so: kernel -> grouped send/recv to rank 0 -> un-swizzle, several frames in flight
-        from zig_vulkan_amd import VoxelRT
+        # RCCL inside libvrt_hip.so: kernel -> grouped send/recv to rank 0 -> un-swizzle, several launches in flight
         ok = 1
-        rt = None
         try:
-            uid = [VoxelRT.dist_unique_id() if rank == 0 else None]
-            if dist is not None and world > 1:
-                dist.broadcast_object_list(uid, src=0)
             root_share = args.root_share if args.root_share >= 0 else max(30, 100 - (40 * (world - 1) + 3) // 7)
-            rt = W.make_renderer(w, grid, device_id=local_rank, shard_rank=rank, shard_count=world, kernel_variant=args.variant,
-                                 shard_root_weight=(root_share if 2 <= world <= 8 else 0))
+            if stub:
+                uid = [b"stub"]
+                rt = _StubRT(fail_native=(rank == args.stub_fail_native_on))
+            else:
+                from zig_vulkan_amd import VoxelRT
+                uid = [VoxelRT.dist_unique_id() if rank == 0 else None]
+            if use_dist and world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            if not stub:
+                rt = W.make_renderer(w, grid, device_id=local_rank, shard_rank=rank, shard_count=world, kernel_variant=args.variant,
+                                     shard_root_weight=(root_share if 2 <= world <= 8 else 0))
             rt.dist_init(uid[0], rank, world, args.dist_frames, frames_per_launch=(args.dist_batch if world > 1 else 1))
             if world == 1:
                 rt.dist_selftest()
+            dist_info = rt.dist_info()
         except Exception as e:  # noqa: BLE001 - any failure means "use the torch path"
             print(f"[bench rank {rank}] native RCCL pipeline unavailable: {e}", file=sys.stderr)
             ok = 0
-        if dist is not None and world > 1:  # every rank must take the same path
-            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        if use_dist and world > 1:  # every rank must take the same path
+            t = torch.tensor([ok], dtype=torch.int32, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             ok = int(t.item())
         native = bool(ok)
         if not native and rt is not None:
             rt.deinit()
+            rt = None
     if sharded and not native:
-        fg = FrameGather(w.width, w.height, rank, world, torch.device("cuda", local_rank))
-        rt = W.make_renderer(w, grid, device_id=local_rank, shard_rank=rank, shard_count=world, stream=stream,
-                             external_target_rgba8=fg.shard.data_ptr(), kernel_variant=args.variant)
+        from zig_vulkan_amd.dist import FrameGather
+        fg = FrameGather(w.width, w.height, rank, world, dev)
+        if stub:
+            rt = _StubRT(False)
+        else:
+            rt = W.make_renderer(w, grid, device_id=local_rank, shard_rank=rank, shard_count=world, stream=stream,
+                                 external_target_rgba8=fg.shard.data_ptr(), kernel_variant=args.variant)
     elif not sharded:
-        rt = W.make_renderer(w, grid, device_id=local_rank, kernel_variant=args.variant, frames_in_flight=args.frames_in_flight)
+        rt = _StubRT(False) if stub else W.make_renderer(w, grid, device_id=local_rank, kernel_variant=args.variant,
+                                                         frames_in_flight=args.frames_in_flight)
+    # the communicator's own idea of its size, from every rank
+    rccl_world = None
+    if native and dist_info is not None:
+        rccl_world = dist_info["world"]
+        if use_dist and world > 1:
+            t = torch.tensor([dist_info["world"]], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            rccl_world = int(t.item())
+        if rccl_world != world:
+            raise SystemExit(f"bench.py: the RCCL communicator spans {rccl_world} ranks, {world} were launched")
     if native:
         rt.dist_wait()
     else:
         rt.wait()
 
-    cams = {}
-    for v in VIEW_ORDER:
-        W.set_view(rt, v)
-        cams[v] = bytes(rt.camera.d_camera)
-
     import ctypes as C
-    from zig_vulkan_amd import _lib as L
+    cams = {}
+    if not stub:
+        for v in all_views:
+            W.set_view(rt, v)
+            cams[v] = bytes(rt.camera.d_camera)
+
+    def set_cam(v: str) -> None:
+        if not stub:
+            C.memmove(C.byref(rt.camera.d_camera), cams[v], 96)
 
     def view_of(i: int, n: int) -> str:
-        # frames of one view are consecutive (a camera moves smoothly; the tile schedule feeds on the
-        # previous frame): first third V0, second third V1, last third V2
+        # frames of one view are consecutive (a camera moves smoothly; the tile schedule feeds on the previous frames)
         return VIEW_ORDER[min(len(VIEW_ORDER) - 1, (i * len(VIEW_ORDER)) // max(n, 1))]
 
     frame_no = [0]  # frames submitted so far (warm-up included): the gather pipeline's slot counter
 
     def step(i: int, n: int) -> None:
-        v = view_of(i, n)
-        C.memmove(C.byref(rt.camera.d_camera), cams[v], 96)
+        set_cam(view_of(i, n))
         if not sharded:
             rt.draw()
             return
         if native:
-            rt.dist_frame()                     # kernel -> one RCCL gather -> un-swizzle, on this frame's stream
+            rt.dist_frame()                     # kernel -> RCCL gather -> un-swizzle, on this launch's stream
             return
         f = frame_no[0]
         frame_no[0] += 1
@@ -242,85 +498,153 @@ def main() -> None:
         rt.draw()                               # this rank's tiles of frame f
         fg.gather_async(f)                      # ONE collective per frame, overlapped with frame f+1's kernel
         if f >= 1:
-            fg.complete(f - 1, rt)              # rank 0: un-swizzle the previous frame
+            fg.complete(f - 1, None if stub else rt)   # rank 0: un-swizzle the previous frame
 
     def drain() -> None:
         if native:
             rt.dist_wait()
         elif sharded and frame_no[0] >= 1:
-            fg.complete(frame_no[0] - 1, rt)
+            fg.complete(frame_no[0] - 1, None if stub else rt)
 
     def barrier() -> None:
-        if dist is not None and world > 1:
+        if use_dist and world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
+
+    def timed_region(n: int) -> float:
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(i, n)
+        drain()  # the last frame's gather + un-swizzle belong to the timed region
+        if not native:
+            rt.wait()
+        barrier()
+        dt = time.perf_counter() - t0
+        if use_dist and world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
     for i in range(args.warmup):
         step(i, args.warmup)
     drain()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, args.steps)
-    drain()  # the last frame's gather + un-swizzle belong to the timed region
-    if not native:
-        rt.wait()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None and world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed_region(args.steps)
 
-    # ---- dominant-kernel duration with HIP events on the kernel's own stream (N=1 only) ----
+    # ---- N = 1: the same steps strictly one frame after another, and the dominant kernel by HIP events ----
     roofline = None
-    kernel_ms_view = {}
-    if rank == 0 and not sharded:
-        reps = max(5, args.steps // len(VIEW_ORDER))
-        for v in VIEW_ORDER:
-            C.memmove(C.byref(rt.camera.d_camera), cams[v], 96)
+    single = None
+    if rank == 0 and not sharded and not stub:
+        rt1 = rt
+        if args.frames_in_flight != 1:
+            rt.deinit()
+            rt1 = rt = W.make_renderer(w, grid, device_id=local_rank, kernel_variant=args.variant, frames_in_flight=1)
+        for i in range(args.warmup):
+            step(i, args.warmup)
+        single = timed_region(args.steps) / args.steps * 1e3
+        reps = max(8, args.steps // len(VIEW_ORDER))
+        kernel_ms_view, frame_stats = {}, {}
+        for v in all_views:
+            set_cam(v)
             # untimed: the camera has just jumped to this view, and the launch order follows the measured tile costs with
             # a lag (re-sorted every 32 frames from a running mean): let it settle as it would under a moving camera
-            rt.draw(frames=128)
-            rt.draw(frames=reps)
-            kernel_ms_view[v] = rt.last_kernel_ms()
-        avg_ms = sum(kernel_ms_view.values()) / len(kernel_ms_view)
+            rt1.draw(frames=SETTLE_FRAMES)
+            rt1.draw(frames=reps)                           # back to back, one event pair around all of them
+            kernel_ms_view[v] = rt1.last_kernel_ms()
+            frame_stats[v] = percentiles(rt1.draw_timed(min(reps, 512)))   # an event pair around every frame
+        avg_ms = sum(kernel_ms_view[v] for v in VIEW_ORDER) / len(VIEW_ORDER)
         avg_bytes = sum(per_view[v]["bytes"] for v in VIEW_ORDER) / len(VIEW_ORDER)
+        avg_issued = sum(per_view[v]["issued_bytes"] for v in VIEW_ORDER) / len(VIEW_ORDER)
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_note = hbm_traffic_from_profile(w.brick_dimension)
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                    "traffic": traffic, "traffic_note": traffic_note, "kernel": rt.kernel_name(), "kernel_ms_avg": avg_ms,
-                    "kernel_ms_per_view": kernel_ms_view, "algorithmic_bytes_per_launch": avg_bytes}
+        pmc, pmc_note = (None, "--pmc off")
+        if args.pmc in ("auto", "live"):
+            rt1.wait()
+            pmc, pmc_note = pmc_live(args, w)
+        if pmc is None and args.pmc in ("auto", "profile"):
+            why = pmc_note
+            pmc, pmc_note = pmc_from_profile(w.brick_dimension)
+            if args.pmc == "auto":
+                pmc_note = f"{pmc_note} (live measurement failed: {why})"
+        traffic = issue_ipc = None
+        insts = None
+        if pmc is not None:
+            # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE on gfx950 tallies 64 B per 128-byte line fetched
+            # (MI355X_MICROARCH.md; tools/ubench/fetch_calib.hip confirms it for scattered dword reads): doubled
+            traffic = 2.0 * pmc["FETCH_SIZE"] * 1024.0 + pmc["WRITE_SIZE"] * 1024.0
+            keys = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_INSTS_LDS")
+            if all(k in pmc for k in keys[:3]):
+                insts = {k: pmc.get(k, 0.0) for k in keys}
+                from zig_vulkan_amd import _lib as VL
+                di = (C.c_int64 * 4)()
+                VL.check(VL.lib.vrt_device_info(local_rank, di))
+                clock_hz = di[0] * 1e3
+                simds = int(di[1]) * 4
+                issue_ipc = sum(insts.values()) / (simds * avg_ms * 1e-3 * clock_hz)
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_note": pmc_note,
+            "definition": "achieved = bytes the REFERENCE algorithm loads for these frames (4 S + 4 K + V + 25 H per ray + 4 B per pixel, "
+                          "SURVEY.md 8(d), counted by the counting build that walks to the grid's face like the shader) / kernel time: a rate "
+                          "of useful work, not of bytes moved.  issued_bytes = what the product kernel's lanes request (its walk ends at the "
+                          "occupied-cell box; 4 B per brick-level trip, 12 per brick entered, 4 per voxel trip, 21 per hit, 4 per pixel). "
+                          "traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE): the touched scene data lives in L2 / MALL.",
+            "kernel": rt1.kernel_name(), "kernel_ms_avg": avg_ms, "kernel_ms_per_view": kernel_ms_view,
+            "frame_ms_percentiles_per_view": frame_stats,
+            "algorithmic_bytes_per_launch": avg_bytes,
+            "issued_bytes": avg_issued, "issued_GBps": avg_issued / (avg_ms * 1e-3) / 1e9,
+            "issue_ipc": issue_ipc,
+            "issue_ipc_note": "wave-instructions per launch (SQ_INSTS_VALU + SALU + VMEM + SMEM + LDS) / (1024 SIMDs x kernel_ms_avg x "
+                              "the device's engine clock): the kernel is bound by instruction issue, not by HBM",
+            "insts_per_launch": insts, "clock_hz": clock_hz if insts else None,
+        }
 
     if rank == 0:
         total_rays = sum(per_view[view_of(i, args.steps)]["rays"] for i in range(args.steps))
+        par = (f"1 GPU, whole frame, {args.frames_in_flight} frame(s) in flight" if not sharded else
+               f"image tiles 16x16 interleaved over {world} GPU(s), every frame gathered once to rank 0, "
+               + (f"native RCCL pipeline: {args.dist_batch if world > 1 else 1} frame(s) per launch and per collective, {args.dist_frames} launches in flight"
+                  if native else "torch.distributed gather per frame, frame f overlaps the kernel of f+1"))
         out = {
-            "metric": "Mrays/s at 1920x1080 on 512^3 brickmap; achieved % of HBM roofline",
+            "metric": metric_name(w),
             "value": total_rays / dt / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_single_stream": single,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "ranks_seen": ranks_seen,
+            "rccl_world": rccl_world,
+            "dist_path": ("native" if native else "torch") if sharded else None,
             "config": {"workload": w.name, "frame": f"{w.width}x{w.height}", "grid": f"{w.voxels}^3 voxels, {w.brick_dimension}^3 bricks",
                        "rays": "primary + shadow" if w.sun_enabled else "primary", "spp": w.spp, "max_bounce": w.max_bounce,
-                       "views": VIEW_ORDER, "rays_per_frame": {v: per_view[v]["rays"] for v in VIEW_ORDER},
-                       "counters_per_frame": {v: per_view[v]["counters"] for v in VIEW_ORDER},
-                       "parallelism": (f"image tiles 16x16 interleaved over {world} GPU(s), 1 RCCL gather per launch to rank 0, "
-                                       + (f"native pipeline, {args.dist_batch if world > 1 else 1} frame(s) per launch, {args.dist_frames} launches in flight" if native else "torch.distributed gather, frame f overlaps kernel of f+1"))
-                       if sharded else f"1 GPU, whole frame, {args.frames_in_flight} frame(s) in flight"},
+                       "views": VIEW_ORDER, "views_reported_only": EXTRA_VIEWS,
+                       "rays_per_frame": {v: per_view[v]["rays"] for v in all_views},
+                       "primary_hit_fraction": {v: per_view[v]["primary_hit_fraction"] for v in all_views},
+                       "counters_per_frame": {v: per_view[v]["counters"] for v in all_views},
+                       "issued_counters_per_frame": {v: per_view[v]["issued"] for v in all_views},
+                       "parallelism": par},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, grid, args.cpu_seconds)
+        if world == 1 and not args.no_cpu_baseline and not stub:
+            port = cpu_baseline_port(w, grid, args.cpu_seconds, per_view)
+            ref, why = cpu_baseline_reference(w, grid, args.cpu_seconds, per_view)
+            if ref is not None:
+                out["cpu_baseline"] = ref
+                out["cpu_baseline_port"] = port
+            else:
+                port["reference_unavailable"] = why
+                out["cpu_baseline"] = port
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    rt.deinit()
-    if dist is not None:
+    if rt is not None:
+        rt.deinit()
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -66,9 +66,9 @@ int main(int argc, char **argv) {
     cc.max_bounce = 0;
     vrt_camera_device cam;
     CHECK(vrt_camera_init(75.0f, width, height, &cc, &cam));
-    // looking at (0, 8, 0); the reference's forward is the direction rays leave AGAINST
+    // view V2: looking at the grid centre (0, 0, 0); the reference's forward is the direction rays leave AGAINST
     // (lower_left_corner = origin - h/2 - v/2 - forward, Camera.zig:177-180); normalised by the callee
-    const float fwd[3] = {cc.origin[0] - 0.0f, cc.origin[1] - 8.0f, cc.origin[2] - 0.0f};
+    const float fwd[3] = {cc.origin[0] - 0.0f, cc.origin[1] - 0.0f, cc.origin[2] - 0.0f};
     CHECK(vrt_camera_set_forward(&cam, 75.0f, 2.0f, fwd));
     vrt_sun_config sc;
     std::memset(&sc, 0, sizeof sc);

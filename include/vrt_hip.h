@@ -112,8 +112,11 @@ typedef struct vrt_config {
     uint32_t material_capacity; /* 0 => 256 (Pipeline.zig:30)                    */
     int32_t device_id;          /* HIP device; -1 => current device              */
     uint32_t want_float_output; /* also keep an RGBA32F target (parity checks)   */
-    uint32_t enable_counters;   /* traversal counters (S,K,V,H,rays): a counting build of the kernel runs
-                                   before the product kernel, which still renders the frame read back */
+    uint32_t enable_counters;   /* traversal counters (S,K,V,H,rays): a counting build of the kernel runs once per
+                                   call, both targets are then overwritten with 0xCD, and the product kernel renders
+                                   the frame that is read back.  1: the counting build walks to the grid's face like
+                                   the shader (the reference algorithm's counts).  2: it ends its brick-level walk at
+                                   the occupied-cell box like the product kernel (the loads the product issues) */
     /* image-tile sharding across processes (one process per GPU).  The frame is
      * cut into tile_w x tile_h tiles, numbered row-major; this context renders
      * tiles t with t % shard_count == shard_rank into a packed tile-major
@@ -175,6 +178,12 @@ int vrt_wait(vrt_ctx *ctx);
  * host round trips (benchmarking; every frame is a full render). */
 int vrt_dispatch_repeat(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames);
 
+/* The same, with the hipEvent time of every frame: ms_per_frame[f] = event before frame f's launch(es) to the event
+ * after them, f = 0 .. frames-1 (<= 4096), all on the context's primary stream, one frame after another (the periodic
+ * re-sort of the tile schedule falls into the frame it precedes).  Blocks until the frames are done.  The measurement
+ * SURVEY.md §8(d) asks for: median and p10/p90 of per-frame kernel times. */
+int vrt_dispatch_timed(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames, float *ms_per_frame);
+
 /* ---- results --------------------------------------------------------------
  * Stand in for handing the storage image to the graphics pass
  * (Pipeline.zig:494-517); layout is what Texture.copyToHost (Texture.zig:185-237)
@@ -214,7 +223,13 @@ int vrt_assemble_frame(vrt_ctx *ctx, const void *gathered, void *dst_frame, uint
  * its own stream (kernel -> gather -> un-swizzle), so one launch's collective overlaps the next launches' kernels.
  * RCCL is reached through dlopen(rccl_path) — pass the library the process already uses (PyTorch's
  * bundled librccl.so) so that there is one RCCL in the address space; libvrt_hip.so does not link it.
- * Rank 0 makes the 128-byte id with vrt_dist_unique_id and the host distributes it to every rank. */
+ * Rank 0 makes the 128-byte id with vrt_dist_unique_id and the host distributes it to every rank.
+ * COLLECTIVE CALLS.  On a context with vrt_dist_init done, every call that launches queued frames carries a
+ * collective and must be made by EVERY rank at the same point of its frame sequence with the same queue length:
+ * vrt_dist_frame (when it fills the queue), vrt_dist_wait, vrt_dist_read_frame — and every scene write
+ * (vrt_upload, vrt_upload_device, vrt_upload_grid, vrt_update_grid_delta), because a scene write first launches
+ * what is queued.  A rank that uploads at another frame than its peers deadlocks the gather.  If a collective fails
+ * (VRT_E_RCCL) the ranks are out of step: the context refuses further vrt_dist_* calls and must be destroyed. */
 int vrt_dist_unique_id(const char *rccl_path, void *out_id128);
 int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight);
 /* The same with frames_per_launch (1..8) consecutive frames traced by ONE kernel launch and gathered by ONE collective:
@@ -230,6 +245,9 @@ int vrt_dist_wait(vrt_ctx *ctx);
 /* rank 0: the most recently submitted frame, row-major RGBA8 (waits for it).  With frames_per_launch > 1 the queue must
  * be empty (full batch just launched, or after vrt_dist_wait): a launch carries a collective, every rank launches together. */
 int vrt_dist_read_frame(vrt_ctx *ctx, void *dst, uint64_t nbytes);
+/* out = {rank, world size — both as the RCCL communicator reports them (ncclCommUserRank / ncclCommCount) —,
+ * frames per launch, launches in flight}: lets a launcher prove how many ranks the gather really spans. */
+int vrt_dist_info(vrt_ctx *ctx, int32_t out[4]);
 /* ncclSend + ncclRecv of one shard to this rank itself: checks the RCCL binding on a single GPU */
 int vrt_dist_selftest(vrt_ctx *ctx);
 
@@ -238,7 +256,7 @@ int vrt_dist_selftest(vrt_ctx *ctx);
  * most recent vrt_dispatch_repeat, in milliseconds; <0 if none completed. */
 double vrt_last_kernel_ms(vrt_ctx *ctx);
 
-/* Traversal counters of the last dispatch (enable_counters=1):
+/* Traversal counters of ONE frame of the last dispatch (enable_counters != 0; the counting build runs once per call):
  * rays = GridHit invocations, S = status-word loads (comp:323-326),
  * K = occupied bricks entered (comp:337), V = voxel steps (comp:415),
  * H = hits (comp:422-427), grid_steps = brick-level DDA iterations. */
@@ -256,6 +274,10 @@ int vrt_get_wave_counters(vrt_ctx *ctx, uint64_t out[3]);
  * pairs written through *n_pairs.  Not part of the reference's interface. */
 int vrt_trace_wave_timeline(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint64_t *out,
                             uint64_t capacity_pairs, uint64_t *n_pairs);
+
+/* out = {engine clock in kHz, compute units, wavefront size, L2 bytes} of HIP device `device` (-1: current):
+ * what bench.py prices an instruction-issue rate against. */
+int vrt_device_info(int device, int64_t out[4]);
 
 const char *vrt_last_error(const vrt_ctx *ctx); /* ctx may be NULL: create errors */
 uint32_t vrt_abi_version(void);

@@ -42,6 +42,10 @@ class GlRef:
             L.glref_get_binary.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_uint32)]
             L.glref_load_binary.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
             L.glref_delete_program.argtypes = [C.c_int]
+            _bufs = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+            L.glref_buffers_set.argtypes = _bufs + _bufs
+            L.glref_ubo_update.argtypes = [C.c_int, C.c_void_p, C.c_int64]
+            L.glref_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
             L.glref_dispatch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                          C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
@@ -84,28 +88,72 @@ class GlRef:
         body = blob[8:]
         prog = self.L.glref_load_binary(body, len(body), fmt)
         if prog <= 0:
+            # Mesa keys a program binary by a SHA-1 of the driver build AND the host's CPU feature bits
+            # (llvmpipe: lp_disk_cache_create -> update_cache_sha1_cpu), so a binary made in the build container is
+            # refused on a box with another CPU although its payload — serialised NIR, made before any machine code —
+            # is the same.  Header (src/mesa/main/program_binary.c): u32 internal_format, u8 sha1[20], u32 size,
+            # u32 crc32 of the payload.  Re-key: take the SHA-1 this host's driver writes into a binary of its own.
+            body = body[:4] + self._local_driver_sha1() + body[24:]
+            prog = self.L.glref_load_binary(body, len(body), fmt)
+        if prog <= 0:
             raise RuntimeError(self._err())
         return prog
+
+    def _local_driver_sha1(self) -> bytes:
+        probe = self.compile("#version 450\nlayout(local_size_x = 1) in;\nvoid main() {}\n")
+        n = self.L.glref_get_binary(probe, None, 0, None)
+        buf = (C.c_uint8 * n)()
+        fmt = C.c_uint32()
+        self.L.glref_get_binary(probe, buf, n, C.byref(fmt))
+        self.delete(probe)
+        return bytes(buf[4:24])
 
     def delete(self, prog: int) -> None:
         self.L.glref_delete_program(prog)
 
-    def dispatch(self, prog: int, width: int, height: int, ubos: Dict[int, np.ndarray], ssbos: Dict[int, np.ndarray],
-                 out_float: bool, workgroup: Tuple[int, int] = (recipe.WORKGROUP, recipe.WORKGROUP)) -> np.ndarray:
-        def pack(d):
-            keys = sorted(d)
-            arrs = [np.ascontiguousarray(d[k]) for k in keys]
-            return (len(keys), (C.c_int * len(keys))(*keys), (C.c_void_p * len(keys))(*[a.ctypes.data for a in arrs]),
-                    (C.c_int64 * len(keys))(*[a.nbytes for a in arrs]), arrs)
-        nu, ub, up, un, keep_u = pack(ubos)
-        ns, sb, sp, sn, keep_s = pack(ssbos)
-        out = np.zeros((height, width, 4), dtype=np.float32 if out_float else np.uint8)
-        rc = self.L.glref_dispatch(prog, width, height, workgroup[0], workgroup[1], nu, ub, up, un, ns, sb, sp, sn,
-                                   1 if out_float else 0, out.ctypes.data)
+    @staticmethod
+    def _pack(d):
+        keys = sorted(d)
+        arrs = [np.ascontiguousarray(d[k]) for k in keys]
+        return (len(keys), (C.c_int * len(keys))(*keys), (C.c_void_p * len(keys))(*[a.ctypes.data for a in arrs]),
+                (C.c_int64 * len(keys))(*[a.nbytes for a in arrs]), arrs)
+
+    def set_buffers(self, ubos: Dict[int, np.ndarray], ssbos: Dict[int, np.ndarray]) -> None:
+        """Create, fill and bind the blocks (copied: the arrays need not outlive the call); they stay bound."""
+        nu, ub, up, un, keep_u = self._pack(ubos)
+        ns, sb, sp, sn, keep_s = self._pack(ssbos)
+        rc = self.L.glref_buffers_set(nu, ub, up, un, ns, sb, sp, sn)
         del keep_u, keep_s
+        if rc != 0:
+            raise (GlRefUnavailable if rc == -2 else RuntimeError)(self._err())
+
+    def update_ubo(self, binding: int, data: np.ndarray) -> None:
+        data = np.ascontiguousarray(data)
+        if self.L.glref_ubo_update(binding, data.ctypes.data, data.nbytes) != 0:
+            raise RuntimeError(self._err())
+
+    def run(self, prog: int, width: int, height: int, out_float: bool, read: bool = True,
+            workgroup: Tuple[int, int] = (recipe.WORKGROUP, recipe.WORKGROUP)) -> Optional[np.ndarray]:
+        out = np.zeros((height, width, 4), dtype=np.float32 if out_float else np.uint8) if read else None
+        rc = self.L.glref_run(prog, width, height, workgroup[0], workgroup[1], 1 if out_float else 0,
+                              out.ctypes.data if read else None)
         if rc != 0:
             raise RuntimeError(self._err())
         return out
+
+    def clear_buffers(self) -> None:
+        self.L.glref_buffers_clear()
+
+    def worker_threads(self) -> int:
+        return int(self.L.glref_worker_threads())
+
+    def dispatch(self, prog: int, width: int, height: int, ubos: Dict[int, np.ndarray], ssbos: Dict[int, np.ndarray],
+                 out_float: bool, workgroup: Tuple[int, int] = (recipe.WORKGROUP, recipe.WORKGROUP)) -> np.ndarray:
+        self.set_buffers(ubos, ssbos)
+        try:
+            return self.run(prog, width, height, out_float, True, workgroup)
+        finally:
+            self.clear_buffers()
 
 
 class ReferenceShader:
@@ -132,15 +180,35 @@ class ReferenceShader:
                                        "in the build container")
             self.progs[fmt] = self.gl.compile(recipe.opengl_dialect(brick_dimension, fmt))
 
-    def render(self, scene, pc: np.ndarray, want_float: bool = True, want_u8: bool = True):
-        assert scene.brick_dimension == self.brick_dimension
-        w, h = (int(v) for v in np.frombuffer(pc[:8].tobytes(), dtype=np.uint32))
+    @staticmethod
+    def _blocks(scene, pc: np.ndarray):
         ubos = {0: np.frombuffer(pc.tobytes(), dtype=np.uint8), 1: scene.grid_state}
         ssbos = {2: scene.materials.view(np.uint8).reshape(-1), 3: scene.brick_status, 4: scene.brick_index,
                  5: scene.brick_occupancy, 6: scene.brick_start_index, 7: scene.material_index}
+        return ubos, ssbos
+
+    def render(self, scene, pc: np.ndarray, want_float: bool = True, want_u8: bool = True):
+        assert scene.brick_dimension == self.brick_dimension
+        w, h = (int(v) for v in np.frombuffer(pc[:8].tobytes(), dtype=np.uint32))
+        ubos, ssbos = self._blocks(scene, pc)
         f = self.gl.dispatch(self.progs["rgba32f"], w, h, ubos, ssbos, True) if want_float else None
         u = self.gl.dispatch(self.progs["rgba8"], w, h, ubos, ssbos, False) if want_u8 else None
         return f, u
+
+    # -- resident scene (bench.py's cpu_baseline leg): buffers uploaded once, 128 constant bytes per frame --
+    def bind(self, scene, pc: np.ndarray) -> None:
+        assert scene.brick_dimension == self.brick_dimension
+        ubos, ssbos = self._blocks(scene, pc)
+        self.gl.set_buffers(ubos, ssbos)
+
+    def frame(self, pc: np.ndarray, read: bool = False) -> Optional[np.ndarray]:
+        """One dispatch of the Rgba8 build over the bound scene; returns when it has finished."""
+        w, h = (int(v) for v in np.frombuffer(pc[:8].tobytes(), dtype=np.uint32))
+        self.gl.update_ubo(0, np.frombuffer(pc.tobytes(), dtype=np.uint8))
+        return self.gl.run(self.progs["rgba8"], w, h, False, read)
+
+    def unbind(self) -> None:
+        self.gl.clear_buffers()
 
 
 def available() -> Optional[str]:

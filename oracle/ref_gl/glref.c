@@ -18,11 +18,13 @@
  *
  * One context per process, used from the thread that called glref_init().
  */
+#include <dirent.h>
 #include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <GL/gl.h>
 #include <GL/glext.h>
@@ -207,53 +209,131 @@ GLREF_API int glref_load_binary(const void *bin, int64_t n, uint32_t format) {
 
 GLREF_API void glref_delete_program(int prog) { if (g_ready && prog > 0) p_glDeleteProgram((GLuint)prog); }
 
-/* One dispatch of a compute program over a width x height image.
- *   ubo[i]  : nubo uniform blocks   -> UBO binding point ubo_binding[i]
- *   ssbo[i] : nssbo storage blocks  -> SSBO binding point ssbo_binding[i]   (sizes in bytes; padded to 4 here)
- *   image unit 0 : a fresh width x height texture, RGBA8 (out_float = 0) or RGBA32F (out_float = 1), write-only
- *   groups = ceil(width / wg_x) x ceil(height / wg_y) x 1   (ComputePipeline.zig:547-550)
- * `out` receives the image rows top to bottom (y ascending), 4 or 16 bytes per pixel.  0 on success. */
-GLREF_API int glref_dispatch(int prog, int width, int height, int wg_x, int wg_y, int nubo, const int *ubo_binding,
-                             const void *const *ubo, const int64_t *ubo_bytes, int nssbo, const int *ssbo_binding,
-                             const void *const *ssbo, const int64_t *ssbo_bytes, int out_float, void *out) {
+/* ---- scene buffers: kept bound between dispatches (the reference uploads its buffers once and only pushes the
+ * 128 constant bytes per frame, ComputePipeline.zig:488-505) ---- */
+static GLuint g_bufs[24];
+static int g_nbufs, g_nubo;
+static int g_ubo_binding[8];
+static GLuint g_tex;
+static int g_tex_w, g_tex_h, g_tex_float = -1;
+
+GLREF_API void glref_buffers_clear(void) {
+    if (!g_ready) return;
+    if (g_nbufs) p_glDeleteBuffers(g_nbufs, g_bufs);
+    g_nbufs = g_nubo = 0;
+    if (g_tex) p_glDeleteTextures(1, &g_tex);
+    g_tex = 0;
+    g_tex_float = -1;
+}
+
+/*   ubo[i]  : nubo uniform blocks   -> UBO binding point ubo_binding[i]
+ *   ssbo[i] : nssbo storage blocks  -> SSBO binding point ssbo_binding[i]   (sizes in bytes; padded to 4 here) */
+GLREF_API int glref_buffers_set(int nubo, const int *ubo_binding, const void *const *ubo, const int64_t *ubo_bytes, int nssbo,
+                                const int *ssbo_binding, const void *const *ssbo, const int64_t *ssbo_bytes) {
     if (!g_ready) return fail("%s", "glref_init not called");
     if (nubo > 8 || nssbo > 16) return fail("%s", "too many buffers");
+    glref_buffers_clear();
     while (p_glGetError() != GL_NO_ERROR) {}
-    GLuint bufs[24];
-    int nb = nubo + nssbo;
-    p_glGenBuffers(nb, bufs);
+    GLint max_ssbo = 0;
+    p_glGetIntegerv(GL_MAX_SHADER_STORAGE_BLOCK_SIZE, &max_ssbo);
+    for (int i = 0; i < nssbo; i++)
+        if (ssbo_bytes[i] > (int64_t)max_ssbo) {
+            snprintf(g_err, sizeof g_err, "storage block %d has %lld bytes, GL_MAX_SHADER_STORAGE_BLOCK_SIZE is %d", ssbo_binding[i],
+                     (long long)ssbo_bytes[i], max_ssbo);
+            return -2;
+        }
+    g_nbufs = nubo + nssbo;
+    g_nubo = nubo;
+    p_glGenBuffers(g_nbufs, g_bufs);
     for (int i = 0; i < nubo; i++) {
-        p_glBindBuffer(GL_UNIFORM_BUFFER, bufs[i]);
-        p_glBufferData(GL_UNIFORM_BUFFER, (GLsizeiptr)ubo_bytes[i], ubo[i], GL_STATIC_DRAW);
-        p_glBindBufferBase(GL_UNIFORM_BUFFER, (GLuint)ubo_binding[i], bufs[i]);
+        g_ubo_binding[i] = ubo_binding[i];
+        p_glBindBuffer(GL_UNIFORM_BUFFER, g_bufs[i]);
+        p_glBufferData(GL_UNIFORM_BUFFER, (GLsizeiptr)ubo_bytes[i], ubo[i], GL_DYNAMIC_DRAW);
+        p_glBindBufferBase(GL_UNIFORM_BUFFER, (GLuint)ubo_binding[i], g_bufs[i]);
     }
     for (int i = 0; i < nssbo; i++) {
         int64_t n = ssbo_bytes[i], padded = (n + 3) & ~(int64_t)3;
         if (padded == 0) padded = 4;
-        p_glBindBuffer(GL_SHADER_STORAGE_BUFFER, bufs[nubo + i]);
+        p_glBindBuffer(GL_SHADER_STORAGE_BUFFER, g_bufs[nubo + i]);
         p_glBufferData(GL_SHADER_STORAGE_BUFFER, (GLsizeiptr)padded, NULL, GL_STATIC_DRAW);
         if (n) p_glBufferSubData(GL_SHADER_STORAGE_BUFFER, 0, (GLsizeiptr)n, ssbo[i]);
         if (padded > n) { const uint32_t z = 0; p_glBufferSubData(GL_SHADER_STORAGE_BUFFER, (GLintptr)n, (GLsizeiptr)(padded - n), &z); }
-        p_glBindBufferBase(GL_SHADER_STORAGE_BUFFER, (GLuint)ssbo_binding[i], bufs[nubo + i]);
+        p_glBindBufferBase(GL_SHADER_STORAGE_BUFFER, (GLuint)ssbo_binding[i], g_bufs[nubo + i]);
     }
-    GLuint tex = 0;
-    p_glGenTextures(1, &tex);
-    p_glBindTexture(GL_TEXTURE_2D, tex);
-    p_glTexStorage2D(GL_TEXTURE_2D, 1, out_float ? GL_RGBA32F : GL_RGBA8, width, height);
-    p_glBindImageTexture(0, tex, 0, GL_FALSE, 0, GL_WRITE_ONLY, out_float ? GL_RGBA32F : GL_RGBA8);
+    if (p_glGetError() != GL_NO_ERROR) return fail("%s", "GL error while creating the scene buffers");
+    return 0;
+}
+
+/* New contents for the uniform block at `binding` (the per-frame push constants). */
+GLREF_API int glref_ubo_update(int binding, const void *data, int64_t bytes) {
+    for (int i = 0; i < g_nubo; i++)
+        if (g_ubo_binding[i] == binding) {
+            p_glBindBuffer(GL_UNIFORM_BUFFER, g_bufs[i]);
+            p_glBufferSubData(GL_UNIFORM_BUFFER, 0, (GLsizeiptr)bytes, data);
+            return 0;
+        }
+    return fail("%s", "no uniform block at that binding");
+}
+
+/* One dispatch over a width x height image with the buffers of glref_buffers_set:
+ *   image unit 0 : a width x height texture, RGBA8 (out_float = 0) or RGBA32F (out_float = 1), write-only
+ *   groups = ceil(width / wg_x) x ceil(height / wg_y) x 1   (ComputePipeline.zig:547-550)
+ * Returns when the dispatch has finished (glFinish).  `out` (may be NULL: timing runs) receives the image rows top to
+ * bottom (y ascending), 4 or 16 bytes per pixel.  0 on success. */
+GLREF_API int glref_run(int prog, int width, int height, int wg_x, int wg_y, int out_float, void *out) {
+    if (!g_ready) return fail("%s", "glref_init not called");
+    while (p_glGetError() != GL_NO_ERROR) {}
+    if (!g_tex || g_tex_w != width || g_tex_h != height || g_tex_float != out_float) {
+        if (g_tex) p_glDeleteTextures(1, &g_tex);
+        p_glGenTextures(1, &g_tex);
+        p_glBindTexture(GL_TEXTURE_2D, g_tex);
+        p_glTexStorage2D(GL_TEXTURE_2D, 1, out_float ? GL_RGBA32F : GL_RGBA8, width, height);
+        g_tex_w = width, g_tex_h = height, g_tex_float = out_float;
+    }
+    p_glBindTexture(GL_TEXTURE_2D, g_tex);
+    p_glBindImageTexture(0, g_tex, 0, GL_FALSE, 0, GL_WRITE_ONLY, out_float ? GL_RGBA32F : GL_RGBA8);
     p_glUseProgram((GLuint)prog);
     p_glDispatchCompute((GLuint)((width + wg_x - 1) / wg_x), (GLuint)((height + wg_y - 1) / wg_y), 1);
     p_glMemoryBarrier(GL_ALL_BARRIER_BITS);
     p_glFinish();
-    p_glPixelStorei(GL_PACK_ALIGNMENT, 1);
-    p_glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, out_float ? GL_FLOAT : GL_UNSIGNED_BYTE, out);
+    if (out) {
+        p_glPixelStorei(GL_PACK_ALIGNMENT, 1);
+        p_glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, out_float ? GL_FLOAT : GL_UNSIGNED_BYTE, out);
+    }
     GLenum e = p_glGetError();
     p_glUseProgram(0);
-    p_glDeleteTextures(1, &tex);
-    p_glDeleteBuffers(nb, bufs);
     if (e != GL_NO_ERROR) {
         snprintf(g_err, sizeof g_err, "GL error 0x%x during dispatch", e);
         return -1;
     }
     return 0;
+}
+
+/* buffers_set + run + buffers_clear in one call */
+GLREF_API int glref_dispatch(int prog, int width, int height, int wg_x, int wg_y, int nubo, const int *ubo_binding,
+                             const void *const *ubo, const int64_t *ubo_bytes, int nssbo, const int *ssbo_binding,
+                             const void *const *ssbo, const int64_t *ssbo_bytes, int out_float, void *out) {
+    int rc = glref_buffers_set(nubo, ubo_binding, ubo, ubo_bytes, nssbo, ssbo_binding, ssbo, ssbo_bytes);
+    if (rc == 0) rc = glref_run(prog, width, height, wg_x, wg_y, out_float, out);
+    glref_buffers_clear();
+    return rc;
+}
+
+/* number of llvmpipe worker threads of this process (threads named "llvmpipe-N"), for the baseline's `cores` */
+GLREF_API int glref_worker_threads(void) {
+    int n = 0;
+    DIR *d = opendir("/proc/self/task");
+    if (!d) return 0;
+    struct dirent *e;
+    while ((e = readdir(d)) != NULL) {
+        if (e->d_name[0] == '.') continue;
+        char path[320], name[64] = {0};
+        snprintf(path, sizeof path, "/proc/self/task/%s/comm", e->d_name);
+        FILE *f = fopen(path, "r");
+        if (!f) continue;
+        if (fgets(name, sizeof name, f) && !strncmp(name, "llvmpipe-", 9)) n++;
+        fclose(f);
+    }
+    closedir(d);
+    return n;
 }

@@ -105,6 +105,17 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) {
+    if (!comm || !count) return ncclInvalidArgument;
+    *count = comm->world->nranks;
+    return ncclSuccess;
+}
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int *rank) {
+    if (!comm || !rank) return ncclInvalidArgument;
+    *rank = comm->rank;
+    return ncclSuccess;
+}
+
 ncclResult_t ncclGroupStart() { return ncclSuccess; } // operations are carried out as they are posted
 ncclResult_t ncclGroupEnd() { return ncclSuccess; }
 

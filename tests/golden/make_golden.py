@@ -36,6 +36,11 @@ CASES = {
 }
 
 
+# Full-size frames of the headline workload (BASELINE.json configs[2]): too large to store, so SHA-256 of the whole
+# RGBA8 and float frames plus crops; written to tests/golden/full/.
+FULL_CASES = {f"cfg2_{v}": (W.WORKLOADS[W.HEADLINE], v) for v in ("V0", "V1", "V2", "V1x")}
+
+
 def scene_digest(grid) -> str:
     h = hashlib.sha256()
     h.update(bytes(grid.device_state))
@@ -62,5 +67,25 @@ def main():
         print(name, c)
 
 
+def main_full():
+    out = os.path.join(OUT, "full")
+    os.makedirs(out, exist_ok=True)
+    grids = {}
+    for name, (w, view) in FULL_CASES.items():
+        grid = grids.setdefault(w.name, W.build_grid(w))
+        pc = push_for(W.camera_for(w, view), W.sun_for(w, 0.0))   # hard sun: the frame does not depend on sin()
+        f, u, c = O.render(oracle_scene_from_grid(grid), pc)
+        cy, cx = 2 * w.height // 3, w.width // 2
+        np.savez_compressed(
+            os.path.join(out, name + ".npz"),
+            workload=np.array(w.name), view=np.array(view), push_constants=pc, scene_sha256=np.array(scene_digest(grid)),
+            rgba8_sha256=np.array(hashlib.sha256(u.tobytes()).hexdigest()), float_sha256=np.array(hashlib.sha256(f.tobytes()).hexdigest()),
+            rgba8_crop=u[cy - 32:cy + 32, cx - 48:cx + 48].copy(), float_crop=f[cy - 32:cy + 32, cx - 48:cx + 48].copy(),
+            crop_origin=np.array([cy - 32, cx - 48]),
+            counters=np.array([c[k] for k in ("rays", "status_loads", "bricks_entered", "voxel_steps", "hits", "grid_steps")], dtype=np.uint64))
+        print(name, c)
+
+
 if __name__ == "__main__":
     main()
+    main_full()

@@ -1,0 +1,91 @@
+"""bench.py's launch and rank plumbing on CPU: world size 2 over gloo with the stub renderer (`--stub`).
+
+What this pins ("make the multi-GPU entry unbreakable"):
+  * `python bench.py --gpus 2` WITHOUT rank environment re-executes itself under torch.distributed.run and
+    reports n_gpus == 2 — never a silent one-GPU run;
+  * exactly one JSON line, from rank 0, with ranks_seen == [0, 1] and the communicator's own world size;
+  * when the native pipeline fails on ONE rank, every rank agrees (all-reduce MIN) to take the torch path;
+  * a WORLD_SIZE that contradicts --gpus is an error, and so is --gpus N on a node with fewer GPUs.
+The renderer is a stub (it renders nothing): the traversal has no CPU implementation, and this test is about
+the plumbing around it.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def _run(args, env=None, timeout=300):
+    return subprocess.run([sys.executable, BENCH, *args], cwd=ROOT, env=env or _env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=timeout)
+
+
+def _one_json_line(stdout: bytes) -> dict:
+    lines = [ln for ln in stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, f"expected ONE line on stdout, got {len(lines)}: {lines}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(400)
+def test_gpus_2_without_rank_env_spawns_two_ranks():
+    r = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--stub"])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = _one_json_line(r.stdout)
+    assert out["n_gpus"] == 2
+    assert out["ranks_seen"] == [0, 1]
+    assert out["rccl_world"] == 2          # what the (stub) communicator reports, min over ranks
+    assert out["dist_path"] == "native"
+    assert out["steps"] == 6 and out["warmup"] == 2
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    assert "re-executing" in r.stderr.decode()
+
+
+@pytest.mark.timeout(400)
+def test_native_failure_on_one_rank_moves_every_rank_to_the_torch_path():
+    r = _run(["--gpus", "2", "--steps", "5", "--warmup", "1", "--stub", "--stub-fail-native-on", "1"])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = _one_json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == [0, 1]
+    assert out["dist_path"] == "torch"     # rank 0's native set-up worked, rank 1's did not: both fall back
+    assert out["rccl_world"] is None
+    assert "torch.distributed gather per frame" in out["config"]["parallelism"]
+
+
+def test_world_size_contradicting_gpus_is_an_error():
+    env = _env()
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "0", "--stub"], env=env)
+    assert r.returncode != 0
+    assert b"WORLD_SIZE=1" in r.stderr
+    assert r.stdout.strip() == b""
+
+
+def test_more_gpus_than_the_node_has_is_an_error():
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _run(["--gpus", str(have + 7), "--steps", "2", "--warmup", "0"])
+    assert r.returncode != 0
+    assert b"refusing to run on fewer" in r.stderr
+    assert r.stdout.strip() == b""
+
+
+def test_metric_string_follows_the_workload():
+    sys.path.insert(0, ROOT)
+    import bench
+    from zig_vulkan_amd import workloads as W
+    assert "1920x1080 on 512^3" in bench.metric_name(W.WORKLOADS[W.HEADLINE])
+    assert "256x256 on 64^3" in bench.metric_name(W.WORKLOADS["cfg0_256x256_64c_b4"])
+    assert "3840x2160 on 2048^3" in bench.metric_name(W.WORKLOADS["cfg4_4k_2048c_b8_sparse"])

@@ -13,6 +13,9 @@ pytestmark = pytest.mark.gpu
 def _sampled_parity(name, view, n_pixels, seed=1234, **overrides):
     w = W.WORKLOADS[name]
     grid = W.build_grid(w)
+    # A counting context runs the counting build once, overwrites both targets with 0xCD and then lets the PRODUCT kernel
+    # render the frame that is read back (vrt_hip.h): a pixel the product kernel leaves unwritten reads back as poison,
+    # which the whole-frame alpha checks below catch for every pixel, not only the sampled ones.
     rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, **overrides)
     W.set_view(rt, view)
     rt.draw()
@@ -108,13 +111,13 @@ def test_headline_frames_are_deterministic_with_two_in_flight():
 def test_headline_cost_ordered_launch_and_split_tiles_keep_the_frame():
     """One frame at a time (the default tile order of such a context: measured cost, re-sorted every 32 frames, heaviest
     tiles split into two half-tile workgroups): the first frame of a view (reverse raster, nothing measured yet) and the
-    frame after 70 more are the same bytes, for all three views; on V1 the settled launch really contains split tiles
+    frame after 70 more are the same bytes, for all views; on V1x the settled launch really contains split tiles
     (more waves than 4 per tile)."""
     import hashlib
     w = W.WORKLOADS[W.HEADLINE]
     grid = W.build_grid(w)
     fresh = {}
-    for view in ["V0", "V1", "V2"]:
+    for view in ["V0", "V1", "V2", "V1x"]:
         rt = W.make_renderer(w, grid)
         W.set_view(rt, view)
         rt.draw()
@@ -122,12 +125,94 @@ def test_headline_cost_ordered_launch_and_split_tiles_keep_the_frame():
         rt.deinit()
     rt = W.make_renderer(w, grid)
     tiles = rt.shard_info().owned_tiles
-    for view in ["V1", "V0", "V2", "V1"]:
+    for view in ["V1", "V0", "V2", "V1x"]:
         W.set_view(rt, view)
         rt.draw(frames=70)
         rt.draw()
         assert hashlib.sha1(rt.read_rgba8().tobytes()).hexdigest() == fresh[view], view
     waves = len(rt.wave_timeline())
-    assert waves > tiles * 4, "no tile was split on V1"
-    assert hashlib.sha1(rt.read_rgba8().tobytes()).hexdigest() == fresh["V1"]
+    assert waves > tiles * 4, "no tile was split on V1x"
+    assert hashlib.sha1(rt.read_rgba8().tobytes()).hexdigest() == fresh["V1x"]
     rt.deinit()
+
+
+def _golden_full(view):
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "full", f"cfg2_{view}.npz"))
+
+
+@pytest.mark.parametrize("view", ["V0", "V1", "V2", "V1x"])
+def test_headline_settled_frame_is_the_committed_golden_frame(view):
+    """PRODUCT-ONLY context (no counting build ever touches its target), headline size, hard sun: after 70 frames the
+    launch order has been re-sorted twice from measured costs and heavy tiles are split — the frame must still be the
+    oracle's frame, checked three ways: SHA-256 of the whole RGBA8 and float frames against tests/golden/full (made by
+    the oracle in tests/golden/make_golden.py), the committed crops, and a fresh oracle sample of 20 000 pixels."""
+    import ctypes as C
+    import hashlib
+    z = _golden_full(view)
+    w = W.WORKLOADS[str(z["workload"])]
+    grid = W.build_grid(w)
+    from tests.golden.make_golden import scene_digest
+    assert scene_digest(grid) == str(z["scene_sha256"])
+    rt = W.make_renderer(w, grid, want_float_output=True, sun_radius=0.0)
+    pc = z["push_constants"].tobytes()
+    C.memmove(C.byref(rt.camera.d_camera), pc[:96], 96)
+    C.memmove(C.byref(rt.sun.device_data), pc[96:], 32)
+    first = None
+    for frames in (1, 70, 1):
+        rt.draw(frames=frames)
+        u = rt.read_rgba8()
+        f = rt.read_rgba32f()
+        assert hashlib.sha256(u.tobytes()).hexdigest() == str(z["rgba8_sha256"]), f"after {frames} more frame(s)"
+        assert hashlib.sha256(f.tobytes()).hexdigest() == str(z["float_sha256"])
+        first = first if first is not None else u
+    rt.deinit()
+    y0, x0 = z["crop_origin"].tolist()
+    h, wd = z["rgba8_crop"].shape[:2]
+    assert np.array_equal(u[y0:y0 + h, x0:x0 + wd], z["rgba8_crop"])
+    assert np.array_equal(f[y0:y0 + h, x0:x0 + wd].view(np.uint32), z["float_crop"].view(np.uint32))
+    rng = np.random.default_rng(99)
+    xy = np.stack([rng.integers(0, w.width, 20000), rng.integers(0, w.height, 20000)], axis=-1).astype(np.int32)
+    fo, uo, _ = O.render_pixels(oracle_scene_from_grid(grid), z["push_constants"].copy(), xy)
+    assert np.array_equal(f[xy[:, 1], xy[:, 0]].view(np.uint32), fo.view(np.uint32))
+    assert np.array_equal(u[xy[:, 1], xy[:, 0]], uo)
+
+
+def test_counting_context_reads_back_the_product_kernels_frame():
+    """The 0xCD poison between the counting build and the product kernel: with the product launch suppressed the frame
+    would be poison, so a frame equal to the oracle's proves the product kernel wrote every pixel of it.  Also: the
+    counters are those of ONE frame however many frames the call renders."""
+    w = W.Workload("t", 640, 360, 128, 8, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True)
+    W.set_view(rt, "V2")
+    rt.draw()
+    c1 = rt.counters()
+    rt.draw(frames=5)
+    c5 = rt.counters()
+    f, u = rt.read_rgba32f(), rt.read_rgba8()
+    pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+    rt.deinit()
+    assert c1 == c5
+    fo, uo, co = O.render(oracle_scene_from_grid(grid), pc)
+    assert c1 == co
+    assert np.array_equal(f.view(np.uint32), fo.view(np.uint32)) and np.array_equal(u, uo)
+    assert not (u == 0xCD).all(axis=2).any()
+
+
+def test_issued_counters_walk_to_the_occupied_box():
+    """enable_counters = 2: the counting build ends its brick-level walk where the product kernel does.  Hits, bricks
+    entered and voxel steps are the reference algorithm's (the box only removes empty cells); grid steps shrink."""
+    w = W.Workload("t", 640, 360, 128, 8, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    got = {}
+    for mode in (1, 2):
+        rt = W.make_renderer(w, grid, enable_counters=mode)
+        W.set_view(rt, "V0")
+        rt.draw()
+        got[mode] = rt.counters()
+        rt.deinit()
+    for k in ("rays", "bricks_entered", "voxel_steps", "hits"):
+        assert got[1][k] == got[2][k], k
+    assert got[2]["grid_steps"] < got[1]["grid_steps"]
+    assert got[2]["status_loads"] <= got[1]["status_loads"]

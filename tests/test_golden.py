@@ -63,3 +63,27 @@ def test_hip_reproduces_golden(path):
     f, u, c = rt.read_rgba32f(), rt.read_rgba8(), rt.counters()
     rt.deinit()
     _check(z, f, u, c)
+
+
+FULL = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "full", "*.npz")))
+
+
+@pytest.mark.parametrize("path", FULL, ids=[os.path.basename(p)[:-4] for p in FULL])
+def test_oracle_reproduces_fullsize_headline_golden(path):
+    """tests/golden/full: the headline workload at its full 1920x1080 (hard sun), whole-frame SHA-256 + crops.  The GPU
+    side is tests/test_fullsize_gpu.py::test_headline_settled_frame_is_the_committed_golden_frame."""
+    z = np.load(path)
+    w = W.WORKLOADS[str(z["workload"])]
+    grid = W.build_grid(w)
+    from tests.golden.make_golden import scene_digest
+    assert scene_digest(grid) == str(z["scene_sha256"]), "synthetic scene generator drifted"
+    cam, sun = W.camera_for(w, str(z["view"])), W.sun_for(w, 0.0)
+    assert np.array_equal(O.push_constants(cam.blob(), sun.blob()), z["push_constants"])
+    f, u, c = O.render(oracle_scene_from_grid(grid), z["push_constants"].copy())
+    assert hashlib.sha256(u.tobytes()).hexdigest() == str(z["rgba8_sha256"])
+    assert hashlib.sha256(f.tobytes()).hexdigest() == str(z["float_sha256"])
+    assert [c[k] for k in COUNTER_KEYS] == z["counters"].tolist()
+
+
+def test_fullsize_fixtures_exist():
+    assert len(FULL) == 4

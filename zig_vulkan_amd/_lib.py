@@ -145,6 +145,7 @@ SIGNATURES = {
     "vrt_buffer_size": (C.c_uint64, [_ctx, C.c_int]),
     "vrt_dispatch": (C.c_int, [_ctx, _P(CameraDevice), _P(SunDevice)]),
     "vrt_dispatch_repeat": (C.c_int, [_ctx, _P(CameraDevice), _P(SunDevice), C.c_uint32]),
+    "vrt_dispatch_timed": (C.c_int, [_ctx, _P(CameraDevice), _P(SunDevice), C.c_uint32, _P(C.c_float)]),
     "vrt_wait": (C.c_int, [_ctx]),
     "vrt_read_rgba8": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
     "vrt_read_rgba32f": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
@@ -165,6 +166,8 @@ SIGNATURES = {
     "vrt_dist_wait": (C.c_int, [_ctx]),
     "vrt_dist_read_frame": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
     "vrt_dist_selftest": (C.c_int, [_ctx]),
+    "vrt_dist_info": (C.c_int, [_ctx, _P(C.c_int32)]),
+    "vrt_device_info": (C.c_int, [C.c_int, _P(C.c_int64)]),
     "vrt_last_kernel_ms": (C.c_double, [_ctx]),
     "vrt_get_counters": (C.c_int, [_ctx, _P(Counters)]),
     "vrt_get_wave_counters": (C.c_int, [_ctx, _P(C.c_uint64 * 3)]),

@@ -32,6 +32,8 @@ int BrickGrid::create(uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, const Grid
     if (brick_count64 == 0) return VRT_E_INVALID_ARG; // Grid.zig:38
     // grid indices are u32 in the shader (comp:318)
     if (brick_count64 > 0xFFFFFFFFull) return VRT_E_OUT_OF_RANGE;
+    // State.Device.voxel_dim_* are u32 (State.zig:61-63): dim * brick_dimension must not wrap
+    if ((uint64_t)dim_x * b > 0xFFFFFFFFull || (uint64_t)dim_y * b > 0xFFFFFFFFull || (uint64_t)dim_z * b > 0xFFFFFFFFull) return VRT_E_OUT_OF_RANGE;
     const uint64_t brick_alloc = cfg.brick_alloc ? cfg.brick_alloc : brick_count64; // Grid.zig:51
     const uint32_t brick_bits = b * b * b;
     // Brick.StartIndex.value is a u31 (State.zig:117-120)

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 #include <thread>
 #include "host_brick_grid.hpp"
 #include "vrt_internal.h"
@@ -57,6 +58,8 @@ struct RcclApi {
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;       // optional (vrt_dist_info)
+    decltype(&ncclCommUserRank) CommUserRank = nullptr; // optional
     bool load(const char *path, std::string &err) {
         lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
         if (!lib) {
@@ -78,6 +81,8 @@ struct RcclApi {
         VRT_RCCL_SYM(Recv, "ncclRecv")
         VRT_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef VRT_RCCL_SYM
+        CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
+        CommUserRank = reinterpret_cast<decltype(CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
         return true;
     }
 };
@@ -112,6 +117,7 @@ struct Dist {
     // an eighth of a whole-frame launch).  vrt_dist_frame queues; a full queue, vrt_dist_wait, vrt_dist_read_frame or a
     // scene upload launches what is queued.
     uint32_t batch = 1;
+    bool failed = false;         // a collective failed: peers are out of step, every later vrt_dist_* call fails
     uint32_t npend = 0;
     vrt::PushConstants pend[vrt::kMaxBatchFrames];
     vrt::KernelFn pend_fn = nullptr;
@@ -206,7 +212,7 @@ struct DeviceGuard {
 
 void free_ctx(vrt_ctx *c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dg(c->device); // the caller's current device is restored on return
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < VRT_BUF_COUNT; i++)
         if (c->dbuf[i]) (void)hipFree(c->dbuf[i]);
@@ -346,6 +352,22 @@ extern "C" {
 
 uint32_t vrt_abi_version(void) { return VRT_ABI_VERSION; }
 
+int vrt_device_info(int device, int64_t out[4]) {
+    if (!out) return VRT_E_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, VRT_E_NO_DEVICE, "no HIP device");
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return fail(nullptr, VRT_E_HIP, "hipGetDevice failed");
+    if (device >= ndev) return fail(nullptr, VRT_E_INVALID_ARG, "device out of range");
+    const hipDeviceAttribute_t attrs[4] = {hipDeviceAttributeClockRate, hipDeviceAttributeMultiprocessorCount, hipDeviceAttributeWarpSize,
+                                           hipDeviceAttributeL2CacheSize};
+    for (int i = 0; i < 4; i++) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, attrs[i], device) != hipSuccess) return fail(nullptr, VRT_E_HIP, "hipDeviceGetAttribute failed");
+        out[i] = v;
+    }
+    return VRT_OK;
+}
+
 const char *vrt_last_error(const vrt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 const char *vrt_kernel_name(const vrt_ctx *ctx) { return ctx ? ctx->kernel_name.c_str() : ""; }
@@ -361,6 +383,9 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     const uint64_t cells = (uint64_t)cfg->dim_x * cfg->dim_y * cfg->dim_z;
     if (cells == 0) return fail(nullptr, VRT_E_INVALID_ARG, "zero grid dimension");
     if (cells > 0xFFFFFFFFull) return fail(nullptr, VRT_E_OUT_OF_RANGE, "grid has more than 2^32-1 cells (u32 grid index, comp:318)");
+    if ((uint64_t)cfg->dim_x * cfg->brick_dimension > 0xFFFFFFFFull || (uint64_t)cfg->dim_y * cfg->brick_dimension > 0xFFFFFFFFull ||
+        (uint64_t)cfg->dim_z * cfg->brick_dimension > 0xFFFFFFFFull)
+        return fail(nullptr, VRT_E_OUT_OF_RANGE, "dim * brick_dimension exceeds u32 (State.Device.voxel_dim_*, State.zig:61-63)");
     const uint64_t brick_alloc = cfg->brick_alloc ? cfg->brick_alloc : cells;
     const uint64_t bits = (uint64_t)cfg->brick_dimension * cfg->brick_dimension * cfg->brick_dimension;
     if (brick_alloc * bits > 0x80000000ull)
@@ -399,7 +424,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         }                                                                                      \
     } while (0)
 
-    VRT_CREATE_HIP(hipSetDevice(device));
+    DeviceGuard dg(device); // everything below runs on `device`; the caller's current device is restored on every return path
+    if (!dg.ok) {
+        free_ctx(c);
+        return fail(nullptr, VRT_E_HIP, "hipSetDevice failed");
+    }
     if (cfg->stream) {
         c->stream = static_cast<hipStream_t>(cfg->stream);
     } else {
@@ -418,9 +447,13 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     c->dsize[VRT_BUF_BRICK_START_INDEX] = brick_alloc * 4u;
     c->dsize[VRT_BUF_MATERIAL_INDEX] = brick_alloc * bits;
     for (int i = 0; i < VRT_BUF_COUNT; i++) {
-        // +16: the kernel reads occupancy as aligned 64-bit words; keep slack at the tail
-        VRT_CREATE_HIP(hipMalloc(&c->dbuf[i], c->dsize[i] + 16u));
-        VRT_CREATE_HIP(hipMemsetAsync(c->dbuf[i], 0, c->dsize[i] + 16u, c->stream));
+        // +16: the kernel reads occupancy as aligned 64-bit words; keep slack at the tail.  The material table is
+        // allocated (and zeroed) for all 256 values a u8 material id can take, whatever material_capacity says:
+        // a voxel whose id is beyond the uploaded table reads a zero record instead of foreign memory.
+        uint64_t alloc = c->dsize[i] + 16u;
+        if (i == VRT_BUF_MATERIALS) alloc = std::max<uint64_t>(alloc, 256u * sizeof(vrt_material) + 16u);
+        VRT_CREATE_HIP(hipMalloc(&c->dbuf[i], alloc));
+        VRT_CREATE_HIP(hipMemsetAsync(c->dbuf[i], 0, alloc, c->stream));
     }
 
     // target image (Pipeline.zig:103-126), whole frame or this rank's packed tiles
@@ -589,6 +622,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.target_rgba8 = c->target8;
     p.target_rgba32f = c->target32f;
     p.counters = c->d_counters;
+    p.count_box = (cfg->enable_counters == 2u) ? 1u : 0u;
     p.width = cfg->width;
     p.height = cfg->height;
     p.tiles_x = sh.tiles_x;
@@ -750,7 +784,8 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
     return VRT_OK;
 }
 
-static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames, bool primary_only = false) {
+static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames, bool primary_only = false,
+                       hipEvent_t *marks = nullptr) {
     if (frames == 0) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "zero frames") : VRT_E_INVALID_ARG;
     if (ctx && ctx->dist) return fail(ctx, VRT_E_STATE, "this context runs the multi-GPU pipeline: use vrt_dist_frame");
     DeviceGuard dg(ctx ? ctx->device : 0);
@@ -827,7 +862,18 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         ctx->last_slot = 0;
         return VRT_OK;
     }
+    if (product_fn) {
+        // Counting context: the counting build runs ONCE per call (the counters are those of one frame however many
+        // frames were asked for), then both targets are overwritten with 0xCD, then the product kernel renders the
+        // frame(s): a pixel the product kernel fails to write reads back as 0xCDCDCDCD / -4.3e8, not as the counting
+        // build's (correct) colour.
+        VRT_HIP(ctx, vrt::launch_trace(fn, ctx->params, ctx->lds_bytes, ctx->stream));
+        VRT_HIP(ctx, hipMemsetAsync(ctx->target8, 0xCD, ctx->target_pixels * 4u, ctx->stream));
+        if (ctx->target32f) VRT_HIP(ctx, hipMemsetAsync(ctx->target32f, 0xCD, ctx->target_pixels * 16u, ctx->stream));
+        fn = product_fn;
+    }
     for (uint32_t f = 0; f < frames; f++) {
+        if (marks) VRT_HIP(ctx, hipEventRecord(marks[f], ctx->stream)); // per-frame timing (vrt_dispatch_timed)
         if (ctx->sched_period && nt > 1u && ctx->sched_since >= ctx->sched_period) {
             // Amortised re-sort, in the frames' own stream (inside the timed region as well): the measured costs (running mean)
             // order the tiles into the buffer no frame reads; frames launched from here on read that one.  A sort costs about
@@ -846,7 +892,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         VRT_HIP(ctx, vrt::launch_trace(fn, ctx->params, ctx->lds_bytes, ctx->stream));
         ctx->sched_since++;
     }
-    if (product_fn) VRT_HIP(ctx, vrt::launch_trace(product_fn, ctx->params, ctx->lds_bytes, ctx->stream));
+    if (marks) VRT_HIP(ctx, hipEventRecord(marks[frames], ctx->stream));
     VRT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->timed_frames = frames;
     ctx->in_flight = true;
@@ -859,6 +905,24 @@ int vrt_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_de
 
 int vrt_dispatch_repeat(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames) {
     return do_dispatch(ctx, camera, sun, frames);
+}
+
+int vrt_dispatch_timed(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames, float *ms_per_frame) {
+    if (!ctx || !ms_per_frame) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "ms_per_frame is NULL") : VRT_E_INVALID_ARG;
+    if (frames == 0 || frames > 4096u) return fail(ctx, VRT_E_INVALID_ARG, "vrt_dispatch_timed: 1..4096 frames");
+    DeviceGuard dg(ctx->device);
+    std::vector<hipEvent_t> marks(frames + 1u, nullptr);
+    int rc = VRT_OK;
+    for (uint32_t i = 0; i <= frames && rc == VRT_OK; i++)
+        if (hipEventCreate(&marks[i]) != hipSuccess) rc = fail(ctx, VRT_E_HIP, "hipEventCreate failed");
+    // frames > 1 or primary_only keeps every frame on the primary stream, one after another
+    if (rc == VRT_OK) rc = do_dispatch(ctx, camera, sun, frames, true, marks.data());
+    if (rc == VRT_OK && hipEventSynchronize(marks[frames]) != hipSuccess) rc = fail(ctx, VRT_E_HIP, "hipEventSynchronize failed");
+    for (uint32_t f = 0; f < frames && rc == VRT_OK; f++)
+        if (hipEventElapsedTime(&ms_per_frame[f], marks[f], marks[f + 1u]) != hipSuccess) rc = fail(ctx, VRT_E_HIP, "hipEventElapsedTime failed");
+    for (hipEvent_t e : marks)
+        if (e) (void)hipEventDestroy(e);
+    return rc;
 }
 
 int vrt_wait(vrt_ctx *ctx) {
@@ -1111,6 +1175,7 @@ namespace {
 // Launch the queued frames: one kernel over (tiles of this rank) x (frames), ONE collective, one un-swizzle per frame.
 int dist_flush(vrt_ctx *ctx) {
     Dist *d = ctx->dist;
+    if (d->failed) return fail(ctx, VRT_E_RCCL, "an earlier collective of this context failed: its ranks are out of step, destroy it");
     const uint32_t n = d->npend;
     if (n == 0) return VRT_OK;
     d->npend = 0; // (also on failure: the frames are dropped, not retried)
@@ -1135,13 +1200,20 @@ int dist_flush(vrt_ctx *ctx) {
     const size_t region = d->shard_bytes * d->batch;
     if (d->world > 1) {
         VRT_NCCL(ctx, d, d->api.GroupStart());
+        // a failing Send / Recv must not leave the group open on this rank: close it, then report, and the context
+        // stays failed (every later vrt_dist_* call returns VRT_E_RCCL) because its peers are now out of step
+        ncclResult_t first_bad = ncclSuccess;
         if (d->rank == 0) {
-            for (int r = 1; r < d->world; r++)
-                VRT_NCCL(ctx, d, d->api.Recv(sl.gathered + (size_t)r * region, d->shard_bytes * n, ncclUint8, r, d->comm, sl.stream));
+            for (int r = 1; r < d->world && first_bad == ncclSuccess; r++)
+                first_bad = d->api.Recv(sl.gathered + (size_t)r * region, d->shard_bytes * n, ncclUint8, r, d->comm, sl.stream);
         } else {
-            VRT_NCCL(ctx, d, d->api.Send(sl.shard, d->shard_bytes * n, ncclUint8, 0, d->comm, sl.stream));
+            first_bad = d->api.Send(sl.shard, d->shard_bytes * n, ncclUint8, 0, d->comm, sl.stream);
         }
-        VRT_NCCL(ctx, d, d->api.GroupEnd());
+        const ncclResult_t end = d->api.GroupEnd();
+        if (first_bad != ncclSuccess || end != ncclSuccess) {
+            d->failed = true;
+            return fail(ctx, VRT_E_RCCL, std::string("RCCL gather failed: ") + d->api.GetErrorString(first_bad != ncclSuccess ? first_bad : end));
+        }
     }
     // 3. rank 0: tile-major shards -> row-major frames
     if (d->rank == 0) {
@@ -1167,6 +1239,22 @@ int vrt_dist_wait(vrt_ctx *ctx) {
     if (rcf != VRT_OK) return rcf;
     for (uint32_t i = 0; i < ctx->dist->nslots; i++) VRT_HIP(ctx, hipStreamSynchronize(ctx->dist->slots[i].stream));
     VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VRT_OK;
+}
+
+int vrt_dist_info(vrt_ctx *ctx, int32_t out[4]) {
+    if (!ctx || !ctx->dist || !out) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called / out NULL") : VRT_E_INVALID_ARG;
+    Dist *d = ctx->dist;
+    int rank = d->rank, world = d->world;
+    // what the communicator itself says, not what vrt_dist_init was told
+    if (d->comm && d->api.CommCount && d->api.CommUserRank) {
+        VRT_NCCL(ctx, d, d->api.CommCount(d->comm, &world));
+        VRT_NCCL(ctx, d, d->api.CommUserRank(d->comm, &rank));
+    }
+    out[0] = rank;
+    out[1] = world;
+    out[2] = (int32_t)d->batch;
+    out[3] = (int32_t)d->nslots;
     return VRT_OK;
 }
 

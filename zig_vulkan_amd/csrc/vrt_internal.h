@@ -90,6 +90,7 @@ struct TraceParams {
     uint32_t brick_batch;                // lanes that must be waiting before a batched voxel-level walk runs (bounce frames)
     uint32_t block_threads;              // 256, or 512 for kVariantLinearLds512
     uint32_t wave_groups;                // 1: launch one 64-thread workgroup per 8x8 block instead of 256 per 16x16 tile
+    uint32_t count_box;                  // counting build only: 1 = walk to the occupied-cell box like the product kernel (issued loads)
     uint32_t tile_order;                 // workgroup -> tile mapping: 1 row bands per XCD, 2 column bands per XCD, 3 reverse raster, 4 strided,
                                          // 5 cost-feedback schedule, 6 raster.  (kernel_variant: 0 = the library chooses between 3 and the
                                          // schedule re-sorted every 32 frames, which is 7 there; 5 there re-sorts before every frame)

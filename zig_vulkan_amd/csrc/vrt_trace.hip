@@ -701,9 +701,10 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     // The walk ends where the ray leaves the bounding box of the OCCUPIED cells on the far side of an axis (every cell beyond
     // is empty, and the ray cannot come back), not only at the grid's face: same hits, same misses, fewer trips -- sky rays of a
     // camera above the terrain and shadow rays towards the sun stop at the height of the highest brick.  The counting build
-    // walks to the grid's face like the shader, so that its counters stay the reference algorithm's.
+    // walks to the grid's face like the shader, so that its counters stay the reference algorithm's — unless asked
+    // (count_box, vrt_config.enable_counters = 2) to count what the product kernel itself walks and requests.
     int lox = 0, loy = 0, loz = 0, hix = dx - 1, hiy = dy - 1, hiz = dz - 1;
-    if constexpr (!COUNT) {
+    if (!COUNT || p.count_box) {
         if (p.cell_bounds) {
             lox = -p.cell_bounds[0], loy = -p.cell_bounds[1], loz = -p.cell_bounds[2];
             hix = p.cell_bounds[3], hiy = p.cell_bounds[4], hiz = p.cell_bounds[5];

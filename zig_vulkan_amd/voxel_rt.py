@@ -223,7 +223,7 @@ class Config:  # VoxelRT.Config, VoxelRT.zig:22-28 (+ the knobs of this implemen
     sun: SunConfig = field(default_factory=SunConfig)
     material_buffer: int = 256  # Pipeline.Config.material_buffer, Pipeline.zig:30
     want_float_output: bool = False
-    enable_counters: bool = False
+    enable_counters: int = 0   # 1/True: the reference algorithm's counts; 2: the loads the product kernel issues (vrt_hip.h)
     device_id: int = -1
     shard_rank: int = 0
     shard_count: int = 1
@@ -255,7 +255,7 @@ class VoxelRT:
         cfg.material_capacity = config.material_buffer
         cfg.device_id = config.device_id
         cfg.want_float_output = 1 if config.want_float_output else 0
-        cfg.enable_counters = 1 if config.enable_counters else 0
+        cfg.enable_counters = int(config.enable_counters)
         cfg.shard_rank = config.shard_rank
         cfg.shard_count = config.shard_count
         cfg.shard_root_weight = config.shard_root_weight
@@ -305,6 +305,13 @@ class VoxelRT:
             check(lib.vrt_dispatch(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data)), self._h)
         else:
             check(lib.vrt_dispatch_repeat(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data), frames), self._h)
+
+    def draw_timed(self, frames: int) -> np.ndarray:
+        """`frames` frames one after another on the primary stream; returns the hipEvent time of each in ms."""
+        ms = np.zeros(frames, dtype=np.float32)
+        check(lib.vrt_dispatch_timed(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data), frames,
+                                     ms.ctypes.data_as(C.POINTER(C.c_float))), self._h)
+        return ms
 
     def wait(self) -> None:
         check(lib.vrt_wait(self._h), self._h)
@@ -406,6 +413,12 @@ class VoxelRT:
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)
         check(lib.vrt_dist_read_frame(self._h, out.ctypes.data, out.nbytes), self._h)
         return out
+
+    def dist_info(self) -> dict:
+        """rank / world as the RCCL communicator reports them, frames per launch, launches in flight."""
+        out = (C.c_int32 * 4)()
+        check(lib.vrt_dist_info(self._h, out), self._h)
+        return {"rank": out[0], "world": out[1], "frames_per_launch": out[2], "launches_in_flight": out[3]}
 
     def dist_selftest(self) -> None:
         check(lib.vrt_dist_selftest(self._h), self._h)

@@ -46,11 +46,16 @@ WORKLOADS: Dict[str, Workload] = {
 
 HEADLINE = "cfg2_1080p_512c_b8"
 
-# camera views: (origin, look-at target or None for the reference's start orientation)
+# camera views: (origin, look-at target or None for the reference's start orientation).  V0, V1, V2 are SURVEY.md §8(d)'s
+# views, cycled by bench.py's timed region; the others are reported per view only.
 VIEWS: Dict[str, Tuple[Sequence[float], Sequence[float] | None]] = {
     "V0": ((0.0, 0.0, 0.0), None),                      # reference start: origin, looking -Z (Camera.zig:7,47)
-    "V1": ((0.0, -44.0, 70.0), (0.0, 12.0, 0.0)),       # outside the grid box, above (world is Y-down)
-    "V2": ((20.0, -20.0, 20.0), (0.0, 8.0, 0.0)),       # Benchmark.zig:152-style corner view
+    "V1": ((0.0, -20.0, 30.0), (0.0, 0.0, 0.0)),        # above the terrain, looking at the grid centre (world is Y-down)
+    "V2": ((20.0, -20.0, 20.0), (0.0, 0.0, 0.0)),       # Benchmark.zig:152's corner position, looking at the centre
+    # round 1's V1: truly outside the grid box (V1 of §8(d) is above the terrain but inside the box); 10 % of the rays hit
+    "V1x": ((0.0, -44.0, 70.0), (0.0, 12.0, 0.0)),
+    # all-ground: just above the terrain looking straight down; 98 % of the primary rays hit (no sky to inflate Mrays/s)
+    "VG": ((0.0, 2.0, 0.0), (0.5, 32.0, 0.5)),
 }
 
 
