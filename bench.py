@@ -68,9 +68,12 @@ def cpu_baseline_port(w, grid, min_wall_s: float, per_view):
                 i = state["next"]
                 state["next"] += 1
                 frame, row = divmod(i, w.height)
-                if row == 0 and frame >= len(VIEW_ORDER) and time.perf_counter() - t0 >= min_wall_s:
+                now = time.perf_counter() - t0
+                # whole frames, one per view at least — unless the workload's frames are so heavy that three of them
+                # exceed 3 x the asked time: then the sample ends mid-frame (the rate is rays traced / time either way)
+                if (row == 0 and frame >= len(VIEW_ORDER) and now >= min_wall_s) or now >= 3.0 * min_wall_s:
                     state["stop"] = True
-                    state["frames"] = frame
+                    state["frames"] = frame + row / w.height
                     break
             pc = pcs[frame % len(VIEW_ORDER)]
             L.oracle_render_rows(C.byref(scene.c), pc.ctypes.data, row, row + 1, f32.ctypes.data, None, C.byref(c))
@@ -84,7 +87,7 @@ def cpu_baseline_port(w, grid, min_wall_s: float, per_view):
     dt = time.perf_counter() - t0
     rays = sum(rays_total)
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{state['frames']} whole frames of {w.name} (views {'/'.join(VIEW_ORDER)} cycled), {rays} rays in {dt:.2f} s wall "
+            "sample": f"{state['frames']:.2f} frames of {w.name} (views {'/'.join(VIEW_ORDER)} cycled, rows in order), {rays} rays in {dt:.2f} s wall "
                       f"= {dt * cores:.0f} core-seconds; oracle/vrt_oracle.c gcc -O2, {cores} threads, rows handed out one at a time"}
 
 
@@ -144,7 +147,7 @@ def pmc_child(args) -> None:
     rt = W.make_renderer(w, grid, kernel_variant=args.variant, frames_in_flight=1)
     for v in VIEW_ORDER:
         W.set_view(rt, v)
-        rt.draw(frames=args.pmc_frames)
+        rt.draw(frames=args.pmc_frames or 24)
         rt.wait()
     rt.deinit()
 
@@ -286,8 +289,8 @@ def main(argv=None) -> None:
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=600)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=None, help="timed frames; default: as many as fit about 2.5 s, at most 600, at least 6")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed frames before them; default: min(30, steps / 2)")
     ap.add_argument("--workload", default=None)
     ap.add_argument("--variant", type=lambda x: int(x, 0), default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -296,7 +299,7 @@ def main(argv=None) -> None:
     ap.add_argument("--pmc", choices=["auto", "live", "profile", "off"], default="auto",
                     help="HBM traffic / instruction counters of the roofline object: live = rocprofv3 passes over a child run now; "
                          "profile = the committed profiles/*_pmc.json; auto = live, falling back to profile")
-    ap.add_argument("--pmc-frames", type=int, default=24, help="frames per view of a PMC child run")
+    ap.add_argument("--pmc-frames", type=int, default=None, help="frames per view of a PMC child run; default: up to 24, about 0.6 s")
     ap.add_argument("--pmc-timeout", type=float, default=240.0)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dist", choices=["native", "torch"], default="native",
@@ -527,6 +530,29 @@ def main(argv=None) -> None:
             dt = float(t.item())
         return dt
 
+    # a first look at the frame time (two untimed frames): sizes the run when --steps / --warmup were left to the script
+    # and the settling / PMC legs for workloads whose frames take milliseconds instead of microseconds
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(2):
+        step(2, 3)
+    drain()
+    if not native:
+        rt.wait()
+    sync()
+    frame_ms_est = max((time.perf_counter() - t0) / 2 * 1e3, 1e-3)
+    if use_dist and world > 1:
+        t = torch.tensor([frame_ms_est], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # every rank must choose the same step count
+        frame_ms_est = float(t.item())
+    if args.steps is None:
+        args.steps = int(min(600, max(6, 2500.0 / frame_ms_est)))
+    if args.warmup is None:
+        args.warmup = min(30, args.steps // 2)
+    if args.pmc_frames is None:
+        args.pmc_frames = int(min(24, max(2, 600.0 / frame_ms_est)))
+    settle_frames = int(min(SETTLE_FRAMES, max(3, 1500.0 / frame_ms_est)))
+
     for i in range(args.warmup):
         step(i, args.warmup)
     drain()
@@ -549,7 +575,7 @@ def main(argv=None) -> None:
             set_cam(v)
             # untimed: the camera has just jumped to this view, and the launch order follows the measured tile costs with
             # a lag (re-sorted every 32 frames from a running mean): let it settle as it would under a moving camera
-            rt1.draw(frames=SETTLE_FRAMES)
+            rt1.draw(frames=settle_frames)
             rt1.draw(frames=reps)                           # back to back, one event pair around all of them
             kernel_ms_view[v] = rt1.last_kernel_ms()
             frame_stats[v] = percentiles(rt1.draw_timed(min(reps, 512)))   # an event pair around every frame
@@ -589,7 +615,7 @@ def main(argv=None) -> None:
                           "of useful work, not of bytes moved.  issued_bytes = what the product kernel's lanes request (its walk ends at the "
                           "occupied-cell box; 4 B per brick-level trip, 12 per brick entered, 4 per voxel trip, 21 per hit, 4 per pixel). "
                           "traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE): the touched scene data lives in L2 / MALL.",
-            "kernel": rt1.kernel_name(), "kernel_ms_avg": avg_ms, "kernel_ms_per_view": kernel_ms_view,
+            "kernel": rt1.kernel_name(), "settle_frames": settle_frames, "kernel_ms_avg": avg_ms, "kernel_ms_per_view": kernel_ms_view,
             "frame_ms_percentiles_per_view": frame_stats,
             "algorithmic_bytes_per_launch": avg_bytes,
             "issued_bytes": avg_issued, "issued_GBps": avg_issued / (avg_ms * 1e-3) / 1e9,

@@ -95,3 +95,70 @@ def test_product_never_references_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "libvrt_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
                 assert "oracle/" not in text.replace("parity oracle", ""), f
+
+
+# ---- bindings/vrt_hip.zig: zig is not in the image, so the binding is checked against the header mechanically ----
+def _zig():
+    return open(os.path.join(ROOT, "bindings", "vrt_hip.zig")).read()
+
+
+def _header():
+    return open(os.path.join(ROOT, "include", "vrt_hip.h")).read()
+
+
+def test_zig_binding_extern_block_is_generated_from_the_header():
+    import subprocess
+    import sys
+    rc = subprocess.call([sys.executable, os.path.join(ROOT, "tools", "gen_zig_binding.py"), "--check"])
+    assert rc == 0, "bindings/vrt_hip.zig is out of date: run python tools/gen_zig_binding.py"
+    declared = set(re.findall(r"pub extern fn (vrt_\w+)\(", _zig()))
+    assert declared == set(_declared_functions())
+
+
+def test_zig_status_enum_lists_every_status_code_of_the_header():
+    """Every value of the header's two status enums has a name in `Status`, `Status` is non-exhaustive (`_`), and check()
+    handles each name: a code the binding does not know can never be illegal behaviour (VERDICT r01 Weak #7)."""
+    hdr = re.sub(r"/\*.*?\*/", "", _header(), flags=re.S)
+    codes = {name: int(val) for name, val in re.findall(r"\b(VRT_(?:OK|E_\w+|VOX_E_\w+))\s*=\s*(-?\d+)", hdr)}
+    assert codes["VRT_E_RCCL"] == -7 and codes["VRT_VOX_E_MULTIPLE_PACK_CHUNKS"] == -106 and len(codes) == 15
+    zig = _zig()
+    body = zig[zig.index("pub const Status = enum(c_int) {"):]
+    body = body[:body.index("};")]
+    zig_codes = {name: int(val) for name, val in re.findall(r"^\s*(\w+)\s*=\s*(-?\d+),", body, flags=re.M)}
+    assert sorted(zig_codes.values()) == sorted(codes.values())
+    assert re.search(r"^\s*_,\s*$", body, flags=re.M), "Status must be a non-exhaustive enum"
+    check = zig[zig.index("pub fn check(rc: c_int)"):]
+    check = check[:check.index("\n}\n")]
+    for name in zig_codes:
+        assert f".{name} =>" in check, f"check() does not handle .{name}"
+    assert "else => error.VrtFailure" in check
+    # the same codes are the ones the ctypes binding names
+    assert {getattr(L, n) for n in dir(L) if n.startswith(("VRT_E_", "VOX_E_"))} | {0} == set(codes.values())
+
+
+def _c_struct_fields(hdr, name):
+    m = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + r";", hdr, flags=re.S)
+    body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        names = decl.split(",")
+        first = names[0].rsplit(" ", 1)[1] if " " in names[0] else names[0]
+        for n in [first] + [x.strip() for x in names[1:]]:
+            fields.append(re.sub(r"\[\d+\]|\*", "", n).strip())
+    return fields
+
+
+def test_zig_extern_structs_have_the_headers_fields_in_order():
+    hdr, zig = _header(), _zig()
+    pairs = {"vrt_grid_state": "GridState", "vrt_material": "Material", "vrt_camera_device": "CameraDevice", "vrt_sun_device": "SunDevice",
+             "vrt_config": "Config", "vrt_shard_info": "ShardInfo", "vrt_counters": "Counters", "vrt_grid_config": "GridConfig",
+             "vrt_camera_config": "CameraConfig", "vrt_sun_config": "SunConfig", "vrt_denoise_config": "DenoiseConfig",
+             "vrt_vox_xyzi": "VoxXyzi", "vrt_vox_rgba": "VoxRgba"}
+    for cname, zname in pairs.items():
+        m = re.search(r"pub const " + zname + r" = extern struct \{(.*?)\};", zig, flags=re.S)
+        assert m, zname
+        zfields = re.findall(r"(?:^|[\{,\n])\s*(\w+):", re.sub(r"//[^\n]*", "", m.group(1)))
+        assert zfields == _c_struct_fields(hdr, cname), (cname, zfields, _c_struct_fields(hdr, cname))

@@ -20,8 +20,9 @@ for f in sorted(glob.glob(os.path.join(out, "stats", "**", "*.db"), recursive=Tr
     for r in rows:
         print(f"   {r[0][:60]}: n={r[4]} min={r[1] / 1e3:.1f}us max={r[2] / 1e3:.1f}us avg={r[3] / 1e3:.1f}us vgpr={r[5]} agpr={r[6]} sgpr={r[7]} "
               f"scratch={r[8]} lds={r[9]} grid={r[10]} wg={r[11]}")
-# the launches of the traversal kernel by bench.py phase (single-stream runs): the main timed region cuts between
-# the views, and the launch order needs a few dozen frames after a cut; the roofline leg times settled frames
+# The launches of the traversal kernel by bench.py phase.  bench.py's launch sequence of the PRODUCT kernel is fixed:
+# 2 counting contexts x 5 views x 1 frame | 2 probe frames, warm-up, timed region | (single-stream leg) warm-up, timed
+# region | per view: settle, `reps` back to back (-> roofline.kernel_ms_per_view), min(reps, 512) with an event pair each.
 log = os.path.join(out, "stats.log")
 if os.path.exists(log):
     import json as _json
@@ -30,27 +31,43 @@ if os.path.exists(log):
         if ln.startswith("{") and '"roofline"' in ln:
             line = _json.loads(ln)
     for f in sorted(glob.glob(os.path.join(out, "stats", "**", "*.db"), recursive=True)):
-        if not line or "frame(s) in flight" not in line["config"].get("parallelism", ""):
+        if not line or not line.get("roofline"):
             break
-        overlapped = "1 frame(s) in flight" not in line["config"]["parallelism"]
         db = sqlite3.connect(f)
         d = [r[0] / 1e3 for r in db.execute("select duration from kernels where name like '%vrt_trace_kernel<%, false,%' order by start")]
-        steps, warmup, settle = line["steps"], line["warmup"], 128
-        reps = max(5, steps // 3)
-        nviews = len(line["config"]["views"])
-        d = d[nviews:]  # (first: the product-kernel frames of the counting context, one per view)
-        if len(d) == warmup + steps + nviews * (settle + reps):
-            print(f"\n## {len(d)} launches of the traversal kernel by bench.py phase (us)")
-            print(f"   warm-up + timed region ({warmup} + {steps} launches, views cut at the thirds): avg {sum(d[:warmup + steps]) / (warmup + steps):.2f}"
-                  + ("  (frames alternate between two streams there: two kernels share the GPU, a kernel's duration is not a frame's cost)" if overlapped else ""))
-            leg = d[warmup + steps:]
-            timed = []
-            for v, name in enumerate(line["config"]["views"]):
-                seg = leg[v * (settle + reps):(v + 1) * (settle + reps)]
-                timed += seg[settle:]
-                print(f"   roofline leg {name}: {settle} settling launches avg {sum(seg[:settle]) / settle:.2f}, {reps} timed launches avg {sum(seg[settle:]) / reps:.2f}")
-            print(f"   timed launches of the roofline leg: avg {sum(timed) / len(timed):.2f}  (bench.py, HIP events around the same launches incl. the "
-                  f"schedule kernels between them: {line['roofline']['kernel_ms_avg'] * 1e3:.2f})")
+        steps, warmup = line["steps"], line["warmup"]
+        views = line["config"]["views"] + line["config"].get("views_reported_only", [])
+        settle = line["roofline"]["settle_frames"]
+        reps = max(8, steps // len(line["config"]["views"]))
+        timed = min(reps, 512)
+        head = 2 * len(views) + 2 + 2 * (warmup + steps)
+        want = head + len(views) * (settle + reps + timed)
+        print(f"\n## {len(d)} launches of the traversal kernel by bench.py phase (us)")
+        if len(d) != want:
+            print(f"   (expected {want} launches from the bench line; phase breakdown skipped)")
+            continue
+        a = 2 * len(views) + 2
+        main = d[a + warmup:a + warmup + steps]
+        single = d[a + warmup + steps + warmup:a + 2 * (warmup + steps)]
+        two = "1 frame(s) in flight" not in line["config"]["parallelism"]
+        print(f"   timed region ({steps} launches): avg {sum(main) / steps:.2f}"
+              + ("  (two frames in flight: two kernels share the GPU, a kernel's duration is not a frame's cost)" if two else ""))
+        print(f"   single-stream timed region ({steps} launches): avg {sum(single) / steps:.2f}   "
+              f"(bench line ms_per_step_single_stream, wall clock incl. launch gaps: {line['ms_per_step_single_stream'] * 1e3:.2f})")
+        leg = d[head:]
+        per = settle + reps + timed
+        tot = []
+        for v, name in enumerate(views):
+            seg = leg[v * per:(v + 1) * per]
+            b2b = seg[settle:settle + reps]
+            ev = sorted(seg[settle + reps:])
+            print(f"   {name}: {reps} back-to-back launches avg {sum(b2b) / reps:.2f} (HIP events: {line['roofline']['kernel_ms_per_view'][name] * 1e3:.2f}); "
+                  f"{timed} individually timed launches median {ev[len(ev) // 2]:.2f} "
+                  f"(HIP events: {line['roofline']['frame_ms_percentiles_per_view'][name]['median'] * 1e3:.2f})")
+            if name in line["config"]["views"]:
+                tot += b2b
+        print(f"   roofline leg, views {'/'.join(line['config']['views'])}: avg {sum(tot) / len(tot):.2f}  "
+              f"(bench line roofline.kernel_ms_avg by HIP events incl. the schedule kernels between the launches: {line['roofline']['kernel_ms_avg'] * 1e3:.2f})")
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     if not os.path.isdir(d):
         continue
