@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/benchmark_path.npz: camera states of the reference's scripted fly-through
+"""Generates tests/golden/benchmark/benchmark_path.npz: camera states of the reference's scripted fly-through
 (src/modules/voxel_rt/Benchmark.zig:22-74, path :141-172) as raw Camera.Device bytes, so that the restatement of
 the zalgebra helpers (un-vendored upstream) in zig_vulkan_amd/csrc/host_benchmark.cpp cannot drift unnoticed.
 
@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from zig_vulkan_amd import Camera, CameraConfig, Sun, SunConfig  # noqa: E402
 from zig_vulkan_amd.voxel_rt import Benchmark  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "benchmark_path.npz")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "benchmark", "benchmark_path.npz")
 W, H = 320, 180
 SEG = 60.0 / 11.0
 

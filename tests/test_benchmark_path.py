@@ -53,12 +53,12 @@ def test_key_orientations_and_completion():
     assert np.allclose(list(cam.d_camera.origin), [0, 13, 0], atol=1.0)  # frozen within one 0.25 s step of the last key
 
 
-# ---- committed camera states of the path (tests/golden/benchmark_path.npz, made by tests/golden/make_benchmark_golden.py) ----
+# ---- committed camera states of the path (tests/golden/benchmark/benchmark_path.npz, made by tests/golden/make_benchmark_golden.py) ----
 import os
 
 import pytest
 
-GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "benchmark_path.npz")
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "benchmark", "benchmark_path.npz")
 PATH_POINTS = np.array([[0, 0, 0], [2, 5, 0], [3, 5, 5], [5, 2, 1], [10, 0, 10], [20, -20, 20], [10, -25, 15], [10, -22, 20], [10, -30, 25],
                         [5, -10, 10], [0, 13, 0]], dtype=np.float64)                                  # Benchmark.zig:146-158
 PATH_EULER = np.array([[0, 0, 0], [0, 45, 0], [10, -20, 0], [20, 180, 0], [50, 90, 0], [60, 0, 0], [80, -10, 0], [75, -40, 0], [80, -10, 0],

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Phase profile of vrt_path_kernel (frames with bounces).  Needs the library built with the development profile:
+    make -C zig_vulkan_amd/csrc -B EXTRA=-DVRT_DEV_PROFILE
+usage: path_profile.py <workload> <view> [variant]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zig_vulkan_amd import workloads as W
+
+w = W.WORKLOADS[sys.argv[1]]
+view = sys.argv[2]
+variant = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0
+grid = W.build_grid(w)
+rt = W.make_renderer(w, grid, kernel_variant=variant)
+rc = W.make_renderer(w, grid, kernel_variant=variant, enable_counters=True)
+W.set_view(rt, view); W.set_view(rc, view)
+rt.draw(2); rt.wait()
+pr = rt.wave_timeline(raw=True).reshape(-1)[:12].astype(float)
+ms = rt.last_kernel_ms()
+rc.draw(); c = rc.counters()
+t_trans, t_walk, t_brick = pr[0:3]
+n_tr, n_wait, n_calls, n_alive_in, n_alive_out, n_brick, n_parked, _, waves = pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10], pr[11]
+tot = t_trans + t_walk + t_brick
+print(f"{w.name} {view} variant {variant:#x}: {ms:.2f} ms, {int(waves)} waves, rays {c['rays']/1e6:.1f}M, grid steps/ray {c['grid_steps']/c['rays']:.1f}, bricks/ray {c['bricks_entered']/c['rays']:.2f}, "
+      f"voxel steps/ray {c['voxel_steps']/c['rays']:.1f}")
+print(f"  cycles: transitions {100*t_trans/tot:.1f} %, walk loop {100*t_walk/tot:.1f} %, bricks {100*t_brick/tot:.1f} %  (sum over waves {tot/1e9:.2f} G cycles)")
+print(f"  transitions: {n_tr/1e6:.2f} M rounds, {n_wait/n_tr:.1f} waiting lanes per round, {t_trans/n_tr:.0f} cycles per round")
+print(f"  walk loop: {n_calls/1e6:.2f} M calls, {n_alive_in/n_calls:.1f} lanes at entry, {n_alive_out/n_calls:.1f} still moving at exit, {t_walk/n_calls:.0f} cycles per call; "
+      f"lane-trips {c['grid_steps']/1e6:.0f} M -> {c['grid_steps']/n_calls:.1f} lane-trips per call")
+print(f"  bricks: {n_brick/1e6:.2f} M rounds, {n_parked/n_brick:.1f} parked lanes per round, {t_brick/n_brick:.0f} cycles per round")
+rt.deinit(); rc.deinit()

@@ -27,6 +27,7 @@ KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t varian
 uint32_t resolve_variant(uint32_t variant);
 size_t trace_lds_bytes(const TraceParams &p, uint32_t variant);
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream, uint32_t frames = 1);
+bool is_path_kernel(KernelFn fn);
 hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra, uint32_t wave_slots,
                            hipStream_t stream);
 hipError_t launch_assemble_rgb(const void *gathered, void *frame, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t shard_count,
@@ -173,7 +174,10 @@ struct vrt_ctx {
     bool staging_busy[kStagingSlots] = {};
     int staging_next = 0;
     vrt::TraceParams params{};
-    vrt::KernelFn kernel = nullptr;        // general bounce loop
+    vrt::KernelFn kernel = nullptr;        // frames with bounces: persistent lanes (vrt_path_kernel) unless kernel_variant bit 21
+    vrt::KernelFn kernel_lockstep = nullptr; // ... the lockstep bounce loop (always used by the multi-GPU pipeline: RGB shards)
+    uint32_t *d_work_counter = nullptr;    // vrt_path_kernel's pixel counters: [2 streams][kMaxBatchFrames]
+    uint32_t path_lds_bytes = 0;           // LDS block filter of vrt_path_kernel (0: grid not eligible)
     vrt::KernelFn kernel_single = nullptr; // specialisation for max_bounce <= 1
     vrt::KernelFn kernel_single1 = nullptr; // ... and samples_per_pixel == 1
     vrt_shard_info shard{};
@@ -219,6 +223,7 @@ void free_ctx(vrt_ctx *c) {
     if (c->own_t8 && c->target8) (void)hipFree(c->target8);
     if (c->own_t32 && c->target32f) (void)hipFree(c->target32f);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_work_counter) (void)hipFree(c->d_work_counter);
     if (c->d_status_blocks) (void)hipFree(c->d_status_blocks);
     if (c->d_cell_bounds) (void)hipFree(c->d_cell_bounds);
     if (c->dist) {
@@ -595,10 +600,34 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (((cfg->kernel_variant >> 8) & 0xFFu) == 0u &&
         c->dsize[VRT_BUF_BRICK_STATUS] + c->dsize[VRT_BUF_BRICK_INDEX] + c->dsize[VRT_BUF_BRICK_OCCUPANCY] > (192ull << 20))
         c->bounce_variant |= 8u << 8;
+    // (min_waves 5 exists for vrt_path_kernel only: the other kernels take their default)
+    const uint32_t mwv = (cfg->kernel_variant >> 8) & 0xFFu;
+    const uint32_t single_variant = (mwv == 5u) ? (cfg->kernel_variant & ~0xFF00u) : cfg->kernel_variant;
+    const uint32_t lockstep_variant = ((mwv == 5u) ? (c->bounce_variant & ~0xFF00u) : c->bounce_variant) | vrt::kVariantLockstepBounce;
+    {
+        // vrt_path_kernel behind the LDS block filter: x and z dimensions powers of two >= 4, filter <= 32 KiB (so that four
+        // workgroups per CU keep their copies), cell index < 2^31
+        auto pow2 = [](uint32_t v) { return v >= 4u && (v & (v - 1u)) == 0u; };
+        const uint64_t nblocks64 = (uint64_t)((cfg->dim_x + 3u) / 4u) * ((cfg->dim_y + 3u) / 4u) * ((cfg->dim_z + 3u) / 4u);
+        size_t bytes = 16;
+        while (bytes < ((nblocks64 + 31u) / 32u) * 4u) bytes <<= 1;
+        // Opt-in (kernel_variant bit 22): measured SLOWER than the plain loop on the 2048^3 path-trace configuration (215 against
+        // 204 ms per frame): the walk is not bound by the L1's line rate after all, and the trip grows from 31 to 45 instructions.
+        if ((cfg->kernel_variant & vrt::kVariantPathFilter) && pow2(cfg->dim_x) && pow2(cfg->dim_z) && cfg->dim_y % 4u == 0u && bytes <= (32u << 10)) {
+            c->path_lds_bytes = (uint32_t)bytes;
+        } else {
+            c->bounce_variant &= ~vrt::kVariantPathFilter;
+        }
+        // the path kernel runs at 4 waves per SIMD (100 VGPRs); the 8-wave choice above is the lockstep kernel's
+        if (!(c->bounce_variant & vrt::kVariantLockstepBounce) && ((c->bounce_variant >> 8) & 0xFFu) == 8u && mwv != 8u) c->bounce_variant &= ~0xFF00u;
+    }
     c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->bounce_variant, 0);
-    c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant, 1);
-    c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, cfg->kernel_variant, 2);
-    if (!c->kernel || !c->kernel_single || !c->kernel_single1) {
+    c->kernel_lockstep = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, lockstep_variant, 0);
+    c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, single_variant, 1);
+    c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, single_variant, 2);
+    VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_work_counter), 2u * vrt::kMaxBatchFrames * sizeof(uint32_t)));
+    VRT_CREATE_HIP(hipMemsetAsync(c->d_work_counter, 0, 2u * vrt::kMaxBatchFrames * sizeof(uint32_t), c->stream));
+    if (!c->kernel || !c->kernel_lockstep || !c->kernel_single || !c->kernel_single1) {
         free_ctx(c);
         return fail(nullptr, VRT_E_INVALID_ARG, "no kernel for this configuration");
     }
@@ -623,6 +652,16 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.target_rgba32f = c->target32f;
     p.counters = c->d_counters;
     p.count_box = (cfg->enable_counters == 2u) ? 1u : 0u;
+    p.work_counter = c->d_work_counter;
+    p.path_lds_bytes = c->path_lds_bytes;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
+        p.path_groups = 8u * (uint32_t)cus; // twice what 4 waves per SIMD hold: late groups find the counter exhausted and leave
+        p.path_fin_batch = 32u;
+        if (const char *e = std::getenv("VRT_PATH_FIN_BATCH")) p.path_fin_batch = (uint32_t)std::max(1, std::atoi(e)); // tuning knob
+        if (const char *e = std::getenv("VRT_PATH_GROUPS")) p.path_groups = (uint32_t)std::max(1, std::atoi(e));
+    }
     p.width = cfg->width;
     p.height = cfg->height;
     p.tiles_x = sh.tiles_x;
@@ -658,6 +697,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.tile_schedule = c->d_tile_schedule;
     p.wave_groups = (cfg->kernel_variant >> 20) & 0x1u;
     p.brick_batch = (cfg->kernel_variant >> 24) & 0xFu ? ((cfg->kernel_variant >> 24) & 0xFu) * 4u : 8u; // tuning knob: units of 4 lanes
+    p.path_brick_batch = (cfg->kernel_variant >> 24) & 0xFu ? ((cfg->kernel_variant >> 24) & 0xFu) * 4u : 32u; // vrt_path_kernel: waiting is cheap there
     p.block_threads = ((vrt::resolve_variant(cfg->kernel_variant) & 0xFFu) == vrt::kVariantLinearLds512) ? 512u : 256u;
     {
         // a stride near owned_tiles * 0.618 that is coprime to owned_tiles
@@ -678,6 +718,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         c->cfg.kernel_variant = (cfg->kernel_variant & ~0xFFu) | fallback;
         c->bounce_variant = (c->bounce_variant & ~0xFFu) | fallback;
         c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->bounce_variant, 0);
+        c->kernel_lockstep = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->bounce_variant | vrt::kVariantLockstepBounce, 0);
         c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 1);
         c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 2);
         c->lds_bytes = 0;
@@ -821,6 +862,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         if (ctx->order_auto) pb.tile_order = 3u;
         pb.target_rgba8 = ctx->target8_b;
         pb.target_rgba32f = ctx->target32f_b;
+        pb.work_counter = ctx->d_work_counter + vrt::kMaxBatchFrames; // its frames run beside the primary stream's
         VRT_HIP(ctx, vrt::launch_trace(fn, pb, ctx->lds_bytes, ctx->stream_b));
         if (product_fn) VRT_HIP(ctx, vrt::launch_trace(product_fn, pb, ctx->lds_bytes, ctx->stream_b));
         VRT_HIP(ctx, hipEventRecord(ctx->ev_b_done, ctx->stream_b));
@@ -1158,6 +1200,9 @@ int vrt_dist_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_
     vrt::KernelFn fn = nullptr;
     const int rcp = pre_dispatch(ctx, camera, sun, &fn); // (a scene write it may have to do launches the queued frames first)
     if (rcp != VRT_OK) return rcp;
+    // the pipeline's launches overlap on several streams and write RGB shards with a row-of-eight-lanes shuffle: both
+    // need the lockstep kernel (vrt_path_kernel has one pixel counter per stream and no fixed lane -> pixel map)
+    if (fn == ctx->kernel) fn = ctx->kernel_lockstep;
     if (d->npend > 0 && d->pend_fn != fn) { // another kernel specialisation (bounces / samples changed): not in the same launch
         const int rcf = dist_flush(ctx);
         if (rcf != VRT_OK) return rcf;

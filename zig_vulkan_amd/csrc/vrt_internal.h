@@ -88,8 +88,13 @@ struct TraceParams {
     uint32_t packed_rgb;                 // 1 (with packed_tiles): 3 bytes per pixel in the shard (alpha is the constant 255): a quarter
                                          // less to gather over xGMI; the un-swizzle on rank 0 puts the alpha back
     uint32_t brick_batch;                // lanes that must be waiting before a batched voxel-level walk runs (bounce frames)
+    uint32_t path_brick_batch;           // the same for vrt_path_kernel
     uint32_t block_threads;              // 256, or 512 for kVariantLinearLds512
     uint32_t wave_groups;                // 1: launch one 64-thread workgroup per 8x8 block instead of 256 per 16x16 tile
+    uint32_t *work_counter;              // vrt_path_kernel: one pixel counter per frame of the launch (zeroed before every launch)
+    uint32_t path_lds_bytes;             // vrt_path_kernel<FILTER>: power-of-two LDS allocation holding the block filter (0: grid not eligible)
+    uint32_t path_groups;                // vrt_path_kernel: workgroups to launch (a few times what the GPU holds)
+    uint32_t path_fin_batch;             // vrt_path_kernel: lanes that must be waiting before the wave leaves the walk loop for them
     uint32_t count_box;                  // counting build only: 1 = walk to the occupied-cell box like the product kernel (issued loads)
     uint32_t tile_order;                 // workgroup -> tile mapping: 1 row bands per XCD, 2 column bands per XCD, 3 reverse raster, 4 strided,
                                          // 5 cost-feedback schedule, 6 raster.  (kernel_variant: 0 = the library chooses between 3 and the
@@ -113,5 +118,9 @@ enum : uint32_t {
     kVariantLinearAhead = 8,  // uncached status word, software-pipelined one cell ahead
     kVariantCount
 };
+// kernel_variant bit 21: frames with bounces run the lockstep kernel (vrt_trace_kernel<SHADE 0>) instead of vrt_path_kernel
+constexpr uint32_t kVariantLockstepBounce = 1u << 21;
+// bit 22: vrt_path_kernel behind the LDS block filter (grids whose x and z dimensions are powers of two; measured slower, opt-in)
+constexpr uint32_t kVariantPathFilter = 1u << 22;
 
 } // namespace vrt

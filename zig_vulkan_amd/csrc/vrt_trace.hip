@@ -336,6 +336,7 @@ struct GridParkRegs {
     // out, parked lanes: bits 0-1 axis INTO the occupied cell, bits 2-3 axis OUT of it
     uint32_t code;
     uint32_t batch;                  // in: the call returns once this many lanes are parked (or nobody is moving)
+    uint32_t min_alive = 0;          // in: ... or, at a back edge, once fewer than this many lanes are still moving (0: never)
 };
 
 #define VRT_PARK(LABEL, IN_AXIS, OUT_MX, OUT_MY, SWAP, NEXT, EXIT)                                       \
@@ -377,8 +378,13 @@ VRT_DI void grid_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, u
         "23:\n\t"
         VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", VRT_NO_LIMIT, VRT_LOAD_BUFFER, "14f")
         "24:\n\t"
-        "s_cbranch_execnz 0b\n\t"
-        "s_branch 31f\n\t"
+        "s_cbranch_execz 31f\n\t"
+        /* back edge (after an A trip): keep walking while at least min_alive lanes are moving; fewer -> hand the wave back
+           so that the finished lanes can be given new rays (vrt_path_kernel; min_alive = 0: never) */
+        "s_bcnt1_i32_b64 %[n], exec\n\t"
+        "s_cmp_ge_u32 %[n], %[minalive]\n\t"
+        "s_cbranch_scc1 0b\n\t"
+        "s_branch 30f\n\t"
         VRT_PARK("10", VRT_IN_FROM_CODE, "mxa", "mya", VRT_SWAP_SETS, "0b", "30f")
         VRT_PARK("11", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "21b", "31f")
         VRT_PARK("12", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "22b", "30f")
@@ -403,9 +409,133 @@ VRT_DI void grid_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, u
           [mxa] "=&s"(mxa), [mya] "=&s"(mya), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz),
           [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n)
         : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z), [rsrc] "s"(rsrc),
-          [batch] "s"(g.batch)
+          [batch] "s"(g.batch), [minalive] "s"(g.min_alive)
         : "vcc", "scc");
 }
+// ---- the park loop behind a block filter in LDS (vrt_path_kernel) ----------------------------------------------------
+// A wave-wide status request of INCOHERENT rays touches one 128-byte line per lane, and the L1 takes about one line
+// per cycle per CU: with 54 lanes walking, a trip of the loop above costs ~700 cycles per wave at 4 waves per SIMD
+// (tools/path_profile.py) — the walk is bound by the L1's line rate, not by its instructions.  Most of those requests
+// ask about cells in empty space.  Here the 1-bit-per-4x4x4-cells filter that vrt_build_status_blocks derives from
+// binding 3 is staged in LDS once per workgroup, every trip looks the next cell's BLOCK up there (ds_read_b32: LDS
+// serves 64 scattered dwords in a few cycles), and only the lanes whose block holds an occupied cell request the
+// status word; the others take 0, which is what the word's bit would be.  Same bits tested, same sequence per lane.
+// The block index is formed from the linear cell index by bit fields, so the grid's x and z dimensions must be powers of
+// two >= 4 (every BASELINE configuration); other grids use the loop above.
+// Order within a trip: step -> next index -> filter lookup issued -> wait for the word requested a trip ago -> test it,
+// counters, exits -> filter bit -> masked request for the next word.  At most one request is in flight, waited for with
+// vmcnt(0), so nothing depends on how a request with an empty EXEC is counted.
+struct FilterConsts {
+    uint32_t wx;    // log2(dim_x) - 2: width of the x block field
+    uint32_t shz;   // log2(dim_x) + 2: the z block field starts here in the cell index
+    uint32_t mz;    // (dim_z >> 2) - 1
+    uint32_t shy;   // log2(dim_x) + log2(dim_z) + 2
+    uint32_t shyb;  // log2(dim_x) + log2(dim_z) - 4: where the y block field goes in the block index
+    uint32_t ldsmask; // (power-of-two LDS allocation) - 4: byte address mask
+};
+
+#define VRT_TRIPF(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, OUT)             \
+    "v_cmp_lt_f32_e64 %[" MX "], %[sdx], %[sdy]\n\t"                      \
+    "v_cmp_lt_f32_e64 %[" MXY "], %[sdx], %[sdz]\n\t"                     \
+    "v_cmp_lt_f32_e64 %[" MY "], %[sdy], %[sdz]\n\t"                      \
+    "v_add_f32_e64 %[t0], %[sdx], |%[ix]|\n\t"                            \
+    "v_add_f32_e64 %[t1], %[sdy], |%[iy]|\n\t"                            \
+    "v_add_f32_e64 %[t2], %[sdz], |%[iz]|\n\t"                            \
+    "s_andn2_b64 %[" MY "], %[" MY "], %[" MX "]\n\t"                     \
+    "s_and_b64 %[" MX "], %[" MX "], %[" MXY "]\n\t"                      \
+    "s_or_b64 %[" MXY "], %[" MX "], %[" MY "]\n\t"                       \
+    "v_cndmask_b32_e64 %[" TS "], %[sdz], %[sdy], %[" MY "]\n\t"          \
+    "v_cndmask_b32_e64 %[" TS "], %[" TS "], %[sdx], %[" MX "]\n\t"       \
+    "v_cndmask_b32_e64 %[sdx], %[sdx], %[t0], %[" MX "]\n\t"              \
+    "v_cndmask_b32_e64 %[sdy], %[sdy], %[t1], %[" MY "]\n\t"              \
+    "v_cndmask_b32_e64 %[sdz], %[t2], %[sdz], %[" MXY "]\n\t"             \
+    "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[" MY "]\n\t"              \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[" MX "]\n\t"               \
+    "v_add_u32_e32 %[" IDXN "], %[" IDX "], %[t0]\n\t"                    \
+    /* block of the next cell: x>>2 | (z>>2) << wx | (y>>2) << shyb */    \
+    "v_bfe_u32 %[t2], %[" IDXN "], 2, %[wx]\n\t"                          \
+    "v_lshrrev_b32_e32 %[t0], %[shz], %[" IDXN "]\n\t"                    \
+    "v_and_b32_e32 %[t0], %[mz], %[t0]\n\t"                               \
+    "v_lshl_or_b32 %[t2], %[t0], %[wx], %[t2]\n\t"                        \
+    "v_lshrrev_b32_e32 %[t0], %[shy], %[" IDXN "]\n\t"                    \
+    "v_lshl_or_b32 %[t2], %[t0], %[shyb], %[t2]\n\t"                      \
+    "v_lshrrev_b32_e32 %[t0], 3, %[t2]\n\t"                               \
+    "v_and_b32_e32 %[t0], %[ldsmask], %[t0]\n\t"                          \
+    "ds_read_b32 %[t0], %[t0]\n\t"                                        \
+    /* the cell just left: its word was requested one trip ago */         \
+    "s_waitcnt vmcnt(0)\n\t"                                              \
+    "v_bfe_u32 %[t1], %[" WORD "], %[" IDX "], 1\n\t"                     \
+    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"                                  \
+    "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[" MX "]\n\t"          \
+    "v_subbrev_co_u32_e64 %[ry], %[by], 0, %[ry], %[" MY "]\n\t"          \
+    "v_addc_co_u32_e64 %[rz], %[cz], -1, %[rz], %[" MXY "]\n\t"           \
+    "s_or_b64 %[ex], %[ex], %[by]\n\t"                                    \
+    "s_orn2_b64 %[ex], %[ex], %[cz]\n\t" /* z: carry-out 0 = borrow */    \
+    "s_andn2_b64 exec, exec, %[ex]\n\t"                                   \
+    /* the next cell's word, only where its block is not empty */         \
+    "s_waitcnt lgkmcnt(0)\n\t"                                            \
+    "v_bfe_u32 %[t0], %[t0], %[t2], 1\n\t"                                \
+    "v_mov_b32_e32 %[" WORDN "], 0\n\t"                                   \
+    "v_cmp_ne_u32_e64 %[by], 0, %[t0]\n\t"                                \
+    "s_and_saveexec_b64 %[cz], %[by]\n\t"                                 \
+    "v_lshrrev_b32_e32 %[t2], 5, %[" IDXN "]\n\t"                         \
+    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"         \
+    "s_mov_b64 exec, %[cz]\n\t"                                           \
+    "s_cbranch_vccnz " OUT "\n\t"
+
+VRT_DI void grid_walk_park_filter_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
+                                         uint32_t &word, u32x4 rsrc, GridParkRegs &g, const FilterConsts &fc) {
+    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
+    float t0, t1, t2;
+    uint32_t wordb, n;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "s_mov_b64 exec, %[alive]\n\t"
+        "s_mov_b64 %[parked], 0\n\t"
+        VRT_TRIPF("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", "10f")
+        "0:\n\t"
+        VRT_TRIPF("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", "11f")
+        "21:\n\t"
+        VRT_TRIPF("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", "12f")
+        "22:\n\t"
+        VRT_TRIPF("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", "13f")
+        "23:\n\t"
+        VRT_TRIPF("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", "14f")
+        "24:\n\t"
+        "s_cbranch_execz 31f\n\t"
+        "s_bcnt1_i32_b64 %[n], exec\n\t"
+        "s_cmp_ge_u32 %[n], %[minalive]\n\t"
+        "s_cbranch_scc1 0b\n\t"
+        "s_branch 30f\n\t"
+        VRT_PARK("10", VRT_IN_FROM_CODE, "mxa", "mya", VRT_SWAP_SETS, "0b", "30f")
+        VRT_PARK("11", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "21b", "31f")
+        VRT_PARK("12", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "22b", "30f")
+        VRT_PARK("13", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "23b", "31f")
+        VRT_PARK("14", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "24b", "30f")
+        "30:\n\t" /* the last trip was an A trip: swap the sets of the lanes still moving */
+        "s_mov_b64 %[alive], exec\n\t"
+        VRT_WAIT_BUFFER
+        VRT_SWAP_SETS
+        "v_mov_b32_e32 %[worda], %[wordb]\n\t"
+        "s_mov_b64 %[mxb], %[mxa]\n\t"
+        "s_mov_b64 %[myb], %[mya]\n\t"
+        "s_branch 32f\n\t"
+        "31:\n\t"
+        "s_mov_b64 %[alive], exec\n\t"
+        VRT_WAIT_BUFFER /* the compiler may move `word`: no load may be in flight outside */
+        "32:\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),
+          [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(word), [wordb] "=&v"(wordb), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in),
+          [code] "+v"(g.code), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive),
+          [mxa] "=&s"(mxa), [mya] "=&s"(mya), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz),
+          [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n)
+        : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z), [rsrc] "s"(rsrc),
+          [batch] "s"(g.batch), [minalive] "s"(g.min_alive), [wx] "s"(fc.wx), [shz] "s"(fc.shz), [mz] "s"(fc.mz), [shy] "s"(fc.shy), [shyb] "s"(fc.shyb),
+          [ldsmask] "s"(fc.ldsmask)
+        : "vcc", "scc", "memory");
+}
+#undef VRT_TRIPF
 #undef VRT_PARK
 #undef VRT_IN_FROM_CODE
 #undef VRT_IN_FROM
@@ -585,7 +715,7 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
 // The loop returns when some lane has left a solid voxel behind; the material test (comp:422-427) and the hit
 // record are done here, and lanes whose voxel is to be ignored walk on.  `axis_in`: the face through which the
 // brick was entered (the brick-level walk's crossed axis), used when the very first voxel is the hit.
-template <int B>
+template <int B, bool EAGER = true>
 VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t brick_index, f3 brick_min, Hit &hit,
                               int axis_in, int &hit_axis) {
     const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
@@ -615,8 +745,12 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
     rsrc.z = p.occupancy_words;
     rsrc.w = 0x00020000u;
     uint32_t word = reinterpret_cast<const uint32_t *>(p.brick_occupancy)[more ? (bit_index >> 5) : 0u];
-    // comp:422, requested before the walk so that a solid voxel's material test starts one dependent load later
-    const uint32_t brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu;
+    // comp:422.  EAGER: requested before the walk, so that a solid voxel's material test starts one dependent load later
+    // (scenes that stay in the caches).  Otherwise requested at the first solid voxel: on a scene larger than the caches
+    // every request is a 128-byte line from HBM, and four of five brick walks of the path-trace configuration end without
+    // a solid voxel (K = 3.2 bricks entered, H = 0.7 hits per ray).
+    uint32_t brick_material_index = 0u;
+    if constexpr (EAGER) brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu;
     GridWalkRegs g;
     g.alive = __builtin_amdgcn_ballot_w64(more);
     g.out_x = 0ull;
@@ -633,6 +767,7 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
         if (__builtin_amdgcn_inverse_ballot_w64(g.occ)) {
             VRT_PROF_BEGIN(tp4);
             const uint32_t voxel_index = solid_bit - base;
+            if constexpr (!EAGER) brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu;
             const uint32_t mi = p.material_index[brick_material_index + voxel_index];
             const vrt_material *m = p.materials + mi;
             const uint32_t mtype = m->type;
@@ -1297,6 +1432,379 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     }
 }
 
+// ---- frames with bounces: persistent lanes -------------------------------------------------------------------------
+// vrt_trace_kernel<SHADE 0> runs the shader's loops in lockstep: the 64 lanes of a wave take sample s together, bounce k
+// together, and every GridHit lasts as long as the longest of its 64 walks.  On the path-trace configuration (incoherent
+// secondary rays through a sparse field, 16 samples, 3 bounces) that leaves about a fifth of the lanes of an instruction
+// busy (367 wave-instructions per ray against ~70 for 64 rays in step; profiles/r02a_cfg4*).  Here a lane is not tied to
+// its wave's progress: each lane carries its own (pixel, sample, bounce, ray) and moves through
+//     FETCH a pixel -> SAMPLE (camera ray) -> START a ray (slab test, walk set-up) -> WALK (the hand-written park loop,
+//     shared by primary, bounce and shadow rays of all lanes) -> DONE (shade: scatter, shadow ray, next bounce) -> END of
+//     the path (tone-map, accumulate the sample) -> STORE the pixel -> FETCH ...
+// A lane whose ray has left the grid is handed its next ray while its neighbours keep walking: the walk loop returns
+// when `path_fin_batch` lanes have finished (or `brick_batch` lanes wait at a brick, or nobody is moving), the transitions
+// run for the lanes that need them, and the loop is re-entered with every lane that has a ray.  Pixels come from one
+// counter per frame (p.work_counter), 64 consecutive pixels of an 8x8 block at a time while the wave is empty.
+// Per lane the sequence of arithmetic operations is exactly ray_color's / main()'s (comp:153-265): the samples of a pixel
+// are traced one after the other by the lane that owns the pixel and summed in order, so frames are bit-identical.
+enum : int { kLaneFetch = 0, kLaneSample, kLaneStart, kLaneWalk, kLaneDone, kLaneEnd, kLaneStore, kLaneExit };
+
+template <int B, int MIN_WAVES, bool FILTER>
+__global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TraceParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_block_filter[];
+    FilterConsts fc{};
+    if constexpr (FILTER) {
+        // stage the block filter (1 bit per 4x4x4 block of cells: "some cell occupied") once per workgroup; the kernel has no
+        // static LDS, so the dynamic region starts at LDS address 0, which the walk loop's ds_read relies on
+        const uint32_t nblocks = p.nbx * p.nby * p.nbz;
+        const uint32_t nwords = (nblocks + 31u) >> 5;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.status_blocks + (size_t)nblocks);
+        for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) lds_block_filter[i] = src[i];
+        __syncthreads();
+        const uint32_t lx = 31u - (uint32_t)__builtin_clz(p.grid.dim_x), lz = 31u - (uint32_t)__builtin_clz(p.grid.dim_z);
+        fc.wx = lx - 2u;
+        fc.shz = lx + 2u;
+        fc.mz = (p.grid.dim_z >> 2) - 1u;
+        fc.shy = lx + lz + 2u;
+        fc.shyb = lx + lz - 4u;
+        fc.ldsmask = p.path_lds_bytes - 4u;
+    }
+    const PushConstants &pc = p.pcs[blockIdx.y];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = p.owned_tiles * (uint32_t)(kTileW * kTileH);
+    uint32_t *const counter = p.work_counter + blockIdx.y;
+    const bool sun_enabled = pc.sun.enabled > 0;
+    const int spp = pc.cam.samples_per_pixel;
+    const int max_bounce = pc.cam.max_bounce;
+    const float t_max = __builtin_inff();
+
+    const f3 g_min = mk3(p.grid.min_point_base_t[0], p.grid.min_point_base_t[1], p.grid.min_point_base_t[2]);
+    const float g_scale = p.grid.max_point_scale[3];
+    const int dx = (int)p.grid.dim_x, dy = (int)p.grid.dim_y, dz = (int)p.grid.dim_z;
+    int lox = 0, loy = 0, loz = 0, hix = dx - 1, hiy = dy - 1, hiz = dz - 1;
+    if (p.cell_bounds) {
+        lox = -p.cell_bounds[0], loy = -p.cell_bounds[1], loz = -p.cell_bounds[2];
+        hix = p.cell_bounds[3], hiy = p.cell_bounds[4], hiz = p.cell_bounds[5];
+    }
+    const int zero_budget = dx + dy + dz + 8;
+    const unsigned long long status_addr = (unsigned long long)p.brick_status;
+    u32x4 rsrc;
+    rsrc.x = (uint32_t)status_addr;
+    rsrc.y = (uint32_t)(status_addr >> 32) | (4u << 16); // stride 4: one record per status word
+    rsrc.z = p.status_words;
+    rsrc.w = 0x00020000u;
+
+    // ---- per-lane state ----
+    int st = kLaneFetch;
+    uint32_t work = 0u;          // pixel: index into this context's tiles, 256 per tile, 8x8 blocks inside
+    int sample_i = 0;
+    f3 acc = mk3(0, 0, 0);       // sum of the samples' colours (comp:173)
+    // the path (RayColor's locals, comp:203-216)
+    int loop_count = 0;
+    f3 color = mk3(0, 0, 0);
+    float cur_dir_y = 0.0f;      // current_ray.direction.y, for BackgroundColor when loop_count ends at 0
+    // the ray being walked: the path's current ray (kind 0) or the shadow ray of its last hit (kind 1)
+    Ray r = Ray{mk3(0, 0, 0), mk3(0, 0, 1), 1.0f, MAT_NONE};
+    int kind = 0;
+    bool found = false;
+    // kept while the shadow ray is walked: the scattered ray (its origin is the shadow ray's origin, hit.point), the
+    // albedo, and whether the material scattered (comp:221-239)
+    f3 sc_dir = mk3(0, 0, 1);
+    float sc_ir = 1.0f;
+    uint32_t sc_ignore = MAT_NONE;
+    f3 attenuation = mk3(0, 0, 0);
+    bool scattered_ok = false;
+    // the walk (grid_hit's locals)
+    RaySetup s;
+    s.ray_delta = s.inv_dir = mk3(1, 1, 1);
+    s.entry_code = 0;
+    s.sx = s.sy = s.sz = 0;
+    s.grid_t_min = s.grid_t_max = 0.0f;
+    Walk w;
+    w.side_dist = mk3(0, 0, 0);
+    w.rx = w.ry = w.rz = -1;
+    w.t_value = 0.0f;
+    int base_x = 0, base_y = 0, base_z = 0;
+    uint32_t grid_index = 0u, word = 0u;
+    uint32_t stride_x = 0u, stride_y = 0u, stride_z = 0u;
+    Hit hit;
+    hit.point = hit.normal = mk3(0, 0, 0);
+    hit.t = 0.0f;
+    hit.index = 0u;
+    int hit_axis = 0;
+    GridParkRegs g;
+    g.alive = 0ull;
+    g.out_x = g.out_y = 0ull;
+    g.t_out = g.t_in = 0.0f;
+    g.code = 3u << 4;
+    g.batch = p.path_brick_batch;
+
+    bool work_left = true; // wave-uniform
+#ifdef VRT_DEV_PROFILE
+    // development-only (make EXTRA=-DVRT_DEV_PROFILE, tools/path_profile.py): cycles and lane counts per phase, per wave
+    unsigned long long pf_t[3] = {0ull, 0ull, 0ull};      // cycles in transitions / walk loop / bricks
+    unsigned long long pf_n[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; // rounds: transitions, waiting lanes; walk calls, alive lanes at entry,
+                                                                                    // alive lanes at exit; brick rounds, parked lanes; hits
+#define VRT_PF_T(k, t0) pf_t[k] += __builtin_readcyclecounter() - (t0)
+#define VRT_PF_N(k, v) pf_n[k] += (unsigned long long)(v)
+#define VRT_PF_NOW() __builtin_readcyclecounter()
+#else
+#define VRT_PF_T(k, t0)
+#define VRT_PF_N(k, v)
+#define VRT_PF_NOW() 0ull
+#endif
+    for (;;) {
+        // How many lanes wait for a transition?  Few: leave them waiting and keep the others walking (the divergent
+        // code below costs the whole wave its issue slots).
+        const unsigned long long walking0 = __builtin_amdgcn_ballot_w64(st == kLaneWalk);
+        const unsigned long long waiting = __builtin_amdgcn_ballot_w64(st != kLaneWalk && st != kLaneExit);
+        const uint32_t n_walking0 = (uint32_t)__builtin_popcountll(walking0), n_waiting = (uint32_t)__builtin_popcountll(waiting);
+        if (n_walking0 == 0u && n_waiting == 0u) break;
+        [[maybe_unused]] const unsigned long long pf0 = VRT_PF_NOW();
+        if (n_waiting != 0u && (n_walking0 == 0u || n_waiting >= min(p.path_fin_batch, max(1u, n_walking0 >> 1)))) {
+            VRT_PF_N(0, 1);
+            VRT_PF_N(1, n_waiting);
+            // (1) a ray has finished: comp:218-258 from the loop condition's GridHit onwards
+            if (st == kLaneDone) {
+                bool after_shadow = false;
+                if (kind == 0) {
+                    if (found) {
+                        // (brick_walk_gfx950 records a hit as distance + material + face: comp:433-436 from those)
+                        const float t_offset = (g_scale * (1.0f / (float)B)) * 0.05f;
+                        hit.normal = axis_normal(s, hit_axis);
+                        hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
+                        loop_count += 1;
+                        Ray scattered = r;
+                        bool result = false;
+                        const vrt_material *m = p.materials + hit.index;
+                        const uint32_t mtype = m->type;
+                        attenuation = mk3(m->albedo_r, m->albedo_g, m->albedo_b);
+                        const float mdata = m->type_data;
+                        switch (mtype) {
+                            case MAT_LAMBERTIAN: result = scatter_lambertian(hit, scattered); break;
+                            case MAT_METAL: result = scatter_metal(mdata, r, hit, scattered); break;
+                            case MAT_DIELECTRIC: result = scatter_dielectric(mdata, r, hit, scattered); break;
+                            default:
+                                loop_count -= 1;
+                                result = false;
+                                break;
+                        }
+                        scattered_ok = result;
+                        sc_dir = scattered.direction;
+                        sc_ir = scattered.internal_reflection;
+                        sc_ignore = scattered.ignore_type_material;
+                        cur_dir_y = r.direction.y;
+                        if (sun_enabled) {
+                            const f3 sun_position = mk3(pc.sun.position[0], pc.sun.position[1], pc.sun.position[2]);
+                            const f3 rv = rand_vec3_range(r.direction.x + r.direction.z, r.direction.y + r.direction.z, -pc.sun.radius, pc.sun.radius);
+                            const f3 shadow_ray_dir = (sun_position + rv) - hit.point;
+                            r = create_ray(hit.point, shadow_ray_dir); // CreateShadowRay, comp:186-190 (ignore type MAT_NONE)
+                            kind = 1;
+                            st = kLaneStart;
+                        } else {
+                            color = color + attenuation;
+                            // the scattered ray starts where the shadow ray would have: keep the origin in r
+                            r.origin = hit.point;
+                            after_shadow = true;
+                        }
+                    } else {
+                        cur_dir_y = r.direction.y;
+                        st = kLaneEnd; // the while condition failed (comp:218)
+                    }
+                } else {
+                    if (!found) color = color + attenuation * mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
+                    after_shadow = true;
+                }
+                if (after_shadow) {
+                    if (!scattered_ok) {
+                        st = kLaneEnd; // comp:253-255
+                    } else {
+                        r.direction = sc_dir; // current_ray = scattered (its origin, hit.point, is r.origin already)
+                        r.internal_reflection = sc_ir;
+                        r.ignore_type_material = sc_ignore;
+                        cur_dir_y = sc_dir.y;
+                        kind = 0;
+                        st = (loop_count < max_bounce) ? kLaneStart : kLaneEnd;
+                    }
+                }
+            }
+            // (2) the path is over: comp:260-264, then the sample loop's accumulation (comp:173)
+            if (st == kLaneEnd) {
+                if (loop_count == 0) {
+                    const f3 sun_color = mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
+                    const float t = 0.5f * (cur_dir_y + 1.0f);
+                    const f3 bg = fma3(splat3(1.0f - t), splat3(1.0f), mk3(0.5f, 0.7f, 1.0f) * t);
+                    color = color + bg * (sun_enabled ? sun_color : splat3(1.0f));
+                }
+                acc = acc + color / (color + splat3(1.0f));
+                sample_i += 1;
+                st = (sample_i < spp) ? kLaneSample : kLaneStore;
+            }
+            // (3) the pixel is finished: comp:176-177
+            if (st == kLaneStore) {
+                const uint32_t owned = p.owned_tiles - 1u - (work >> 8);
+                const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
+                const uint32_t j = work & 255u;
+                const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
+                const uint32_t px = (tile % p.tiles_x) * kTileW + in_x, py = (tile / p.tiles_x) * kTileH + in_y;
+                const float fspp = (float)spp;
+                const f3 c = mk3(__builtin_sqrtf(acc.x / fspp), __builtin_sqrtf(acc.y / fspp), __builtin_sqrtf(acc.z / fspp));
+                const size_t o = (p.shard_count > 1u || p.packed_tiles) ? (size_t)owned * (kTileW * kTileH) + in_y * kTileW + in_x : (size_t)py * p.width + px;
+                reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] =
+                    unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
+                if (p.target_rgba32f) reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(c.x, c.y, c.z, 1.0f);
+                st = kLaneFetch;
+            }
+            // (4) next pixel: one atomic per wave for all the lanes that ask
+            {
+                const unsigned long long asking = __builtin_amdgcn_ballot_w64(st == kLaneFetch);
+                if (asking != 0ull) {
+                    if (work_left) {
+                        const uint32_t n = (uint32_t)__builtin_popcountll(asking);
+                        uint32_t first = 0u;
+                        if (lane == (uint32_t)__builtin_ctzll(asking)) first = atomicAdd(counter, n);
+                        first = (uint32_t)__builtin_amdgcn_readlane((int)first, __builtin_ctzll(asking));
+                        if (st == kLaneFetch) {
+                            const uint32_t mine = first + (uint32_t)__builtin_popcountll(asking & ((1ull << lane) - 1ull));
+                            if (mine < total) {
+                                work = mine;
+                                sample_i = 0;
+                                acc = mk3(0, 0, 0);
+                                st = kLaneSample;
+                            } else {
+                                st = kLaneExit;
+                            }
+                        }
+                        work_left = first + n < total;
+                    } else if (st == kLaneFetch) {
+                        st = kLaneExit;
+                    }
+                }
+            }
+            // (5) next sample of the pixel: comp:162-171
+            if (st == kLaneSample) {
+                const uint32_t owned = p.owned_tiles - 1u - (work >> 8);
+                const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
+                const uint32_t j = work & 255u;
+                const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
+                const uint32_t px = (tile % p.tiles_x) * kTileW + in_x, py = (tile / p.tiles_x) * kTileH + in_y;
+                if (px >= p.width || py >= p.height) {
+                    st = kLaneFetch; // outside the image (comp:155-159): nothing to trace, nothing to store
+                } else {
+                    const float x = (float)px, y = (float)py;
+                    const f3 horizontal = mk3(pc.cam.horizontal[0], pc.cam.horizontal[1], pc.cam.horizontal[2]);
+                    const f3 vertical = mk3(pc.cam.vertical[0], pc.cam.vertical[1], pc.cam.vertical[2]);
+                    const f3 llc = mk3(pc.cam.lower_left_corner[0], pc.cam.lower_left_corner[1], pc.cam.lower_left_corner[2]);
+                    const f3 origin = mk3(pc.cam.origin[0], pc.cam.origin[1], pc.cam.origin[2]);
+                    const float flag = (sample_i > 0) ? 1.0f : 0.0f;
+                    const float noise_x = hash_12(((x + (float)sample_i) * 0.2f) * flag, (y * 0.2f) * flag);
+                    const float u = (x + noise_x) / (float)(pc.cam.image_width - 1u);
+                    const float noise_y = hash_12((x * 0.2f) * flag, ((y + (float)sample_i) * 0.2f) * flag);
+                    const float v = (y + noise_y) / (float)(pc.cam.image_height - 1u);
+                    const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
+                    r = create_ray(origin, ray_dir);
+                    kind = 0;
+                    loop_count = 0;
+                    color = mk3(0, 0, 0);
+                    cur_dir_y = r.direction.y;
+                    st = (loop_count < max_bounce) ? kLaneStart : kLaneEnd;
+                }
+            }
+            // (6) a new ray: comp:271-312 (GridHit up to its loop)
+            if (st == kLaneStart) {
+                found = false;
+                st = kLaneDone;
+                if (grid_slab(p, r, 0.00001f, t_max, s)) {
+                    const float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
+                    const f3 fposition = p.scale_pow2 ? (ray_at(r, global_t_value) - g_min) * p.inv_grid_scale : (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
+                    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
+                    const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
+                    const int py = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
+                    const int pz = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
+                    w.rx = steps_left_box(s.sx, px, lox, hix, zero_budget);
+                    w.ry = steps_left_box(s.sy, py, loy, hiy, zero_budget);
+                    w.rz = steps_left_box(s.sz, pz, loz, hiz, zero_budget);
+                    base_x = walk_base_box(s.sx, px, lox, hix), base_y = walk_base_box(s.sy, py, loy, hiy), base_z = walk_base_box(s.sz, pz, loz, hiz);
+                    w.t_value = 0;
+                    grid_index = (uint32_t)px + (uint32_t)dx * ((uint32_t)pz + (uint32_t)dz * (uint32_t)py);
+                    stride_x = (uint32_t)s.sx, stride_y = (uint32_t)s.sy * (uint32_t)dx * (uint32_t)dz, stride_z = (uint32_t)s.sz * (uint32_t)dx;
+                    const bool more = (global_t_value <= t_max) && (unsigned)px < (unsigned)dx && (unsigned)py < (unsigned)dy && (unsigned)pz < (unsigned)dz &&
+                                      (w.rx | w.ry | w.rz) >= 0;
+                    if (more) {
+                        word = p.brick_status[grid_index >> 5];
+                        g.t_out = 0.0f;
+                        g.code = 3u << 4; // the first cell of the walk was entered through the slab test, not by a step
+                        st = kLaneWalk;
+                    }
+                }
+            }
+        }
+        VRT_PF_T(0, pf0);
+        // (7) every lane that has a ray walks (comp:314-375), until enough of them are done for the next round of transitions
+        const unsigned long long walking = __builtin_amdgcn_ballot_w64(st == kLaneWalk);
+        if (walking == 0ull) continue;
+        [[maybe_unused]] const unsigned long long pf1 = VRT_PF_NOW();
+        const uint32_t n_walking = (uint32_t)__builtin_popcountll(walking);
+        const uint32_t fin = min(p.path_fin_batch, max(1u, n_walking >> 1));
+        g.alive = walking;
+        g.min_alive = n_walking >= fin ? n_walking - fin + 1u : 1u;
+        uint32_t cell; // the occupied cell each parked lane stood on before its last step
+        if constexpr (FILTER) grid_walk_park_filter_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g, fc);
+        else grid_walk_park_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
+        VRT_PF_T(1, pf1);
+        VRT_PF_N(2, 1);
+        VRT_PF_N(3, n_walking);
+        VRT_PF_N(4, __builtin_popcountll(g.alive));
+        [[maybe_unused]] const unsigned long long pf2 = VRT_PF_NOW();
+        const bool was_walking = (walking >> lane) & 1ull;
+        const bool parked = __builtin_amdgcn_inverse_ballot_w64(g.parked);
+        const bool moving = __builtin_amdgcn_inverse_ballot_w64(g.alive);
+        if (was_walking && !parked && !moving) {
+            found = false; // left the box of the occupied cells
+            st = kLaneDone;
+        }
+        if (g.parked != 0ull) {
+            VRT_PF_N(5, 1);
+            VRT_PF_N(6, __builtin_popcountll(g.parked));
+            if (parked) {
+                int a = (int)(g.code & 3u);
+                const uint32_t out = (g.code >> 2) & 3u;
+                // the counters as they were on the occupied cell: undo the decrement of the step out of it
+                const int rx = w.rx + (out == 0u ? 1 : 0), ry = w.ry + (out == 1u ? 1 : 0), rz = w.rz + (out == 2u ? 1 : 0);
+                const int cx = base_x - __mul24(s.sx, rx), cy = base_y - __mul24(s.sy, ry), cz = base_z - __mul24(s.sz, rz); // cell position
+                const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min);  // comp:331
+                const float global_t_value = g.t_in * g_scale + s.grid_t_min + 0.01f * g_scale;          // comp:347 (deferred) + comp:332
+                hit.t = global_t_value;
+                const uint32_t brick_index = p.brick_index[cell]; // comp:337
+                const bool hit_voxel = brick_walk_gfx950<B, false>(p, r, s, g_scale, brick_index, brick_min, hit, a, hit_axis);
+                if (hit_voxel) {
+                    found = true;
+                    st = kLaneDone;
+                } else if (!(global_t_value <= t_max) || min3i(w.rx, w.ry, w.rz) < 0) {
+                    found = false; // t became NaN (comp:316), or the step out of this cell left the box
+                    st = kLaneDone;
+                } else {
+                    word = p.brick_status[grid_index >> 5]; // (an A-trip park left the lane's word in the other register set)
+                }
+            }
+        }
+        // every lane: the axis of its last step, for its first trip in the next call
+        g.code = parked ? ((g.code >> 2) & 3u) << 4
+                        : (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
+        VRT_PF_T(2, pf2);
+    }
+#ifdef VRT_DEV_PROFILE
+    if (p.wave_timeline && lane == 0u) {
+        for (int k = 0; k < 3; k++) atomicAdd(&p.wave_timeline[k], pf_t[k]);
+        for (int k = 0; k < 8; k++) atomicAdd(&p.wave_timeline[3 + k], pf_n[k]);
+        atomicAdd(&p.wave_timeline[11], 1ull);
+    }
+#endif
+#undef VRT_PF_T
+#undef VRT_PF_N
+#undef VRT_PF_NOW
+}
+
 // Builds the derived status structures from the uploaded brick_status words (binding 3):
 // out[0 .. nblocks)            one uint2 per 4x4x4 block of cells
 // out[nblocks ..) as u32 words  filter: bit b set iff block b has any occupied cell
@@ -1612,7 +2120,7 @@ static KernelFn pick_variant(uint32_t variant) {
     const uint32_t mode = variant & 0xFFu, mw = (variant >> 8) & 0xFFu;
     // (builds forced to 5, 7 or 8 waves per SIMD through __launch_bounds__ spilled and measured 6-21 % slower; they
     // are no longer instantiated)
-    if (mw != 0u && mw != (uint32_t)kDefaultMinWaves && mw != 8u) return nullptr;
+    if (mw != 0u && mw != (uint32_t)kDefaultMinWaves && mw != 8u && !(SHADE == 0 && !COUNT && mw == 5u)) return nullptr;
     // (the several-samples-per-pixel kernel, SHADE 1, needs 87 VGPRs left to itself = 5 waves per SIMD; held to 80 it spills
     // 36 bytes outside the loops and runs at 6: 4K / 1024^3 / 4 rays per pixel 1.215 -> 1.183 ms per frame)
     // (the bounce kernel, SHADE 0, takes 114 VGPRs = 4 waves per SIMD.  Its incoherent secondary rays wait on memory, and on a
@@ -1621,6 +2129,13 @@ static KernelFn pick_variant(uint32_t variant) {
     // bitmaps) the same build is 16 % SLOWER than the 4-wave one (0.518 against 0.447 ms, 1080p, 2 bounces), so both exist and
     // vrt_create asks for the 8-wave one (min_waves 8) by the size of bindings 3-5)
     if constexpr (SHADE == 0 && !COUNT) {
+        // frames with bounces: persistent lanes (vrt_path_kernel) unless the lockstep form is asked for (bit 21)
+        if (mode == kVariantLinearAlways && !(variant & kVariantLockstepBounce)) {
+            // bit 22: behind the LDS block filter (the library sets it when the grid allows); min_waves 5: 96 VGPRs
+            const bool filter = (variant & kVariantPathFilter) != 0u;
+            if (mw == 5u) return filter ? (KernelFn)vrt_path_kernel<B, 5, true> : (KernelFn)vrt_path_kernel<B, 5, false>;
+            return filter ? (KernelFn)vrt_path_kernel<B, kDefaultMinWaves, true> : (KernelFn)vrt_path_kernel<B, kDefaultMinWaves, false>;
+        }
         if (mw == 8u) return pick_mode<B, COUNT, 8, SHADE>(mode);
     }
     return pick_mode<B, COUNT, (SHADE == 1 && !COUNT) ? 6 : kDefaultMinWaves, SHADE>(mode);
@@ -1655,8 +2170,27 @@ size_t trace_lds_bytes(const TraceParams &p, uint32_t variant) {
     return 0;
 }
 
+bool is_path_kernel(KernelFn fn) {
+    return fn == (KernelFn)vrt_path_kernel<4, 4, false> || fn == (KernelFn)vrt_path_kernel<8, 4, false> || fn == (KernelFn)vrt_path_kernel<4, 5, false> ||
+           fn == (KernelFn)vrt_path_kernel<8, 5, false> || fn == (KernelFn)vrt_path_kernel<4, 4, true> || fn == (KernelFn)vrt_path_kernel<8, 4, true> ||
+           fn == (KernelFn)vrt_path_kernel<4, 5, true> || fn == (KernelFn)vrt_path_kernel<8, 5, true>;
+}
+static bool is_path_filter_kernel(KernelFn fn) {
+    return fn == (KernelFn)vrt_path_kernel<4, 4, true> || fn == (KernelFn)vrt_path_kernel<8, 4, true> || fn == (KernelFn)vrt_path_kernel<4, 5, true> ||
+           fn == (KernelFn)vrt_path_kernel<8, 5, true>;
+}
+
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream, uint32_t frames) {
     if (p.owned_tiles == 0 || frames == 0) return hipSuccess;
+    if (is_path_kernel(fn)) {
+        // persistent lanes: as many workgroups as the GPU holds a few times over; they take pixels from p.work_counter
+        if (!p.work_counter) return hipErrorInvalidValue;
+        hipError_t e = hipMemsetAsync(p.work_counter, 0, kMaxBatchFrames * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        const uint32_t groups = p.owned_tiles < p.path_groups ? p.owned_tiles : p.path_groups;
+        hipLaunchKernelGGL(fn, dim3(groups, frames), dim3(256), is_path_filter_kernel(fn) ? p.path_lds_bytes : 0u, stream, p);
+        return hipGetLastError();
+    }
     // grid.y = the frames of this launch (p.pcs[0 .. frames-1]); workgroups are dispatched x-fastest, so the tiles of
     // frame 0 start first
     if (p.block_threads == 512u) hipLaunchKernelGGL(fn, dim3((p.owned_tiles + 1u) / 2u, frames), dim3(512), lds_bytes, stream, p);
