@@ -472,3 +472,87 @@ def test_walk_ends_at_the_bounding_box_of_the_occupied_cells():
     check(rt, empty, (0.0, 0.0, 0.0), (1.0, 0.5, 3.0), "empty grid, camera inside")
     check(rt, empty, (0.0, -30.0, 0.0), (0.0, 0.0, 0.0), "empty grid, camera outside")
     rt.deinit()
+
+
+# ---- vrt_path_kernel (frames with bounces, persistent lanes): chosen by the library for scenes larger than the caches, forced
+# ---- here (kernel_variant bit 23) on small scenes so that whole frames can be compared with the oracle
+PATH = 1 << 23
+PATH_FILTER = PATH | (1 << 22)      # ... with the walk loop behind the LDS block filter (x, z dimensions powers of two)
+PATH_5WAVES = PATH | (5 << 8)
+
+
+@pytest.mark.parametrize("variant", [PATH, PATH_FILTER, PATH_5WAVES, PATH | (2 << 24), PATH_FILTER | (12 << 24)])
+@pytest.mark.parametrize("b", [4, 8])
+def test_path_kernel_stochastic_path_bit_exact(b, variant):
+    """The reference's default shading (2 samples, 2 bounces, soft sun) through the persistent-lane kernel, at several
+    batch thresholds; 250 x 131 is not a multiple of the tile size, so some fetched pixels lie outside the image."""
+    w = W.Workload("t", 250, 131, 128, b, 2, 2, True, 5.0)
+    grid = W.build_grid(w)
+    for view in ["V0", "V2"]:
+        f, u, c, pc = _run_hip(w, grid, view, variant=variant)
+        fo, uo, co = O.render(oracle_scene_from_grid(grid), pc)
+        _compare(f, u, c, fo, uo, co)
+
+
+@pytest.mark.parametrize("variant", [PATH, PATH_FILTER])
+def test_path_kernel_all_material_types_many_samples(variant):
+    """Glass, metal, lambertian and an unknown material type, 5 samples, 3 bounces, sparse allocation."""
+    from zig_vulkan_amd import BrickGrid, default_materials
+    mats = default_materials(256)
+    mats[1] = (7, 0.9, 0.2, 0.9, 1.0)
+    mats[2] = (2, 0.9, 0.9, 1.0, 1.52)
+    mats[3] = (1, 0.8, 0.8, 0.8, 0.05)
+    grid = BrickGrid(32, 32, 32, min_point=(-32, -32, -32), scale=2.0, brick_dimension=8, brick_alloc=9000)
+    grid.synth_sparse(7, 0.1)
+    w = W.Workload("t", 200, 120, 256, 8, 5, 3, True, 5.0, "sparse", 0.1, 9000)
+    rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, kernel_variant=variant)
+    rt.push_materials(mats)
+    for view in ["V1", "V1x"]:
+        W.set_view(rt, view)
+        rt.draw()
+        f, u, c = rt.read_rgba32f(), rt.read_rgba8(), rt.counters()
+        fo, uo, co = O.render(oracle_scene_from_grid(grid, mats), O.push_constants(rt.camera.blob(), rt.sun.blob()))
+        _compare(f, u, c, fo, uo, co)
+        assert co["hits"] > 0
+    rt.deinit()
+
+
+def test_path_kernel_sharded_context_and_two_frames_in_flight():
+    """A shard (rank 1 of 3) rendered by the path kernel holds the same packed tiles as the lockstep kernel's shard; and with
+    two frames in flight (two streams, one pixel counter each) every frame equals the single-stream frame."""
+    w = W.Workload("t", 208, 112, 128, 8, 2, 2, True, 5.0)
+    grid = W.build_grid(w)
+    shards = {}
+    for variant in (PATH, 1 << 21):
+        rt = W.make_renderer(w, grid, shard_rank=1, shard_count=3, kernel_variant=variant)
+        W.set_view(rt, "V2")
+        rt.draw()
+        shards[variant] = rt.read_rgba8().copy()
+        rt.deinit()
+    assert np.array_equal(shards[PATH], shards[1 << 21]) and shards[PATH].any()
+    one = W.make_renderer(w, grid, kernel_variant=PATH)
+    two = W.make_renderer(w, grid, kernel_variant=PATH, frames_in_flight=2)
+    for view in ["V0", "V2", "V1", "V2", "V0"]:
+        for rt in (one, two):
+            W.set_view(rt, view)
+            rt.draw()
+        assert np.array_equal(one.read_rgba8(), two.read_rgba8()), view
+    one.deinit()
+    two.deinit()
+
+
+def test_large_scene_takes_the_path_kernel_small_scene_the_lockstep_kernel():
+    """The library's choice (vrt_create): bindings 3-5 above 192 MiB -> persistent lanes.  Checked through the frame only: both
+    kernels must give the oracle's pixels, whichever runs (kernel names are not part of the ABI)."""
+    w = W.WORKLOADS["refapp_1024x576_512c_b4"]
+    grid = W.build_grid(w)
+    rt = W.make_renderer(w, grid, want_float_output=True)
+    W.set_view(rt, "V2")
+    rt.draw()
+    f, u = rt.read_rgba32f(), rt.read_rgba8()
+    pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+    rt.deinit()
+    rng = np.random.default_rng(3)
+    xy = np.stack([rng.integers(0, w.width, 6000), rng.integers(0, w.height, 6000)], axis=-1).astype(np.int32)
+    fo, uo, _ = O.render_pixels(oracle_scene_from_grid(grid), pc, xy)
+    assert np.array_equal(f[xy[:, 1], xy[:, 0]].view(np.uint32), fo.view(np.uint32)) and np.array_equal(u[xy[:, 1], xy[:, 0]], uo)

@@ -600,10 +600,9 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (((cfg->kernel_variant >> 8) & 0xFFu) == 0u &&
         c->dsize[VRT_BUF_BRICK_STATUS] + c->dsize[VRT_BUF_BRICK_INDEX] + c->dsize[VRT_BUF_BRICK_OCCUPANCY] > (192ull << 20))
         c->bounce_variant |= 8u << 8;
-    // (min_waves 5 exists for vrt_path_kernel only: the other kernels take their default)
     const uint32_t mwv = (cfg->kernel_variant >> 8) & 0xFFu;
-    const uint32_t single_variant = (mwv == 5u) ? (cfg->kernel_variant & ~0xFF00u) : cfg->kernel_variant;
-    const uint32_t lockstep_variant = ((mwv == 5u) ? (c->bounce_variant & ~0xFF00u) : c->bounce_variant) | vrt::kVariantLockstepBounce;
+    const uint32_t single_variant = cfg->kernel_variant;
+    const uint32_t lockstep_variant = c->bounce_variant | vrt::kVariantLockstepBounce; // (before the path kernel's occupancy is filled in below)
     {
         // vrt_path_kernel behind the LDS block filter: x and z dimensions powers of two >= 4, filter <= 32 KiB (so that four
         // workgroups per CU keep their copies), cell index < 2^31
@@ -618,8 +617,20 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         } else {
             c->bounce_variant &= ~vrt::kVariantPathFilter;
         }
-        // the path kernel runs at 4 waves per SIMD (100 VGPRs); the 8-wave choice above is the lockstep kernel's
-        if (!(c->bounce_variant & vrt::kVariantLockstepBounce) && ((c->bounce_variant >> 8) & 0xFFu) == 8u && mwv != 8u) c->bounce_variant &= ~0xFF00u;
+        // Which kernel traces frames with bounces.  Scenes whose traversal structures exceed the caches (the 8-wave criterion
+        // above): vrt_path_kernel at 5 waves per SIMD (96 VGPRs) — 4K / 2048^3 sparse / 16 spp / 3 bounces 193.6 ms per frame
+        // against 206 for the lockstep kernel at 8 waves, 50.7 against 62 from outside the grid.  Scenes that stay in the caches:
+        // the lockstep kernel — the reference app's shape (1024x576, 512^3 terrain, 2 spp, 2 bounces) 0.38 / 0.48 / 0.54 ms against
+        // 0.58 / 0.92 / 1.11 for the path kernel, whose waiting for batches of lanes costs more than the coherent rays lose.
+        // kernel_variant bit 21 forces the lockstep kernel, bit 23 the path kernel.
+        const bool big_scene = ((c->bounce_variant >> 8) & 0xFFu) == 8u && mwv == 0u;
+        const bool want_path = (cfg->kernel_variant & vrt::kVariantForcePath) || (big_scene && !(cfg->kernel_variant & vrt::kVariantLockstepBounce));
+        if (want_path) {
+            c->bounce_variant &= ~vrt::kVariantLockstepBounce;
+            if (mwv == 0u) c->bounce_variant = (c->bounce_variant & ~0xFF00u) | (5u << 8);
+        } else {
+            c->bounce_variant |= vrt::kVariantLockstepBounce;
+        }
     }
     c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->bounce_variant, 0);
     c->kernel_lockstep = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, lockstep_variant, 0);

@@ -118,8 +118,10 @@ enum : uint32_t {
     kVariantLinearAhead = 8,  // uncached status word, software-pipelined one cell ahead
     kVariantCount
 };
-// kernel_variant bit 21: frames with bounces run the lockstep kernel (vrt_trace_kernel<SHADE 0>) instead of vrt_path_kernel
+// frames with bounces: bit 21 forces the lockstep kernel (vrt_trace_kernel<SHADE 0>), bit 23 vrt_path_kernel (persistent lanes);
+// neither: the library chooses by the size of the scene (vrt_create)
 constexpr uint32_t kVariantLockstepBounce = 1u << 21;
+constexpr uint32_t kVariantForcePath = 1u << 23;
 // bit 22: vrt_path_kernel behind the LDS block filter (grids whose x and z dimensions are powers of two; measured slower, opt-in)
 constexpr uint32_t kVariantPathFilter = 1u << 22;
 

@@ -2120,7 +2120,8 @@ static KernelFn pick_variant(uint32_t variant) {
     const uint32_t mode = variant & 0xFFu, mw = (variant >> 8) & 0xFFu;
     // (builds forced to 5, 7 or 8 waves per SIMD through __launch_bounds__ spilled and measured 6-21 % slower; they
     // are no longer instantiated)
-    if (mw != 0u && mw != (uint32_t)kDefaultMinWaves && mw != 8u && !(SHADE == 0 && !COUNT && mw == 5u)) return nullptr;
+    // (min_waves 5 is vrt_path_kernel's: every other kernel reads it as its default)
+    if (mw != 0u && mw != (uint32_t)kDefaultMinWaves && mw != 8u && mw != 5u) return nullptr;
     // (the several-samples-per-pixel kernel, SHADE 1, needs 87 VGPRs left to itself = 5 waves per SIMD; held to 80 it spills
     // 36 bytes outside the loops and runs at 6: 4K / 1024^3 / 4 rays per pixel 1.215 -> 1.183 ms per frame)
     // (the bounce kernel, SHADE 0, takes 114 VGPRs = 4 waves per SIMD.  Its incoherent secondary rays wait on memory, and on a

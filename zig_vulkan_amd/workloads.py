@@ -42,6 +42,9 @@ WORKLOADS: Dict[str, Workload] = {
     # configs[4]: 3840x2160, 2048^3 sparse brickmap, 16 spp diffuse path trace
     "cfg4_4k_2048c_b8_sparse": Workload("cfg4_4k_2048c_b8_sparse", 3840, 2160, 2048, 8, 16, 2, True, 5.0, "sparse", 0.08,
                                         4_000_000),
+    # not a BASELINE config: the shape of the reference app's own default run (src/main.zig:23,77-81,122-135: 1024x576 internal
+    # resolution, 2 samples, max_bounce 2, sun on, 4^3 bricks), on the cubic synthetic terrain
+    "refapp_1024x576_512c_b4": Workload("refapp_1024x576_512c_b4", 1024, 576, 512, 4, 2, 2, True, 5.0),
 }
 
 HEADLINE = "cfg2_1080p_512c_b8"
