@@ -10,7 +10,7 @@
  * PARITY PINNED against the reference's own shader: the image holds Mesa 23.2.1 (llvmpipe), so
  * brick_raytracer.comp itself is compiled by Mesa's GLSL compiler and run on the host cores
  * (oracle/_ref, recipe oracle/ref_gl/recipe.py; the reference's own build — zig + a network-fetched
- * glslang + Vulkan — cannot run here).  Built with -DORACLE_LOWERING_LLVMPIPE (fma/dot/sin lowered as
+ * glslang + Vulkan — cannot run here).  Built with -DORACLE_LOWERING_LLVMPIPE (fma/dot lowered as
  * llvmpipe lowers them) this file reproduces the shader's frames BIT FOR BIT: the committed vectors
  * tests/golden/ref/ and random scenes (tests/test_ref_gl.py) — primary and shadow rays, soft sun,
  * several samples, bounces, every scatter function, 4^3 and 8^3 bricks.  The default build differs from
@@ -28,10 +28,9 @@
  *   - normalize(v)         -> v * (1.0f / sqrtf(dot(v,v)))
  *   - fract(x)             -> x - floorf(x)
  *   - reflect(I,N)         -> I - (2*dot(N,I))*N
- *   - sin(x)               -> vrt_sinf(x): double-precision Cody-Waite
- *                             reduction + fixed polynomial, specified below
- *                             (GLSL.std.450 Sin precision is implementation
- *                             defined; libm/ocml sinf differ from each other)
+ *   - sin(x)               -> vrt_sinf(x): the Cephes single-precision kernel as Mesa gallivm
+ *                             lowers it, specified below (GLSL.std.450 Sin precision is
+ *                             implementation defined; libm/ocml sinf differ from each other)
  *   - int(x)               -> (int)clamp(x, -2^31, 2147483520) (vrt_f2i; GLSL leaves the
  *                             out-of-range conversion undefined, C makes it UB)
  *   - Rgba8 imageStore     -> rintf(clamp(c,0,1)*255)
@@ -127,7 +126,7 @@ typedef struct {
  * -DORACLE_LOWERING_LLVMPIPE builds a second library, libvrt_oracle_llvmpipe.so, whose built-ins are lowered
  * exactly as Mesa 23.2.1 llvmpipe lowers them (measured through oracle/_ref, tests/test_ref_gl.py):
  *   fma(a,b,c) -> a*b + c with two roundings (nir lower_ffma32), dot(a,b) -> (a.z*b.z + a.y*b.y) + a.x*b.x
- *   (nir lower_fdot, reduction from the last channel), sin -> gallivm's lp_build_sin_or_cos polynomial.
+ *   (nir lower_fdot, reduction from the last channel); sin is gallivm's in both builds.
  * It exists for ONE purpose: to be compared with the reference shader run under llvmpipe (oracle/_ref) bit for
  * bit, which checks every statement of the restatement except the lowering rules themselves. */
 #ifdef ORACLE_LOWERING_LLVMPIPE
@@ -167,16 +166,15 @@ static inline int32_t vrt_f2i(float x) {
     return (int32_t)fminf(fmaxf(x, -2147483648.0f), 2147483520.0f);
 }
 
-/* sin(x) by specification: k = rint(x*2/pi) in double, r = x - k*pi/2 with a
- * two-constant Cody-Waite subtraction in double (fma), then degree-13/12 Taylor
- * polynomials in double evaluated by Horner with fma, rounded once to float.
- * Identical operation sequence in zig_vulkan_amd/csrc/vrt_math.h. */
-#ifdef ORACLE_LOWERING_LLVMPIPE
-/* Mesa gallivm's sine (src/gallium/auxiliary/gallivm/lp_bld_arit.c, lp_build_sin_or_cos — the Cephes / sse_mathfun
- * single-precision kernel): |x| scaled by 4/pi, j = (int(y) + 1) & ~1, three-constant Cody-Waite reduction, one of
- * two polynomials by bit 1 of j, sign from x's sign xor bit 2 of j, clamp to [-1, 1], NaN for non-finite input.
- * ORACLE_FMULADD is how llvm.fmuladd comes out of LLVM's x86 back end on an FMA-capable host: fused. */
-#define ORACLE_FMULADD(a, b, c) fmaf((a), (b), (c))
+/* sin(x) by specification — GLSL.std.450 Sin has implementation-defined precision, and libm, ocml and every GPU differ.
+ * The specified algorithm is the Cephes / sse_mathfun single-precision kernel exactly as Mesa's gallivm lowers GLSL sin
+ * (src/gallium/auxiliary/gallivm/lp_bld_arit.c, lp_build_sin_or_cos), i.e. what the reference shader computes when it
+ * runs under llvmpipe: |x| scaled by 4/pi, j = (int(y) + 1) & ~1, three-constant Cody-Waite reduction, one of two
+ * polynomials by bit 1 of j, sign from x's sign xor bit 2 of j, clamp to [-1, 1], NaN for non-finite input; every
+ * multiply-add of it fused (how llvm.fmuladd comes out on an FMA host).  About 30 binary32 operations; absolute error
+ * <= 1.2e-7 for |x| <= 8192 (tests/test_oracle_kat.py).  Round 1 specified a binary64 evaluation rounded once: three times
+ * the instructions at half rate on the GPU, 12-15 % of the cycles of a wave that shades hits.
+ * Identical operation sequence in zig_vulkan_amd/csrc/vrt_math.h; bit-identical to llvmpipe's sin (tests/test_ref_gl.py). */
 static inline float vrt_sinf(float a) {
     uint32_t ai; memcpy(&ai, &a, 4);
     uint32_t absi = ai & 0x7fffffffu;
@@ -190,20 +188,20 @@ static inline float vrt_sinf(float a) {
     const float y = (float)(int32_t)emm2_and;
     const uint32_t sign_bit = (ai ^ (emm2_add << 29)) & 0x80000000u;
     const int use_sin_poly = (emm2_and & 2u) == 0;
-    x = ORACLE_FMULADD(y, -0.78515625f, x);
-    x = ORACLE_FMULADD(y, -2.4187564849853515625e-4f, x);
-    x = ORACLE_FMULADD(y, -3.77489497744594108e-8f, x);
+    x = fmaf(y, -0.78515625f, x);
+    x = fmaf(y, -2.4187564849853515625e-4f, x);
+    x = fmaf(y, -3.77489497744594108e-8f, x);
     const float z = x * x;
-    float yc = ORACLE_FMULADD(z, 2.443315711809948E-005f, -1.388731625493765E-003f);
-    yc = ORACLE_FMULADD(yc, z, 4.166664568298827E-002f);
+    float yc = fmaf(z, 2.443315711809948E-005f, -1.388731625493765E-003f);
+    yc = fmaf(yc, z, 4.166664568298827E-002f);
     yc = yc * z;
     yc = yc * z;
     yc = yc - z * 0.5f;
     yc = yc + 1.0f;
-    float ys = ORACLE_FMULADD(z, -1.9515295891E-4f, 8.3321608736E-3f);
-    ys = ORACLE_FMULADD(ys, z, -1.6666654611E-1f);
+    float ys = fmaf(z, -1.9515295891E-4f, 8.3321608736E-3f);
+    ys = fmaf(ys, z, -1.6666654611E-1f);
     ys = ys * z;
-    ys = ORACLE_FMULADD(ys, x, x);
+    ys = fmaf(ys, x, x);
     float r = use_sin_poly ? ys : yc;
     uint32_t ri; memcpy(&ri, &r, 4);
     ri ^= sign_bit;
@@ -212,40 +210,6 @@ static inline float vrt_sinf(float a) {
     r = (r > 1.0f) ? 1.0f : r;
     return r;
 }
-#else
-static inline float vrt_sinf(float xf) {
-    const double x = (double)xf;
-    const double kd = rint(x * 0.63661977236758134308);
-    double r = fma(-kd, 1.57079632673412561417e+00, x);
-    r = fma(-kd, 6.07710050650619224932e-11, r);
-    /* |kd| >= 2^62 (or NaN): quadrant is meaningless; pin it to 0 so the conversion is defined */
-    const int64_t k = (fabs(kd) < 4611686018427387904.0) ? (int64_t)kd : 0;
-    const double r2 = r * r;
-    double ps = -1.0 / 6227020800.0;
-    ps = fma(ps, r2, 1.0 / 39916800.0);
-    ps = fma(ps, r2, -1.0 / 362880.0);
-    ps = fma(ps, r2, 1.0 / 5040.0);
-    ps = fma(ps, r2, -1.0 / 120.0);
-    ps = fma(ps, r2, 1.0 / 6.0);
-    ps = ps * r2;
-    const double s = fma(-ps, r, r); /* r - r^3/6 + ... */
-    double pc = 1.0 / 479001600.0;
-    pc = fma(pc, r2, -1.0 / 3628800.0);
-    pc = fma(pc, r2, 1.0 / 40320.0);
-    pc = fma(pc, r2, -1.0 / 720.0);
-    pc = fma(pc, r2, 1.0 / 24.0);
-    pc = fma(pc, r2, -0.5);
-    const double c = fma(pc, r2, 1.0);
-    double res;
-    switch ((int)(k & 3)) {
-        case 0: res = s; break;
-        case 1: res = c; break;
-        case 2: res = -s; break;
-        default: res = -c; break;
-    }
-    return (float)res;
-}
-#endif
 
 /* ---------------------------------------------------------------- rand.comp */
 /* rand.comp:3 */

@@ -41,19 +41,23 @@ def test_hash12_zero_and_independent_restatement():
         assert L.oracle_hash12(px, py) == np_hash12(px, py)
 
 
-def test_specified_sin_is_within_one_ulp_of_true_sine():
+def test_specified_sin_is_the_cephes_single_precision_kernel():
+    """sin is specified (GLSL leaves its precision open): the Cephes / sse_mathfun kernel as Mesa gallivm lowers GLSL sin.
+    Accuracy: absolute error <= 1.2e-7 where its three-constant reduction holds (|x| <= 8192), a few 1e-7 up to the
+    arguments the shader's RNG produces; exact zeros and symmetry; NaN for non-finite input.  (Bit-equality with llvmpipe's
+    own sin is measured in tests/test_ref_gl.py.)"""
     L = O.lib()
     rng = np.random.default_rng(2)
-    xs = np.concatenate([rng.uniform(-4, 4, 3000), rng.uniform(-2e5, 2e5, 3000), [0.0, 1e-8, math.pi, -math.pi / 2]]).astype(np.float32)
-    exact_match = 0
-    for x in xs:
-        got = f32(L.oracle_sinf(x))
-        want = f32(math.sin(float(x)))  # double sin of the float input, rounded
-        ulp = np.spacing(np.abs(want)) if want != 0 else f32(1e-45)
-        assert abs(float(got) - float(want)) <= float(ulp), (x, got, want)
-        exact_match += got == want
-    assert exact_match > 0.99 * len(xs)
+    small = np.concatenate([rng.uniform(-4, 4, 3000), rng.uniform(-8192, 8192, 3000), [0.0, 1e-8, math.pi, -math.pi / 2]]).astype(np.float32)
+    for x in small:
+        assert abs(float(L.oracle_sinf(x)) - math.sin(float(x))) <= 1.2e-7, x
+    for x in rng.uniform(-2e5, 2e5, 3000).astype(np.float32):
+        assert abs(float(L.oracle_sinf(x)) - math.sin(float(x))) <= 2e-5, x
     assert L.oracle_sinf(0.0) == 0.0
+    for x in (0.5, 3.0, 100.25, 54321.0):
+        assert L.oracle_sinf(-x) == -L.oracle_sinf(x)
+    assert math.isnan(L.oracle_sinf(float("inf"))) and math.isnan(L.oracle_sinf(float("nan")))
+    assert -1.0 <= L.oracle_sinf(3.0e38) <= 1.0
 
 
 def test_rand_is_fract_of_sine_product():

@@ -9,7 +9,7 @@
 //   normalize(v)  = v * (1 / sqrt(dot(v,v)))         (IEEE divide and sqrt)
 //   fract(x)      = x - floor(x)
 //   reflect(I,N)  = I - (2*dot(N,I))*N
-//   sin(x)        = vrt_sin (f64 Cody-Waite reduction + fixed f64 polynomial)
+//   sin(x)        = vrt_sin (the Cephes single-precision kernel as Mesa gallivm lowers it, fused multiply-adds)
 //   int(x)        = (int)clamp(x, -2^31, 2147483520)  (f2i_clamp)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -54,32 +54,41 @@ VRT_DI int f2i_clamp(float x) {
     return (int)__builtin_fminf(__builtin_fmaxf(x, -2147483648.0f), 2147483520.0f);
 }
 
-// sin by specification (same sequence as the parity oracle's restatement).
-VRT_DI float vrt_sin(float xf) {
-    const double x = (double)xf;
-    const double kd = __builtin_rint(x * 0.63661977236758134308);
-    double r = __builtin_fma(-kd, 1.57079632673412561417e+00, x);
-    r = __builtin_fma(-kd, 6.07710050650619224932e-11, r);
-    const long long k = (__builtin_fabs(kd) < 4611686018427387904.0) ? (long long)kd : 0ll;
-    const double r2 = r * r;
-    double ps = -1.0 / 6227020800.0;
-    ps = __builtin_fma(ps, r2, 1.0 / 39916800.0);
-    ps = __builtin_fma(ps, r2, -1.0 / 362880.0);
-    ps = __builtin_fma(ps, r2, 1.0 / 5040.0);
-    ps = __builtin_fma(ps, r2, -1.0 / 120.0);
-    ps = __builtin_fma(ps, r2, 1.0 / 6.0);
-    ps = ps * r2;
-    const double s = __builtin_fma(-ps, r, r);
-    double pc = 1.0 / 479001600.0;
-    pc = __builtin_fma(pc, r2, -1.0 / 3628800.0);
-    pc = __builtin_fma(pc, r2, 1.0 / 40320.0);
-    pc = __builtin_fma(pc, r2, -1.0 / 720.0);
-    pc = __builtin_fma(pc, r2, 1.0 / 24.0);
-    pc = __builtin_fma(pc, r2, -0.5);
-    const double c = __builtin_fma(pc, r2, 1.0);
-    const int q = (int)(k & 3);
-    const double res = (q == 0) ? s : ((q == 1) ? c : ((q == 2) ? -s : -c));
-    return (float)res;
+// sin by specification (same operation sequence as the parity oracle's restatement): the Cephes /
+// sse_mathfun single-precision kernel as Mesa's gallivm lowers GLSL sin — what the reference shader computes under
+// llvmpipe — with every multiply-add fused.  ~30 binary32 operations (round 1's binary64 evaluation was ~75 at half rate:
+// 12-15 % of the cycles of a wave that shades hits).
+VRT_DI float vrt_sin(float a) {
+    const uint32_t ai = __builtin_bit_cast(uint32_t, a);
+    float x = __builtin_bit_cast(float, ai & 0x7fffffffu);
+    const bool finite = x < __builtin_inff();
+    const float scale_y = x * 1.27323954473516f;
+    // float -> int32 by truncation; 0x80000000 beyond the int range (the x86 conversion the reference run uses)
+    const int emm2_i = (scale_y < 2147483648.0f) ? (int)scale_y : (int)0x80000000;
+    const uint32_t emm2_add = (uint32_t)emm2_i + 1u;
+    const uint32_t emm2_and = emm2_add & ~1u;
+    const float y = (float)(int)emm2_and;
+    const uint32_t sign_bit = (ai ^ (emm2_add << 29)) & 0x80000000u;
+    const bool use_sin_poly = (emm2_and & 2u) == 0u;
+    x = __builtin_fmaf(y, -0.78515625f, x);
+    x = __builtin_fmaf(y, -2.4187564849853515625e-4f, x);
+    x = __builtin_fmaf(y, -3.77489497744594108e-8f, x);
+    const float z = x * x;
+    float yc = __builtin_fmaf(z, 2.443315711809948E-005f, -1.388731625493765E-003f);
+    yc = __builtin_fmaf(yc, z, 4.166664568298827E-002f);
+    yc = yc * z;
+    yc = yc * z;
+    yc = yc - z * 0.5f;
+    yc = yc + 1.0f;
+    float ys = __builtin_fmaf(z, -1.9515295891E-4f, 8.3321608736E-3f);
+    ys = __builtin_fmaf(ys, z, -1.6666654611E-1f);
+    ys = ys * z;
+    ys = __builtin_fmaf(ys, x, x);
+    float r = use_sin_poly ? ys : yc;
+    r = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, r) ^ sign_bit);
+    r = (r < -1.0f) ? -1.0f : r;
+    r = (r > 1.0f) ? 1.0f : r;
+    return finite ? r : __builtin_nanf("");
 }
 
 // ---- rand.comp (assets/shaders/rand.comp:3-26) -----------------------------
