@@ -153,6 +153,7 @@ def pmc_child(args) -> None:
 
 
 def _pmc_read(dirs, kernel_substr: str):
+    """kernel_substr: the brick dimension (first template argument of the product kernels)."""
     import glob
     import sqlite3
     out = {}
@@ -160,7 +161,7 @@ def _pmc_read(dirs, kernel_substr: str):
         for f in sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)):
             db = sqlite3.connect(f)
             for c, v, n in db.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like ? "
-                                      "group by counter_name", (f"%{kernel_substr}%",)):
+                                      "or kernel_name like ? group by counter_name", (f"%vrt_trace_kernel<{kernel_substr}, false%", f"%vrt_path_kernel<{kernel_substr},%")):
                 out[c] = v
                 out["_dispatches"] = n
     return out
@@ -190,7 +191,7 @@ def pmc_live(args, w):
             if r.returncode != 0:
                 return None, f"rocprofv3 pass {group} exited {r.returncode}: {r.stdout.decode(errors='replace')[-300:]}"
             dirs.append(d)
-        c = _pmc_read(dirs, f"vrt_trace_kernel<{w.brick_dimension}, false")
+        c = _pmc_read(dirs, str(w.brick_dimension))   # the product kernel: vrt_trace_kernel<B, false, ...> or vrt_path_kernel<B, ...>
         if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             return None, "rocprofv3 ran but the traversal kernel's counters were not found"
         return c, (f"measured in this run: {len(PMC_PASSES)} rocprofv3 --pmc passes over {int(c.get('_dispatches', 0))} launches of the product "

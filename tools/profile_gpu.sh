@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 300 --warmup 30 --no-cpu-baseline $*"
+BENCH="python $ROOT/bench.py --steps 300 --warmup 30 --no-cpu-baseline --pmc off --frames-in-flight 1 $*"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 # PMC passes, each in its own run, kernel-trace only
 i=0
@@ -20,3 +20,4 @@ done
 cd $ROOT
 python tools/summarize_prof.py $OUT $OUT/pmc.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+rm -rf $OUT/stats $OUT/pmc[0-9]   # the rocpd databases are large (gpurun copies back at most 64 MiB); the summaries are what is kept

@@ -34,7 +34,7 @@ if os.path.exists(log):
         if not line or not line.get("roofline"):
             break
         db = sqlite3.connect(f)
-        d = [r[0] / 1e3 for r in db.execute("select duration from kernels where name like '%vrt_trace_kernel<%, false,%' order by start")]
+        d = [r[0] / 1e3 for r in db.execute("select duration from kernels where name like '%vrt_trace_kernel<%, false,%' or name like '%vrt_path_kernel<%' order by start")]
         steps, warmup = line["steps"], line["warmup"]
         views = line["config"]["views"] + line["config"].get("views_reported_only", [])
         settle = line["roofline"]["settle_frames"]
