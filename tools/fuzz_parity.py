@@ -2,7 +2,8 @@
 """Randomised parity fuzz (usage: fuzz_parity.py [cases] [seed] [big]): random small grids (odd dimensions, both brick sizes, any
 scale, sparse allocation), random materials incl. glass / metal / unknown types, random cameras inside and outside the
 box, samples 1-3, bounces 0-2, sun on/off with and without jitter — product kernel against the oracle, whole frames,
-float target bit for bit.  The committed tests pin chosen cases; this looks for the ones nobody chose."""
+float target bit for bit.  The committed tests pin chosen cases; this looks for the ones nobody chose.  A mismatching case is
+dumped whole (seven buffers, push constants, both frames) to gpurun_out/fuzz_fail_seed<seed>_case<case>.npz."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,7 +39,8 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True) -> int:
         sun_on, radius = bool(rng.random() < 0.7), float(rng.choice([0.0, 5.0, 40.0]))
         rt = VoxelRT(grid, Config(internal_resolution_width=w, internal_resolution_height=h, camera=CameraConfig(samples_per_pixel=spp, max_bounce=bounce),
                                   sun=SunConfig(enabled=sun_on, radius=radius), want_float_output=True,
-                                  kernel_variant=int(rng.choice([0, 0, 6, 1, 0x10070000, 0x10070000])) if big else 0))
+                                  kernel_variant=int(rng.choice([0, 0, 6, 1, 0x10070000, 0x10070000, 1 << 23, (1 << 23) | (1 << 22), (1 << 23) | (5 << 8), (1 << 23) | (2 << 24)])) if big
+                                  else int(rng.choice([0, 0, 1 << 23]))))
         rt.push_materials(mats)
         size = np.array(dims) * scale
         centre = np.array(min_point) + 0.5 * size
@@ -59,6 +61,15 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True) -> int:
         ok = np.array_equal(f.view(np.uint32)[~both_nan], fo.view(np.uint32)[~both_nan]) and np.array_equal(u, uo)
         if not ok:
             bad += 1
+            # the whole case, for a bit-level post-mortem off the box (an unexplained mismatch must leave its inputs)
+            out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+            os.makedirs(out_dir, exist_ok=True)
+            sc = oracle_scene_from_grid(grid, mats)
+            np.savez_compressed(os.path.join(out_dir, f"fuzz_fail_seed{seed}_case{case}.npz"), kernel=np.array(name), brick_dimension=np.int32(b),
+                                grid_state=sc.grid_state, materials=sc.materials.view(np.uint8).reshape(-1), brick_status=sc.brick_status,
+                                brick_index=sc.brick_index, brick_occupancy=sc.brick_occupancy, brick_start_index=sc.brick_start_index,
+                                material_index=sc.material_index, push_constants=pc, hip_rgba32f=f, oracle_rgba32f=fo, hip_rgba8=u, oracle_rgba8=uo,
+                                kernel_variant=np.int64(rt.config.kernel_variant))
             du = np.argwhere(u != uo)
             db = np.argwhere((f.view(np.uint32) != fo.view(np.uint32)) & ~both_nan)
             print(f"   float bits differ at {len(db)} places, first {[(i.tolist(), float(f[tuple(i)]), float(fo[tuple(i)]), hex(int(f.view(np.uint32)[tuple(i)])), hex(int(fo.view(np.uint32)[tuple(i)]))) for i in db[:4]]}")
