@@ -46,6 +46,8 @@ class GlRef:
             L.glref_buffers_set.argtypes = _bufs + _bufs
             L.glref_ubo_update.argtypes = [C.c_int, C.c_void_p, C.c_int64]
             L.glref_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+            L.glref_compile_raster.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+            L.glref_present.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
             L.glref_dispatch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                          C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
@@ -67,6 +69,21 @@ class GlRef:
         if prog <= 0:
             raise RuntimeError("Mesa GLSL compiler: " + self._err())
         return prog
+
+    def compile_raster(self, vertex: str, fragment: str) -> int:
+        v, f = vertex.encode(), fragment.encode()
+        prog = self.L.glref_compile_raster(v, len(v), f, len(f))
+        if prog <= 0:
+            raise RuntimeError("Mesa GLSL compiler: " + self._err())
+        return prog
+
+    def present(self, prog: int, image_rgba8: np.ndarray, out_w: int, out_h: int, ubo: np.ndarray) -> np.ndarray:
+        img = np.ascontiguousarray(image_rgba8, dtype=np.uint8)
+        ubo = np.ascontiguousarray(ubo)
+        out = np.zeros((out_h, out_w, 4), dtype=np.float32)
+        if self.L.glref_present(prog, img.ctypes.data, img.shape[1], img.shape[0], 0, ubo.ctypes.data, ubo.nbytes, out_w, out_h, out.ctypes.data) != 0:
+            raise RuntimeError(self._err())
+        return out
 
     def save_binary(self, prog: int, path: str) -> None:
         n = self.L.glref_get_binary(prog, None, 0, None)
@@ -211,6 +228,30 @@ class ReferenceShader:
         self.gl.clear_buffers()
 
 
+class ReferencePresent:
+    """The reference's present / denoise pass (image.vert + image.frag) as built by recipe.py: one fullscreen quad into an
+    out_w x out_h float target, sampling the traced RGBA8 image with a linear / repeat sampler."""
+
+    def __init__(self):
+        self.gl = GlRef()
+        if os.path.exists(recipe.PRESENT_BINARY):
+            try:
+                self.prog = self.gl.load_binary(recipe.PRESENT_BINARY)
+                return
+            except RuntimeError:
+                if not recipe.reference_available():
+                    raise
+        if not recipe.reference_available():
+            raise GlRefUnavailable(f"{recipe.PRESENT_BINARY} missing and /root/reference absent")
+        self.prog = self.gl.compile_raster(*recipe.present_dialect())
+
+    def render(self, image_rgba8: np.ndarray, out_w: int, out_h: int, samples: int = 20, distribution_bias: float = 0.6,
+               pixel_multiplier: float = 1.5, inverse_hue_tolerance: float = 20.0) -> np.ndarray:
+        pc = np.zeros(1, dtype=np.dtype([("samples", np.int32), ("b", np.float32), ("m", np.float32), ("t", np.float32)]))
+        pc[0] = (samples, distribution_bias, pixel_multiplier, inverse_hue_tolerance)   # GraphicsPipeline.PushConstant, GraphicsPipeline.zig:27-32
+        return self.gl.present(self.prog, image_rgba8, out_w, out_h, pc.view(np.uint8))
+
+
 def available() -> Optional[str]:
     """None when the reference shader can be run here, else the reason."""
     try:
@@ -221,4 +262,6 @@ def available() -> Optional[str]:
         return None
     missing = [recipe.binary_path(b, f) for b in recipe.BRICK_DIMENSIONS for f in recipe.FORMATS
                if not os.path.exists(recipe.binary_path(b, f))]
+    if not os.path.exists(recipe.PRESENT_BINARY):
+        missing.append(recipe.PRESENT_BINARY)
     return ("missing " + ", ".join(os.path.basename(m) for m in missing)) if missing else None

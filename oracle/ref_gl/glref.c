@@ -89,6 +89,23 @@ GLFN(void, glPixelStorei, GLenum, GLint);
 GLFN(void, glDispatchCompute, GLuint, GLuint, GLuint);
 GLFN(void, glMemoryBarrier, GLbitfield);
 GLFN(void, glFinish, void);
+GLFN(void, glGenVertexArrays, GLsizei, GLuint *);
+GLFN(void, glDeleteVertexArrays, GLsizei, const GLuint *);
+GLFN(void, glBindVertexArray, GLuint);
+GLFN(void, glVertexAttribPointer, GLuint, GLint, GLenum, GLboolean, GLsizei, const void *);
+GLFN(void, glEnableVertexAttribArray, GLuint);
+GLFN(void, glGenFramebuffers, GLsizei, GLuint *);
+GLFN(void, glDeleteFramebuffers, GLsizei, const GLuint *);
+GLFN(void, glBindFramebuffer, GLenum, GLuint);
+GLFN(void, glFramebufferTexture2D, GLenum, GLenum, GLenum, GLuint, GLint);
+GLFN(GLenum, glCheckFramebufferStatus, GLenum);
+GLFN(void, glViewport, GLint, GLint, GLsizei, GLsizei);
+GLFN(void, glDrawArrays, GLenum, GLint, GLsizei);
+GLFN(void, glReadPixels, GLint, GLint, GLsizei, GLsizei, GLenum, GLenum, void *);
+GLFN(void, glTexSubImage2D, GLenum, GLint, GLint, GLint, GLsizei, GLsizei, GLenum, GLenum, const void *);
+GLFN(void, glTexParameteri, GLenum, GLenum, GLint);
+GLFN(void, glActiveTexture, GLenum);
+GLFN(void, glDisable, GLenum);
 
 GLREF_API const char *glref_last_error(void) { return g_err; }
 
@@ -100,6 +117,9 @@ static int fail(const char *fmt, const char *arg) {
 /* Creates the llvmpipe GL 4.5 core context (idempotent).  0 on success. */
 GLREF_API int glref_init(void) {
     if (g_ready) return 0;
+    /* llvmpipe filters 8-bit textures with 8-bit fixed-point weights unless told otherwise; the present pass is compared at
+       1e-4, so ask for its float path (a documented gallivm switch; harmless for the compute shader) */
+    setenv("GALLIVM_PERF", "no_aos_sampling", 0);
     const char *paths[] = {"/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so", "swrast_dri.so", NULL};
     void *drv = NULL;
     for (int i = 0; paths[i] && !drv; i++) drv = dlopen(paths[i], RTLD_NOW | RTLD_GLOBAL);
@@ -134,6 +154,9 @@ GLREF_API int glref_init(void) {
     LOAD(glBufferData); LOAD(glBufferSubData); LOAD(glGetBufferSubData); LOAD(glBindBufferBase); LOAD(glGenTextures);
     LOAD(glDeleteTextures); LOAD(glBindTexture); LOAD(glTexStorage2D); LOAD(glBindImageTexture); LOAD(glGetTexImage);
     LOAD(glPixelStorei); LOAD(glDispatchCompute); LOAD(glMemoryBarrier); LOAD(glFinish);
+    LOAD(glGenVertexArrays); LOAD(glDeleteVertexArrays); LOAD(glBindVertexArray); LOAD(glVertexAttribPointer); LOAD(glEnableVertexAttribArray);
+    LOAD(glGenFramebuffers); LOAD(glDeleteFramebuffers); LOAD(glBindFramebuffer); LOAD(glFramebufferTexture2D); LOAD(glCheckFramebufferStatus);
+    LOAD(glViewport); LOAD(glDrawArrays); LOAD(glReadPixels); LOAD(glTexSubImage2D); LOAD(glTexParameteri); LOAD(glActiveTexture); LOAD(glDisable);
 #undef LOAD
     g_ready = 1;
     return 0;
@@ -176,6 +199,107 @@ GLREF_API int glref_compile(const char *src, int len) {
         return fail("link: %s", log);
     }
     return (int)prog;
+}
+
+/* Compiles + links a vertex and a fragment shader (the reference's image.vert / image.frag).  Program name or -1. */
+GLREF_API int glref_compile_raster(const char *vs, int vs_len, const char *fs, int fs_len) {
+    if (!g_ready) return fail("%s", "glref_init not called");
+    GLuint prog = p_glCreateProgram();
+    p_glProgramParameteri(prog, GL_PROGRAM_BINARY_RETRIEVABLE_HINT, GL_TRUE);
+    const char *srcs[2] = {vs, fs};
+    const GLint lens[2] = {vs_len, fs_len};
+    const GLenum kinds[2] = {GL_VERTEX_SHADER, GL_FRAGMENT_SHADER};
+    for (int i = 0; i < 2; i++) {
+        GLuint sh = p_glCreateShader(kinds[i]);
+        p_glShaderSource(sh, 1, &srcs[i], &lens[i]);
+        p_glCompileShader(sh);
+        GLint ok = 0;
+        p_glGetShaderiv(sh, GL_COMPILE_STATUS, &ok);
+        if (!ok) {
+            char log[3800] = {0};
+            p_glGetShaderInfoLog(sh, sizeof log - 1, NULL, log);
+            p_glDeleteShader(sh);
+            p_glDeleteProgram(prog);
+            return fail(i ? "fragment shader: %s" : "vertex shader: %s", log);
+        }
+        p_glAttachShader(prog, sh);
+        p_glDeleteShader(sh);
+    }
+    p_glLinkProgram(prog);
+    GLint ok = 0;
+    p_glGetProgramiv(prog, GL_LINK_STATUS, &ok);
+    if (!ok) {
+        char log[3800] = {0};
+        p_glGetProgramInfoLog(prog, sizeof log - 1, NULL, log);
+        p_glDeleteProgram(prog);
+        return fail("link: %s", log);
+    }
+    return (int)prog;
+}
+
+/* The reference's present pass: one fullscreen quad (two triangles; attribute 0 = vec3 position, 1 = vec2 uv, as
+ * image.vert declares them) drawn into an out_w x out_h RGBA32F target, sampling an RGBA8 UNORM image of img_w x img_h
+ * through texture unit 0 with the reference's sampler state (linear min / mag, repeat; Pipeline.zig:194-211).  `ubo` goes to
+ * uniform binding `ubo_binding` (the push constants).  uv (0,0) is placed at the first row / column of BOTH the sampled image
+ * and `out`, so rows of `out` run top to bottom like the traced image's.  0 on success. */
+GLREF_API int glref_present(int prog, const void *img_rgba8, int img_w, int img_h, int ubo_binding, const void *ubo, int64_t ubo_bytes, int out_w,
+                            int out_h, float *out_rgba32f) {
+    if (!g_ready) return fail("%s", "glref_init not called");
+    while (p_glGetError() != GL_NO_ERROR) {}
+    GLuint tex[2], fbo, vao, buf[2];
+    p_glGenTextures(2, tex);
+    p_glActiveTexture(GL_TEXTURE0);
+    p_glBindTexture(GL_TEXTURE_2D, tex[0]);
+    p_glTexStorage2D(GL_TEXTURE_2D, 1, GL_RGBA8, img_w, img_h);
+    p_glPixelStorei(GL_UNPACK_ALIGNMENT, 1);
+    p_glTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, img_w, img_h, GL_RGBA, GL_UNSIGNED_BYTE, img_rgba8);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_LINEAR);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_LINEAR);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_REPEAT);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_REPEAT);
+    p_glBindTexture(GL_TEXTURE_2D, tex[1]);
+    p_glTexStorage2D(GL_TEXTURE_2D, 1, GL_RGBA32F, out_w, out_h);
+    p_glGenFramebuffers(1, &fbo);
+    p_glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+    p_glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, tex[1], 0);
+    if (p_glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) return fail("%s", "framebuffer incomplete");
+    p_glBindTexture(GL_TEXTURE_2D, tex[0]);
+    /* x, y, z, u, v: framebuffer row 0 (NDC y = -1) gets v = 0 */
+    static const float quad[6][5] = {{-1, -1, 0, 0, 0}, {1, -1, 0, 1, 0}, {1, 1, 0, 1, 1}, {-1, -1, 0, 0, 0}, {1, 1, 0, 1, 1}, {-1, 1, 0, 0, 1}};
+    p_glGenVertexArrays(1, &vao);
+    p_glBindVertexArray(vao);
+    p_glGenBuffers(2, buf);
+    p_glBindBuffer(GL_ARRAY_BUFFER, buf[0]);
+    p_glBufferData(GL_ARRAY_BUFFER, sizeof quad, quad, GL_STATIC_DRAW);
+    p_glVertexAttribPointer(0, 3, GL_FLOAT, GL_FALSE, 5 * sizeof(float), (const void *)0);
+    p_glVertexAttribPointer(1, 2, GL_FLOAT, GL_FALSE, 5 * sizeof(float), (const void *)(3 * sizeof(float)));
+    p_glEnableVertexAttribArray(0);
+    p_glEnableVertexAttribArray(1);
+    p_glBindBuffer(GL_UNIFORM_BUFFER, buf[1]);
+    p_glBufferData(GL_UNIFORM_BUFFER, (GLsizeiptr)ubo_bytes, ubo, GL_STATIC_DRAW);
+    p_glBindBufferBase(GL_UNIFORM_BUFFER, (GLuint)ubo_binding, buf[1]);
+    p_glViewport(0, 0, out_w, out_h);
+    p_glDisable(GL_DEPTH_TEST);
+    p_glDisable(GL_BLEND);
+    p_glDisable(GL_CULL_FACE);
+    p_glUseProgram((GLuint)prog);
+    p_glDrawArrays(GL_TRIANGLES, 0, 6);
+    p_glFinish();
+    p_glPixelStorei(GL_PACK_ALIGNMENT, 1);
+    p_glReadPixels(0, 0, out_w, out_h, GL_RGBA, GL_FLOAT, out_rgba32f);
+    GLenum e = p_glGetError();
+    p_glUseProgram(0);
+    p_glBindFramebuffer(GL_FRAMEBUFFER, 0);
+    p_glBindVertexArray(0);
+    p_glDeleteVertexArrays(1, &vao);
+    p_glDeleteBuffers(2, buf);
+    p_glDeleteFramebuffers(1, &fbo);
+    p_glDeleteTextures(2, tex);
+    if (e != GL_NO_ERROR) {
+        snprintf(g_err, sizeof g_err, "GL error 0x%x during the present pass", e);
+        return -1;
+    }
+    return 0;
 }
 
 /* Mesa's program binary (serialised NIR + metadata; loadable by the same Mesa build only).

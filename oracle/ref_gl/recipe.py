@@ -11,7 +11,8 @@ What it does
   2. reads /root/reference/assets/shaders/brick_raytracer.comp and rand.comp WHERE THEY LIE, applies the dialect
      edits below IN MEMORY (the text is never written to disk), has Mesa 23.2.1's GLSL compiler compile it, and
      stores Mesa's program binary (serialised NIR — no source text) as oracle/_ref/brick_raytracer.b<B>.<fmt>.glbin
-     for B in {4, 8} and fmt in {rgba8, rgba32f}.  oracle/_ref/ is git-ignored and travels to the GPU box, where the
+     for B in {4, 8} and fmt in {rgba8, rgba32f}; likewise image.vert + image.frag (the present / denoise pass) as
+     oracle/_ref/image_present.glbin.  oracle/_ref/ is git-ignored and travels to the GPU box, where the
      same image holds the same Mesa build, so the binaries load there without /root/reference.
 
 Why edits are needed at all: the shader is Vulkan GLSL (built by the reference through a network-fetched glslang
@@ -108,6 +109,21 @@ def opengl_dialect(brick_dimension: int, fmt: str) -> str:
     return src
 
 
+def present_dialect():
+    """(vertex, fragment) text of the reference's present pass, image.vert / image.frag (assets/shaders), for OpenGL: the ONE
+    edit is E5 (`layout (push_constant) uniform PushConstant` -> `layout (std140, binding = 0) uniform PushConstant`: int,
+    float, float, float at offsets 0, 4, 8, 12 either way).  In memory only."""
+    with open(os.path.join(REFERENCE_SHADERS, "image.vert")) as fh:
+        vs = fh.read()
+    with open(os.path.join(REFERENCE_SHADERS, "image.frag")) as fh:
+        fs = fh.read()
+    fs = _sub_once(r"layout \(push_constant\) uniform", "layout (std140, binding = 0) uniform", fs, "E5 image.frag")
+    return vs, fs
+
+
+PRESENT_BINARY = os.path.join(REF_DIR, "image_present.glbin")
+
+
 def binary_path(brick_dimension: int, fmt: str) -> str:
     return os.path.join(REF_DIR, f"brick_raytracer.b{brick_dimension}.{fmt}.glbin")
 
@@ -128,6 +144,11 @@ def build(force: bool = False) -> None:
             prog = gl.compile(opengl_dialect(b, fmt))
             gl.save_binary(prog, out)
             gl.delete(prog)
+    present_mtime = max(os.path.getmtime(os.path.join(REFERENCE_SHADERS, f)) for f in ("image.vert", "image.frag"))
+    if force or not os.path.exists(PRESENT_BINARY) or os.path.getmtime(PRESENT_BINARY) < max(present_mtime, os.path.getmtime(__file__)):
+        prog = gl.compile_raster(*present_dialect())
+        gl.save_binary(prog, PRESENT_BINARY)
+        gl.delete(prog)
 
 
 if __name__ == "__main__":

@@ -84,5 +84,33 @@ def main():
         print(f"{name}: {w.width}x{w.height}, oracle(llvmpipe lowering) bit-equal: {same}")
 
 
+# The present / denoise pass (image.vert + image.frag of the reference, same route): input = the RGBA8 frame the reference's
+# compute shader produced (a fixture above), output = the float colour of the fullscreen pass at two window sizes.
+PRESENT_CASES = {
+    "present_path_b4_160x90": ("path_b4_spp3_b2_V2", (160, 90), {}),
+    "present_path_b4_200x120": ("path_b4_spp3_b2_V2", (200, 120), {}),
+    "present_shadow_b8_160x90_s12": ("shadow_b8_r0_V2", (160, 90), dict(samples=12, pixel_multiplier=2.0)),   # hard shadows: black texels -> NaN
+}
+
+
+def main_present():
+    from oracle.ref_gl import ReferencePresent
+    rp = ReferencePresent()
+    info = GlRef().info()
+    for name, (src, (ow, oh), kw) in PRESENT_CASES.items():
+        img = np.load(os.path.join(OUT, src + ".npz"))["rgba8"]
+        f = rp.render(img, ow, oh, **kw)
+        fo, _ = O.denoise(img, ow, oh, **kw)
+        ok = ~np.isnan(f[..., :3])
+        np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                            provenance=np.array(f"image.vert + image.frag of /root/reference (edit E5 of oracle/ref_gl/recipe.py), {info}, GALLIVM_PERF=no_aos_sampling"),
+                            image_rgba8=img, out_size=np.array([ow, oh]),
+                            params=np.array([kw.get("samples", 20), kw.get("distribution_bias", 0.6), kw.get("pixel_multiplier", 1.5),
+                                             kw.get("inverse_hue_tolerance", 20.0)], dtype=np.float64),
+                            rgb32f=np.ascontiguousarray(f[:, :, :3]))
+        print(f"{name}: max |reference - denoise oracle| = {np.abs(f[..., :3][ok] - fo[..., :3][ok]).max():.3g}, NaN pixels {int((~ok).any(axis=2).sum())}")
+
+
 if __name__ == "__main__":
     main()
+    main_present()

@@ -4,11 +4,11 @@ tests/golden/ref/*.npz hold frames that /root/reference/assets/shaders/brick_ray
 23.2.1 compiled it and llvmpipe ran it (oracle/_ref; made by tests/golden/make_ref_golden.py).  Three layers:
 
   1. fixtures (always run, CPU): oracle/vrt_oracle.c built with llvmpipe's lowering of the GLSL built-ins
-     (fma unfused, dot from the last channel, gallivm's sine, two algebraic rewrites in hash12) reproduces every
+     (fma unfused, dot from the last channel, two algebraic rewrites in hash12) reproduces every
      fixture BIT FOR BIT — float colour and RGBA8.  That checks every statement of the restatement: ray
      generation, sample jitter, both DDA levels, shadow rays, soft sun, all scatter functions, the RNG, tone-map.
-  2. the oracle proper ("hw" lowering: fused fma, dot as an fma chain, correctly rounded sine — what the HIP
-     kernel matches bit for bit) against the same fixtures within north_star's 1e-4 per channel.  Two conforming
+  2. the oracle proper ("hw" lowering: fused fma, dot as an fma chain — what the HIP kernel matches bit for bit;
+     sin is gallivm's in both builds) against the same fixtures within north_star's 1e-4 per channel.  Two conforming
      GLSL implementations differ in the last bits of fma / dot; a last-bit difference flips a DDA tie or a hit /
      miss at isolated pixels, and flips the sin-hash RNG wholesale.  So: deterministic fixtures must agree within
      1e-4 on all but a stated handful of pixels; stochastic ones (soft sun, bounces) are compared as images
@@ -28,7 +28,9 @@ import pytest
 from oracle import oracle as O
 from oracle import ref_gl
 
-FIXTURES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref", "*.npz")))
+_ALL = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref", "*.npz")))
+FIXTURES = [p for p in _ALL if not os.path.basename(p).startswith("present_")]
+PRESENT = [p for p in _ALL if os.path.basename(p).startswith("present_")]
 IDS = [os.path.basename(p)[:-4] for p in FIXTURES]
 TOL = 1e-4                     # north_star: "within 1e-4 per channel"
 # fixtures whose pixels do not depend on sin(): primary rays, hard-sun shadow rays, 1 sample
@@ -223,3 +225,70 @@ def test_hip_against_reference_shader_fixture(path):
     assert np.array_equal(f.view(np.uint32), fo.view(np.uint32)) and np.array_equal(u, uo)
     # ... and within north_star's tolerance of what the reference shader itself produced
     _compare_hw_lowering(os.path.basename(path), f, u, z)
+
+
+# ---------------------------------------------------------------------------------------------- the present / denoise pass
+# tests/golden/ref/present_*.npz: image.vert + image.frag of the reference through the same llvmpipe route (one dialect
+# edit: push constants -> std140 block).  pow() and the bilinear filter are implementation-defined, so this pass is held to
+# north_star's 1e-4, not to bit equality; and a tap whose four texels are black is exactly 0 -> normalize() = NaN only if the
+# filter weights are exactly 0 / 1, which llvmpipe's coordinate arithmetic and ours decide differently at a handful of pixels.
+PRESENT_IDS = [os.path.basename(p)[:-4] for p in PRESENT]
+
+
+def _present_args(z):
+    p = z["params"]
+    return dict(samples=int(p[0]), distribution_bias=float(p[1]), pixel_multiplier=float(p[2]), inverse_hue_tolerance=float(p[3]))
+
+
+def _compare_present(f, z):
+    ref = z["rgb32f"]
+    nan_ref, nan_got = np.isnan(ref).any(axis=2), np.isnan(f[..., :3]).any(axis=2)
+    black = int((z["image_rgba8"][..., :3] == 0).all(axis=2).sum())
+    assert int((nan_ref != nan_got).sum()) <= black          # NaN only ever comes from black texels
+    both = ~nan_ref & ~nan_got
+    assert both.mean() > 0.99
+    assert float(np.abs(f[..., :3][both] - ref[both]).max()) <= TOL
+
+
+def test_present_fixtures_present():
+    assert len(PRESENT) >= 3
+
+
+@pytest.mark.parametrize("path", PRESENT, ids=PRESENT_IDS)
+def test_denoise_oracle_within_tolerance_of_reference_fragment_shader(path):
+    z = np.load(path)
+    ow, oh = (int(v) for v in z["out_size"])
+    f, _ = O.denoise(z["image_rgba8"], ow, oh, **_present_args(z))
+    _compare_present(f, z)
+
+
+@live
+@pytest.mark.parametrize("path", PRESENT, ids=PRESENT_IDS)
+def test_live_reference_fragment_shader_reproduces_fixture(path):
+    z = np.load(path)
+    ow, oh = (int(v) for v in z["out_size"])
+    f = ref_gl.ReferencePresent().render(z["image_rgba8"], ow, oh, **_present_args(z))
+    assert np.array_equal(np.isnan(f[..., :3]), np.isnan(z["rgb32f"]))
+    ok = ~np.isnan(z["rgb32f"])
+    assert np.array_equal(f[..., :3][ok].view(np.uint32), z["rgb32f"][ok].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", PRESENT, ids=PRESENT_IDS)
+def test_hip_denoise_within_tolerance_of_reference_fragment_shader(path):
+    """vrt_denoise over the fixture's image (set as the context's target through the ABI) against the reference's frame."""
+    import ctypes as C
+    import torch
+    from zig_vulkan_amd import BrickGrid, Config, VoxelRT
+    z = np.load(path)
+    img = np.ascontiguousarray(z["image_rgba8"])
+    h, w = img.shape[:2]
+    ow, oh = (int(v) for v in z["out_size"])
+    dev = torch.from_numpy(img.reshape(-1)).cuda()
+    grid = BrickGrid(1, 1, 1)
+    rt = VoxelRT(grid, Config(internal_resolution_width=w, internal_resolution_height=h, external_target_rgba8=dev.data_ptr()))
+    a = _present_args(z)
+    u, f = rt.denoise(ow, oh, samples=a["samples"], distribution_bias=a["distribution_bias"], pixel_multiplier=a["pixel_multiplier"],
+                      inverse_hue_tolerance=a["inverse_hue_tolerance"], want_float=True)
+    rt.deinit()
+    _compare_present(f, z)
