@@ -647,7 +647,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         static const char *const mode_names[] = {"?", "linear-status+byte-occupancy", "blocked-status", "blocked-status+lds-filter", "linear-status+wide-occupancy", "linear-status-uncached", "linear-status-in-lds", "linear-status-in-lds(512-thread groups)", "linear-status-one-cell-ahead"};
         const uint32_t rv = vrt::resolve_variant(cfg->kernel_variant);
         std::snprintf(buf, sizeof buf, "vrt_trace_kernel<B=%u,COUNT=%d,%s,minwaves=%u>", cfg->brick_dimension, cfg->enable_counters ? 1 : 0,
-                      mode_names[rv & 0xFFu], ((rv >> 8) & 0xFFu) ? ((rv >> 8) & 0xFFu) : 4u);
+                      mode_names[rv & 0xFFu], ((rv >> 8) & 0xFFu) ? ((rv >> 8) & 0xFFu) : 4u); // (as asked; the library's own choices: DESIGN.md §4)
         c->kernel_name = buf;
     }
 

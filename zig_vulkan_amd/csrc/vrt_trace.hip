@@ -2121,7 +2121,15 @@ static KernelFn pick_variant(uint32_t variant) {
     // (builds forced to 5, 7 or 8 waves per SIMD through __launch_bounds__ spilled and measured 6-21 % slower; they
     // are no longer instantiated)
     // (min_waves 5 is vrt_path_kernel's: every other kernel reads it as its default)
-    if (mw != 0u && mw != (uint32_t)kDefaultMinWaves && mw != 8u && mw != 5u) return nullptr;
+    if (mw != 0u && mw != (uint32_t)kDefaultMinWaves && mw != 8u && mw != 5u && mw != 7u) return nullptr;
+    if constexpr (SHADE == 2 && !COUNT) {
+        // the one-sample, no-bounce kernel (the headline's) is held to 72 VGPRs = 7 waves per SIMD (4 registers spilled outside the
+        // loops): on frames that keep the GPU full it is 1.5-2 % faster than at its natural 75 VGPRs = 6 waves (1080p / 512^3 / V1, V2:
+        // 0.132 -> 0.130, 0.134 -> 0.131 ms; `value` 25.1 -> 25.7 Grays/s), on a tail-bound frame (V1x) 4 % slower.  min_waves 4 asks
+        // for the natural build.
+        if (mw == 0u || mw == 7u) return pick_mode<B, COUNT, 7, SHADE>(mode);
+        if (mw == 8u) return pick_mode<B, COUNT, 8, SHADE>(mode); // tuning build: 64 VGPRs
+    }
     // (the several-samples-per-pixel kernel, SHADE 1, needs 87 VGPRs left to itself = 5 waves per SIMD; held to 80 it spills
     // 36 bytes outside the loops and runs at 6: 4K / 1024^3 / 4 rays per pixel 1.215 -> 1.183 ms per frame)
     // (the bounce kernel, SHADE 0, takes 114 VGPRs = 4 waves per SIMD.  Its incoherent secondary rays wait on memory, and on a
