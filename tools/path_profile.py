@@ -14,7 +14,9 @@ rt = W.make_renderer(w, grid, kernel_variant=variant)
 rc = W.make_renderer(w, grid, kernel_variant=variant, enable_counters=True)
 W.set_view(rt, view); W.set_view(rc, view)
 rt.draw(2); rt.wait()
-pr = rt.wave_timeline(raw=True).reshape(-1)[:12].astype(float)
+raw = rt.wave_timeline(raw=True).reshape(-1).astype(float)
+pr = raw[:12]
+bw = raw[12:20]
 ms = rt.last_kernel_ms()
 rc.draw(); c = rc.counters()
 t_trans, t_walk, t_brick = pr[0:3]
@@ -28,3 +30,5 @@ print(f"  walk loop: {n_calls/1e6:.2f} M calls, {n_alive_in/n_calls:.1f} lanes a
       f"lane-trips {c['grid_steps']/1e6:.0f} M -> {c['grid_steps']/n_calls:.1f} lane-trips per call")
 print(f"  bricks: {n_brick/1e6:.2f} M rounds, {n_parked/n_brick:.1f} parked lanes per round, {t_brick/n_brick:.0f} cycles per round")
 rt.deinit(); rc.deinit()
+print(f"  inside the brick rounds (wave-cycles, share of all): voxel loops {100*bw[2]/tot:.1f} %, material test + hit record {100*bw[4]/tot:.1f} %, "
+      f"rest of the round (cell -> brick index -> first occupancy word, walk set-up) {100*(t_brick-bw[2]-bw[4])/tot:.1f} %")

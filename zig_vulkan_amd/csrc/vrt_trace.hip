@@ -359,59 +359,77 @@ struct GridParkRegs {
 #define VRT_IN_FROM(MX, MY) "v_cndmask_b32_e64 %[t0], 2, 1, %[" MY "]\n\t" "v_cndmask_b32_e64 %[t0], %[t0], 0, %[" MX "]\n\t"
 #define VRT_SWAP_SETS "v_swap_b32 %[tsa], %[tsb]\n\t" "v_swap_b32 %[idxa], %[idxb]\n\t"
 
+#define VRT_PARK_WALK_ASM(LIMIT) \
+        "s_mov_b64 %[save], exec\n\t" \
+        "s_mov_b64 exec, %[alive]\n\t" \
+        "s_mov_b64 %[parked], 0\n\t" \
+        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, VRT_LOAD_BUFFER, "10f") \
+        "0:\n\t" \
+        VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, VRT_LOAD_BUFFER, "11f") \
+        "21:\n\t" \
+        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, VRT_LOAD_BUFFER, "12f") \
+        "22:\n\t" \
+        VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, VRT_LOAD_BUFFER, "13f") \
+        "23:\n\t" \
+        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, VRT_LOAD_BUFFER, "14f") \
+        "24:\n\t" \
+        "s_cbranch_execz 31f\n\t" \
+        /* back edge (after an A trip): keep walking while at least min_alive lanes are moving; fewer -> hand the wave back \
+           so that the finished lanes can be given new rays (vrt_path_kernel; min_alive = 0: never) */ \
+        "s_bcnt1_i32_b64 %[n], exec\n\t" \
+        "s_cmp_ge_u32 %[n], %[minalive]\n\t" \
+        "s_cbranch_scc1 0b\n\t" \
+        "s_branch 30f\n\t" \
+        VRT_PARK("10", VRT_IN_FROM_CODE, "mxa", "mya", VRT_SWAP_SETS, "0b", "30f") \
+        VRT_PARK("11", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "21b", "31f") \
+        VRT_PARK("12", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "22b", "30f") \
+        VRT_PARK("13", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "23b", "31f") \
+        VRT_PARK("14", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "24b", "30f") \
+        "30:\n\t" /* the last trip was an A trip: swap the sets of the lanes still moving */ \
+        "s_mov_b64 %[alive], exec\n\t" \
+        VRT_WAIT_BUFFER \
+        VRT_SWAP_SETS \
+        "v_mov_b32_e32 %[worda], %[wordb]\n\t" \
+        "s_mov_b64 %[mxb], %[mxa]\n\t" \
+        "s_mov_b64 %[myb], %[mya]\n\t" \
+        "s_branch 32f\n\t" \
+        "31:\n\t" \
+        "s_mov_b64 %[alive], exec\n\t" \
+        VRT_WAIT_BUFFER /* the compiler may move `word`: no load may be in flight outside */ \
+        "32:\n\t" \
+        "s_mov_b64 exec, %[save]"
+#define VRT_PARK_WALK_OPERANDS                                                                                                                   \
+    [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),          \
+        [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(word), [wordb] "=&v"(wordb), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in),              \
+        [code] "+v"(g.code), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive),    \
+        [mxa] "=&s"(mxa), [mya] "=&s"(mya), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz),              \
+        [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n)
+#define VRT_PARK_WALK_INPUTS                                                                                                                          \
+    [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z), [rsrc] "s"(rsrc), \
+        [batch] "s"(g.batch), [minalive] "s"(g.min_alive)
+
 VRT_DI void grid_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
                                   uint32_t &word, u32x4 rsrc, GridParkRegs &g) {
     unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb, n;
-    asm volatile(
-        "s_mov_b64 %[save], exec\n\t"
-        "s_mov_b64 exec, %[alive]\n\t"
-        "s_mov_b64 %[parked], 0\n\t"
-        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", VRT_NO_LIMIT, VRT_LOAD_BUFFER, "10f")
-        "0:\n\t"
-        VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", VRT_NO_LIMIT, VRT_LOAD_BUFFER, "11f")
-        "21:\n\t"
-        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", VRT_NO_LIMIT, VRT_LOAD_BUFFER, "12f")
-        "22:\n\t"
-        VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", VRT_NO_LIMIT, VRT_LOAD_BUFFER, "13f")
-        "23:\n\t"
-        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", VRT_NO_LIMIT, VRT_LOAD_BUFFER, "14f")
-        "24:\n\t"
-        "s_cbranch_execz 31f\n\t"
-        /* back edge (after an A trip): keep walking while at least min_alive lanes are moving; fewer -> hand the wave back
-           so that the finished lanes can be given new rays (vrt_path_kernel; min_alive = 0: never) */
-        "s_bcnt1_i32_b64 %[n], exec\n\t"
-        "s_cmp_ge_u32 %[n], %[minalive]\n\t"
-        "s_cbranch_scc1 0b\n\t"
-        "s_branch 30f\n\t"
-        VRT_PARK("10", VRT_IN_FROM_CODE, "mxa", "mya", VRT_SWAP_SETS, "0b", "30f")
-        VRT_PARK("11", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "21b", "31f")
-        VRT_PARK("12", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "22b", "30f")
-        VRT_PARK("13", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "23b", "31f")
-        VRT_PARK("14", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "24b", "30f")
-        "30:\n\t" /* the last trip was an A trip: swap the sets of the lanes still moving */
-        "s_mov_b64 %[alive], exec\n\t"
-        VRT_WAIT_BUFFER
-        VRT_SWAP_SETS
-        "v_mov_b32_e32 %[worda], %[wordb]\n\t"
-        "s_mov_b64 %[mxb], %[mxa]\n\t"
-        "s_mov_b64 %[myb], %[mya]\n\t"
-        "s_branch 32f\n\t"
-        "31:\n\t"
-        "s_mov_b64 %[alive], exec\n\t"
-        VRT_WAIT_BUFFER /* the compiler may move `word`: no load may be in flight outside */
-        "32:\n\t"
-        "s_mov_b64 exec, %[save]"
-        : [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),
-          [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(word), [wordb] "=&v"(wordb), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in),
-          [code] "+v"(g.code), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive),
-          [mxa] "=&s"(mxa), [mya] "=&s"(mya), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz),
-          [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n)
-        : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z), [rsrc] "s"(rsrc),
-          [batch] "s"(g.batch), [minalive] "s"(g.min_alive)
-        : "vcc", "scc");
+    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS : "vcc", "scc");
 }
+
+// The voxel level on the same park loop (vrt_path_kernel): voxels of one brick, bits of brick_occupancy by their global bit
+// index; `scale`, `t_max` as in the loop condition comp:469.  A lane that has left a SOLID voxel behind is parked; the call
+// returns when nobody is moving (batch 64, min_alive 0), so that the material test behind it (three dependent cache misses on a
+// scene larger than the caches) runs ONCE for all the lanes of the round instead of once per lane that finds a voxel.
+VRT_DI void voxel_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
+                                   uint32_t &word, u32x4 rsrc, GridParkRegs &g, float scale, float t_max) {
+    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
+    float t0, t1, t2;
+    uint32_t wordb, n;
+    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
+}
+#undef VRT_PARK_WALK_ASM
+#undef VRT_PARK_WALK_OPERANDS
+#undef VRT_PARK_WALK_INPUTS
 // ---- the park loop behind a block filter in LDS (vrt_path_kernel) ----------------------------------------------------
 // A wave-wide status request of INCOHERENT rays touches one 128-byte line per lane, and the L1 takes about one line
 // per cycle per CU: with 54 lanes walking, a trip of the loop above costs ~700 cycles per wave at 4 waves per SIMD
@@ -789,6 +807,86 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
         }
         asm("s_andn2_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(found)) : "scc");
         first = false;
+    }
+    return found;
+}
+
+// comp:378-471 for vrt_path_kernel: the same per-lane operations as brick_walk_gfx950 on the voxel-level PARK loop.  Lanes that
+// have left a solid voxel behind wait (parked) until no lane of the round is moving; then the material test (comp:422-427) is made
+// for all of them at once — on a scene larger than the caches it is three dependent cache misses (start index -> material id ->
+// material), and brick_walk_gfx950 pays them once per lane that finds a voxel (22 % of the wave-cycles of the 2048^3 path trace,
+// tools/path_profile.py).  A lane whose voxel is to be ignored (comp:427) walks on in the next pass.
+template <int B>
+VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t brick_index, f3 brick_min, Hit &hit,
+                                   int axis_in, int &hit_axis) {
+    const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
+    const float voxel_scale = g_scale * brick_voxel_scale;
+    const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
+    Walk w;
+    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
+    const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
+    const int py = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
+    const int pz = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
+    constexpr int kZeroBudget = 3 * B + 8;
+    w.rx = steps_left(s.sx, px, B, kZeroBudget);
+    w.ry = steps_left(s.sy, py, B, kZeroBudget);
+    w.rz = steps_left(s.sz, pz, B, kZeroBudget);
+    w.t_value = 0;
+    const float local_t_max = s.grid_t_max - hit.t;
+    const uint32_t base = brick_index * (uint32_t)(B * B * B);
+    uint32_t bit_index = base + ((uint32_t)px + (uint32_t)B * ((uint32_t)pz + (uint32_t)B * (uint32_t)py));
+    const uint32_t stride_x = (uint32_t)s.sx, stride_y = (uint32_t)(s.sy * (B * B)), stride_z = (uint32_t)(s.sz * B);
+    const bool more = more_init(px, py, pz, B) && (0.0f <= local_t_max); // comp:409 with t_value = 0
+
+    const unsigned long long occ_addr = (unsigned long long)p.brick_occupancy;
+    u32x4 rsrc;
+    rsrc.x = (uint32_t)occ_addr;
+    rsrc.y = (uint32_t)(occ_addr >> 32) | (4u << 16);
+    rsrc.z = p.occupancy_words;
+    rsrc.w = 0x00020000u;
+    const uint32_t *occ_words = reinterpret_cast<const uint32_t *>(p.brick_occupancy);
+    uint32_t word = occ_words[more ? (bit_index >> 5) : 0u];
+    GridParkRegs g;
+    g.alive = __builtin_amdgcn_ballot_w64(more);
+    g.out_x = 0ull;
+    g.out_y = 0ull;
+    g.t_out = 0.0f;
+    g.t_in = 0.0f;
+    g.code = 3u << 4; // the first voxel of the walk was entered through the brick's face, not by a step of this walk
+    g.batch = 64u;
+    g.min_alive = 0u;
+    bool found = false;
+    while (g.alive != 0ull) {
+        uint32_t solid_bit; // parked lanes: bit index of the solid voxel they left behind
+        voxel_walk_park_gfx950(w, s.inv_dir, bit_index, solid_bit, stride_x, stride_y, stride_z, word, rsrc, g, voxel_scale, local_t_max);
+        if (g.parked == 0ull) break; // every lane has left the brick (or the grid box)
+        const bool parked = __builtin_amdgcn_inverse_ballot_w64(g.parked);
+        bool resume = false;
+        if (parked) {
+            const uint32_t voxel_index = solid_bit - base;
+            const uint32_t brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu; // comp:422
+            const uint32_t mi = p.material_index[brick_material_index + voxel_index];
+            const vrt_material *m = p.materials + mi;
+            const uint32_t mtype = m->type;
+            const float mdata = m->type_data;
+            const bool ignore_brick = (mtype == r.ignore_type_material) && (r.internal_reflection == mdata); // comp:427
+            if (!ignore_brick) {
+                const uint32_t in = g.code & 3u;
+                hit.index = mi;
+                const float t_offset = voxel_scale * 0.05f;
+                hit.t += g.t_in * voxel_scale - t_offset; // t_value of the step into this voxel (comp:442), 0 for the first
+                hit_axis = (in == 3u) ? axis_in : (int)in;
+                found = true;
+            } else {
+                // walk on: the lane has already taken the step out of the ignored voxel; comp:409 for that step
+                resume = min3i(w.rx, w.ry, w.rz) >= 0 && (voxel_scale * g.t_out <= local_t_max);
+            }
+        }
+        // every lane: the axis of its last step, for its first trip in the next call
+        g.code = parked ? ((g.code >> 2) & 3u) << 4
+                        : (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
+        if (resume) word = occ_words[bit_index >> 5]; // (an A-trip park left the lane's word in the other register set)
+        asm("s_or_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(resume)) : "scc");
     }
     return found;
 }
@@ -1541,6 +1639,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TracePar
 
     bool work_left = true; // wave-uniform
 #ifdef VRT_DEV_PROFILE
+    if (threadIdx.x < 8) vrt_prof[threadIdx.x] = 0ull; // (the brick walk's own phase hooks; static LDS: not with FILTER)
+    __syncthreads();
     // development-only (make EXTRA=-DVRT_DEV_PROFILE, tools/path_profile.py): cycles and lane counts per phase, per wave
     unsigned long long pf_t[3] = {0ull, 0ull, 0ull};      // cycles in transitions / walk loop / bricks
     unsigned long long pf_n[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; // rounds: transitions, waiting lanes; walk calls, alive lanes at entry,
@@ -1776,7 +1876,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TracePar
                 const float global_t_value = g.t_in * g_scale + s.grid_t_min + 0.01f * g_scale;          // comp:347 (deferred) + comp:332
                 hit.t = global_t_value;
                 const uint32_t brick_index = p.brick_index[cell]; // comp:337
-                const bool hit_voxel = brick_walk_gfx950<B, false>(p, r, s, g_scale, brick_index, brick_min, hit, a, hit_axis);
+                const bool hit_voxel = brick_walk_park_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, a, hit_axis);
                 if (hit_voxel) {
                     found = true;
                     st = kLaneDone;
@@ -1799,6 +1899,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TracePar
         for (int k = 0; k < 8; k++) atomicAdd(&p.wave_timeline[3 + k], pf_n[k]);
         atomicAdd(&p.wave_timeline[11], 1ull);
     }
+    __syncthreads();
+    if (p.wave_timeline && threadIdx.x < 8) atomicAdd(&p.wave_timeline[12 + threadIdx.x], vrt_prof[threadIdx.x]);
 #endif
 #undef VRT_PF_T
 #undef VRT_PF_N
