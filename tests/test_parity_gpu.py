@@ -38,7 +38,7 @@ def _compare(f, u, c, fo, uo, co):
 
 
 @pytest.mark.parametrize("view", ["V0", "V1", "V2"])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 0x10002, 0x20003, 0x30001, 0x60001, 0x140001])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 0x70009, 0x10002, 0x20003, 0x30001, 0x60001, 0x140001])
 def test_config0_primary_rays(view, variant):
     w = W.WORKLOADS["cfg0_256x256_64c_b4"]
     grid = W.build_grid(w)

@@ -33,6 +33,7 @@ hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t 
 hipError_t launch_assemble_rgb(const void *gathered, void *frame, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t shard_count,
                                uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream, uint32_t frames, uint32_t frame_src_stride_bytes);
 hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
+hipError_t launch_build_status_bytes(const TraceParams &p, hipStream_t stream);
 hipError_t launch_build_cell_bounds(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
                           void *out_f32, hipStream_t stream);
@@ -151,6 +152,7 @@ struct vrt_ctx {
     uint32_t sched_period = 0, sched_since = 0, sched_cur = 0;
     bool order_auto = false; // kernel_variant left the tile order to the library
     uint32_t bounce_variant = 0; // kernel_variant with the occupancy choice of the bounce kernel filled in
+    uint32_t single_variant = 0; // kernel_variant with the library's choice of mode for frames without bounces filled in
     uint32_t tile_order = 0, sched_extra = 0, sched_stride = 0, wave_slots = 0;
     uint64_t sched_seq = 0, b_seen_sched = 0;
     hipEvent_t ev_sched = nullptr, ev_b_sched = nullptr;
@@ -161,6 +163,7 @@ struct vrt_ctx {
     hipStream_t denoised_stream = nullptr;
     void *d_status_blocks = nullptr; // derived: 4x4x4 block words + block filter (vrt_trace.hip)
     int *d_cell_bounds = nullptr;    // derived: bounding box of the occupied cells (TraceParams::cell_bounds)
+    uint8_t *d_status_bytes = nullptr; // derived: one byte per grid cell (TraceParams::status_bytes)
     vrt::TileOwnership own{};        // weighted tile ownership (period 0: tile t belongs to rank t % shard_count)
     bool status_dirty = true;        // brick_status changed since the derived copy was built
     size_t lds_bytes = 0;
@@ -226,6 +229,7 @@ void free_ctx(vrt_ctx *c) {
     if (c->d_work_counter) (void)hipFree(c->d_work_counter);
     if (c->d_status_blocks) (void)hipFree(c->d_status_blocks);
     if (c->d_cell_bounds) (void)hipFree(c->d_cell_bounds);
+    if (c->d_status_bytes) (void)hipFree(c->d_status_bytes);
     if (c->dist) {
         Dist *d = c->dist;
         for (uint32_t i = 0; i < d->nslots; i++) {
@@ -555,6 +559,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_cell_bounds), 6 * sizeof(int)));
     VRT_CREATE_HIP(hipMemsetAsync(c->d_cell_bounds, 0x80, 6 * sizeof(int), c->stream)); // no cell occupied yet
     {
+        const size_t status_bytes_size = (size_t)((cells + 31u) / 32u) * 32u + 64u; // 32 bytes per status word
+        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_status_bytes), status_bytes_size));
+        VRT_CREATE_HIP(hipMemsetAsync(c->d_status_bytes, 0, status_bytes_size, c->stream));
+    }
+    {
         // tile schedule starts as reverse raster (bottom rows first); the feedback kernel refines it
         const uint32_t n = sh.owned_tiles ? sh.owned_tiles : 1u;
         int cus = 0;
@@ -601,7 +610,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         c->dsize[VRT_BUF_BRICK_STATUS] + c->dsize[VRT_BUF_BRICK_INDEX] + c->dsize[VRT_BUF_BRICK_OCCUPANCY] > (192ull << 20))
         c->bounce_variant |= 8u << 8;
     const uint32_t mwv = (cfg->kernel_variant >> 8) & 0xFFu;
-    const uint32_t single_variant = cfg->kernel_variant;
+    // Frames without bounces, mode left to the library: the hand-written loops on the byte-per-cell copy of the status bits for
+    // grids up to 64^3 cells (1080p / 512^3 / 8^3 bricks V1, V2: 0.122 -> 0.118 ms, 1080p / 256^3 / 4^3: 0.098 -> 0.095; a tail-bound
+    // frame from outside the grid pays 5 % for the larger footprint), the words beyond (128^3 cells: -4 % inside, +9 ... +22 % outside)
+    const uint32_t single_variant = ((cfg->kernel_variant & 0xFFu) == vrt::kVariantDefault && cells <= (1ull << 18))
+                                        ? (cfg->kernel_variant | (uint32_t)vrt::kVariantBytes) : cfg->kernel_variant;
     const uint32_t lockstep_variant = c->bounce_variant | vrt::kVariantLockstepBounce; // (before the path kernel's occupancy is filled in below)
     {
         // vrt_path_kernel behind the LDS block filter: x and z dimensions powers of two >= 4, filter <= 32 KiB (so that four
@@ -634,6 +647,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     }
     c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->bounce_variant, 0);
     c->kernel_lockstep = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, lockstep_variant, 0);
+    c->single_variant = single_variant;
     c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, single_variant, 1);
     c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, single_variant, 2);
     VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_work_counter), 2u * vrt::kMaxBatchFrames * sizeof(uint32_t)));
@@ -644,8 +658,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     }
     {
         char buf[96];
-        static const char *const mode_names[] = {"?", "linear-status+byte-occupancy", "blocked-status", "blocked-status+lds-filter", "linear-status+wide-occupancy", "linear-status-uncached", "linear-status-in-lds", "linear-status-in-lds(512-thread groups)", "linear-status-one-cell-ahead"};
-        const uint32_t rv = vrt::resolve_variant(cfg->kernel_variant);
+        static const char *const mode_names[] = {"?", "linear-status+byte-occupancy", "blocked-status", "blocked-status+lds-filter", "linear-status+wide-occupancy", "linear-status-uncached", "linear-status-in-lds", "linear-status-in-lds(512-thread groups)", "linear-status-one-cell-ahead", "byte-status"};
+        const uint32_t rv = vrt::resolve_variant(single_variant); // (the kernel of frames without bounces; DESIGN.md §4 for the others)
         std::snprintf(buf, sizeof buf, "vrt_trace_kernel<B=%u,COUNT=%d,%s,minwaves=%u>", cfg->brick_dimension, cfg->enable_counters ? 1 : 0,
                       mode_names[rv & 0xFFu], ((rv >> 8) & 0xFFu) ? ((rv >> 8) & 0xFFu) : 4u); // (as asked; the library's own choices: DESIGN.md §4)
         c->kernel_name = buf;
@@ -693,6 +707,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.occupancy_words = (uint32_t)(c->dsize[VRT_BUF_BRICK_OCCUPANCY] / 4u);
     p.status_blocks = static_cast<const uint2 *>(c->d_status_blocks);
     p.cell_bounds = c->d_cell_bounds;
+    p.status_bytes = c->d_status_bytes;
+    p.status_cells = (uint32_t)cells;
     // (order_auto: frames that alternate between the two streams of a frames_in_flight = 2 context take reverse raster (3)
     // instead, see do_dispatch and DESIGN.md §4)
     p.tile_order = c->tile_order;
@@ -727,6 +743,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         const uint32_t mode = vrt::resolve_variant(cfg->kernel_variant) & 0xFFu;
         const uint32_t fallback = (mode == vrt::kVariantLinearLds || mode == vrt::kVariantLinearLds512) ? vrt::kVariantLinearAlways : vrt::kVariantBlocked;
         c->cfg.kernel_variant = (cfg->kernel_variant & ~0xFFu) | fallback;
+        c->single_variant = c->cfg.kernel_variant;
         c->bounce_variant = (c->bounce_variant & ~0xFFu) | fallback;
         c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->bounce_variant, 0);
         c->kernel_lockstep = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->bounce_variant | vrt::kVariantLockstepBounce, 0);
@@ -827,6 +844,7 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
         if (rcw != VRT_OK) return rcw;
         VRT_HIP(ctx, vrt::launch_build_status_blocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
         VRT_HIP(ctx, vrt::launch_build_cell_bounds(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
+        VRT_HIP(ctx, vrt::launch_build_status_bytes(ctx->params, ctx->stream));
         rcw = end_scene_write(ctx);
         if (rcw != VRT_OK) return rcw;
         ctx->status_dirty = false;
@@ -851,7 +869,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     vrt::KernelFn product_fn = nullptr;
     if (ctx->d_counters) {
         const int shade = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? 2 : 1) : 0;
-        product_fn = vrt::select_trace_kernel((int)ctx->cfg.brick_dimension, false, shade == 0 ? ctx->bounce_variant : ctx->cfg.kernel_variant, shade);
+        product_fn = vrt::select_trace_kernel((int)ctx->cfg.brick_dimension, false, shade == 0 ? ctx->bounce_variant : ctx->single_variant, shade);
         if (!product_fn) return fail(ctx, VRT_E_STATE, "no product kernel for this configuration");
     }
 

@@ -72,6 +72,9 @@ struct TraceParams {
     // (0x80808080 in all six while no cell is occupied).  A ray that has left this box on the far side of an axis cannot meet an
     // occupied cell any more, so the brick-level walk of the product kernels ends there instead of at the grid's face.
     const int *cell_bounds;
+    // derived from binding 3: one byte per grid cell, 1 = occupied (kVariantBytes: the walk loop reads the byte of the next cell)
+    const uint8_t *status_bytes;
+    uint32_t status_cells;               // grid cells = bytes of status_bytes
     // derived, device-built copy of brick_status: one 64-bit word per 4x4x4 block of grid cells,
     // block index bx + nbx*(bz + nbz*by), bit (x&3) + 4*(z&3) + 16*(y&3)  (x, z, y order as comp:318)
     const uint2 *status_blocks;
@@ -116,6 +119,7 @@ enum : uint32_t {
     kVariantLinearLds = 6,    // linear status bitmap staged in LDS per workgroup (grids whose bitmap fits)
     kVariantLinearLds512 = 7, // the same with 512-thread workgroups (two tiles share one LDS copy)
     kVariantLinearAhead = 8,  // uncached status word, software-pipelined one cell ahead
+    kVariantBytes = 9,        // the hand-written loops on a byte-per-cell copy of the status bits
     kVariantCount
 };
 // frames with bounces: bit 21 forces the lockstep kernel (vrt_trace_kernel<SHADE 0>), bit 23 vrt_path_kernel (persistent lanes);

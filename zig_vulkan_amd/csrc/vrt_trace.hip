@@ -171,27 +171,31 @@ struct GridWalkRegs {
     uint32_t stub;                   // out: 0 the call ended in its first trip, 1/2 in a later trip, 3 every lane left
 };
 
-#define VRT_TRIP(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, OUT) \
+#define VRT_TRIP_T(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT) \
     "v_cmp_lt_f32_e64 %[" MX "], %[sdx], %[sdy]\n\t"                      \
     "v_cmp_lt_f32_e64 %[" MXY "], %[sdx], %[sdz]\n\t"                     \
     "v_cmp_lt_f32_e64 %[" MY "], %[sdy], %[sdz]\n\t"                      \
-    "v_add_f32_e64 %[t0], %[sdx], |%[ix]|\n\t"                            \
-    "v_add_f32_e64 %[t1], %[sdy], |%[iy]|\n\t"                            \
-    "v_add_f32_e64 %[t2], %[sdz], |%[iz]|\n\t"                            \
     "s_andn2_b64 %[" MY "], %[" MY "], %[" MX "]\n\t"                     \
     "s_and_b64 %[" MX "], %[" MX "], %[" MXY "]\n\t"                      \
     "s_or_b64 %[" MXY "], %[" MX "], %[" MY "]\n\t"                       \
-    "v_cndmask_b32_e64 %[" TS "], %[sdz], %[sdy], %[" MY "]\n\t"          \
-    "v_cndmask_b32_e64 %[" TS "], %[" TS "], %[sdx], %[" MX "]\n\t"       \
-    "v_cndmask_b32_e64 %[sdx], %[sdx], %[t0], %[" MX "]\n\t"              \
-    "v_cndmask_b32_e64 %[sdy], %[sdy], %[t1], %[" MY "]\n\t"              \
-    "v_cndmask_b32_e64 %[sdz], %[t2], %[sdz], %[" MXY "]\n\t"             \
+    /* the crossed distance = the side distance of the crossed axis = the smallest of the three (ties: equal values; a   \
+       walk never holds a NaN side distance: safeInverse keeps 1/dir finite and NaN rays fail the slab test) */            \
+    "v_min3_f32 %[" TS "], %[sdx], %[sdy], %[sdz]\n\t"                    \
+    /* side_dist of the crossed axis += |1/dir|: one add under the axis' lane mask as EXEC instead of three adds and three  \
+       selects (the loop is bound by the vector pipe; the scalar unit has slots to spare) */                                  \
+    "s_mov_b64 %[ex], exec\n\t"                                           \
+    "s_mov_b64 exec, %[" MX "]\n\t"                                       \
+    "v_add_f32_e64 %[sdx], %[sdx], |%[ix]|\n\t"                           \
+    "s_mov_b64 exec, %[" MY "]\n\t"                                       \
+    "v_add_f32_e64 %[sdy], %[sdy], |%[iy]|\n\t"                           \
+    "s_andn2_b64 exec, %[ex], %[" MXY "]\n\t"                             \
+    "v_add_f32_e64 %[sdz], %[sdz], |%[iz]|\n\t"                           \
+    "s_mov_b64 exec, %[ex]\n\t"                                           \
     "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[" MY "]\n\t"              \
     "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[" MX "]\n\t"               \
     "v_add_u32_e32 %[" IDXN "], %[" IDX "], %[t0]\n\t"                    \
     LOAD(IDXN, WORDN) /* request the next cell's word; wait for the one requested a trip ago */ \
-    "v_bfe_u32 %[t1], %[" WORD "], %[" IDX "], 1\n\t"                     \
-    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"                                  \
+    TEST(WORD, IDX)                                                       \
     "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[" MX "]\n\t"          \
     "v_subbrev_co_u32_e64 %[ry], %[by], 0, %[ry], %[" MY "]\n\t"          \
     "v_addc_co_u32_e64 %[rz], %[cz], -1, %[rz], %[" MXY "]\n\t"           \
@@ -200,6 +204,19 @@ struct GridWalkRegs {
     "s_orn2_b64 %[ex], %[ex], %[cz]\n\t" /* z: carry-out 0 = borrow */    \
     "s_andn2_b64 exec, exec, %[ex]\n\t"                                   \
     "s_cbranch_vccnz " OUT "\n\t"
+
+#define VRT_TRIP(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, OUT) VRT_TRIP_T(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, VRT_TEST_BIT, OUT)
+// the cell just left is occupied: bit (index % 32) of its word ...
+#define VRT_TEST_BIT(WORD, IDX)                                           \
+    "v_bfe_u32 %[t1], %[" WORD "], %[" IDX "], 1\n\t"                     \
+    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"
+// ... or, with the status expanded to ONE BYTE PER CELL (TraceParams::status_bytes, derived from binding 3 on every status
+// upload), the byte itself: no shift for the address, no bit-field extract for the test — 16 instead of 18 vector instructions
+// per trip of a loop that is bound by the vector pipe (two cycles per wave64 instruction per SIMD)
+#define VRT_TEST_BYTE(WORD, IDX) "v_cmp_ne_u32_e32 vcc, 0, %[" WORD "]\n\t"
+#define VRT_LOAD_BYTE(IDXN, WORDN)                                        \
+    "buffer_load_ubyte %[" WORDN "], %[" IDXN "], %[rsrc], 0 offen\n\t"   \
+    "s_waitcnt vmcnt(1)\n\t"
 
 // Where the bitmap words come from.  Global memory: a stride-4 buffer resource indexed by the word index (an
 // index outside the buffer reads 0).  LDS (brick level, grids whose status bitmap fits): the bitmap staged at
@@ -230,15 +247,15 @@ struct GridWalkRegs {
 // request for wordb; a B trip the other way round.  A call starts with an A trip.  On exit the B set holds the
 // last step and the A set the one before it, idxa/worda the current cell and idxb the cell just left: a call
 // that ends in an A trip swaps the sets on its way out.
-#define VRT_WALK_ASM(LIMIT, LOAD, WAITALL)                                                                            \
+#define VRT_WALK_ASM(LIMIT, LOAD, TEST, WAITALL)                                                                            \
     "s_mov_b64 %[save], exec\n\t"                                                                         \
     "s_mov_b64 exec, %[alive]\n\t"                                                                        \
-    VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, "1f")                  \
+    VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "1f")                  \
     "0:\n\t"                                                                                              \
-    VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, "2f")                  \
-    VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, "3f")                  \
-    VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, "2f")                  \
-    VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, "3f")                  \
+    VRT_TRIP_T("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "2f")                  \
+    VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "3f")                  \
+    VRT_TRIP_T("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "2f")                  \
+    VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "3f")                  \
     "s_cbranch_execnz 0b\n\t"                                                                             \
     "s_mov_b32 %[stub], 3\n\t"                                                                            \
     "s_branch 4f\n\t"                                                                                     \
@@ -289,7 +306,7 @@ VRT_DI void grid_walk_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32
     unsigned long long mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb;
-    asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_BUFFER, VRT_WAIT_BUFFER) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
+    asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_BUFFER, VRT_TEST_BIT, VRT_WAIT_BUFFER) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
 }
 
 // brick level with the status bitmap in LDS; `rsrc` is the byte-address mask (allocation size - 4)
@@ -298,7 +315,17 @@ VRT_DI void grid_walk_lds_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, ui
     unsigned long long mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb;
-    asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_LDS, VRT_WAIT_LDS) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
+    asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_LDS, VRT_TEST_BIT, VRT_WAIT_LDS) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
+}
+
+// brick level on the byte-per-cell copy of the status bits: `index` is the byte offset, `word` the byte of the current cell;
+// rsrc: a raw buffer (stride 0) over TraceParams::status_bytes, so that an out-of-grid index reads 0
+VRT_DI void grid_walk_bytes_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
+                                   uint32_t &word, u32x4 rsrc, GridWalkRegs &g) {
+    unsigned long long mxya, mxyb, ex, by, cz, save;
+    float t0, t1, t2;
+    uint32_t wordb;
+    asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_BYTE, VRT_TEST_BYTE, VRT_WAIT_BUFFER) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
 }
 
 // voxel level (comp:409-470): voxels of one brick, bits of brick_occupancy addressed by the global bit index
@@ -308,7 +335,7 @@ VRT_DI void voxel_walk_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint3
     unsigned long long mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb;
-    asm volatile(VRT_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_BUFFER, VRT_WAIT_BUFFER) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
+    asm volatile(VRT_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_BUFFER, VRT_TEST_BIT, VRT_WAIT_BUFFER) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
 }
 #undef VRT_WALK_ASM
 #undef VRT_WALK_OUTPUTS
@@ -462,8 +489,9 @@ struct FilterConsts {
     "s_andn2_b64 %[" MY "], %[" MY "], %[" MX "]\n\t"                     \
     "s_and_b64 %[" MX "], %[" MX "], %[" MXY "]\n\t"                      \
     "s_or_b64 %[" MXY "], %[" MX "], %[" MY "]\n\t"                       \
-    "v_cndmask_b32_e64 %[" TS "], %[sdz], %[sdy], %[" MY "]\n\t"          \
-    "v_cndmask_b32_e64 %[" TS "], %[" TS "], %[sdx], %[" MX "]\n\t"       \
+    /* the crossed distance = the side distance of the crossed axis = the smallest of the three (ties: equal values; a   \
+       walk never holds a NaN side distance: safeInverse keeps 1/dir finite and NaN rays fail the slab test) */            \
+    "v_min3_f32 %[" TS "], %[sdx], %[sdy], %[sdz]\n\t"                    \
     "v_cndmask_b32_e64 %[sdx], %[sdx], %[t0], %[" MX "]\n\t"              \
     "v_cndmask_b32_e64 %[sdy], %[sdy], %[t1], %[" MY "]\n\t"              \
     "v_cndmask_b32_e64 %[sdz], %[t2], %[sdz], %[" MXY "]\n\t"             \
@@ -561,6 +589,10 @@ VRT_DI void grid_walk_park_filter_gfx950(Walk &w, const f3 &inv_dir, uint32_t &i
 #undef VRT_T_LIMIT
 #undef VRT_NO_LIMIT
 #undef VRT_TRIP
+#undef VRT_TRIP_T
+#undef VRT_TEST_BIT
+#undef VRT_TEST_BYTE
+#undef VRT_LOAD_BYTE
 
 // comp:298 / comp:395
 VRT_DI f3 initial_side_dist(f3 fstep, f3 fposition, f3 ray_delta) {
@@ -899,7 +931,8 @@ enum StatusMode : int {
     kStatusLinearWide = 3, // linear words for status, 64-bit words for occupancy
     kStatusLinearAlways = 4, // linear words, loaded on every step (no per-lane word cache, no branch)
     kStatusLinearLds = 5,    // the whole linear status bitmap staged in LDS per workgroup, read on every step
-    kStatusLinearAhead = 6   // as kStatusLinearAlways, software-pipelined: the next cell's word is requested before the current cell is tested
+    kStatusLinearAhead = 6,  // as kStatusLinearAlways, software-pipelined: the next cell's word is requested before the current cell is tested
+    kStatusBytes = 7         // the hand-written loop on a byte-per-cell copy of the status bits (no shift, no bit-field extract per trip)
 };
 
 // comp:271-376.  t_min = 1e-5, t_max = +inf at every call site (comp:218,247).
@@ -1029,7 +1062,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         VRT_COUNT(bricks_entered);
         VRT_COUNT_WAVE(wave_brick_walks);
         bool found;
-        if constexpr ((MODE == kStatusLinearAlways || MODE == kStatusLinearLds) && !COUNT) {
+        if constexpr ((MODE == kStatusLinearAlways || MODE == kStatusLinearLds || MODE == kStatusBytes) && !COUNT) {
             found = brick_walk_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, brick_axis, hit_axis);
         } else {
             found = brick_walk<B, COUNT, MODE == kStatusLinear || MODE == kStatusLinearLds || MODE == kStatusLinearAhead>(
@@ -1040,7 +1073,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     auto enter_brick = [&]() { enter_brick_at(w.rx, w.ry, w.rz, w.t_value, grid_index, axis); };
     // brick_walk_gfx950 records a hit as distance + material + face; comp:433-436 from those, once the walk is over
     auto finish_hit = [&]() {
-        if constexpr ((MODE == kStatusLinearAlways || MODE == kStatusLinearLds) && !COUNT) {
+        if constexpr ((MODE == kStatusLinearAlways || MODE == kStatusLinearLds || MODE == kStatusBytes) && !COUNT) {
             if (stop == -1) {
                 const float t_offset = (g_scale * (1.0f / (float)B)) * 0.05f;
                 hit.normal = axis_normal(s, hit_axis);
@@ -1139,20 +1172,22 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
             more = ((inside ? 0 : -1) | stop) >= 0;
         }
         return stop == -1;
-    } else if constexpr ((MODE == kStatusLinearAlways || MODE == kStatusLinearLds) && !COUNT) {
+    } else if constexpr ((MODE == kStatusLinearAlways || MODE == kStatusLinearLds || MODE == kStatusBytes) && !COUNT) {
         // The shipped default: grid_walk_gfx950 runs trips until some lane stands on an occupied cell (or all
         // lanes have left); the bricks are walked here, with the state from BEFORE the lane's last step rebuilt
         // from the post-step state and the crossed-axis lane masks, and the walk is resumed.
-        const unsigned long long status_addr = (unsigned long long)p.brick_status;
+        const unsigned long long status_addr = (MODE == kStatusBytes) ? (unsigned long long)p.status_bytes : (unsigned long long)p.brick_status;
         u32x4 rsrc;
         rsrc.x = (uint32_t)status_addr;
-        rsrc.y = (uint32_t)(status_addr >> 32) | (4u << 16); // stride 4: one record per status word
-        rsrc.z = p.status_words;
+        // words: stride 4, one record per status word.  bytes: a raw buffer (stride 0), num_records = bytes = cells
+        rsrc.y = (uint32_t)(status_addr >> 32) | ((MODE == kStatusBytes) ? 0u : (4u << 16));
+        rsrc.z = (MODE == kStatusBytes) ? p.status_cells : p.status_words;
         rsrc.w = 0x00020000u;
         // LDS variant: byte-address mask of the power-of-two LDS allocation holding the bitmap (trace_lds_bytes)
         [[maybe_unused]] const uint32_t lds_mask = (0xFFFFFFFFu >> __builtin_clz(p.status_words * 4u - 1u)) & ~3u;
         uint32_t word;
         if constexpr (MODE == kStatusLinearLds) word = lds_word0(more ? (grid_index >> 5) : 0u);
+        else if constexpr (MODE == kStatusBytes) word = p.status_bytes[more ? grid_index : 0u];
         else word = p.brick_status[more ? (grid_index >> 5) : 0u];
         GridWalkRegs g;
         g.alive = __builtin_amdgcn_ballot_w64(more);
@@ -1165,6 +1200,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
             uint32_t cell; // the cell each lane stood on before its last step
             VRT_PROF_BEGIN(tp0);
             if constexpr (MODE == kStatusLinearLds) grid_walk_lds_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, lds_mask, g);
+            else if constexpr (MODE == kStatusBytes) grid_walk_bytes_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
             else grid_walk_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
             VRT_PROF_END(0, tp0);
             if (g.occ == 0ull) break; // every lane has left the grid
@@ -1941,6 +1977,19 @@ __global__ __launch_bounds__(256) void vrt_build_status_blocks(const uint32_t *_
     if (lane == 32 && base_word + 1u < nwords) filter[base_word + 1u] = (uint32_t)(nonempty >> 32);
 }
 
+// One byte per grid cell (TraceParams::status_bytes): 1 where the cell's status bit is set.  One thread per status word.
+__global__ __launch_bounds__(256) void vrt_build_status_bytes(const uint32_t *__restrict__ status, uint8_t *__restrict__ out, uint32_t words, uint32_t /*cells*/) {
+    const uint32_t wi = blockIdx.x * 256u + threadIdx.x;
+    if (wi >= words) return;
+    const uint32_t bits = status[wi];
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)wi * 32u); // (the allocation holds 32 bytes per status word)
+    for (uint32_t k = 0; k < 8u; k++) {
+        const uint32_t nib = (bits >> (4u * k)) & 0xFu;
+        const uint32_t v = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+        dst[k] = v;
+    }
+}
+
 // Bounding box of the occupied grid cells (TraceParams::cell_bounds), from the status bits of binding 3: one thread per
 // status word, six atomic maxima over {-x, -y, -z, x, y, z}; bounds[] starts as 0x80808080 (hipMemsetAsync 0x80).
 __global__ __launch_bounds__(256) void vrt_build_cell_bounds(const uint32_t *__restrict__ status, int *__restrict__ bounds, uint32_t words,
@@ -2213,6 +2262,8 @@ static KernelFn pick_mode(uint32_t mode) {
         case kVariantLinearLds: return vrt_trace_kernel<B, COUNT, kStatusLinearLds, MW, SHADE>;
         case kVariantLinearLds512: return vrt_trace_kernel<B, COUNT, kStatusLinearLds, MW, SHADE, 512>;
         case kVariantLinearAhead: return vrt_trace_kernel<B, COUNT, kStatusLinearAhead, MW, SHADE>;
+        // (byte status: the hand-written loop of frames without bounces; counting builds and the bounce kernels keep the words)
+        case kVariantBytes: return vrt_trace_kernel<B, COUNT, (COUNT || SHADE == 0) ? kStatusLinearAlways : kStatusBytes, MW, SHADE>;
         default: return nullptr;
     }
 }
@@ -2323,6 +2374,13 @@ hipError_t launch_build_cell_bounds(const TraceParams &p, uint32_t dim_x, uint32
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(vrt_build_cell_bounds, dim3((p.status_words + 255u) / 256u), dim3(256), 0, stream, p.brick_status, bounds, p.status_words,
                        dim_x * dim_y * dim_z, dim_x, dim_z);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_status_bytes(const TraceParams &p, hipStream_t stream) {
+    if (!p.status_bytes) return hipSuccess;
+    hipLaunchKernelGGL(vrt_build_status_bytes, dim3((p.status_words + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
+                       const_cast<uint8_t *>(p.status_bytes), p.status_words, p.status_cells);
     return hipGetLastError();
 }
 
