@@ -172,15 +172,16 @@ struct GridWalkRegs {
 };
 
 #define VRT_TRIP_T(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT) \
-    "v_cmp_lt_f32_e64 %[" MX "], %[sdx], %[sdy]\n\t"                      \
-    "v_cmp_lt_f32_e64 %[" MXY "], %[sdx], %[sdz]\n\t"                     \
-    "v_cmp_lt_f32_e64 %[" MY "], %[sdy], %[sdz]\n\t"                      \
-    "s_andn2_b64 %[" MY "], %[" MY "], %[" MX "]\n\t"                     \
-    "s_and_b64 %[" MX "], %[" MX "], %[" MXY "]\n\t"                      \
-    "s_or_b64 %[" MXY "], %[" MX "], %[" MY "]\n\t"                       \
-    /* the crossed distance = the side distance of the crossed axis = the smallest of the three (ties: equal values; a   \
-       walk never holds a NaN side distance: safeInverse keeps 1/dir finite and NaN rays fail the slab test) */            \
+    /* The crossed distance = the smallest side distance, and the crossed axis from it: the shader's                       \
+       x<y ? (x<z ? X : Z) : (y<z ? Y : Z) picks Z whenever z is minimal (ties included), else Y whenever y is, else X —    \
+       one min3 and two equality tests instead of three compares and two selects.  (A walk never holds a NaN side          \
+       distance: safeInverse keeps 1/dir finite and NaN rays fail the slab test.) */                                        \
     "v_min3_f32 %[" TS "], %[sdx], %[sdy], %[sdz]\n\t"                    \
+    "v_cmp_eq_f32_e64 %[" MXY "], %[sdz], %[" TS "]\n\t" /* z crossed */   \
+    "v_cmp_eq_f32_e64 %[" MY "], %[sdy], %[" TS "]\n\t"                   \
+    "s_andn2_b64 %[" MY "], %[" MY "], %[" MXY "]\n\t"  /* y crossed: y minimal, z not */ \
+    "s_andn2_b64 %[" MXY "], exec, %[" MXY "]\n\t"      /* x or y crossed */ \
+    "s_andn2_b64 %[" MX "], %[" MXY "], %[" MY "]\n\t"  /* x crossed */    \
     /* side_dist of the crossed axis += |1/dir|: one add under the axis' lane mask as EXEC instead of three adds and three  \
        selects (the loop is bound by the vector pipe; the scalar unit has slots to spare) */                                  \
     "s_mov_b64 %[ex], exec\n\t"                                           \
