@@ -667,7 +667,8 @@ VRT_DI bool bit64(uint2 w, uint32_t bit) { // bit 0..63 of a 64-bit word held as
     return (half >> (bit & 31u)) & 1u;
 }
 
-VRT_DI bool more_init(int px, int py, int pz, int dim) { return (unsigned)px < (unsigned)dim && (unsigned)py < (unsigned)dim && (unsigned)pz < (unsigned)dim; }
+// all three in [0, dim), dim a power of two (4 or 8): the OR of three such values stays below dim, and any negative or larger one lifts it above
+VRT_DI bool more_init(int px, int py, int pz, int dim) { return (unsigned)(px | py | pz) < (unsigned)dim; }
 
 // comp:378-471.  Returns true on a (non-ignored) voxel hit and fills `hit`.
 // LITERAL: one byte load per voxel step (comp:415); otherwise 64-bit occupancy words:
@@ -681,9 +682,9 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
     const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
     Walk w;
     w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
-    const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
-    const int py = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
-    const int pz = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
+    const int px = f2i_clamp(__builtin_floorf(fposition.x));
+    const int py = f2i_clamp(__builtin_floorf(fposition.y));
+    const int pz = f2i_clamp(__builtin_floorf(fposition.z));
     constexpr int kZeroBudget = 3 * B + 8;
     w.rx = steps_left(s.sx, px, B, kZeroBudget);
     w.ry = steps_left(s.sy, py, B, kZeroBudget);
@@ -774,9 +775,9 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
     const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
     Walk w;
     w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
-    const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
-    const int py = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
-    const int pz = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
+    const int px = f2i_clamp(__builtin_floorf(fposition.x));
+    const int py = f2i_clamp(__builtin_floorf(fposition.y));
+    const int pz = f2i_clamp(__builtin_floorf(fposition.z));
     constexpr int kZeroBudget = 3 * B + 8;
     w.rx = steps_left(s.sx, px, B, kZeroBudget);
     w.ry = steps_left(s.sy, py, B, kZeroBudget);
@@ -857,9 +858,9 @@ VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const Ray
     const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
     Walk w;
     w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
-    const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
-    const int py = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
-    const int pz = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
+    const int px = f2i_clamp(__builtin_floorf(fposition.x));
+    const int py = f2i_clamp(__builtin_floorf(fposition.y));
+    const int pz = f2i_clamp(__builtin_floorf(fposition.z));
     constexpr int kZeroBudget = 3 * B + 8;
     w.rx = steps_left(s.sx, px, B, kZeroBudget);
     w.ry = steps_left(s.sy, py, B, kZeroBudget);
@@ -961,9 +962,9 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     const f3 fposition = p.scale_pow2 ? (ray_at(r, global_t_value) - g_min) * p.inv_grid_scale : (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
     Walk w;
     w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
-    const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
-    const int py = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
-    const int pz = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
+    const int px = f2i_clamp(__builtin_floorf(fposition.x));
+    const int py = f2i_clamp(__builtin_floorf(fposition.y));
+    const int pz = f2i_clamp(__builtin_floorf(fposition.z));
     const int zero_budget = dx + dy + dz + 8;
     // The walk ends where the ray leaves the bounding box of the OCCUPIED cells on the far side of an axis (every cell beyond
     // is empty, and the ray cannot come back), not only at the grid's face: same hits, same misses, fewer trips -- sky rays of a
@@ -1855,9 +1856,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TracePar
                     const float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
                     const f3 fposition = p.scale_pow2 ? (ray_at(r, global_t_value) - g_min) * p.inv_grid_scale : (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
                     w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
-                    const int px = f2i_clamp(__builtin_floorf(fposition.x + 0.f));
-                    const int py = f2i_clamp(__builtin_floorf(fposition.y + 0.f));
-                    const int pz = f2i_clamp(__builtin_floorf(fposition.z + 0.f));
+                    const int px = f2i_clamp(__builtin_floorf(fposition.x));
+                    const int py = f2i_clamp(__builtin_floorf(fposition.y));
+                    const int pz = f2i_clamp(__builtin_floorf(fposition.z));
                     w.rx = steps_left_box(s.sx, px, lox, hix, zero_budget);
                     w.ry = steps_left_box(s.sy, py, loy, hiy, zero_budget);
                     w.rz = steps_left_box(s.sz, pz, loz, hiz, zero_budget);
