@@ -24,6 +24,10 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True) -> int:
         grid = BrickGrid(*dims, min_point=min_point, scale=scale, brick_dimension=b)
         n = int(rng.integers(1, max(2, int(0.2 * cells * b ** 3))))
         xyz = np.stack([rng.integers(0, b * d, n) for d in dims], axis=-1)
+        if rng.random() < 0.5:  # the occupied cells fill only a sub-box of the grid: rays enter the grid in front of it (skip_to_box)
+            lo = [int(rng.integers(0, d)) for d in dims]
+            hi = [int(rng.integers(l, d)) for l, d in zip(lo, dims)]
+            xyz = np.stack([b * l + rng.integers(0, b * (h - l + 1), n) for l, h in zip(lo, hi)], axis=-1)
         if rng.random() < 0.5:  # clumps: whole columns
             xyz[:, 1] = rng.integers(0, b * dims[1], n) // 2 * 2
         grid.insert_many(xyz, rng.integers(0, 14, n))

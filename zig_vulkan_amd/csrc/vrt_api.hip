@@ -677,6 +677,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.target_rgba32f = c->target32f;
     p.counters = c->d_counters;
     p.count_box = (cfg->enable_counters == 2u) ? 1u : 0u;
+    p.skip_to_box = 1u;
+    if (const char *e = std::getenv("VRT_SKIP_TO_BOX")) p.skip_to_box = std::atoi(e) ? 1u : 0u; // tuning knob (A/B measurements)
     p.work_counter = c->d_work_counter;
     p.path_lds_bytes = c->path_lds_bytes;
     {

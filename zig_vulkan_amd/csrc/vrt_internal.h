@@ -99,6 +99,7 @@ struct TraceParams {
     uint32_t path_groups;                // vrt_path_kernel: workgroups to launch (a few times what the GPU holds)
     uint32_t path_fin_batch;             // vrt_path_kernel: lanes that must be waiting before the wave leaves the walk loop for them
     uint32_t count_box;                  // counting build only: 1 = walk to the occupied-cell box like the product kernel (issued loads)
+    uint32_t skip_to_box;                // 1: rays that enter the grid in front of the occupied-cell box jump to its near face (skip_to_box())
     uint32_t tile_order;                 // workgroup -> tile mapping: 1 row bands per XCD, 2 column bands per XCD, 3 reverse raster, 4 strided,
                                          // 5 cost-feedback schedule, 6 raster.  (kernel_variant: 0 = the library chooses between 3 and the
                                          // schedule re-sorted every 32 frames, which is 7 there; 5 there re-sorts before every frame)

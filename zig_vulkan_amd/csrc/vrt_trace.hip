@@ -937,6 +937,93 @@ enum StatusMode : int {
     kStatusBytes = 7         // the hand-written loop on a byte-per-cell copy of the status bits (no shift, no bit-field extract per trip)
 };
 
+// ---- skip to the box of occupied cells ---------------------------------------------------------------------------
+// A ray that enters the grid OUTSIDE the bounding box of the occupied cells along some axis A (a camera above the terrain:
+// A = y) walks through cells that are known to be empty until it has crossed A `need` times (need = cells to the box's near
+// face).  The shader's walk is a three-way merge of three non-decreasing sequences — the side distances of x, y and z, each
+// built by repeated addition of |1/dir| — with ties going to z, then y, then x (comp:345-372).  So the state after the
+// need-th crossing of A is known without walking: T = A's side distance after need-1 additions is the distance of that
+// crossing; every element of another axis B that precedes T in merge order (c < T, or c == T where B wins the tie) has been
+// consumed; B's side distance is its first element that does not.  All additions are the walk's own, in the walk's order per
+// axis, so every side distance, counter and index is bit for bit what the walk would hold: ~2 vector instructions per
+// skipped step instead of a 13-instruction trip.  A lane whose B counter runs out first has left the box (a miss, as in the
+// walk).  Afterwards the lane stands on the first cell inside the box's A range, entered through A at distance T.  One round per
+// axis (x, y, z; the order does not matter: each round skips what is left in front of its axis' near face).
+VRT_DI float next_below(float t) { // the largest float < t (t finite)
+    const uint32_t b = __builtin_bit_cast(uint32_t, t);
+    return __builtin_bit_cast(float, t > 0.0f ? b - 1u : (t < 0.0f ? b + 1u : 0x80000001u));
+}
+// t after `count` further additions of |inv| (per lane): 2 vector + 1 scalar instruction and the branch per step
+VRT_DI void skip_add_gfx950(float &t, float inv, int count) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %[save], exec\n\t"
+                 "0:\n\t"
+                 "v_add_co_u32_e32 %[n], vcc, -1, %[n]\n\t" /* carry-out: the count was >= 1 */
+                 "s_and_b64 exec, exec, vcc\n\t"
+                 "v_add_f32_e64 %[t], %[t], |%[d]|\n\t"
+                 "s_cbranch_execnz 0b\n\t"
+                 "s_mov_b64 exec, %[save]"
+                 : [t] "+v"(t), [n] "+v"(count), [save] "=&s"(save)
+                 : [d] "v"(inv)
+                 : "vcc", "scc");
+}
+// consume the elements c, c+|inv|, ... of another axis that are <= lim, at most `left`+1 of them (the last one crosses the far
+// face of the box: left ends at -1); `left` is the axis' steps-left counter: 3 vector + 2 scalar instructions per step
+VRT_DI void skip_merge_gfx950(float &c, float inv, int &left, float lim) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %[save], exec\n\t"
+                 "0:\n\t"
+                 "v_cmp_le_f32_e32 vcc, %[c], %[lim]\n\t"
+                 "s_and_b64 exec, exec, vcc\n\t"
+                 "v_add_f32_e64 %[c], %[c], |%[d]|\n\t"
+                 "v_add_co_u32_e32 %[r], vcc, -1, %[r]\n\t" /* carry-out: a step was left; none: the lane leaves the box here */
+                 "s_and_b64 exec, exec, vcc\n\t"
+                 "s_cbranch_execnz 0b\n\t"
+                 "s_mov_b64 exec, %[save]"
+                 : [c] "+v"(c), [r] "+v"(left), [save] "=&s"(save)
+                 : [d] "v"(inv), [lim] "v"(lim)
+                 : "vcc", "scc");
+}
+VRT_DI float &comp3(f3 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+VRT_DI float comp3(const f3 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+// one round: bring axis A (compile time) inside the box's range for the lanes that are in front of it
+template <int A>
+VRT_DI void skip_round(Walk &w, const RaySetup &s, int span, uint32_t &index, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z, bool &more,
+                       int &in_axis, float &t_in, bool &skipped) {
+    constexpr int B1 = (A + 1) % 3, B2 = (A + 2) % 3; // the other two axes; an axis wins a tie against A iff it comes later in x, y, z
+    int *const r[3] = {&w.rx, &w.ry, &w.rz};
+    const uint32_t stride[3] = {stride_x, stride_y, stride_z};
+    const int step_a = A == 0 ? s.sx : (A == 1 ? s.sy : s.sz);
+    // crossings still to go before the near face (steps left to the FAR face minus the box's extent); an axis the ray does not
+    // move along holds the hang-guard budget instead and never needs any
+    const int need = step_a != 0 ? *r[A] - span : 0;
+    const bool want = more && need > 0;
+    if (__builtin_amdgcn_ballot_w64(want) == 0ull) return;
+    if (want) {
+        float t = comp3(w.side_dist, A);
+        skip_add_gfx950(t, comp3(s.inv_dir, A), need - 1);
+        const float t_strict = next_below(t); // c < t  <=>  c <= t_strict
+        const int r1 = *r[B1], r2 = *r[B2];
+        skip_merge_gfx950(comp3(w.side_dist, B1), comp3(s.inv_dir, B1), *r[B1], B1 > A ? t : t_strict);
+        skip_merge_gfx950(comp3(w.side_dist, B2), comp3(s.inv_dir, B2), *r[B2], B2 > A ? t : t_strict);
+        comp3(w.side_dist, A) = t + comp3(s.ray_delta, A);
+        *r[A] -= need;
+        index += (uint32_t)need * stride[A] + (uint32_t)(r1 - *r[B1]) * stride[B1] + (uint32_t)(r2 - *r[B2]) * stride[B2];
+        more = (*r[B1] | *r[B2]) >= 0; // a counter below zero: the far face of the box was crossed on the way
+        in_axis = A;
+        t_in = t;
+        skipped = true;
+    }
+}
+VRT_DI bool skip_to_box(Walk &w, const RaySetup &s, int span_x, int span_y, int span_z, uint32_t &index, uint32_t stride_x, uint32_t stride_y,
+                        uint32_t stride_z, bool &more, int &in_axis, float &t_in) {
+    bool skipped = false;
+    skip_round<0>(w, s, span_x, index, stride_x, stride_y, stride_z, more, in_axis, t_in, skipped);
+    skip_round<1>(w, s, span_y, index, stride_x, stride_y, stride_z, more, in_axis, t_in, skipped);
+    skip_round<2>(w, s, span_z, index, stride_x, stride_y, stride_z, more, in_axis, t_in, skipped);
+    return skipped;
+}
+
 // comp:271-376.  t_min = 1e-5, t_max = +inf at every call site (comp:218,247).
 // BATCH (used for frames with bounces, whose secondary rays are incoherent): a lane that reaches an
 // occupied cell does not walk its brick at once but waits (__ballot) until p.brick_batch lanes are waiting or
@@ -1002,6 +1089,14 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     // same integer test as the box exit
     int stop = 0;
     bool more = (unsigned)px < (unsigned)dx && (unsigned)py < (unsigned)dy && (unsigned)pz < (unsigned)dz && (w.rx | w.ry | w.rz) >= 0;
+    // a ray that enters the grid in front of the box jumps to the box's near face (skip_to_box above); such a lane's first cell
+    // was entered by a step through `axis` at crossed distance skip_t, not through the slab test
+    [[maybe_unused]] bool skipped = false;
+    [[maybe_unused]] float skip_t = 0.0f;
+    if ((!COUNT || p.count_box) && p.cell_bounds && p.skip_to_box) {
+        skipped = skip_to_box(w, s, hix - lox, hiy - loy, hiz - loz, grid_index, stride_x, stride_y, stride_z, more, axis, skip_t);
+        w.t_value = skip_t;
+    }
 
     auto cell_occupied = [&]() -> bool {
         VRT_COUNT(grid_steps);
@@ -1097,8 +1192,8 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         g.alive = __builtin_amdgcn_ballot_w64(more);
         g.out_x = 0ull;
         g.out_y = 0ull;
-        g.t_out = 0.0f;
-        g.code = 3u << 4; // the first cell of the walk was entered through the slab test, not by a step
+        g.t_out = skip_t;
+        g.code = (uint32_t)axis << 4; // 3: the first cell of the walk was entered through the slab test, not by a step
         g.batch = p.brick_batch;
         while (g.alive != 0ull) {
             uint32_t cell; // the occupied cell each parked lane stood on before its last step
@@ -1193,9 +1288,9 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         else word = p.brick_status[more ? (grid_index >> 5) : 0u];
         GridWalkRegs g;
         g.alive = __builtin_amdgcn_ballot_w64(more);
-        g.out_x = 0ull;
-        g.out_y = 0ull;
-        g.t_out = 0.0f;
+        g.out_x = __builtin_amdgcn_ballot_w64(skipped && axis == 0);
+        g.out_y = __builtin_amdgcn_ballot_w64(skipped && axis == 1);
+        g.t_out = skip_t;
         bool first = true; // wave-uniform
         VRT_PROF_END(3, tp3);
         while (g.alive != 0ull) {
@@ -1208,7 +1303,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
             if (g.occ == 0ull) break; // every lane has left the grid
             if (__builtin_amdgcn_inverse_ballot_w64(g.occ)) {
                 // axis 3: the first cell of the walk was entered through the slab test, not by a step
-                int a = (first && g.stub == 0u) ? 3
+                int a = (first && g.stub == 0u && !skipped) ? 3
                                                 : (__builtin_amdgcn_inverse_ballot_w64(g.in_x) ? 0 : (__builtin_amdgcn_inverse_ballot_w64(g.in_y) ? 1 : 2));
                 const bool out_x = __builtin_amdgcn_inverse_ballot_w64(g.out_x), out_y = __builtin_amdgcn_inverse_ballot_w64(g.out_y);
                 VRT_PROF_BEGIN(tp1);
