@@ -1961,12 +1961,16 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TracePar
                     w.t_value = 0;
                     grid_index = (uint32_t)px + (uint32_t)dx * ((uint32_t)pz + (uint32_t)dz * (uint32_t)py);
                     stride_x = (uint32_t)s.sx, stride_y = (uint32_t)s.sy * (uint32_t)dx * (uint32_t)dz, stride_z = (uint32_t)s.sz * (uint32_t)dx;
-                    const bool more = (global_t_value <= t_max) && (unsigned)px < (unsigned)dx && (unsigned)py < (unsigned)dy && (unsigned)pz < (unsigned)dz &&
-                                      (w.rx | w.ry | w.rz) >= 0;
+                    bool more = (global_t_value <= t_max) && (unsigned)px < (unsigned)dx && (unsigned)py < (unsigned)dy && (unsigned)pz < (unsigned)dz &&
+                                (w.rx | w.ry | w.rz) >= 0;
+                    int in_axis = 3; // the first cell of the walk was entered through the slab test, not by a step ...
+                    float skip_t = 0.0f;
+                    // ... unless the ray enters the grid in front of the occupied-cell box and jumps to its near face
+                    if (p.cell_bounds && p.skip_to_box) skip_to_box(w, s, hix - lox, hiy - loy, hiz - loz, grid_index, stride_x, stride_y, stride_z, more, in_axis, skip_t);
                     if (more) {
                         word = p.brick_status[grid_index >> 5];
-                        g.t_out = 0.0f;
-                        g.code = 3u << 4; // the first cell of the walk was entered through the slab test, not by a step
+                        g.t_out = skip_t;
+                        g.code = (uint32_t)in_axis << 4;
                         st = kLaneWalk;
                     }
                 }
