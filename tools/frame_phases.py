@@ -18,5 +18,5 @@ for v in views:
     tot = pr[7]
     other = tot - pr[0] - pr[1] - pr[3]
     print(f"{w.name} {v}: whole {tot/1e9:.3f} G wave-cycles | grid loop {100*pr[0]/tot:.1f} % | bricks {100*pr[1]/tot:.1f} % (voxel loops {100*pr[2]/tot:.1f}, material {100*pr[4]/tot:.1f}) "
-          f"| grid_hit setup {100*pr[3]/tot:.1f} % | rest (ray gen, shading, sun jitter, tone-map, store) {100*other/tot:.1f} %")
+          f"| grid_hit setup {100*pr[3]/tot:.1f} % (slab test {100*pr[6]/tot:.1f}, skip to box {100*pr[5]/tot:.1f}) | rest (ray gen, shading, sun jitter, tone-map, store) {100*other/tot:.1f} %")
 rt.deinit()

@@ -55,6 +55,71 @@ static int check_idxen() {
     return bad;
 }
 
+// Third assumption (skip_to_box): v_cmpx narrows EXEC for the very next vector instruction and for s_cbranch_execnz, with no
+// wait states inserted by hand; a carry-out under partial EXEC narrows it the same way.  The two loops of vrt_trace.hip, verbatim
+// in structure, against plain C loops.
+__global__ void probe_skip(const float *c0, const float *d, const float *lim, const int *left, const int *count, float *c_out, int *n_out, float *t_out) {
+    float c = c0[threadIdx.x], t = c0[threadIdx.x];
+    int n = 0, cnt = count[threadIdx.x];
+    unsigned long long save;
+#define STEP "v_cmpx_le_f32_e32 vcc, %[c], %[lim]\n\tv_add_f32_e64 %[c], %[c], |%[d]|\n\tv_add_u32_e32 %[n], 1, %[n]\n\t"
+    asm volatile("s_mov_b64 %[save], exec\n\t"
+                 "0:\n\t" STEP STEP STEP STEP
+                 "v_cmpx_ge_i32_e32 vcc, %[r], %[n]\n\t"
+                 "s_cbranch_execnz 0b\n\t"
+                 "s_mov_b64 exec, %[save]"
+                 : [c] "+v"(c), [n] "+v"(n), [save] "=&s"(save)
+                 : [d] "v"(d[threadIdx.x]), [lim] "v"(lim[threadIdx.x]), [r] "v"(left[threadIdx.x])
+                 : "vcc", "scc");
+#undef STEP
+#define STEP "v_add_co_u32_e32 %[n], vcc, -1, %[n]\n\ts_and_b64 exec, exec, vcc\n\tv_add_f32_e64 %[t], %[t], |%[d]|\n\t"
+    asm volatile("s_mov_b64 %[save], exec\n\t"
+                 "0:\n\t" STEP STEP STEP STEP
+                 "s_cbranch_execnz 0b\n\t"
+                 "s_mov_b64 exec, %[save]"
+                 : [t] "+v"(t), [n] "+v"(cnt), [save] "=&s"(save)
+                 : [d] "v"(d[threadIdx.x])
+                 : "vcc", "scc");
+#undef STEP
+    c_out[threadIdx.x] = c;
+    n_out[threadIdx.x] = n;
+    t_out[threadIdx.x] = t;
+}
+
+static int check_skip_loops() {
+    float hc[64], hd[64], hl[64], oc[64], ot[64];
+    int hr[64], hk[64], on[64];
+    uint32_t seed = 12345u;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (seed >> 8) * (1.0f / 16777216.0f); };
+    for (int i = 0; i < 64; ++i) {
+        hd[i] = (i & 1 ? -1.0f : 1.0f) * (1.0f + 3.0f * rnd());   // sign ignored (|d|)
+        hc[i] = rnd() * 1.5f;
+        hl[i] = (i % 7 == 0) ? hc[i] - 0.25f : hc[i] + 40.0f * rnd(); // some lanes consume nothing
+        hr[i] = (i % 5 == 0) ? (int)(3 * rnd()) : 64;                 // some lanes run out of steps
+        hk[i] = (i % 4 == 0) ? 0 : (int)(37 * rnd());
+    }
+    float *dc, *dd, *dl, *doc, *dot; int *dr, *dk, *don;
+    hipMalloc(&dc, 256); hipMalloc(&dd, 256); hipMalloc(&dl, 256); hipMalloc(&doc, 256); hipMalloc(&dot, 256);
+    hipMalloc(&dr, 256); hipMalloc(&dk, 256); hipMalloc(&don, 256);
+    hipMemcpy(dc, hc, 256, hipMemcpyHostToDevice); hipMemcpy(dd, hd, 256, hipMemcpyHostToDevice); hipMemcpy(dl, hl, 256, hipMemcpyHostToDevice);
+    hipMemcpy(dr, hr, 256, hipMemcpyHostToDevice); hipMemcpy(dk, hk, 256, hipMemcpyHostToDevice);
+    probe_skip<<<1, 64>>>(dc, dd, dl, dr, dk, doc, don, dot);
+    hipMemcpy(oc, doc, 256, hipMemcpyDeviceToHost); hipMemcpy(on, don, 256, hipMemcpyDeviceToHost); hipMemcpy(ot, dot, 256, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int i = 0; i < 64; ++i) {
+        volatile float c = hc[i], t = hc[i];
+        const float ad = hd[i] < 0 ? -hd[i] : hd[i];
+        int n = 0;
+        while (n <= hr[i] && c <= hl[i]) { c = c + ad; n++; }
+        for (int k = 0; k < hk[i]; ++k) t = t + ad;
+        const bool dead = n > hr[i];
+        const bool ok = (dead ? on[i] > hr[i] : (on[i] == n && oc[i] == c)) && ot[i] == t;
+        if (!ok) { if (bad < 4) printf("skip lane %d: n %d want %d  c %g want %g  t %g want %g\n", i, on[i], n, oc[i], (float)c, ot[i], (float)t); bad++; }
+    }
+    printf("skip-loop mismatches %d\n", bad);
+    return bad;
+}
+
 int main() {
     uint32_t h[64];
     for (int i = 0; i < 64; ++i) h[i] = (i % 3 == 0) ? 0u : (uint32_t)i; // lanes 0,3,6,... borrow when active
@@ -73,7 +138,7 @@ int main() {
         if ((uint32_t)ho[2 + i] != want) bad++;
     }
     printf("borrow %016llx expect %016llx  cmp %016llx expect %016llx  vgpr_mismatch %d\n", ho[0], expect, ho[1], region, bad);
-    const bool ok = ho[0] == expect && ho[1] == region && bad == 0 && check_idxen() == 0;
+    const bool ok = ho[0] == expect && ho[1] == region && bad == 0 && check_idxen() == 0 && check_skip_loops() == 0;
     printf(ok ? "ISA_PROBE_OK\n" : "ISA_PROBE_FAIL\n");
     return ok ? 0 : 1;
 }

@@ -953,37 +953,44 @@ VRT_DI float next_below(float t) { // the largest float < t (t finite)
     const uint32_t b = __builtin_bit_cast(uint32_t, t);
     return __builtin_bit_cast(float, t > 0.0f ? b - 1u : (t < 0.0f ? b + 1u : 0x80000001u));
 }
-// t after `count` further additions of |inv| (per lane): 2 vector + 1 scalar instruction and the branch per step
+// t after `count` further additions of |inv| (per lane): 2 vector + 1 scalar instruction per step, four steps per back edge
+#define VRT_SKIP_ADD_STEP                                        \
+    "v_add_co_u32_e32 %[n], vcc, -1, %[n]\n\t" /* carry-out: the count was >= 1 */ \
+    "s_and_b64 exec, exec, vcc\n\t"                              \
+    "v_add_f32_e64 %[t], %[t], |%[d]|\n\t"
 VRT_DI void skip_add_gfx950(float &t, float inv, int count) {
     unsigned long long save;
     asm volatile("s_mov_b64 %[save], exec\n\t"
-                 "0:\n\t"
-                 "v_add_co_u32_e32 %[n], vcc, -1, %[n]\n\t" /* carry-out: the count was >= 1 */
-                 "s_and_b64 exec, exec, vcc\n\t"
-                 "v_add_f32_e64 %[t], %[t], |%[d]|\n\t"
+                 "0:\n\t" VRT_SKIP_ADD_STEP VRT_SKIP_ADD_STEP VRT_SKIP_ADD_STEP VRT_SKIP_ADD_STEP
                  "s_cbranch_execnz 0b\n\t"
                  "s_mov_b64 exec, %[save]"
                  : [t] "+v"(t), [n] "+v"(count), [save] "=&s"(save)
                  : [d] "v"(inv)
                  : "vcc", "scc");
 }
-// consume the elements c, c+|inv|, ... of another axis that are <= lim, at most `left`+1 of them (the last one crosses the far
-// face of the box: left ends at -1); `left` is the axis' steps-left counter: 3 vector + 2 scalar instructions per step
-VRT_DI void skip_merge_gfx950(float &c, float inv, int &left, float lim) {
+#undef VRT_SKIP_ADD_STEP
+// Consume the elements c, c+|inv|, ... of another axis that are <= lim; returns how many.  The axis has `left` steps before
+// the far face of the box: a lane that consumes more has left the box, and what it holds afterwards is never used — so the
+// bound is tested once per four steps only (v_cmpx drops a lane from EXEC the moment its element is beyond lim): 3 vector
+// instructions per step, one more and the branch per four.
+#define VRT_SKIP_MERGE_STEP                                      \
+    "v_cmpx_le_f32_e32 vcc, %[c], %[lim]\n\t"                    \
+    "v_add_f32_e64 %[c], %[c], |%[d]|\n\t"                       \
+    "v_add_u32_e32 %[n], 1, %[n]\n\t"
+VRT_DI int skip_merge_gfx950(float &c, float inv, int left, float lim) {
     unsigned long long save;
+    int n = 0;
     asm volatile("s_mov_b64 %[save], exec\n\t"
-                 "0:\n\t"
-                 "v_cmp_le_f32_e32 vcc, %[c], %[lim]\n\t"
-                 "s_and_b64 exec, exec, vcc\n\t"
-                 "v_add_f32_e64 %[c], %[c], |%[d]|\n\t"
-                 "v_add_co_u32_e32 %[r], vcc, -1, %[r]\n\t" /* carry-out: a step was left; none: the lane leaves the box here */
-                 "s_and_b64 exec, exec, vcc\n\t"
+                 "0:\n\t" VRT_SKIP_MERGE_STEP VRT_SKIP_MERGE_STEP VRT_SKIP_MERGE_STEP VRT_SKIP_MERGE_STEP
+                 "v_cmpx_ge_i32_e32 vcc, %[r], %[n]\n\t"
                  "s_cbranch_execnz 0b\n\t"
                  "s_mov_b64 exec, %[save]"
-                 : [c] "+v"(c), [r] "+v"(left), [save] "=&s"(save)
-                 : [d] "v"(inv), [lim] "v"(lim)
+                 : [c] "+v"(c), [n] "+v"(n), [save] "=&s"(save)
+                 : [d] "v"(inv), [lim] "v"(lim), [r] "v"(left)
                  : "vcc", "scc");
+    return n;
 }
+#undef VRT_SKIP_MERGE_STEP
 VRT_DI float &comp3(f3 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 VRT_DI float comp3(const f3 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 // one round: bring axis A (compile time) inside the box's range for the lanes that are in front of it
@@ -1003,12 +1010,13 @@ VRT_DI void skip_round(Walk &w, const RaySetup &s, int span, uint32_t &index, ui
         float t = comp3(w.side_dist, A);
         skip_add_gfx950(t, comp3(s.inv_dir, A), need - 1);
         const float t_strict = next_below(t); // c < t  <=>  c <= t_strict
-        const int r1 = *r[B1], r2 = *r[B2];
-        skip_merge_gfx950(comp3(w.side_dist, B1), comp3(s.inv_dir, B1), *r[B1], B1 > A ? t : t_strict);
-        skip_merge_gfx950(comp3(w.side_dist, B2), comp3(s.inv_dir, B2), *r[B2], B2 > A ? t : t_strict);
+        const int n1 = skip_merge_gfx950(comp3(w.side_dist, B1), comp3(s.inv_dir, B1), *r[B1], B1 > A ? t : t_strict);
+        const int n2 = skip_merge_gfx950(comp3(w.side_dist, B2), comp3(s.inv_dir, B2), *r[B2], B2 > A ? t : t_strict);
         comp3(w.side_dist, A) = t + comp3(s.ray_delta, A);
         *r[A] -= need;
-        index += (uint32_t)need * stride[A] + (uint32_t)(r1 - *r[B1]) * stride[B1] + (uint32_t)(r2 - *r[B2]) * stride[B2];
+        *r[B1] -= n1;
+        *r[B2] -= n2;
+        index += (uint32_t)need * stride[A] + (uint32_t)n1 * stride[B1] + (uint32_t)n2 * stride[B2];
         more = (*r[B1] | *r[B2]) >= 0; // a counter below zero: the far face of the box was crossed on the way
         in_axis = A;
         t_in = t;
@@ -1039,7 +1047,10 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     VRT_COUNT(rays);
     VRT_PROF_BEGIN(tp3);
     RaySetup s;
-    if (!grid_slab(p, r, t_min, t_max, s)) return false;
+    VRT_PROF_BEGIN(tp6);
+    const bool slab_hit = grid_slab(p, r, t_min, t_max, s);
+    VRT_PROF_END(6, tp6);
+    if (!slab_hit) return false;
 
     const f3 g_min = mk3(p.grid.min_point_base_t[0], p.grid.min_point_base_t[1], p.grid.min_point_base_t[2]);
     const float g_scale = p.grid.max_point_scale[3];
@@ -1094,8 +1105,10 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     [[maybe_unused]] bool skipped = false;
     [[maybe_unused]] float skip_t = 0.0f;
     if ((!COUNT || p.count_box) && p.cell_bounds && p.skip_to_box) {
+        VRT_PROF_BEGIN(tp5);
         skipped = skip_to_box(w, s, hix - lox, hiy - loy, hiz - loz, grid_index, stride_x, stride_y, stride_z, more, axis, skip_t);
         w.t_value = skip_t;
+        VRT_PROF_END(5, tp5);
     }
 
     auto cell_occupied = [&]() -> bool {
