@@ -31,4 +31,4 @@ print(f"  walk loop: {n_calls/1e6:.2f} M calls, {n_alive_in/n_calls:.1f} lanes a
 print(f"  bricks: {n_brick/1e6:.2f} M rounds, {n_parked/n_brick:.1f} parked lanes per round, {t_brick/n_brick:.0f} cycles per round")
 rt.deinit(); rc.deinit()
 print(f"  inside the brick rounds (wave-cycles, share of all): voxel loops {100*bw[2]/tot:.1f} %, material test + hit record {100*bw[4]/tot:.1f} %, "
-      f"rest of the round (cell -> brick index -> first occupancy word, walk set-up) {100*(t_brick-bw[2]-bw[4])/tot:.1f} %")
+      f"brick staged in LDS / first word requested {100*bw[5]/tot:.1f} %, rest of the round (cell -> brick index, walk set-up, hit record) {100*(t_brick-bw[2]-bw[4]-bw[5])/tot:.1f} %")

@@ -687,6 +687,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         p.path_groups = 8u * (uint32_t)cus; // twice what 4 waves per SIMD hold: late groups find the counter exhausted and leave
         p.path_fin_batch = 32u;
         if (const char *e = std::getenv("VRT_PATH_FIN_BATCH")) p.path_fin_batch = (uint32_t)std::max(1, std::atoi(e)); // tuning knob
+        p.path_brick_lds = (cfg->brick_dimension == 8u) ? 1u : 0u;
+        if (const char *e = std::getenv("VRT_PATH_BRICK_LDS")) p.path_brick_lds = (std::atoi(e) && cfg->brick_dimension == 8u) ? 1u : 0u; // tuning knob (A/B)
+        p.path_eager_start = 0u;
+        if (const char *e = std::getenv("VRT_PATH_EAGER_START")) p.path_eager_start = std::atoi(e) ? 1u : 0u; // tuning knob (A/B)
         if (const char *e = std::getenv("VRT_PATH_GROUPS")) p.path_groups = (uint32_t)std::max(1, std::atoi(e));
     }
     p.width = cfg->width;

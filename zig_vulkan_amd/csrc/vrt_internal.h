@@ -98,6 +98,8 @@ struct TraceParams {
     uint32_t path_lds_bytes;             // vrt_path_kernel<FILTER>: power-of-two LDS allocation holding the block filter (0: grid not eligible)
     uint32_t path_groups;                // vrt_path_kernel: workgroups to launch (a few times what the GPU holds)
     uint32_t path_fin_batch;             // vrt_path_kernel: lanes that must be waiting before the wave leaves the walk loop for them
+    uint32_t path_brick_lds;             // vrt_path_kernel, 8^3 bricks: 1 = a lane's brick is staged in LDS for the voxel-level walk (16 KiB per workgroup)
+    uint32_t path_eager_start;           // ... and its brick_start_index entry is requested together with the brick (one dependent miss less per hit)
     uint32_t count_box;                  // counting build only: 1 = walk to the occupied-cell box like the product kernel (issued loads)
     uint32_t skip_to_box;                // 1: rays that enter the grid in front of the occupied-cell box jump to its near face (skip_to_box())
     uint32_t tile_order;                 // workgroup -> tile mapping: 1 row bands per XCD, 2 column bands per XCD, 3 reverse raster, 4 strided,

@@ -387,19 +387,19 @@ struct GridParkRegs {
 #define VRT_IN_FROM(MX, MY) "v_cndmask_b32_e64 %[t0], 2, 1, %[" MY "]\n\t" "v_cndmask_b32_e64 %[t0], %[t0], 0, %[" MX "]\n\t"
 #define VRT_SWAP_SETS "v_swap_b32 %[tsa], %[tsb]\n\t" "v_swap_b32 %[idxa], %[idxb]\n\t"
 
-#define VRT_PARK_WALK_ASM(LIMIT) \
+#define VRT_PARK_WALK_ASM(LIMIT, LOAD, WAITALL) \
         "s_mov_b64 %[save], exec\n\t" \
         "s_mov_b64 exec, %[alive]\n\t" \
         "s_mov_b64 %[parked], 0\n\t" \
-        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, VRT_LOAD_BUFFER, "10f") \
+        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, "10f") \
         "0:\n\t" \
-        VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, VRT_LOAD_BUFFER, "11f") \
+        VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, "11f") \
         "21:\n\t" \
-        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, VRT_LOAD_BUFFER, "12f") \
+        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, "12f") \
         "22:\n\t" \
-        VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, VRT_LOAD_BUFFER, "13f") \
+        VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, "13f") \
         "23:\n\t" \
-        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, VRT_LOAD_BUFFER, "14f") \
+        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, "14f") \
         "24:\n\t" \
         "s_cbranch_execz 31f\n\t" \
         /* back edge (after an A trip): keep walking while at least min_alive lanes are moving; fewer -> hand the wave back \
@@ -415,7 +415,7 @@ struct GridParkRegs {
         VRT_PARK("14", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "24b", "30f") \
         "30:\n\t" /* the last trip was an A trip: swap the sets of the lanes still moving */ \
         "s_mov_b64 %[alive], exec\n\t" \
-        VRT_WAIT_BUFFER \
+        WAITALL \
         VRT_SWAP_SETS \
         "v_mov_b32_e32 %[worda], %[wordb]\n\t" \
         "s_mov_b64 %[mxb], %[mxa]\n\t" \
@@ -423,7 +423,7 @@ struct GridParkRegs {
         "s_branch 32f\n\t" \
         "31:\n\t" \
         "s_mov_b64 %[alive], exec\n\t" \
-        VRT_WAIT_BUFFER /* the compiler may move `word`: no load may be in flight outside */ \
+        WAITALL /* the compiler may move `word`: no load may be in flight outside */ \
         "32:\n\t" \
         "s_mov_b64 exec, %[save]"
 #define VRT_PARK_WALK_OPERANDS                                                                                                                   \
@@ -441,7 +441,7 @@ VRT_DI void grid_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, u
     unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb, n;
-    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS : "vcc", "scc");
+    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_BUFFER, VRT_WAIT_BUFFER) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS : "vcc", "scc");
 }
 
 // The voxel level on the same park loop (vrt_path_kernel): voxels of one brick, bits of brick_occupancy by their global bit
@@ -453,7 +453,35 @@ VRT_DI void voxel_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, 
     unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb, n;
-    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
+    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_BUFFER, VRT_WAIT_BUFFER) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
+}
+
+// The same with the brick's occupancy bits staged in LDS (8^3 bricks: 64 bytes = 16 words per lane).  On a scene larger than
+// the caches the lanes of a round stand in ~25 different bricks; every trip of the loop above asks the L1 for one more word of
+// each, the L1 has long dropped the line, and the trip waits for an L2 round trip (a request is only one trip ahead): ~600
+// cycles x ~15 trips of the longest lane.  Here the lane's whole brick is fetched ONCE by four global_load_lds_dwordx4 in flight
+// together (chunk c of lane l lands at wave base + 1024 c + 16 l: the layout the instruction dictates; tools/ubench/glds_probe.hip)
+// and the trips read LDS: word w of the brick at lane base + ((w >> 2) << 10) + ((w & 3) << 2), w = (bit index >> 5) & 15.
+#define VRT_LOAD_LDS_BRICK(IDXN, WORDN)                                   \
+    "v_lshrrev_b32_e32 %[t2], 3, %[" IDXN "]\n\t"                         \
+    "v_and_b32_e32 %[t0], 48, %[t2]\n\t"                                 \
+    "v_and_or_b32 %[t2], %[t2], 12, %[lb]\n\t"                           \
+    "v_lshl_add_u32 %[t2], %[t0], 6, %[t2]\n\t"                          \
+    "ds_read_b32 %[" WORDN "], %[t2]\n\t"                                \
+    "s_waitcnt lgkmcnt(1)\n\t"
+VRT_DI void voxel_walk_park_lds_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
+                                       uint32_t &word, uint32_t lane_base, GridParkRegs &g, float scale, float t_max) {
+    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
+    float t0, t1, t2;
+    uint32_t wordb, n;
+    const uint32_t rsrc = 0u; // (operand of the shared input list; unused)
+    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_LDS_BRICK, VRT_WAIT_LDS) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max), [lb] "v"(lane_base) : "vcc", "scc");
+}
+#undef VRT_LOAD_LDS_BRICK
+// byte address (LDS) of the word that holds bit `bit_index` of the lane's staged brick
+VRT_DI uint32_t brick_lds_address(uint32_t lane_base, uint32_t bit_index) {
+    const uint32_t w = (bit_index >> 5) & 15u;
+    return lane_base + ((w >> 2) << 10) + ((w & 3u) << 2);
 }
 #undef VRT_PARK_WALK_ASM
 #undef VRT_PARK_WALK_OPERANDS
@@ -850,9 +878,12 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
 // for all of them at once — on a scene larger than the caches it is three dependent cache misses (start index -> material id ->
 // material), and brick_walk_gfx950 pays them once per lane that finds a voxel (22 % of the wave-cycles of the 2048^3 path trace,
 // tools/path_profile.py).  A lane whose voxel is to be ignored (comp:427) walks on in the next pass.
-template <int B>
+// LDS (8^3 bricks): the lane's brick is staged at LDS byte address wave_lds + 1024 c + 16 lane (c = 0..3) and walked there
+// (voxel_walk_park_lds_gfx950).
+template <int B, bool LDS = false>
 VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t brick_index, f3 brick_min, Hit &hit,
-                                   int axis_in, int &hit_axis) {
+                                   int axis_in, int &hit_axis, uint32_t wave_lds = 0u) {
+    static_assert(!LDS || B == 8, "the LDS layout is written for 64-byte bricks");
     const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
     const float voxel_scale = g_scale * brick_voxel_scale;
     const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
@@ -879,7 +910,27 @@ VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const Ray
     rsrc.z = p.occupancy_words;
     rsrc.w = 0x00020000u;
     const uint32_t *occ_words = reinterpret_cast<const uint32_t *>(p.brick_occupancy);
-    uint32_t word = occ_words[more ? (bit_index >> 5) : 0u];
+    typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+    [[maybe_unused]] const uint32_t lane_base = wave_lds + ((threadIdx.x & 63u) << 4);
+    uint32_t word;
+    [[maybe_unused]] uint32_t eager_start = 0u;
+    VRT_PROF_BEGIN(tp5);
+    if constexpr (LDS) {
+        const uint32_t *src = occ_words + (size_t)brick_index * 16u;
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef const __attribute__((address_space(1))) void glb_void;
+        lds_void *dst = reinterpret_cast<lds_void *>((size_t)__builtin_amdgcn_readfirstlane(wave_lds));
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            __builtin_amdgcn_global_load_lds((glb_void *)(src + 4 * c), (lds_void *)((__attribute__((address_space(3))) char *)dst + 1024 * c), 16, 0, 0);
+        // (path_eager_start: the brick's start index travels with the four chunks instead of after the walk)
+        if (p.path_eager_start) eager_start = p.brick_start_index[brick_index];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        word = reinterpret_cast<lds_u32 *>(0)[brick_lds_address(lane_base, bit_index) >> 2];
+    } else {
+        word = occ_words[more ? (bit_index >> 5) : 0u];
+    }
+    VRT_PROF_END(5, tp5);
     GridParkRegs g;
     g.alive = __builtin_amdgcn_ballot_w64(more);
     g.out_x = 0ull;
@@ -892,13 +943,17 @@ VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const Ray
     bool found = false;
     while (g.alive != 0ull) {
         uint32_t solid_bit; // parked lanes: bit index of the solid voxel they left behind
-        voxel_walk_park_gfx950(w, s.inv_dir, bit_index, solid_bit, stride_x, stride_y, stride_z, word, rsrc, g, voxel_scale, local_t_max);
+        VRT_PROF_BEGIN(tp2);
+        if constexpr (LDS) voxel_walk_park_lds_gfx950(w, s.inv_dir, bit_index, solid_bit, stride_x, stride_y, stride_z, word, lane_base, g, voxel_scale, local_t_max);
+        else voxel_walk_park_gfx950(w, s.inv_dir, bit_index, solid_bit, stride_x, stride_y, stride_z, word, rsrc, g, voxel_scale, local_t_max);
+        VRT_PROF_END(2, tp2);
         if (g.parked == 0ull) break; // every lane has left the brick (or the grid box)
         const bool parked = __builtin_amdgcn_inverse_ballot_w64(g.parked);
         bool resume = false;
+        VRT_PROF_BEGIN(tp4);
         if (parked) {
             const uint32_t voxel_index = solid_bit - base;
-            const uint32_t brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu; // comp:422
+            const uint32_t brick_material_index = ((LDS && p.path_eager_start) ? eager_start : p.brick_start_index[brick_index]) & 0x7FFFFFFFu; // comp:422
             const uint32_t mi = p.material_index[brick_material_index + voxel_index];
             const vrt_material *m = p.materials + mi;
             const uint32_t mtype = m->type;
@@ -916,10 +971,14 @@ VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const Ray
                 resume = min3i(w.rx, w.ry, w.rz) >= 0 && (voxel_scale * g.t_out <= local_t_max);
             }
         }
+        VRT_PROF_END(4, tp4);
         // every lane: the axis of its last step, for its first trip in the next call
         g.code = parked ? ((g.code >> 2) & 3u) << 4
                         : (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
-        if (resume) word = occ_words[bit_index >> 5]; // (an A-trip park left the lane's word in the other register set)
+        if (resume) { // (an A-trip park left the lane's word in the other register set)
+            if constexpr (LDS) word = reinterpret_cast<lds_u32 *>(0)[brick_lds_address(lane_base, bit_index) >> 2];
+            else word = occ_words[bit_index >> 5];
+        }
         asm("s_or_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(resume)) : "scc");
     }
     return found;
@@ -1713,6 +1772,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TracePar
         fc.shyb = lx + lz - 4u;
         fc.ldsmask = p.path_lds_bytes - 4u;
     }
+    // brick staging area of this wave (8^3 bricks, p.path_brick_lds): 4 KiB behind the block filter, as an LDS byte address
+    [[maybe_unused]] const uint32_t wave_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds_block_filter +
+                                               (FILTER ? p.path_lds_bytes : 0u) + (threadIdx.x >> 6) * 4096u;
     const PushConstants &pc = p.pcs[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = p.owned_tiles * (uint32_t)(kTileW * kTileH);
@@ -2026,7 +2088,13 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TracePar
                 const float global_t_value = g.t_in * g_scale + s.grid_t_min + 0.01f * g_scale;          // comp:347 (deferred) + comp:332
                 hit.t = global_t_value;
                 const uint32_t brick_index = p.brick_index[cell]; // comp:337
-                const bool hit_voxel = brick_walk_park_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, a, hit_axis);
+                bool hit_voxel;
+                if constexpr (B == 8) {
+                    hit_voxel = p.path_brick_lds ? brick_walk_park_gfx950<B, true>(p, r, s, g_scale, brick_index, brick_min, hit, a, hit_axis, wave_lds)
+                                                 : brick_walk_park_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, a, hit_axis);
+                } else {
+                    hit_voxel = brick_walk_park_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, a, hit_axis);
+                }
                 if (hit_voxel) {
                     found = true;
                     st = kLaneDone;
@@ -2464,7 +2532,7 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
         hipError_t e = hipMemsetAsync(p.work_counter, 0, kMaxBatchFrames * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
         const uint32_t groups = p.owned_tiles < p.path_groups ? p.owned_tiles : p.path_groups;
-        hipLaunchKernelGGL(fn, dim3(groups, frames), dim3(256), is_path_filter_kernel(fn) ? p.path_lds_bytes : 0u, stream, p);
+        hipLaunchKernelGGL(fn, dim3(groups, frames), dim3(256), (is_path_filter_kernel(fn) ? p.path_lds_bytes : 0u) + (p.path_brick_lds ? 4u * 4096u : 0u), stream, p);
         return hipGetLastError();
     }
     // grid.y = the frames of this launch (p.pcs[0 .. frames-1]); workgroups are dispatched x-fastest, so the tiles of
