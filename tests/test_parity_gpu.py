@@ -416,6 +416,8 @@ def test_random_scenes_fuzz_slice():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.fuzz(60, 5, verbose=False) == 0
+    # grids the path kernel's block filter accepts, frames with bounces: the block-skipping walk (skip_empty_block)
+    assert mod.fuzz(24, 11, big=True, verbose=False, pow2=True) == 0
 
 
 def test_walk_ends_at_the_bounding_box_of_the_occupied_cells():
@@ -477,7 +479,7 @@ def test_walk_ends_at_the_bounding_box_of_the_occupied_cells():
 # ---- vrt_path_kernel (frames with bounces, persistent lanes): chosen by the library for scenes larger than the caches, forced
 # ---- here (kernel_variant bit 23) on small scenes so that whole frames can be compared with the oracle
 PATH = 1 << 23
-PATH_FILTER = PATH | (1 << 22)      # ... with the walk loop behind the LDS block filter (x, z dimensions powers of two)
+PATH_FILTER = PATH | (1 << 22)      # ... with the block-skipping walk: lanes in empty 4x4x4 blocks of cells jump to the block's exit face (x, z dimensions powers of two)
 PATH_5WAVES = PATH | (5 << 8)
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity fuzz (usage: fuzz_parity.py [cases] [seed] [big]): random small grids (odd dimensions, both brick sizes, any
+"""Randomised parity fuzz (usage: fuzz_parity.py [cases] [seed] [big|pow2]; pow2: grids and frames that take vrt_path_kernel's block-skipping walk): random small grids (odd dimensions, both brick sizes, any
 scale, sparse allocation), random materials incl. glass / metal / unknown types, random cameras inside and outside the
 box, samples 1-3, bounces 0-2, sun on/off with and without jitter — product kernel against the oracle, whole frames,
 float target bit for bit.  The committed tests pin chosen cases; this looks for the ones nobody chose.  A mismatching case is
@@ -11,19 +11,25 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from zig_vulkan_amd import BrickGrid, Config, CameraConfig, SunConfig, VoxelRT, default_materials
 from helpers import O, oracle_scene_from_grid
 
-def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True) -> int:
+def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: bool = False) -> int:
     """Returns the number of mismatching cases."""
     rng = np.random.default_rng(seed)
     bad = 0
     for case in range(cases):
         b = int(rng.choice([4, 8]))
         dims = [int(rng.integers(1, 25 if big else 9)) for _ in range(3)]
+        if pow2:  # grids the path kernel's block filter accepts: x, z powers of two >= 4, y a multiple of 4
+            dims = [int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 12, 16, 20])), int(rng.choice([4, 8, 16, 32]))]
         scale = float(rng.choice([0.5, 1.0, 2.0, 0.3, 1.7, 4.0]))
         min_point = [float(-0.5 * d * scale + rng.normal() * 0.3) for d in dims]
         cells = dims[0] * dims[1] * dims[2]
         grid = BrickGrid(*dims, min_point=min_point, scale=scale, brick_dimension=b)
         n = int(rng.integers(1, max(2, int(0.2 * cells * b ** 3))))
         xyz = np.stack([rng.integers(0, b * d, n) for d in dims], axis=-1)
+        if pow2 and rng.random() < 0.7:  # mostly empty space with a few clumps: whole 4x4x4 blocks of cells without a voxel
+            k = int(rng.integers(1, 6))
+            centres = np.stack([rng.integers(0, b * d, k) for d in dims], axis=-1)
+            xyz = np.clip(centres[rng.integers(0, k, n)] + rng.integers(-2 * b, 2 * b + 1, (n, 3)), 0, np.array(dims) * b - 1)
         if rng.random() < 0.5:  # the occupied cells fill only a sub-box of the grid: rays enter the grid in front of it (skip_to_box)
             lo = [int(rng.integers(0, d)) for d in dims]
             hi = [int(rng.integers(l, d)) for l, d in zip(lo, dims)]
@@ -40,11 +46,13 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True) -> int:
         mats[13] = (1, 0.7, 0.6, 0.5, 0.6)
         w, h = int(rng.integers(1, 400 if big else 90)), int(rng.integers(1, 260 if big else 70))
         spp, bounce = int(rng.integers(1, 4)), int(rng.integers(0, 3))
+        if pow2:
+            bounce = int(rng.integers(1, 4))
         sun_on, radius = bool(rng.random() < 0.7), float(rng.choice([0.0, 5.0, 40.0]))
         rt = VoxelRT(grid, Config(internal_resolution_width=w, internal_resolution_height=h, camera=CameraConfig(samples_per_pixel=spp, max_bounce=bounce),
                                   sun=SunConfig(enabled=sun_on, radius=radius), want_float_output=True,
                                   kernel_variant=int(rng.choice([0, 0, 6, 1, 0x10070000, 0x10070000, 1 << 23, (1 << 23) | (1 << 22), (1 << 23) | (5 << 8), (1 << 23) | (2 << 24)])) if big
-                                  else int(rng.choice([0, 0, 1 << 23]))))
+                                  else int(rng.choice([(1 << 23) | (1 << 22), (1 << 23) | (1 << 22) | (5 << 8), 1 << 23]) if pow2 else rng.choice([0, 0, 1 << 23]))))
         rt.push_materials(mats)
         size = np.array(dims) * scale
         centre = np.array(min_point) + 0.5 * size
@@ -88,4 +96,4 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True) -> int:
 
 if __name__ == "__main__":
     sys.exit(1 if fuzz(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 7,
-                       len(sys.argv) > 3 and sys.argv[3] == "big") else 0)
+                       len(sys.argv) > 3 and sys.argv[3] in ("big", "pow2"), pow2=len(sys.argv) > 3 and sys.argv[3] == "pow2") else 0)

@@ -617,16 +617,22 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
                                         ? (cfg->kernel_variant | (uint32_t)vrt::kVariantBytes) : cfg->kernel_variant;
     const uint32_t lockstep_variant = c->bounce_variant | vrt::kVariantLockstepBounce; // (before the path kernel's occupancy is filled in below)
     {
-        // vrt_path_kernel behind the LDS block filter: x and z dimensions powers of two >= 4, filter <= 32 KiB (so that four
-        // workgroups per CU keep their copies), cell index < 2^31
+        // vrt_path_kernel with the LDS block filter: x and z dimensions powers of two >= 4, y a multiple of 4, filter <= 32 KiB
+        // (two 640-thread workgroups per CU keep their copies next to the staged bricks), cell index < 2^31
         auto pow2 = [](uint32_t v) { return v >= 4u && (v & (v - 1u)) == 0u; };
         const uint64_t nblocks64 = (uint64_t)((cfg->dim_x + 3u) / 4u) * ((cfg->dim_y + 3u) / 4u) * ((cfg->dim_z + 3u) / 4u);
         size_t bytes = 16;
         while (bytes < ((nblocks64 + 31u) / 32u) * 4u) bytes <<= 1;
-        // Opt-in (kernel_variant bit 22): measured SLOWER than the plain loop on the 2048^3 path-trace configuration (215 against
-        // 204 ms per frame): the walk is not bound by the L1's line rate after all, and the trip grows from 31 to 45 instructions.
-        if ((cfg->kernel_variant & vrt::kVariantPathFilter) && pow2(cfg->dim_x) && pow2(cfg->dim_z) && cfg->dim_y % 4u == 0u && bytes <= (32u << 10)) {
+        // Opt-in (kernel_variant bit 22, or VRT_PATH_BLOCK_SKIP=1): the block-skipping walk (vrt_path_kernel<FILTER>: lanes in
+        // empty 4x4x4 blocks jump to the block's exit face instead of taking a trip per cell).  Measured on the 2048^3 path trace:
+        // 10 % fewer wave-cycles per frame, but the filter's 32 KiB of LDS allow four waves per SIMD instead of five, and the
+        // frame takes 200 ms against 176.
+        const bool eligible = pow2(cfg->dim_x) && pow2(cfg->dim_z) && cfg->dim_y % 4u == 0u && bytes <= (32u << 10);
+        bool block_skip = eligible && (cfg->kernel_variant & vrt::kVariantPathFilter) != 0u;
+        if (const char *e = std::getenv("VRT_PATH_BLOCK_SKIP")) block_skip = eligible && std::atoi(e) != 0; // tuning knob (A/B)
+        if (block_skip) {
             c->path_lds_bytes = (uint32_t)bytes;
+            c->bounce_variant |= vrt::kVariantPathFilter;
         } else {
             c->bounce_variant &= ~vrt::kVariantPathFilter;
         }
@@ -689,6 +695,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (const char *e = std::getenv("VRT_PATH_FIN_BATCH")) p.path_fin_batch = (uint32_t)std::max(1, std::atoi(e)); // tuning knob
         p.path_brick_lds = (cfg->brick_dimension == 8u) ? 1u : 0u;
         if (const char *e = std::getenv("VRT_PATH_BRICK_LDS")) p.path_brick_lds = (std::atoi(e) && cfg->brick_dimension == 8u) ? 1u : 0u; // tuning knob (A/B)
+        p.path_skip_rounds = 8u;
+        p.path_ready_batch = 32u;
+        if (const char *e = std::getenv("VRT_PATH_SKIP_ROUNDS")) p.path_skip_rounds = (uint32_t)std::max(1, std::atoi(e)); // tuning knobs
+        if (const char *e = std::getenv("VRT_PATH_READY_BATCH")) p.path_ready_batch = (uint32_t)std::max(1, std::atoi(e));
         p.path_eager_start = 0u;
         if (const char *e = std::getenv("VRT_PATH_EAGER_START")) p.path_eager_start = std::atoi(e) ? 1u : 0u; // tuning knob (A/B)
         if (const char *e = std::getenv("VRT_PATH_GROUPS")) p.path_groups = (uint32_t)std::max(1, std::atoi(e));

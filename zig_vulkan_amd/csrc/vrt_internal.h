@@ -98,6 +98,8 @@ struct TraceParams {
     uint32_t path_lds_bytes;             // vrt_path_kernel<FILTER>: power-of-two LDS allocation holding the block filter (0: grid not eligible)
     uint32_t path_groups;                // vrt_path_kernel: workgroups to launch (a few times what the GPU holds)
     uint32_t path_fin_batch;             // vrt_path_kernel: lanes that must be waiting before the wave leaves the walk loop for them
+    uint32_t path_skip_rounds;           // vrt_path_kernel<FILTER>: block look-ups (and jumps over empty blocks) per lane between two calls of the trip loop
+    uint32_t path_ready_batch;           // ... unless this many lanes already stand in blocks that hold occupied cells
     uint32_t path_brick_lds;             // vrt_path_kernel, 8^3 bricks: 1 = a lane's brick is staged in LDS for the voxel-level walk (16 KiB per workgroup)
     uint32_t path_eager_start;           // ... and its brick_start_index entry is requested together with the brick (one dependent miss less per hit)
     uint32_t count_box;                  // counting build only: 1 = walk to the occupied-cell box like the product kernel (issued loads)
@@ -129,7 +131,8 @@ enum : uint32_t {
 // neither: the library chooses by the size of the scene (vrt_create)
 constexpr uint32_t kVariantLockstepBounce = 1u << 21;
 constexpr uint32_t kVariantForcePath = 1u << 23;
-// bit 22: vrt_path_kernel behind the LDS block filter (grids whose x and z dimensions are powers of two; measured slower, opt-in)
+// bit 22: vrt_path_kernel with the block-skipping walk (LDS block filter; grids whose x and z dimensions are powers of two, y a
+// multiple of 4; fewer wave-cycles but one wave per SIMD less: measured slower, opt-in)
 constexpr uint32_t kVariantPathFilter = 1u << 22;
 
 } // namespace vrt

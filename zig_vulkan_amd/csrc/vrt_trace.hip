@@ -486,131 +486,20 @@ VRT_DI uint32_t brick_lds_address(uint32_t lane_base, uint32_t bit_index) {
 #undef VRT_PARK_WALK_ASM
 #undef VRT_PARK_WALK_OPERANDS
 #undef VRT_PARK_WALK_INPUTS
-// ---- the park loop behind a block filter in LDS (vrt_path_kernel) ----------------------------------------------------
-// A wave-wide status request of INCOHERENT rays touches one 128-byte line per lane, and the L1 takes about one line
-// per cycle per CU: with 54 lanes walking, a trip of the loop above costs ~700 cycles per wave at 4 waves per SIMD
-// (tools/path_profile.py) — the walk is bound by the L1's line rate, not by its instructions.  Most of those requests
-// ask about cells in empty space.  Here the 1-bit-per-4x4x4-cells filter that vrt_build_status_blocks derives from
-// binding 3 is staged in LDS once per workgroup, every trip looks the next cell's BLOCK up there (ds_read_b32: LDS
-// serves 64 scattered dwords in a few cycles), and only the lanes whose block holds an occupied cell request the
-// status word; the others take 0, which is what the word's bit would be.  Same bits tested, same sequence per lane.
-// The block index is formed from the linear cell index by bit fields, so the grid's x and z dimensions must be powers of
-// two >= 4 (every BASELINE configuration); other grids use the loop above.
-// Order within a trip: step -> next index -> filter lookup issued -> wait for the word requested a trip ago -> test it,
-// counters, exits -> filter bit -> masked request for the next word.  At most one request is in flight, waited for with
-// vmcnt(0), so nothing depends on how a request with an empty EXEC is counted.
+// ---- block filter (vrt_path_kernel<FILTER>) ---------------------------------------------------------------------------
+// The 1-bit-per-4x4x4-cells filter that vrt_build_status_blocks derives from binding 3 ("some cell of the block is occupied"),
+// staged in LDS once per workgroup.  The block index is formed from the linear cell index by bit fields, so the grid's x and z
+// dimensions must be powers of two >= 4 and y a multiple of 4 (every BASELINE configuration); other grids walk cell by cell.
+// (Round 2 first used the filter only to suppress status requests for cells of empty blocks, one trip per cell as before:
+// slower, 215 against 204 ms on the 2048^3 path trace.  Now a lane in an empty block JUMPS to the block's exit face,
+// skip_empty_block, and only lanes in non-empty blocks take trips.)
 struct FilterConsts {
-    uint32_t wx;    // log2(dim_x) - 2: width of the x block field
-    uint32_t shz;   // log2(dim_x) + 2: the z block field starts here in the cell index
-    uint32_t mz;    // (dim_z >> 2) - 1
-    uint32_t shy;   // log2(dim_x) + log2(dim_z) + 2
-    uint32_t shyb;  // log2(dim_x) + log2(dim_z) - 4: where the y block field goes in the block index
-    uint32_t ldsmask; // (power-of-two LDS allocation) - 4: byte address mask
+    uint32_t wx;   // log2(dim_x) - 2: width of the x block field
+    uint32_t shz;  // log2(dim_x) + 2: the z block field starts here in the cell index
+    uint32_t mz;   // (dim_z >> 2) - 1
+    uint32_t shy;  // log2(dim_x) + log2(dim_z) + 2
+    uint32_t shyb; // log2(dim_x) + log2(dim_z) - 4: where the y block field goes in the block index
 };
-
-#define VRT_TRIPF(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, OUT)             \
-    "v_cmp_lt_f32_e64 %[" MX "], %[sdx], %[sdy]\n\t"                      \
-    "v_cmp_lt_f32_e64 %[" MXY "], %[sdx], %[sdz]\n\t"                     \
-    "v_cmp_lt_f32_e64 %[" MY "], %[sdy], %[sdz]\n\t"                      \
-    "v_add_f32_e64 %[t0], %[sdx], |%[ix]|\n\t"                            \
-    "v_add_f32_e64 %[t1], %[sdy], |%[iy]|\n\t"                            \
-    "v_add_f32_e64 %[t2], %[sdz], |%[iz]|\n\t"                            \
-    "s_andn2_b64 %[" MY "], %[" MY "], %[" MX "]\n\t"                     \
-    "s_and_b64 %[" MX "], %[" MX "], %[" MXY "]\n\t"                      \
-    "s_or_b64 %[" MXY "], %[" MX "], %[" MY "]\n\t"                       \
-    /* the crossed distance = the side distance of the crossed axis = the smallest of the three (ties: equal values; a   \
-       walk never holds a NaN side distance: safeInverse keeps 1/dir finite and NaN rays fail the slab test) */            \
-    "v_min3_f32 %[" TS "], %[sdx], %[sdy], %[sdz]\n\t"                    \
-    "v_cndmask_b32_e64 %[sdx], %[sdx], %[t0], %[" MX "]\n\t"              \
-    "v_cndmask_b32_e64 %[sdy], %[sdy], %[t1], %[" MY "]\n\t"              \
-    "v_cndmask_b32_e64 %[sdz], %[t2], %[sdz], %[" MXY "]\n\t"             \
-    "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[" MY "]\n\t"              \
-    "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[" MX "]\n\t"               \
-    "v_add_u32_e32 %[" IDXN "], %[" IDX "], %[t0]\n\t"                    \
-    /* block of the next cell: x>>2 | (z>>2) << wx | (y>>2) << shyb */    \
-    "v_bfe_u32 %[t2], %[" IDXN "], 2, %[wx]\n\t"                          \
-    "v_lshrrev_b32_e32 %[t0], %[shz], %[" IDXN "]\n\t"                    \
-    "v_and_b32_e32 %[t0], %[mz], %[t0]\n\t"                               \
-    "v_lshl_or_b32 %[t2], %[t0], %[wx], %[t2]\n\t"                        \
-    "v_lshrrev_b32_e32 %[t0], %[shy], %[" IDXN "]\n\t"                    \
-    "v_lshl_or_b32 %[t2], %[t0], %[shyb], %[t2]\n\t"                      \
-    "v_lshrrev_b32_e32 %[t0], 3, %[t2]\n\t"                               \
-    "v_and_b32_e32 %[t0], %[ldsmask], %[t0]\n\t"                          \
-    "ds_read_b32 %[t0], %[t0]\n\t"                                        \
-    /* the cell just left: its word was requested one trip ago */         \
-    "s_waitcnt vmcnt(0)\n\t"                                              \
-    "v_bfe_u32 %[t1], %[" WORD "], %[" IDX "], 1\n\t"                     \
-    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"                                  \
-    "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[" MX "]\n\t"          \
-    "v_subbrev_co_u32_e64 %[ry], %[by], 0, %[ry], %[" MY "]\n\t"          \
-    "v_addc_co_u32_e64 %[rz], %[cz], -1, %[rz], %[" MXY "]\n\t"           \
-    "s_or_b64 %[ex], %[ex], %[by]\n\t"                                    \
-    "s_orn2_b64 %[ex], %[ex], %[cz]\n\t" /* z: carry-out 0 = borrow */    \
-    "s_andn2_b64 exec, exec, %[ex]\n\t"                                   \
-    /* the next cell's word, only where its block is not empty */         \
-    "s_waitcnt lgkmcnt(0)\n\t"                                            \
-    "v_bfe_u32 %[t0], %[t0], %[t2], 1\n\t"                                \
-    "v_mov_b32_e32 %[" WORDN "], 0\n\t"                                   \
-    "v_cmp_ne_u32_e64 %[by], 0, %[t0]\n\t"                                \
-    "s_and_saveexec_b64 %[cz], %[by]\n\t"                                 \
-    "v_lshrrev_b32_e32 %[t2], 5, %[" IDXN "]\n\t"                         \
-    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"         \
-    "s_mov_b64 exec, %[cz]\n\t"                                           \
-    "s_cbranch_vccnz " OUT "\n\t"
-
-VRT_DI void grid_walk_park_filter_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
-                                         uint32_t &word, u32x4 rsrc, GridParkRegs &g, const FilterConsts &fc) {
-    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
-    float t0, t1, t2;
-    uint32_t wordb, n;
-    asm volatile(
-        "s_mov_b64 %[save], exec\n\t"
-        "s_mov_b64 exec, %[alive]\n\t"
-        "s_mov_b64 %[parked], 0\n\t"
-        VRT_TRIPF("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", "10f")
-        "0:\n\t"
-        VRT_TRIPF("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", "11f")
-        "21:\n\t"
-        VRT_TRIPF("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", "12f")
-        "22:\n\t"
-        VRT_TRIPF("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", "13f")
-        "23:\n\t"
-        VRT_TRIPF("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", "14f")
-        "24:\n\t"
-        "s_cbranch_execz 31f\n\t"
-        "s_bcnt1_i32_b64 %[n], exec\n\t"
-        "s_cmp_ge_u32 %[n], %[minalive]\n\t"
-        "s_cbranch_scc1 0b\n\t"
-        "s_branch 30f\n\t"
-        VRT_PARK("10", VRT_IN_FROM_CODE, "mxa", "mya", VRT_SWAP_SETS, "0b", "30f")
-        VRT_PARK("11", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "21b", "31f")
-        VRT_PARK("12", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "22b", "30f")
-        VRT_PARK("13", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "23b", "31f")
-        VRT_PARK("14", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "24b", "30f")
-        "30:\n\t" /* the last trip was an A trip: swap the sets of the lanes still moving */
-        "s_mov_b64 %[alive], exec\n\t"
-        VRT_WAIT_BUFFER
-        VRT_SWAP_SETS
-        "v_mov_b32_e32 %[worda], %[wordb]\n\t"
-        "s_mov_b64 %[mxb], %[mxa]\n\t"
-        "s_mov_b64 %[myb], %[mya]\n\t"
-        "s_branch 32f\n\t"
-        "31:\n\t"
-        "s_mov_b64 %[alive], exec\n\t"
-        VRT_WAIT_BUFFER /* the compiler may move `word`: no load may be in flight outside */
-        "32:\n\t"
-        "s_mov_b64 exec, %[save]"
-        : [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),
-          [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(word), [wordb] "=&v"(wordb), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in),
-          [code] "+v"(g.code), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive),
-          [mxa] "=&s"(mxa), [mya] "=&s"(mya), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz),
-          [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n)
-        : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z), [rsrc] "s"(rsrc),
-          [batch] "s"(g.batch), [minalive] "s"(g.min_alive), [wx] "s"(fc.wx), [shz] "s"(fc.shz), [mz] "s"(fc.mz), [shy] "s"(fc.shy), [shyb] "s"(fc.shyb),
-          [ldsmask] "s"(fc.ldsmask)
-        : "vcc", "scc", "memory");
-}
-#undef VRT_TRIPF
 #undef VRT_PARK
 #undef VRT_IN_FROM_CODE
 #undef VRT_IN_FROM
@@ -1052,33 +941,41 @@ VRT_DI int skip_merge_gfx950(float &c, float inv, int left, float lim) {
 #undef VRT_SKIP_MERGE_STEP
 VRT_DI float &comp3(f3 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 VRT_DI float comp3(const f3 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
-// one round: bring axis A (compile time) inside the box's range for the lanes that are in front of it
+// The lane crosses axis A (compile time) `need` more times, the last time at distance t (= A's side distance after need-1
+// additions): consume what the other two axes hold before t in merge order and move the walk state behind that crossing.
 template <int A>
-VRT_DI void skip_round(Walk &w, const RaySetup &s, int span, uint32_t &index, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z, bool &more,
-                       int &in_axis, float &t_in, bool &skipped) {
+VRT_DI void skip_axis(Walk &w, const RaySetup &s, int need, float t, uint32_t &index, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z, bool &more,
+                      int &in_axis, float &t_in) {
     constexpr int B1 = (A + 1) % 3, B2 = (A + 2) % 3; // the other two axes; an axis wins a tie against A iff it comes later in x, y, z
     int *const r[3] = {&w.rx, &w.ry, &w.rz};
     const uint32_t stride[3] = {stride_x, stride_y, stride_z};
+    const float t_strict = next_below(t); // c < t  <=>  c <= t_strict
+    const int n1 = skip_merge_gfx950(comp3(w.side_dist, B1), comp3(s.inv_dir, B1), *r[B1], B1 > A ? t : t_strict);
+    const int n2 = skip_merge_gfx950(comp3(w.side_dist, B2), comp3(s.inv_dir, B2), *r[B2], B2 > A ? t : t_strict);
+    comp3(w.side_dist, A) = t + comp3(s.ray_delta, A);
+    *r[A] -= need;
+    *r[B1] -= n1;
+    *r[B2] -= n2;
+    index += (uint32_t)need * stride[A] + (uint32_t)n1 * stride[B1] + (uint32_t)n2 * stride[B2];
+    more = (*r[A] | *r[B1] | *r[B2]) >= 0; // a counter below zero: the far face of the box was crossed on the way
+    in_axis = A;
+    t_in = t;
+}
+// one round: bring axis A inside the box's range for the lanes that are in front of it
+template <int A>
+VRT_DI void skip_round(Walk &w, const RaySetup &s, int span, uint32_t &index, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z, bool &more,
+                       int &in_axis, float &t_in, bool &skipped) {
     const int step_a = A == 0 ? s.sx : (A == 1 ? s.sy : s.sz);
+    const int r_a = A == 0 ? w.rx : (A == 1 ? w.ry : w.rz);
     // crossings still to go before the near face (steps left to the FAR face minus the box's extent); an axis the ray does not
     // move along holds the hang-guard budget instead and never needs any
-    const int need = step_a != 0 ? *r[A] - span : 0;
+    const int need = step_a != 0 ? r_a - span : 0;
     const bool want = more && need > 0;
     if (__builtin_amdgcn_ballot_w64(want) == 0ull) return;
     if (want) {
         float t = comp3(w.side_dist, A);
         skip_add_gfx950(t, comp3(s.inv_dir, A), need - 1);
-        const float t_strict = next_below(t); // c < t  <=>  c <= t_strict
-        const int n1 = skip_merge_gfx950(comp3(w.side_dist, B1), comp3(s.inv_dir, B1), *r[B1], B1 > A ? t : t_strict);
-        const int n2 = skip_merge_gfx950(comp3(w.side_dist, B2), comp3(s.inv_dir, B2), *r[B2], B2 > A ? t : t_strict);
-        comp3(w.side_dist, A) = t + comp3(s.ray_delta, A);
-        *r[A] -= need;
-        *r[B1] -= n1;
-        *r[B2] -= n2;
-        index += (uint32_t)need * stride[A] + (uint32_t)n1 * stride[B1] + (uint32_t)n2 * stride[B2];
-        more = (*r[B1] | *r[B2]) >= 0; // a counter below zero: the far face of the box was crossed on the way
-        in_axis = A;
-        t_in = t;
+        skip_axis<A>(w, s, need, t, index, stride_x, stride_y, stride_z, more, in_axis, t_in);
         skipped = true;
     }
 }
@@ -1089,6 +986,56 @@ VRT_DI bool skip_to_box(Walk &w, const RaySetup &s, int span_x, int span_y, int 
     skip_round<1>(w, s, span_y, index, stride_x, stride_y, stride_z, more, in_axis, t_in, skipped);
     skip_round<2>(w, s, span_z, index, stride_x, stride_y, stride_z, more, in_axis, t_in, skipped);
     return skipped;
+}
+
+// The lane stands in a 4x4x4 block of cells that holds no occupied cell (at cell (bx, by, bz) of it): jump behind the step
+// that leaves the block.  Each axis has its exit crossing (the e-th from now, e = cells to the block's face in the ray's
+// direction + 1, at the side distance after e-1 additions); the one that comes first in merge order (smallest distance; z
+// before y before x among equals, as the walk picks) is the step that leaves the block, and everything before it is consumed
+// exactly as skip_to_box does.  ~100 vector instructions and no memory access for what would be one to ten trips.
+VRT_DI void skip_empty_block(Walk &w, const RaySetup &s, uint32_t bx, uint32_t by, uint32_t bz, uint32_t &index, uint32_t stride_x, uint32_t stride_y,
+                             uint32_t stride_z, bool &more, int &in_axis, float &t_in) {
+    const int ex = s.sx > 0 ? 4 - (int)bx : (int)bx + 1, ey = s.sy > 0 ? 4 - (int)by : (int)by + 1, ez = s.sz > 0 ? 4 - (int)bz : (int)bz + 1;
+    auto exit_distance = [](float sd, float d, int e, int step) {
+        const float a1 = sd + d, a2 = a1 + d, a3 = a2 + d;
+        const float t = e == 1 ? sd : (e == 2 ? a1 : (e == 3 ? a2 : a3));
+        return step != 0 ? t : __builtin_inff(); // an axis the ray does not move along is never crossed
+    };
+    const float tx = exit_distance(w.side_dist.x, s.ray_delta.x, ex, s.sx);
+    const float ty = exit_distance(w.side_dist.y, s.ray_delta.y, ey, s.sy);
+    const float tz = exit_distance(w.side_dist.z, s.ray_delta.z, ez, s.sz);
+    const bool az = tz <= tx && tz <= ty, ay = !az && ty <= tx, ax = !az && !ay;
+    const float t = ax ? tx : (ay ? ty : tz);
+    const float t_strict = next_below(t); // c < t  <=>  c <= t_strict
+    // The other two axes: their elements that precede t in merge order (x loses every tie, z wins every tie, y wins against x
+    // only) — at most three each, their own exit crossing comes later.  Straight-line: no loop, no lane mask juggling.
+    const float never = -__builtin_inff();
+    auto consume = [](float &c, float d, float lim, int &n) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const bool before = c <= lim;
+            c = before ? c + d : c;
+            n += before ? 1 : 0;
+        }
+    };
+    float cx = w.side_dist.x, cy = w.side_dist.y, cz = w.side_dist.z;
+    int nx = 0, ny = 0, nz = 0;
+    consume(cx, s.ray_delta.x, ax ? never : t_strict, nx);
+    consume(cy, s.ray_delta.y, ay ? never : (ax ? t : t_strict), ny);
+    consume(cz, s.ray_delta.z, az ? never : t, nz);
+    w.side_dist.x = ax ? t + s.ray_delta.x : cx;
+    w.side_dist.y = ay ? t + s.ray_delta.y : cy;
+    w.side_dist.z = az ? t + s.ray_delta.z : cz;
+    nx = ax ? ex : nx;
+    ny = ay ? ey : ny;
+    nz = az ? ez : nz;
+    w.rx -= nx;
+    w.ry -= ny;
+    w.rz -= nz;
+    index += (uint32_t)nx * stride_x + (uint32_t)ny * stride_y + (uint32_t)nz * stride_z;
+    more = (w.rx | w.ry | w.rz) >= 0; // a counter below zero: the far face of the box of occupied cells was crossed on the way
+    in_axis = ax ? 0 : (ay ? 1 : 2);
+    t_in = t;
 }
 
 // comp:271-376.  t_min = 1e-5, t_max = +inf at every call site (comp:218,247).
@@ -1752,8 +1699,12 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
 // are traced one after the other by the lane that owns the pixel and summed in order, so frames are bit-identical.
 enum : int { kLaneFetch = 0, kLaneSample, kLaneStart, kLaneWalk, kLaneDone, kLaneEnd, kLaneStore, kLaneExit };
 
+// FILTER: 512-thread workgroups (eight waves, two per SIMD, share one LDS copy of the block filter); two workgroups per CU:
+// 2 x (32 KiB filter + 8 x 4 KiB of staged bricks) = 128 of the CU's 160 KiB, four waves per SIMD.  (640-thread groups for five
+// waves per SIMD do not pair up: ten waves leave the SIMDs 3/3/2/2, and 96 registers do not admit a sixth wave.)
+constexpr int kPathFilterThreads = 512;
 template <int B, int MIN_WAVES, bool FILTER>
-__global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TraceParams p) {
+__global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN_WAVES) void vrt_path_kernel(const TraceParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_block_filter[];
     FilterConsts fc{};
     if constexpr (FILTER) {
@@ -1770,7 +1721,6 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TracePar
         fc.mz = (p.grid.dim_z >> 2) - 1u;
         fc.shy = lx + lz + 2u;
         fc.shyb = lx + lz - 4u;
-        fc.ldsmask = p.path_lds_bytes - 4u;
     }
     // brick staging area of this wave (8^3 bricks, p.path_brick_lds): 4 KiB behind the block filter, as an LDS byte address
     [[maybe_unused]] const uint32_t wave_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds_block_filter +
@@ -1844,6 +1794,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TracePar
     g.t_out = g.t_in = 0.0f;
     g.code = 3u << 4;
     g.batch = p.path_brick_batch;
+    // FILTER: a walking lane is `ready` once its cell is known to lie in a block that holds occupied cells (it takes trips);
+    // otherwise its block is looked up, and jumped over if empty.  `stale`: the lane has jumped since `word` was loaded.
+    [[maybe_unused]] bool ready = false, stale = false;
 
     bool work_left = true; // wave-uniform
 #ifdef VRT_DEV_PROFILE
@@ -2043,7 +1996,12 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TracePar
                     // ... unless the ray enters the grid in front of the occupied-cell box and jumps to its near face
                     if (p.cell_bounds && p.skip_to_box) skip_to_box(w, s, hix - lox, hiy - loy, hiz - loz, grid_index, stride_x, stride_y, stride_z, more, in_axis, skip_t);
                     if (more) {
-                        word = p.brick_status[grid_index >> 5];
+                        if constexpr (FILTER) {
+                            ready = false;
+                            stale = true; // (the word is requested when the lane is about to take trips)
+                        } else {
+                            word = p.brick_status[grid_index >> 5];
+                        }
                         g.t_out = skip_t;
                         g.code = (uint32_t)in_axis << 4;
                         st = kLaneWalk;
@@ -2053,16 +2011,50 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TracePar
         }
         VRT_PF_T(0, pf0);
         // (7) every lane that has a ray walks (comp:314-375), until enough of them are done for the next round of transitions
-        const unsigned long long walking = __builtin_amdgcn_ballot_w64(st == kLaneWalk);
+        unsigned long long walking = __builtin_amdgcn_ballot_w64(st == kLaneWalk);
         if (walking == 0ull) continue;
         [[maybe_unused]] const unsigned long long pf1 = VRT_PF_NOW();
+        if constexpr (FILTER) {
+            // (7a) lanes whose block is not known to hold occupied cells: look the block up (LDS); empty -> jump behind the step
+            // that leaves it (no memory access), and again, until enough lanes are ready for trips or the round's budget is spent
+            for (uint32_t it = 0; it < p.path_skip_rounds; it++) {
+                const bool seeking = (st == kLaneWalk) && !ready;
+                if (__builtin_amdgcn_ballot_w64(seeking) == 0ull) break;
+                if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kLaneWalk && ready)) >= p.path_ready_batch) break;
+                if (seeking) {
+                    const uint32_t bi = ((grid_index >> 2) & ((1u << fc.wx) - 1u)) | (((grid_index >> fc.shz) & fc.mz) << fc.wx) | ((grid_index >> fc.shy) << fc.shyb);
+                    if ((lds_block_filter[bi >> 5] >> (bi & 31u)) & 1u) {
+                        ready = true;
+                    } else {
+                        bool more = true;
+                        int in_axis = 0;
+                        float t_in = 0.0f;
+                        skip_empty_block(w, s, grid_index & 3u, (grid_index >> (fc.shy - 2u)) & 3u, (grid_index >> (fc.wx + 2u)) & 3u, grid_index, stride_x, stride_y,
+                                         stride_z, more, in_axis, t_in);
+                        g.t_out = t_in;
+                        g.code = (uint32_t)in_axis << 4;
+                        stale = true;
+                        if (!more) {
+                            found = false; // left the box of the occupied cells
+                            st = kLaneDone;
+                        }
+                    }
+                }
+            }
+            walking = __builtin_amdgcn_ballot_w64(st == kLaneWalk && ready);
+            if (walking == 0ull) continue;
+            if (st == kLaneWalk && ready && stale) {
+                word = p.brick_status[grid_index >> 5];
+                stale = false;
+            }
+        }
         const uint32_t n_walking = (uint32_t)__builtin_popcountll(walking);
         const uint32_t fin = min(p.path_fin_batch, max(1u, n_walking >> 1));
         g.alive = walking;
-        g.min_alive = n_walking >= fin ? n_walking - fin + 1u : 1u;
+        // (FILTER: five trips per call, the way through a block of four cells; then the blocks are looked up again)
+        g.min_alive = FILTER ? 65u : (n_walking >= fin ? n_walking - fin + 1u : 1u);
         uint32_t cell; // the occupied cell each parked lane stood on before its last step
-        if constexpr (FILTER) grid_walk_park_filter_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g, fc);
-        else grid_walk_park_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
+        grid_walk_park_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
         VRT_PF_T(1, pf1);
         VRT_PF_N(2, 1);
         VRT_PF_N(3, n_walking);
@@ -2074,6 +2066,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TracePar
         if (was_walking && !parked && !moving) {
             found = false; // left the box of the occupied cells
             st = kLaneDone;
+        }
+        if constexpr (FILTER) {
+            if (was_walking) ready = false; // it has moved: its block is looked up again
         }
         if (g.parked != 0ull) {
             VRT_PF_N(5, 1);
@@ -2106,9 +2101,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_path_kernel(const TracePar
                 }
             }
         }
-        // every lane: the axis of its last step, for its first trip in the next call
-        g.code = parked ? ((g.code >> 2) & 3u) << 4
-                        : (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
+        // every lane of the call: the axis of its last step, for its first trip in the next call
+        if (was_walking)
+            g.code = parked ? ((g.code >> 2) & 3u) << 4
+                            : (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
         VRT_PF_T(2, pf2);
     }
 #ifdef VRT_DEV_PROFILE
@@ -2531,8 +2527,11 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
         if (!p.work_counter) return hipErrorInvalidValue;
         hipError_t e = hipMemsetAsync(p.work_counter, 0, kMaxBatchFrames * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
-        const uint32_t groups = p.owned_tiles < p.path_groups ? p.owned_tiles : p.path_groups;
-        hipLaunchKernelGGL(fn, dim3(groups, frames), dim3(256), (is_path_filter_kernel(fn) ? p.path_lds_bytes : 0u) + (p.path_brick_lds ? 4u * 4096u : 0u), stream, p);
+        const bool filter = is_path_filter_kernel(fn);
+        const uint32_t threads = filter ? (uint32_t)kPathFilterThreads : 256u;
+        const uint32_t want = filter ? (p.path_groups * 256u + threads - 1u) / threads : p.path_groups;
+        const uint32_t groups = p.owned_tiles < want ? p.owned_tiles : want;
+        hipLaunchKernelGGL(fn, dim3(groups, frames), dim3(threads), (filter ? p.path_lds_bytes : 0u) + (p.path_brick_lds ? (threads >> 6) * 4096u : 0u), stream, p);
         return hipGetLastError();
     }
     // grid.y = the frames of this launch (p.pcs[0 .. frames-1]); workgroups are dispatched x-fastest, so the tiles of
