@@ -1,0 +1,58 @@
+"""Resource usage of the shipped kernels, read from the code object inside libvrt_hip.so (no GPU needed).
+
+The hand-scheduled kernels depend on register budgets the compiler must not silently leave: the one-sample kernel runs at
+7 waves per SIMD (72 VGPRs) without scratch, the path kernel at 5 (96 VGPRs).  And no kernel may own STATIC LDS: round 2 saw
+the optimiser move a whole per-lane struct (RaySetup) to LDS because of one select over its members — 12 KiB per workgroup and
++20 % on the headline frame, with identical instruction counts.  This test is the tripwire for that class of regression."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zig_vulkan_amd", "libvrt_hip.so")
+
+
+def _kernels():
+    if not (os.path.exists(os.path.join(LLVM, "llvm-objdump")) and os.path.exists(os.path.join(LLVM, "llvm-readelf"))):
+        pytest.skip("llvm-objdump / llvm-readelf not found under /opt/rocm/lib/llvm/bin")
+    if not os.path.exists(LIB):
+        pytest.skip("libvrt_hip.so not built")
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        shutil.copy(LIB, os.path.join(d, "lib.so"))
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "lib.so"], cwd=d, check=True, capture_output=True)
+        for name in sorted(os.listdir(d)):
+            if "gfx950" not in name:
+                continue
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", name], cwd=d, check=True, capture_output=True, text=True).stdout
+            for m in re.finditer(r"\.group_segment_fixed_size: (\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size: (\d+).*?\.vgpr_count:\s+(\d+)", notes, re.S):
+                lds, kname, scratch, vgpr = m.groups()
+                out[kname] = dict(lds=int(lds), scratch=int(scratch), vgpr=int(vgpr))
+    assert len(out) > 100
+    return out
+
+
+def test_no_kernel_owns_static_lds_except_the_schedule_kernel():
+    for name, k in _kernels().items():
+        if "vrt_schedule_kernel" in name:
+            continue
+        assert k["lds"] == 0, f"{name}: {k['lds']} bytes of static LDS (a per-lane struct promoted to LDS?)"
+
+
+def test_one_sample_kernels_hold_7_waves_without_scratch():
+    """vrt_trace_kernel<B, COUNT 0, MODE words / bytes, MIN_WAVES 7, SHADE 2>: what frames without bounces at 1 spp run."""
+    ks = {n: k for n, k in _kernels().items() if re.search(r"vrt_trace_kernelILi[48]ELb0ELi[47]ELi7ELi2ELi256E", n)}
+    assert len(ks) == 4
+    for name, k in ks.items():
+        assert k["vgpr"] <= 72 and k["scratch"] == 0, (name, k)
+
+
+def test_path_kernel_holds_5_waves():
+    ks = {n: k for n, k in _kernels().items() if re.search(r"vrt_path_kernelILi[48]ELi5ELb0E", n)}
+    assert len(ks) == 2
+    for name, k in ks.items():
+        assert k["vgpr"] <= 96 and k["scratch"] <= 128, (name, k)
