@@ -613,8 +613,10 @@ def main(argv=None) -> None:
             "traffic": traffic, "traffic_note": pmc_note,
             "definition": "achieved = bytes the REFERENCE algorithm loads for these frames (4 S + 4 K + V + 25 H per ray + 4 B per pixel, "
                           "SURVEY.md 8(d), counted by the counting build that walks to the grid's face like the shader) / kernel time: a rate "
-                          "of useful work, not of bytes moved.  issued_bytes = what the product kernel's lanes request (its walk ends at the "
-                          "occupied-cell box; 4 B per brick-level trip, 12 per brick entered, 4 per voxel trip, 21 per hit, 4 per pixel). "
+                          "of useful work, not of bytes moved — the product kernel never asks for the status words of cells it knows to "
+                          "be empty (it jumps to the near face of the occupied-cell box and stops at its far face), so frac can exceed 1 on "
+                          "views from outside the box.  issued_bytes = what the product kernel's lanes request (4 B per brick-level trip "
+                          "taken, 12 per brick entered, 4 per voxel trip, 21 per hit, 4 per pixel). "
                           "traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE): the touched scene data lives in L2 / MALL.",
             "kernel": rt1.kernel_name(), "settle_frames": settle_frames, "kernel_ms_avg": avg_ms, "kernel_ms_per_view": kernel_ms_view,
             "frame_ms_percentiles_per_view": frame_stats,
