@@ -52,7 +52,7 @@ def test_one_sample_kernels_hold_7_waves_without_scratch():
 
 
 def test_path_kernel_holds_5_waves():
-    ks = {n: k for n, k in _kernels().items() if re.search(r"vrt_path_kernelILi[48]ELi5ELb0E", n)}
-    assert len(ks) == 2
+    ks = {n: k for n, k in _kernels().items() if re.search(r"vrt_path_kernelILi[48]ELi5ELb0E", n)}   # plain and half-block walk
+    assert len(ks) == 4
     for name, k in ks.items():
         assert k["vgpr"] <= 96 and k["scratch"] <= 128, (name, k)

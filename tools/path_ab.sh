@@ -1,5 +1,5 @@
 set -u
 cd ${GRAFT_REPO_ROOT:-.}
-VRT_HIP_LIB=$PWD/tools/libvrt_hip_prof.so python tools/path_profile.py cfg4_4k_2048c_b8_sparse V0 2>&1 | grep -v amdgpu.ids
-for r in 2 4 16 32; do echo "== skip_rounds=$r"; VRT_PATH_SKIP_ROUNDS=$r python tools/variant_sweep.py cfg4_4k_2048c_b8_sparse 0 3 V0 2>&1 | grep -v amdgpu.ids | tail -1; done
-for r in 8 16 48 64; do echo "== ready_batch=$r"; VRT_PATH_READY_BATCH=$r python tools/variant_sweep.py cfg4_4k_2048c_b8_sparse 0 3 V0 2>&1 | grep -v amdgpu.ids | tail -1; done
+python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k "path or cfg4 or bounce" 2>&1 | grep -E "passed|failed|error" | tail -2
+timeout 900 python tools/fuzz_parity.py 60 8101 pow2 2>&1 | tail -2
+for l in 0 1; do echo "== cfg4 halfblocks=$l"; VRT_PATH_HALFBLOCKS=$l python tools/variant_sweep.py cfg4_4k_2048c_b8_sparse 0 3 V0,V1,V1x 2>&1 | grep -v amdgpu.ids | tail -1; done

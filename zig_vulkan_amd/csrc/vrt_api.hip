@@ -24,6 +24,7 @@
 namespace vrt {
 using KernelFn = void (*)(const TraceParams);
 KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, int shade);
+KernelFn path_kernel_halfblock_twin(KernelFn fn);
 uint32_t resolve_variant(uint32_t variant);
 size_t trace_lds_bytes(const TraceParams &p, uint32_t variant);
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream, uint32_t frames = 1);
@@ -34,6 +35,7 @@ hipError_t launch_assemble_rgb(const void *gathered, void *frame, uint32_t width
                                uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream, uint32_t frames, uint32_t frame_src_stride_bytes);
 hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_build_status_bytes(const TraceParams &p, hipStream_t stream);
+hipError_t launch_build_status_halfblocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_build_cell_bounds(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
                           void *out_f32, hipStream_t stream);
@@ -164,6 +166,7 @@ struct vrt_ctx {
     void *d_status_blocks = nullptr; // derived: 4x4x4 block words + block filter (vrt_trace.hip)
     int *d_cell_bounds = nullptr;    // derived: bounding box of the occupied cells (TraceParams::cell_bounds)
     uint8_t *d_status_bytes = nullptr; // derived: one byte per grid cell (TraceParams::status_bytes)
+    uint32_t *d_status_halfblocks = nullptr; // derived: status bits by 4 x 4 x 2 cells per word (vrt_path_kernel on eligible grids)
     vrt::TileOwnership own{};        // weighted tile ownership (period 0: tile t belongs to rank t % shard_count)
     bool status_dirty = true;        // brick_status changed since the derived copy was built
     size_t lds_bytes = 0;
@@ -230,6 +233,7 @@ void free_ctx(vrt_ctx *c) {
     if (c->d_status_blocks) (void)hipFree(c->d_status_blocks);
     if (c->d_cell_bounds) (void)hipFree(c->d_cell_bounds);
     if (c->d_status_bytes) (void)hipFree(c->d_status_bytes);
+    if (c->d_status_halfblocks) (void)hipFree(c->d_status_halfblocks);
     if (c->dist) {
         Dist *d = c->dist;
         for (uint32_t i = 0; i < d->nslots; i++) {
@@ -647,11 +651,21 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (want_path) {
             c->bounce_variant &= ~vrt::kVariantLockstepBounce;
             if (mwv == 0u) c->bounce_variant = (c->bounce_variant & ~0xFF00u) | (5u << 8);
+            // the path kernel's walk loop reads the status bits by half-blocks of 4 x 4 x 2 cells where the grid allows (x, z
+            // powers of two >= 4, y even): a third of the L1 requests of the linear words (vrt_trace.hip)
+            bool halfblocks = pow2(cfg->dim_x) && pow2(cfg->dim_z) && cfg->dim_y % 2u == 0u;
+            if (const char *e = std::getenv("VRT_PATH_HALFBLOCKS")) halfblocks = halfblocks && std::atoi(e) != 0; // tuning knob (A/B)
+            if (halfblocks) {
+                const size_t bytes_hb = (size_t)(cells / 32u) * 4u + 64u;
+                VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_status_halfblocks), bytes_hb));
+                VRT_CREATE_HIP(hipMemsetAsync(c->d_status_halfblocks, 0, bytes_hb, c->stream));
+            }
         } else {
             c->bounce_variant |= vrt::kVariantLockstepBounce;
         }
     }
     c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->bounce_variant, 0);
+    if (c->d_status_halfblocks) c->kernel = vrt::path_kernel_halfblock_twin(c->kernel);
     c->kernel_lockstep = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, lockstep_variant, 0);
     c->single_variant = single_variant;
     c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, single_variant, 1);
@@ -724,6 +738,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.status_blocks = static_cast<const uint2 *>(c->d_status_blocks);
     p.cell_bounds = c->d_cell_bounds;
     p.status_bytes = c->d_status_bytes;
+    p.status_halfblocks = c->d_status_halfblocks;
     p.status_cells = (uint32_t)cells;
     // (order_auto: frames that alternate between the two streams of a frames_in_flight = 2 context take reverse raster (3)
     // instead, see do_dispatch and DESIGN.md §4)
@@ -861,6 +876,7 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
         VRT_HIP(ctx, vrt::launch_build_status_blocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
         VRT_HIP(ctx, vrt::launch_build_cell_bounds(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
         VRT_HIP(ctx, vrt::launch_build_status_bytes(ctx->params, ctx->stream));
+        VRT_HIP(ctx, vrt::launch_build_status_halfblocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
         rcw = end_scene_write(ctx);
         if (rcw != VRT_OK) return rcw;
         ctx->status_dirty = false;
@@ -886,6 +902,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     if (ctx->d_counters) {
         const int shade = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? 2 : 1) : 0;
         product_fn = vrt::select_trace_kernel((int)ctx->cfg.brick_dimension, false, shade == 0 ? ctx->bounce_variant : ctx->single_variant, shade);
+        if (shade == 0 && ctx->d_status_halfblocks) product_fn = vrt::path_kernel_halfblock_twin(product_fn);
         if (!product_fn) return fail(ctx, VRT_E_STATE, "no product kernel for this configuration");
     }
 

@@ -72,6 +72,8 @@ struct TraceParams {
     // (0x80808080 in all six while no cell is occupied).  A ray that has left this box on the far side of an axis cannot meet an
     // occupied cell any more, so the brick-level walk of the product kernels ends there instead of at the grid's face.
     const int *cell_bounds;
+    // derived from binding 3: the status bits ordered by 4 x 4 x 2 cells per word (vrt_path_kernel's walk loop; nullptr: not used)
+    const uint32_t *status_halfblocks;
     // derived from binding 3: one byte per grid cell, 1 = occupied (kVariantBytes: the walk loop reads the byte of the next cell)
     const uint8_t *status_bytes;
     uint32_t status_cells;               // grid cells = bytes of status_bytes

@@ -199,7 +199,7 @@ struct GridWalkRegs {
     "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[" MY "]\n\t"              \
     "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[" MX "]\n\t"               \
     "v_add_u32_e32 %[" IDXN "], %[" IDX "], %[t0]\n\t"                    \
-    LOAD(IDXN, WORDN) /* request the next cell's word; wait for the one requested a trip ago */ \
+    LOAD(IDX, IDXN, WORD, WORDN) /* request the next cell's word; wait for the one requested a trip ago */ \
     TEST(WORD, IDX)                                                       \
     "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[" MX "]\n\t"          \
     "v_subbrev_co_u32_e64 %[ry], %[by], 0, %[ry], %[" MY "]\n\t"          \
@@ -219,7 +219,7 @@ struct GridWalkRegs {
 // upload), the byte itself: no shift for the address, no bit-field extract for the test — 16 instead of 18 vector instructions
 // per trip of a loop that is bound by the vector pipe (two cycles per wave64 instruction per SIMD)
 #define VRT_TEST_BYTE(WORD, IDX) "v_cmp_ne_u32_e32 vcc, 0, %[" WORD "]\n\t"
-#define VRT_LOAD_BYTE(IDXN, WORDN)                                        \
+#define VRT_LOAD_BYTE(IDX, IDXN, WORD, WORDN)                                        \
     "buffer_load_ubyte %[" WORDN "], %[" IDXN "], %[rsrc], 0 offen\n\t"   \
     "s_waitcnt vmcnt(1)\n\t"
 
@@ -228,12 +228,12 @@ struct GridWalkRegs {
 // LDS address 0, byte address masked into the power-of-two allocation.  The vector memory pipeline takes
 // one wave-wide scattered dword request per ~16 cycles per CU (tools/ubench/step_bench.hip: the trip runs at 63
 // cycles per SIMD with the buffer load, 40-44 without); LDS serves the same request several times faster.
-#define VRT_LOAD_BUFFER(IDXN, WORDN)                                      \
+#define VRT_LOAD_BUFFER(IDX, IDXN, WORD, WORDN)                                      \
     "v_lshrrev_b32_e32 %[t2], 5, %[" IDXN "]\n\t"                         \
     "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"         \
     "s_waitcnt vmcnt(1)\n\t"
 #define VRT_WAIT_BUFFER "s_waitcnt vmcnt(0)\n\t"
-#define VRT_LOAD_LDS(IDXN, WORDN)                                         \
+#define VRT_LOAD_LDS(IDX, IDXN, WORD, WORDN)                                         \
     "v_lshrrev_b32_e32 %[t2], 3, %[" IDXN "]\n\t"                         \
     "v_and_b32_e32 %[t2], %[rsrc], %[t2]\n\t"                             \
     "ds_read_b32 %[" WORDN "], %[t2]\n\t"                                 \
@@ -391,19 +391,19 @@ struct GridParkRegs {
 #define VRT_IN_FROM(MX, MY) "v_cndmask_b32_e64 %[t0], 2, 1, %[" MY "]\n\t" "v_cndmask_b32_e64 %[t0], %[t0], 0, %[" MX "]\n\t"
 #define VRT_SWAP_SETS "v_swap_b32 %[tsa], %[tsb]\n\t" "v_swap_b32 %[idxa], %[idxb]\n\t"
 
-#define VRT_PARK_WALK_ASM(LIMIT, LOAD, WAITALL) \
+#define VRT_PARK_WALK_ASM(LIMIT, LOAD, TEST, WAITALL) \
         "s_mov_b64 %[save], exec\n\t" \
         "s_mov_b64 exec, %[alive]\n\t" \
         "s_mov_b64 %[parked], 0\n\t" \
-        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, "10f") \
+        VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "10f") \
         "0:\n\t" \
-        VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, "11f") \
+        VRT_TRIP_T("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "11f") \
         "21:\n\t" \
-        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, "12f") \
+        VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "12f") \
         "22:\n\t" \
-        VRT_TRIP("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, "13f") \
+        VRT_TRIP_T("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "13f") \
         "23:\n\t" \
-        VRT_TRIP("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, "14f") \
+        VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "14f") \
         "24:\n\t" \
         "s_cbranch_execz 31f\n\t" \
         /* back edge (after an A trip): keep walking while at least min_alive lanes are moving; fewer -> hand the wave back \
@@ -445,7 +445,7 @@ VRT_DI void grid_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, u
     unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb, n;
-    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_BUFFER, VRT_WAIT_BUFFER) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS : "vcc", "scc");
+    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_BUFFER, VRT_TEST_BIT, VRT_WAIT_BUFFER) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS : "vcc", "scc");
 }
 
 // The voxel level on the same park loop (vrt_path_kernel): voxels of one brick, bits of brick_occupancy by their global bit
@@ -457,7 +457,7 @@ VRT_DI void voxel_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, 
     unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb, n;
-    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_BUFFER, VRT_WAIT_BUFFER) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
+    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_BUFFER, VRT_TEST_BIT, VRT_WAIT_BUFFER) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
 }
 
 // The same with the brick's occupancy bits staged in LDS (8^3 bricks: 64 bytes = 16 words per lane).  On a scene larger than
@@ -466,7 +466,7 @@ VRT_DI void voxel_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, 
 // cycles x ~15 trips of the longest lane.  Here the lane's whole brick is fetched ONCE by four global_load_lds_dwordx4 in flight
 // together (chunk c of lane l lands at wave base + 1024 c + 16 l: the layout the instruction dictates; tools/ubench/glds_probe.hip)
 // and the trips read LDS: word w of the brick at lane base + ((w >> 2) << 10) + ((w & 3) << 2), w = (bit index >> 5) & 15.
-#define VRT_LOAD_LDS_BRICK(IDXN, WORDN)                                   \
+#define VRT_LOAD_LDS_BRICK(IDX, IDXN, WORD, WORDN)                                   \
     "v_lshrrev_b32_e32 %[t2], 3, %[" IDXN "]\n\t"                         \
     "v_and_b32_e32 %[t0], 48, %[t2]\n\t"                                 \
     "v_and_or_b32 %[t2], %[t2], 12, %[lb]\n\t"                           \
@@ -479,13 +479,75 @@ VRT_DI void voxel_walk_park_lds_gfx950(Walk &w, const f3 &inv_dir, uint32_t &ind
     float t0, t1, t2;
     uint32_t wordb, n;
     const uint32_t rsrc = 0u; // (operand of the shared input list; unused)
-    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_LDS_BRICK, VRT_WAIT_LDS) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max), [lb] "v"(lane_base) : "vcc", "scc");
+    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_LDS_BRICK, VRT_TEST_BIT, VRT_WAIT_LDS) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max), [lb] "v"(lane_base) : "vcc", "scc");
 }
 #undef VRT_LOAD_LDS_BRICK
 // byte address (LDS) of the word that holds bit `bit_index` of the lane's staged brick
 VRT_DI uint32_t brick_lds_address(uint32_t lane_base, uint32_t bit_index) {
     const uint32_t w = (bit_index >> 5) & 15u;
     return lane_base + ((w >> 2) << 10) + ((w & 3u) << 2);
+}
+// ---- the brick-level park loop on HALF-BLOCK words (vrt_path_kernel on scenes larger than the caches) ---------------------
+// Measured on the 2048^3 path trace (tools/pmc_cfg4.sh): 64.5 G L1 accesses per frame, 0.58 per cycle per CU — a wave-wide
+// request of incoherent lanes is one tag look-up per lane, and the L1 handles about one per cycle; 77 % of them are the status
+// words of the walk loop, one per lane per trip, although the average L1 miss costs only ~190 cycles.  So the walk is bound by the
+// NUMBER of requests.  Here the status bits are read from a derived copy ordered by 4 x 4 x 2 cells (x, z, y) per 32-bit word
+// (TraceParams::status_halfblocks, bit (x&3) | (z&3) << 2 | (y&1) << 4): a lane asks for a word only when its step enters
+// another half-block — one step in three on average — and keeps the word otherwise.  Same bits tested, same sequence per lane.
+// The indices are formed from the linear cell index by bit fields: x and z dimensions powers of two >= 4, y even.
+// Every trip issues exactly one request (if no lane changes its half-block, all lanes re-request theirs), so vmcnt(1) still
+// means "the word asked for a trip ago has arrived".
+struct HalfBlockConsts {
+    // cell index = x | z << lx | y << (lx + lz); word index = x >> 2 | (z >> 2) << (lx - 2) | (y >> 1) << (lx + lz - 4)
+    //            = ((index >> 2) & mx) | ((index >> 4) & mzs) | ((index >> 5) & mys)
+    uint32_t nmask; // ~(3 | 3 << lx | 1 << (lx + lz)): two cell indices in the same half-block agree in these bits
+    uint32_t mx;    // (1 << (lx - 2)) - 1
+    uint32_t mzs;   // ((dim_z >> 2) - 1) << (lx - 2)
+    uint32_t mys;   // ~((1 << (lx + lz - 4)) - 1)
+    uint32_t lx;    // log2(dim_x): z & 3 starts here
+    uint32_t lxz;   // log2(dim_x) + log2(dim_z): y & 1 is this bit
+};
+#define VRT_LOAD_HALFBLOCK(IDX, IDXN, WORD, WORDN)                         \
+    "v_xor_b32_e32 %[t2], %[" IDXN "], %[" IDX "]\n\t"                     \
+    "v_and_b32_e32 %[t2], %[nmask], %[t2]\n\t"                             \
+    "v_cmp_ne_u32_e64 %[by], 0, %[t2]\n\t" /* lanes whose step enters another half-block */ \
+    "s_cmp_eq_u64 %[by], 0\n\t"                                            \
+    "s_cselect_b64 %[by], exec, %[by]\n\t" /* nobody: everybody asks again (one request per trip, always) */ \
+    "s_and_saveexec_b64 %[cz], %[by]\n\t"                                  \
+    "v_lshrrev_b32_e32 %[t2], 2, %[" IDXN "]\n\t"                          \
+    "v_and_b32_e32 %[t2], %[mx], %[t2]\n\t"                                \
+    "v_lshrrev_b32_e32 %[t0], 4, %[" IDXN "]\n\t"                          \
+    "v_and_or_b32 %[t2], %[t0], %[mzs], %[t2]\n\t"                         \
+    "v_lshrrev_b32_e32 %[t0], 5, %[" IDXN "]\n\t"                          \
+    "v_and_or_b32 %[t2], %[t0], %[mys], %[t2]\n\t"                         \
+    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"          \
+    "s_andn2_b64 exec, %[cz], %[by]\n\t"   /* the lanes that stay in their half-block keep its word */ \
+    "s_waitcnt vmcnt(1)\n\t"                                               \
+    "v_mov_b32_e32 %[" WORDN "], %[" WORD "]\n\t"                          \
+    "s_mov_b64 exec, %[cz]\n\t"
+#define VRT_TEST_HALFBLOCK(WORD, IDX)                                      \
+    "v_bfe_u32 %[t1], %[" IDX "], %[lx], 2\n\t"                            \
+    "v_and_b32_e32 %[t0], 3, %[" IDX "]\n\t"                               \
+    "v_lshl_or_b32 %[t0], %[t1], 2, %[t0]\n\t"                             \
+    "v_bfe_u32 %[t1], %[" IDX "], %[lxz], 1\n\t"                           \
+    "v_lshl_or_b32 %[t0], %[t1], 4, %[t0]\n\t"                             \
+    "v_bfe_u32 %[t1], %[" WORD "], %[t0], 1\n\t"                           \
+    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"
+VRT_DI void grid_walk_park_halfblocks_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
+                                             uint32_t &word, u32x4 rsrc, GridParkRegs &g, const HalfBlockConsts &hb) {
+    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
+    float t0, t1, t2;
+    uint32_t wordb, n;
+    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_HALFBLOCK, VRT_TEST_HALFBLOCK, VRT_WAIT_BUFFER)
+                 : VRT_PARK_WALK_OPERANDS
+                 : VRT_PARK_WALK_INPUTS, [nmask] "s"(hb.nmask), [mx] "s"(hb.mx), [mzs] "s"(hb.mzs), [mys] "s"(hb.mys), [lx] "s"(hb.lx), [lxz] "s"(hb.lxz)
+                 : "vcc", "scc");
+}
+#undef VRT_LOAD_HALFBLOCK
+#undef VRT_TEST_HALFBLOCK
+// index of the half-block word that holds cell `index`
+VRT_DI uint32_t halfblock_word(const HalfBlockConsts &hb, uint32_t index) {
+    return ((index >> 2) & hb.mx) | ((index >> 4) & hb.mzs) | ((index >> 5) & hb.mys);
 }
 #undef VRT_PARK_WALK_ASM
 #undef VRT_PARK_WALK_OPERANDS
@@ -1708,7 +1770,7 @@ enum : int { kLaneFetch = 0, kLaneSample, kLaneStart, kLaneWalk, kLaneDone, kLan
 // 2 x (32 KiB filter + 8 x 4 KiB of staged bricks) = 128 of the CU's 160 KiB, four waves per SIMD.  (640-thread groups for five
 // waves per SIMD do not pair up: ten waves leave the SIMDs 3/3/2/2, and 96 registers do not admit a sixth wave.)
 constexpr int kPathFilterThreads = 512;
-template <int B, int MIN_WAVES, bool FILTER>
+template <int B, int MIN_WAVES, bool FILTER, bool HALF = false>
 __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN_WAVES) void vrt_path_kernel(const TraceParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_block_filter[];
     FilterConsts fc{};
@@ -1754,6 +1816,29 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
     rsrc.y = (uint32_t)(status_addr >> 32) | (4u << 16); // stride 4: one record per status word
     rsrc.z = p.status_words;
     rsrc.w = 0x00020000u;
+
+    // the walk loop on half-block words (p.status_halfblocks: derived, 4 x 4 x 2 cells per word; eligible grids only)
+    HalfBlockConsts hb;
+    u32x4 hb_rsrc;
+    constexpr bool halfblocks = HALF; // (a template parameter: two asm blocks with scalar outputs behind a run-time branch do not compile)
+    {
+        // (computed unconditionally and pinned to SGPRs: they are scalar operands of the hand-written loop)
+        auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+        const uint32_t lx = 31u - (uint32_t)__builtin_clz(p.grid.dim_x | 4u), lz = 31u - (uint32_t)__builtin_clz(p.grid.dim_z | 4u);
+        hb.nmask = uni(~(3u | (3u << lx) | (1u << (lx + lz))));
+        hb.mx = uni((1u << (lx - 2u)) - 1u);
+        hb.mzs = uni(((p.grid.dim_z >> 2) - 1u) << (lx - 2u));
+        hb.mys = uni(~((1u << (lx + lz - 4u)) - 1u));
+        hb.lx = uni(lx);
+        hb.lxz = uni(lx + lz);
+        const unsigned long long a = (unsigned long long)p.status_halfblocks;
+        hb_rsrc.x = uni((uint32_t)a);
+        hb_rsrc.y = uni((uint32_t)(a >> 32) | (4u << 16));
+        hb_rsrc.z = uni(p.status_words);
+        hb_rsrc.w = 0x00020000u;
+    }
+    // the status word of a cell, in the layout the walk loop reads
+    auto status_word = [&](uint32_t index) { return halfblocks ? p.status_halfblocks[halfblock_word(hb, index)] : p.brick_status[index >> 5]; };
 
     // ---- per-lane state ----
     int st = kLaneFetch;
@@ -2005,7 +2090,7 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                             ready = false;
                             stale = true; // (the word is requested when the lane is about to take trips)
                         } else {
-                            word = p.brick_status[grid_index >> 5];
+                            word = status_word(grid_index);
                         }
                         g.t_out = skip_t;
                         g.code = (uint32_t)in_axis << 4;
@@ -2049,7 +2134,7 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
             walking = __builtin_amdgcn_ballot_w64(st == kLaneWalk && ready);
             if (walking == 0ull) continue;
             if (st == kLaneWalk && ready && stale) {
-                word = p.brick_status[grid_index >> 5];
+                word = status_word(grid_index);
                 stale = false;
             }
         }
@@ -2059,7 +2144,8 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
         // (FILTER: five trips per call, the way through a block of four cells; then the blocks are looked up again)
         g.min_alive = FILTER ? 65u : (n_walking >= fin ? n_walking - fin + 1u : 1u);
         uint32_t cell; // the occupied cell each parked lane stood on before its last step
-        grid_walk_park_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
+        if constexpr (halfblocks) grid_walk_park_halfblocks_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, hb);
+        else grid_walk_park_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
         VRT_PF_T(1, pf1);
         VRT_PF_N(2, 1);
         VRT_PF_N(3, n_walking);
@@ -2102,7 +2188,7 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                     found = false; // t became NaN (comp:316), or the step out of this cell left the box
                     st = kLaneDone;
                 } else {
-                    word = p.brick_status[grid_index >> 5]; // (an A-trip park left the lane's word in the other register set)
+                    word = status_word(grid_index); // (an A-trip park left the lane's word in the other register set)
                 }
             }
         }
@@ -2158,6 +2244,23 @@ __global__ __launch_bounds__(256) void vrt_build_status_blocks(const uint32_t *_
     const uint32_t nwords = (nblocks + 31u) >> 5;
     if (lane == 0 && base_word < nwords) filter[base_word] = (uint32_t)(nonempty & 0xFFFFFFFFull);
     if (lane == 32 && base_word + 1u < nwords) filter[base_word + 1u] = (uint32_t)(nonempty >> 32);
+}
+
+// The status bits ordered by half-blocks of 4 x 4 x 2 cells (TraceParams::status_halfblocks, grid_walk_park_halfblocks_gfx950):
+// word (x>>2) + (dim_x/4) * ((z>>2) + (dim_z/4) * (y>>1)), bit (x&3) | (z&3) << 2 | (y&1) << 4.  One thread per word.
+__global__ __launch_bounds__(256) void vrt_build_status_halfblocks(const uint32_t *__restrict__ status, uint32_t *__restrict__ out, uint32_t dim_x,
+                                                                   uint32_t dim_y, uint32_t dim_z) {
+    const uint32_t nx = dim_x >> 2, nz = dim_z >> 2, ny = dim_y >> 1;
+    const uint32_t wi = blockIdx.x * 256u + threadIdx.x;
+    if (wi >= nx * nz * ny) return;
+    const uint32_t bx = wi % nx, bz = (wi / nx) % nz, by = wi / (nx * nz);
+    uint32_t word = 0u;
+    for (uint32_t k = 0; k < 32u; k++) {
+        const uint32_t x = bx * 4u + (k & 3u), z = bz * 4u + ((k >> 2) & 3u), y = by * 2u + (k >> 4);
+        const uint32_t gi = x + dim_x * (z + dim_z * y);
+        word |= ((status[gi >> 5] >> (gi & 31u)) & 1u) << k;
+    }
+    out[wi] = word;
 }
 
 // One byte per grid cell (TraceParams::status_bytes): 1 where the cell's status bit is set.  One thread per status word.
@@ -2457,7 +2560,7 @@ static KernelFn pick_variant(uint32_t variant) {
     // (builds forced to 5, 7 or 8 waves per SIMD through __launch_bounds__ spilled and measured 6-21 % slower; they
     // are no longer instantiated)
     // (min_waves 5 is vrt_path_kernel's: every other kernel reads it as its default)
-    if (mw != 0u && mw != (uint32_t)kDefaultMinWaves && mw != 8u && mw != 5u && mw != 7u) return nullptr;
+    if (mw != 0u && mw != (uint32_t)kDefaultMinWaves && mw != 8u && mw != 5u && mw != 6u && mw != 7u) return nullptr;
     if constexpr (SHADE == 2 && !COUNT) {
         // the one-sample, no-bounce kernel (the headline's) is held to 72 VGPRs = 7 waves per SIMD (4 registers spilled outside the
         // loops): on frames that keep the GPU full it is 1.5-2 % faster than at its natural 75 VGPRs = 6 waves (1080p / 512^3 / V1, V2:
@@ -2479,6 +2582,7 @@ static KernelFn pick_variant(uint32_t variant) {
             // bit 22: behind the LDS block filter (the library sets it when the grid allows); min_waves 5: 96 VGPRs
             const bool filter = (variant & kVariantPathFilter) != 0u;
             if (mw == 5u) return filter ? (KernelFn)vrt_path_kernel<B, 5, true> : (KernelFn)vrt_path_kernel<B, 5, false>;
+            if (mw == 6u && !filter) return (KernelFn)vrt_path_kernel<B, 6, false>; // tuning build: 80 VGPRs
             return filter ? (KernelFn)vrt_path_kernel<B, kDefaultMinWaves, true> : (KernelFn)vrt_path_kernel<B, kDefaultMinWaves, false>;
         }
         if (mw == 8u) return pick_mode<B, COUNT, 8, SHADE>(mode);
@@ -2515,10 +2619,24 @@ size_t trace_lds_bytes(const TraceParams &p, uint32_t variant) {
     return 0;
 }
 
+static bool is_path_halfblock_kernel(KernelFn fn);
 bool is_path_kernel(KernelFn fn) {
     return fn == (KernelFn)vrt_path_kernel<4, 4, false> || fn == (KernelFn)vrt_path_kernel<8, 4, false> || fn == (KernelFn)vrt_path_kernel<4, 5, false> ||
            fn == (KernelFn)vrt_path_kernel<8, 5, false> || fn == (KernelFn)vrt_path_kernel<4, 4, true> || fn == (KernelFn)vrt_path_kernel<8, 4, true> ||
-           fn == (KernelFn)vrt_path_kernel<4, 5, true> || fn == (KernelFn)vrt_path_kernel<8, 5, true>;
+           fn == (KernelFn)vrt_path_kernel<4, 5, true> || fn == (KernelFn)vrt_path_kernel<8, 5, true> || fn == (KernelFn)vrt_path_kernel<4, 6, false> ||
+           fn == (KernelFn)vrt_path_kernel<8, 6, false> || is_path_halfblock_kernel(fn);
+}
+// the same kernel with the walk loop on half-block words (TraceParams::status_halfblocks); fn itself if it has none
+KernelFn path_kernel_halfblock_twin(KernelFn fn) {
+    if (fn == (KernelFn)vrt_path_kernel<4, 4, false>) return (KernelFn)vrt_path_kernel<4, 4, false, true>;
+    if (fn == (KernelFn)vrt_path_kernel<8, 4, false>) return (KernelFn)vrt_path_kernel<8, 4, false, true>;
+    if (fn == (KernelFn)vrt_path_kernel<4, 5, false>) return (KernelFn)vrt_path_kernel<4, 5, false, true>;
+    if (fn == (KernelFn)vrt_path_kernel<8, 5, false>) return (KernelFn)vrt_path_kernel<8, 5, false, true>;
+    return fn;
+}
+static bool is_path_halfblock_kernel(KernelFn fn) {
+    return fn == (KernelFn)vrt_path_kernel<4, 4, false, true> || fn == (KernelFn)vrt_path_kernel<8, 4, false, true> ||
+           fn == (KernelFn)vrt_path_kernel<4, 5, false, true> || fn == (KernelFn)vrt_path_kernel<8, 5, false, true>;
 }
 static bool is_path_filter_kernel(KernelFn fn) {
     return fn == (KernelFn)vrt_path_kernel<4, 4, true> || fn == (KernelFn)vrt_path_kernel<8, 4, true> || fn == (KernelFn)vrt_path_kernel<4, 5, true> ||
@@ -2550,6 +2668,14 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
 hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra,
                            uint32_t wave_slots, hipStream_t stream) {
     hipLaunchKernelGGL(vrt_schedule_kernel, dim3(1), dim3(1024), 0, stream, cost, snap, prev_order, order, n, extra, wave_slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_status_halfblocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
+    if (!p.status_halfblocks) return hipSuccess;
+    const uint32_t words = (dim_x >> 2) * (dim_z >> 2) * (dim_y >> 1);
+    hipLaunchKernelGGL(vrt_build_status_halfblocks, dim3((words + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
+                       const_cast<uint32_t *>(p.status_halfblocks), dim_x, dim_y, dim_z);
     return hipGetLastError();
 }
 
