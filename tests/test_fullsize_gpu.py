@@ -216,3 +216,60 @@ def test_issued_counters_walk_to_the_occupied_box():
         assert got[1][k] == got[2][k], k
     assert got[2]["grid_steps"] < got[1]["grid_steps"]
     assert got[2]["status_loads"] <= got[1]["status_loads"]
+
+
+def _frames_with_env(name, views, env, **overrides):
+    """Whole RGBA8 frames of a workload with tuning knobs of the library set through the environment (read by vrt_create)."""
+    import os
+    w = W.WORKLOADS[name] if isinstance(name, str) else name
+    grid = _GRIDS.setdefault(w.name, W.build_grid(w))
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        rt = W.make_renderer(w, grid, **overrides)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    out = []
+    for v in views:
+        W.set_view(rt, v)
+        rt.draw()
+        out.append(rt.read_rgba8().copy())
+    rt.deinit()
+    return out
+
+
+_GRIDS = {}
+
+
+@pytest.mark.parametrize("name", ["cfg2_1080p_512c_b8", "cfg3_4k_1024c_b8"])
+def test_skip_to_the_box_changes_no_pixel_at_full_size(name):
+    """Size-independent property of the jump to the occupied-cell box (skip_to_box): whole full-size frames with the jump and
+    with every cell walked (VRT_SKIP_TO_BOX=0) are the same bytes — from inside the box, above it, and far outside."""
+    views = ["V0", "V1", "V2", "V1x"]
+    walked = _frames_with_env(name, views, {"VRT_SKIP_TO_BOX": "0"})
+    jumped = _frames_with_env(name, views, {"VRT_SKIP_TO_BOX": "1"})
+    for v, a, b in zip(views, walked, jumped):
+        assert np.array_equal(a, b), v
+        assert a[..., :3].any()
+
+
+def test_path_kernel_memory_layouts_change_no_pixel():
+    """vrt_path_kernel on a scene of the path-trace configuration's kind (sparse 1024^3, 8^3 bricks, 4 samples, 3 bounces) at 720p:
+    bricks staged in LDS or read through the L1, walk loop on half-block words or on the linear words, jump to the box or not —
+    all the same frame; so is the lockstep kernel's."""
+    w = W.Workload("path_layouts", 1280, 720, 1024, 8, 4, 2, True, 5.0, "sparse", 0.08, 200000)
+    views = ["V0", "V1x"]
+    path = 1 << 23
+    base = _frames_with_env(w, views, {}, kernel_variant=path)
+    for env in ({"VRT_PATH_BRICK_LDS": "0"}, {"VRT_PATH_HALFBLOCKS": "0"}, {"VRT_PATH_BRICK_LDS": "0", "VRT_PATH_HALFBLOCKS": "0", "VRT_SKIP_TO_BOX": "0"}):
+        for v, a, b in zip(views, base, _frames_with_env(w, views, env, kernel_variant=path)):
+            assert np.array_equal(a, b), (env, v)
+    for v, a, b in zip(views, base, _frames_with_env(w, views, {}, kernel_variant=1 << 21)):
+        assert np.array_equal(a, b), ("lockstep", v)
+    for v, a, b in zip(views, base, _frames_with_env(w, views, {}, kernel_variant=path | (1 << 22))):
+        assert np.array_equal(a, b), ("block-skipping walk", v)
+    assert base[0][..., :3].any()
