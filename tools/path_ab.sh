@@ -1,6 +1,3 @@
 set -u
 cd ${GRAFT_REPO_ROOT:-.}
-for b in 16 24 48 64; do echo "== fin_batch=$b"; VRT_PATH_FIN_BATCH=$b python tools/variant_sweep.py cfg4_4k_2048c_b8_sparse 0 3 V0 2>&1 | grep -v amdgpu.ids | tail -1; done
-for b in 4 6 12 16; do echo "== brick_batch=$((b*4))"; python tools/variant_sweep.py cfg4_4k_2048c_b8_sparse $((b<<24)) 3 V0 2>&1 | grep -v amdgpu.ids | tail -1; done
-for g in 1024 1536 3072; do echo "== groups=$g"; VRT_PATH_GROUPS=$g python tools/variant_sweep.py cfg4_4k_2048c_b8_sparse 0 3 V0 2>&1 | grep -v amdgpu.ids | tail -1; done
-echo "== 4 waves"; python tools/variant_sweep.py cfg4_4k_2048c_b8_sparse $(( (4<<8) | (1<<23) )) 3 V0 2>&1 | grep -v amdgpu.ids | tail -1
+for wl in cfg2_1080p_512c_b4 cfg3_4k_1024c_b8; do for v in 0 9; do echo "== $wl variant=$v"; python tools/variant_sweep.py $wl $v 200 2>&1 | grep -v amdgpu.ids | tail -1; done; done
