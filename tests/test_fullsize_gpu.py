@@ -87,6 +87,30 @@ def test_grid_edits_reach_the_next_dispatch():
     assert np.array_equal(f.view(np.uint32), fo.view(np.uint32)) and np.array_equal(u, uo) and c == co
 
 
+def test_grid_edits_reach_the_path_kernels_derived_structures():
+    """The same for a context that traces its frames with vrt_path_kernel (bounces; forced here): its walk loop reads a derived
+    copy of the status bits (half-block words) and the occupied-cell box, both rebuilt on upload — a clump inserted into an empty
+    corner of the grid, outside the old box, must be seen by the next frame."""
+    from zig_vulkan_amd import BrickGrid
+    w = W.Workload("edit_path", 320, 180, 256, 8, 2, 2, True, 5.0)
+    grid = BrickGrid(32, 32, 32, min_point=(-16.0, -16.0, -16.0), scale=1.0, brick_dimension=8, brick_alloc=4000)
+    rng = np.random.default_rng(5)
+    grid.insert_many(np.stack([rng.integers(96, 160, 4000) for _ in range(3)], axis=-1), rng.integers(0, 6, 4000))   # a blob in the middle
+    rt = W.make_renderer(w, grid, kernel_variant=1 << 23)
+    rt.camera.look_at((-8.0, 8.0, -8.0), (-13.0, 13.0, -13.0))  # from inside the grid towards the corner that is edited below (insert() flips y)
+    rt.draw()
+    before = rt.read_rgba8().copy()
+    grid.insert_many(np.stack([rng.integers(8, 40, 3000) for _ in range(3)], axis=-1), rng.integers(0, 6, 3000))     # the corner: outside the blob's box
+    rt.update_grid_delta()
+    rt.draw()
+    after = rt.read_rgba8().copy()
+    pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+    rt.deinit()
+    assert (before != after).any()
+    _, uo, _ = O.render(oracle_scene_from_grid(grid), pc)
+    assert np.array_equal(after, uo)
+
+
 def test_headline_frames_are_deterministic_with_two_in_flight():
     """90 frames of the headline workload, two in flight, views cycled: every frame's bytes equal the first frame of
     its view (a timing-dependent fault in the hand-written loops would show up as a differing frame;
