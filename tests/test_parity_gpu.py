@@ -558,3 +558,32 @@ def test_large_scene_takes_the_path_kernel_small_scene_the_lockstep_kernel():
     xy = np.stack([rng.integers(0, w.width, 6000), rng.integers(0, w.height, 6000)], axis=-1).astype(np.int32)
     fo, uo, _ = O.render_pixels(oracle_scene_from_grid(grid), pc, xy)
     assert np.array_equal(f[xy[:, 1], xy[:, 0]].view(np.uint32), fo.view(np.uint32)) and np.array_equal(u[xy[:, 1], xy[:, 0]], uo)
+
+
+@pytest.mark.parametrize("variant,bounces", [(0, 0), (0, 2), (PATH, 2), (PATH_FILTER, 2)])
+def test_axis_aligned_rays_jump_to_the_box(variant, bounces):
+    """Rays with one or two direction components exactly 0 (odd image size, camera on a grid axis looking along it: the centre
+    row, the centre column and the centre pixel), started in front of an island of bricks in a larger empty grid: the jump to
+    the occupied-cell box has to leave the axes the ray does not move along alone (they carry the hang-guard budget, not a
+    distance), from every side of the box."""
+    from zig_vulkan_amd import BrickGrid, default_materials
+    b = 8
+    grid = BrickGrid(16, 16, 16, min_point=(-8.0, -8.0, -8.0), scale=1.0, brick_dimension=b, brick_alloc=600)
+    rng = np.random.default_rng(3)
+    grid.insert_many(np.stack([rng.integers(40, 88, 6000) for _ in range(3)], axis=-1), rng.integers(0, 6, 6000))  # cells 5..10 of 16
+    w = W.Workload("axis", 65, 33, 128, b, 2 if bounces else 1, bounces, True, 0.0)
+    rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, kernel_variant=variant)
+    rt.push_materials(default_materials(256))
+    scene = oracle_scene_from_grid(grid)
+    hits = 0
+    for origin, target in [((0.0, 0.0, -7.5), (0.0, 0.0, 0.0)), ((0.0, 0.0, 7.5), (0.0, 0.0, 0.0)), ((-7.5, 0.0, 0.0), (0.0, 0.0, 0.0)),
+                           ((7.5, 0.0, 0.0), (0.0, 0.0, 0.0)), ((0.0, -7.5, 0.0), (0.0, 0.0, 0.001)), ((0.5, 7.5, 0.5), (0.5, 0.0, 0.501)),
+                           ((-7.5, -7.5, 0.0), (0.0, 0.0, 0.0)), ((-12.0, 0.0, 0.0), (0.0, 0.0, 0.0))]:
+        rt.camera.look_at(origin, target)
+        rt.draw()
+        f, u, c = rt.read_rgba32f(), rt.read_rgba8(), rt.counters()
+        fo, uo, co = O.render(scene, O.push_constants(rt.camera.blob(), rt.sun.blob()))
+        _compare(f, u, c, fo, uo, co)
+        hits += co["hits"]
+    rt.deinit()
+    assert hits > 0
