@@ -124,6 +124,13 @@ def test_hardware_assumptions_of_the_hand_written_loops():
         pytest.skip("tools/isa_probe not built (run __graft_entry__.build())")
     out = subprocess.run([probe], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "ISA_PROBE_OK" in out.stdout, out.stdout + out.stderr
+    # ... and global_load_lds_dwordx4 under a partial EXEC mask puts lane l's 16 bytes at base + 16 l and leaves the inactive
+    # lanes' slots alone — the layout vrt_path_kernel's staged bricks are read back from
+    glds = os.path.join(os.path.dirname(probe), "ubench", "glds_probe")
+    if not os.path.exists(glds):
+        pytest.skip("tools/ubench/glds_probe not built (run __graft_entry__.build())")
+    out = subprocess.run([glds], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "GLDS_PROBE_OK" in out.stdout, out.stdout + out.stderr
 
 
 def test_compiled_host_on_the_c_abi_renders_the_same_frame(tmp_path):
