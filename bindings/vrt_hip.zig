@@ -239,6 +239,7 @@ pub extern fn vrt_dist_init_batched(ctx: ?*Ctx, rccl_path: ?[*:0]const u8, id128
 pub extern fn vrt_dist_frame(ctx: ?*Ctx, camera: [*c]const CameraDevice, sun: [*c]const SunDevice) c_int;
 pub extern fn vrt_dist_wait(ctx: ?*Ctx) c_int;
 pub extern fn vrt_dist_read_frame(ctx: ?*Ctx, dst: ?*anyopaque, nbytes: u64) c_int;
+pub extern fn vrt_dist_broadcast(ctx: ?*Ctx, id: BufferId, byte_offset: u64, nbytes: u64, root: c_int) c_int;
 pub extern fn vrt_dist_info(ctx: ?*Ctx, out: *[4]i32) c_int;
 pub extern fn vrt_dist_selftest(ctx: ?*Ctx) c_int;
 pub extern fn vrt_last_kernel_ms(ctx: ?*Ctx) f64;

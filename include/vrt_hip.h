@@ -227,7 +227,7 @@ int vrt_assemble_frame(vrt_ctx *ctx, const void *gathered, void *dst_frame, uint
  * COLLECTIVE CALLS.  On a context with vrt_dist_init done, every call that launches queued frames carries a
  * collective and must be made by EVERY rank at the same point of its frame sequence with the same queue length:
  * vrt_dist_frame (when it fills the queue), vrt_dist_wait, vrt_dist_read_frame — and every scene write
- * (vrt_upload, vrt_upload_device, vrt_upload_grid, vrt_update_grid_delta), because a scene write first launches
+ * (vrt_upload, vrt_upload_device, vrt_upload_grid, vrt_update_grid_delta, vrt_dist_broadcast), because a scene write first launches
  * what is queued.  A rank that uploads at another frame than its peers deadlocks the gather.  If a collective fails
  * (VRT_E_RCCL) the ranks are out of step: the context refuses further vrt_dist_* calls and must be destroyed. */
 int vrt_dist_unique_id(const char *rccl_path, void *out_id128);
@@ -245,6 +245,13 @@ int vrt_dist_wait(vrt_ctx *ctx);
 /* rank 0: the most recently submitted frame, row-major RGBA8 (waits for it).  With frames_per_launch > 1 the queue must
  * be empty (full batch just launched, or after vrt_dist_wait): a launch carries a collective, every rank launches together. */
 int vrt_dist_read_frame(vrt_ctx *ctx, void *dst, uint64_t nbytes);
+/* Replica update (the reference's incremental edits, VoxelRT.zig:107-172, on a scene replicated per GPU): makes bytes
+ * [byte_offset, byte_offset + nbytes) of scene buffer `id` on every rank equal to rank `root`'s — what root holds after its own
+ * vrt_upload / vrt_update_grid_delta of that range.  For hosts where only one process edits the grid; hosts that apply the same
+ * edits on every rank do not need it.  A collective and a scene write: every rank calls it with the same arguments at the same
+ * point of its frame sequence (ncclBroadcast where the library has it, send / recv from the root otherwise).  Range errors
+ * are the upload's (VRT_E_OUT_OF_RANGE). */
+int vrt_dist_broadcast(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, uint64_t nbytes, int root);
 /* out = {rank, world size — both as the RCCL communicator reports them (ncclCommUserRank / ncclCommCount) —,
  * frames per launch, launches in flight}: lets a launcher prove how many ranks the gather really spans. */
 int vrt_dist_info(vrt_ctx *ctx, int32_t out[4]);

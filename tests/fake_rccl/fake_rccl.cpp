@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE ONLY — a stand-in for the few RCCL entry points libvrt_hip.so binds with dlopen
-// (ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclGroupStart/End, ncclSend, ncclRecv,
+// (ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclGroupStart/End, ncclSend, ncclRecv, ncclBroadcast,
 // ncclGetErrorString), for running the multi-rank frame pipeline of vrt_dist_* with all "ranks" as contexts of ONE
 // process on ONE GPU (tests/test_dist_fake_rccl.py).  Real RCCL refuses two ranks on one device, and the boxes
 // have one GPU; without this the send/recv branch of vrt_dist_frame would first run in the driver's 8-GPU bench.
@@ -181,6 +181,19 @@ ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t, int peer, nc
         std::lock_guard<std::mutex> lk(g_mu);
         comm->world->pool.push_back(g);
     }
+    return ncclSuccess;
+}
+
+// in place or out of place: the root's sendbuff reaches every other rank's recvbuff (as point-to-point operations of this stand-in)
+ncclResult_t ncclBroadcast(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t t, int root, ncclComm_t comm, hipStream_t stream) {
+    if (!comm || root < 0 || root >= comm->world->nranks) return ncclInvalidArgument;
+    if (comm->rank != root) return ncclRecv(recvbuff, count, t, root, comm, stream);
+    for (int peer = 0; peer < comm->world->nranks; peer++) {
+        if (peer == root) continue;
+        const ncclResult_t r = ncclSend(sendbuff, count, t, peer, comm, stream);
+        if (r != ncclSuccess) return r;
+    }
+    if (recvbuff != sendbuff && hipMemcpyAsync(recvbuff, sendbuff, count, hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
     return ncclSuccess;
 }
 

@@ -112,3 +112,70 @@ def test_more_ranks_than_tiles_and_tiny_frames(size, world, root_weight, frames_
         rt.deinit()
     both_nan_free = np.array_equal(got, ref)
     assert both_nan_free, f"owned tiles per rank {owned}"
+
+
+@pytest.mark.parametrize("world,no_broadcast", [(2, False), (5, True), (8, False)])
+def test_edits_made_on_one_rank_reach_every_replica(world, no_broadcast, monkeypatch):
+    """SURVEY.md §8(f) #1, the multi-GPU half: only rank 0's host edits its BrickGrid; vrt_dist_broadcast_grid_delta uploads
+    rank 0's dirty ranges and broadcasts them (ncclBroadcast, or grouped send / recv where the library lacks it), frames are in
+    flight before and after; every rank renders its own tiles from its own replica, so the assembled frame equals the
+    single-context frame of the edited scene only if every replica took the edit."""
+    if not os.path.exists(FAKE):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
+    if no_broadcast:
+        monkeypatch.setenv("VRT_DIST_NO_BROADCAST", "1")
+    w = W.Workload("t", 330, 210, 64, 4, 1, 0, True, 0.0)
+    grids = [W.build_grid(w) for _ in range(world)]          # one host copy per rank, identical so far
+    edited = W.build_grid(w)
+
+    def edit(g):
+        for y in range(20, 60):
+            for dx in range(3):
+                for dz in range(3):
+                    g.insert(30 + dx, y, 30 + dz, 7)
+                    g.insert(5 + dx, y, 50 + dz, 5)
+
+    edit(edited)
+    plain = W.make_renderer(w, edited)
+    W.set_view(plain, "V1")
+    plain.draw()
+    want = plain.read_rgba8().copy()
+    plain.deinit()
+
+    uid = b"fake-rccl-edit" + bytes([world]) + os.urandom(16) + bytes(128 - 31)
+    ranks = [W.make_renderer(w, grids[r], shard_rank=r, shard_count=world) for r in range(world)]
+    for r, rt in enumerate(ranks):
+        W.set_view(rt, "V1")
+        rt.dist_init(uid, r, world, frames_in_flight=3, rccl_path=FAKE)
+    before, errors, shared = [], [], {}
+    ready = threading.Barrier(world)
+
+    def drive(r):
+        try:
+            rt = ranks[r]
+            for _ in range(4):
+                rt.dist_frame()                                  # frames of the unedited scene, left in flight
+            if r == 0:
+                before.append(rt.dist_read_frame().copy())
+                edit(grids[0])                                   # only this host edits
+                shared["ranges"] = rt.grid_delta_ranges()
+            ready.wait(timeout=60)                               # (a process would get the ranges over its own channel)
+            rt.dist_broadcast_grid_delta(root=0, ranges=shared["ranges"])
+            for _ in range(4):
+                rt.dist_frame()
+            rt.dist_wait()
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    assert not errors, errors
+    after = ranks[0].dist_read_frame().copy()
+    for rt in ranks:
+        rt.deinit()
+    assert shared["ranges"] and not np.array_equal(before[0], want)
+    assert np.array_equal(after, want)

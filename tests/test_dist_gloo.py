@@ -105,3 +105,52 @@ def test_assemble_reference_inverts_the_tile_swizzle():
         ty, tx = divmod(t, g["tiles_x"])
         gathered[t % world, t // world] = padded[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE]
     assert np.array_equal(assemble_reference(gathered, wd, ht, world), frame)
+
+
+def _edit_worker(rank: int, world: int, port: int, out_path: str):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from zig_vulkan_amd import _lib as L
+    from zig_vulkan_amd import workloads as W
+    from zig_vulkan_amd.dist import broadcast_grid_delta
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = W.Workload("t", 64, 64, 64, 4, 1, 0, True, 0.0)
+        grid = W.build_grid(w)           # replicated scene
+        bufs = [L.BUF_BRICK_STATUS, L.BUF_BRICK_INDEX, L.BUF_BRICK_OCCUPANCY, L.BUF_BRICK_START_INDEX, L.BUF_MATERIAL_INDEX]
+        # stands in for the rank's device buffers (no GPU here): what VoxelRT.upload would write
+        device = {b: np.ascontiguousarray(grid.array(b)).view(np.uint8).reshape(-1).copy() for b in bufs}
+
+        def upload(buf_id, off, data):
+            device[buf_id][off:off + data.size] = data
+
+        if rank == 0:                    # only this host edits
+            for y in range(20, 60):
+                for d in range(3):
+                    grid.insert(30 + d, y, 30, 7)
+                    grid.insert(5, y, 50 + d, 5)
+        applied = broadcast_grid_delta(grid, upload, rank, root=0)
+        if rank == 1:
+            np.save(out_path, np.concatenate([device[b] for b in bufs]))
+            np.save(out_path + ".n.npy", np.array([len(applied), sum(n for _, _, n in applied)]))
+        else:
+            assert not any(grid.delta(b)[0] for b in bufs)   # root's deltas were reset
+            np.save(out_path + ".root.npy", np.concatenate([np.ascontiguousarray(grid.array(b)).view(np.uint8).reshape(-1) for b in bufs]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_replica_update(tmp_path):
+    """Edits made on rank 0's host reach rank 1's buffers through zig_vulkan_amd.dist.broadcast_grid_delta (the torch path's
+    counterpart of vrt_dist_broadcast): after the collective rank 1 holds byte for byte what rank 0's BrickGrid holds, and
+    only the dirty ranges travelled."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rank1.npy")
+    mp.spawn(_edit_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got, want = np.load(out), np.load(out + ".root.npy")
+    n_ranges, n_bytes = np.load(out + ".n.npy").tolist()
+    assert np.array_equal(got, want)
+    assert 1 <= n_ranges <= 5 and 0 < n_bytes < want.size // 2

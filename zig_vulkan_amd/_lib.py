@@ -167,6 +167,7 @@ SIGNATURES = {
     "vrt_dist_wait": (C.c_int, [_ctx]),
     "vrt_dist_read_frame": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
     "vrt_dist_selftest": (C.c_int, [_ctx]),
+    "vrt_dist_broadcast": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
     "vrt_dist_info": (C.c_int, [_ctx, _P(C.c_int32)]),
     "vrt_device_info": (C.c_int, [C.c_int, _P(C.c_int64)]),
     "vrt_last_kernel_ms": (C.c_double, [_ctx]),

@@ -61,6 +61,7 @@ struct RcclApi {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr; // optional: replica updates fall back to send / recv from the root
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclCommCount) CommCount = nullptr;       // optional (vrt_dist_info)
     decltype(&ncclCommUserRank) CommUserRank = nullptr; // optional
@@ -85,6 +86,8 @@ struct RcclApi {
         VRT_RCCL_SYM(Recv, "ncclRecv")
         VRT_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef VRT_RCCL_SYM
+        Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(lib, "ncclBroadcast"));
+        if (std::getenv("VRT_DIST_NO_BROADCAST")) Broadcast = nullptr; // test knob: the send / recv form of vrt_dist_broadcast
         CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
         CommUserRank = reinterpret_cast<decltype(CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
         return true;
@@ -1417,6 +1420,50 @@ int vrt_dist_selftest(vrt_ctx *ctx) {
     (void)hipFree(a);
     (void)hipFree(b);
     return rc;
+}
+
+// Replica update (delta upload "+ replica broadcast"): one collective per dirty range.
+int vrt_dist_broadcast(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, uint64_t nbytes, int root) {
+    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
+    Dist *d = ctx->dist;
+    if (d->failed) return fail(ctx, VRT_E_RCCL, "an earlier collective failed: the ranks are out of step, destroy the context");
+    if ((int)id < 0 || id >= VRT_BUF_COUNT) return fail(ctx, VRT_E_INVALID_ARG, "bad buffer id");
+    if (root < 0 || root >= d->world) return fail(ctx, VRT_E_INVALID_ARG, "root is not a rank of the communicator");
+    if (byte_offset > ctx->dsize[id] || nbytes > ctx->dsize[id] - byte_offset)
+        return fail(ctx, VRT_E_OUT_OF_RANGE, "range exceeds device buffer (DestOutOfDeviceMemory)");
+    if (nbytes == 0) return VRT_OK;
+    DeviceGuard dg(ctx->device);
+    // a scene write: frames queued or in flight see the scene as it was, later ones as it becomes
+    const int rcb = begin_scene_write(ctx);
+    if (rcb != VRT_OK) return rcb;
+    uint8_t *range = static_cast<uint8_t *>(ctx->dbuf[id]) + byte_offset;
+    ncclResult_t r = ncclSuccess;
+    if (d->world > 1) {
+        if (d->api.Broadcast) {
+            r = d->api.Broadcast(range, range, (size_t)nbytes, ncclUint8, root, d->comm, ctx->stream);
+        } else {
+            r = d->api.GroupStart();
+            if (d->rank == root) {
+                for (int peer = 0; peer < d->world && r == ncclSuccess; peer++)
+                    if (peer != root) r = d->api.Send(range, (size_t)nbytes, ncclUint8, peer, d->comm, ctx->stream);
+            } else if (r == ncclSuccess) {
+                r = d->api.Recv(range, (size_t)nbytes, ncclUint8, root, d->comm, ctx->stream);
+            }
+            const ncclResult_t r2 = d->api.GroupEnd(); // (always: an open group would swallow every later call)
+            if (r == ncclSuccess) r = r2;
+        }
+    }
+    if (r != ncclSuccess) {
+        d->failed = true;
+        return fail(ctx, VRT_E_RCCL, std::string("replica broadcast: ") + d->api.GetErrorString(r));
+    }
+    if (id == VRT_BUF_GRID_STATE && d->rank != root) {
+        // the kernel takes the UBO through its argument block: bring the host mirror up to date
+        VRT_HIP(ctx, hipMemcpyAsync(reinterpret_cast<uint8_t *>(&ctx->params.grid) + byte_offset, range, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+        VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (id == VRT_BUF_BRICK_STATUS) ctx->status_dirty = true;
+    return end_scene_write(ctx);
 }
 
 int vrt_get_counters(vrt_ctx *ctx, vrt_counters *out) {

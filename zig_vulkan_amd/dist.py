@@ -45,6 +45,34 @@ def assemble_reference(gathered: np.ndarray, width: int, height: int, world: int
     return frame[:height, :width]
 
 
+def broadcast_grid_delta(grid, upload, rank: int, root: int = 0, group=None) -> list:
+    """Replica update of the torch path (the native pipeline has vrt_dist_broadcast): incremental edits made on rank `root`'s
+    host BrickGrid reach every rank's device buffers.  Root packs its dirty ranges (Grid.zig:129-194) as (buffer id, byte
+    offset, bytes), one broadcast_object_list carries them, and EVERY rank — root too — applies them with `upload(buffer_id,
+    byte_offset, uint8 array)` (VoxelRT.upload); root's deltas are reset as VoxelRT.updateGridDelta does (VoxelRT.zig:107-172).
+    Collective; any backend.  Returns the ranges applied as (buffer id, byte offset, bytes)."""
+    import torch.distributed as dist
+    from . import _lib as L
+    # the five buffers BrickGrid tracks deltas for, with their element sizes
+    tracked = ((L.BUF_BRICK_STATUS, 4), (L.BUF_BRICK_INDEX, 4), (L.BUF_BRICK_OCCUPANCY, 1), (L.BUF_BRICK_START_INDEX, 4), (L.BUF_MATERIAL_INDEX, 1))
+    box = [None]
+    if rank == root:
+        pieces = []
+        for buf_id, es in tracked:
+            active, a, b = grid.delta(buf_id)
+            if active and b > a:
+                data = np.ascontiguousarray(grid.array(buf_id)).view(np.uint8).reshape(-1)
+                pieces.append((buf_id, a * es, data[a * es:b * es].tobytes()))
+        box[0] = pieces
+    dist.broadcast_object_list(box, src=root, group=group)
+    for buf_id, off, payload in box[0]:
+        upload(buf_id, off, np.frombuffer(payload, dtype=np.uint8))
+    if rank == root:
+        for buf_id, _ in tracked:
+            grid.reset_delta(buf_id)
+    return [(b, o, len(p)) for b, o, p in box[0]]
+
+
 class FrameGather:
     """Per-frame collective of the sharded renderer, pipelined over `depth` frames.
 

@@ -423,6 +423,38 @@ class VoxelRT:
     def dist_selftest(self) -> None:
         check(lib.vrt_dist_selftest(self._h), self._h)
 
+    # element sizes of the five buffers BrickGrid tracks deltas for (Grid.zig:129-194)
+    _DELTA_BUFFERS = ((L.BUF_BRICK_STATUS, 4), (L.BUF_BRICK_INDEX, 4), (L.BUF_BRICK_OCCUPANCY, 1), (L.BUF_BRICK_START_INDEX, 4),
+                      (L.BUF_MATERIAL_INDEX, 1))
+
+    def dist_broadcast(self, buf_id: int, byte_offset: int, nbytes: int, root: int = 0) -> None:
+        """Collective: the byte range of scene buffer `buf_id` on every rank becomes rank `root`'s (vrt_dist_broadcast)."""
+        check(lib.vrt_dist_broadcast(self._h, buf_id, byte_offset, nbytes, root), self._h)
+
+    def grid_delta_ranges(self) -> list:
+        """[(buffer id, byte offset, bytes)] of this host's dirty ranges (what update_grid_delta is about to upload)."""
+        out = []
+        for buf_id, es in self._DELTA_BUFFERS:
+            active, a, b = self.brick_grid.delta(buf_id)
+            if active and b > a:
+                out.append((buf_id, a * es, (b - a) * es))
+        return out
+
+    def dist_broadcast_grid_delta(self, root: int = 0, ranges: Optional[list] = None) -> None:
+        """Incremental edits made on ONE rank's host reach every replica: rank `root` uploads its dirty
+        ranges (update_grid_delta) and every rank takes part in one broadcast per range.  Collective.  `ranges`: root's
+        grid_delta_ranges() as every rank knows them; None: they are shared over torch.distributed first."""
+        rank = self.dist_info()["rank"]
+        if ranges is None:
+            import torch.distributed as dist
+            box = [self.grid_delta_ranges() if rank == root else None]
+            dist.broadcast_object_list(box, src=root)
+            ranges = box[0]
+        if rank == root:
+            self.update_grid_delta()
+        for buf_id, off, nbytes in ranges:
+            self.dist_broadcast(buf_id, off, nbytes, root)
+
     def create_benchmark(self) -> "Benchmark":  # VoxelRT.createBenchmark, VoxelRT.zig:72-74
         return Benchmark(self.camera)
 
