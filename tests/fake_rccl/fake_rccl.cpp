@@ -119,7 +119,9 @@ ncclResult_t ncclCommUserRank(const ncclComm_t comm, int *rank) {
 ncclResult_t ncclGroupStart() { return ncclSuccess; } // operations are carried out as they are posted
 ncclResult_t ncclGroupEnd() { return ncclSuccess; }
 
-ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t, int peer, ncclComm_t comm, hipStream_t stream) {
+// (implementations are file-local: a call from ncclBroadcast below must not go through the PLT, where it would bind to the
+// real RCCL's ncclSend / ncclRecv if PyTorch's librccl is already in the process)
+static ncclResult_t send_impl(const void *sendbuff, size_t count, int peer, ncclComm_t comm, hipStream_t stream) {
     if (!comm || peer < 0 || peer >= comm->world->nranks) return ncclInvalidArgument;
     Posted s{nullptr, count, nullptr};
     static const bool zero_copy = std::getenv("FAKE_RCCL_ZERO_COPY") != nullptr;
@@ -159,7 +161,7 @@ ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t, int pe
     return ncclSuccess;
 }
 
-ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t, int peer, ncclComm_t comm, hipStream_t stream) {
+static ncclResult_t recv_impl(void *recvbuff, size_t count, int peer, ncclComm_t comm, hipStream_t stream) {
     if (!comm || peer < 0 || peer >= comm->world->nranks) return ncclInvalidArgument;
     Posted s;
     {
@@ -184,13 +186,19 @@ ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t, int peer, nc
     return ncclSuccess;
 }
 
+ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t, int peer, ncclComm_t comm, hipStream_t stream) {
+    return send_impl(sendbuff, count, peer, comm, stream);
+}
+ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t, int peer, ncclComm_t comm, hipStream_t stream) {
+    return recv_impl(recvbuff, count, peer, comm, stream);
+}
 // in place or out of place: the root's sendbuff reaches every other rank's recvbuff (as point-to-point operations of this stand-in)
-ncclResult_t ncclBroadcast(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t t, int root, ncclComm_t comm, hipStream_t stream) {
+ncclResult_t ncclBroadcast(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t, int root, ncclComm_t comm, hipStream_t stream) {
     if (!comm || root < 0 || root >= comm->world->nranks) return ncclInvalidArgument;
-    if (comm->rank != root) return ncclRecv(recvbuff, count, t, root, comm, stream);
+    if (comm->rank != root) return recv_impl(recvbuff, count, root, comm, stream);
     for (int peer = 0; peer < comm->world->nranks; peer++) {
         if (peer == root) continue;
-        const ncclResult_t r = ncclSend(sendbuff, count, t, peer, comm, stream);
+        const ncclResult_t r = send_impl(sendbuff, count, peer, comm, stream);
         if (r != ncclSuccess) return r;
     }
     if (recvbuff != sendbuff && hipMemcpyAsync(recvbuff, sendbuff, count, hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;

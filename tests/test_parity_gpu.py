@@ -311,7 +311,11 @@ def test_native_rccl_pipeline_single_rank():
         assert np.array_equal(rt.dist_read_frame(), ref[view])
     for y in range(20, 60):
         grid.insert(31, y, 31, 7)
-    rt.update_grid_delta()
+    # (the replica update of a one-process-edits host: upload on the root + ncclBroadcast of each dirty range — RCCL's own,
+    # here with a single rank)
+    ranges = rt.grid_delta_ranges()
+    assert ranges
+    rt.dist_broadcast_grid_delta(root=0, ranges=ranges)
     W.set_view(rt, "V1")
     for _ in range(5):
         rt.dist_frame()

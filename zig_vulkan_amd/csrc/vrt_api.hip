@@ -1438,8 +1438,8 @@ int vrt_dist_broadcast(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, uin
     if (rcb != VRT_OK) return rcb;
     uint8_t *range = static_cast<uint8_t *>(ctx->dbuf[id]) + byte_offset;
     ncclResult_t r = ncclSuccess;
-    if (d->world > 1) {
-        if (d->api.Broadcast) {
+    {
+        if (d->api.Broadcast) { // (also with a single rank: the call is then RCCL's own no-op, and the binding is exercised)
             r = d->api.Broadcast(range, range, (size_t)nbytes, ncclUint8, root, d->comm, ctx->stream);
         } else {
             r = d->api.GroupStart();
