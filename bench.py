@@ -306,11 +306,12 @@ def main(argv=None) -> None:
     ap.add_argument("--dist", choices=["native", "torch"], default="native",
                     help="N>1 frame gather: native = RCCL send/recv inside libvrt_hip.so (pipelined); torch = torch.distributed.gather (fallback)")
     ap.add_argument("--dist-frames", type=int, default=4, help="launches in flight per rank of the native multi-GPU pipeline")
-    ap.add_argument("--dist-batch", type=int, default=4,
+    ap.add_argument("--dist-batch", type=int, default=8,
                     help="frames traced by one launch and carried by one collective when world > 1 (every frame is gathered once; "
                          "1 = one collective per frame)")
     ap.add_argument("--root-share", type=int, default=-1,
-                    help="native multi-GPU pipeline: rank 0's share of the tiles in percent of an equal share; -1: 100 - 40 (world - 1) / 7")
+                    help="native multi-GPU pipeline: rank 0's share of the tiles in percent of an equal share; -1: 100 - 70 (world - 2) / 6 "
+                         "(100 % at 2 ranks ... 30 % at 8: one-GPU emulation of root and peers, tools/root_share_sweep.sh)")
     ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)            # tests/test_bench_plumbing.py
     ap.add_argument("--stub-fail-native-on", type=int, default=-1, help=argparse.SUPPRESS)
@@ -417,7 +418,7 @@ def main(argv=None) -> None:
         # RCCL inside libvrt_hip.so: kernel -> grouped send/recv to rank 0 -> un-swizzle, several launches in flight
         ok = 1
         try:
-            root_share = args.root_share if args.root_share >= 0 else max(30, 100 - (40 * (world - 1) + 3) // 7)
+            root_share = args.root_share if args.root_share >= 0 else max(30, 100 - (70 * max(0, world - 2) + 3) // 6)
             if stub:
                 uid = [b"stub"]
                 rt = _StubRT(fail_native=(rank == args.stub_fail_native_on))

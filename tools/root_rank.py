@@ -15,8 +15,11 @@ fake.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
 fake.ncclSend.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 w = W.WORKLOADS[W.HEADLINE]
 grid = W.build_grid(w)
-world, batch, slots = 8, 8, 4
-for weight in (0, 65, 40):
+# usage: root_rank.py [world] [frames per launch] [launches in flight] [root shares in %, comma separated; 0 = equal share]
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+slots = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+for weight in ([int(v) for v in sys.argv[4].split(',')] if len(sys.argv) > 4 else (0, 65, 40)):
     uid = b"root-rank" + os.urandom(16) + bytes(128 - 25)
     rt = W.make_renderer(w, grid, shard_rank=0, shard_count=world, shard_root_weight=weight)
     rt.dist_init(uid, 0, world, frames_in_flight=slots, rccl_path=FAKE, frames_per_launch=batch)
@@ -41,6 +44,6 @@ for weight in (0, 65, 40):
         for _ in range(n): rt.dist_frame()
         rt.dist_wait(); out[view] = round((time.perf_counter() - t0) / n * 1e6, 1)
         th.join()
-    print(f"rank 0 of 8, root share {weight or 100} % ({batch} frames per launch, {slots} launches in flight), peers fed: us per frame", out, " mean", round(sum(out.values()) / 3, 1))
+    print(f"rank 0 of {world}, root share {weight or 100} % ({batch} frames per launch, {slots} launches in flight), peers fed: us per frame", out, " mean", round(sum(out.values()) / 3, 1))
     rt.deinit()
     for c in comms: fake.ncclCommDestroy(c)
