@@ -160,7 +160,9 @@ pub const Config = extern struct {
     kernel_variant: u32 = 0,
     frames_in_flight: u32 = 1,
     shard_root_weight: u32 = 0,
-    _reserved: [5]u32 = [_]u32{0} ** 5,
+    /// TUNE_* bits, 0 = the library's defaults; every setting renders the same frame (A/B measurements, equivalence tests)
+    tuning_flags: u32 = 0,
+    _reserved: [4]u32 = [_]u32{0} ** 4,
 };
 
 pub const ShardInfo = extern struct {
@@ -182,6 +184,12 @@ pub const Counters = extern struct {
     hits: u64,
     grid_steps: u64,
 };
+
+pub const TUNE_NO_SKIP_TO_BOX: u32 = 1 << 0;
+pub const TUNE_NO_PATH_BRICK_LDS: u32 = 1 << 1;
+pub const TUNE_NO_PATH_HALFBLOCKS: u32 = 1 << 2;
+pub const TUNE_PATH_EAGER_START: u32 = 1 << 3;
+pub const TUNE_DIST_NO_BROADCAST: u32 = 1 << 4;
 
 pub const GridConfig = extern struct { // Grid.zig:13-20
     brick_alloc: u64 = 0,
@@ -250,6 +258,7 @@ pub extern fn vrt_device_info(device: c_int, out: *[4]i64) c_int;
 pub extern fn vrt_last_error(ctx: ?*const Ctx) [*:0]const u8;
 pub extern fn vrt_abi_version() u32;
 pub extern fn vrt_kernel_name(ctx: ?*const Ctx) [*:0]const u8;
+pub extern fn vrt_compiled_kernel_count() c_int;
 pub extern fn vrt_grid_create(dim_x: u32, dim_y: u32, dim_z: u32, cfg: [*c]const GridConfig, out: *?*Grid) c_int;
 pub extern fn vrt_grid_destroy(g: ?*Grid) void;
 pub extern fn vrt_grid_insert(g: ?*Grid, x: u64, y: u64, z: u64, material_index: u8) c_int;

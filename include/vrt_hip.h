@@ -139,8 +139,18 @@ typedef struct vrt_config {
      * the same value.  Tile t then belongs to owner[t % period] of a fixed periodic pattern instead of rank t % count;
      * vrt_shard_info.owned_tiles / tiles_per_rank describe the result. */
     uint32_t shard_root_weight;
-    uint32_t _reserved[5];
+    /* VRT_TUNE_* bits, 0 = the library's defaults.  Every setting renders the same frame bit for bit: the flags exist for A/B
+     * measurements and for the equivalence tests (tests/test_fullsize_gpu.py).  The library reads no environment variable. */
+    uint32_t tuning_flags;
+    uint32_t _reserved[4];
 } vrt_config;
+
+#define VRT_TUNE_NO_SKIP_TO_BOX     (1u << 0) /* walk every cell between the grid's face and the box of the occupied cells */
+#define VRT_TUNE_NO_PATH_BRICK_LDS  (1u << 1) /* vrt_path_kernel: walk 8^3 bricks in global memory instead of staging them in LDS */
+#define VRT_TUNE_NO_PATH_HALFBLOCKS (1u << 2) /* vrt_path_kernel: the shader's linear status words instead of the half-block words */
+#define VRT_TUNE_PATH_EAGER_START   (1u << 3) /* vrt_path_kernel: request brick_start_index together with the staged brick */
+#define VRT_TUNE_DIST_NO_BROADCAST  (1u << 4) /* vrt_dist_broadcast as grouped send / recv from the root (every rank alike) */
+#define VRT_TUNE_ALL                0x1Fu
 
 typedef struct vrt_ctx vrt_ctx;
 
@@ -288,7 +298,14 @@ int vrt_device_info(int device, int64_t out[4]);
 
 const char *vrt_last_error(const vrt_ctx *ctx); /* ctx may be NULL: create errors */
 uint32_t vrt_abi_version(void);
-const char *vrt_kernel_name(const vrt_ctx *ctx); /* mangled name of the traversal kernel in use */
+/* The traversal kernel that rendered the most recent frame (before the first frame: the one a frame without bounces and with
+ * one sample per pixel would take), as its template-id — the kernel name rocprofv3 reports minus the `void vrt::` prefix and
+ * the argument list, e.g. "vrt_trace_kernel<8, false, 7, 7, 2, 256>" (B, COUNT, MODE, MIN_WAVES, SHADE, BLOCK) or
+ * "vrt_path_kernel<8, 5, false, true>" (B, MIN_WAVES, FILTER, HALF).  On a counting context: the product kernel, not the
+ * counting build that ran before it. */
+const char *vrt_kernel_name(const vrt_ctx *ctx);
+/* number of traversal kernels compiled into this build of the library (tests/test_kernel_resources.py) */
+int vrt_compiled_kernel_count(void);
 
 /* =========================================================================
  * Host-side scene objects (CPU only; usable without a GPU).  C view of the

@@ -111,6 +111,69 @@ def main_present():
         print(f"{name}: max |reference - denoise oracle| = {np.abs(f[..., :3][ok] - fo[..., :3][ok]).max():.3g}, NaN pixels {int((~ok).any(axis=2).sum())}")
 
 
+# ---- full size: the headline workload (BASELINE.json configs[2]: 1920x1080, 512^3 voxels, 8^3 bricks, primary + shadow) and the
+# reference app's own default run, rendered by the REFERENCE SHADER under llvmpipe.  Too large to store: SHA-256 of the whole
+# RGBA8 and float frames, SHA-256 per band of 16 rows (to localise a mismatch), float crops.  The scene is the deterministic
+# synthetic terrain (vrt_synth_terrain); its digest is stored so that a changed generator cannot pass unnoticed.
+FULL_OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_full")
+CROP = 48
+BAND = 16
+
+
+def refapp_workload():
+    """src/main.zig:77-81,122-135 of the reference: 128 x 64 x 128 bricks of 4^3 (min (-32,-16,-32), scale 0.5), 1024x576 internal
+    resolution, 2 samples, max_bounce 2, sun on (radius 5) — the only workload a user of the reference has ever seen."""
+    return W.WORKLOADS["refapp_1024x576_128x64x128_b4"]
+
+
+def full_cases():
+    head = W.WORKLOADS[W.HEADLINE]
+    cases = {}
+    for v in ("V0", "V1", "V2"):
+        cases[f"cfg2_r0_{v}"] = (head, v, 0.0, None)      # hard sun: no pixel depends on sin()
+        cases[f"cfg2_r5_{v}"] = (head, v, 5.0, None)      # the reference's default sun radius (Sun.zig:9): sin-hash RNG in every shadow ray
+    ra = refapp_workload()
+    cases["refapp_V0"] = (ra, "V0", 5.0, None)            # at its full 1024x576
+    cases["refapp_256x144_V0"] = (ra, "V0", 5.0, (256, 144))
+    cases["refapp_256x144_V2"] = (ra, "V2", 5.0, (256, 144))
+    return cases
+
+
+def crop_origins(w, h):
+    """Eight crops spread over the frame (fixed positions: lower half = terrain, horizon, sky)."""
+    return [(min(int(h * fy) // 8 * 8, h - CROP), min(int(w * fx) // 8 * 8, w - CROP)) for fy, fx in ((0.15, 0.2), (0.35, 0.7), (0.5, 0.45), (0.55, 0.1), (0.65, 0.8), (0.75, 0.3), (0.85, 0.6), (0.93, 0.05))]
+
+
+def main_full():
+    from tests.golden.make_golden import scene_digest
+    os.makedirs(FULL_OUT, exist_ok=True)
+    info = GlRef().info()
+    grids, refs = {}, {}
+    for name, (w, view, radius, size) in full_cases().items():
+        grid = grids.setdefault(w.name, W.build_grid(w))
+        scene = oracle_scene_from_grid(grid)
+        width, height = size or (w.width, w.height)
+        pc = O.push_constants(W.camera_for(w, view, width, height).blob(), W.sun_for(w, radius).blob())
+        ref = refs.setdefault(w.brick_dimension, ReferenceShader(w.brick_dimension))
+        f, u = ref.render(scene, pc)
+        bands = [hashlib.sha256(np.ascontiguousarray(f[y:y + BAND]).tobytes()).hexdigest() for y in range(0, height, BAND)]
+        origins = crop_origins(width, height)
+        crops = np.stack([f[y:y + CROP, x:x + CROP, :3] for y, x in origins])
+        np.savez_compressed(
+            os.path.join(FULL_OUT, name + ".npz"),
+            provenance=np.array(f"brick_raytracer.comp + rand.comp of /root/reference, OpenGL dialect edits E1-E8 of oracle/ref_gl/recipe.py, {info}"),
+            workload=np.array(w.name), view=np.array(view), size=np.array([width, height]), brick_dimension=np.int32(w.brick_dimension),
+            push_constants=pc, scene_sha256=np.array(scene_digest(grid)),
+            rgba8_sha256=np.array(hashlib.sha256(u.tobytes()).hexdigest()), float_sha256=np.array(hashlib.sha256(f.tobytes()).hexdigest()),
+            band_rows=np.int32(BAND), band_sha256=np.array(bands), crop_origins=np.array(origins), float_crops=crops,
+            mean_rgb=f[:, :, :3].mean(axis=(0, 1)).astype(np.float64))
+        print(f"{name}: {width}x{height}, mean colour {f[:, :, :3].mean(axis=(0, 1))}")
+
+
 if __name__ == "__main__":
-    main()
-    main_present()
+    if len(sys.argv) > 1 and sys.argv[1] == "full":
+        main_full()
+    else:
+        main()
+        main_present()
+        main_full()

@@ -117,15 +117,15 @@ def test_more_ranks_than_tiles_and_tiny_frames(size, world, root_weight, frames_
 
 
 @pytest.mark.parametrize("world,no_broadcast", [(2, False), (5, True), (8, False)])
-def test_edits_made_on_one_rank_reach_every_replica(world, no_broadcast, monkeypatch):
+def test_edits_made_on_one_rank_reach_every_replica(world, no_broadcast):
     """SURVEY.md §8(f) #1, the multi-GPU half: only rank 0's host edits its BrickGrid; vrt_dist_broadcast_grid_delta uploads
     rank 0's dirty ranges and broadcasts them (ncclBroadcast, or grouped send / recv where the library lacks it), frames are in
     flight before and after; every rank renders its own tiles from its own replica, so the assembled frame equals the
     single-context frame of the edited scene only if every replica took the edit."""
     if not os.path.exists(FAKE):
         pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
-    if no_broadcast:
-        monkeypatch.setenv("VRT_DIST_NO_BROADCAST", "1")
+    from zig_vulkan_amd import _lib as L
+    flags = L.TUNE_DIST_NO_BROADCAST if no_broadcast else 0   # (every rank alike: a mix would pair ncclBroadcast with send / recv)
     w = W.Workload("t", 330, 210, 64, 4, 1, 0, True, 0.0)
     grids = [W.build_grid(w) for _ in range(world)]          # one host copy per rank, identical so far
     edited = W.build_grid(w)
@@ -145,7 +145,7 @@ def test_edits_made_on_one_rank_reach_every_replica(world, no_broadcast, monkeyp
     plain.deinit()
 
     uid = b"fake-rccl-edit" + bytes([world]) + os.urandom(16) + bytes(128 - 31)
-    ranks = [W.make_renderer(w, grids[r], shard_rank=r, shard_count=world) for r in range(world)]
+    ranks = [W.make_renderer(w, grids[r], shard_rank=r, shard_count=world, tuning_flags=flags) for r in range(world)]
     for r, rt in enumerate(ranks):
         W.set_view(rt, "V1")
         rt.dist_init(uid, r, world, frames_in_flight=3, rccl_path=FAKE)

@@ -4,7 +4,8 @@ size-independent properties (ray count bounds, alpha, determinism across launche
 import numpy as np
 import pytest
 
-from tests.helpers import O, oracle_scene_from_grid
+from tests.helpers import O, dev_library_or_none, oracle_scene_from_grid, variant_kwargs
+from zig_vulkan_amd import _lib as L
 from zig_vulkan_amd import workloads as W
 
 pytestmark = pytest.mark.gpu
@@ -242,21 +243,11 @@ def test_issued_counters_walk_to_the_occupied_box():
     assert got[2]["status_loads"] <= got[1]["status_loads"]
 
 
-def _frames_with_env(name, views, env, **overrides):
-    """Whole RGBA8 frames of a workload with tuning knobs of the library set through the environment (read by vrt_create)."""
-    import os
+def _frames_with_flags(name, views, tuning_flags, **overrides):
+    """Whole RGBA8 frames of a workload with vrt_config.tuning_flags set (VRT_TUNE_*: the library reads no environment)."""
     w = W.WORKLOADS[name] if isinstance(name, str) else name
     grid = _GRIDS.setdefault(w.name, W.build_grid(w))
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        rt = W.make_renderer(w, grid, **overrides)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    rt = W.make_renderer(w, grid, tuning_flags=tuning_flags, **overrides)
     out = []
     for v in views:
         W.set_view(rt, v)
@@ -272,10 +263,10 @@ _GRIDS = {}
 @pytest.mark.parametrize("name", ["cfg2_1080p_512c_b8", "cfg3_4k_1024c_b8"])
 def test_skip_to_the_box_changes_no_pixel_at_full_size(name):
     """Size-independent property of the jump to the occupied-cell box (skip_to_box): whole full-size frames with the jump and
-    with every cell walked (VRT_SKIP_TO_BOX=0) are the same bytes — from inside the box, above it, and far outside."""
+    with every cell walked (VRT_TUNE_NO_SKIP_TO_BOX) are the same bytes — from inside the box, above it, and far outside."""
     views = ["V0", "V1", "V2", "V1x"]
-    walked = _frames_with_env(name, views, {"VRT_SKIP_TO_BOX": "0"})
-    jumped = _frames_with_env(name, views, {"VRT_SKIP_TO_BOX": "1"})
+    walked = _frames_with_flags(name, views, L.TUNE_NO_SKIP_TO_BOX)
+    jumped = _frames_with_flags(name, views, 0)
     for v, a, b in zip(views, walked, jumped):
         assert np.array_equal(a, b), v
         assert a[..., :3].any()
@@ -288,12 +279,14 @@ def test_path_kernel_memory_layouts_change_no_pixel():
     w = W.Workload("path_layouts", 1280, 720, 1024, 8, 4, 2, True, 5.0, "sparse", 0.08, 200000)
     views = ["V0", "V1x"]
     path = 1 << 23
-    base = _frames_with_env(w, views, {}, kernel_variant=path)
-    for env in ({"VRT_PATH_BRICK_LDS": "0"}, {"VRT_PATH_HALFBLOCKS": "0"}, {"VRT_PATH_BRICK_LDS": "0", "VRT_PATH_HALFBLOCKS": "0", "VRT_SKIP_TO_BOX": "0"}):
-        for v, a, b in zip(views, base, _frames_with_env(w, views, env, kernel_variant=path)):
-            assert np.array_equal(a, b), (env, v)
-    for v, a, b in zip(views, base, _frames_with_env(w, views, {}, kernel_variant=1 << 21)):
+    base = _frames_with_flags(w, views, 0, kernel_variant=path)
+    for flags in (L.TUNE_NO_PATH_BRICK_LDS, L.TUNE_NO_PATH_HALFBLOCKS, L.TUNE_PATH_EAGER_START,
+                  L.TUNE_NO_PATH_BRICK_LDS | L.TUNE_NO_PATH_HALFBLOCKS | L.TUNE_NO_SKIP_TO_BOX):
+        for v, a, b in zip(views, base, _frames_with_flags(w, views, flags, kernel_variant=path)):
+            assert np.array_equal(a, b), (flags, v)
+    for v, a, b in zip(views, base, _frames_with_flags(w, views, 0, kernel_variant=1 << 21)):
         assert np.array_equal(a, b), ("lockstep", v)
-    for v, a, b in zip(views, base, _frames_with_env(w, views, {}, kernel_variant=path | (1 << 22))):
-        assert np.array_equal(a, b), ("block-skipping walk", v)
+    if dev_library_or_none():  # the block-skipping walk lives in the development build
+        for v, a, b in zip(views, base, _frames_with_flags(w, views, 0, **variant_kwargs(path | (1 << 22)))):
+            assert np.array_equal(a, b), ("block-skipping walk", v)
     assert base[0][..., :3].any()

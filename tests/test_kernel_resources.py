@@ -32,8 +32,17 @@ def _kernels():
             for m in re.finditer(r"\.group_segment_fixed_size: (\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size: (\d+).*?\.vgpr_count:\s+(\d+)", notes, re.S):
                 lds, kname, scratch, vgpr = m.groups()
                 out[kname] = dict(lds=int(lds), scratch=int(scratch), vgpr=int(vgpr))
-    assert len(out) > 100
+    assert len(out) >= 20
     return out
+
+
+def test_the_product_binary_holds_only_shipped_kernels():
+    """at most 40 kernels in the product code objects (round 2 shipped 175, most of them losers of an A/B);
+    the variants that lost live in the development build (make dev)."""
+    ks = _kernels()
+    assert len(ks) <= 40, sorted(ks)
+    traversal = [n for n in ks if "vrt_trace_kernel" in n or "vrt_path_kernel" in n]
+    assert len(traversal) == 22, sorted(traversal)
 
 
 def test_no_kernel_owns_static_lds_except_the_schedule_kernel():

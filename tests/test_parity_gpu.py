@@ -5,7 +5,7 @@ channel; this suite demands max-abs-err == 0."""
 import numpy as np
 import pytest
 
-from tests.helpers import O, oracle_scene_from_grid, push_for
+from tests.helpers import O, available_variants, oracle_scene_from_grid, push_for, variant_kwargs
 from zig_vulkan_amd import _lib as L
 from zig_vulkan_amd import workloads as W
 
@@ -16,7 +16,7 @@ TOL = 1e-4  # north_star tolerance; asserted as an upper bound next to exact equ
 
 def _run_hip(w, grid, view, *, width=None, height=None, variant=0, sun_radius=None, counters=True):
     rt = W.make_renderer(w, grid, width=width or w.width, height=height or w.height, want_float_output=True,
-                         enable_counters=counters, kernel_variant=variant,
+                         enable_counters=counters, **variant_kwargs(variant),
                          **({"sun_radius": sun_radius} if sun_radius is not None else {}))
     W.set_view(rt, view)
     rt.draw()
@@ -37,8 +37,14 @@ def _compare(f, u, c, fo, uo, co):
         assert c == co
 
 
+# shipped kernels (words / bytes) under every tile order (bits 16-19) and one-wave workgroups (bit 20) ...
+SHIPPED = [0, 5, 9, 0x70009, 0x10005, 0x20009, 0x30005, 0x60009, 0x100005]
+# ... and the variants that lost their A/B measurement: only in the development build (skipped where it is absent)
+DEV_ONLY = [1, 2, 3, 4, 6, 7, 8, 0x10002, 0x20003, 0x30001, 0x60001, 0x140001, 0x409, 0x809]
+
+
 @pytest.mark.parametrize("view", ["V0", "V1", "V2"])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 0x70009, 0x10002, 0x20003, 0x30001, 0x60001, 0x140001])
+@pytest.mark.parametrize("variant", SHIPPED + DEV_ONLY)
 def test_config0_primary_rays(view, variant):
     w = W.WORKLOADS["cfg0_256x256_64c_b4"]
     grid = W.build_grid(w)
@@ -221,16 +227,16 @@ def test_vox_model_scene_like_main_zig():
 def test_reference_app_default_scene_shape_non_cubic_grid():
     """The reference app's own defaults (src/main.zig:77-81,122-135): 128x64x128 bricks of 4^3 at
     min (-32,-16,-32), scale 0.5, 1024x576, spp 2, max_bounce 2, sun on — a non-cubic grid whose status
-    bitmap (128 KiB) does not fit the LDS budget, so the global-memory variant is selected."""
+    bitmap is 128 KiB (test_dev_lds_variant_falls_back_to_global_memory asks the development build to stage it in LDS)."""
     from zig_vulkan_amd import BrickGrid, Config, CameraConfig, SunConfig, VoxelRT, default_materials
     grid = BrickGrid(128, 64, 128, min_point=(-32.0, -16.0, -32.0), scale=0.5, brick_dimension=4)
     grid.synth_terrain(420)
     rt = VoxelRT(grid, Config(internal_resolution_width=1024, internal_resolution_height=576, camera=CameraConfig(samples_per_pixel=2, max_bounce=2),
-                              sun=SunConfig(enabled=True), want_float_output=True, enable_counters=True, kernel_variant=6))
+                              sun=SunConfig(enabled=True), want_float_output=True, enable_counters=True))
     rt.push_materials(default_materials(256))
-    assert "global-memory variant" in rt.kernel_name()  # the LDS-staged variant was asked for and does not fit
     rt.camera.set_origin((0.0, 0.0, 0.0))  # Camera.Config default origin, looking -Z
     rt.draw()
+    assert rt.kernel_name() == "vrt_trace_kernel<4, false, 4, 4, 0, 256>"  # what ran: the lockstep bounce kernel on the shader's words
     f, u, c = rt.read_rgba32f(), rt.read_rgba8(), rt.counters()
     pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
     rt.deinit()
@@ -252,8 +258,8 @@ def test_grid_scale_not_a_power_of_two(b, scale):
     n = 16
     grid = BrickGrid(n, n, n, min_point=(-0.5 * n * scale, -0.5 * n * scale, -0.5 * n * scale), scale=scale, brick_dimension=b)
     grid.synth_terrain(420)
-    for variant in (0, 4):
-        rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, kernel_variant=variant)
+    for variant in available_variants((0, 4)):
+        rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, **variant_kwargs(variant))
         rt.camera.look_at((0.9 * n * scale, -0.8 * n * scale, 1.1 * n * scale), (0.0, 0.1 * n * scale, 0.0))
         rt.draw()
         f, u, c = rt.read_rgba32f(), rt.read_rgba8(), rt.counters()
@@ -274,8 +280,8 @@ def test_odd_grid_dimensions(dims):
     n = 40 * dims[0] * dims[1] * dims[2]
     xyz = np.stack([rng.integers(0, 4 * d, n) for d in dims], axis=-1)
     grid.insert_many(xyz, rng.integers(0, 8, n))
-    for variant in (0, 1, 2, 3, 5, 6, 7, 8):
-        rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, kernel_variant=variant)
+    for variant in available_variants((0, 1, 2, 3, 5, 6, 7, 8, 9)):
+        rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, **variant_kwargs(variant))
         rt.camera.look_at((30.0, -25.0, 40.0), (0.0, 5.0, 0.0))
         rt.draw()
         f, u, c = rt.read_rgba32f(), rt.read_rgba8(), rt.counters()
@@ -511,7 +517,7 @@ def test_path_kernel_all_material_types_many_samples(variant):
     grid = BrickGrid(32, 32, 32, min_point=(-32, -32, -32), scale=2.0, brick_dimension=8, brick_alloc=9000)
     grid.synth_sparse(7, 0.1)
     w = W.Workload("t", 200, 120, 256, 8, 5, 3, True, 5.0, "sparse", 0.1, 9000)
-    rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, kernel_variant=variant)
+    rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, **variant_kwargs(variant))
     rt.push_materials(mats)
     for view in ["V1", "V1x"]:
         W.set_view(rt, view)
@@ -576,7 +582,7 @@ def test_axis_aligned_rays_jump_to_the_box(variant, bounces):
     rng = np.random.default_rng(3)
     grid.insert_many(np.stack([rng.integers(40, 88, 6000) for _ in range(3)], axis=-1), rng.integers(0, 6, 6000))  # cells 5..10 of 16
     w = W.Workload("axis", 65, 33, 128, b, 2 if bounces else 1, bounces, True, 0.0)
-    rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, kernel_variant=variant)
+    rt = W.make_renderer(w, grid, want_float_output=True, enable_counters=True, **variant_kwargs(variant))
     rt.push_materials(default_materials(256))
     scene = oracle_scene_from_grid(grid)
     hits = 0
@@ -591,3 +597,26 @@ def test_axis_aligned_rays_jump_to_the_box(variant, bounces):
         hits += co["hits"]
     rt.deinit()
     assert hits > 0
+
+
+def test_dev_lds_variant_falls_back_to_global_memory():
+    """Development build: the LDS-staged status bitmap (variant 6) of the reference app's 128x64x128 grid is 128 KiB, above the
+    64 KiB budget — vrt_create selects the global-memory kernel and says so."""
+    from zig_vulkan_amd import BrickGrid, Config, SunConfig, VoxelRT
+    kw = variant_kwargs(6)
+    grid = BrickGrid(128, 64, 128, min_point=(-32.0, -16.0, -32.0), scale=0.5, brick_dimension=4)
+    rt = VoxelRT(grid, Config(internal_resolution_width=64, internal_resolution_height=64, sun=SunConfig(enabled=True), **kw))
+    assert "global-memory variant" in rt.kernel_name()
+    rt.deinit()
+
+
+def test_product_build_refuses_development_variants():
+    """The product library holds only the kernels it chooses itself: a development variant is an argument error, not a silent
+    substitution."""
+    w = W.Workload("t", 64, 64, 64, 4, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    for variant in (1, 2, 3, 4, 6, 7, 8, 0x805, (1 << 23) | (1 << 22)):
+        with pytest.raises(L.VrtError) as e:
+            W.make_renderer(w, grid, kernel_variant=variant)
+        assert e.value.code == L.VRT_E_INVALID_ARG and "development" in str(e.value)
+    assert L.lib.vrt_compiled_kernel_count() <= 40

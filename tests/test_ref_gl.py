@@ -187,8 +187,49 @@ def test_live_llvmpipe_lowering_rules_are_as_assumed():
         assert np.array_equal(bits(o[:, 0]), bits(mine))                                          # gallivm's sine
 
 
+# ---------------------------------------------------------------------------------------------- full-size reference frames
+# tests/golden/ref_full/*.npz (make_ref_golden.py main_full): the headline workload at 1920x1080 / 512^3 / 8^3 bricks and the
+# reference app's own default run, rendered by the reference shader under llvmpipe; whole-frame SHA-256 + band hashes + crops.
+FULL = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_full", "*.npz")))
+_FULL_GRIDS = {}
+
+
+def _full_scene(z):
+    from tests.golden.make_golden import scene_digest
+    from tests.helpers import oracle_scene_from_grid
+    from zig_vulkan_amd import workloads as W
+    w = W.WORKLOADS[str(z["workload"])]
+    if w.name not in _FULL_GRIDS:
+        _FULL_GRIDS.clear()
+        grid = W.build_grid(w)
+        assert scene_digest(grid) == str(z["scene_sha256"]), "the synthetic scene generator no longer produces the fixture's scene"
+        _FULL_GRIDS[w.name] = oracle_scene_from_grid(grid)
+    return _FULL_GRIDS[w.name]
+
+
+@pytest.mark.parametrize("path", FULL, ids=[os.path.basename(p)[:-4] for p in FULL])
+def test_restatement_with_llvmpipe_lowering_equals_reference_shader_at_full_size(path):
+    """Every pixel of the full-size frames: oracle (llvmpipe lowering) == reference shader, by the frame's SHA-256."""
+    z = np.load(path)
+    f, u, _ = O.render(_full_scene(z), z["push_constants"].copy(), lowering="llvmpipe", want_counters=False)
+    crop = z["float_crops"].shape[1]
+    for (y, x), want in zip(z["crop_origins"], z["float_crops"]):
+        assert np.array_equal(f[y:y + crop, x:x + crop, :3].view(np.uint32), want.view(np.uint32)), (x, y)
+    assert hashlib.sha256(f.tobytes()).hexdigest() == str(z["float_sha256"])
+    assert hashlib.sha256(u.tobytes()).hexdigest() == str(z["rgba8_sha256"])
+
+
+@live
+def test_live_reference_shader_reproduces_fullsize_headline_fixture():
+    z = np.load([p for p in FULL if p.endswith("cfg2_r5_V2.npz")][0])
+    f, u = ref_gl.ReferenceShader(int(z["brick_dimension"])).render(_full_scene(z), z["push_constants"].copy())
+    assert hashlib.sha256(f.tobytes()).hexdigest() == str(z["float_sha256"])
+    assert hashlib.sha256(u.tobytes()).hexdigest() == str(z["rgba8_sha256"])
+
+
 # ---------------------------------------------------------------------------------------------- GPU: HIP vs fixtures
-def _hip_render(z):
+def _hip_render(z, **config):
+    """The fixture's inputs through the C ABI; config: extra VoxelRT.Config fields (library=..., kernel_variant=...)."""
     from zig_vulkan_amd import BrickGrid, Config, VoxelRT
     from zig_vulkan_amd import _lib as L
     import ctypes as C
@@ -200,7 +241,7 @@ def _hip_render(z):
     w, h = (int(v) for v in np.frombuffer(pc[:8], dtype=np.uint32))
     grid = BrickGrid(*dim, min_point=tuple(float(v) for v in fl[8:11]), scale=float(fl[15]), brick_dimension=b,
                      brick_alloc=int(z["brick_start_index"].size))
-    cfg = Config(internal_resolution_width=w, internal_resolution_height=h, want_float_output=True)
+    cfg = Config(internal_resolution_width=w, internal_resolution_height=h, want_float_output=True, **config)
     rt = VoxelRT(grid, cfg, upload_grid=False)
     # the fixture's seven buffers, byte for byte, through the same entry point the host uses (Pipeline.transfer*)
     for buf, key in ((L.BUF_GRID_STATE, "grid_state"), (L.BUF_MATERIALS, "materials"), (L.BUF_BRICK_STATUS, "brick_status"),

@@ -1,0 +1,148 @@
+"""HIP == the reference shader's own frames, BIT FOR BIT — bounces, soft sun and every scatter function included.
+
+The product kernels fuse fma and evaluate dot as an fma chain (what GLSL leaves to the implementation, and what hardware does);
+the only executable reference, Mesa llvmpipe, does neither, and one ulp in the argument of the sin-hash RNG (rand.comp:3-20)
+makes every stochastic sample an independent draw — so the product can be compared with the reference's stochastic frames only as
+images (tests/test_ref_gl.py).  libvrt_hip_reflow.so is the SAME kernel source compiled with -DVRT_LOWERING_LLVMPIPE: fma, dot
+and the two hash12 forms lowered as llvmpipe lowers them (vrt_math.h; the hand-written loops hold only additions and compares).
+Every other statement — ray set-up, both DDA levels, the skip to the occupied-cell box, scatter functions, RNG, shading,
+tone-map, store, the path kernel's lane scheduling — is the product's, and here it must reproduce
+
+  * tests/golden/ref/*.npz      all eleven frames the reference shader rendered under llvmpipe (160x90 ... 256x256), and
+  * tests/golden/ref_full/*.npz the headline workload at its full 1920x1080 / 512^3 / 8^3 bricks (hard and soft sun, V0/V1/V2)
+                                and the reference app's own default run (1024x576, 128x64x128 bricks of 4^3, 2 spp, 2 bounces),
+                                as SHA-256 of the whole frame + per-band hashes + float crops,
+
+with zero differing bits (north_star asks for 1e-4 per channel).  Made by tests/golden/make_ref_golden.py from
+/root/reference/assets/shaders/brick_raytracer.comp:153-596 and rand.comp:3-26.
+"""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_ref_gl import FIXTURES, IDS, _hip_render
+from zig_vulkan_amd import _lib as L
+from zig_vulkan_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+FULL = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_full", "*.npz")))
+FULL_IDS = [os.path.basename(p)[:-4] for p in FULL]
+PATH = 1 << 23       # force vrt_path_kernel (persistent lanes) on scenes the library would give to the lockstep kernel
+LOCKSTEP = 1 << 21
+
+
+def _reflow():
+    # (no skip: __graft_entry__.build() builds the twin, and a GPU box without it must fail loudly)
+    assert os.path.exists(L.REFLOW_LIB_PATH), "libvrt_hip_reflow.so is missing: make -C zig_vulkan_amd/csrc reflow"
+    return L.REFLOW_LIB_PATH
+
+
+def _assert_is_fixture(f, u, z):
+    diff = int((f[:, :, :3].view(np.uint32) != z["rgb32f"].view(np.uint32)).any(axis=2).sum())
+    assert diff == 0, f"{diff} of {f.shape[0] * f.shape[1]} pixels differ from the reference shader's frame"
+    assert np.array_equal(u, z["rgba8"])
+    assert np.all(f[:, :, 3] == 1.0)
+    assert hashlib.sha256(np.ascontiguousarray(f).tobytes()).hexdigest() == str(z["float_sha256"])
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=IDS)
+def test_reflow_kernels_reproduce_the_reference_shaders_frame_bit_for_bit(path):
+    z = np.load(path)
+    f, u = _hip_render(z, library=_reflow())
+    _assert_is_fixture(f, u, z)
+
+
+@pytest.mark.parametrize("path", [p for p in FIXTURES if "path_" in p or "sparse_" in p], ids=lambda p: os.path.basename(p)[:-4])
+@pytest.mark.parametrize("variant", [PATH, LOCKSTEP], ids=["path-kernel", "lockstep-kernel"])
+def test_reflow_bounce_frames_on_both_bounce_kernels(path, variant):
+    """The fixtures with bounces (all scatter functions, soft sun, several samples) through vrt_path_kernel and through the lockstep
+    kernel: the reference's frame either way."""
+    z = np.load(path)
+    f, u = _hip_render(z, library=_reflow(), kernel_variant=variant)
+    _assert_is_fixture(f, u, z)
+
+
+def test_reflow_differs_from_the_product_only_where_lowering_can():
+    """Sanity of the set-up itself: the twin is NOT the product (on a stochastic fixture the two builds must differ somewhere — if
+    they did not, the flag would not have reached the kernels), and on a deterministic fixture they agree to the last few bits."""
+    z = np.load([p for p in FIXTURES if "path_b4_spp3" in p][0])
+    fr, _ = _hip_render(z, library=_reflow())
+    fp, _ = _hip_render(z)
+    assert not np.array_equal(fr, fp)
+    z = np.load([p for p in FIXTURES if "cfg0_V1" in p][0])
+    fr, _ = _hip_render(z, library=_reflow())
+    fp, _ = _hip_render(z)
+    d = np.abs(fr - fp).max(axis=2)
+    assert float((d <= 1e-6).mean()) > 0.999
+
+
+# ---------------------------------------------------------------------------------------------- full size
+_GRIDS = {}
+
+
+def _full_render(z, **config):
+    from tests.golden.make_golden import scene_digest
+    import ctypes as C
+    w = W.WORKLOADS[str(z["workload"])]
+    grid = _GRIDS.get(w.name)
+    if grid is None:
+        _GRIDS.clear()      # (one 146 MiB grid at a time)
+        grid = _GRIDS.setdefault(w.name, W.build_grid(w))
+    assert scene_digest(grid) == str(z["scene_sha256"]), "the synthetic scene generator no longer produces the fixture's scene"
+    width, height = (int(v) for v in z["size"])
+    rt = W.make_renderer(w, grid, width=width, height=height, want_float_output=True, **config)
+    pc = z["push_constants"].tobytes()
+    C.memmove(C.byref(rt.camera.d_camera), pc[:96], 96)
+    C.memmove(C.byref(rt.sun.device_data), pc[96:], 32)
+    rt.draw()
+    f, u, name = rt.read_rgba32f(), rt.read_rgba8(), rt.kernel_name()
+    rt.deinit()
+    return f, u, name
+
+
+@pytest.mark.parametrize("path", FULL, ids=FULL_IDS)
+def test_reflow_kernels_reproduce_the_reference_shader_at_full_size(path):
+    z = np.load(path)
+    f, u, name = _full_render(z, library=_reflow())
+    width, height = (int(v) for v in z["size"])
+    band = int(z["band_rows"])
+    bad = [i for i, y in enumerate(range(0, height, band))
+           if hashlib.sha256(np.ascontiguousarray(f[y:y + band]).tobytes()).hexdigest() != str(z["band_sha256"][i])]
+    crop = z["float_crops"].shape[1]
+    for (y, x), want in zip(z["crop_origins"], z["float_crops"]):
+        got = f[y:y + crop, x:x + crop, :3]
+        n = int((got.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert n == 0, f"{name}: crop at ({x},{y}): {n} pixels differ from the reference shader's"
+    assert not bad, f"{name}: bands of {band} rows that differ from the reference shader's frame: {bad[:20]} ({len(bad)} of {len(z['band_sha256'])})"
+    assert hashlib.sha256(f.tobytes()).hexdigest() == str(z["float_sha256"])
+    assert hashlib.sha256(u.tobytes()).hexdigest() == str(z["rgba8_sha256"])
+
+
+def test_full_size_fixtures_exist():
+    names = set(FULL_IDS)
+    assert {f"cfg2_r{r}_{v}" for r in (0, 5) for v in ("V0", "V1", "V2")} <= names
+    assert {"refapp_V0", "refapp_256x144_V0", "refapp_256x144_V2"} <= names
+    for p in FULL:
+        assert "brick_raytracer.comp" in str(np.load(p)["provenance"])
+
+
+@pytest.mark.parametrize("path", [p for p in FULL if "cfg2_r0_" in p], ids=lambda p: os.path.basename(p)[:-4])
+def test_product_kernels_within_tolerance_of_the_reference_shader_at_full_size(path):
+    """The PRODUCT build (fused fma) against the reference shader's own headline frames, hard sun (no pixel depends on sin): within
+    north_star's 1e-4 per channel on the crops except at isolated pixels where a last-bit difference flips a DDA tie or a hit / miss
+    (VERDICT r02 measured 0 / 11 / 29 such pixels of 2 073 600 on V0 / V1 / V2)."""
+    z = np.load(path)
+    f, u, name = _full_render(z)
+    crop = z["float_crops"].shape[1]
+    flipped = total = 0
+    for (y, x), want in zip(z["crop_origins"], z["float_crops"]):
+        d = np.abs(f[y:y + crop, x:x + crop, :3] - want).max(axis=2)
+        flipped += int((d > 1e-4).sum())
+        total += d.size
+        assert float(d[d <= 1e-4].max()) <= 1e-6
+    assert flipped <= max(2, total // 2000), (name, flipped, total)
+    assert np.abs(f[:, :, :3].mean(axis=(0, 1)) - z["mean_rgb"]).max() <= 1e-5

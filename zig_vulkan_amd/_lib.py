@@ -33,6 +33,9 @@ ERROR_NAMES = {
     VRT_E_RCCL: "VRT_E_RCCL",
 }
 
+# vrt_config.tuning_flags (VRT_TUNE_*): A/B switches, every setting renders the same frame
+TUNE_NO_SKIP_TO_BOX, TUNE_NO_PATH_BRICK_LDS, TUNE_NO_PATH_HALFBLOCKS, TUNE_PATH_EAGER_START, TUNE_DIST_NO_BROADCAST = 1, 2, 4, 8, 16
+
 # vrt_buffer_id — shader bindings 1..7
 BUF_GRID_STATE, BUF_MATERIALS, BUF_BRICK_STATUS, BUF_BRICK_INDEX, BUF_BRICK_OCCUPANCY, BUF_BRICK_START_INDEX, BUF_MATERIAL_INDEX = range(7)
 BUF_COUNT = 7
@@ -93,7 +96,8 @@ class Config(C.Structure):  # vrt_config
         ("kernel_variant", C.c_uint32),
         ("frames_in_flight", C.c_uint32),
         ("shard_root_weight", C.c_uint32),
-        ("_reserved", C.c_uint32 * 5),
+        ("tuning_flags", C.c_uint32),
+        ("_reserved", C.c_uint32 * 4),
     ]
 
 
@@ -139,6 +143,7 @@ SIGNATURES = {
     "vrt_abi_version": (C.c_uint32, []),
     "vrt_last_error": (C.c_char_p, [_ctx]),
     "vrt_kernel_name": (C.c_char_p, [_ctx]),
+    "vrt_compiled_kernel_count": (C.c_int, []),
     "vrt_create": (C.c_int, [_P(Config), _P(_ctx)]),
     "vrt_destroy": (None, [_ctx]),
     "vrt_upload": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64]),
@@ -216,7 +221,8 @@ ERROR_NAMES.update({VOX_E_INVALID_ID: "InvalidId", VOX_E_EXPECTED_SIZE_HEADER: "
                     VOX_E_MULTIPLE_PACK_CHUNKS: "MultiplePackChunks"})
 
 
-def _load() -> C.CDLL:
+def load_library(path: str) -> C.CDLL:
+    """Load one build of the library and bind every function include/vrt_hip.h declares (AttributeError if one is absent)."""
     # torch bundles its own libamdhip64.so.7; whichever HIP runtime is mapped first serves the whole
     # process.  Load torch's first so libvrt_hip.so (NEEDED libamdhip64.so.7) shares it — the other
     # order leaves torch with "No HIP GPUs are available".
@@ -224,21 +230,29 @@ def _load() -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    if not os.path.exists(LIB_PATH):
+    path = os.path.abspath(path)
+    if path in _loaded:
+        return _loaded[path]
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `make -C zig_vulkan_amd/csrc` (or __graft_entry__.build()). "
+            f"{path} is missing: build it with `make -C zig_vulkan_amd/csrc` (or __graft_entry__.build()). "
             "zig_vulkan_amd has no non-HIP implementation of the traversal path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
     if lib.vrt_abi_version() != VRT_ABI_VERSION:
-        raise ImportError("libvrt_hip.so ABI version mismatch")
+        raise ImportError(f"{path}: ABI version mismatch")
+    _loaded[path] = lib
     return lib
 
 
-lib = _load()
+_loaded: dict = {}
+lib = load_library(LIB_PATH)
+# test-infrastructure twins of the product library (zig_vulkan_amd/csrc/Makefile); absent unless built
+REFLOW_LIB_PATH = os.path.join(_HERE, "libvrt_hip_reflow.so")  # GLSL built-ins lowered as Mesa llvmpipe lowers them (make reflow)
+DEV_LIB_PATH = os.path.join(_HERE, "libvrt_hip_dev.so")        # + the variants that lost their A/B measurement (make dev)
 
 
 def rccl_library_path() -> str:

@@ -20,11 +20,13 @@
 #include <thread>
 #include "host_brick_grid.hpp"
 #include "vrt_internal.h"
+#include "vrt_kernels.h"
 
 namespace vrt {
-using KernelFn = void (*)(const TraceParams);
 KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, int shade);
 KernelFn path_kernel_halfblock_twin(KernelFn fn);
+bool is_path_halfblock_kernel(KernelFn fn);
+const char *kernel_name_of(KernelFn fn);
 uint32_t resolve_variant(uint32_t variant);
 size_t trace_lds_bytes(const TraceParams &p, uint32_t variant);
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream, uint32_t frames = 1);
@@ -87,7 +89,6 @@ struct RcclApi {
         VRT_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef VRT_RCCL_SYM
         Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(lib, "ncclBroadcast"));
-        if (std::getenv("VRT_DIST_NO_BROADCAST")) Broadcast = nullptr; // test knob: the send / recv form of vrt_dist_broadcast
         CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
         CommUserRank = reinterpret_cast<decltype(CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
         return true;
@@ -189,9 +190,11 @@ struct vrt_ctx {
     uint32_t path_lds_bytes = 0;           // LDS block filter of vrt_path_kernel (0: grid not eligible)
     vrt::KernelFn kernel_single = nullptr; // specialisation for max_bounce <= 1
     vrt::KernelFn kernel_single1 = nullptr; // ... and samples_per_pixel == 1
+    vrt::KernelFn product[3] = {};         // counting contexts: the product kernel that renders the frame read back, by shade (0 bounces, 1, 2)
+    vrt::KernelFn last_fn = nullptr;       // the kernel of the most recent frame (vrt_kernel_name)
     vrt_shard_info shard{};
     std::string err;
-    std::string kernel_name;
+    std::string kernel_name, name_note;
 };
 
 namespace {
@@ -200,6 +203,13 @@ int fail(vrt_ctx *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg;
     else g_create_error = msg;
     return code;
+}
+
+// remember which kernel rendered the most recent frame (vrt_kernel_name reports what ran, not what was asked for)
+void note_kernel(vrt_ctx *c, vrt::KernelFn fn) {
+    if (fn == c->last_fn) return;
+    c->last_fn = fn;
+    c->kernel_name = std::string(vrt::kernel_name_of(fn)) + c->name_note;
 }
 
 int hip_fail(vrt_ctx *ctx, hipError_t e, const char *what) {
@@ -388,6 +398,8 @@ const char *vrt_last_error(const vrt_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 const char *vrt_kernel_name(const vrt_ctx *ctx) { return ctx ? ctx->kernel_name.c_str() : ""; }
 
+int vrt_compiled_kernel_count(void) { return vrt::compiled_kernel_count(); }
+
 int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (!out) return fail(nullptr, VRT_E_INVALID_ARG, "out is NULL");
     *out = nullptr;
@@ -410,6 +422,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         return fail(nullptr, VRT_E_INVALID_ARG, "tile size must be 16x16 (or 0)");
     const uint32_t shard_count = cfg->shard_count ? cfg->shard_count : 1u;
     if (cfg->shard_rank >= shard_count) return fail(nullptr, VRT_E_INVALID_ARG, "shard_rank >= shard_count");
+    if (cfg->tuning_flags & ~VRT_TUNE_ALL) return fail(nullptr, VRT_E_INVALID_ARG, "unknown tuning_flags bit");
     if ((cfg->kernel_variant & 0xFFu) >= vrt::kVariantCount || ((cfg->kernel_variant >> 28) && ((cfg->kernel_variant >> 16) & 0xFu) != 7u)) return fail(nullptr, VRT_E_INVALID_ARG, "unknown kernel_variant");
 
     int ndev = 0;
@@ -559,17 +572,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         VRT_CREATE_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(vrt::DeviceCounters), c->stream));
     }
     const uint32_t nbx = (cfg->dim_x + 3u) / 4u, nby = (cfg->dim_y + 3u) / 4u, nbz = (cfg->dim_z + 3u) / 4u;
-    const size_t nblocks = (size_t)nbx * nby * nbz;
-    const size_t status_blocks_bytes = nblocks * 8u + ((nblocks + 31u) / 32u) * 4u + 16u;
-    VRT_CREATE_HIP(hipMalloc(&c->d_status_blocks, status_blocks_bytes));
-    VRT_CREATE_HIP(hipMemsetAsync(c->d_status_blocks, 0, status_blocks_bytes, c->stream));
     VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_cell_bounds), 6 * sizeof(int)));
     VRT_CREATE_HIP(hipMemsetAsync(c->d_cell_bounds, 0x80, 6 * sizeof(int), c->stream)); // no cell occupied yet
-    {
-        const size_t status_bytes_size = (size_t)((cells + 31u) / 32u) * 32u + 64u; // 32 bytes per status word
-        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_status_bytes), status_bytes_size));
-        VRT_CREATE_HIP(hipMemsetAsync(c->d_status_bytes, 0, status_bytes_size, c->stream));
-    }
+    // (the other derived copies of the status bits — byte per cell, half-block words, 4^3 block words — are allocated further
+    // down, each only when a kernel this context selects reads it)
     {
         // tile schedule starts as reverse raster (bottom rows first); the feedback kernel refines it
         const uint32_t n = sh.owned_tiles ? sh.owned_tiles : 1u;
@@ -610,8 +616,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         VRT_CREATE_HIP(hipEventCreateWithFlags(&c->staging_ev[i], hipEventDisableTiming));
     }
 
-    // the bounce kernel comes in a 4- and an 8-waves-per-SIMD build (vrt_trace.hip, pick_variant): the second one for scenes
-    // whose traversal structures (bindings 3-5) exceed what the caches hold
+    // the bounce kernel comes in a 4- and an 8-waves-per-SIMD build (vrt_trace.hip, select_trace_kernel): the second one for
+    // scenes whose traversal structures (bindings 3-5) exceed what the caches hold
     c->bounce_variant = cfg->kernel_variant;
     if (((cfg->kernel_variant >> 8) & 0xFFu) == 0u &&
         c->dsize[VRT_BUF_BRICK_STATUS] + c->dsize[VRT_BUF_BRICK_INDEX] + c->dsize[VRT_BUF_BRICK_OCCUPANCY] > (192ull << 20))
@@ -620,23 +626,37 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     // Frames without bounces, mode left to the library: the hand-written loops on the byte-per-cell copy of the status bits for
     // grids up to 64^3 cells (1080p / 512^3 / 8^3 bricks V1, V2: 0.122 -> 0.118 ms, 1080p / 256^3 / 4^3: 0.098 -> 0.095; a tail-bound
     // frame from outside the grid pays 5 % for the larger footprint), the words beyond (128^3 cells: -4 % inside, +9 ... +22 % outside)
-    const uint32_t single_variant = ((cfg->kernel_variant & 0xFFu) == vrt::kVariantDefault && cells <= (1ull << 18))
-                                        ? (cfg->kernel_variant | (uint32_t)vrt::kVariantBytes) : cfg->kernel_variant;
-    const uint32_t lockstep_variant = c->bounce_variant | vrt::kVariantLockstepBounce; // (before the path kernel's occupancy is filled in below)
+    uint32_t single_variant = ((cfg->kernel_variant & 0xFFu) == vrt::kVariantDefault && cells <= (1ull << 18))
+                                  ? (cfg->kernel_variant | (uint32_t)vrt::kVariantBytes) : cfg->kernel_variant;
     {
-        // vrt_path_kernel with the LDS block filter: x and z dimensions powers of two >= 4, y a multiple of 4, filter <= 32 KiB
-        // (two 640-thread workgroups per CU keep their copies next to the staged bricks), cell index < 2^31
+        // development variants that stage a structure in LDS: a grid whose structure exceeds the budget reads global memory instead
+        vrt::TraceParams sizes{};
+        sizes.nbx = nbx, sizes.nby = nby, sizes.nbz = nbz;
+        sizes.status_words = (uint32_t)((cells + 31u) / 32u);
+        c->lds_bytes = vrt::trace_lds_bytes(sizes, cfg->kernel_variant);
+        if (c->lds_bytes > 64u * 1024u) {
+            const uint32_t mode = vrt::resolve_variant(cfg->kernel_variant) & 0xFFu;
+            const uint32_t fallback = (mode == vrt::kVariantLinearLds || mode == vrt::kVariantLinearLds512) ? vrt::kVariantLinearAlways : vrt::kVariantBlocked;
+            c->cfg.kernel_variant = (cfg->kernel_variant & ~0xFFu) | fallback;
+            single_variant = c->cfg.kernel_variant;
+            c->bounce_variant = (c->bounce_variant & ~0xFFu) | fallback;
+            c->lds_bytes = 0;
+            c->name_note = "[LDS structure > 64 KiB: global-memory variant]";
+        }
+    }
+    uint32_t lockstep_variant = c->bounce_variant | vrt::kVariantLockstepBounce; // (before the path kernel's occupancy is filled in below)
+    bool want_halfblocks = false;
+    {
         auto pow2 = [](uint32_t v) { return v >= 4u && (v & (v - 1u)) == 0u; };
-        const uint64_t nblocks64 = (uint64_t)((cfg->dim_x + 3u) / 4u) * ((cfg->dim_y + 3u) / 4u) * ((cfg->dim_z + 3u) / 4u);
+        // Development build only (kernel_variant bit 22): the block-skipping walk of vrt_path_kernel<FILTER> — lanes in empty
+        // 4x4x4 blocks jump to the block's exit face instead of taking a trip per cell.  x and z dimensions powers of two >= 4,
+        // y a multiple of 4, filter <= 32 KiB, cell index < 2^31.  Measured on the 2048^3 path trace: 10 % fewer wave-cycles
+        // per frame, but the filter's 32 KiB of LDS allow four waves per SIMD instead of five: 200 ms against 176.
+        const uint64_t nblocks64 = (uint64_t)nbx * nby * nbz;
         size_t bytes = 16;
         while (bytes < ((nblocks64 + 31u) / 32u) * 4u) bytes <<= 1;
-        // Opt-in (kernel_variant bit 22, or VRT_PATH_BLOCK_SKIP=1): the block-skipping walk (vrt_path_kernel<FILTER>: lanes in
-        // empty 4x4x4 blocks jump to the block's exit face instead of taking a trip per cell).  Measured on the 2048^3 path trace:
-        // 10 % fewer wave-cycles per frame, but the filter's 32 KiB of LDS allow four waves per SIMD instead of five, and the
-        // frame takes 200 ms against 176.
         const bool eligible = pow2(cfg->dim_x) && pow2(cfg->dim_z) && cfg->dim_y % 4u == 0u && bytes <= (32u << 10);
-        bool block_skip = eligible && (cfg->kernel_variant & vrt::kVariantPathFilter) != 0u;
-        if (const char *e = std::getenv("VRT_PATH_BLOCK_SKIP")) block_skip = eligible && std::atoi(e) != 0; // tuning knob (A/B)
+        const bool block_skip = eligible && (cfg->kernel_variant & vrt::kVariantPathFilter) != 0u;
         if (block_skip) {
             c->path_lds_bytes = (uint32_t)bytes;
             c->bounce_variant |= vrt::kVariantPathFilter;
@@ -655,38 +675,69 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
             c->bounce_variant &= ~vrt::kVariantLockstepBounce;
             if (mwv == 0u) c->bounce_variant = (c->bounce_variant & ~0xFF00u) | (5u << 8);
             // the path kernel's walk loop reads the status bits by half-blocks of 4 x 4 x 2 cells where the grid allows (x, z
-            // powers of two >= 4, y even): a third of the L1 requests of the linear words (vrt_trace.hip)
-            bool halfblocks = pow2(cfg->dim_x) && pow2(cfg->dim_z) && cfg->dim_y % 2u == 0u;
-            if (const char *e = std::getenv("VRT_PATH_HALFBLOCKS")) halfblocks = halfblocks && std::atoi(e) != 0; // tuning knob (A/B)
-            if (halfblocks) {
-                const size_t bytes_hb = (size_t)(cells / 32u) * 4u + 64u;
-                VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_status_halfblocks), bytes_hb));
-                VRT_CREATE_HIP(hipMemsetAsync(c->d_status_halfblocks, 0, bytes_hb, c->stream));
-            }
+            // powers of two >= 4, y even): a third of the L1 requests of the linear words (vrt_trace_kernels.h)
+            want_halfblocks = pow2(cfg->dim_x) && pow2(cfg->dim_z) && cfg->dim_y % 2u == 0u && !block_skip &&
+                              !(cfg->tuning_flags & VRT_TUNE_NO_PATH_HALFBLOCKS);
         } else {
             c->bounce_variant |= vrt::kVariantLockstepBounce;
         }
     }
-    c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->bounce_variant, 0);
-    if (c->d_status_halfblocks) c->kernel = vrt::path_kernel_halfblock_twin(c->kernel);
-    c->kernel_lockstep = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, lockstep_variant, 0);
+    auto select_all = [&]() {
+        const bool cnt = cfg->enable_counters != 0;
+        c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cnt, c->bounce_variant, 0);
+        if (want_halfblocks) c->kernel = vrt::path_kernel_halfblock_twin(c->kernel);
+        c->kernel_lockstep = vrt::select_trace_kernel((int)cfg->brick_dimension, cnt, lockstep_variant, 0);
+        c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cnt, single_variant, 1);
+        c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cnt, single_variant, 2);
+        // a counting context renders the frame that is read back with the product kernels (do_dispatch)
+        for (int shade = 0; shade < 3; shade++) {
+            c->product[shade] = nullptr;
+            if (!cnt) continue;
+            c->product[shade] = vrt::select_trace_kernel((int)cfg->brick_dimension, false, shade == 0 ? c->bounce_variant : single_variant, shade);
+            if (shade == 0 && want_halfblocks) c->product[shade] = vrt::path_kernel_halfblock_twin(c->product[shade]);
+        }
+    };
+    select_all();
     c->single_variant = single_variant;
-    c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, single_variant, 1);
-    c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, single_variant, 2);
+    {
+        const bool cnt = cfg->enable_counters != 0;
+        if (!c->kernel || !c->kernel_lockstep || !c->kernel_single || !c->kernel_single1 ||
+            (cnt && (!c->product[0] || !c->product[1] || !c->product[2]))) {
+            free_ctx(c);
+#ifdef VRT_DEV_VARIANTS
+            return fail(nullptr, VRT_E_INVALID_ARG, "no kernel for this configuration");
+#else
+            return fail(nullptr, VRT_E_INVALID_ARG, "no kernel for this kernel_variant in the product build of libvrt_hip (development variants: make dev)");
+#endif
+        }
+        // derived copies of the status bits, each only if a kernel of this context reads it
+        auto any_kernel = [&](auto pred) {
+            const vrt::KernelFn fns[7] = {c->kernel, c->kernel_lockstep, c->kernel_single, c->kernel_single1, c->product[0], c->product[1], c->product[2]};
+            for (vrt::KernelFn fn : fns) {
+                const vrt::KernelEntry *e = fn ? vrt::kernel_entry_of(fn) : nullptr;
+                if (e && pred(*e)) return true;
+            }
+            return false;
+        };
+        if (any_kernel([](const vrt::KernelEntry &e) { return !e.path && e.mode == vrt::kStatusBytes; })) {
+            const size_t status_bytes_size = (size_t)((cells + 31u) / 32u) * 32u + 64u; // 32 bytes per status word
+            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_status_bytes), status_bytes_size));
+            VRT_CREATE_HIP(hipMemsetAsync(c->d_status_bytes, 0, status_bytes_size, c->stream));
+        }
+        if (any_kernel([](const vrt::KernelEntry &e) { return e.path && e.half; })) {
+            const size_t bytes_hb = (size_t)(cells / 32u) * 4u + 64u;
+            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_status_halfblocks), bytes_hb));
+            VRT_CREATE_HIP(hipMemsetAsync(c->d_status_halfblocks, 0, bytes_hb, c->stream));
+        }
+        if (any_kernel([](const vrt::KernelEntry &e) { return (e.path && e.filter) || (!e.path && (e.mode == vrt::kStatusBlocked || e.mode == vrt::kStatusBlockedLds)); })) {
+            const size_t nblocks = (size_t)nbx * nby * nbz;
+            const size_t status_blocks_bytes = nblocks * 8u + ((nblocks + 31u) / 32u) * 4u + 16u;
+            VRT_CREATE_HIP(hipMalloc(&c->d_status_blocks, status_blocks_bytes));
+            VRT_CREATE_HIP(hipMemsetAsync(c->d_status_blocks, 0, status_blocks_bytes, c->stream));
+        }
+    }
     VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_work_counter), 2u * vrt::kMaxBatchFrames * sizeof(uint32_t)));
     VRT_CREATE_HIP(hipMemsetAsync(c->d_work_counter, 0, 2u * vrt::kMaxBatchFrames * sizeof(uint32_t), c->stream));
-    if (!c->kernel || !c->kernel_lockstep || !c->kernel_single || !c->kernel_single1) {
-        free_ctx(c);
-        return fail(nullptr, VRT_E_INVALID_ARG, "no kernel for this configuration");
-    }
-    {
-        char buf[96];
-        static const char *const mode_names[] = {"?", "linear-status+byte-occupancy", "blocked-status", "blocked-status+lds-filter", "linear-status+wide-occupancy", "linear-status-uncached", "linear-status-in-lds", "linear-status-in-lds(512-thread groups)", "linear-status-one-cell-ahead", "byte-status"};
-        const uint32_t rv = vrt::resolve_variant(single_variant); // (the kernel of frames without bounces; DESIGN.md §4 for the others)
-        std::snprintf(buf, sizeof buf, "vrt_trace_kernel<B=%u,COUNT=%d,%s,minwaves=%u>", cfg->brick_dimension, cfg->enable_counters ? 1 : 0,
-                      mode_names[rv & 0xFFu], ((rv >> 8) & 0xFFu) ? ((rv >> 8) & 0xFFu) : 4u); // (as asked; the library's own choices: DESIGN.md §4)
-        c->kernel_name = buf;
-    }
 
     vrt::TraceParams &p = c->params;
     std::memset(&p, 0, sizeof p);
@@ -700,8 +751,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.target_rgba32f = c->target32f;
     p.counters = c->d_counters;
     p.count_box = (cfg->enable_counters == 2u) ? 1u : 0u;
-    p.skip_to_box = 1u;
-    if (const char *e = std::getenv("VRT_SKIP_TO_BOX")) p.skip_to_box = std::atoi(e) ? 1u : 0u; // tuning knob (A/B measurements)
+    p.skip_to_box = (cfg->tuning_flags & VRT_TUNE_NO_SKIP_TO_BOX) ? 0u : 1u;
     p.work_counter = c->d_work_counter;
     p.path_lds_bytes = c->path_lds_bytes;
     {
@@ -709,16 +759,20 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
         p.path_groups = 8u * (uint32_t)cus; // twice what 4 waves per SIMD hold: late groups find the counter exhausted and leave
         p.path_fin_batch = 32u;
-        if (const char *e = std::getenv("VRT_PATH_FIN_BATCH")) p.path_fin_batch = (uint32_t)std::max(1, std::atoi(e)); // tuning knob
-        p.path_brick_lds = (cfg->brick_dimension == 8u) ? 1u : 0u;
-        if (const char *e = std::getenv("VRT_PATH_BRICK_LDS")) p.path_brick_lds = (std::atoi(e) && cfg->brick_dimension == 8u) ? 1u : 0u; // tuning knob (A/B)
+        p.path_brick_lds = (cfg->brick_dimension == 8u && !(cfg->tuning_flags & VRT_TUNE_NO_PATH_BRICK_LDS)) ? 1u : 0u;
         p.path_skip_rounds = 8u;
         p.path_ready_batch = 32u;
-        if (const char *e = std::getenv("VRT_PATH_SKIP_ROUNDS")) p.path_skip_rounds = (uint32_t)std::max(1, std::atoi(e)); // tuning knobs
-        if (const char *e = std::getenv("VRT_PATH_READY_BATCH")) p.path_ready_batch = (uint32_t)std::max(1, std::atoi(e));
-        p.path_eager_start = 0u;
-        if (const char *e = std::getenv("VRT_PATH_EAGER_START")) p.path_eager_start = std::atoi(e) ? 1u : 0u; // tuning knob (A/B)
-        if (const char *e = std::getenv("VRT_PATH_GROUPS")) p.path_groups = (uint32_t)std::max(1, std::atoi(e));
+        p.path_eager_start = (cfg->tuning_flags & VRT_TUNE_PATH_EAGER_START) ? 1u : 0u;
+#ifdef VRT_DEV_VARIANTS
+        // development build only: numeric knobs of vrt_path_kernel for parameter sweeps (tools/); the product reads no environment
+        auto dev_knob = [](const char *name, uint32_t &v) {
+            if (const char *e = std::getenv(name)) v = (uint32_t)std::max(1, std::atoi(e));
+        };
+        dev_knob("VRT_DEV_PATH_FIN_BATCH", p.path_fin_batch);
+        dev_knob("VRT_DEV_PATH_SKIP_ROUNDS", p.path_skip_rounds);
+        dev_knob("VRT_DEV_PATH_READY_BATCH", p.path_ready_batch);
+        dev_knob("VRT_DEV_PATH_GROUPS", p.path_groups);
+#endif
     }
     p.width = cfg->width;
     p.height = cfg->height;
@@ -759,7 +813,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.wave_groups = (cfg->kernel_variant >> 20) & 0x1u;
     p.brick_batch = (cfg->kernel_variant >> 24) & 0xFu ? ((cfg->kernel_variant >> 24) & 0xFu) * 4u : 8u; // tuning knob: units of 4 lanes
     p.path_brick_batch = (cfg->kernel_variant >> 24) & 0xFu ? ((cfg->kernel_variant >> 24) & 0xFu) * 4u : 32u; // vrt_path_kernel: waiting is cheap there
-    p.block_threads = ((vrt::resolve_variant(cfg->kernel_variant) & 0xFFu) == vrt::kVariantLinearLds512) ? 512u : 256u;
+    p.block_threads = ((vrt::resolve_variant(c->cfg.kernel_variant) & 0xFFu) == vrt::kVariantLinearLds512) ? 512u : 256u;
     {
         // a stride near owned_tiles * 0.618 that is coprime to owned_tiles
         auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
@@ -771,22 +825,6 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.nbx = nbx;
     p.nby = nby;
     p.nbz = nbz;
-    c->lds_bytes = vrt::trace_lds_bytes(p, cfg->kernel_variant);
-    if (c->lds_bytes > 64u * 1024u) {
-        // the LDS-staged structure of a very large grid does not fit the LDS budget: read from global memory
-        const uint32_t mode = vrt::resolve_variant(cfg->kernel_variant) & 0xFFu;
-        const uint32_t fallback = (mode == vrt::kVariantLinearLds || mode == vrt::kVariantLinearLds512) ? vrt::kVariantLinearAlways : vrt::kVariantBlocked;
-        c->cfg.kernel_variant = (cfg->kernel_variant & ~0xFFu) | fallback;
-        c->single_variant = c->cfg.kernel_variant;
-        c->bounce_variant = (c->bounce_variant & ~0xFFu) | fallback;
-        c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->bounce_variant, 0);
-        c->kernel_lockstep = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->bounce_variant | vrt::kVariantLockstepBounce, 0);
-        c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 1);
-        c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cfg->enable_counters != 0, c->cfg.kernel_variant, 2);
-        c->lds_bytes = 0;
-        p.block_threads = 256u;
-        c->kernel_name += "[LDS structure > 64 KiB: global-memory variant]";
-    }
     // the status bitmap is read 16 bytes at a time by the LDS-staging variant: the +16 slack of dbuf covers the tail
     if (c->stream_b) {
         // everything enqueued on the primary stream so far (clears) precedes the first frame on stream_b
@@ -794,6 +832,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         c->upload_seq = 1;
     }
 #undef VRT_CREATE_HIP
+    note_kernel(c, c->product[2] ? c->product[2] : c->kernel_single1);
     *out = c;
     return VRT_OK;
 }
@@ -903,11 +942,12 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     // so that every parity check made on a counting context checks the shipped code path.
     vrt::KernelFn product_fn = nullptr;
     if (ctx->d_counters) {
-        const int shade = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? 2 : 1) : 0;
-        product_fn = vrt::select_trace_kernel((int)ctx->cfg.brick_dimension, false, shade == 0 ? ctx->bounce_variant : ctx->single_variant, shade);
-        if (shade == 0 && ctx->d_status_halfblocks) product_fn = vrt::path_kernel_halfblock_twin(product_fn);
+        product_fn = ctx->product[(camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? 2 : 1) : 0];
         if (!product_fn) return fail(ctx, VRT_E_STATE, "no product kernel for this configuration");
     }
+    note_kernel(ctx, product_fn ? product_fn : fn);
+    // (the persistent-lane kernel takes its pixels from a counter: it neither reads the tile schedule nor reports tile costs)
+    const bool scheduled = !vrt::is_path_kernel(product_fn ? product_fn : fn);
 
     // (tile_order 5 re-sorts the tile schedule in place before every frame on the primary stream: a frame running on
     // the second stream would read it while it is being rewritten, so that order runs one frame at a time.  The
@@ -951,7 +991,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     VRT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     const uint32_t nt = ctx->shard.owned_tiles;
     const uint32_t ns = ctx->sched_stride; // stride of a schedule buffer
-    if (ctx->params.tile_order == 5u && nt > 1u && !ctx->sched_period) {
+    if (ctx->params.tile_order == 5u && nt > 1u && !ctx->sched_period && scheduled) {
         // re-sort the tile list by last frame's measured cost (inside the timed region: it is per-frame work)
         VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule + 2u * (size_t)ns, ctx->d_tile_schedule, ctx->d_tile_schedule, nt, 0u, ctx->wave_slots, ctx->stream));
     }
@@ -981,7 +1021,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     }
     for (uint32_t f = 0; f < frames; f++) {
         if (marks) VRT_HIP(ctx, hipEventRecord(marks[f], ctx->stream)); // per-frame timing (vrt_dispatch_timed)
-        if (ctx->sched_period && nt > 1u && ctx->sched_since >= ctx->sched_period) {
+        if (ctx->sched_period && nt > 1u && ctx->sched_since >= ctx->sched_period && scheduled) {
             // Amortised re-sort, in the frames' own stream (inside the timed region as well): the measured costs (running mean)
             // order the tiles into the buffer no frame reads; frames launched from here on read that one.  A sort costs about
             // 35 us of the stream's time (the kernel plus the two kernel boundaries).  Measured alternatives: on a second
@@ -1164,9 +1204,17 @@ int vrt_trace_wave_timeline(vrt_ctx *ctx, const vrt_camera_device *camera, const
     const uint64_t waves = ((uint64_t)ctx->shard.owned_tiles + (ctx->params.tile_order == 5u ? ctx->sched_extra : 0u)) * 4u;
     if (capacity_pairs < waves) return fail(ctx, VRT_E_OUT_OF_RANGE, "timeline buffer too small");
     DeviceGuard dg(ctx->device);
+    const size_t bytes = std::max<size_t>(waves * 16u, 32u * sizeof(unsigned long long)); // (the profile build of vrt_path_kernel writes 20 words)
+#ifndef VRT_DEV_PROFILE
+    {
+        // the persistent-lane kernel has no wave -> tile map to report: refuse instead of returning zeros
+        const vrt::KernelFn would = (camera && camera->max_bounce > 1) ? (ctx->d_counters ? ctx->product[0] : ctx->kernel) : nullptr;
+        if (would && vrt::is_path_kernel(would)) return fail(ctx, VRT_E_STATE, "vrt_trace_wave_timeline: frames with bounces run vrt_path_kernel on this context (no per-tile waves)");
+    }
+#endif
     unsigned long long *d = nullptr;
-    VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), waves * 16u));
-    VRT_HIP(ctx, hipMemsetAsync(d, 0, waves * 16u, ctx->stream));
+    VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), bytes));
+    VRT_HIP(ctx, hipMemsetAsync(d, 0, bytes, ctx->stream));
     ctx->params.wave_timeline = d;
     const int rc = do_dispatch(ctx, camera, sun, 1, true);
     ctx->params.wave_timeline = nullptr;
@@ -1222,6 +1270,7 @@ int vrt_dist_init_batched(vrt_ctx *ctx, const char *rccl_path, const void *id128
         delete d;
         return fail(ctx, VRT_E_RCCL, err);
     }
+    if (ctx->cfg.tuning_flags & VRT_TUNE_DIST_NO_BROADCAST) d->api.Broadcast = nullptr; // the send / recv form of vrt_dist_broadcast
     d->rank = rank;
     d->world = world;
     d->nslots = frames_in_flight;
@@ -1272,6 +1321,7 @@ int vrt_dist_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_
         const int rcf = dist_flush(ctx);
         if (rcf != VRT_OK) return rcf;
     }
+    note_kernel(ctx, fn);
     d->pend[d->npend].cam = *camera;
     d->pend[d->npend].sun = *sun;
     d->pend_fn = fn;

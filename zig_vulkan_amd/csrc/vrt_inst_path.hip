@@ -1,0 +1,19 @@
+// vrt_inst_path.hip — vrt_path_kernel (frames with bounces on scenes larger than the caches: persistent lanes).
+#include "vrt_inst_common.h"
+
+namespace vrt {
+namespace {
+const KernelEntry kEntries[] = {
+    // 5 waves per SIMD (96 VGPRs); HALF: the walk loop on half-block words (grids whose x / z dimensions are powers of two)
+    VRT_PATH_ENTRY(4, 5, false, false), VRT_PATH_ENTRY(4, 5, false, true),
+    VRT_PATH_ENTRY(8, 5, false, false), VRT_PATH_ENTRY(8, 5, false, true),
+#ifdef VRT_DEV_VARIANTS
+    VRT_PATH_ENTRY(4, 4, false, false), VRT_PATH_ENTRY(4, 4, false, true), VRT_PATH_ENTRY(8, 4, false, false), VRT_PATH_ENTRY(8, 4, false, true),
+    VRT_PATH_ENTRY(4, 6, false, false), VRT_PATH_ENTRY(8, 6, false, false),
+    // the block-skipping walk behind the LDS block filter (measured slower: DESIGN.md §4)
+    VRT_PATH_ENTRY(4, 4, true, false), VRT_PATH_ENTRY(8, 4, true, false), VRT_PATH_ENTRY(4, 5, true, false), VRT_PATH_ENTRY(8, 5, true, false),
+#endif
+};
+} // namespace
+KernelTable inst_path() { return KernelTable{kEntries, (int)(sizeof kEntries / sizeof kEntries[0])}; }
+} // namespace vrt

@@ -1,0 +1,54 @@
+// vrt_kernels.h — the table of compiled traversal kernels: what the instantiation units (vrt_inst_*.hip) export and what
+// the selection code in vrt_trace.hip searches.
+#pragma once
+#include "vrt_internal.h"
+
+namespace vrt {
+
+using KernelFn = void (*)(const TraceParams);
+
+// How the brick-level walk of vrt_trace_kernel learns whether a grid cell is occupied (template parameter MODE).
+// The product build compiles kStatusLinearAlways and kStatusBytes; the others lost their A/B measurement
+// and exist only in the development build (-DVRT_DEV_VARIANTS).
+enum StatusMode : int {
+    kStatusLinear = 0,       // the shader's own words: bit i%32 of word i/32, cached per lane (comp:318-328)
+    kStatusBlocked = 1,      // device-built 4x4x4 block words from global memory, cached per lane
+    kStatusBlockedLds = 2,   // same, behind an LDS-resident 1-bit-per-block "non-empty" filter
+    kStatusLinearWide = 3,   // linear words for status, 64-bit words for occupancy
+    kStatusLinearAlways = 4, // the hand-written loops on the shader's words, one request per trip (counting builds: compiler loops)
+    kStatusLinearLds = 5,    // the whole linear status bitmap staged in LDS per workgroup, read on every step
+    kStatusLinearAhead = 6,  // as kStatusLinearAlways, software-pipelined in C++: the next cell's word is requested before the current cell is tested
+    kStatusBytes = 7         // the hand-written loops on a byte-per-cell copy of the status bits (no shift, no bit-field extract per trip)
+};
+
+// One compiled kernel.  `name` is its template-id exactly as rocprofv3 / llvm-cxxfilt print it (vrt_kernel_name()).
+struct KernelEntry {
+    KernelFn fn;
+    const char *name;
+    uint8_t path;      // 0: vrt_trace_kernel<B, COUNT, MODE, MIN_WAVES, SHADE, BLOCK>   1: vrt_path_kernel<B, MIN_WAVES, FILTER, HALF>
+    uint8_t b;         // brick dimension
+    uint8_t count;     // trace: counting build
+    uint8_t mode;      // trace: StatusMode
+    uint8_t min_waves; // waves per SIMD the register allocator leaves room for (__launch_bounds__)
+    uint8_t shade;     // trace: 0 bounce loop, 1 max_bounce <= 1, 2 ... and one sample per pixel
+    uint16_t block;    // trace: threads per workgroup (256; 512 for the two-tiles-per-LDS-copy development variant)
+    uint8_t filter;    // path: block-skipping walk behind the LDS block filter (development)
+    uint8_t half;      // path: walk loop on half-block words
+};
+struct KernelTable {
+    const KernelEntry *entries;
+    int count;
+};
+KernelTable inst_trace_b4();
+KernelTable inst_trace_b8();
+KernelTable inst_trace_count();
+KernelTable inst_path();
+
+const KernelEntry *find_trace_kernel(int b, bool count, int mode, int min_waves, int shade, int block = 256);
+const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half);
+const KernelEntry *kernel_entry_of(KernelFn fn);
+int compiled_kernel_count();
+
+constexpr int kPathFilterThreads = 512; // vrt_path_kernel<FILTER>: eight waves share one LDS copy of the block filter
+
+} // namespace vrt

@@ -11,6 +11,17 @@
 //   reflect(I,N)  = I - (2*dot(N,I))*N
 //   sin(x)        = vrt_sin (the Cephes single-precision kernel as Mesa gallivm lowers it, fused multiply-adds)
 //   int(x)        = (int)clamp(x, -2^31, 2147483520)  (f2i_clamp)
+//
+// -DVRT_LOWERING_LLVMPIPE (make reflow -> libvrt_hip_reflow.so, test infrastructure): the same kernels with fma, dot and the
+// two hash12 forms lowered exactly as Mesa 23.2.1 llvmpipe lowers them — the rules the parity oracle applies under
+// -DORACLE_LOWERING_LLVMPIPE, measured on Mesa itself (tests/test_ref_gl.py):
+//   fma(a,b,c)    = a*b + c                          (two roundings: nir lower_ffma32)
+//   dot(a,b)      = (a.z*b.z + a.y*b.y) + a.x*b.x    (nir lower_fdot, reduction from the last channel)
+//   hash12        = the dot with its first two terms factored (nir_opt_algebraic), the jitter's constant folded
+// Nothing else differs: the hand-written loops hold only additions and compares, sin is gallivm's in both builds.  That build
+// exists to be compared BIT FOR BIT with frames the reference's own shader produced under llvmpipe (tests/golden/ref/,
+// tests/test_reflow_gpu.py): bounces, soft sun and every scatter function included, where a one-ulp difference in the
+// sin-hash RNG's argument would otherwise make every sample an independent draw.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,10 +42,21 @@ VRT_DI f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
 VRT_DI f3 operator/(f3 a, f3 b) { return f3{a.x / b.x, a.y / b.y, a.z / b.z}; }
 VRT_DI f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
 VRT_DI f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
-VRT_DI f3 fma3(f3 a, f3 b, f3 c) { return f3{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y), __builtin_fmaf(a.z, b.z, c.z)}; }
+#ifdef VRT_LOWERING_LLVMPIPE
+VRT_DI float gl_fma(float a, float b, float c) { return a * b + c; } // (-ffp-contract=off: never re-fused)
+#else
+VRT_DI float gl_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#endif
+VRT_DI f3 fma3(f3 a, f3 b, f3 c) { return f3{gl_fma(a.x, b.x, c.x), gl_fma(a.y, b.y, c.y), gl_fma(a.z, b.z, c.z)}; }
 VRT_DI f3 floor3(f3 a) { return f3{__builtin_floorf(a.x), __builtin_floorf(a.y), __builtin_floorf(a.z)}; }
 VRT_DI f3 abs3(f3 a) { return f3{__builtin_fabsf(a.x), __builtin_fabsf(a.y), __builtin_fabsf(a.z)}; }
+#ifdef VRT_LOWERING_LLVMPIPE
+VRT_DI float dot3(f3 a, f3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }
+VRT_DI float dot2(float ax, float ay, float bx, float by) { return ay * by + ax * bx; }
+#else
 VRT_DI float dot3(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+VRT_DI float dot2(float ax, float ay, float bx, float by) { return __builtin_fmaf(ay, by, ax * bx); }
+#endif
 VRT_DI f3 normalize3(f3 a) {
     const float inv = 1.0f / __builtin_sqrtf(dot3(a, a));
     return a * inv;
@@ -94,7 +116,7 @@ VRT_DI float vrt_sin(float a) {
 // ---- rand.comp (assets/shaders/rand.comp:3-26) -----------------------------
 VRT_DI float rand_1(float co) { return fract1(vrt_sin(co * 91.3458f) * 47453.5453f); }
 VRT_DI float rand_2(float cx, float cy) {
-    const float d = __builtin_fmaf(cy, 78.233f, cx * 12.9898f);
+    const float d = dot2(cx, cy, 12.9898f, 78.233f);
     return fract1(vrt_sin(d) * 43758.5453f);
 }
 VRT_DI float rand_3(f3 co) {
@@ -110,10 +132,30 @@ VRT_DI f3 rand_vec3_range(float cx, float cy, float mn, float mx) {
 }
 VRT_DI float hash_12(float px, float py) {
     f3 p3 = f3{fract1(px * .1031f), fract1(py * .1031f), fract1(px * .1031f)};
+#ifdef VRT_LOWERING_LLVMPIPE
+    // p3.z == p3.x (p.xyx), so the dot is A*(B+k) + B*(A+k) + A*(A+k); Mesa factors a*b + a*c -> a*(b+c) out of the first two
+    // terms of its reduction (the parity oracle states the same rule)
+    const float d = (p3.x + p3.y) * (p3.x + 33.33f) + p3.x * (p3.y + 33.33f);
+#else
     const f3 q = f3{p3.y + 33.33f, p3.z + 33.33f, p3.x + 33.33f};
     const float d = dot3(p3, q);
+#endif
     p3 = f3{p3.x + d, p3.y + d, p3.z + d};
     return fract1((p3.x + p3.y) * p3.z);
+}
+// comp:167,169: hash12(vec2(ax, ay) * 0.2 * float(sample_i > 0))
+VRT_DI float hash_12_jitter(float ax, float ay, float flag) {
+#ifdef VRT_LOWERING_LLVMPIPE
+    // Mesa folds ((a * 0.2) * flag) * .1031 of the inlined hash12 into a * (0.2 * .1031) for flag == 1 (the product is 0 for
+    // flag == 0) and factors the dot as above (the parity oracle states the same rule)
+    if (flag == 0.0f) return hash_12(0.0f, 0.0f);
+    const float k = 0.2f * .1031f;
+    const float A = fract1(ax * k), B = fract1(ay * k);
+    const float d = (A + B) * (A + 33.33f) + A * (B + 33.33f);
+    return fract1(((A + d) + (B + d)) * (A + d));
+#else
+    return hash_12((ax * 0.2f) * flag, (ay * 0.2f) * flag);
+#endif
 }
 
 } // namespace vrt

@@ -1,2216 +1,11 @@
-// vrt_trace.hip — brickmap traversal kernels for gfx950 (MI355X), wave64.
-//
-// Replaces the dispatch of assets/shaders/brick_raytracer.comp
-// (src/modules/voxel_rt/ComputePipeline.zig:550).  One lane = one pixel, one
-// wave = an 8x8 pixel block (coherent rays), one 256-thread workgroup = a
-// 16x16 tile.  Arithmetic follows vrt_math.h's contract operation by
-// operation; what differs from the shader is only how memory is touched:
-//   * brick status is read from a device-built blocked copy: one 64-bit word
-//     per 4x4x4 block of grid cells, so a ray loads a new word every ~4 steps
-//     in any direction (the shader's linear words only serve rays moving along
-//     x, comp:318-326);
-//   * an LDS-resident filter (1 bit per 4x4x4 block: "some cell occupied")
-//     lets lanes crossing empty space skip the global load altogether;
-//   * occupancy is read as one 64-bit word per brick (4^3) or per y-layer (8^3)
-//     and bit-tested in registers, instead of one byte load per voxel step
-//     (comp:415);
-//   * blockIdx is remapped so that each XCD (block b runs on XCD b % 8) gets a
-//     contiguous band of image tiles and its L2 holds one region of the grid;
-//   * DDA steps are branch-free selects (no exec-mask churn on the scalar unit).
+// vrt_trace.hip — derived-structure builders, tile schedule, root-side un-swizzle, and the launchers / kernel selection
+// called from vrt_api.hip.  The traversal kernels themselves live in vrt_trace_kernels.h and are instantiated by vrt_inst_*.hip.
 #include <hip/hip_runtime.h>
+#include <climits>
 #include "vrt_internal.h"
-#include "vrt_math.h"
+#include "vrt_kernels.h"
 
 namespace vrt {
-
-constexpr uint32_t MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_NONE = 3;
-
-struct Ray {
-    f3 origin, direction;
-    float internal_reflection;
-    uint32_t ignore_type_material;
-};
-
-struct Hit {
-    f3 point, normal;
-    float t;
-    uint32_t index;
-};
-
-template <bool COUNT>
-struct Cnt {
-    uint32_t rays = 0, status_loads = 0, bricks_entered = 0, voxel_steps = 0, hits = 0, grid_steps = 0;
-    uint32_t wave_grid_iters = 0, wave_brick_walks = 0, wave_voxel_iters = 0;
-};
-template <>
-struct Cnt<false> {};
-
-#define VRT_COUNT(field)   \
-    if constexpr (COUNT) { \
-        c.field++;         \
-    }
-// counts once per wave per execution: only the first active lane increments
-#define VRT_COUNT_WAVE(field)                                                              \
-    if constexpr (COUNT) {                                                                 \
-        if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) c.field++; \
-    }
-
-// comp:180-184
-VRT_DI Ray create_ray(f3 origin, f3 direction) { return Ray{origin, normalize3(direction), 1.0f, MAT_NONE}; }
-// comp:192-195
-VRT_DI f3 ray_at(const Ray &r, float t) { return fma3(splat3(t), r.direction, r.origin); }
-// comp:267
-VRT_DI float safe_inverse(float x) { return (x == 0.0f) ? 1e12f : (1.0f / x); }
-
-// Development-only phase profile (make EXTRA=-DVRT_DEV_PROFILE; tools/one_tile.py --profile): core-clock
-// cycles per phase, summed over the waves of a workgroup in LDS and written to the wave-timeline buffer.
-#ifdef VRT_DEV_PROFILE
-__shared__ unsigned long long vrt_prof[8];
-VRT_DI unsigned long long prof_now() { return __builtin_readcyclecounter(); }
-VRT_DI void prof_add(int k, unsigned long long t0) {
-    const unsigned long long dt = __builtin_readcyclecounter() - t0;
-    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-    if ((threadIdx.x & 63u) == (uint32_t)(__builtin_ctzll(act))) atomicAdd(&vrt_prof[k], dt);
-}
-#define VRT_PROF_BEGIN(t) const unsigned long long t = prof_now()
-#define VRT_PROF_END(k, t) prof_add(k, t)
-#else
-#define VRT_PROF_BEGIN(t)
-#define VRT_PROF_END(k, t)
-#endif
-
-// DDA walker state shared by the two levels.  Instead of the cell position the walker keeps, per
-// axis, how many more steps it may take before it leaves the box through the face it is moving
-// towards (rem = dim-1-pos for step +1, pos for step -1): stepping decrements one counter and "still
-// inside" is min3(rem) >= 0 — two VALU ops and no lane-mask merging on the scalar unit, against
-// three compares and their s_and/s_or chain on positions.  An axis with step 0 never moves; its
-// counter holds the hang-guard budget instead (see the oracle's header: same definition).  The
-// position, needed only when a brick is entered, is base - step*rem.
-struct Walk {
-    f3 side_dist;
-    int rx, ry, rz;
-    float t_value;
-};
-
-VRT_DI int steps_left(int step, int pos, int dim, int zero_budget) {
-    // (pos may be any int when the start lies outside the box; wrap instead of overflowing)
-    return step > 0 ? (int)((uint32_t)(dim - 1) - (uint32_t)pos) : (step < 0 ? pos : zero_budget);
-}
-VRT_DI int walk_base(int step, int pos, int dim) { return step > 0 ? dim - 1 : (step < 0 ? 0 : pos); }
-// the same against a box [lo, hi] of cells (pos inside the grid): steps that can be taken before the far face of the box is
-// crossed, negative when the position is already beyond it; an axis the ray does not move along gets the hang-guard budget
-// while the position is inside the box's range and -1 outside (the ray never reaches the box)
-VRT_DI int steps_left_box(int step, int pos, int lo, int hi, int zero_budget) {
-    // (as selects: the compiler turns the nested form into two levels of divergent branches per axis)
-    const int fwd = (int)((uint32_t)hi - (uint32_t)pos), back = (int)((uint32_t)pos - (uint32_t)lo);
-    const int moving = step > 0 ? fwd : back;
-    const int still = (fwd | back) >= 0 ? zero_budget : -1; // inside the box's range iff neither difference is negative
-    return step != 0 ? moving : still;
-}
-VRT_DI int walk_base_box(int step, int pos, int lo, int hi) { return step > 0 ? hi : (step < 0 ? lo : pos); }
-VRT_DI int min3i(int a, int b, int c) { return min(min(a, b), c); }
-
-// comp:345-372 / comp:440-467: the branchy min-axis step as selects,
-//   x<y ? (x<z ? X : Z) : (y<z ? Y : Z)
-// also advancing a linear index (cell index x + dim_x*(z + dim_z*y), comp:318, or voxel index,
-// comp:412) by the stride of the crossed axis instead of recomputing it with two 32-bit multiplies
-// (v_mad_u64_u32 on gfx950, quarter rate); exact in modular u32 arithmetic.  `axis` records the face
-// crossed; hit.normal (comp:350,356,364,370) is rebuilt from it only when a voxel is actually hit.
-// DEFER_T: leave t_value unscaled (the crossed side distance itself); the brick-level walk only needs
-// `t_value = side_dist * scale` (comp:347) when a brick is entered, so it multiplies there.
-template <bool DEFER_T>
-VRT_DI void dda_step(Walk &w, const f3 &ray_delta, float scale, int &axis, uint32_t &index, uint32_t stride_x, uint32_t stride_y,
-                     uint32_t stride_z) {
-    const bool x_lt_y = w.side_dist.x < w.side_dist.y;
-    const bool x_lt_z = w.side_dist.x < w.side_dist.z;
-    const bool y_lt_z = w.side_dist.y < w.side_dist.z;
-    // lane masks combined with bitwise operators: one s_and / s_andn2 / s_or each on the scalar unit
-    const bool ax = x_lt_y & x_lt_z;
-    const bool ay = (!x_lt_y) & y_lt_z;
-    const bool axy = ax | ay; // z is crossed when neither x nor y is
-    const float sd = ax ? w.side_dist.x : (ay ? w.side_dist.y : w.side_dist.z);
-    w.t_value = DEFER_T ? sd : sd * scale;
-    const float nx = w.side_dist.x + ray_delta.x;
-    const float ny = w.side_dist.y + ray_delta.y;
-    const float nz = w.side_dist.z + ray_delta.z;
-    w.side_dist.x = ax ? nx : w.side_dist.x;
-    w.side_dist.y = ay ? ny : w.side_dist.y;
-    w.side_dist.z = axy ? w.side_dist.z : nz;
-    w.rx -= ax ? 1 : 0;
-    w.ry -= ay ? 1 : 0;
-    w.rz -= axy ? 0 : 1;
-    index += ax ? stride_x : (ay ? stride_y : stride_z);
-    axis = ax ? 0 : (ay ? 1 : 2);
-}
-
-// ---- the brick-level walk loop, hand-written for gfx950 -------------------------------------------------
-// Measured model (tools/ubench/step_bench.hip): a SIMD issues about one instruction per cycle in total —
-// vector, scalar and branch alike — and a wave on its own needs >= 4 cycles per instruction, more across a
-// VALU -> SGPR -> SALU -> VALU hand-over.  So the loop is written for the smallest TOTAL instruction count with
-// short dependency chains, and everything the compiler adds around an inline-asm step (copies of loop-carried
-// lane masks, exit-flag merging on the scalar unit, s_nop padding at the asm boundary) is avoided by keeping the
-// whole loop inside one asm block: 30 instructions per trip (18 VALU, 8 SALU, 1 VMEM, 1 waitcnt, 2 branches)
-// against 41 for the compiler's loop around the same step.
-//
-// One trip = take the DDA step out of the current cell (dda_step<true> as selects; comp:345-372 semantics,
-// `!(x<y)` is s_andn2 of the x<y mask so NaNs take the shader's branches), request the next cell's status word,
-// and only then test the bit of the cell just left, whose word was requested one trip earlier and has had a
-// whole step to arrive (s_waitcnt vmcnt(1)).  The steps-left counters are decremented with the crossed-
-// axis lane mask as borrow-in; their borrow-OUT is the box-exit test (a counter at 0 is decremented exactly
-// when the lane leaves through that face), so leaving lanes are dropped from EXEC with scalar work only.  The
-// loop is unrolled (four trips per back edge) with the roles of two register sets alternating (A/B: crossed distance
-// and crossed-axis masks of the last and of the previous step), so nothing is copied between trips.  It runs until some lane
-// meets an occupied cell or every lane has left the grid; the caller walks the bricks (rare: about once per
-// wave per ray) and calls again.  Status words come through a stride-4 buffer resource: a lane outside the grid
-// carries an arbitrary index and reads 0 instead of faulting (tools/isa_probe.hip checks this and the
-// carry-out-under-partial-EXEC behaviour on the hardware).
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-
-struct GridWalkRegs {
-    unsigned long long alive;        // in/out: lanes still walking the grid
-    unsigned long long occ;          // out: lanes whose cell BEFORE their last step is occupied (0: every lane has left)
-    unsigned long long out_x, out_y; // in/out: crossed-x / crossed-y lanes of the last step taken
-    unsigned long long in_x, in_y;   // out: the same for the step before it (the step INTO the tested cell)
-    float t_out, t_in;               // crossed distance of the last step (in/out) and of the one before it (out)
-    uint32_t stub;                   // out: 0 the call ended in its first trip, 1/2 in a later trip, 3 every lane left
-};
-
-#define VRT_TRIP_T(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT) \
-    /* The crossed distance = the smallest side distance, and the crossed axis from it: the shader's                       \
-       x<y ? (x<z ? X : Z) : (y<z ? Y : Z) picks Z whenever z is minimal (ties included), else Y whenever y is, else X —    \
-       one min3 and two equality tests instead of three compares and two selects.  (A walk never holds a NaN side          \
-       distance: safeInverse keeps 1/dir finite and NaN rays fail the slab test.) */                                        \
-    "v_min3_f32 %[" TS "], %[sdx], %[sdy], %[sdz]\n\t"                    \
-    "v_cmp_eq_f32_e64 %[" MXY "], %[sdz], %[" TS "]\n\t" /* z crossed */   \
-    "v_cmp_eq_f32_e64 %[" MY "], %[sdy], %[" TS "]\n\t"                   \
-    "s_andn2_b64 %[" MY "], %[" MY "], %[" MXY "]\n\t"  /* y crossed: y minimal, z not */ \
-    "s_andn2_b64 %[" MXY "], exec, %[" MXY "]\n\t"      /* x or y crossed */ \
-    "s_andn2_b64 %[" MX "], %[" MXY "], %[" MY "]\n\t"  /* x crossed */    \
-    /* side_dist of the crossed axis += |1/dir|: one add under the axis' lane mask as EXEC instead of three adds and three  \
-       selects (the loop is bound by the vector pipe; the scalar unit has slots to spare) */                                  \
-    "s_mov_b64 %[ex], exec\n\t"                                           \
-    "s_mov_b64 exec, %[" MX "]\n\t"                                       \
-    "v_add_f32_e64 %[sdx], %[sdx], |%[ix]|\n\t"                           \
-    "s_mov_b64 exec, %[" MY "]\n\t"                                       \
-    "v_add_f32_e64 %[sdy], %[sdy], |%[iy]|\n\t"                           \
-    "s_andn2_b64 exec, %[ex], %[" MXY "]\n\t"                             \
-    "v_add_f32_e64 %[sdz], %[sdz], |%[iz]|\n\t"                           \
-    "s_mov_b64 exec, %[ex]\n\t"                                           \
-    "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[" MY "]\n\t"              \
-    "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[" MX "]\n\t"               \
-    "v_add_u32_e32 %[" IDXN "], %[" IDX "], %[t0]\n\t"                    \
-    LOAD(IDX, IDXN, WORD, WORDN) /* request the next cell's word; wait for the one requested a trip ago */ \
-    TEST(WORD, IDX)                                                       \
-    "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[" MX "]\n\t"          \
-    "v_subbrev_co_u32_e64 %[ry], %[by], 0, %[ry], %[" MY "]\n\t"          \
-    "v_addc_co_u32_e64 %[rz], %[cz], -1, %[rz], %[" MXY "]\n\t"           \
-    LIMIT(TS, MXY)                                                        \
-    "s_or_b64 %[ex], %[ex], %[by]\n\t"                                    \
-    "s_orn2_b64 %[ex], %[ex], %[cz]\n\t" /* z: carry-out 0 = borrow */    \
-    "s_andn2_b64 exec, exec, %[ex]\n\t"                                   \
-    "s_cbranch_vccnz " OUT "\n\t"
-
-#define VRT_TRIP(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, OUT) VRT_TRIP_T(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, VRT_TEST_BIT, OUT)
-// the cell just left is occupied: bit (index % 32) of its word ...
-#define VRT_TEST_BIT(WORD, IDX)                                           \
-    "v_bfe_u32 %[t1], %[" WORD "], %[" IDX "], 1\n\t"                     \
-    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"
-// ... or, with the status expanded to ONE BYTE PER CELL (TraceParams::status_bytes, derived from binding 3 on every status
-// upload), the byte itself: no shift for the address, no bit-field extract for the test — 16 instead of 18 vector instructions
-// per trip of a loop that is bound by the vector pipe (two cycles per wave64 instruction per SIMD)
-#define VRT_TEST_BYTE(WORD, IDX) "v_cmp_ne_u32_e32 vcc, 0, %[" WORD "]\n\t"
-#define VRT_LOAD_BYTE(IDX, IDXN, WORD, WORDN)                                        \
-    "buffer_load_ubyte %[" WORDN "], %[" IDXN "], %[rsrc], 0 offen\n\t"   \
-    "s_waitcnt vmcnt(1)\n\t"
-
-// Where the bitmap words come from.  Global memory: a stride-4 buffer resource indexed by the word index (an
-// index outside the buffer reads 0).  LDS (brick level, grids whose status bitmap fits): the bitmap staged at
-// LDS address 0, byte address masked into the power-of-two allocation.  The vector memory pipeline takes
-// one wave-wide scattered dword request per ~16 cycles per CU (tools/ubench/step_bench.hip: the trip runs at 63
-// cycles per SIMD with the buffer load, 40-44 without); LDS serves the same request several times faster.
-#define VRT_LOAD_BUFFER(IDX, IDXN, WORD, WORDN)                                      \
-    "v_lshrrev_b32_e32 %[t2], 5, %[" IDXN "]\n\t"                         \
-    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"         \
-    "s_waitcnt vmcnt(1)\n\t"
-#define VRT_WAIT_BUFFER "s_waitcnt vmcnt(0)\n\t"
-#define VRT_LOAD_LDS(IDX, IDXN, WORD, WORDN)                                         \
-    "v_lshrrev_b32_e32 %[t2], 3, %[" IDXN "]\n\t"                         \
-    "v_and_b32_e32 %[t2], %[rsrc], %[t2]\n\t"                             \
-    "ds_read_b32 %[" WORDN "], %[t2]\n\t"                                 \
-    "s_waitcnt lgkmcnt(1)\n\t"
-#define VRT_WAIT_LDS "s_waitcnt lgkmcnt(0)\n\t"
-
-// voxel level only (comp:469): the lane also leaves when the crossed distance, scaled to world units, is not
-// <= the distance left inside the grid box (NaN leaves, as `!(t <= max)` does)
-#define VRT_NO_LIMIT(TS, MXY)
-#define VRT_T_LIMIT(TS, MXY) /* (the x|y mask of this trip is dead by now: its register takes the compare) */ \
-    "v_mul_f32_e32 %[t1], %[scale], %[" TS "]\n\t"                        \
-    "v_cmp_nle_f32_e64 %[" MXY "], %[t1], %[tmax]\n\t"                    \
-    "s_or_b64 %[ex], %[ex], %[" MXY "]\n\t"
-
-// Register sets: an A trip leaves cell idxa (word worda), writes {tsa, mxa, mya} and produces idxb and the
-// request for wordb; a B trip the other way round.  A call starts with an A trip.  On exit the B set holds the
-// last step and the A set the one before it, idxa/worda the current cell and idxb the cell just left: a call
-// that ends in an A trip swaps the sets on its way out.
-#define VRT_WALK_ASM(LIMIT, LOAD, TEST, WAITALL)                                                                            \
-    "s_mov_b64 %[save], exec\n\t"                                                                         \
-    "s_mov_b64 exec, %[alive]\n\t"                                                                        \
-    VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "1f")                  \
-    "0:\n\t"                                                                                              \
-    VRT_TRIP_T("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "2f")                  \
-    VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "3f")                  \
-    VRT_TRIP_T("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "2f")                  \
-    VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "3f")                  \
-    "s_cbranch_execnz 0b\n\t"                                                                             \
-    "s_mov_b32 %[stub], 3\n\t"                                                                            \
-    "s_branch 4f\n\t"                                                                                     \
-    "1:\n\t"                                                                                              \
-    "s_mov_b32 %[stub], 0\n\t"                                                                            \
-    "s_branch 4f\n\t"                                                                                     \
-    "3:\n\t"                                                                                              \
-    "s_mov_b32 %[stub], 2\n\t"                                                                            \
-    "4:\n\t"                                                                                              \
-    "s_mov_b64 %[occ], vcc\n\t"                                                                           \
-    "s_mov_b64 %[alive], exec\n\t"                                                                        \
-    "s_mov_b64 exec, %[save]\n\t"                                                                         \
-    WAITALL                                                                                               \
-    "s_mov_b64 %[ex], %[mxa]\n\t"                                                                         \
-    "s_mov_b64 %[mxa], %[mxb]\n\t"                                                                        \
-    "s_mov_b64 %[mxb], %[ex]\n\t"                                                                         \
-    "s_mov_b64 %[ex], %[mya]\n\t"                                                                         \
-    "s_mov_b64 %[mya], %[myb]\n\t"                                                                        \
-    "s_mov_b64 %[myb], %[ex]\n\t"                                                                         \
-    "v_mov_b32_e32 %[t0], %[tsa]\n\t"                                                                     \
-    "v_mov_b32_e32 %[tsa], %[tsb]\n\t"                                                                    \
-    "v_mov_b32_e32 %[tsb], %[t0]\n\t"                                                                     \
-    "v_mov_b32_e32 %[t0], %[idxa]\n\t"                                                                    \
-    "v_mov_b32_e32 %[idxa], %[idxb]\n\t"                                                                  \
-    "v_mov_b32_e32 %[idxb], %[t0]\n\t"                                                                    \
-    "v_mov_b32_e32 %[worda], %[wordb]\n\t"                                                                \
-    "s_branch 6f\n\t"                                                                                     \
-    "2:\n\t"                                                                                              \
-    "s_mov_b32 %[stub], 1\n\t"                                                                            \
-    "s_mov_b64 %[occ], vcc\n\t"                                                                           \
-    "s_mov_b64 %[alive], exec\n\t"                                                                        \
-    "s_mov_b64 exec, %[save]\n\t"                                                                         \
-    WAITALL /* the compiler may move `word`: no load may be in flight outside */                          \
-    "6:"
-
-#define VRT_WALK_OUTPUTS                                                                                                                        \
-    [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),          \
-        [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(word), [wordb] "=&v"(wordb), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in),              \
-        [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive), [mxa] "=&s"(g.in_x),    \
-        [mya] "=&s"(g.in_y), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz), [save] "=&s"(save),         \
-        [occ] "=&s"(g.occ), [stub] "=&s"(g.stub)
-#define VRT_WALK_INPUTS \
-    [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z), [rsrc] "s"(rsrc)
-
-// brick level (comp:314-375): cells of the grid, bits of brick_status
-VRT_DI void grid_walk_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
-                             uint32_t &word, u32x4 rsrc, GridWalkRegs &g) {
-    unsigned long long mxya, mxyb, ex, by, cz, save;
-    float t0, t1, t2;
-    uint32_t wordb;
-    asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_BUFFER, VRT_TEST_BIT, VRT_WAIT_BUFFER) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
-}
-
-// brick level with the status bitmap in LDS; `rsrc` is the byte-address mask (allocation size - 4)
-VRT_DI void grid_walk_lds_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
-                                 uint32_t &word, uint32_t rsrc, GridWalkRegs &g) {
-    unsigned long long mxya, mxyb, ex, by, cz, save;
-    float t0, t1, t2;
-    uint32_t wordb;
-    asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_LDS, VRT_TEST_BIT, VRT_WAIT_LDS) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
-}
-
-// brick level on the byte-per-cell copy of the status bits: `index` is the byte offset, `word` the byte of the current cell;
-// rsrc: a raw buffer (stride 0) over TraceParams::status_bytes, so that an out-of-grid index reads 0
-VRT_DI void grid_walk_bytes_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
-                                   uint32_t &word, u32x4 rsrc, GridWalkRegs &g) {
-    unsigned long long mxya, mxyb, ex, by, cz, save;
-    float t0, t1, t2;
-    uint32_t wordb;
-    asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_BYTE, VRT_TEST_BYTE, VRT_WAIT_BUFFER) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
-}
-
-// voxel level (comp:409-470): voxels of one brick, bits of brick_occupancy addressed by the global bit index
-// brick * B^3 + voxel; `scale` and `t_max` as in the loop condition comp:469
-VRT_DI void voxel_walk_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
-                              uint32_t &word, u32x4 rsrc, GridWalkRegs &g, float scale, float t_max) {
-    unsigned long long mxya, mxyb, ex, by, cz, save;
-    float t0, t1, t2;
-    uint32_t wordb;
-    asm volatile(VRT_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_BUFFER, VRT_TEST_BIT, VRT_WAIT_BUFFER) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
-}
-#undef VRT_WALK_ASM
-#undef VRT_WALK_OUTPUTS
-#undef VRT_WALK_INPUTS
-
-// ---- the same loop with parking, for frames with bounces ----------------------------------------------------
-// Secondary rays are incoherent: the lanes of a wave meet their bricks at different trips, and walking each
-// brick at once (the shader's order) runs the long voxel-level code for a few lanes at a time.  Here a lane
-// whose trip left an occupied cell behind is PARKED: dropped from EXEC with, per lane, tsa = the distance into
-// that cell, tsb = the distance of the step out of it, idxb = the cell, idxa = the cell it now stands on and the
-// two crossed axes in `code` (an A trip swaps the two register sets for the parked lanes to get there).  The
-// other lanes keep walking until `batch` lanes are parked or nobody is moving; then the call returns and the
-// caller walks all parked bricks in ONE execution.  Per lane the sequence of operations is unchanged.  The
-// in-axis of a lane's FIRST trip in a call comes from code bits 4-5 (its last step may be many trips old); later
-// trips read it from the other set's crossed-axis masks.  On exit the sets are swapped for the still-moving
-// lanes as well if the last trip was an A trip, so that set B / idxa / worda are "last step / current cell /
-// its status word" for every lane.  (Measured on the 2048^3 path-trace config: 325 -> 220 ms per frame against
-// the per-trip state machine this replaces; on primary + shadow frames the plain loop above is 3 % faster.)
-struct GridParkRegs {
-    unsigned long long alive;        // in: lanes to walk; out: lanes still moving when the call ended
-    unsigned long long parked;       // out: lanes that left an occupied cell behind (0: every lane has left)
-    unsigned long long out_x, out_y; // in/out: crossed-x / crossed-y lanes of the last trip (moving lanes: their last step)
-    float t_out, t_in;               // per lane: crossed distance of the lane's last step (in/out) and of the step before it (out)
-    // per lane.  in: bits 4-5 = axis crossed by the lane's last step before this call (3: none, the slab entry).
-    // out, parked lanes: bits 0-1 axis INTO the occupied cell, bits 2-3 axis OUT of it
-    uint32_t code;
-    uint32_t batch;                  // in: the call returns once this many lanes are parked (or nobody is moving)
-    uint32_t min_alive = 0;          // in: ... or, at a back edge, once fewer than this many lanes are still moving (0: never)
-};
-
-#define VRT_PARK(LABEL, IN_AXIS, OUT_MX, OUT_MY, SWAP, NEXT, EXIT)                                       \
-    LABEL ":\n\t"                                                                                         \
-    "s_mov_b64 %[ex], exec\n\t"                                                                           \
-    "s_mov_b64 exec, vcc\n\t"                                                                             \
-    IN_AXIS                                                                                               \
-    "v_cndmask_b32_e64 %[t1], 2, 1, %[" OUT_MY "]\n\t"                                                    \
-    "v_cndmask_b32_e64 %[t1], %[t1], 0, %[" OUT_MX "]\n\t"                                                \
-    "v_lshl_or_b32 %[code], %[t1], 2, %[t0]\n\t"                                                          \
-    SWAP                                                                                                  \
-    "s_or_b64 %[parked], %[parked], vcc\n\t"                                                              \
-    "s_andn2_b64 exec, %[ex], vcc\n\t"                                                                    \
-    "s_bcnt1_i32_b64 %[n], %[parked]\n\t"                                                                 \
-    "s_cmp_ge_u32 %[n], %[batch]\n\t"                                                                     \
-    "s_cbranch_scc1 " EXIT "\n\t"                                                                         \
-    "s_cbranch_execnz " NEXT "\n\t"                                                                       \
-    "s_branch " EXIT "\n\t"
-#define VRT_IN_FROM_CODE "v_bfe_u32 %[t0], %[code], 4, 2\n\t"
-#define VRT_IN_FROM(MX, MY) "v_cndmask_b32_e64 %[t0], 2, 1, %[" MY "]\n\t" "v_cndmask_b32_e64 %[t0], %[t0], 0, %[" MX "]\n\t"
-#define VRT_SWAP_SETS "v_swap_b32 %[tsa], %[tsb]\n\t" "v_swap_b32 %[idxa], %[idxb]\n\t"
-
-#define VRT_PARK_WALK_ASM(LIMIT, LOAD, TEST, WAITALL) \
-        "s_mov_b64 %[save], exec\n\t" \
-        "s_mov_b64 exec, %[alive]\n\t" \
-        "s_mov_b64 %[parked], 0\n\t" \
-        VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "10f") \
-        "0:\n\t" \
-        VRT_TRIP_T("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "11f") \
-        "21:\n\t" \
-        VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "12f") \
-        "22:\n\t" \
-        VRT_TRIP_T("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "13f") \
-        "23:\n\t" \
-        VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "14f") \
-        "24:\n\t" \
-        "s_cbranch_execz 31f\n\t" \
-        /* back edge (after an A trip): keep walking while at least min_alive lanes are moving; fewer -> hand the wave back \
-           so that the finished lanes can be given new rays (vrt_path_kernel; min_alive = 0: never) */ \
-        "s_bcnt1_i32_b64 %[n], exec\n\t" \
-        "s_cmp_ge_u32 %[n], %[minalive]\n\t" \
-        "s_cbranch_scc1 0b\n\t" \
-        "s_branch 30f\n\t" \
-        VRT_PARK("10", VRT_IN_FROM_CODE, "mxa", "mya", VRT_SWAP_SETS, "0b", "30f") \
-        VRT_PARK("11", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "21b", "31f") \
-        VRT_PARK("12", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "22b", "30f") \
-        VRT_PARK("13", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "23b", "31f") \
-        VRT_PARK("14", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "24b", "30f") \
-        "30:\n\t" /* the last trip was an A trip: swap the sets of the lanes still moving */ \
-        "s_mov_b64 %[alive], exec\n\t" \
-        WAITALL \
-        VRT_SWAP_SETS \
-        "v_mov_b32_e32 %[worda], %[wordb]\n\t" \
-        "s_mov_b64 %[mxb], %[mxa]\n\t" \
-        "s_mov_b64 %[myb], %[mya]\n\t" \
-        "s_branch 32f\n\t" \
-        "31:\n\t" \
-        "s_mov_b64 %[alive], exec\n\t" \
-        WAITALL /* the compiler may move `word`: no load may be in flight outside */ \
-        "32:\n\t" \
-        "s_mov_b64 exec, %[save]"
-#define VRT_PARK_WALK_OPERANDS                                                                                                                   \
-    [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),          \
-        [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(word), [wordb] "=&v"(wordb), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in),              \
-        [code] "+v"(g.code), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive),    \
-        [mxa] "=&s"(mxa), [mya] "=&s"(mya), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz),              \
-        [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n)
-#define VRT_PARK_WALK_INPUTS                                                                                                                          \
-    [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z), [rsrc] "s"(rsrc), \
-        [batch] "s"(g.batch), [minalive] "s"(g.min_alive)
-
-VRT_DI void grid_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
-                                  uint32_t &word, u32x4 rsrc, GridParkRegs &g) {
-    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
-    float t0, t1, t2;
-    uint32_t wordb, n;
-    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_BUFFER, VRT_TEST_BIT, VRT_WAIT_BUFFER) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS : "vcc", "scc");
-}
-
-// The voxel level on the same park loop (vrt_path_kernel): voxels of one brick, bits of brick_occupancy by their global bit
-// index; `scale`, `t_max` as in the loop condition comp:469.  A lane that has left a SOLID voxel behind is parked; the call
-// returns when nobody is moving (batch 64, min_alive 0), so that the material test behind it (three dependent cache misses on a
-// scene larger than the caches) runs ONCE for all the lanes of the round instead of once per lane that finds a voxel.
-VRT_DI void voxel_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
-                                   uint32_t &word, u32x4 rsrc, GridParkRegs &g, float scale, float t_max) {
-    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
-    float t0, t1, t2;
-    uint32_t wordb, n;
-    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_BUFFER, VRT_TEST_BIT, VRT_WAIT_BUFFER) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
-}
-
-// The same with the brick's occupancy bits staged in LDS (8^3 bricks: 64 bytes = 16 words per lane).  On a scene larger than
-// the caches the lanes of a round stand in ~25 different bricks; every trip of the loop above asks the L1 for one more word of
-// each, the L1 has long dropped the line, and the trip waits for an L2 round trip (a request is only one trip ahead): ~600
-// cycles x ~15 trips of the longest lane.  Here the lane's whole brick is fetched ONCE by four global_load_lds_dwordx4 in flight
-// together (chunk c of lane l lands at wave base + 1024 c + 16 l: the layout the instruction dictates; tools/ubench/glds_probe.hip)
-// and the trips read LDS: word w of the brick at lane base + ((w >> 2) << 10) + ((w & 3) << 2), w = (bit index >> 5) & 15.
-#define VRT_LOAD_LDS_BRICK(IDX, IDXN, WORD, WORDN)                                   \
-    "v_lshrrev_b32_e32 %[t2], 3, %[" IDXN "]\n\t"                         \
-    "v_and_b32_e32 %[t0], 48, %[t2]\n\t"                                 \
-    "v_and_or_b32 %[t2], %[t2], 12, %[lb]\n\t"                           \
-    "v_lshl_add_u32 %[t2], %[t0], 6, %[t2]\n\t"                          \
-    "ds_read_b32 %[" WORDN "], %[t2]\n\t"                                \
-    "s_waitcnt lgkmcnt(1)\n\t"
-VRT_DI void voxel_walk_park_lds_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
-                                       uint32_t &word, uint32_t lane_base, GridParkRegs &g, float scale, float t_max) {
-    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
-    float t0, t1, t2;
-    uint32_t wordb, n;
-    const uint32_t rsrc = 0u; // (operand of the shared input list; unused)
-    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_LDS_BRICK, VRT_TEST_BIT, VRT_WAIT_LDS) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max), [lb] "v"(lane_base) : "vcc", "scc");
-}
-#undef VRT_LOAD_LDS_BRICK
-// byte address (LDS) of the word that holds bit `bit_index` of the lane's staged brick
-VRT_DI uint32_t brick_lds_address(uint32_t lane_base, uint32_t bit_index) {
-    const uint32_t w = (bit_index >> 5) & 15u;
-    return lane_base + ((w >> 2) << 10) + ((w & 3u) << 2);
-}
-// ---- the brick-level park loop on HALF-BLOCK words (vrt_path_kernel on scenes larger than the caches) ---------------------
-// Measured on the 2048^3 path trace (tools/pmc_cfg4.sh): 64.5 G L1 accesses per frame, 0.58 per cycle per CU — a wave-wide
-// request of incoherent lanes is one tag look-up per lane, and the L1 handles about one per cycle; 77 % of them are the status
-// words of the walk loop, one per lane per trip, although the average L1 miss costs only ~190 cycles.  So the walk is bound by the
-// NUMBER of requests.  Here the status bits are read from a derived copy ordered by 4 x 4 x 2 cells (x, z, y) per 32-bit word
-// (TraceParams::status_halfblocks, bit (x&3) | (z&3) << 2 | (y&1) << 4): a lane asks for a word only when its step enters
-// another half-block — one step in three on average — and keeps the word otherwise.  Same bits tested, same sequence per lane.
-// The indices are formed from the linear cell index by bit fields: x and z dimensions powers of two >= 4, y even.
-// Every trip issues exactly one request (if no lane changes its half-block, all lanes re-request theirs), so vmcnt(1) still
-// means "the word asked for a trip ago has arrived".
-struct HalfBlockConsts {
-    // cell index = x | z << lx | y << (lx + lz); word index = x >> 2 | (z >> 2) << (lx - 2) | (y >> 1) << (lx + lz - 4)
-    //            = ((index >> 2) & mx) | ((index >> 4) & mzs) | ((index >> 5) & mys)
-    uint32_t nmask; // ~(3 | 3 << lx | 1 << (lx + lz)): two cell indices in the same half-block agree in these bits
-    uint32_t mx;    // (1 << (lx - 2)) - 1
-    uint32_t mzs;   // ((dim_z >> 2) - 1) << (lx - 2)
-    uint32_t mys;   // ~((1 << (lx + lz - 4)) - 1)
-    uint32_t lx;    // log2(dim_x): z & 3 starts here
-    uint32_t lxz;   // log2(dim_x) + log2(dim_z): y & 1 is this bit
-};
-#define VRT_LOAD_HALFBLOCK(IDX, IDXN, WORD, WORDN)                         \
-    "v_xor_b32_e32 %[t2], %[" IDXN "], %[" IDX "]\n\t"                     \
-    "v_and_b32_e32 %[t2], %[nmask], %[t2]\n\t"                             \
-    "v_cmp_ne_u32_e64 %[by], 0, %[t2]\n\t" /* lanes whose step enters another half-block */ \
-    "s_cmp_eq_u64 %[by], 0\n\t"                                            \
-    "s_cselect_b64 %[by], exec, %[by]\n\t" /* nobody: everybody asks again (one request per trip, always) */ \
-    "s_and_saveexec_b64 %[cz], %[by]\n\t"                                  \
-    "v_lshrrev_b32_e32 %[t2], 2, %[" IDXN "]\n\t"                          \
-    "v_and_b32_e32 %[t2], %[mx], %[t2]\n\t"                                \
-    "v_lshrrev_b32_e32 %[t0], 4, %[" IDXN "]\n\t"                          \
-    "v_and_or_b32 %[t2], %[t0], %[mzs], %[t2]\n\t"                         \
-    "v_lshrrev_b32_e32 %[t0], 5, %[" IDXN "]\n\t"                          \
-    "v_and_or_b32 %[t2], %[t0], %[mys], %[t2]\n\t"                         \
-    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"          \
-    "s_andn2_b64 exec, %[cz], %[by]\n\t"   /* the lanes that stay in their half-block keep its word */ \
-    "s_waitcnt vmcnt(1)\n\t"                                               \
-    "v_mov_b32_e32 %[" WORDN "], %[" WORD "]\n\t"                          \
-    "s_mov_b64 exec, %[cz]\n\t"
-#define VRT_TEST_HALFBLOCK(WORD, IDX)                                      \
-    "v_bfe_u32 %[t1], %[" IDX "], %[lx], 2\n\t"                            \
-    "v_and_b32_e32 %[t0], 3, %[" IDX "]\n\t"                               \
-    "v_lshl_or_b32 %[t0], %[t1], 2, %[t0]\n\t"                             \
-    "v_bfe_u32 %[t1], %[" IDX "], %[lxz], 1\n\t"                           \
-    "v_lshl_or_b32 %[t0], %[t1], 4, %[t0]\n\t"                             \
-    "v_bfe_u32 %[t1], %[" WORD "], %[t0], 1\n\t"                           \
-    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"
-VRT_DI void grid_walk_park_halfblocks_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
-                                             uint32_t &word, u32x4 rsrc, GridParkRegs &g, const HalfBlockConsts &hb) {
-    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
-    float t0, t1, t2;
-    uint32_t wordb, n;
-    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_HALFBLOCK, VRT_TEST_HALFBLOCK, VRT_WAIT_BUFFER)
-                 : VRT_PARK_WALK_OPERANDS
-                 : VRT_PARK_WALK_INPUTS, [nmask] "s"(hb.nmask), [mx] "s"(hb.mx), [mzs] "s"(hb.mzs), [mys] "s"(hb.mys), [lx] "s"(hb.lx), [lxz] "s"(hb.lxz)
-                 : "vcc", "scc");
-}
-#undef VRT_LOAD_HALFBLOCK
-#undef VRT_TEST_HALFBLOCK
-// index of the half-block word that holds cell `index`
-VRT_DI uint32_t halfblock_word(const HalfBlockConsts &hb, uint32_t index) {
-    return ((index >> 2) & hb.mx) | ((index >> 4) & hb.mzs) | ((index >> 5) & hb.mys);
-}
-#undef VRT_PARK_WALK_ASM
-#undef VRT_PARK_WALK_OPERANDS
-#undef VRT_PARK_WALK_INPUTS
-// ---- block filter (vrt_path_kernel<FILTER>) ---------------------------------------------------------------------------
-// The 1-bit-per-4x4x4-cells filter that vrt_build_status_blocks derives from binding 3 ("some cell of the block is occupied"),
-// staged in LDS once per workgroup.  The block index is formed from the linear cell index by bit fields, so the grid's x and z
-// dimensions must be powers of two >= 4 and y a multiple of 4 (every BASELINE configuration); other grids walk cell by cell.
-// (Round 2 first used the filter only to suppress status requests for cells of empty blocks, one trip per cell as before:
-// slower, 215 against 204 ms on the 2048^3 path trace.  Now a lane in an empty block JUMPS to the block's exit face,
-// skip_empty_block, and only lanes in non-empty blocks take trips.)
-struct FilterConsts {
-    uint32_t wx;   // log2(dim_x) - 2: width of the x block field
-    uint32_t shz;  // log2(dim_x) + 2: the z block field starts here in the cell index
-    uint32_t mz;   // (dim_z >> 2) - 1
-    uint32_t shy;  // log2(dim_x) + log2(dim_z) + 2
-    uint32_t shyb; // log2(dim_x) + log2(dim_z) - 4: where the y block field goes in the block index
-};
-#undef VRT_PARK
-#undef VRT_IN_FROM_CODE
-#undef VRT_IN_FROM
-#undef VRT_SWAP_SETS
-#undef VRT_T_LIMIT
-#undef VRT_NO_LIMIT
-#undef VRT_TRIP
-#undef VRT_TRIP_T
-#undef VRT_TEST_BIT
-#undef VRT_TEST_BYTE
-#undef VRT_LOAD_BYTE
-
-// comp:298 / comp:395
-VRT_DI f3 initial_side_dist(f3 fstep, f3 fposition, f3 ray_delta) {
-    const f3 intersection_delta = floor3(fposition) - fposition;
-    return fma3(fstep, intersection_delta, fstep * 0.5f + splat3(0.5f)) * ray_delta;
-}
-
-struct RaySetup {
-    f3 ray_delta; // |1/dir|
-    f3 inv_dir;   // 1/dir (safeInverse), kept for the |abs|-modifier form of the hand-scheduled step
-    int entry_code; // slab-entry normal (comp:529-531): axis index | sign bits, see axis_normal()
-    int sx, sy, sz;
-    float grid_t_min, grid_t_max;
-};
-
-// comp:522-536 with comp:278 (slab test against the grid box)
-VRT_DI bool grid_slab(const TraceParams &p, const Ray &r, float t_min, float t_max, RaySetup &s) {
-    const f3 g_min = mk3(p.grid.min_point_base_t[0], p.grid.min_point_base_t[1], p.grid.min_point_base_t[2]);
-    const f3 g_max = mk3(p.grid.max_point_scale[0], p.grid.max_point_scale[1], p.grid.max_point_scale[2]);
-    const f3 inv = mk3(safe_inverse(r.direction.x), safe_inverse(r.direction.y), safe_inverse(r.direction.z));
-    const f3 t_lower = (g_min - r.origin) * inv;
-    const f3 t_upper = (g_max - r.origin) * inv;
-    const f3 t_mins = mk3(gl_min(t_lower.x, t_upper.x), gl_min(t_lower.y, t_upper.y), gl_min(t_lower.z, t_upper.z));
-    const f3 t_maxes = mk3(gl_max(t_lower.x, t_upper.x), gl_max(t_lower.y, t_upper.y), gl_max(t_lower.z, t_upper.z));
-    // indexOfMaxComponent, comp:501-503 (ties resolve to 0)
-    const bool iy = (t_mins.y > t_mins.x) && (t_mins.y > t_mins.z);
-    const bool iz = (t_mins.z > t_mins.x) && (t_mins.z > t_mins.y);
-    // iy and iz cannot both hold; index = iy + 2*iz
-    const float inv_i = iz ? inv.z : (iy ? inv.y : inv.x);
-    const float tmin_i = iz ? t_mins.z : (iy ? t_mins.y : t_mins.x);
-    // packed: bits 0-1 axis (0,1,2), bit 2 = negative, bit 3 = zero or NaN.  (Not "the axis now, the sign from inv_dir when
-    // needed": a select over the members of RaySetup becomes an indexed load, and the optimiser then moves the whole struct
-    // to LDS — 12 KiB per workgroup and +20 % on the headline frame.)
-    s.entry_code = (iz ? 2 : (iy ? 1 : 0)) | (inv_i < 0.0f ? 4 : 0) | (!(inv_i < 0.0f) && !(inv_i > 0.0f) ? 8 : 0);
-    s.grid_t_min = gl_max(t_min, tmin_i);
-    s.grid_t_max = gl_min(t_max, gl_min(gl_min(t_maxes.x, t_maxes.y), t_maxes.z));
-    s.ray_delta = abs3(inv);
-    s.inv_dir = inv;
-    s.sx = (int)sign1(r.direction.x);
-    s.sy = (int)sign1(r.direction.y);
-    s.sz = (int)sign1(r.direction.z);
-    return s.grid_t_min <= s.grid_t_max;
-}
-
-VRT_DI f3 axis_normal(const RaySetup &s, int axis) {
-    // normal_axis, comp:304-308: (step < 0) ? 1 : -1 on the crossed axis; axis 3 = slab-entry normal
-    const float nx = (s.sx < 0) ? 1.0f : -1.0f, ny = (s.sy < 0) ? 1.0f : -1.0f, nz = (s.sz < 0) ? 1.0f : -1.0f;
-    const int ea = s.entry_code & 3;
-    const float ev = (s.entry_code & 8) ? 0.0f : ((s.entry_code & 4) ? -1.0f : 1.0f);
-    return mk3(axis == 0 ? nx : ((axis == 3 && ea == 0) ? ev : 0.0f), axis == 1 ? ny : ((axis == 3 && ea == 1) ? ev : 0.0f),
-               axis == 2 ? nz : ((axis == 3 && ea == 2) ? ev : 0.0f));
-}
-
-// bit (index % 32) of a status word.  v_bfe_u32 takes the offset from the low five bits of its operand,
-// so no separate `index & 31`; written as asm because the compiler does not drop the mask by itself.
-VRT_DI bool status_bit(uint32_t word, uint32_t index) {
-    uint32_t r;
-    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(r) : "v"(word), "v"(index));
-    return r != 0u;
-}
-
-// Word i of the dynamic LDS region.  The traversal kernel declares no static LDS, so its dynamic region
-// starts at LDS address 0 (MI355X guide, G17); addressing it as address-space-3 offset 0 saves the
-// per-access add of a link-time base the compiler cannot fold.
-VRT_DI uint32_t lds_word0(uint32_t i) {
-    typedef __attribute__((address_space(3))) const uint32_t lds_u32;
-    return reinterpret_cast<lds_u32 *>(0)[i];
-}
-
-VRT_DI bool bit64(uint2 w, uint32_t bit) { // bit 0..63 of a 64-bit word held as two dwords
-    const uint32_t half = (bit & 32u) ? w.y : w.x;
-    return (half >> (bit & 31u)) & 1u;
-}
-
-// all three in [0, dim), dim a power of two (4 or 8): the OR of three such values stays below dim, and any negative or larger one lifts it above
-VRT_DI bool more_init(int px, int py, int pz, int dim) { return (unsigned)(px | py | pz) < (unsigned)dim; }
-
-// comp:378-471.  Returns true on a (non-ignored) voxel hit and fills `hit`.
-// LITERAL: one byte load per voxel step (comp:415); otherwise 64-bit occupancy words:
-// brick_occupancy bit v%8 of byte brick*(B^3/8) + v/8 (Grid.zig:180-182) read as little-endian
-// 64-bit words — the whole brick for B=4, one y-layer (v = x + 8*(z + 8*y)) for B=8.
-template <int B, bool COUNT, bool LITERAL>
-VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t brick_index, f3 brick_min, Hit &hit,
-                       int &axis, Cnt<COUNT> &c) {
-    const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
-    const float voxel_scale = g_scale * brick_voxel_scale;
-    const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
-    Walk w;
-    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
-    const int px = f2i_clamp(__builtin_floorf(fposition.x));
-    const int py = f2i_clamp(__builtin_floorf(fposition.y));
-    const int pz = f2i_clamp(__builtin_floorf(fposition.z));
-    constexpr int kZeroBudget = 3 * B + 8;
-    w.rx = steps_left(s.sx, px, B, kZeroBudget);
-    w.ry = steps_left(s.sy, py, B, kZeroBudget);
-    w.rz = steps_left(s.sz, pz, B, kZeroBudget);
-    w.t_value = 0;
-    const float local_t_max = s.grid_t_max - hit.t;
-    uint32_t voxel_index = (uint32_t)px + (uint32_t)B * ((uint32_t)pz + (uint32_t)B * (uint32_t)py); // comp:412, kept current by dda_step
-    const uint32_t stride_x = (uint32_t)s.sx, stride_y = (uint32_t)(s.sy * (B * B)), stride_z = (uint32_t)(s.sz * B);
-
-    uint2 occ = make_uint2(0u, 0u);
-    uint32_t occ_layer = ~0u;
-    const uint2 *occ_words = reinterpret_cast<const uint2 *>(p.brick_occupancy);
-    if constexpr (!LITERAL && B == 4) occ = occ_words[brick_index];
-    // B == 8: one 64-bit word per y-layer.  The walk moves through the layers in one direction (sy), so the
-    // word of the layer after the current one is requested a layer early: a walk then waits for memory once,
-    // not once per layer (these dependent loads are what a wave with many brick walks spends its time on).
-    uint2 occ_ahead = make_uint2(0u, 0u);
-    [[maybe_unused]] const uint2 *brick_layers = occ_words + (size_t)brick_index * 8u;
-    [[maybe_unused]] auto layer_ahead = [&](uint32_t layer) -> uint2 {
-        const uint32_t next = layer + (uint32_t)s.sy; // sy == 0: the layer never changes, any valid word will do
-        return brick_layers[next < 8u ? next : layer];
-    };
-    if constexpr (!LITERAL && B == 8) {
-        if (more_init(px, py, pz, B)) {
-            occ_layer = (uint32_t)py;
-            occ = brick_layers[occ_layer];
-            occ_ahead = layer_ahead(occ_layer);
-        }
-    }
-
-    // Single-exit loop (one back-edge condition, no return inside): the structurizer then needs one
-    // exec update per iteration instead of a chain of exit-flag merges on the scalar unit.
-    bool found = false;
-    bool more = (unsigned)px < (unsigned)B && (unsigned)py < (unsigned)B && (unsigned)pz < (unsigned)B && w.t_value <= local_t_max;
-    VRT_PROF_BEGIN(tp2);
-    while (more) {
-        VRT_COUNT(voxel_steps);
-        VRT_COUNT_WAVE(wave_voxel_iters);
-        bool solid;
-        if constexpr (LITERAL) {
-            const uint32_t byte = p.brick_occupancy[brick_index * (uint32_t)(B * B * B / 8) + (voxel_index >> 3)];
-            solid = (byte >> (voxel_index & 7u)) & 1u;
-        } else if constexpr (B == 4) {
-            solid = bit64(occ, voxel_index);
-        } else {
-            const uint32_t layer = voxel_index >> 6; // y
-            if (occ_layer != layer) { // crossed into the next layer: its word was requested a layer ago
-                occ = occ_ahead;
-                occ_layer = layer;
-                occ_ahead = layer_ahead(layer);
-            }
-            solid = bit64(occ, voxel_index & 63u);
-        }
-        if (solid) {
-            VRT_COUNT(hits);
-            const uint32_t brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu; // comp:422
-            const uint32_t mi = p.material_index[brick_material_index + voxel_index];
-            const vrt_material *m = p.materials + mi;
-            const uint32_t mtype = m->type;
-            const float mdata = m->type_data;
-            const bool ignore_brick = (mtype == r.ignore_type_material) && (r.internal_reflection == mdata); // comp:427
-            if (!ignore_brick) {
-                hit.index = mi;
-                const float t_offset = voxel_scale * 0.05f;
-                hit.t += w.t_value - t_offset;
-                hit.normal = axis_normal(s, axis);
-                hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
-                found = true;
-            }
-        }
-        // (after a hit this step is dead work, once per ray; its results are never read)
-        dda_step<false>(w, s.ray_delta, voxel_scale, axis, voxel_index, stride_x, stride_y, stride_z);
-        more = !found && min3i(w.rx, w.ry, w.rz) >= 0 && w.t_value <= local_t_max;
-    }
-    VRT_PROF_END(2, tp2);
-    return found;
-}
-
-// comp:378-471 on the hand-written voxel loop (voxel_walk_gfx950): same operations per lane as brick_walk.
-// The loop returns when some lane has left a solid voxel behind; the material test (comp:422-427) and the hit
-// record are done here, and lanes whose voxel is to be ignored walk on.  `axis_in`: the face through which the
-// brick was entered (the brick-level walk's crossed axis), used when the very first voxel is the hit.
-template <int B, bool EAGER = true>
-VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t brick_index, f3 brick_min, Hit &hit,
-                              int axis_in, int &hit_axis) {
-    const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
-    const float voxel_scale = g_scale * brick_voxel_scale;
-    const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
-    Walk w;
-    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
-    const int px = f2i_clamp(__builtin_floorf(fposition.x));
-    const int py = f2i_clamp(__builtin_floorf(fposition.y));
-    const int pz = f2i_clamp(__builtin_floorf(fposition.z));
-    constexpr int kZeroBudget = 3 * B + 8;
-    w.rx = steps_left(s.sx, px, B, kZeroBudget);
-    w.ry = steps_left(s.sy, py, B, kZeroBudget);
-    w.rz = steps_left(s.sz, pz, B, kZeroBudget);
-    w.t_value = 0;
-    const float local_t_max = s.grid_t_max - hit.t;
-    // global bit index of the voxel in brick_occupancy: brick * B^3 + voxel index (comp:412-415)
-    const uint32_t base = brick_index * (uint32_t)(B * B * B);
-    uint32_t bit_index = base + ((uint32_t)px + (uint32_t)B * ((uint32_t)pz + (uint32_t)B * (uint32_t)py));
-    const uint32_t stride_x = (uint32_t)s.sx, stride_y = (uint32_t)(s.sy * (B * B)), stride_z = (uint32_t)(s.sz * B);
-    const bool more = more_init(px, py, pz, B) && (0.0f <= local_t_max); // comp:409 with t_value = 0
-
-    const unsigned long long occ_addr = (unsigned long long)p.brick_occupancy;
-    u32x4 rsrc;
-    rsrc.x = (uint32_t)occ_addr;
-    rsrc.y = (uint32_t)(occ_addr >> 32) | (4u << 16);
-    rsrc.z = p.occupancy_words;
-    rsrc.w = 0x00020000u;
-    uint32_t word = reinterpret_cast<const uint32_t *>(p.brick_occupancy)[more ? (bit_index >> 5) : 0u];
-    // comp:422.  EAGER: requested before the walk, so that a solid voxel's material test starts one dependent load later
-    // (scenes that stay in the caches).  Otherwise requested at the first solid voxel: on a scene larger than the caches
-    // every request is a 128-byte line from HBM, and four of five brick walks of the path-trace configuration end without
-    // a solid voxel (K = 3.2 bricks entered, H = 0.7 hits per ray).
-    uint32_t brick_material_index = 0u;
-    if constexpr (EAGER) brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu;
-    GridWalkRegs g;
-    g.alive = __builtin_amdgcn_ballot_w64(more);
-    g.out_x = 0ull;
-    g.out_y = 0ull;
-    g.t_out = 0.0f;
-    bool first = true; // wave-uniform
-    bool found = false;
-    while (g.alive != 0ull) {
-        uint32_t solid_bit; // bit index of the voxel each lane stood on before its last step
-        VRT_PROF_BEGIN(tp2);
-        voxel_walk_gfx950(w, s.inv_dir, bit_index, solid_bit, stride_x, stride_y, stride_z, word, rsrc, g, voxel_scale, local_t_max);
-        VRT_PROF_END(2, tp2);
-        if (g.occ == 0ull) break; // every lane has left the brick (or the grid box)
-        if (__builtin_amdgcn_inverse_ballot_w64(g.occ)) {
-            VRT_PROF_BEGIN(tp4);
-            const uint32_t voxel_index = solid_bit - base;
-            if constexpr (!EAGER) brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu;
-            const uint32_t mi = p.material_index[brick_material_index + voxel_index];
-            const vrt_material *m = p.materials + mi;
-            const uint32_t mtype = m->type;
-            const float mdata = m->type_data;
-            const bool ignore_brick = (mtype == r.ignore_type_material) && (r.internal_reflection == mdata); // comp:427
-            if (!ignore_brick) {
-                const int a = (first && g.stub == 0u)
-                                  ? axis_in
-                                  : (__builtin_amdgcn_inverse_ballot_w64(g.in_x) ? 0 : (__builtin_amdgcn_inverse_ballot_w64(g.in_y) ? 1 : 2));
-                // (hit.normal and hit.point are derived from hit_axis and hit.t once the walk is over: six registers
-                // less to carry through both loops)
-                hit.index = mi;
-                const float t_offset = voxel_scale * 0.05f;
-                hit.t += g.t_in * voxel_scale - t_offset; // t_value of the step into this voxel (comp:442), 0 for the first
-                hit_axis = a;
-                found = true;
-            }
-            VRT_PROF_END(4, tp4);
-        }
-        asm("s_andn2_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(found)) : "scc");
-        first = false;
-    }
-    return found;
-}
-
-// comp:378-471 for vrt_path_kernel: the same per-lane operations as brick_walk_gfx950 on the voxel-level PARK loop.  Lanes that
-// have left a solid voxel behind wait (parked) until no lane of the round is moving; then the material test (comp:422-427) is made
-// for all of them at once — on a scene larger than the caches it is three dependent cache misses (start index -> material id ->
-// material), and brick_walk_gfx950 pays them once per lane that finds a voxel (22 % of the wave-cycles of the 2048^3 path trace,
-// tools/path_profile.py).  A lane whose voxel is to be ignored (comp:427) walks on in the next pass.
-// LDS (8^3 bricks): the lane's brick is staged at LDS byte address wave_lds + 1024 c + 16 lane (c = 0..3) and walked there
-// (voxel_walk_park_lds_gfx950).
-template <int B, bool LDS = false>
-VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t brick_index, f3 brick_min, Hit &hit,
-                                   int axis_in, int &hit_axis, uint32_t wave_lds = 0u) {
-    static_assert(!LDS || B == 8, "the LDS layout is written for 64-byte bricks");
-    const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
-    const float voxel_scale = g_scale * brick_voxel_scale;
-    const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
-    Walk w;
-    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
-    const int px = f2i_clamp(__builtin_floorf(fposition.x));
-    const int py = f2i_clamp(__builtin_floorf(fposition.y));
-    const int pz = f2i_clamp(__builtin_floorf(fposition.z));
-    constexpr int kZeroBudget = 3 * B + 8;
-    w.rx = steps_left(s.sx, px, B, kZeroBudget);
-    w.ry = steps_left(s.sy, py, B, kZeroBudget);
-    w.rz = steps_left(s.sz, pz, B, kZeroBudget);
-    w.t_value = 0;
-    const float local_t_max = s.grid_t_max - hit.t;
-    const uint32_t base = brick_index * (uint32_t)(B * B * B);
-    uint32_t bit_index = base + ((uint32_t)px + (uint32_t)B * ((uint32_t)pz + (uint32_t)B * (uint32_t)py));
-    const uint32_t stride_x = (uint32_t)s.sx, stride_y = (uint32_t)(s.sy * (B * B)), stride_z = (uint32_t)(s.sz * B);
-    const bool more = more_init(px, py, pz, B) && (0.0f <= local_t_max); // comp:409 with t_value = 0
-
-    const unsigned long long occ_addr = (unsigned long long)p.brick_occupancy;
-    u32x4 rsrc;
-    rsrc.x = (uint32_t)occ_addr;
-    rsrc.y = (uint32_t)(occ_addr >> 32) | (4u << 16);
-    rsrc.z = p.occupancy_words;
-    rsrc.w = 0x00020000u;
-    const uint32_t *occ_words = reinterpret_cast<const uint32_t *>(p.brick_occupancy);
-    typedef __attribute__((address_space(3))) const uint32_t lds_u32;
-    [[maybe_unused]] const uint32_t lane_base = wave_lds + ((threadIdx.x & 63u) << 4);
-    uint32_t word;
-    [[maybe_unused]] uint32_t eager_start = 0u;
-    VRT_PROF_BEGIN(tp5);
-    if constexpr (LDS) {
-        const uint32_t *src = occ_words + (size_t)brick_index * 16u;
-        typedef __attribute__((address_space(3))) void lds_void;
-        typedef const __attribute__((address_space(1))) void glb_void;
-        lds_void *dst = reinterpret_cast<lds_void *>((size_t)__builtin_amdgcn_readfirstlane(wave_lds));
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-            __builtin_amdgcn_global_load_lds((glb_void *)(src + 4 * c), (lds_void *)((__attribute__((address_space(3))) char *)dst + 1024 * c), 16, 0, 0);
-        // (path_eager_start: the brick's start index travels with the four chunks instead of after the walk)
-        if (p.path_eager_start) eager_start = p.brick_start_index[brick_index];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        word = reinterpret_cast<lds_u32 *>(0)[brick_lds_address(lane_base, bit_index) >> 2];
-    } else {
-        word = occ_words[more ? (bit_index >> 5) : 0u];
-    }
-    VRT_PROF_END(5, tp5);
-    GridParkRegs g;
-    g.alive = __builtin_amdgcn_ballot_w64(more);
-    g.out_x = 0ull;
-    g.out_y = 0ull;
-    g.t_out = 0.0f;
-    g.t_in = 0.0f;
-    g.code = 3u << 4; // the first voxel of the walk was entered through the brick's face, not by a step of this walk
-    g.batch = 64u;
-    g.min_alive = 0u;
-    bool found = false;
-    while (g.alive != 0ull) {
-        uint32_t solid_bit; // parked lanes: bit index of the solid voxel they left behind
-        VRT_PROF_BEGIN(tp2);
-        if constexpr (LDS) voxel_walk_park_lds_gfx950(w, s.inv_dir, bit_index, solid_bit, stride_x, stride_y, stride_z, word, lane_base, g, voxel_scale, local_t_max);
-        else voxel_walk_park_gfx950(w, s.inv_dir, bit_index, solid_bit, stride_x, stride_y, stride_z, word, rsrc, g, voxel_scale, local_t_max);
-        VRT_PROF_END(2, tp2);
-        if (g.parked == 0ull) break; // every lane has left the brick (or the grid box)
-        const bool parked = __builtin_amdgcn_inverse_ballot_w64(g.parked);
-        bool resume = false;
-        VRT_PROF_BEGIN(tp4);
-        if (parked) {
-            const uint32_t voxel_index = solid_bit - base;
-            const uint32_t brick_material_index = ((LDS && p.path_eager_start) ? eager_start : p.brick_start_index[brick_index]) & 0x7FFFFFFFu; // comp:422
-            const uint32_t mi = p.material_index[brick_material_index + voxel_index];
-            const vrt_material *m = p.materials + mi;
-            const uint32_t mtype = m->type;
-            const float mdata = m->type_data;
-            const bool ignore_brick = (mtype == r.ignore_type_material) && (r.internal_reflection == mdata); // comp:427
-            if (!ignore_brick) {
-                const uint32_t in = g.code & 3u;
-                hit.index = mi;
-                const float t_offset = voxel_scale * 0.05f;
-                hit.t += g.t_in * voxel_scale - t_offset; // t_value of the step into this voxel (comp:442), 0 for the first
-                hit_axis = (in == 3u) ? axis_in : (int)in;
-                found = true;
-            } else {
-                // walk on: the lane has already taken the step out of the ignored voxel; comp:409 for that step
-                resume = min3i(w.rx, w.ry, w.rz) >= 0 && (voxel_scale * g.t_out <= local_t_max);
-            }
-        }
-        VRT_PROF_END(4, tp4);
-        // every lane: the axis of its last step, for its first trip in the next call
-        g.code = parked ? ((g.code >> 2) & 3u) << 4
-                        : (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
-        if (resume) { // (an A-trip park left the lane's word in the other register set)
-            if constexpr (LDS) word = reinterpret_cast<lds_u32 *>(0)[brick_lds_address(lane_base, bit_index) >> 2];
-            else word = occ_words[bit_index >> 5];
-        }
-        asm("s_or_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(resume)) : "scc");
-    }
-    return found;
-}
-
-// How the brick-level walk learns whether a grid cell is occupied.
-enum StatusMode : int {
-    kStatusLinear = 0,     // the shader's own words: bit i%32 of word i/32, cached per lane (comp:318-328)
-    kStatusBlocked = 1,    // device-built 4x4x4 block words from global memory, cached per lane
-    kStatusBlockedLds = 2, // same, behind an LDS-resident 1-bit-per-block "non-empty" filter
-    kStatusLinearWide = 3, // linear words for status, 64-bit words for occupancy
-    kStatusLinearAlways = 4, // linear words, loaded on every step (no per-lane word cache, no branch)
-    kStatusLinearLds = 5,    // the whole linear status bitmap staged in LDS per workgroup, read on every step
-    kStatusLinearAhead = 6,  // as kStatusLinearAlways, software-pipelined: the next cell's word is requested before the current cell is tested
-    kStatusBytes = 7         // the hand-written loop on a byte-per-cell copy of the status bits (no shift, no bit-field extract per trip)
-};
-
-// ---- skip to the box of occupied cells ---------------------------------------------------------------------------
-// A ray that enters the grid OUTSIDE the bounding box of the occupied cells along some axis A (a camera above the terrain:
-// A = y) walks through cells that are known to be empty until it has crossed A `need` times (need = cells to the box's near
-// face).  The shader's walk is a three-way merge of three non-decreasing sequences — the side distances of x, y and z, each
-// built by repeated addition of |1/dir| — with ties going to z, then y, then x (comp:345-372).  So the state after the
-// need-th crossing of A is known without walking: T = A's side distance after need-1 additions is the distance of that
-// crossing; every element of another axis B that precedes T in merge order (c < T, or c == T where B wins the tie) has been
-// consumed; B's side distance is its first element that does not.  All additions are the walk's own, in the walk's order per
-// axis, so every side distance, counter and index is bit for bit what the walk would hold: ~2 vector instructions per
-// skipped step instead of a 13-instruction trip.  A lane whose B counter runs out first has left the box (a miss, as in the
-// walk).  Afterwards the lane stands on the first cell inside the box's A range, entered through A at distance T.  One round per
-// axis (x, y, z; the order does not matter: each round skips what is left in front of its axis' near face).
-VRT_DI float next_below(float t) { // the largest float < t (t finite)
-    const uint32_t b = __builtin_bit_cast(uint32_t, t);
-    return __builtin_bit_cast(float, t > 0.0f ? b - 1u : (t < 0.0f ? b + 1u : 0x80000001u));
-}
-// t after `count` further additions of |inv| (per lane): 2 vector + 1 scalar instruction per step, four steps per back edge
-#define VRT_SKIP_ADD_STEP                                        \
-    "v_add_co_u32_e32 %[n], vcc, -1, %[n]\n\t" /* carry-out: the count was >= 1 */ \
-    "s_and_b64 exec, exec, vcc\n\t"                              \
-    "v_add_f32_e64 %[t], %[t], |%[d]|\n\t"
-VRT_DI void skip_add_gfx950(float &t, float inv, int count) {
-    unsigned long long save;
-    asm volatile("s_mov_b64 %[save], exec\n\t"
-                 "0:\n\t" VRT_SKIP_ADD_STEP VRT_SKIP_ADD_STEP VRT_SKIP_ADD_STEP VRT_SKIP_ADD_STEP
-                 "s_cbranch_execnz 0b\n\t"
-                 "s_mov_b64 exec, %[save]"
-                 : [t] "+v"(t), [n] "+v"(count), [save] "=&s"(save)
-                 : [d] "v"(inv)
-                 : "vcc", "scc");
-}
-#undef VRT_SKIP_ADD_STEP
-// Consume the elements c, c+|inv|, ... of another axis that are <= lim; returns how many.  The axis has `left` steps before
-// the far face of the box: a lane that consumes more has left the box, and what it holds afterwards is never used — so the
-// bound is tested once per four steps only (v_cmpx drops a lane from EXEC the moment its element is beyond lim): 3 vector
-// instructions per step, one more and the branch per four.
-#define VRT_SKIP_MERGE_STEP                                      \
-    "v_cmpx_le_f32_e32 vcc, %[c], %[lim]\n\t"                    \
-    "v_add_f32_e64 %[c], %[c], |%[d]|\n\t"                       \
-    "v_add_u32_e32 %[n], 1, %[n]\n\t"
-VRT_DI int skip_merge_gfx950(float &c, float inv, int left, float lim) {
-    unsigned long long save;
-    int n = 0;
-    asm volatile("s_mov_b64 %[save], exec\n\t"
-                 "0:\n\t" VRT_SKIP_MERGE_STEP VRT_SKIP_MERGE_STEP VRT_SKIP_MERGE_STEP VRT_SKIP_MERGE_STEP
-                 "v_cmpx_ge_i32_e32 vcc, %[r], %[n]\n\t"
-                 "s_cbranch_execnz 0b\n\t"
-                 "s_mov_b64 exec, %[save]"
-                 : [c] "+v"(c), [n] "+v"(n), [save] "=&s"(save)
-                 : [d] "v"(inv), [lim] "v"(lim), [r] "v"(left)
-                 : "vcc", "scc");
-    return n;
-}
-#undef VRT_SKIP_MERGE_STEP
-VRT_DI float &comp3(f3 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
-VRT_DI float comp3(const f3 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
-// The lane crosses axis A (compile time) `need` more times, the last time at distance t (= A's side distance after need-1
-// additions): consume what the other two axes hold before t in merge order and move the walk state behind that crossing.
-template <int A>
-VRT_DI void skip_axis(Walk &w, const RaySetup &s, int need, float t, uint32_t &index, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z, bool &more,
-                      int &in_axis, float &t_in) {
-    constexpr int B1 = (A + 1) % 3, B2 = (A + 2) % 3; // the other two axes; an axis wins a tie against A iff it comes later in x, y, z
-    int *const r[3] = {&w.rx, &w.ry, &w.rz};
-    const uint32_t stride[3] = {stride_x, stride_y, stride_z};
-    const float t_strict = next_below(t); // c < t  <=>  c <= t_strict
-    const int n1 = skip_merge_gfx950(comp3(w.side_dist, B1), comp3(s.inv_dir, B1), *r[B1], B1 > A ? t : t_strict);
-    const int n2 = skip_merge_gfx950(comp3(w.side_dist, B2), comp3(s.inv_dir, B2), *r[B2], B2 > A ? t : t_strict);
-    comp3(w.side_dist, A) = t + comp3(s.ray_delta, A);
-    *r[A] -= need;
-    *r[B1] -= n1;
-    *r[B2] -= n2;
-    index += (uint32_t)need * stride[A] + (uint32_t)n1 * stride[B1] + (uint32_t)n2 * stride[B2];
-    more = (*r[A] | *r[B1] | *r[B2]) >= 0; // a counter below zero: the far face of the box was crossed on the way
-    in_axis = A;
-    t_in = t;
-}
-// one round: bring axis A inside the box's range for the lanes that are in front of it
-template <int A>
-VRT_DI void skip_round(Walk &w, const RaySetup &s, int span, uint32_t &index, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z, bool &more,
-                       int &in_axis, float &t_in, bool &skipped) {
-    const int step_a = A == 0 ? s.sx : (A == 1 ? s.sy : s.sz);
-    const int r_a = A == 0 ? w.rx : (A == 1 ? w.ry : w.rz);
-    // crossings still to go before the near face (steps left to the FAR face minus the box's extent); an axis the ray does not
-    // move along holds the hang-guard budget instead and never needs any
-    const int need = step_a != 0 ? r_a - span : 0;
-    const bool want = more && need > 0;
-    if (__builtin_amdgcn_ballot_w64(want) == 0ull) return;
-    if (want) {
-        float t = comp3(w.side_dist, A);
-        skip_add_gfx950(t, comp3(s.inv_dir, A), need - 1);
-        skip_axis<A>(w, s, need, t, index, stride_x, stride_y, stride_z, more, in_axis, t_in);
-        skipped = true;
-    }
-}
-VRT_DI bool skip_to_box(Walk &w, const RaySetup &s, int span_x, int span_y, int span_z, uint32_t &index, uint32_t stride_x, uint32_t stride_y,
-                        uint32_t stride_z, bool &more, int &in_axis, float &t_in) {
-    bool skipped = false;
-    skip_round<0>(w, s, span_x, index, stride_x, stride_y, stride_z, more, in_axis, t_in, skipped);
-    skip_round<1>(w, s, span_y, index, stride_x, stride_y, stride_z, more, in_axis, t_in, skipped);
-    skip_round<2>(w, s, span_z, index, stride_x, stride_y, stride_z, more, in_axis, t_in, skipped);
-    return skipped;
-}
-
-// The lane stands in a 4x4x4 block of cells that holds no occupied cell (at cell (bx, by, bz) of it): jump behind the step
-// that leaves the block.  Each axis has its exit crossing (the e-th from now, e = cells to the block's face in the ray's
-// direction + 1, at the side distance after e-1 additions); the one that comes first in merge order (smallest distance; z
-// before y before x among equals, as the walk picks) is the step that leaves the block, and everything before it is consumed
-// exactly as skip_to_box does.  ~100 vector instructions and no memory access for what would be one to ten trips.
-VRT_DI void skip_empty_block(Walk &w, const RaySetup &s, uint32_t bx, uint32_t by, uint32_t bz, uint32_t &index, uint32_t stride_x, uint32_t stride_y,
-                             uint32_t stride_z, bool &more, int &in_axis, float &t_in) {
-    const int ex = s.sx > 0 ? 4 - (int)bx : (int)bx + 1, ey = s.sy > 0 ? 4 - (int)by : (int)by + 1, ez = s.sz > 0 ? 4 - (int)bz : (int)bz + 1;
-    auto exit_distance = [](float sd, float d, int e, int step) {
-        const float a1 = sd + d, a2 = a1 + d, a3 = a2 + d;
-        const float t = e == 1 ? sd : (e == 2 ? a1 : (e == 3 ? a2 : a3));
-        return step != 0 ? t : __builtin_inff(); // an axis the ray does not move along is never crossed
-    };
-    const float tx = exit_distance(w.side_dist.x, s.ray_delta.x, ex, s.sx);
-    const float ty = exit_distance(w.side_dist.y, s.ray_delta.y, ey, s.sy);
-    const float tz = exit_distance(w.side_dist.z, s.ray_delta.z, ez, s.sz);
-    const bool az = tz <= tx && tz <= ty, ay = !az && ty <= tx, ax = !az && !ay;
-    const float t = ax ? tx : (ay ? ty : tz);
-    const float t_strict = next_below(t); // c < t  <=>  c <= t_strict
-    // The other two axes: their elements that precede t in merge order (x loses every tie, z wins every tie, y wins against x
-    // only) — at most three each, their own exit crossing comes later.  Straight-line: no loop, no lane mask juggling.
-    const float never = -__builtin_inff();
-    auto consume = [](float &c, float d, float lim, int &n) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const bool before = c <= lim;
-            c = before ? c + d : c;
-            n += before ? 1 : 0;
-        }
-    };
-    float cx = w.side_dist.x, cy = w.side_dist.y, cz = w.side_dist.z;
-    int nx = 0, ny = 0, nz = 0;
-    consume(cx, s.ray_delta.x, ax ? never : t_strict, nx);
-    consume(cy, s.ray_delta.y, ay ? never : (ax ? t : t_strict), ny);
-    consume(cz, s.ray_delta.z, az ? never : t, nz);
-    w.side_dist.x = ax ? t + s.ray_delta.x : cx;
-    w.side_dist.y = ay ? t + s.ray_delta.y : cy;
-    w.side_dist.z = az ? t + s.ray_delta.z : cz;
-    nx = ax ? ex : nx;
-    ny = ay ? ey : ny;
-    nz = az ? ez : nz;
-    w.rx -= nx;
-    w.ry -= ny;
-    w.rz -= nz;
-    index += (uint32_t)nx * stride_x + (uint32_t)ny * stride_y + (uint32_t)nz * stride_z;
-    more = (w.rx | w.ry | w.rz) >= 0; // a counter below zero: the far face of the box of occupied cells was crossed on the way
-    in_axis = ax ? 0 : (ay ? 1 : 2);
-    t_in = t;
-}
-
-// comp:271-376.  t_min = 1e-5, t_max = +inf at every call site (comp:218,247).
-// BATCH (used for frames with bounces, whose secondary rays are incoherent): a lane that reaches an
-// occupied cell does not walk its brick at once but waits (__ballot) until p.brick_batch lanes are waiting or
-// no lane is still moving, so the long voxel-level walk runs for many lanes per execution instead of a
-// few (measured on the 2048^3 path-trace config: 3.8 lanes per execution unbatched; a threshold of 4 lanes
-// gives +8.5 % there, larger thresholds stall the moving lanes and lose).  The per-lane
-// sequence of operations is unchanged; only their interleaving across lanes differs.
-
-template <int B, bool COUNT, int MODE, bool BATCH = false>
-VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray &r, Hit &hit, Cnt<COUNT> &c) {
-    const float t_min = 0.00001f;
-    const float t_max = __builtin_inff();
-    VRT_COUNT(rays);
-    VRT_PROF_BEGIN(tp3);
-    RaySetup s;
-    VRT_PROF_BEGIN(tp6);
-    const bool slab_hit = grid_slab(p, r, t_min, t_max, s);
-    VRT_PROF_END(6, tp6);
-    if (!slab_hit) return false;
-
-    const f3 g_min = mk3(p.grid.min_point_base_t[0], p.grid.min_point_base_t[1], p.grid.min_point_base_t[2]);
-    const float g_scale = p.grid.max_point_scale[3];
-    const int dx = (int)p.grid.dim_x, dy = (int)p.grid.dim_y, dz = (int)p.grid.dim_z;
-
-    float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
-    const f3 fposition = p.scale_pow2 ? (ray_at(r, global_t_value) - g_min) * p.inv_grid_scale : (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
-    Walk w;
-    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
-    const int px = f2i_clamp(__builtin_floorf(fposition.x));
-    const int py = f2i_clamp(__builtin_floorf(fposition.y));
-    const int pz = f2i_clamp(__builtin_floorf(fposition.z));
-    const int zero_budget = dx + dy + dz + 8;
-    // The walk ends where the ray leaves the bounding box of the OCCUPIED cells on the far side of an axis (every cell beyond
-    // is empty, and the ray cannot come back), not only at the grid's face: same hits, same misses, fewer trips -- sky rays of a
-    // camera above the terrain and shadow rays towards the sun stop at the height of the highest brick.  The counting build
-    // walks to the grid's face like the shader, so that its counters stay the reference algorithm's — unless asked
-    // (count_box, vrt_config.enable_counters = 2) to count what the product kernel itself walks and requests.
-    int lox = 0, loy = 0, loz = 0, hix = dx - 1, hiy = dy - 1, hiz = dz - 1;
-    if (!COUNT || p.count_box) {
-        if (p.cell_bounds) {
-            lox = -p.cell_bounds[0], loy = -p.cell_bounds[1], loz = -p.cell_bounds[2];
-            hix = p.cell_bounds[3], hiy = p.cell_bounds[4], hiz = p.cell_bounds[5];
-        }
-    }
-    w.rx = steps_left_box(s.sx, px, lox, hix, zero_budget);
-    w.ry = steps_left_box(s.sy, py, loy, hiy, zero_budget);
-    w.rz = steps_left_box(s.sz, pz, loz, hiz, zero_budget);
-    const int base_x = walk_base_box(s.sx, px, lox, hix), base_y = walk_base_box(s.sy, py, loy, hiy), base_z = walk_base_box(s.sz, pz, loz, hiz);
-    w.t_value = 0;
-
-    uint32_t word_index = ~0u; // comp:301
-    uint32_t word_bits = 0;
-    uint32_t block_index = ~0u;
-    uint2 block_bits = make_uint2(0u, 0u);
-    int axis = 3;
-    [[maybe_unused]] int hit_axis = 0; // default kernel: the face of the voxel hit, turned into hit.normal / hit.point after the walk
-
-    // `global_t_value <= t_max` (comp:316) with t_max = +inf only fails for a NaN t, and t only
-    // changes when a brick is entered: test it there instead of on every step.
-    if (!(global_t_value <= t_max)) return false;
-    // comp:318, kept current by dda_step; meaningless (and unused) while the position is outside
-    uint32_t grid_index = (uint32_t)px + (uint32_t)dx * ((uint32_t)pz + (uint32_t)dz * (uint32_t)py);
-    const uint32_t stride_x = (uint32_t)s.sx, stride_y = (uint32_t)s.sy * (uint32_t)dx * (uint32_t)dz, stride_z = (uint32_t)s.sz * (uint32_t)dx;
-
-    // stop: 0 keep walking, -1 voxel hit, -2 t became NaN; negative values end the loop through the
-    // same integer test as the box exit
-    int stop = 0;
-    bool more = (unsigned)px < (unsigned)dx && (unsigned)py < (unsigned)dy && (unsigned)pz < (unsigned)dz && (w.rx | w.ry | w.rz) >= 0;
-    // a ray that enters the grid in front of the box jumps to the box's near face (skip_to_box above); such a lane's first cell
-    // was entered by a step through `axis` at crossed distance skip_t, not through the slab test
-    [[maybe_unused]] bool skipped = false;
-    [[maybe_unused]] float skip_t = 0.0f;
-    if ((!COUNT || p.count_box) && p.cell_bounds && p.skip_to_box) {
-        VRT_PROF_BEGIN(tp5);
-        skipped = skip_to_box(w, s, hix - lox, hiy - loy, hiz - loz, grid_index, stride_x, stride_y, stride_z, more, axis, skip_t);
-        w.t_value = skip_t;
-        VRT_PROF_END(5, tp5);
-    }
-
-    auto cell_occupied = [&]() -> bool {
-        VRT_COUNT(grid_steps);
-        VRT_COUNT_WAVE(wave_grid_iters);
-        if constexpr (MODE == kStatusLinearLds) {
-            if constexpr (COUNT) {
-                const uint32_t wi = grid_index >> 5;
-                if (wi != word_index) {
-                    word_index = wi;
-                    c.status_loads++;
-                }
-            }
-            return status_bit(lds_word0(grid_index >> 5), grid_index); // ds_read_b32 + v_bfe_u32
-        } else if constexpr (MODE == kStatusLinearAlways) {
-            if constexpr (COUNT) {
-                const uint32_t wi = grid_index >> 5;
-                if (wi != word_index) {
-                    word_index = wi;
-                    c.status_loads++;
-                }
-            }
-            return status_bit(p.brick_status[grid_index >> 5], grid_index);
-        } else if constexpr (MODE == kStatusLinear || MODE == kStatusLinearWide) {
-            const uint32_t wi = grid_index >> 5;
-            if (wi != word_index) { // comp:323-326
-                word_bits = p.brick_status[wi];
-                word_index = wi;
-                VRT_COUNT(status_loads);
-            }
-            return (word_bits >> (grid_index & 31u)) & 1u;
-        } else {
-            if constexpr (COUNT) { // the algorithmic count follows the reference's word rule
-                const uint32_t wi = grid_index >> 5;
-                if (wi != word_index) {
-                    word_index = wi;
-                    c.status_loads++;
-                }
-            }
-            const int cx = base_x - s.sx * w.rx, cy = base_y - s.sy * w.ry, cz = base_z - s.sz * w.rz;
-            const uint32_t bi = (uint32_t)(cx >> 2) + p.nbx * ((uint32_t)(cz >> 2) + p.nbz * (uint32_t)(cy >> 2));
-            if (bi != block_index) {
-                block_index = bi;
-                if constexpr (MODE == kStatusBlockedLds) {
-                    const uint32_t fw = lds_filter[bi >> 5];
-                    block_bits = ((fw >> (bi & 31u)) & 1u) ? p.status_blocks[bi] : make_uint2(0u, 0u);
-                } else {
-                    block_bits = p.status_blocks[bi];
-                }
-            }
-            return bit64(block_bits, (uint32_t)((cx & 3) | ((cz & 3) << 2) | ((cy & 3) << 4)));
-        }
-    };
-    // walk the brick of the cell reached with steps-left (rx,ry,rz), crossed-distance t and linear index `cell`
-    auto enter_brick_at = [&](int rx, int ry, int rz, float t_cross, uint32_t cell, int &brick_axis) {
-        const int cx = base_x - __mul24(s.sx, rx), cy = base_y - __mul24(s.sy, ry), cz = base_z - __mul24(s.sz, rz); // cell position
-        const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min);  // comp:331
-        global_t_value = t_cross * g_scale + s.grid_t_min + 0.01f * g_scale;                     // comp:347 (deferred) + comp:332
-        hit.t = global_t_value;
-        const uint32_t brick_index = p.brick_index[cell]; // comp:337
-        VRT_COUNT(bricks_entered);
-        VRT_COUNT_WAVE(wave_brick_walks);
-        bool found;
-        if constexpr ((MODE == kStatusLinearAlways || MODE == kStatusLinearLds || MODE == kStatusBytes) && !COUNT) {
-            found = brick_walk_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, brick_axis, hit_axis);
-        } else {
-            found = brick_walk<B, COUNT, MODE == kStatusLinear || MODE == kStatusLinearLds || MODE == kStatusLinearAhead>(
-                p, r, s, g_scale, brick_index, brick_min, hit, brick_axis, c);
-        }
-        stop = found ? -1 : ((global_t_value <= t_max) ? 0 : -2);
-    };
-    auto enter_brick = [&]() { enter_brick_at(w.rx, w.ry, w.rz, w.t_value, grid_index, axis); };
-    // brick_walk_gfx950 records a hit as distance + material + face; comp:433-436 from those, once the walk is over
-    auto finish_hit = [&]() {
-        if constexpr ((MODE == kStatusLinearAlways || MODE == kStatusLinearLds || MODE == kStatusBytes) && !COUNT) {
-            if (stop == -1) {
-                const float t_offset = (g_scale * (1.0f / (float)B)) * 0.05f;
-                hit.normal = axis_normal(s, hit_axis);
-                hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
-            }
-        }
-    };
-
-    if constexpr (BATCH && MODE == kStatusLinearAlways && !COUNT) {
-        // frames with bounces on the default kernel: the hand-written loop with parking (grid_walk_park_gfx950)
-        const unsigned long long status_addr = (unsigned long long)p.brick_status;
-        u32x4 rsrc;
-        rsrc.x = (uint32_t)status_addr;
-        rsrc.y = (uint32_t)(status_addr >> 32) | (4u << 16); // stride 4: one record per status word
-        rsrc.z = p.status_words;
-        rsrc.w = 0x00020000u;
-        uint32_t word = p.brick_status[more ? (grid_index >> 5) : 0u];
-        GridParkRegs g;
-        g.alive = __builtin_amdgcn_ballot_w64(more);
-        g.out_x = 0ull;
-        g.out_y = 0ull;
-        g.t_out = skip_t;
-        g.code = (uint32_t)axis << 4; // 3: the first cell of the walk was entered through the slab test, not by a step
-        g.batch = p.brick_batch;
-        while (g.alive != 0ull) {
-            uint32_t cell; // the occupied cell each parked lane stood on before its last step
-            grid_walk_park_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
-            if (g.parked == 0ull) break; // every lane has left the grid
-            const bool parked = __builtin_amdgcn_inverse_ballot_w64(g.parked);
-            bool resume = false;
-            if (parked) {
-                int a = (int)(g.code & 3u);
-                const uint32_t out = (g.code >> 2) & 3u;
-                // the counters as they were on the occupied cell: undo the decrement of the step out of it
-                enter_brick_at(w.rx + (out == 0u ? 1 : 0), w.ry + (out == 1u ? 1 : 0), w.rz + (out == 2u ? 1 : 0), g.t_in, cell, a);
-                resume = (stop == 0) && min3i(w.rx, w.ry, w.rz) >= 0;
-            }
-            // every lane: the axis of its last step, for its first trip in the next call
-            g.code = parked ? ((g.code >> 2) & 3u) << 4
-                            : (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
-            if (resume) word = p.brick_status[grid_index >> 5]; // (an A-trip park left the lane's word in the other register set)
-            // (as asm: the compiler would do this on the vector unit and could not hand the result back to an SGPR operand)
-            asm("s_or_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(resume)) : "scc");
-        }
-        finish_hit();
-        return stop == -1;
-    } else if constexpr (BATCH) {
-        // lane state: 0 at a cell (test it), 1 waiting to walk a brick, 2 finished, 3 take the DDA step
-        int state = more ? 0 : 2;
-        while (__any(state != 2)) {
-            if (state == 0) state = cell_occupied() ? 1 : 3;
-            const unsigned long long waiting = __ballot(state == 1);
-            if (waiting != 0ull) {
-                const unsigned long long moving = __ballot(state == 3);
-                if (moving == 0ull || (uint32_t)__popcll(waiting) >= p.brick_batch) {
-                    if (state == 1) {
-                        enter_brick();
-                        state = (stop != 0) ? 2 : 3;
-                    }
-                }
-            }
-            if (state == 3) {
-                dda_step<true>(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
-                state = (min3i(w.rx, w.ry, w.rz) >= 0) ? 0 : 2;
-            }
-        }
-        finish_hit();
-        return stop == -1;
-    } else if constexpr (MODE == kStatusLinearAhead) {
-        // Software-pipelined walk.  The DDA step does not depend on the cell test, so it is taken first and
-        // the status word of the NEXT cell is requested right away; the current cell is tested while that load
-        // is in flight (its latency otherwise sits between every two steps).  If the current cell is occupied
-        // its brick is walked with the pre-step state, rebuilt from the post-step state and the crossed axis.
-        uint32_t word = more ? p.brick_status[grid_index >> 5] : 0u;
-        while (more) {
-            VRT_COUNT(grid_steps);
-            VRT_COUNT_WAVE(wave_grid_iters);
-            if constexpr (COUNT) {
-                const uint32_t wi = grid_index >> 5;
-                if (wi != word_index) {
-                    word_index = wi;
-                    c.status_loads++;
-                }
-            }
-            const bool occupied = status_bit(word, grid_index);
-            const float t_here = w.t_value; // crossed distance of the step INTO the current cell
-            int axis_here = axis;
-            dda_step<true>(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
-            const bool inside = min3i(w.rx, w.ry, w.rz) >= 0;
-            word = inside ? p.brick_status[grid_index >> 5] : 0u;
-            if (occupied) {
-                const int a = axis; // the step just taken left the current cell through this axis
-                enter_brick_at(w.rx + (a == 0 ? 1 : 0), w.ry + (a == 1 ? 1 : 0), w.rz + (a == 2 ? 1 : 0), t_here,
-                               grid_index - (a == 0 ? stride_x : (a == 1 ? stride_y : stride_z)), axis_here);
-            }
-            more = ((inside ? 0 : -1) | stop) >= 0;
-        }
-        return stop == -1;
-    } else if constexpr ((MODE == kStatusLinearAlways || MODE == kStatusLinearLds || MODE == kStatusBytes) && !COUNT) {
-        // The shipped default: grid_walk_gfx950 runs trips until some lane stands on an occupied cell (or all
-        // lanes have left); the bricks are walked here, with the state from BEFORE the lane's last step rebuilt
-        // from the post-step state and the crossed-axis lane masks, and the walk is resumed.
-        const unsigned long long status_addr = (MODE == kStatusBytes) ? (unsigned long long)p.status_bytes : (unsigned long long)p.brick_status;
-        u32x4 rsrc;
-        rsrc.x = (uint32_t)status_addr;
-        // words: stride 4, one record per status word.  bytes: a raw buffer (stride 0), num_records = bytes = cells
-        rsrc.y = (uint32_t)(status_addr >> 32) | ((MODE == kStatusBytes) ? 0u : (4u << 16));
-        rsrc.z = (MODE == kStatusBytes) ? p.status_cells : p.status_words;
-        rsrc.w = 0x00020000u;
-        // LDS variant: byte-address mask of the power-of-two LDS allocation holding the bitmap (trace_lds_bytes)
-        [[maybe_unused]] const uint32_t lds_mask = (0xFFFFFFFFu >> __builtin_clz(p.status_words * 4u - 1u)) & ~3u;
-        uint32_t word;
-        if constexpr (MODE == kStatusLinearLds) word = lds_word0(more ? (grid_index >> 5) : 0u);
-        else if constexpr (MODE == kStatusBytes) word = p.status_bytes[more ? grid_index : 0u];
-        else word = p.brick_status[more ? (grid_index >> 5) : 0u];
-        GridWalkRegs g;
-        g.alive = __builtin_amdgcn_ballot_w64(more);
-        g.out_x = __builtin_amdgcn_ballot_w64(skipped && axis == 0);
-        g.out_y = __builtin_amdgcn_ballot_w64(skipped && axis == 1);
-        g.t_out = skip_t;
-        bool first = true; // wave-uniform
-        VRT_PROF_END(3, tp3);
-        while (g.alive != 0ull) {
-            uint32_t cell; // the cell each lane stood on before its last step
-            VRT_PROF_BEGIN(tp0);
-            if constexpr (MODE == kStatusLinearLds) grid_walk_lds_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, lds_mask, g);
-            else if constexpr (MODE == kStatusBytes) grid_walk_bytes_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
-            else grid_walk_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
-            VRT_PROF_END(0, tp0);
-            if (g.occ == 0ull) break; // every lane has left the grid
-            if (__builtin_amdgcn_inverse_ballot_w64(g.occ)) {
-                // axis 3: the first cell of the walk was entered through the slab test, not by a step
-                int a = (first && g.stub == 0u && !skipped) ? 3
-                                                : (__builtin_amdgcn_inverse_ballot_w64(g.in_x) ? 0 : (__builtin_amdgcn_inverse_ballot_w64(g.in_y) ? 1 : 2));
-                const bool out_x = __builtin_amdgcn_inverse_ballot_w64(g.out_x), out_y = __builtin_amdgcn_inverse_ballot_w64(g.out_y);
-                VRT_PROF_BEGIN(tp1);
-                enter_brick_at(w.rx + (out_x ? 1 : 0), w.ry + (out_y ? 1 : 0), w.rz + ((out_x | out_y) ? 0 : 1), g.t_in, cell, a);
-                VRT_PROF_END(1, tp1);
-            }
-            // (as asm: the compiler would do this on the vector unit and could not hand the result back to an SGPR operand)
-            asm("s_andn2_b64 %0, %0, %1" : "+s"(g.alive) : "s"(__builtin_amdgcn_ballot_w64(stop != 0)) : "scc");
-            first = false;
-        }
-        finish_hit();
-        return stop == -1;
-    } else {
-        while (more) { // single-exit loop, see brick_walk
-            if (cell_occupied()) enter_brick();
-            dda_step<true>(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
-            more = (min3i(w.rx, w.ry, w.rz) | stop) >= 0;
-        }
-        return stop == -1;
-    }
-}
-
-// ---- scatter functions (comp:539-596) -------------------------------------
-VRT_DI bool scatter_lambertian(const Hit &hit, Ray &scattered) {
-    const f3 rv = rand_vec3_range(hit.point.x + hit.point.z, hit.point.y + hit.point.z, -0.4f, 0.4f);
-    scattered = create_ray(hit.point, normalize3(hit.normal + rv));
-    return true;
-}
-VRT_DI bool scatter_metal(float fuzz, const Ray &r_in, const Hit &hit, Ray &scattered) {
-    const f3 reflected = reflect3(r_in.direction, hit.normal);
-    const f3 rv = rand_vec3_range(hit.point.x + hit.point.z, hit.point.y + hit.point.z, -fuzz, fuzz);
-    scattered = create_ray(hit.point, reflected + rv);
-    return dot3(scattered.direction, hit.normal) > 0;
-}
-VRT_DI bool transmission_direction(float n1, float n2, f3 ray_dir, f3 normal, f3 &refrac_dir) {
-    const float eta = n1 / n2;
-    const float c1 = -dot3(ray_dir, normal);
-    const float w = eta * c1;
-    const float c2m = (w - eta) * (w + eta);
-    if (c2m < -1.0f) return false;
-    refrac_dir = fma3(splat3(eta), ray_dir, normal * (w - __builtin_sqrtf(1.0f + c2m)));
-    return true;
-}
-VRT_DI bool scatter_dielectric(float ir, const Ray &r_in, const Hit &hit, Ray &scattered) {
-    const f3 rv = rand_vec3_range(hit.point.x + hit.point.z, hit.point.y + hit.point.z, -0.05f, 0.05f);
-    const f3 normal = normalize3(hit.normal + rv);
-    f3 direction = mk3(0, 0, 0);
-    const bool should_refract = transmission_direction(ir, r_in.internal_reflection, r_in.direction, normal, direction);
-    if (should_refract && rand_3(hit.point) > 0.5f) {
-        scattered = create_ray(hit.point, direction);
-        scattered.ignore_type_material = MAT_DIELECTRIC;
-        scattered.internal_reflection = ir;
-    } else {
-        direction = reflect3(r_in.direction, normal);
-        scattered = create_ray(hit.point, direction);
-    }
-    return true;
-}
-
-// comp:203-265 when push_constant.max_bounce <= 1 (Camera.Config.max_bounce = 0: "only primary
-// ray", Camera.zig:74).  The bounce loop then runs at most once, so the scatter functions — whose only
-// products are the next ray and the continue flag — have no observable effect and are not evaluated.
-template <int B, bool COUNT, int MODE>
-VRT_DI f3 ray_color_single(const TraceParams &p, const PushConstants &pc, const uint32_t *lds_filter, const Ray &ray, Cnt<COUNT> &c) {
-    const bool sun_enabled = pc.sun.enabled > 0;
-    const f3 sun_color = mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
-    f3 color = mk3(0, 0, 0);
-    int loop_count = 0;
-    Hit hit;
-    if (pc.cam.max_bounce > 0 && grid_hit<B, COUNT, MODE>(p, lds_filter, ray, hit, c)) {
-        const vrt_material *m = p.materials + hit.index;
-        const uint32_t mtype = m->type;
-        const f3 attenuation = mk3(m->albedo_r, m->albedo_g, m->albedo_b);
-        loop_count = (mtype <= MAT_DIELECTRIC) ? 1 : 0; // unknown type: loop_count -= 1 (comp:235-238)
-        if (sun_enabled) {
-            const f3 sun_position = mk3(pc.sun.position[0], pc.sun.position[1], pc.sun.position[2]);
-            const f3 rv = rand_vec3_range(ray.direction.x + ray.direction.z, ray.direction.y + ray.direction.z, -pc.sun.radius,
-                                          pc.sun.radius);
-            const Ray shadow_ray = create_ray(hit.point, (sun_position + rv) - hit.point);
-            Hit shadow_hit;
-            if (!grid_hit<B, COUNT, MODE>(p, lds_filter, shadow_ray, shadow_hit, c)) color = color + attenuation * sun_color;
-        } else {
-            color = color + attenuation;
-        }
-    }
-    if (loop_count == 0) {
-        const float t = 0.5f * (ray.direction.y + 1.0f);
-        const f3 bg = fma3(splat3(1.0f - t), splat3(1.0f), mk3(0.5f, 0.7f, 1.0f) * t);
-        color = color + bg * (sun_enabled ? sun_color : splat3(1.0f));
-    }
-    return color / (color + splat3(1.0f));
-}
-
-// comp:203-265
-template <int B, bool COUNT, int MODE>
-VRT_DI f3 ray_color(const TraceParams &p, const PushConstants &pc, const uint32_t *lds_filter, Ray current_ray, Cnt<COUNT> &c) {
-    const bool sun_enabled = pc.sun.enabled > 0;
-    const f3 sun_color = mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
-    const f3 sun_position = mk3(pc.sun.position[0], pc.sun.position[1], pc.sun.position[2]);
-    const int max_bounce = pc.cam.max_bounce;
-    Hit hit;
-    hit.point = mk3(0, 0, 0);
-    hit.normal = mk3(0, 0, 0);
-    hit.t = 0;
-    hit.index = 0;
-    int loop_count = 0;
-    f3 color = mk3(0, 0, 0);
-
-    while (loop_count < max_bounce && grid_hit<B, COUNT, MODE, true>(p, lds_filter, current_ray, hit, c)) {
-        loop_count += 1;
-        Ray scattered = current_ray;
-        bool result = false;
-        const vrt_material *m = p.materials + hit.index;
-        const uint32_t mtype = m->type;
-        const f3 attenuation = mk3(m->albedo_r, m->albedo_g, m->albedo_b);
-        const float mdata = m->type_data;
-        switch (mtype) {
-            case MAT_LAMBERTIAN: result = scatter_lambertian(hit, scattered); break;
-            case MAT_METAL: result = scatter_metal(mdata, current_ray, hit, scattered); break;
-            case MAT_DIELECTRIC: result = scatter_dielectric(mdata, current_ray, hit, scattered); break;
-            default:
-                loop_count -= 1;
-                result = false;
-                break;
-        }
-        if (sun_enabled) {
-            const f3 rv = rand_vec3_range(current_ray.direction.x + current_ray.direction.z,
-                                          current_ray.direction.y + current_ray.direction.z, -pc.sun.radius, pc.sun.radius);
-            const f3 sun_sample_position = sun_position + rv;
-            const f3 shadow_ray_dir = sun_sample_position - hit.point;
-            // CreateShadowRay, comp:186-190: sun_enabled > 0 here, so the ignore type is MAT_NONE
-            Ray shadow_ray = create_ray(hit.point, shadow_ray_dir);
-            Hit shadow_hit;
-            if (!grid_hit<B, COUNT, MODE, true>(p, lds_filter, shadow_ray, shadow_hit, c)) {
-                color = color + attenuation * sun_color;
-            }
-        } else {
-            color = color + attenuation;
-        }
-        if (!result) break;
-        current_ray = scattered;
-    }
-    if (loop_count == 0) {
-        // BackgroundColor, comp:197-201
-        const float t = 0.5f * (current_ray.direction.y + 1.0f);
-        const f3 bg = fma3(splat3(1.0f - t), splat3(1.0f), mk3(0.5f, 0.7f, 1.0f) * t);
-        color = color + bg * (sun_enabled ? sun_color : splat3(1.0f));
-    }
-    return color / (color + splat3(1.0f));
-}
-
-VRT_DI uint32_t unorm8(float c) {
-    c = (c > 0.0f) ? c : 0.0f; // NaN -> 0
-    c = (c > 1.0f) ? 1.0f : c;
-    return (uint32_t)__builtin_rintf(c * 255.0f);
-}
-
-// Workgroup -> image tile.  Block b executes on XCD b % 8; give XCD k the k-th
-// contiguous slice of this context's tile list.
-VRT_DI uint32_t xcd_slice_index(uint32_t b, uint32_t n) {
-    const uint32_t q = n >> 3, rem = n & 7u;
-    const uint32_t xcd = b & 7u, i = b >> 3;
-    return (xcd < rem) ? xcd * (q + 1u) + i : rem * (q + 1u) + (xcd - rem) * q + i;
-}
-
-// comp:153-178
-// A wave-uniform float the optimiser may not move out of a loop (empty asm pinned to an SGPR).
-VRT_DI float opaque_uniform(float v) {
-    asm volatile("" : "+s"(v));
-    return v;
-}
-VRT_DI f3 opaque_uniform3(const float (&v)[3]) { return mk3(opaque_uniform(v[0]), opaque_uniform(v[1]), opaque_uniform(v[2])); }
-
-// SHADE: 0 general bounce loop; 1 max_bounce <= 1 (ray_color_single); 2 the same with one sample per
-// pixel (no accumulator kept live across the traversal)
-template <int B, bool COUNT, int MODE, int MIN_WAVES, int SHADE, int BLOCK = 256>
-__global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const TraceParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_filter[];
-    if constexpr (MODE == kStatusLinearLds) {
-        // stage the brick-status bitmap (binding 3) in LDS: 16 bytes per lane per trip
-        const uint32_t nvec = (p.status_words + 3u) >> 2;
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.brick_status);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_filter);
-        for (uint32_t i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-    }
-    if constexpr (MODE == kStatusBlockedLds) {
-        // stage the block filter (1 bit per 4x4x4 block of cells) once per workgroup
-        const uint32_t nwords = (p.nbx * p.nby * p.nbz + 31u) >> 5;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.status_blocks + (size_t)p.nbx * p.nby * p.nbz);
-        for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) lds_filter[i] = src[i];
-        __syncthreads();
-    }
-    // One wave = one 8x8 pixel block.  wave_groups: the workgroup IS one wave (64 threads), so the
-    // hardware dispatcher hands 8x8 blocks to whichever SIMD frees a slot (dynamic load balance at
-    // wave granularity); otherwise a 256-thread workgroup covers one 16x16 tile with four waves.
-    // BLOCK 512: two 16x16 tiles per workgroup share one LDS copy of the status bitmap
-    const uint32_t unit = p.wave_groups ? (blockIdx.x >> 2) : (BLOCK == 512 ? blockIdx.x * 2u + (threadIdx.x >> 8) : blockIdx.x);
-    const uint32_t wave = p.wave_groups ? (blockIdx.x & 3u) : ((threadIdx.x >> 6) & 3u);
-    if (BLOCK == 512 && unit >= p.owned_tiles) return; // odd tile count: the last workgroup's second half is idle
-    uint32_t owned;
-    uint32_t split = 0u, half = 0u; // split: this workgroup renders one half of the tile (rows 4*half .. 4*half+3 of each 8x8 block)
-    if (p.tile_order == 5u) {
-        // cost-feedback schedule: tiles sorted by the time they took last frame, heaviest first, so the
-        // kernel's tail is made of cheap tiles (longest-processing-time-first list scheduling).  Launch
-        // order also spreads consecutive tiles over XCDs (block b runs on XCD b % 8).
-        // (stored XCD-major: workgroup b runs on XCD b % 8, and the eight XCDs read disjoint lines of the list)
-        // An entry with bit 31 renders HALF of its tile (bit 30 says which) on 32 lanes per wave: the schedule kernel
-        // splits the tiles whose slowest wave would otherwise outlast the rest of the frame (the lanes of such a wave
-        // walk their bricks one after the other; half the lanes, fewer separate walks: 88 -> 70 us for the slowest
-        // tile of view V1).  The list has p.sched_extra spare entries for the second halves; unused ones are ~0.
-        const uint32_t entry = p.tile_schedule[(unit & 7u) * ((p.owned_tiles + p.sched_extra + 7u) >> 3) + (unit >> 3)];
-        if (entry == 0xFFFFFFFFu) return; // a spare entry (uniform over the workgroup)
-        owned = entry & 0x3FFFFFFFu;
-        split = entry >> 31;
-        half = (entry >> 30) & 1u;
-    } else if (p.tile_order == 6u) {
-        // raster order; consecutive tiles go to consecutive XCDs: every XCD samples the whole image
-        // (a contiguous band per XCD measured 22-28 % slower on the headline frame: sky bands idle)
-        owned = unit;
-    } else if (p.tile_order == 3u) {
-        // reverse raster, consecutive tiles on consecutive XCDs: every XCD samples the whole image, and
-        // the rows that usually hold the ground (long rays) start first so that sky tiles fill the tail
-        owned = p.owned_tiles - 1u - unit;
-    } else if (p.tile_order == 4u) {
-        // strided permutation: consecutive launches sample the whole image (stride coprime to the count)
-        owned = (uint32_t)(((unsigned long long)unit * p.tile_stride) % p.owned_tiles);
-    } else if (p.tile_order == 2u) {
-        // XCD k gets a band of tile columns: slice index runs column-major over the tile grid
-        const uint32_t cm = xcd_slice_index(unit, p.owned_tiles);
-        const uint32_t col = cm / p.tiles_y, row = cm % p.tiles_y;
-        owned = row * p.tiles_x + col;
-    } else {
-        owned = xcd_slice_index(unit, p.owned_tiles);
-    }
-    const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
-    const uint32_t tile_x = tile % p.tiles_x, tile_y = tile / p.tiles_x;
-    // lane -> pixel: wave w of the tile covers the 8x8 quadrant (w&1, w>>1)
-    const uint32_t lane = threadIdx.x & 63u;
-    const PushConstants &pc = p.pcs[blockIdx.y]; // frame blockIdx.y of this launch (kernarg segment, scalar loads)
-    const uint32_t in_x = (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t in_y = (wave >> 1) * 8u + (split ? half * 4u + ((lane >> 3) & 3u) : (lane >> 3));
-    const uint32_t px = tile_x * kTileW + in_x;
-    const uint32_t py = tile_y * kTileH + in_y;
-
-#ifdef VRT_DEV_PROFILE
-    if (threadIdx.x < 8) vrt_prof[threadIdx.x] = 0ull;
-    __syncthreads();
-#endif
-    VRT_PROF_BEGIN(tp7);
-    const unsigned long long t_begin = (p.tile_order == 5u) ? __builtin_readcyclecounter() : 0ull;
-    const unsigned long long wall_begin = p.wave_timeline ? wall_clock64() : 0ull;
-    Cnt<COUNT> c;
-    const bool inside = (px < p.width) && (py < p.height) && (!split || lane < 32u); // comp:155-159
-    uint32_t rgba = 0u; // this lane's pixel (0 outside the image), also needed after the branch by the RGB shard store
-    if (inside) {
-        f3 color = mk3(0, 0, 0);
-        const int spp = (SHADE == 2) ? 1 : pc.cam.samples_per_pixel;
-        const float x = (float)px, y = (float)py;
-        // CameraGetRay operands, comp:474-477
-        const f3 horizontal = mk3(pc.cam.horizontal[0], pc.cam.horizontal[1], pc.cam.horizontal[2]);
-        const f3 vertical = mk3(pc.cam.vertical[0], pc.cam.vertical[1], pc.cam.vertical[2]);
-        const f3 llc = mk3(pc.cam.lower_left_corner[0], pc.cam.lower_left_corner[1], pc.cam.lower_left_corner[2]);
-        const f3 origin = mk3(pc.cam.origin[0], pc.cam.origin[1], pc.cam.origin[2]);
-        if constexpr (SHADE == 2) {
-            // sample 0 is un-jittered: hash12(0) = 0 (comp:167-170)
-            const float u = (x + 0.0f) / (float)(pc.cam.image_width - 1u);
-            const float v = (y + 0.0f) / (float)(pc.cam.image_height - 1u);
-            const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
-            color = mk3(0, 0, 0) + ray_color_single<B, COUNT, MODE>(p, pc, lds_filter, create_ray(origin, ray_dir), c);
-        } else {
-            for (int sample_i = 0; sample_i < spp; sample_i++) {
-                // Re-derive the camera vectors from their SGPRs in every trip: a VALU op takes a single scalar
-                // operand, so the compiler copies them to VGPRs — hoisted out of this loop, twelve copies would
-                // stay live across the whole traversal and cost a wave per SIMD.
-                const f3 horizontal = opaque_uniform3(pc.cam.horizontal);
-                const f3 vertical = opaque_uniform3(pc.cam.vertical);
-                const f3 llc = opaque_uniform3(pc.cam.lower_left_corner);
-                const f3 origin = opaque_uniform3(pc.cam.origin);
-                const float flag = (sample_i > 0) ? 1.0f : 0.0f;
-                const float noise_x = hash_12(((x + (float)sample_i) * 0.2f) * flag, (y * 0.2f) * flag);
-                const float u = (x + noise_x) / (float)(pc.cam.image_width - 1u);
-                const float noise_y = hash_12((x * 0.2f) * flag, ((y + (float)sample_i) * 0.2f) * flag);
-                const float v = (y + noise_y) / (float)(pc.cam.image_height - 1u);
-                const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
-                if constexpr (SHADE == 1) color = color + ray_color_single<B, COUNT, MODE>(p, pc, lds_filter, create_ray(origin, ray_dir), c);
-                else color = color + ray_color<B, COUNT, MODE>(p, pc, lds_filter, create_ray(origin, ray_dir), c);
-            }
-        }
-        const float fspp = (float)spp;
-        color = mk3(__builtin_sqrtf(color.x / fspp), __builtin_sqrtf(color.y / fspp), __builtin_sqrtf(color.z / fspp));
-
-        size_t o;
-        if (p.shard_count > 1u || p.packed_tiles) {
-            o = (size_t)owned * (kTileW * kTileH) + in_y * kTileW + in_x; // packed tile-major shard
-        } else {
-            o = (size_t)py * p.width + px; // row-major frame
-        }
-        rgba = unorm8(color.x) | (unorm8(color.y) << 8) | (unorm8(color.z) << 16) | (255u << 24);
-        if (!p.packed_rgb) reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] = rgba;
-        if (p.target_rgba32f) {
-            reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(color.x, color.y, color.z, 1.0f);
-        }
-    }
-    if (p.packed_rgb) {
-        // RGB shard (multi-GPU pipeline): 16x16 tiles of 3-byte pixels, 768 bytes per tile.  The eight lanes of a row of
-        // this wave's 8x8 block hold 24 consecutive bytes = 6 dwords; lane k < 6 of the row assembles dword k from the
-        // two pixels it spans (bytes 4k .. 4k+3; pixel = byte / 3) and stores it.
-        const uint32_t k = lane & 7u;
-        const uint32_t first = k + (k >= 3u ? 1u : 0u); // = 4k / 3 for k < 6
-        const int src = (int)((lane & ~7u) + first);
-        const uint32_t lo = (uint32_t)__shfl((int)rgba, src, 64), hi = (uint32_t)__shfl((int)rgba, src + 1, 64);
-        const uint32_t m = k % 3u;
-        const uint32_t dword = (m == 0u) ? ((lo & 0xFFFFFFu) | (hi << 24)) : ((m == 1u) ? (((lo >> 8) & 0xFFFFu) | (hi << 16)) : (((lo >> 16) & 0xFFu) | (hi << 8)));
-        if (k < 6u)
-            reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[(size_t)owned * 192u + in_y * 12u + (in_x >> 3) * 6u + k] = dword;
-    }
-#ifdef VRT_DEV_PROFILE
-    VRT_PROF_END(7, tp7);
-    __syncthreads();
-    if (p.wave_timeline && threadIdx.x < 8) p.wave_timeline[(size_t)blockIdx.x * 8 + threadIdx.x] = vrt_prof[threadIdx.x];
-#else
-    if (p.wave_timeline && lane == 0) {
-        const size_t w_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        p.wave_timeline[2 * w_id] = wall_begin;
-        p.wave_timeline[2 * w_id + 1] = wall_clock64();
-    }
-#endif
-    if (p.tile_order == 5u) {
-        // the wave's cycles, one plain store per wave into its own slot: the tile's cost for the next schedule.  (An
-        // atomic add per wave into one word per tile measured 4.5 % of the kernel: the wave's slot is held until the
-        // atomic is acknowledged.)
-        const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
-        if (lane == 0) p.tile_cost[((size_t)half * p.owned_tiles + owned) * 4u + wave] = (uint32_t)(dt >> 6);
-    }
-    if constexpr (COUNT) {
-        // wave-level reduction, then one atomic per wave per counter
-        unsigned long long v[9] = {c.rays, c.status_loads, c.bricks_entered, c.voxel_steps, c.hits, c.grid_steps,
-                                   c.wave_grid_iters, c.wave_brick_walks, c.wave_voxel_iters};
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            unsigned long long s = v[k];
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-            v[k] = s;
-        }
-        if (lane == 0) {
-            atomicAdd(&p.counters->rays, v[0]);
-            atomicAdd(&p.counters->status_loads, v[1]);
-            atomicAdd(&p.counters->bricks_entered, v[2]);
-            atomicAdd(&p.counters->voxel_steps, v[3]);
-            atomicAdd(&p.counters->hits, v[4]);
-            atomicAdd(&p.counters->grid_steps, v[5]);
-            atomicAdd(&p.counters->wave_grid_iters, v[6]);
-            atomicAdd(&p.counters->wave_brick_walks, v[7]);
-            atomicAdd(&p.counters->wave_voxel_iters, v[8]);
-        }
-    }
-}
-
-// ---- frames with bounces: persistent lanes -------------------------------------------------------------------------
-// vrt_trace_kernel<SHADE 0> runs the shader's loops in lockstep: the 64 lanes of a wave take sample s together, bounce k
-// together, and every GridHit lasts as long as the longest of its 64 walks.  On the path-trace configuration (incoherent
-// secondary rays through a sparse field, 16 samples, 3 bounces) that leaves about a fifth of the lanes of an instruction
-// busy (367 wave-instructions per ray against ~70 for 64 rays in step; profiles/r02a_cfg4*).  Here a lane is not tied to
-// its wave's progress: each lane carries its own (pixel, sample, bounce, ray) and moves through
-//     FETCH a pixel -> SAMPLE (camera ray) -> START a ray (slab test, walk set-up) -> WALK (the hand-written park loop,
-//     shared by primary, bounce and shadow rays of all lanes) -> DONE (shade: scatter, shadow ray, next bounce) -> END of
-//     the path (tone-map, accumulate the sample) -> STORE the pixel -> FETCH ...
-// A lane whose ray has left the grid is handed its next ray while its neighbours keep walking: the walk loop returns
-// when `path_fin_batch` lanes have finished (or `brick_batch` lanes wait at a brick, or nobody is moving), the transitions
-// run for the lanes that need them, and the loop is re-entered with every lane that has a ray.  Pixels come from one
-// counter per frame (p.work_counter), 64 consecutive pixels of an 8x8 block at a time while the wave is empty.
-// Per lane the sequence of arithmetic operations is exactly ray_color's / main()'s (comp:153-265): the samples of a pixel
-// are traced one after the other by the lane that owns the pixel and summed in order, so frames are bit-identical.
-enum : int { kLaneFetch = 0, kLaneSample, kLaneStart, kLaneWalk, kLaneDone, kLaneEnd, kLaneStore, kLaneExit };
-
-// FILTER: 512-thread workgroups (eight waves, two per SIMD, share one LDS copy of the block filter); two workgroups per CU:
-// 2 x (32 KiB filter + 8 x 4 KiB of staged bricks) = 128 of the CU's 160 KiB, four waves per SIMD.  (640-thread groups for five
-// waves per SIMD do not pair up: ten waves leave the SIMDs 3/3/2/2, and 96 registers do not admit a sixth wave.)
-constexpr int kPathFilterThreads = 512;
-template <int B, int MIN_WAVES, bool FILTER, bool HALF = false>
-__global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN_WAVES) void vrt_path_kernel(const TraceParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_block_filter[];
-    FilterConsts fc{};
-    if constexpr (FILTER) {
-        // stage the block filter (1 bit per 4x4x4 block of cells: "some cell occupied") once per workgroup; the kernel has no
-        // static LDS, so the dynamic region starts at LDS address 0, which the walk loop's ds_read relies on
-        const uint32_t nblocks = p.nbx * p.nby * p.nbz;
-        const uint32_t nwords = (nblocks + 31u) >> 5;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.status_blocks + (size_t)nblocks);
-        for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) lds_block_filter[i] = src[i];
-        __syncthreads();
-        const uint32_t lx = 31u - (uint32_t)__builtin_clz(p.grid.dim_x), lz = 31u - (uint32_t)__builtin_clz(p.grid.dim_z);
-        fc.wx = lx - 2u;
-        fc.shz = lx + 2u;
-        fc.mz = (p.grid.dim_z >> 2) - 1u;
-        fc.shy = lx + lz + 2u;
-        fc.shyb = lx + lz - 4u;
-    }
-    // brick staging area of this wave (8^3 bricks, p.path_brick_lds): 4 KiB behind the block filter, as an LDS byte address
-    [[maybe_unused]] const uint32_t wave_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds_block_filter +
-                                               (FILTER ? p.path_lds_bytes : 0u) + (threadIdx.x >> 6) * 4096u;
-    const PushConstants &pc = p.pcs[blockIdx.y];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total = p.owned_tiles * (uint32_t)(kTileW * kTileH);
-    uint32_t *const counter = p.work_counter + blockIdx.y;
-    const bool sun_enabled = pc.sun.enabled > 0;
-    const int spp = pc.cam.samples_per_pixel;
-    const int max_bounce = pc.cam.max_bounce;
-    const float t_max = __builtin_inff();
-
-    const f3 g_min = mk3(p.grid.min_point_base_t[0], p.grid.min_point_base_t[1], p.grid.min_point_base_t[2]);
-    const float g_scale = p.grid.max_point_scale[3];
-    const int dx = (int)p.grid.dim_x, dy = (int)p.grid.dim_y, dz = (int)p.grid.dim_z;
-    int lox = 0, loy = 0, loz = 0, hix = dx - 1, hiy = dy - 1, hiz = dz - 1;
-    if (p.cell_bounds) {
-        lox = -p.cell_bounds[0], loy = -p.cell_bounds[1], loz = -p.cell_bounds[2];
-        hix = p.cell_bounds[3], hiy = p.cell_bounds[4], hiz = p.cell_bounds[5];
-    }
-    const int zero_budget = dx + dy + dz + 8;
-    const unsigned long long status_addr = (unsigned long long)p.brick_status;
-    u32x4 rsrc;
-    rsrc.x = (uint32_t)status_addr;
-    rsrc.y = (uint32_t)(status_addr >> 32) | (4u << 16); // stride 4: one record per status word
-    rsrc.z = p.status_words;
-    rsrc.w = 0x00020000u;
-
-    // the walk loop on half-block words (p.status_halfblocks: derived, 4 x 4 x 2 cells per word; eligible grids only)
-    HalfBlockConsts hb;
-    u32x4 hb_rsrc;
-    constexpr bool halfblocks = HALF; // (a template parameter: two asm blocks with scalar outputs behind a run-time branch do not compile)
-    {
-        // (computed unconditionally and pinned to SGPRs: they are scalar operands of the hand-written loop)
-        auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-        const uint32_t lx = 31u - (uint32_t)__builtin_clz(p.grid.dim_x | 4u), lz = 31u - (uint32_t)__builtin_clz(p.grid.dim_z | 4u);
-        hb.nmask = uni(~(3u | (3u << lx) | (1u << (lx + lz))));
-        hb.mx = uni((1u << (lx - 2u)) - 1u);
-        hb.mzs = uni(((p.grid.dim_z >> 2) - 1u) << (lx - 2u));
-        hb.mys = uni(~((1u << (lx + lz - 4u)) - 1u));
-        hb.lx = uni(lx);
-        hb.lxz = uni(lx + lz);
-        const unsigned long long a = (unsigned long long)p.status_halfblocks;
-        hb_rsrc.x = uni((uint32_t)a);
-        hb_rsrc.y = uni((uint32_t)(a >> 32) | (4u << 16));
-        hb_rsrc.z = uni(p.status_words);
-        hb_rsrc.w = 0x00020000u;
-    }
-    // the status word of a cell, in the layout the walk loop reads
-    auto status_word = [&](uint32_t index) { return halfblocks ? p.status_halfblocks[halfblock_word(hb, index)] : p.brick_status[index >> 5]; };
-
-    // ---- per-lane state ----
-    int st = kLaneFetch;
-    uint32_t work = 0u;          // pixel: index into this context's tiles, 256 per tile, 8x8 blocks inside
-    int sample_i = 0;
-    f3 acc = mk3(0, 0, 0);       // sum of the samples' colours (comp:173)
-    // the path (RayColor's locals, comp:203-216)
-    int loop_count = 0;
-    f3 color = mk3(0, 0, 0);
-    float cur_dir_y = 0.0f;      // current_ray.direction.y, for BackgroundColor when loop_count ends at 0
-    // the ray being walked: the path's current ray (kind 0) or the shadow ray of its last hit (kind 1)
-    Ray r = Ray{mk3(0, 0, 0), mk3(0, 0, 1), 1.0f, MAT_NONE};
-    int kind = 0;
-    bool found = false;
-    // kept while the shadow ray is walked: the scattered ray (its origin is the shadow ray's origin, hit.point), the
-    // albedo, and whether the material scattered (comp:221-239)
-    f3 sc_dir = mk3(0, 0, 1);
-    float sc_ir = 1.0f;
-    uint32_t sc_ignore = MAT_NONE;
-    f3 attenuation = mk3(0, 0, 0);
-    bool scattered_ok = false;
-    // the walk (grid_hit's locals)
-    RaySetup s;
-    s.ray_delta = s.inv_dir = mk3(1, 1, 1);
-    s.entry_code = 0;
-    s.sx = s.sy = s.sz = 0;
-    s.grid_t_min = s.grid_t_max = 0.0f;
-    Walk w;
-    w.side_dist = mk3(0, 0, 0);
-    w.rx = w.ry = w.rz = -1;
-    w.t_value = 0.0f;
-    int base_x = 0, base_y = 0, base_z = 0;
-    uint32_t grid_index = 0u, word = 0u;
-    uint32_t stride_x = 0u, stride_y = 0u, stride_z = 0u;
-    Hit hit;
-    hit.point = hit.normal = mk3(0, 0, 0);
-    hit.t = 0.0f;
-    hit.index = 0u;
-    int hit_axis = 0;
-    GridParkRegs g;
-    g.alive = 0ull;
-    g.out_x = g.out_y = 0ull;
-    g.t_out = g.t_in = 0.0f;
-    g.code = 3u << 4;
-    g.batch = p.path_brick_batch;
-    // FILTER: a walking lane is `ready` once its cell is known to lie in a block that holds occupied cells (it takes trips);
-    // otherwise its block is looked up, and jumped over if empty.  `stale`: the lane has jumped since `word` was loaded.
-    [[maybe_unused]] bool ready = false, stale = false;
-
-    bool work_left = true; // wave-uniform
-#ifdef VRT_DEV_PROFILE
-    if (threadIdx.x < 8) vrt_prof[threadIdx.x] = 0ull; // (the brick walk's own phase hooks; static LDS: not with FILTER)
-    __syncthreads();
-    // development-only (make EXTRA=-DVRT_DEV_PROFILE, tools/path_profile.py): cycles and lane counts per phase, per wave
-    unsigned long long pf_t[3] = {0ull, 0ull, 0ull};      // cycles in transitions / walk loop / bricks
-    unsigned long long pf_n[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; // rounds: transitions, waiting lanes; walk calls, alive lanes at entry,
-                                                                                    // alive lanes at exit; brick rounds, parked lanes; hits
-#define VRT_PF_T(k, t0) pf_t[k] += __builtin_readcyclecounter() - (t0)
-#define VRT_PF_N(k, v) pf_n[k] += (unsigned long long)(v)
-#define VRT_PF_NOW() __builtin_readcyclecounter()
-#else
-#define VRT_PF_T(k, t0)
-#define VRT_PF_N(k, v)
-#define VRT_PF_NOW() 0ull
-#endif
-    for (;;) {
-        // How many lanes wait for a transition?  Few: leave them waiting and keep the others walking (the divergent
-        // code below costs the whole wave its issue slots).
-        const unsigned long long walking0 = __builtin_amdgcn_ballot_w64(st == kLaneWalk);
-        const unsigned long long waiting = __builtin_amdgcn_ballot_w64(st != kLaneWalk && st != kLaneExit);
-        const uint32_t n_walking0 = (uint32_t)__builtin_popcountll(walking0), n_waiting = (uint32_t)__builtin_popcountll(waiting);
-        if (n_walking0 == 0u && n_waiting == 0u) break;
-        [[maybe_unused]] const unsigned long long pf0 = VRT_PF_NOW();
-        if (n_waiting != 0u && (n_walking0 == 0u || n_waiting >= min(p.path_fin_batch, max(1u, n_walking0 >> 1)))) {
-            VRT_PF_N(0, 1);
-            VRT_PF_N(1, n_waiting);
-            // (1) a ray has finished: comp:218-258 from the loop condition's GridHit onwards
-            if (st == kLaneDone) {
-                bool after_shadow = false;
-                if (kind == 0) {
-                    if (found) {
-                        // (brick_walk_gfx950 records a hit as distance + material + face: comp:433-436 from those)
-                        const float t_offset = (g_scale * (1.0f / (float)B)) * 0.05f;
-                        hit.normal = axis_normal(s, hit_axis);
-                        hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
-                        loop_count += 1;
-                        Ray scattered = r;
-                        bool result = false;
-                        const vrt_material *m = p.materials + hit.index;
-                        const uint32_t mtype = m->type;
-                        attenuation = mk3(m->albedo_r, m->albedo_g, m->albedo_b);
-                        const float mdata = m->type_data;
-                        switch (mtype) {
-                            case MAT_LAMBERTIAN: result = scatter_lambertian(hit, scattered); break;
-                            case MAT_METAL: result = scatter_metal(mdata, r, hit, scattered); break;
-                            case MAT_DIELECTRIC: result = scatter_dielectric(mdata, r, hit, scattered); break;
-                            default:
-                                loop_count -= 1;
-                                result = false;
-                                break;
-                        }
-                        scattered_ok = result;
-                        sc_dir = scattered.direction;
-                        sc_ir = scattered.internal_reflection;
-                        sc_ignore = scattered.ignore_type_material;
-                        cur_dir_y = r.direction.y;
-                        if (sun_enabled) {
-                            const f3 sun_position = mk3(pc.sun.position[0], pc.sun.position[1], pc.sun.position[2]);
-                            const f3 rv = rand_vec3_range(r.direction.x + r.direction.z, r.direction.y + r.direction.z, -pc.sun.radius, pc.sun.radius);
-                            const f3 shadow_ray_dir = (sun_position + rv) - hit.point;
-                            r = create_ray(hit.point, shadow_ray_dir); // CreateShadowRay, comp:186-190 (ignore type MAT_NONE)
-                            kind = 1;
-                            st = kLaneStart;
-                        } else {
-                            color = color + attenuation;
-                            // the scattered ray starts where the shadow ray would have: keep the origin in r
-                            r.origin = hit.point;
-                            after_shadow = true;
-                        }
-                    } else {
-                        cur_dir_y = r.direction.y;
-                        st = kLaneEnd; // the while condition failed (comp:218)
-                    }
-                } else {
-                    if (!found) color = color + attenuation * mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
-                    after_shadow = true;
-                }
-                if (after_shadow) {
-                    if (!scattered_ok) {
-                        st = kLaneEnd; // comp:253-255
-                    } else {
-                        r.direction = sc_dir; // current_ray = scattered (its origin, hit.point, is r.origin already)
-                        r.internal_reflection = sc_ir;
-                        r.ignore_type_material = sc_ignore;
-                        cur_dir_y = sc_dir.y;
-                        kind = 0;
-                        st = (loop_count < max_bounce) ? kLaneStart : kLaneEnd;
-                    }
-                }
-            }
-            // (2) the path is over: comp:260-264, then the sample loop's accumulation (comp:173)
-            if (st == kLaneEnd) {
-                if (loop_count == 0) {
-                    const f3 sun_color = mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
-                    const float t = 0.5f * (cur_dir_y + 1.0f);
-                    const f3 bg = fma3(splat3(1.0f - t), splat3(1.0f), mk3(0.5f, 0.7f, 1.0f) * t);
-                    color = color + bg * (sun_enabled ? sun_color : splat3(1.0f));
-                }
-                acc = acc + color / (color + splat3(1.0f));
-                sample_i += 1;
-                st = (sample_i < spp) ? kLaneSample : kLaneStore;
-            }
-            // (3) the pixel is finished: comp:176-177
-            if (st == kLaneStore) {
-                const uint32_t owned = p.owned_tiles - 1u - (work >> 8);
-                const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
-                const uint32_t j = work & 255u;
-                const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
-                const uint32_t px = (tile % p.tiles_x) * kTileW + in_x, py = (tile / p.tiles_x) * kTileH + in_y;
-                const float fspp = (float)spp;
-                const f3 c = mk3(__builtin_sqrtf(acc.x / fspp), __builtin_sqrtf(acc.y / fspp), __builtin_sqrtf(acc.z / fspp));
-                const size_t o = (p.shard_count > 1u || p.packed_tiles) ? (size_t)owned * (kTileW * kTileH) + in_y * kTileW + in_x : (size_t)py * p.width + px;
-                reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] =
-                    unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
-                if (p.target_rgba32f) reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(c.x, c.y, c.z, 1.0f);
-                st = kLaneFetch;
-            }
-            // (4) next pixel: one atomic per wave for all the lanes that ask
-            {
-                const unsigned long long asking = __builtin_amdgcn_ballot_w64(st == kLaneFetch);
-                if (asking != 0ull) {
-                    if (work_left) {
-                        const uint32_t n = (uint32_t)__builtin_popcountll(asking);
-                        uint32_t first = 0u;
-                        if (lane == (uint32_t)__builtin_ctzll(asking)) first = atomicAdd(counter, n);
-                        first = (uint32_t)__builtin_amdgcn_readlane((int)first, __builtin_ctzll(asking));
-                        if (st == kLaneFetch) {
-                            const uint32_t mine = first + (uint32_t)__builtin_popcountll(asking & ((1ull << lane) - 1ull));
-                            if (mine < total) {
-                                work = mine;
-                                sample_i = 0;
-                                acc = mk3(0, 0, 0);
-                                st = kLaneSample;
-                            } else {
-                                st = kLaneExit;
-                            }
-                        }
-                        work_left = first + n < total;
-                    } else if (st == kLaneFetch) {
-                        st = kLaneExit;
-                    }
-                }
-            }
-            // (5) next sample of the pixel: comp:162-171
-            if (st == kLaneSample) {
-                const uint32_t owned = p.owned_tiles - 1u - (work >> 8);
-                const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
-                const uint32_t j = work & 255u;
-                const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
-                const uint32_t px = (tile % p.tiles_x) * kTileW + in_x, py = (tile / p.tiles_x) * kTileH + in_y;
-                if (px >= p.width || py >= p.height) {
-                    st = kLaneFetch; // outside the image (comp:155-159): nothing to trace, nothing to store
-                } else {
-                    const float x = (float)px, y = (float)py;
-                    const f3 horizontal = mk3(pc.cam.horizontal[0], pc.cam.horizontal[1], pc.cam.horizontal[2]);
-                    const f3 vertical = mk3(pc.cam.vertical[0], pc.cam.vertical[1], pc.cam.vertical[2]);
-                    const f3 llc = mk3(pc.cam.lower_left_corner[0], pc.cam.lower_left_corner[1], pc.cam.lower_left_corner[2]);
-                    const f3 origin = mk3(pc.cam.origin[0], pc.cam.origin[1], pc.cam.origin[2]);
-                    const float flag = (sample_i > 0) ? 1.0f : 0.0f;
-                    const float noise_x = hash_12(((x + (float)sample_i) * 0.2f) * flag, (y * 0.2f) * flag);
-                    const float u = (x + noise_x) / (float)(pc.cam.image_width - 1u);
-                    const float noise_y = hash_12((x * 0.2f) * flag, ((y + (float)sample_i) * 0.2f) * flag);
-                    const float v = (y + noise_y) / (float)(pc.cam.image_height - 1u);
-                    const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
-                    r = create_ray(origin, ray_dir);
-                    kind = 0;
-                    loop_count = 0;
-                    color = mk3(0, 0, 0);
-                    cur_dir_y = r.direction.y;
-                    st = (loop_count < max_bounce) ? kLaneStart : kLaneEnd;
-                }
-            }
-            // (6) a new ray: comp:271-312 (GridHit up to its loop)
-            if (st == kLaneStart) {
-                found = false;
-                st = kLaneDone;
-                if (grid_slab(p, r, 0.00001f, t_max, s)) {
-                    const float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
-                    const f3 fposition = p.scale_pow2 ? (ray_at(r, global_t_value) - g_min) * p.inv_grid_scale : (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
-                    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
-                    const int px = f2i_clamp(__builtin_floorf(fposition.x));
-                    const int py = f2i_clamp(__builtin_floorf(fposition.y));
-                    const int pz = f2i_clamp(__builtin_floorf(fposition.z));
-                    w.rx = steps_left_box(s.sx, px, lox, hix, zero_budget);
-                    w.ry = steps_left_box(s.sy, py, loy, hiy, zero_budget);
-                    w.rz = steps_left_box(s.sz, pz, loz, hiz, zero_budget);
-                    base_x = walk_base_box(s.sx, px, lox, hix), base_y = walk_base_box(s.sy, py, loy, hiy), base_z = walk_base_box(s.sz, pz, loz, hiz);
-                    w.t_value = 0;
-                    grid_index = (uint32_t)px + (uint32_t)dx * ((uint32_t)pz + (uint32_t)dz * (uint32_t)py);
-                    stride_x = (uint32_t)s.sx, stride_y = (uint32_t)s.sy * (uint32_t)dx * (uint32_t)dz, stride_z = (uint32_t)s.sz * (uint32_t)dx;
-                    bool more = (global_t_value <= t_max) && (unsigned)px < (unsigned)dx && (unsigned)py < (unsigned)dy && (unsigned)pz < (unsigned)dz &&
-                                (w.rx | w.ry | w.rz) >= 0;
-                    int in_axis = 3; // the first cell of the walk was entered through the slab test, not by a step ...
-                    float skip_t = 0.0f;
-                    // ... unless the ray enters the grid in front of the occupied-cell box and jumps to its near face
-                    if (p.cell_bounds && p.skip_to_box) skip_to_box(w, s, hix - lox, hiy - loy, hiz - loz, grid_index, stride_x, stride_y, stride_z, more, in_axis, skip_t);
-                    if (more) {
-                        if constexpr (FILTER) {
-                            ready = false;
-                            stale = true; // (the word is requested when the lane is about to take trips)
-                        } else {
-                            word = status_word(grid_index);
-                        }
-                        g.t_out = skip_t;
-                        g.code = (uint32_t)in_axis << 4;
-                        st = kLaneWalk;
-                    }
-                }
-            }
-        }
-        VRT_PF_T(0, pf0);
-        // (7) every lane that has a ray walks (comp:314-375), until enough of them are done for the next round of transitions
-        unsigned long long walking = __builtin_amdgcn_ballot_w64(st == kLaneWalk);
-        if (walking == 0ull) continue;
-        [[maybe_unused]] const unsigned long long pf1 = VRT_PF_NOW();
-        if constexpr (FILTER) {
-            // (7a) lanes whose block is not known to hold occupied cells: look the block up (LDS); empty -> jump behind the step
-            // that leaves it (no memory access), and again, until enough lanes are ready for trips or the round's budget is spent
-            for (uint32_t it = 0; it < p.path_skip_rounds; it++) {
-                const bool seeking = (st == kLaneWalk) && !ready;
-                if (__builtin_amdgcn_ballot_w64(seeking) == 0ull) break;
-                if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kLaneWalk && ready)) >= p.path_ready_batch) break;
-                if (seeking) {
-                    const uint32_t bi = ((grid_index >> 2) & ((1u << fc.wx) - 1u)) | (((grid_index >> fc.shz) & fc.mz) << fc.wx) | ((grid_index >> fc.shy) << fc.shyb);
-                    if ((lds_block_filter[bi >> 5] >> (bi & 31u)) & 1u) {
-                        ready = true;
-                    } else {
-                        bool more = true;
-                        int in_axis = 0;
-                        float t_in = 0.0f;
-                        skip_empty_block(w, s, grid_index & 3u, (grid_index >> (fc.shy - 2u)) & 3u, (grid_index >> (fc.wx + 2u)) & 3u, grid_index, stride_x, stride_y,
-                                         stride_z, more, in_axis, t_in);
-                        g.t_out = t_in;
-                        g.code = (uint32_t)in_axis << 4;
-                        stale = true;
-                        if (!more) {
-                            found = false; // left the box of the occupied cells
-                            st = kLaneDone;
-                        }
-                    }
-                }
-            }
-            walking = __builtin_amdgcn_ballot_w64(st == kLaneWalk && ready);
-            if (walking == 0ull) continue;
-            if (st == kLaneWalk && ready && stale) {
-                word = status_word(grid_index);
-                stale = false;
-            }
-        }
-        const uint32_t n_walking = (uint32_t)__builtin_popcountll(walking);
-        const uint32_t fin = min(p.path_fin_batch, max(1u, n_walking >> 1));
-        g.alive = walking;
-        // (FILTER: five trips per call, the way through a block of four cells; then the blocks are looked up again)
-        g.min_alive = FILTER ? 65u : (n_walking >= fin ? n_walking - fin + 1u : 1u);
-        uint32_t cell; // the occupied cell each parked lane stood on before its last step
-        if constexpr (halfblocks) grid_walk_park_halfblocks_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, hb);
-        else grid_walk_park_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
-        VRT_PF_T(1, pf1);
-        VRT_PF_N(2, 1);
-        VRT_PF_N(3, n_walking);
-        VRT_PF_N(4, __builtin_popcountll(g.alive));
-        [[maybe_unused]] const unsigned long long pf2 = VRT_PF_NOW();
-        const bool was_walking = (walking >> lane) & 1ull;
-        const bool parked = __builtin_amdgcn_inverse_ballot_w64(g.parked);
-        const bool moving = __builtin_amdgcn_inverse_ballot_w64(g.alive);
-        if (was_walking && !parked && !moving) {
-            found = false; // left the box of the occupied cells
-            st = kLaneDone;
-        }
-        if constexpr (FILTER) {
-            if (was_walking) ready = false; // it has moved: its block is looked up again
-        }
-        if (g.parked != 0ull) {
-            VRT_PF_N(5, 1);
-            VRT_PF_N(6, __builtin_popcountll(g.parked));
-            if (parked) {
-                int a = (int)(g.code & 3u);
-                const uint32_t out = (g.code >> 2) & 3u;
-                // the counters as they were on the occupied cell: undo the decrement of the step out of it
-                const int rx = w.rx + (out == 0u ? 1 : 0), ry = w.ry + (out == 1u ? 1 : 0), rz = w.rz + (out == 2u ? 1 : 0);
-                const int cx = base_x - __mul24(s.sx, rx), cy = base_y - __mul24(s.sy, ry), cz = base_z - __mul24(s.sz, rz); // cell position
-                const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min);  // comp:331
-                const float global_t_value = g.t_in * g_scale + s.grid_t_min + 0.01f * g_scale;          // comp:347 (deferred) + comp:332
-                hit.t = global_t_value;
-                const uint32_t brick_index = p.brick_index[cell]; // comp:337
-                bool hit_voxel;
-                if constexpr (B == 8) {
-                    hit_voxel = p.path_brick_lds ? brick_walk_park_gfx950<B, true>(p, r, s, g_scale, brick_index, brick_min, hit, a, hit_axis, wave_lds)
-                                                 : brick_walk_park_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, a, hit_axis);
-                } else {
-                    hit_voxel = brick_walk_park_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, a, hit_axis);
-                }
-                if (hit_voxel) {
-                    found = true;
-                    st = kLaneDone;
-                } else if (!(global_t_value <= t_max) || min3i(w.rx, w.ry, w.rz) < 0) {
-                    found = false; // t became NaN (comp:316), or the step out of this cell left the box
-                    st = kLaneDone;
-                } else {
-                    word = status_word(grid_index); // (an A-trip park left the lane's word in the other register set)
-                }
-            }
-        }
-        // every lane of the call: the axis of its last step, for its first trip in the next call
-        if (was_walking)
-            g.code = parked ? ((g.code >> 2) & 3u) << 4
-                            : (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
-        VRT_PF_T(2, pf2);
-    }
-#ifdef VRT_DEV_PROFILE
-    if (p.wave_timeline && lane == 0u) {
-        for (int k = 0; k < 3; k++) atomicAdd(&p.wave_timeline[k], pf_t[k]);
-        for (int k = 0; k < 8; k++) atomicAdd(&p.wave_timeline[3 + k], pf_n[k]);
-        atomicAdd(&p.wave_timeline[11], 1ull);
-    }
-    __syncthreads();
-    if (p.wave_timeline && threadIdx.x < 8) atomicAdd(&p.wave_timeline[12 + threadIdx.x], vrt_prof[threadIdx.x]);
-#endif
-#undef VRT_PF_T
-#undef VRT_PF_N
-#undef VRT_PF_NOW
-}
 
 // Builds the derived status structures from the uploaded brick_status words (binding 3):
 // out[0 .. nblocks)            one uint2 per 4x4x4 block of cells
@@ -2530,78 +325,91 @@ __global__ __launch_bounds__(256) void vrt_assemble_rgb4_kernel(const uint8_t *_
     *reinterpret_cast<uint4 *>(frame + (size_t)y * width + x) = out;
 }
 
-// ---- launchers (called from vrt_api.hip) ------------------------------------
-using KernelFn = void (*)(const TraceParams);
+// ---- kernel selection and launchers (called from vrt_api.hip) -----------------------------------------------------------
+static const KernelTable *all_tables(int *n) {
+    static const KernelTable tables[4] = {inst_trace_b4(), inst_trace_b8(), inst_trace_count(), inst_path()};
+    *n = 4;
+    return tables;
+}
+template <typename Pred>
+static const KernelEntry *find_entry(Pred pred) {
+    int nt = 0;
+    const KernelTable *t = all_tables(&nt);
+    for (int i = 0; i < nt; i++)
+        for (int k = 0; k < t[i].count; k++)
+            if (pred(t[i].entries[k])) return &t[i].entries[k];
+    return nullptr;
+}
+const KernelEntry *find_trace_kernel(int b, bool count, int mode, int min_waves, int shade, int block) {
+    return find_entry([&](const KernelEntry &e) {
+        return !e.path && e.b == b && (e.count != 0) == count && e.mode == mode && e.min_waves == min_waves && e.shade == shade && e.block == block;
+    });
+}
+const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half) {
+    return find_entry([&](const KernelEntry &e) { return e.path && e.b == b && e.min_waves == min_waves && (e.filter != 0) == filter && (e.half != 0) == half; });
+}
+const KernelEntry *kernel_entry_of(KernelFn fn) {
+    return find_entry([&](const KernelEntry &e) { return e.fn == fn; });
+}
+int compiled_kernel_count() {
+    int nt = 0, n = 0;
+    const KernelTable *t = all_tables(&nt);
+    for (int i = 0; i < nt; i++) n += t[i].count;
+    return n;
+}
 
 constexpr int kDefaultMinWaves = 4; // waves per SIMD the register allocator must leave room for
-
-// kernel_variant = mode | (min_waves << 8); min_waves 0 => kDefaultMinWaves.  The occupancy knob
-// exists for tuning runs (bench.py --variant 0x603 ...).
-template <int B, bool COUNT, int MW, int SHADE>
-static KernelFn pick_mode(uint32_t mode) {
-    switch (mode) {
-        case kVariantLiteral: return vrt_trace_kernel<B, COUNT, kStatusLinear, MW, SHADE>;
-        case kVariantBlocked: return vrt_trace_kernel<B, COUNT, kStatusBlocked, MW, SHADE>;
-        case kVariantBlockedLds: return vrt_trace_kernel<B, COUNT, kStatusBlockedLds, MW, SHADE>;
-        case kVariantLinearWide: return vrt_trace_kernel<B, COUNT, kStatusLinearWide, MW, SHADE>;
-        case kVariantLinearAlways: return vrt_trace_kernel<B, COUNT, kStatusLinearAlways, MW, SHADE>;
-        case kVariantLinearLds: return vrt_trace_kernel<B, COUNT, kStatusLinearLds, MW, SHADE>;
-        case kVariantLinearLds512: return vrt_trace_kernel<B, COUNT, kStatusLinearLds, MW, SHADE, 512>;
-        case kVariantLinearAhead: return vrt_trace_kernel<B, COUNT, kStatusLinearAhead, MW, SHADE>;
-        // (byte status: the hand-written loop of frames without bounces; counting builds and the bounce kernels keep the words)
-        case kVariantBytes: return vrt_trace_kernel<B, COUNT, (COUNT || SHADE == 0) ? kStatusLinearAlways : kStatusBytes, MW, SHADE>;
-        default: return nullptr;
-    }
-}
-
-template <int B, bool COUNT, int SHADE>
-static KernelFn pick_variant(uint32_t variant) {
-    const uint32_t mode = variant & 0xFFu, mw = (variant >> 8) & 0xFFu;
-    // (builds forced to 5, 7 or 8 waves per SIMD through __launch_bounds__ spilled and measured 6-21 % slower; they
-    // are no longer instantiated)
-    // (min_waves 5 is vrt_path_kernel's: every other kernel reads it as its default)
-    if (mw != 0u && mw != (uint32_t)kDefaultMinWaves && mw != 8u && mw != 5u && mw != 6u && mw != 7u) return nullptr;
-    if constexpr (SHADE == 2 && !COUNT) {
-        // the one-sample, no-bounce kernel (the headline's) is held to 72 VGPRs = 7 waves per SIMD (4 registers spilled outside the
-        // loops): on frames that keep the GPU full it is 1.5-2 % faster than at its natural 75 VGPRs = 6 waves (1080p / 512^3 / V1, V2:
-        // 0.132 -> 0.130, 0.134 -> 0.131 ms; `value` 25.1 -> 25.7 Grays/s), on a tail-bound frame (V1x) 4 % slower.  min_waves 4 asks
-        // for the natural build.
-        if (mw == 0u || mw == 7u) return pick_mode<B, COUNT, 7, SHADE>(mode);
-        if (mw == 8u) return pick_mode<B, COUNT, 8, SHADE>(mode); // tuning build: 64 VGPRs
-    }
-    // (the several-samples-per-pixel kernel, SHADE 1, needs 87 VGPRs left to itself = 5 waves per SIMD; held to 80 it spills
-    // 36 bytes outside the loops and runs at 6: 4K / 1024^3 / 4 rays per pixel 1.215 -> 1.183 ms per frame)
-    // (the bounce kernel, SHADE 0, takes 114 VGPRs = 4 waves per SIMD.  Its incoherent secondary rays wait on memory, and on a
-    // scene that does not stay in the caches more waves pay for the spills: 4K / 2048^3 sparse path-trace config, ms per frame
-    // V1 / V0 at 4, 5, 6, 8 waves per SIMD: 83.7 / 283, 71.6 / 238, 66.1 / 219, 60.6 / 201.  On the 512^3 terrain (17 MiB of
-    // bitmaps) the same build is 16 % SLOWER than the 4-wave one (0.518 against 0.447 ms, 1080p, 2 bounces), so both exist and
-    // vrt_create asks for the 8-wave one (min_waves 8) by the size of bindings 3-5)
-    if constexpr (SHADE == 0 && !COUNT) {
-        // frames with bounces: persistent lanes (vrt_path_kernel) unless the lockstep form is asked for (bit 21)
-        if (mode == kVariantLinearAlways && !(variant & kVariantLockstepBounce)) {
-            // bit 22: behind the LDS block filter (the library sets it when the grid allows); min_waves 5: 96 VGPRs
-            const bool filter = (variant & kVariantPathFilter) != 0u;
-            if (mw == 5u) return filter ? (KernelFn)vrt_path_kernel<B, 5, true> : (KernelFn)vrt_path_kernel<B, 5, false>;
-            if (mw == 6u && !filter) return (KernelFn)vrt_path_kernel<B, 6, false>; // tuning build: 80 VGPRs
-            return filter ? (KernelFn)vrt_path_kernel<B, kDefaultMinWaves, true> : (KernelFn)vrt_path_kernel<B, kDefaultMinWaves, false>;
-        }
-        if (mw == 8u) return pick_mode<B, COUNT, 8, SHADE>(mode);
-    }
-    return pick_mode<B, COUNT, (SHADE == 1 && !COUNT) ? 6 : kDefaultMinWaves, SHADE>(mode);
-}
 
 uint32_t resolve_variant(uint32_t variant) {
     return (variant & 0xFFu) == kVariantDefault ? ((variant & ~0xFFu) | (uint32_t)kVariantLinearAlways) : variant;
 }
 
-// shade: 0 general, 1 max_bounce <= 1 (no scatter evaluation), 2 the same with samples_per_pixel == 1
+// kernel_variant = mode | (min_waves << 8) | flags.  shade: 0 general, 1 max_bounce <= 1 (no scatter evaluation), 2 the same with
+// samples_per_pixel == 1.  Returns nullptr when this build of the library does not hold the kernel asked for (the product
+// build compiles the variants the library itself chooses; the others live in the development build, make dev).
 KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, int shade) {
     variant = resolve_variant(variant);
-#define VRT_PICK3(BD, CNT) (shade == 2 ? pick_variant<BD, CNT, 2>(variant) : (shade == 1 ? pick_variant<BD, CNT, 1>(variant) : pick_variant<BD, CNT, 0>(variant)))
-    if (brick_dimension == 4) return counters ? VRT_PICK3(4, true) : VRT_PICK3(4, false);
-    if (brick_dimension == 8) return counters ? VRT_PICK3(8, true) : VRT_PICK3(8, false);
-#undef VRT_PICK3
-    return nullptr;
+    const uint32_t vmode = variant & 0xFFu, mw = (variant >> 8) & 0xFFu;
+    if (mw != 0u && (mw < 4u || mw > 8u)) return nullptr;
+    int mode, block = 256;
+    switch (vmode) {
+        case kVariantLiteral: mode = kStatusLinear; break;
+        case kVariantBlocked: mode = kStatusBlocked; break;
+        case kVariantBlockedLds: mode = kStatusBlockedLds; break;
+        case kVariantLinearWide: mode = kStatusLinearWide; break;
+        case kVariantLinearAlways: mode = kStatusLinearAlways; break;
+        case kVariantLinearLds: mode = kStatusLinearLds; break;
+        case kVariantLinearLds512: mode = kStatusLinearLds; block = 512; break;
+        case kVariantLinearAhead: mode = kStatusLinearAhead; break;
+        // (byte status: the hand-written loop of frames without bounces; counting builds and the bounce kernels keep the words)
+        case kVariantBytes: mode = (counters || shade == 0) ? kStatusLinearAlways : kStatusBytes; break;
+        default: return nullptr;
+    }
+    const KernelEntry *e = nullptr;
+    if (shade == 2 && !counters) {
+        // the one-sample, no-bounce kernel (the headline's) is held to 72 VGPRs = 7 waves per SIMD (4 registers spilled outside the
+        // loops): on frames that keep the GPU full it is 1.5-2 % faster than at its natural 75 VGPRs = 6 waves, on a tail-bound
+        // frame (V1x) 4 % slower.  min_waves 4 asks for the natural build, 8 for the 64-VGPR one (development build).
+        e = find_trace_kernel(brick_dimension, false, mode, (mw == 0u || mw == 7u) ? 7 : (mw == 8u ? 8 : kDefaultMinWaves), 2, block);
+    } else if (shade == 0 && !counters) {
+        // frames with bounces: persistent lanes (vrt_path_kernel) unless the lockstep form is asked for (bit 21).
+        // (The lockstep bounce kernel takes 114 VGPRs = 4 waves per SIMD.  Its incoherent secondary rays wait on memory, and on a
+        // scene that does not stay in the caches more waves pay for the spills: 4K / 2048^3 sparse path trace, ms per frame V1 / V0
+        // at 4, 5, 6, 8 waves per SIMD: 83.7 / 283, 71.6 / 238, 66.1 / 219, 60.6 / 201.  On the 512^3 terrain the 8-wave build is
+        // 16 % SLOWER than the 4-wave one, so both exist and vrt_create asks for the 8-wave one by the size of bindings 3-5.)
+        if (mode == kStatusLinearAlways && !(variant & kVariantLockstepBounce)) {
+            // bit 22: behind the LDS block filter (development build); min_waves 5: 96 VGPRs
+            const bool filter = (variant & kVariantPathFilter) != 0u;
+            e = find_path_kernel(brick_dimension, mw == 5u ? 5 : ((mw == 6u && !filter) ? 6 : kDefaultMinWaves), filter, false);
+        } else {
+            e = find_trace_kernel(brick_dimension, false, mode, mw == 8u ? 8 : kDefaultMinWaves, 0, block);
+        }
+    } else {
+        // (the several-samples-per-pixel kernel, shade 1, needs 87 VGPRs left to itself = 5 waves per SIMD; held to 80 it spills
+        // 36 bytes outside the loops and runs at 6: 4K / 1024^3 / 4 rays per pixel 1.215 -> 1.183 ms per frame)
+        e = find_trace_kernel(brick_dimension, counters, mode, (shade == 1 && !counters) ? 6 : kDefaultMinWaves, shade, block);
+    }
+    return e ? e->fn : nullptr;
 }
 
 // bytes of dynamic LDS the variant needs for this grid
@@ -2619,28 +427,28 @@ size_t trace_lds_bytes(const TraceParams &p, uint32_t variant) {
     return 0;
 }
 
-static bool is_path_halfblock_kernel(KernelFn fn);
 bool is_path_kernel(KernelFn fn) {
-    return fn == (KernelFn)vrt_path_kernel<4, 4, false> || fn == (KernelFn)vrt_path_kernel<8, 4, false> || fn == (KernelFn)vrt_path_kernel<4, 5, false> ||
-           fn == (KernelFn)vrt_path_kernel<8, 5, false> || fn == (KernelFn)vrt_path_kernel<4, 4, true> || fn == (KernelFn)vrt_path_kernel<8, 4, true> ||
-           fn == (KernelFn)vrt_path_kernel<4, 5, true> || fn == (KernelFn)vrt_path_kernel<8, 5, true> || fn == (KernelFn)vrt_path_kernel<4, 6, false> ||
-           fn == (KernelFn)vrt_path_kernel<8, 6, false> || is_path_halfblock_kernel(fn);
+    const KernelEntry *e = kernel_entry_of(fn);
+    return e && e->path;
 }
 // the same kernel with the walk loop on half-block words (TraceParams::status_halfblocks); fn itself if it has none
 KernelFn path_kernel_halfblock_twin(KernelFn fn) {
-    if (fn == (KernelFn)vrt_path_kernel<4, 4, false>) return (KernelFn)vrt_path_kernel<4, 4, false, true>;
-    if (fn == (KernelFn)vrt_path_kernel<8, 4, false>) return (KernelFn)vrt_path_kernel<8, 4, false, true>;
-    if (fn == (KernelFn)vrt_path_kernel<4, 5, false>) return (KernelFn)vrt_path_kernel<4, 5, false, true>;
-    if (fn == (KernelFn)vrt_path_kernel<8, 5, false>) return (KernelFn)vrt_path_kernel<8, 5, false, true>;
-    return fn;
+    const KernelEntry *e = kernel_entry_of(fn);
+    if (!e || !e->path || e->filter || e->half) return fn;
+    const KernelEntry *t = find_path_kernel(e->b, e->min_waves, false, true);
+    return t ? t->fn : fn;
 }
-static bool is_path_halfblock_kernel(KernelFn fn) {
-    return fn == (KernelFn)vrt_path_kernel<4, 4, false, true> || fn == (KernelFn)vrt_path_kernel<8, 4, false, true> ||
-           fn == (KernelFn)vrt_path_kernel<4, 5, false, true> || fn == (KernelFn)vrt_path_kernel<8, 5, false, true>;
+bool is_path_halfblock_kernel(KernelFn fn) {
+    const KernelEntry *e = kernel_entry_of(fn);
+    return e && e->path && e->half;
 }
 static bool is_path_filter_kernel(KernelFn fn) {
-    return fn == (KernelFn)vrt_path_kernel<4, 4, true> || fn == (KernelFn)vrt_path_kernel<8, 4, true> || fn == (KernelFn)vrt_path_kernel<4, 5, true> ||
-           fn == (KernelFn)vrt_path_kernel<8, 5, true>;
+    const KernelEntry *e = kernel_entry_of(fn);
+    return e && e->path && e->filter;
+}
+const char *kernel_name_of(KernelFn fn) {
+    const KernelEntry *e = kernel_entry_of(fn);
+    return e ? e->name : "?";
 }
 
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream, uint32_t frames) {
@@ -2697,6 +505,7 @@ hipError_t launch_build_status_bytes(const TraceParams &p, hipStream_t stream) {
 }
 
 hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
+    if (!p.status_blocks) return hipSuccess;
     const uint32_t nblocks = p.nbx * p.nby * p.nbz;
     hipLaunchKernelGGL(vrt_build_status_blocks, dim3((nblocks + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
                        const_cast<uint2 *>(p.status_blocks), dim_x, dim_y, dim_z, p.nbx, p.nby, p.nbz);

@@ -233,6 +233,8 @@ class Config:  # VoxelRT.Config, VoxelRT.zig:22-28 (+ the knobs of this implemen
     stream: int = 0
     external_target_rgba8: int = 0
     external_target_rgba32f: int = 0
+    tuning_flags: int = 0      # VRT_TUNE_* (include/vrt_hip.h): A/B switches, every setting renders the same frame
+    library: Optional[str] = None  # path of another build of libvrt_hip (reflow / dev twins); None: the product library
 
 
 class VoxelRT:
@@ -265,17 +267,21 @@ class VoxelRT:
         cfg.external_target_rgba8 = config.external_target_rgba8 or None
         cfg.external_target_rgba32f = config.external_target_rgba32f or None
         h = C.c_void_p()
-        check(lib.vrt_create(C.byref(cfg), C.byref(h)))
+        self._check(self._lib.vrt_create(C.byref(cfg), C.byref(h)))
         self._h = h
         self.width, self.height = cfg.width, cfg.height
         if upload_grid:
-            check(lib.vrt_upload_grid(self._h, brick_grid._h), self._h)  # VoxelRT.zig:62 (+ first full delta)
+            check(self._lib.vrt_upload_grid(self._h, brick_grid._h))  # VoxelRT.zig:62 (+ first full delta)
 
     init = classmethod(lambda cls, *a, **k: cls(*a, **k))
 
+    def _check(self, rc: int) -> None:
+        if rc != L.VRT_OK:
+            raise L.VrtError(rc, (self._lib.vrt_last_error(self._h) or b"").decode())
+
     def deinit(self) -> None:
         if getattr(self, "_h", None):
-            lib.vrt_destroy(self._h)
+            self._lib.vrt_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -287,50 +293,50 @@ class VoxelRT:
     # -- uploads ------------------------------------------------------------
     def push_materials(self, materials: np.ndarray) -> None:  # VoxelRT.zig:85-87
         materials = np.ascontiguousarray(materials)
-        check(lib.vrt_upload(self._h, L.BUF_MATERIALS, 0, materials.ctypes.data, materials.nbytes), self._h)
+        self._check(self._lib.vrt_upload(self._h, L.BUF_MATERIALS, 0, materials.ctypes.data, materials.nbytes))
 
     def update_grid_delta(self) -> None:  # VoxelRT.zig:107-172
-        check(lib.vrt_update_grid_delta(self._h, self.brick_grid._h), self._h)
+        self._check(self._lib.vrt_update_grid_delta(self._h, self.brick_grid._h))
 
     def upload(self, buf_id: int, byte_offset: int, data: np.ndarray) -> None:  # Pipeline.transfer*, Pipeline.zig:560-652
         data = np.ascontiguousarray(data)
-        check(lib.vrt_upload(self._h, buf_id, byte_offset, data.ctypes.data, data.nbytes), self._h)
+        self._check(self._lib.vrt_upload(self._h, buf_id, byte_offset, data.ctypes.data, data.nbytes))
 
     def buffer_size(self, buf_id: int) -> int:
-        return lib.vrt_buffer_size(self._h, buf_id)
+        return self._lib.vrt_buffer_size(self._h, buf_id)
 
     # -- frame --------------------------------------------------------------
     def draw(self, frames: int = 1) -> None:  # VoxelRT.draw -> Pipeline.draw -> compute dispatch (Pipeline.zig:441)
         if frames == 1:
-            check(lib.vrt_dispatch(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data)), self._h)
+            self._check(self._lib.vrt_dispatch(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data)))
         else:
-            check(lib.vrt_dispatch_repeat(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data), frames), self._h)
+            self._check(self._lib.vrt_dispatch_repeat(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data), frames))
 
     def draw_timed(self, frames: int) -> np.ndarray:
         """`frames` frames one after another on the primary stream; returns the hipEvent time of each in ms."""
         ms = np.zeros(frames, dtype=np.float32)
-        check(lib.vrt_dispatch_timed(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data), frames,
-                                     ms.ctypes.data_as(C.POINTER(C.c_float))), self._h)
+        self._check(self._lib.vrt_dispatch_timed(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data), frames,
+                                     ms.ctypes.data_as(C.POINTER(C.c_float))))
         return ms
 
     def wait(self) -> None:
-        check(lib.vrt_wait(self._h), self._h)
+        self._check(self._lib.vrt_wait(self._h))
 
     def last_kernel_ms(self) -> float:
-        return lib.vrt_last_kernel_ms(self._h)
+        return self._lib.vrt_last_kernel_ms(self._h)
 
     def shard_info(self) -> L.ShardInfo:
         s = L.ShardInfo()
-        check(lib.vrt_get_shard_info(self._h, C.byref(s)), self._h)
+        self._check(self._lib.vrt_get_shard_info(self._h, C.byref(s)))
         return s
 
     def target_bytes_rgba8(self) -> int:
-        return lib.vrt_target_bytes_rgba8(self._h)
+        return self._lib.vrt_target_bytes_rgba8(self._h)
 
     def read_rgba8(self) -> np.ndarray:
         n = self.target_bytes_rgba8()
         out = np.empty(n, dtype=np.uint8)
-        check(lib.vrt_read_rgba8(self._h, out.ctypes.data, n), self._h)
+        self._check(self._lib.vrt_read_rgba8(self._h, out.ctypes.data, n))
         if self.config.shard_count <= 1:
             return out.reshape(self.height, self.width, 4)
         return out.reshape(-1, 16, 16, 4)
@@ -338,36 +344,36 @@ class VoxelRT:
     def read_rgba32f(self) -> np.ndarray:
         n = self.target_bytes_rgba8() * 4
         out = np.empty(n // 4, dtype=np.float32)
-        check(lib.vrt_read_rgba32f(self._h, out.ctypes.data, n), self._h)
+        self._check(self._lib.vrt_read_rgba32f(self._h, out.ctypes.data, n))
         if self.config.shard_count <= 1:
             return out.reshape(self.height, self.width, 4)
         return out.reshape(-1, 16, 16, 4)
 
     def set_target(self, rgba8_ptr: int, rgba32f_ptr: int = 0) -> None:
-        check(lib.vrt_set_target(self._h, rgba8_ptr, rgba32f_ptr or None), self._h)
+        self._check(self._lib.vrt_set_target(self._h, rgba8_ptr, rgba32f_ptr or None))
 
     def denoise(self, out_w: int, out_h: int, *, samples: int = 20, distribution_bias: float = 0.6, pixel_multiplier: float = 1.5,
                 inverse_hue_tolerance: float = 20.0, want_float: bool = False):
         """The present/denoise pass (image.frag) over the most recent frame; returns rgba8 (and rgba32f)."""
         dc = L.DenoiseConfig(samples, distribution_bias, pixel_multiplier, inverse_hue_tolerance)
-        check(lib.vrt_denoise(self._h, C.byref(dc), out_w, out_h, 1 if want_float else 0), self._h)
+        self._check(self._lib.vrt_denoise(self._h, C.byref(dc), out_w, out_h, 1 if want_float else 0))
         u8 = np.empty((out_h, out_w, 4), dtype=np.uint8)
-        check(lib.vrt_read_denoised_rgba8(self._h, u8.ctypes.data, u8.nbytes), self._h)
+        self._check(self._lib.vrt_read_denoised_rgba8(self._h, u8.ctypes.data, u8.nbytes))
         if not want_float:
             return u8
         f32 = np.empty((out_h, out_w, 4), dtype=np.float32)
-        check(lib.vrt_read_denoised_rgba32f(self._h, f32.ctypes.data, f32.nbytes), self._h)
+        self._check(self._lib.vrt_read_denoised_rgba32f(self._h, f32.ctypes.data, f32.nbytes))
         return u8, f32
 
     def device_target_rgba8(self) -> int:
-        return lib.vrt_device_target_rgba8(self._h)
+        return self._lib.vrt_device_target_rgba8(self._h)
 
     def assemble_frame(self, gathered_ptr: int, dst_ptr: int, bytes_per_pixel: int = 4) -> None:
-        check(lib.vrt_assemble_frame(self._h, gathered_ptr, dst_ptr, bytes_per_pixel), self._h)
+        self._check(self._lib.vrt_assemble_frame(self._h, gathered_ptr, dst_ptr, bytes_per_pixel))
 
     def counters(self) -> dict:
         c = L.Counters()
-        check(lib.vrt_get_counters(self._h, C.byref(c)), self._h)
+        self._check(self._lib.vrt_get_counters(self._h, C.byref(c)))
         return {k: getattr(c, k) for k, _ in L.Counters._fields_}
 
     def wave_timeline(self, raw: bool = False) -> np.ndarray:
@@ -376,14 +382,14 @@ class VoxelRT:
         n = (self.shard_info().owned_tiles + 1024) * 4
         out = np.zeros((n, 2), dtype=np.uint64)
         got = C.c_uint64()
-        check(lib.vrt_trace_wave_timeline(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data), out.ctypes.data, n,
-                                          C.byref(got)), self._h)
+        self._check(self._lib.vrt_trace_wave_timeline(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data), out.ctypes.data, n,
+                                          C.byref(got)))
         out = out[:got.value]
         return out if raw else out[out[:, 1] != 0]
 
     def wave_counters(self) -> dict:
         out = (C.c_uint64 * 3)()
-        check(lib.vrt_get_wave_counters(self._h, C.byref(out)), self._h)
+        self._check(self._lib.vrt_get_wave_counters(self._h, C.byref(out)))
         return {"wave_grid_iters": out[0], "wave_brick_walks": out[1], "wave_voxel_iters": out[2]}
 
     # -- multi-GPU frame pipeline (native RCCL; see include/vrt_hip.h vrt_dist_*) --------------------
@@ -400,28 +406,28 @@ class VoxelRT:
         a single-process stand-in)."""
         assert len(unique_id) == 128
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
-        check(lib.vrt_dist_init_batched(self._h, (rccl_path or L.rccl_library_path()).encode(), buf, rank, world, frames_in_flight,
-                                        frames_per_launch), self._h)
+        self._check(self._lib.vrt_dist_init_batched(self._h, (rccl_path or L.rccl_library_path()).encode(), buf, rank, world, frames_in_flight,
+                                        frames_per_launch))
 
     def dist_frame(self) -> None:
-        check(lib.vrt_dist_frame(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data)), self._h)
+        self._check(self._lib.vrt_dist_frame(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data)))
 
     def dist_wait(self) -> None:
-        check(lib.vrt_dist_wait(self._h), self._h)
+        self._check(self._lib.vrt_dist_wait(self._h))
 
     def dist_read_frame(self) -> np.ndarray:
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)
-        check(lib.vrt_dist_read_frame(self._h, out.ctypes.data, out.nbytes), self._h)
+        self._check(self._lib.vrt_dist_read_frame(self._h, out.ctypes.data, out.nbytes))
         return out
 
     def dist_info(self) -> dict:
         """rank / world as the RCCL communicator reports them, frames per launch, launches in flight."""
         out = (C.c_int32 * 4)()
-        check(lib.vrt_dist_info(self._h, out), self._h)
+        self._check(self._lib.vrt_dist_info(self._h, out))
         return {"rank": out[0], "world": out[1], "frames_per_launch": out[2], "launches_in_flight": out[3]}
 
     def dist_selftest(self) -> None:
-        check(lib.vrt_dist_selftest(self._h), self._h)
+        self._check(self._lib.vrt_dist_selftest(self._h))
 
     # element sizes of the five buffers BrickGrid tracks deltas for (Grid.zig:129-194)
     _DELTA_BUFFERS = ((L.BUF_BRICK_STATUS, 4), (L.BUF_BRICK_INDEX, 4), (L.BUF_BRICK_OCCUPANCY, 1), (L.BUF_BRICK_START_INDEX, 4),
@@ -429,7 +435,7 @@ class VoxelRT:
 
     def dist_broadcast(self, buf_id: int, byte_offset: int, nbytes: int, root: int = 0) -> None:
         """Collective: the byte range of scene buffer `buf_id` on every rank becomes rank `root`'s (vrt_dist_broadcast)."""
-        check(lib.vrt_dist_broadcast(self._h, buf_id, byte_offset, nbytes, root), self._h)
+        self._check(self._lib.vrt_dist_broadcast(self._h, buf_id, byte_offset, nbytes, root))
 
     def grid_delta_ranges(self) -> list:
         """[(buffer id, byte offset, bytes)] of this host's dirty ranges (what update_grid_delta is about to upload)."""
@@ -459,4 +465,4 @@ class VoxelRT:
         return Benchmark(self.camera)
 
     def kernel_name(self) -> str:
-        return lib.vrt_kernel_name(self._h).decode()
+        return self._lib.vrt_kernel_name(self._h).decode()

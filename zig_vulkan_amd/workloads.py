@@ -25,6 +25,7 @@ class Workload:
     scene: str = "terrain"  # "terrain" | "sparse"
     sparse_p: float = 0.0
     brick_alloc: int = 0   # 0 => dense allocation (every brick slot, Grid.zig:51)
+    dims: Tuple[int, int, int] | None = None   # bricks per axis when the grid is not cubic (None: voxels / brick_dimension each)
 
 
 # BASELINE.json configs[0..4]
@@ -45,6 +46,9 @@ WORKLOADS: Dict[str, Workload] = {
     # not a BASELINE config: the shape of the reference app's own default run (src/main.zig:23,77-81,122-135: 1024x576 internal
     # resolution, 2 samples, max_bounce 2, sun on, 4^3 bricks), on the cubic synthetic terrain
     "refapp_1024x576_512c_b4": Workload("refapp_1024x576_512c_b4", 1024, 576, 512, 4, 2, 2, True, 5.0),
+    # the reference app's own default run, grid shape included (src/main.zig:77-81: 128 x 64 x 128 bricks of 4^3, min point
+    # (-32, -16, -32), scale 0.5; :23,122-135: 1024x576, 2 samples, max_bounce 2, sun on): the workload a user of the reference sees
+    "refapp_1024x576_128x64x128_b4": Workload("refapp_1024x576_128x64x128_b4", 1024, 576, 512, 4, 2, 2, True, 5.0, dims=(128, 64, 128)),
 }
 
 HEADLINE = "cfg2_1080p_512c_b8"
@@ -66,7 +70,8 @@ def build_grid(w: Workload) -> BrickGrid:
     n = w.voxels // w.brick_dimension
     # world box 64 units wide like the reference default scene (src/main.zig:77-81)
     scale = 64.0 / n
-    grid = BrickGrid(n, n, n, min_point=(-32.0, -32.0, -32.0), scale=scale, brick_dimension=w.brick_dimension,
+    dx, dy, dz = w.dims or (n, n, n)
+    grid = BrickGrid(dx, dy, dz, min_point=(-32.0, -32.0 * dy / dx, -32.0 * dz / dx), scale=scale, brick_dimension=w.brick_dimension,
                      brick_alloc=w.brick_alloc or None)
     if w.scene == "terrain":
         grid.synth_terrain(SEED)
