@@ -91,11 +91,14 @@ def cpu_baseline_port(w, grid, min_wall_s: float, per_view):
                       f"= {dt * cores:.0f} core-seconds; oracle/vrt_oracle.c gcc -O2, {cores} threads, rows handed out one at a time"}
 
 
-def cpu_baseline_reference(w, grid, min_wall_s: float, per_view):
+def cpu_baseline_reference(w, grid, min_wall_s: float, per_view, hip_frames=None):
     """The reference's own shader (brick_raytracer.comp) compiled by Mesa and run by llvmpipe on this box's host cores
     (oracle/_ref; north_star's "reference under lavapipe": same gallivm back end, OpenGL instead of Vulkan front end).
     Scene buffers are uploaded once; each frame pushes the 128 constant bytes and dispatches ceil(W/32) x ceil(H/32)
-    workgroups, timed to glFinish.  Returns (dict, None) or (None, reason)."""
+    workgroups, timed to glFinish.  Returns (dict, parity, None) or (None, None, reason).
+    hip_frames: {"product": {view: (f32, u8)}, "reflow": {...}} — frames libvrt_hip rendered for the same 128 push-constant
+    bytes; one reference frame per view is then read back (untimed) and compared pixel by pixel: the on-box parity
+    certificate (`parity_vs_reference`)."""
     try:
         from oracle import oracle as O
         from oracle import ref_gl
@@ -104,14 +107,32 @@ def cpu_baseline_reference(w, grid, min_wall_s: float, per_view):
         reason = ref_gl.available()
         if reason is not None:
             return None, reason
-        ref = ref_gl.ReferenceShader(w.brick_dimension, want_float=False)
+        ref = ref_gl.ReferenceShader(w.brick_dimension, want_float=bool(hip_frames))
         scene = oracle_scene_from_grid(grid)
         pcs = [O.push_constants(W.camera_for(w, v).blob(), W.sun_for(w).blob()) for v in VIEW_ORDER]
         try:
             ref.bind(scene, pcs[0])
         except ref_gl.GlRefUnavailable as e:   # a storage block above GL_MAX_SHADER_STORAGE_BLOCK_SIZE (128 MiB)
-            return None, str(e)
+            return None, None, str(e)
         ref.frame(pcs[0])  # untimed: JIT of the compute variant, page faults
+        parity = None
+        if hip_frames:
+            import numpy as np
+            parity = {"against": "frames of assets/shaders/brick_raytracer.comp (reference) run under Mesa llvmpipe on this box, same 128 push-constant "
+                                 "bytes, same scene buffers; float colour (rgba32f build of the shader) and its Rgba8 image",
+                      "views": list(VIEW_ORDER), "pixels_per_view": w.width * w.height, "tolerance": 1e-4}
+            for build in hip_frames:
+                parity[build] = {"pixels_over_1e-4": {}, "max_abs_err": {}, "pixels_not_bit_equal": {}, "rgba8_pixels_differing": {}}
+            for i, v in enumerate(VIEW_ORDER):
+                rf = ref.frame(pcs[i], read=True, want_float=True)     # untimed
+                ru = ref.frame(pcs[i], read=True)
+                for build, frames in hip_frames.items():
+                    hf, hu = frames[v]
+                    d = np.abs(hf[:, :, :3] - rf[:, :, :3]).max(axis=2)
+                    parity[build]["pixels_over_1e-4"][v] = int((d > 1e-4).sum())
+                    parity[build]["max_abs_err"][v] = float(d.max())
+                    parity[build]["pixels_not_bit_equal"][v] = int((hf.view(np.uint32) != rf.view(np.uint32)).any(axis=2).sum())
+                    parity[build]["rgba8_pixels_differing"][v] = int((hu != ru).any(axis=2).sum())
         t0 = time.perf_counter()
         frames = 0
         rays = 0
@@ -127,9 +148,36 @@ def cpu_baseline_reference(w, grid, min_wall_s: float, per_view):
         return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "reference",
                 "sample": f"{frames} whole frames of {w.name} (views {'/'.join(VIEW_ORDER)} cycled), {rays} rays in {dt:.2f} s wall; "
                           f"assets/shaders/brick_raytracer.comp of the reference as Mesa program binary (oracle/_ref), {info}, "
-                          f"{threads} llvmpipe worker threads (Mesa's cap) on a {os.cpu_count()}-core host"}, None
+                          f"{threads} llvmpipe worker threads (Mesa's cap) on a {os.cpu_count()}-core host"}, parity, None
     except Exception as e:  # noqa: BLE001 - a baseline must never take the bench down
-        return None, f"{type(e).__name__}: {e}"
+        return None, None, f"{type(e).__name__}: {e}"
+
+
+def hbm_achievable(dev):
+    """What this box's HBM delivers to plain streaming kernels ("report that achievable figure too"): a
+    device-to-device copy (read + write) and a read-only reduction over 2 GiB buffers, far beyond L2 + MALL, by events."""
+    import torch
+    n = 2 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev).fill_(1)
+    b = torch.empty_like(a)
+
+    def timed(fn, reps=6):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    copy = 2 * n / timed(lambda: b.copy_(a)) / 1e9
+    af = a.view(torch.float32)
+    read = n / timed(lambda: af.sum()) / 1e9
+    del a, b, af
+    torch.cuda.empty_cache()
+    return {"copy_read_plus_write_GBps": copy, "read_only_GBps": read, "method": "torch copy_ / sum over 2 GiB, 6 repetitions, torch.cuda.Event"}
 
 
 # ------------------------------------------------------------------------------------------------ PMC (rocprofv3)
@@ -240,18 +288,21 @@ def ensure_ranks(args, argv) -> None:
 
 class _StubRT:
     """TEST ONLY (`--stub`, tests/test_bench_plumbing.py): stands in for the renderer so that the rank plumbing —
-    environment, process group, broadcasts, the native/torch agreement, max-over-ranks timing, the one JSON line —
-    runs at world size 2 over gloo on a box without GPUs.  Renders nothing."""
+    environment, process group, broadcasts, the native/torch agreement, the root-share auto-tune and its agreement across
+    ranks, the two timed legs, max-over-ranks timing, the one JSON line — runs at world size 2 over gloo on a box without
+    GPUs.  Renders nothing; a frame "takes" a time that depends on the root share so that the tuner has something to choose."""
 
-    def __init__(self, fail_native: bool):
+    def __init__(self, fail_native: bool, root_share: int = 100, batch: int = 1):
         import types
         self.fail_native = fail_native
         self.camera = types.SimpleNamespace(d_camera=(bytearray(96)))
         self.frames = 0
+        self.batch = batch
+        self.frame_s = 0.0004 * (1.0 + abs(root_share - 60) / 100.0) / (1.0 + 0.25 * (batch > 1))
 
     def draw(self, frames: int = 1):
         self.frames += frames
-        time.sleep(0.0005 * frames)
+        time.sleep(self.frame_s * frames)
 
     def dist_init(self, *a, **k):
         if self.fail_native:
@@ -261,13 +312,21 @@ class _StubRT:
         self.draw()
 
     def dist_info(self):
-        return {"rank": int(os.environ.get("RANK", "0")), "world": int(os.environ.get("WORLD_SIZE", "1")), "frames_per_launch": 1,
+        return {"rank": int(os.environ.get("RANK", "0")), "world": int(os.environ.get("WORLD_SIZE", "1")), "frames_per_launch": self.batch,
                 "launches_in_flight": 1}
+
+    def dist_stats(self):
+        return {"launches_sampled": 4, "frames_sampled": 4 * self.batch, "kernel_ms_per_launch": self.frame_s * 1e3 * self.batch,
+                "collective_ms_per_launch": 0.01, "unswizzle_ms_per_launch": 0.005, "owned_tiles": 10, "shard_bytes_per_frame": 7680,
+                "frames_per_launch": self.batch}
 
     def set_target(self, *a):
         pass
 
     def assemble_frame(self, *a):
+        pass
+
+    def dist_profile(self, *a):
         pass
 
     def kernel_name(self):
@@ -284,6 +343,284 @@ def percentiles(ms):
     a = np.sort(np.asarray(ms, dtype=np.float64))
     return {"median": float(np.percentile(a, 50)), "p10": float(np.percentile(a, 10)), "p90": float(np.percentile(a, 90)),
             "mean": float(a.mean()), "n": int(a.size)}
+
+
+def default_root_share(world: int) -> int:
+    """Rank 0's share of the tiles in percent of an equal share, before tuning: 100 at 2 ranks ... 30 at 8 (the root also takes
+    in every other rank's shards and un-swizzles every frame; one-GPU emulation of both sides, tools/root_share_sweep.sh)."""
+    return max(30, 100 - (70 * max(0, world - 2) + 3) // 6)
+
+
+def root_share_candidates(world: int):
+    """The three shares the warm-up auto-tune times (two at 2 ranks): the emulated default, 0.6 x it and 1.5 x it."""
+    t = default_root_share(world)
+    return sorted({t, max(10, int(round(t * 0.6))), min(100, int(round(t * 1.5)))})
+
+
+def count_rays(W, w, grid, views, variant, device_id):
+    """Rays and bytes per view by the counting builds of the kernel (untimed): mode 1 the reference algorithm's loads, mode 2
+    what the product kernel requests."""
+    per_view = {}
+    pixels = w.width * w.height
+    for mode, key in ((1, "counters"), (2, "issued")):
+        rtc = W.make_renderer(w, grid, enable_counters=mode, device_id=device_id, kernel_variant=variant)
+        for v in views:
+            W.set_view(rtc, v)
+            rtc.draw()
+            c = rtc.counters()
+            pv = per_view.setdefault(v, {})
+            pv[key] = c
+            if mode == 1:
+                # SURVEY.md §8(d): the loads of the REFERENCE algorithm (per-lane word cache, walk to the grid's face)
+                pv["rays"] = c["rays"]
+                pv["bytes"] = 4 * c["status_loads"] + 4 * c["bricks_entered"] + c["voxel_steps"] + 25 * c["hits"] + 4 * pixels
+                primaries = pixels * w.spp
+                if w.max_bounce == 0:
+                    ph = (c["rays"] - primaries) if w.sun_enabled else c["hits"]
+                    pv["primary_hit_fraction"] = ph / primaries
+                else:
+                    pv["primary_hit_fraction"] = None
+            else:
+                # what the PRODUCT kernel requests (DESIGN.md §4): a status dword per brick-level trip of a walk that ends at
+                # the occupied-cell box; per brick entered the index, the start index and the first occupancy dword; an
+                # occupancy dword per voxel trip; per hit the material id and the 20-byte material; the pixel store
+                pv["issued_bytes"] = (4 * c["grid_steps"] + 12 * c["bricks_entered"] + 4 * c["voxel_steps"] + 21 * c["hits"] + 4 * pixels)
+        rtc.deinit()
+    return per_view
+
+
+def view_of(i: int, n: int) -> str:
+    # frames of one view are consecutive (a camera moves smoothly; the tile schedule feeds on the previous frames)
+    return VIEW_ORDER[min(len(VIEW_ORDER) - 1, (i * len(VIEW_ORDER)) // max(n, 1))]
+
+
+class Env:
+    """What every leg needs to know about this process."""
+
+    def __init__(self, args, torch, dist, world, rank, local_rank, dev, stub, use_dist):
+        self.args, self.torch, self.dist = args, torch, dist
+        self.world, self.rank, self.local_rank, self.dev, self.stub, self.use_dist = world, rank, local_rank, dev, stub, use_dist
+        self.multi = use_dist and world > 1
+
+    def sync(self) -> None:
+        if not self.stub:
+            self.torch.cuda.synchronize()
+
+    def barrier(self) -> None:
+        if self.multi:
+            self.dist.barrier()
+        self.sync()
+
+    def all_max(self, x: float) -> float:
+        if not self.multi:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_min_int(self, x: int) -> int:
+        if not self.multi:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.int32, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item())
+
+    def bcast(self, obj):
+        if not self.multi:
+            return obj
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def gather_objects(self, obj):
+        if not self.multi:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+
+class Leg:
+    """One renderer configuration that can be stepped and timed: the single-GPU context, or one (frames per collective, root
+    share) setting of the multi-GPU pipeline (native RCCL inside libvrt_hip.so, or the torch.distributed fallback)."""
+
+    def __init__(self, env: Env, W, w, grid, *, sharded: bool, want_native: bool, batch: int = 1, root_share: int = 100, frames_in_flight: int = 2):
+        import ctypes as C
+        self.env, self.W, self.w, self.sharded, self.batch, self.root_share = env, W, w, sharded, batch, root_share
+        self.native, self.fg, self.rt, self.dist_info, self.rccl_world = False, None, None, None, None
+        self.frame_no = 0
+        args, stub, rank, world = env.args, env.stub, env.rank, env.world
+        if sharded and want_native:
+            # RCCL inside libvrt_hip.so: kernel -> grouped send/recv to rank 0 -> un-swizzle, several launches in flight
+            ok = 1
+            try:
+                if stub:
+                    uid = b"stub"
+                    self.rt = _StubRT(fail_native=(rank == args.stub_fail_native_on), root_share=root_share, batch=batch)
+                else:
+                    from zig_vulkan_amd import VoxelRT
+                    uid = VoxelRT.dist_unique_id() if rank == 0 else None
+                uid = env.bcast(uid)
+                if not stub:
+                    self.rt = W.make_renderer(w, grid, device_id=env.local_rank, shard_rank=rank, shard_count=world, kernel_variant=args.variant,
+                                              shard_root_weight=(root_share if (2 <= world <= 8 and root_share < 100) else 0))
+                self.rt.dist_init(uid, rank, world, args.dist_frames, frames_per_launch=(batch if world > 1 else 1))
+                if world == 1:
+                    self.rt.dist_selftest()
+                self.dist_info = self.rt.dist_info()
+            except Exception as e:  # noqa: BLE001 - any failure means "use the torch path"
+                print(f"[bench rank {rank}] native RCCL pipeline unavailable: {e}", file=sys.stderr)
+                ok = 0
+            ok = env.all_min_int(ok)          # every rank must take the same path
+            self.native = bool(ok)
+            if not self.native and self.rt is not None:
+                self.rt.deinit()
+                self.rt = None
+        if sharded and not self.native:
+            from zig_vulkan_amd.dist import FrameGather
+            self.batch, self.root_share = 1, 100
+            self.fg = FrameGather(w.width, w.height, rank, world, env.dev)
+            if stub:
+                self.rt = _StubRT(False)
+            else:
+                stream = env.torch.cuda.current_stream().cuda_stream
+                self.rt = W.make_renderer(w, grid, device_id=env.local_rank, shard_rank=rank, shard_count=world, stream=stream,
+                                          external_target_rgba8=self.fg.shard.data_ptr(), kernel_variant=args.variant)
+        elif not sharded:
+            self.rt = _StubRT(False) if stub else W.make_renderer(w, grid, device_id=env.local_rank, kernel_variant=args.variant,
+                                                                  frames_in_flight=frames_in_flight)
+        # the communicator's own idea of its size, from every rank
+        if self.native and self.dist_info is not None:
+            self.rccl_world = env.all_min_int(self.dist_info["world"])
+            if self.rccl_world != world:
+                raise SystemExit(f"bench.py: the RCCL communicator spans {self.rccl_world} ranks, {world} were launched")
+        if self.native:
+            self.rt.dist_wait()
+        else:
+            self.rt.wait()
+        self.cams = {}
+        if not stub:
+            for v in VIEW_ORDER + EXTRA_VIEWS:
+                W.set_view(self.rt, v)
+                self.cams[v] = bytes(self.rt.camera.d_camera)
+        self._C = C
+
+    def set_cam(self, v: str) -> None:
+        if not self.env.stub:
+            self._C.memmove(self._C.byref(self.rt.camera.d_camera), self.cams[v], 96)
+
+    def step(self, i: int, n: int) -> None:
+        self.set_cam(view_of(i, n))
+        if not self.sharded:
+            self.rt.draw()
+            return
+        if self.native:
+            self.rt.dist_frame()                     # kernel -> RCCL gather -> un-swizzle, on this launch's stream
+            return
+        f = self.frame_no
+        self.frame_no += 1
+        self.fg.begin_frame(f)                       # buffer f%2 is free once frame f-2's gather is done
+        self.rt.set_target(self.fg.shard_for(f).data_ptr())
+        self.rt.draw()                               # this rank's tiles of frame f
+        self.fg.gather_async(f)                      # ONE collective per frame, overlapped with frame f+1's kernel
+        if f >= 1:
+            self.fg.complete(f - 1, None if self.env.stub else self.rt)   # rank 0: un-swizzle the previous frame
+
+    def drain(self) -> None:
+        if self.native:
+            self.rt.dist_wait()
+        elif self.sharded and self.frame_no >= 1:
+            self.fg.complete(self.frame_no - 1, None if self.env.stub else self.rt)
+
+    def run(self, n: int) -> None:
+        """n untimed frames."""
+        for i in range(n):
+            self.step(i, n)
+        self.drain()
+
+    def timed(self, n: int) -> float:
+        """EXACTLY n steps between barrier + synchronize on both sides; the maximum over ranks."""
+        env = self.env
+        env.barrier()
+        t0 = time.perf_counter()
+        for i in range(n):
+            self.step(i, n)
+        self.drain()  # the last frame's gather + un-swizzle belong to the timed region
+        if not self.native:
+            self.rt.wait()
+        env.barrier()
+        return env.all_max(time.perf_counter() - t0)
+
+    def estimate_frame_ms(self) -> float:
+        env = self.env
+        env.barrier()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            self.step(2, 3)
+        self.drain()
+        if not self.native:
+            self.rt.wait()
+        env.sync()
+        return env.all_max(max((time.perf_counter() - t0) / 2 * 1e3, 1e-3))   # every rank must choose the same step count
+
+    def breakdown(self, launches: int):
+        """Per-rank stage times of the native pipeline (events on each launch's stream, vrt_dist_profile), after the timed region:
+        kernel / this rank's part of the collective / root un-swizzle, in us per frame; every rank's row and the maxima."""
+        if not (self.native and self.sharded):
+            return None
+        self.rt.dist_profile(True)
+        n = max(1, launches) * max(1, self.batch if self.env.world > 1 else 1)
+        for i in range(n):
+            self.step(i, n)
+        self.rt.dist_wait()
+        st = self.rt.dist_stats()
+        self.rt.dist_profile(False)
+        fpl = max(1, st["frames_per_launch"] if self.env.world > 1 else 1)
+        row = {"rank": self.env.rank, "owned_tiles": st["owned_tiles"], "launches_sampled": st["launches_sampled"],
+               "kernel_us_per_frame": st["kernel_ms_per_launch"] * 1e3 / fpl,
+               "collective_us_per_frame": st["collective_ms_per_launch"] * 1e3 / fpl,
+               "unswizzle_us_per_frame": st["unswizzle_ms_per_launch"] * 1e3 / fpl,
+               "shard_bytes_per_frame": st["shard_bytes_per_frame"]}
+        rows = self.env.gather_objects(row)
+        peers = [r for r in rows if r["rank"] != 0] or rows
+        return {"per_rank": rows,
+                "max_over_ranks": {k: max(r[k] for r in rows) for k in ("kernel_us_per_frame", "collective_us_per_frame", "unswizzle_us_per_frame")},
+                "root": {k: rows[0][k] for k in ("kernel_us_per_frame", "collective_us_per_frame", "unswizzle_us_per_frame", "owned_tiles")},
+                "peers_max_kernel_us_per_frame": max(r["kernel_us_per_frame"] for r in peers),
+                "note": "events on each launch's own stream after the timed region (vrt_dist_profile); collective = the grouped receives on rank 0, "
+                        "the send elsewhere, waiting for the other side included"}
+
+    def close(self) -> None:
+        if self.rt is not None:
+            self.rt.deinit()
+            self.rt = None
+
+
+def tuned_leg(env: Env, W, w, grid, batch: int, want_native: bool):
+    """The multi-GPU leg with rank 0's tile share chosen by a warm-up auto-tune: each candidate share gets its own context and
+    communicator, 8 untimed + 32 timed frames (maximum over ranks, so every rank sees the same numbers and picks the same
+    winner); the winner's context is kept, the others are destroyed.  --root-share N (>= 0) skips the tune."""
+    args, world = env.args, env.world
+    if args.root_share >= 0 or not (2 <= world <= 8) or not want_native:
+        share = args.root_share if args.root_share >= 0 else 100
+        return Leg(env, W, w, grid, sharded=True, want_native=want_native, batch=batch, root_share=share), {"tuned": False, "root_share": share}
+    legs, ms = {}, {}
+    for share in root_share_candidates(world):
+        leg = Leg(env, W, w, grid, sharded=True, want_native=True, batch=batch, root_share=share)
+        if not leg.native:     # every rank fell back to the torch path together: nothing to tune
+            for other in legs.values():
+                other.close()
+            return leg, {"tuned": False, "root_share": 100}
+        leg.run(max(8, batch))
+        ms[share] = leg.timed(32) / 32 * 1e3
+        legs[share] = leg
+    best = min(sorted(ms), key=lambda k: ms[k])
+    best = env.bcast(best)   # (identical on every rank already — the times are maxima over ranks — but a broadcast costs nothing)
+    for share, leg in legs.items():
+        if share != best:
+            leg.close()
+    return legs[best], {"tuned": True, "root_share": best, "candidates_ms_per_frame": {str(k): ms[k] for k in sorted(ms)},
+                        "method": "per candidate: own context + communicator, 8 untimed + 32 timed frames, max over ranks"}
 
 
 def main(argv=None) -> None:
@@ -307,11 +644,12 @@ def main(argv=None) -> None:
                     help="N>1 frame gather: native = RCCL send/recv inside libvrt_hip.so (pipelined); torch = torch.distributed.gather (fallback)")
     ap.add_argument("--dist-frames", type=int, default=4, help="launches in flight per rank of the native multi-GPU pipeline")
     ap.add_argument("--dist-batch", type=int, default=8,
-                    help="frames traced by one launch and carried by one collective when world > 1 (every frame is gathered once; "
-                         "1 = one collective per frame)")
+                    help="frames traced by one launch and carried by one collective in the batched leg when world > 1 (every frame is gathered "
+                         "once); the north_star-literal leg, one collective per frame, is always timed as well")
     ap.add_argument("--root-share", type=int, default=-1,
-                    help="native multi-GPU pipeline: rank 0's share of the tiles in percent of an equal share; -1: 100 - 70 (world - 2) / 6 "
-                         "(100 % at 2 ranks ... 30 % at 8: one-GPU emulation of root and peers, tools/root_share_sweep.sh)")
+                    help="native multi-GPU pipeline: rank 0's share of the tiles in percent of an equal share; -1: chosen per leg by a warm-up "
+                         "auto-tune over three candidates around 100 - 70 (world - 2) / 6")
+    ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the secondary leg on BASELINE's sharded config (4K, 1024^3)")
     ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)            # tests/test_bench_plumbing.py
     ap.add_argument("--stub-fail-native-on", type=int, default=-1, help=argparse.SUPPRESS)
@@ -329,7 +667,7 @@ def main(argv=None) -> None:
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
 
@@ -351,14 +689,11 @@ def main(argv=None) -> None:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-
-    def sync() -> None:
-        if not stub:
-            torch.cuda.synchronize()
+    env = Env(args, torch, dist, world, rank, local_rank, dev, stub, use_dist)
 
     # every rank announces itself: rank 0 reports who took part
     ranks_seen = [rank]
-    if use_dist and world > 1:
+    if env.multi:
         t = torch.zeros(world, dtype=torch.int32, device=dev)
         t[rank] = 1
         dist.all_reduce(t)
@@ -370,183 +705,44 @@ def main(argv=None) -> None:
     w = W.WORKLOADS[args.workload or W.HEADLINE]
     grid = None if stub else W.build_grid(w)
     sharded = world > 1 or args.force_gather
-    stream = 0 if stub else torch.cuda.current_stream().cuda_stream
     all_views = VIEW_ORDER + EXTRA_VIEWS
+
+    def stub_counts():
+        return {v: {"rays": 1000, "bytes": 4000, "issued_bytes": 2000, "counters": {}, "issued": {}, "primary_hit_fraction": 0.5} for v in all_views}
 
     # ---- rays and bytes per view, counted by counting builds of the kernel (untimed) ----
     per_view = {}
-    if rank == 0 and not stub:
-        pixels = w.width * w.height
-        for mode, key in ((1, "counters"), (2, "issued")):
-            rtc = W.make_renderer(w, grid, enable_counters=mode, device_id=local_rank, kernel_variant=args.variant)
-            for v in all_views:
-                W.set_view(rtc, v)
-                rtc.draw()
-                c = rtc.counters()
-                pv = per_view.setdefault(v, {})
-                pv[key] = c
-                if mode == 1:
-                    # the loads of the REFERENCE algorithm (per-lane word cache, walk to the grid's face)
-                    pv["rays"] = c["rays"]
-                    pv["bytes"] = 4 * c["status_loads"] + 4 * c["bricks_entered"] + c["voxel_steps"] + 25 * c["hits"] + 4 * pixels
-                    primaries = pixels * w.spp
-                    if w.max_bounce == 0:
-                        ph = (c["rays"] - primaries) if w.sun_enabled else c["hits"]
-                        pv["primary_hit_fraction"] = ph / primaries
-                    else:
-                        pv["primary_hit_fraction"] = None
-                else:
-                    # what the PRODUCT kernel requests: a status dword per brick-level trip of a walk that ends at
-                    # the occupied-cell box; per brick entered the index, the start index and the first occupancy dword; an
-                    # occupancy dword per voxel trip; per hit the material id and the 20-byte material; the pixel store
-                    pv["issued_bytes"] = (4 * c["grid_steps"] + 12 * c["bricks_entered"] + 4 * c["voxel_steps"] + 21 * c["hits"] + 4 * pixels)
-            rtc.deinit()
-    elif stub:
-        per_view = {v: {"rays": 1000, "bytes": 4000, "issued_bytes": 2000, "counters": {}, "issued": {}, "primary_hit_fraction": 0.5}
-                    for v in all_views}
-    if use_dist and world > 1:
-        obj = [per_view]
-        dist.broadcast_object_list(obj, src=0)
-        per_view = obj[0]
+    if stub:
+        per_view = stub_counts()
+    elif rank == 0:
+        per_view = count_rays(W, w, grid, all_views, args.variant, local_rank)
+    per_view = env.bcast(per_view)
 
-    # ---- the timed renderer ----
-    fg = None
-    native = False
-    rt = None
-    dist_info = None
-    if sharded and args.dist == "native":
-        # RCCL inside libvrt_hip.so: kernel -> grouped send/recv to rank 0 -> un-swizzle, several launches in flight
-        ok = 1
-        try:
-            root_share = args.root_share if args.root_share >= 0 else max(30, 100 - (70 * max(0, world - 2) + 3) // 6)
-            if stub:
-                uid = [b"stub"]
-                rt = _StubRT(fail_native=(rank == args.stub_fail_native_on))
-            else:
-                from zig_vulkan_amd import VoxelRT
-                uid = [VoxelRT.dist_unique_id() if rank == 0 else None]
-            if use_dist and world > 1:
-                dist.broadcast_object_list(uid, src=0)
-            if not stub:
-                rt = W.make_renderer(w, grid, device_id=local_rank, shard_rank=rank, shard_count=world, kernel_variant=args.variant,
-                                     shard_root_weight=(root_share if 2 <= world <= 8 else 0))
-            rt.dist_init(uid[0], rank, world, args.dist_frames, frames_per_launch=(args.dist_batch if world > 1 else 1))
-            if world == 1:
-                rt.dist_selftest()
-            dist_info = rt.dist_info()
-        except Exception as e:  # noqa: BLE001 - any failure means "use the torch path"
-            print(f"[bench rank {rank}] native RCCL pipeline unavailable: {e}", file=sys.stderr)
-            ok = 0
-        if use_dist and world > 1:  # every rank must take the same path
-            t = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = int(t.item())
-        native = bool(ok)
-        if not native and rt is not None:
-            rt.deinit()
-            rt = None
-    if sharded and not native:
-        from zig_vulkan_amd.dist import FrameGather
-        fg = FrameGather(w.width, w.height, rank, world, dev)
-        if stub:
-            rt = _StubRT(False)
-        else:
-            rt = W.make_renderer(w, grid, device_id=local_rank, shard_rank=rank, shard_count=world, stream=stream,
-                                 external_target_rgba8=fg.shard.data_ptr(), kernel_variant=args.variant)
-    elif not sharded:
-        rt = _StubRT(False) if stub else W.make_renderer(w, grid, device_id=local_rank, kernel_variant=args.variant,
-                                                         frames_in_flight=args.frames_in_flight)
-    # the communicator's own idea of its size, from every rank
-    rccl_world = None
-    if native and dist_info is not None:
-        rccl_world = dist_info["world"]
-        if use_dist and world > 1:
-            t = torch.tensor([dist_info["world"]], dtype=torch.int32, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            rccl_world = int(t.item())
-        if rccl_world != world:
-            raise SystemExit(f"bench.py: the RCCL communicator spans {rccl_world} ranks, {world} were launched")
-    if native:
-        rt.dist_wait()
+    def rays_of(pv, n):
+        return sum(pv[view_of(i, n)]["rays"] for i in range(n))
+
+    # ---- the timed legs ----
+    want_native = args.dist == "native"
+    legs_out = {}
+    tune_reports = {}
+    if not sharded:
+        leg = Leg(env, W, w, grid, sharded=False, want_native=False, frames_in_flight=args.frames_in_flight)
+        plan = [("single", leg)]
     else:
-        rt.wait()
-
-    import ctypes as C
-    cams = {}
-    if not stub:
-        for v in all_views:
-            W.set_view(rt, v)
-            cams[v] = bytes(rt.camera.d_camera)
-
-    def set_cam(v: str) -> None:
-        if not stub:
-            C.memmove(C.byref(rt.camera.d_camera), cams[v], 96)
-
-    def view_of(i: int, n: int) -> str:
-        # frames of one view are consecutive (a camera moves smoothly; the tile schedule feeds on the previous frames)
-        return VIEW_ORDER[min(len(VIEW_ORDER) - 1, (i * len(VIEW_ORDER)) // max(n, 1))]
-
-    frame_no = [0]  # frames submitted so far (warm-up included): the gather pipeline's slot counter
-
-    def step(i: int, n: int) -> None:
-        set_cam(view_of(i, n))
-        if not sharded:
-            rt.draw()
-            return
-        if native:
-            rt.dist_frame()                     # kernel -> RCCL gather -> un-swizzle, on this launch's stream
-            return
-        f = frame_no[0]
-        frame_no[0] += 1
-        fg.begin_frame(f)                       # buffer f%2 is free once frame f-2's gather is done
-        rt.set_target(fg.shard_for(f).data_ptr())
-        rt.draw()                               # this rank's tiles of frame f
-        fg.gather_async(f)                      # ONE collective per frame, overlapped with frame f+1's kernel
-        if f >= 1:
-            fg.complete(f - 1, None if stub else rt)   # rank 0: un-swizzle the previous frame
-
-    def drain() -> None:
-        if native:
-            rt.dist_wait()
-        elif sharded and frame_no[0] >= 1:
-            fg.complete(frame_no[0] - 1, None if stub else rt)
-
-    def barrier() -> None:
-        if use_dist and world > 1:
-            dist.barrier()
-        sync()
-
-    def timed_region(n: int) -> float:
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(n):
-            step(i, n)
-        drain()  # the last frame's gather + un-swizzle belong to the timed region
-        if not native:
-            rt.wait()
-        barrier()
-        dt = time.perf_counter() - t0
-        if use_dist and world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        # north_star's literal "one RCCL gather per frame" first, then the batched default: both are reported,
+        # `value` is the batched leg's
+        batches = [1] if (world == 1 or not want_native or args.dist_batch <= 1) else [1, args.dist_batch]
+        plan = []
+        for b in batches:
+            leg, rep = tuned_leg(env, W, w, grid, b, want_native)
+            tune_reports[f"batch{b}"] = rep
+            plan.append((f"batch{leg.batch}" if leg.native else "torch", leg))
+            if not leg.native:
+                break       # the torch fallback has one form only
 
     # a first look at the frame time (two untimed frames): sizes the run when --steps / --warmup were left to the script
     # and the settling / PMC legs for workloads whose frames take milliseconds instead of microseconds
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(2):
-        step(2, 3)
-    drain()
-    if not native:
-        rt.wait()
-    sync()
-    frame_ms_est = max((time.perf_counter() - t0) / 2 * 1e3, 1e-3)
-    if use_dist and world > 1:
-        t = torch.tensor([frame_ms_est], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # every rank must choose the same step count
-        frame_ms_est = float(t.item())
+    frame_ms_est = plan[-1][1].estimate_frame_ms()
     if args.steps is None:
         args.steps = int(min(600, max(6, 2500.0 / frame_ms_est)))
     if args.warmup is None:
@@ -555,36 +751,72 @@ def main(argv=None) -> None:
         args.pmc_frames = int(min(24, max(2, 600.0 / frame_ms_est)))
     settle_frames = int(min(SETTLE_FRAMES, max(3, 1500.0 / frame_ms_est)))
 
-    for i in range(args.warmup):
-        step(i, args.warmup)
-    drain()
-    dt = timed_region(args.steps)
+    primary_name = plan[-1][0]
+    for name, leg in plan:
+        leg.run(args.warmup)
+        dt = leg.timed(args.steps)
+        legs_out[name] = {"value": rays_of(per_view, args.steps) / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt / args.steps * 1e3,
+                          "frames_per_collective": leg.batch, "root_share_percent": leg.root_share if leg.native else None,
+                          "dist_path": ("native" if leg.native else "torch") if sharded else None,
+                          "breakdown": leg.breakdown(2 * args.dist_frames)}
+    leg = plan[-1][1]
+    dt = legs_out[primary_name]["ms_per_step"] * args.steps * 1e-3
+    native, rccl_world = leg.native, leg.rccl_world
+    for name, other in plan[:-1]:
+        other.close()
+
+    # ---- N > 1: the same pipeline on BASELINE.json's sharded configuration (configs[3]: 3840x2160, 1024^3, 4 rays per pixel) ----
+    secondary = None
+    if sharded and world > 1 and native and not args.no_secondary and (args.workload or W.HEADLINE) == W.HEADLINE:
+        try:
+            w2 = W.WORKLOADS["cfg3_4k_1024c_b8"]
+            grid2 = None if stub else W.build_grid(w2)
+            pv2 = stub_counts() if stub else (count_rays(W, w2, grid2, VIEW_ORDER, args.variant, local_rank) if rank == 0 else None)
+            pv2 = env.bcast(pv2)
+            leg2, rep2 = tuned_leg(env, W, w2, grid2, args.dist_batch, True)
+            est2 = leg2.estimate_frame_ms()
+            steps2 = int(min(args.steps, max(6, 2000.0 / est2)))
+            leg2.run(min(args.warmup, steps2))
+            dt2 = leg2.timed(steps2)
+            secondary = {"workload": w2.name, "metric": metric_name(w2), "value": rays_of(pv2, steps2) / dt2 / 1e6, "unit": "Mrays/s", "steps": steps2,
+                         "ms_per_step": dt2 / steps2 * 1e3, "frames_per_collective": leg2.batch, "root_share": rep2,
+                         "breakdown": leg2.breakdown(2 * args.dist_frames)}
+            leg2.close()
+            del grid2
+        except Exception as e:  # noqa: BLE001 - the secondary leg must never take the headline line down
+            print(f"[bench rank {rank}] secondary leg failed: {type(e).__name__}: {e}", file=sys.stderr)
+            secondary = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- N = 1: the same steps strictly one frame after another, and the dominant kernel by HIP events ----
     roofline = None
     single = None
     if rank == 0 and not sharded and not stub:
-        rt1 = rt
+        rt = leg.rt
         if args.frames_in_flight != 1:
-            rt.deinit()
-            rt1 = rt = W.make_renderer(w, grid, device_id=local_rank, kernel_variant=args.variant, frames_in_flight=1)
-        for i in range(args.warmup):
-            step(i, args.warmup)
-        single = timed_region(args.steps) / args.steps * 1e3
-        reps = max(8, args.steps // len(VIEW_ORDER))
+            leg.close()
+            leg = Leg(env, W, w, grid, sharded=False, want_native=False, frames_in_flight=1)
+        rt1 = leg.rt
+        leg.run(args.warmup)
+        single = leg.timed(args.steps) / args.steps * 1e3
+        reps = max(100, args.steps // len(VIEW_ORDER))   # >= 100 timed frames per view, whatever --steps says
         kernel_ms_view, frame_stats = {}, {}
         for v in all_views:
-            set_cam(v)
+            leg.set_cam(v)
             # untimed: the camera has just jumped to this view, and the launch order follows the measured tile costs with
-            # a lag (re-sorted every 32 frames from a running mean): let it settle as it would under a moving camera
+            # a lag (re-sorted from a running mean): let it settle as it would under a moving camera
             rt1.draw(frames=settle_frames)
             rt1.draw(frames=reps)                           # back to back, one event pair around all of them
             kernel_ms_view[v] = rt1.last_kernel_ms()
             frame_stats[v] = percentiles(rt1.draw_timed(min(reps, 512)))   # an event pair around every frame
+        kernel_ran = rt1.kernel_name()   # the symbol of the launches timed above (vrt_kernel_name reports what ran)
         avg_ms = sum(kernel_ms_view[v] for v in VIEW_ORDER) / len(VIEW_ORDER)
         avg_bytes = sum(per_view[v]["bytes"] for v in VIEW_ORDER) / len(VIEW_ORDER)
         avg_issued = sum(per_view[v]["issued_bytes"] for v in VIEW_ORDER) / len(VIEW_ORDER)
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
+        try:
+            hbm = hbm_achievable(dev)
+        except Exception as e:  # noqa: BLE001
+            hbm = {"error": f"{type(e).__name__}: {e}"}
         pmc, pmc_note = (None, "--pmc off")
         if args.pmc in ("auto", "live"):
             rt1.wait()
@@ -594,14 +826,16 @@ def main(argv=None) -> None:
             pmc, pmc_note = pmc_from_profile(w.brick_dimension)
             if args.pmc == "auto":
                 pmc_note = f"{pmc_note} (live measurement failed: {why})"
-        traffic = issue_ipc = None
+        traffic = issue_ipc = valu_frac = None
         insts = None
+        clock_hz = None
         if pmc is not None:
             # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE on gfx950 tallies 64 B per 128-byte line fetched
             # (MI355X_MICROARCH.md; tools/ubench/fetch_calib.hip confirms it for scattered dword reads): doubled
             traffic = 2.0 * pmc["FETCH_SIZE"] * 1024.0 + pmc["WRITE_SIZE"] * 1024.0
             keys = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_INSTS_LDS")
             if all(k in pmc for k in keys[:3]):
+                import ctypes as C
                 insts = {k: pmc.get(k, 0.0) for k in keys}
                 from zig_vulkan_amd import _lib as VL
                 di = (C.c_int64 * 4)()
@@ -609,6 +843,7 @@ def main(argv=None) -> None:
                 clock_hz = di[0] * 1e3
                 simds = int(di[1]) * 4
                 issue_ipc = sum(insts.values()) / (simds * avg_ms * 1e-3 * clock_hz)
+                valu_frac = insts["SQ_INSTS_VALU"] * 2.0 / (simds * avg_ms * 1e-3 * clock_hz)
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_note": pmc_note,
@@ -619,25 +854,33 @@ def main(argv=None) -> None:
                           "views from outside the box.  issued_bytes = what the product kernel's lanes request (4 B per brick-level trip "
                           "taken, 12 per brick entered, 4 per voxel trip, 21 per hit, 4 per pixel). "
                           "traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE): the touched scene data lives in L2 / MALL.",
-            "kernel": rt1.kernel_name(), "settle_frames": settle_frames, "kernel_ms_avg": avg_ms, "kernel_ms_per_view": kernel_ms_view,
+            "kernel": kernel_ran, "settle_frames": settle_frames, "timed_frames_per_view": reps,
+            "kernel_ms_avg": avg_ms, "kernel_ms_per_view": kernel_ms_view,
             "frame_ms_percentiles_per_view": frame_stats,
             "algorithmic_bytes_per_launch": avg_bytes,
             "issued_bytes": avg_issued, "issued_GBps": avg_issued / (avg_ms * 1e-3) / 1e9,
+            "frac_issued": avg_issued / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "valu_frac": valu_frac,
+            "valu_frac_note": "SQ_INSTS_VALU x 2 cycles (a wave64 vector instruction holds its SIMD's pipe for two) / (SIMDs x kernel_ms_avg x "
+                              "engine clock): the share of the vector pipe the launch keeps busy — the ceiling that binds this path; "
+                              "frac_issued = issued_GBps / HBM peak; hbm_traffic_GBps = traffic / kernel time: what HBM really carries",
+            "hbm_traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+            "hbm_achievable": hbm,
             "issue_ipc": issue_ipc,
             "issue_ipc_note": "wave-instructions per launch (SQ_INSTS_VALU + SALU + VMEM + SMEM + LDS) / (1024 SIMDs x kernel_ms_avg x "
                               "the device's engine clock): the kernel is bound by instruction issue, not by HBM",
-            "insts_per_launch": insts, "clock_hz": clock_hz if insts else None,
+            "insts_per_launch": insts, "clock_hz": clock_hz,
         }
 
     if rank == 0:
-        total_rays = sum(per_view[view_of(i, args.steps)]["rays"] for i in range(args.steps))
         par = (f"1 GPU, whole frame, {args.frames_in_flight} frame(s) in flight" if not sharded else
                f"image tiles 16x16 interleaved over {world} GPU(s), every frame gathered once to rank 0, "
-               + (f"native RCCL pipeline: {args.dist_batch if world > 1 else 1} frame(s) per launch and per collective, {args.dist_frames} launches in flight"
+               + (f"native RCCL pipeline: {leg.batch if world > 1 else 1} frame(s) per launch and per collective (`value`; the one-collective-per-frame "
+                  f"leg is legs.batch1), {args.dist_frames} launches in flight, rank 0 owns {leg.root_share} % of an equal share of the tiles"
                   if native else "torch.distributed gather per frame, frame f overlaps the kernel of f+1"))
         out = {
             "metric": metric_name(w),
-            "value": total_rays / dt / 1e6,
+            "value": legs_out[primary_name]["value"],
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -662,18 +905,48 @@ def main(argv=None) -> None:
                        "parallelism": par},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline and not stub:
+        if sharded:
+            out["legs"] = legs_out
+            out["legs_note"] = ("batch1 = north_star's literal one RCCL gather per frame; the batched leg traces N frames per launch and gathers them "
+                                "with one collective (N frames of latency for 2-3x the frame rate at 8 ranks: a rank's 1/R of the tiles does not "
+                                "fill a GPU); `value` is the last leg's")
+            out["root_share_tuning"] = tune_reports
+            out["secondary"] = secondary
+        if world == 1 and not sharded and not args.no_cpu_baseline and not stub:
+            # frames of this library for the parity certificate: the product build, and its reference-lowering twin where built
+            hip_frames = {}
+            try:
+                from zig_vulkan_amd import _lib as VL
+                builds = {"product": None}
+                if os.path.exists(VL.REFLOW_LIB_PATH):
+                    builds["reflow"] = VL.REFLOW_LIB_PATH
+                for build, path in builds.items():
+                    rtf = W.make_renderer(w, grid, device_id=local_rank, want_float_output=True, kernel_variant=args.variant,
+                                          **({"library": path} if path else {}))
+                    hip_frames[build] = {}
+                    for v in VIEW_ORDER:
+                        W.set_view(rtf, v)
+                        rtf.draw()
+                        hip_frames[build][v] = (rtf.read_rgba32f().copy(), rtf.read_rgba8().copy())
+                    rtf.deinit()
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] parity frames unavailable: {type(e).__name__}: {e}", file=sys.stderr)
+                hip_frames = {}
             port = cpu_baseline_port(w, grid, args.cpu_seconds, per_view)
-            ref, why = cpu_baseline_reference(w, grid, args.cpu_seconds, per_view)
+            ref, parity, why = cpu_baseline_reference(w, grid, args.cpu_seconds, per_view, hip_frames)
             if ref is not None:
                 out["cpu_baseline"] = ref
                 out["cpu_baseline_port"] = port
+                if parity is not None:
+                    parity["note"] = ("product = libvrt_hip.so (fma fused, dot as an fma chain: what GLSL leaves to the implementation); reflow = the same "
+                                      "kernel source compiled with llvmpipe's lowering of fma / dot (libvrt_hip_reflow.so, test infrastructure): "
+                                      "expected bit-equal to the reference frame, every pixel")
+                    out["parity_vs_reference"] = parity
             else:
                 port["reference_unavailable"] = why
                 out["cpu_baseline"] = port
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if rt is not None:
-        rt.deinit()
+    leg.close()
     if use_dist:
         dist.destroy_process_group()
 

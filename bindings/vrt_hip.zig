@@ -249,6 +249,8 @@ pub extern fn vrt_dist_wait(ctx: ?*Ctx) c_int;
 pub extern fn vrt_dist_read_frame(ctx: ?*Ctx, dst: ?*anyopaque, nbytes: u64) c_int;
 pub extern fn vrt_dist_broadcast(ctx: ?*Ctx, id: BufferId, byte_offset: u64, nbytes: u64, root: c_int) c_int;
 pub extern fn vrt_dist_info(ctx: ?*Ctx, out: *[4]i32) c_int;
+pub extern fn vrt_dist_profile(ctx: ?*Ctx, enable: u32) c_int;
+pub extern fn vrt_dist_stats(ctx: ?*Ctx, out: *[8]f64) c_int;
 pub extern fn vrt_dist_selftest(ctx: ?*Ctx) c_int;
 pub extern fn vrt_last_kernel_ms(ctx: ?*Ctx) f64;
 pub extern fn vrt_get_counters(ctx: ?*Ctx, out: [*c]Counters) c_int;

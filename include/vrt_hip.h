@@ -265,6 +265,14 @@ int vrt_dist_broadcast(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, uin
 /* out = {rank, world size — both as the RCCL communicator reports them (ncclCommUserRank / ncclCommCount) —,
  * frames per launch, launches in flight}: lets a launcher prove how many ranks the gather really spans. */
 int vrt_dist_info(vrt_ctx *ctx, int32_t out[4]);
+/* Per-launch breakdown of the pipeline, by events on each launch's own stream (measurement; off by default because the extra
+ * event records sit between the stages).  vrt_dist_profile(ctx, 1) clears the sums and starts sampling; every launch whose
+ * events can be read when its slot is reused, and every slot's last launch at vrt_dist_wait, adds its stage times.
+ * vrt_dist_stats: out = {launches sampled, frames in them, kernel ms, collective ms, un-swizzle ms (the three are averages
+ * per launch; collective = this rank's part of the grouped send / recv: the receives on rank 0, the send elsewhere, waiting
+ * for the peer included; un-swizzle: rank 0 only), tiles this rank owns, bytes of one frame's shard, frames per launch}. */
+int vrt_dist_profile(vrt_ctx *ctx, uint32_t enable);
+int vrt_dist_stats(vrt_ctx *ctx, double out[8]);
 /* ncclSend + ncclRecv of one shard to this rank itself: checks the RCCL binding on a single GPU */
 int vrt_dist_selftest(vrt_ctx *ctx);
 

@@ -218,11 +218,12 @@ class ReferenceShader:
         ubos, ssbos = self._blocks(scene, pc)
         self.gl.set_buffers(ubos, ssbos)
 
-    def frame(self, pc: np.ndarray, read: bool = False) -> Optional[np.ndarray]:
-        """One dispatch of the Rgba8 build over the bound scene; returns when it has finished."""
+    def frame(self, pc: np.ndarray, read: bool = False, want_float: bool = False) -> Optional[np.ndarray]:
+        """One dispatch over the bound scene (the Rgba8 build, or the rgba32f build of the same shader); returns when it has
+        finished, with the frame if `read`."""
         w, h = (int(v) for v in np.frombuffer(pc[:8].tobytes(), dtype=np.uint32))
         self.gl.update_ubo(0, np.frombuffer(pc.tobytes(), dtype=np.uint8))
-        return self.gl.run(self.progs["rgba8"], w, h, False, read)
+        return self.gl.run(self.progs["rgba32f" if want_float else "rgba8"], w, h, want_float, read)
 
     def unbind(self) -> None:
         self.gl.clear_buffers()

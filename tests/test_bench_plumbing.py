@@ -51,6 +51,21 @@ def test_gpus_2_without_rank_env_spawns_two_ranks():
     assert out["steps"] == 6 and out["warmup"] == 2
     assert out["value"] > 0 and out["ms_per_step"] > 0
     assert "re-executing" in r.stderr.decode()
+    # two timed legs in one invocation: north_star's literal one-gather-per-frame and the batched default; `value` is the batched leg's
+    assert set(out["legs"]) == {"batch1", "batch8"}
+    assert out["value"] == out["legs"]["batch8"]["value"] and out["ms_per_step"] == pytest.approx(out["legs"]["batch8"]["ms_per_step"])
+    assert out["legs"]["batch1"]["frames_per_collective"] == 1 and out["legs"]["batch8"]["frames_per_collective"] == 8
+    # the root share comes from a warm-up auto-tune whose winner every rank agrees on (times are maxima over ranks); the stub's
+    # frames are fastest at a share of 60 %
+    for leg in ("batch1", "batch8"):
+        tune = out["root_share_tuning"][leg]
+        assert tune["tuned"] and set(tune["candidates_ms_per_frame"]) == {"60", "100"} and tune["root_share"] == 60
+        assert out["legs"][leg]["root_share_percent"] == 60
+        bd = out["legs"][leg]["breakdown"]
+        assert [row["rank"] for row in bd["per_rank"]] == [0, 1] and bd["max_over_ranks"]["kernel_us_per_frame"] > 0
+    # and the same pipeline on BASELINE's sharded configuration as a secondary leg
+    assert out["secondary"]["workload"] == "cfg3_4k_1024c_b8" and out["secondary"]["value"] > 0
+    assert out["secondary"]["root_share"]["root_share"] == 60
 
 
 @pytest.mark.timeout(400)
@@ -62,6 +77,7 @@ def test_native_failure_on_one_rank_moves_every_rank_to_the_torch_path():
     assert out["dist_path"] == "torch"     # rank 0's native set-up worked, rank 1's did not: both fall back
     assert out["rccl_world"] is None
     assert "torch.distributed gather per frame" in out["config"]["parallelism"]
+    assert set(out["legs"]) == {"torch"} and out["secondary"] is None
 
 
 def test_world_size_contradicting_gpus_is_an_error():

@@ -19,7 +19,11 @@ FAKE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "li
 @pytest.mark.parametrize("world,frames_in_flight,frames_per_launch,root_weight",
                          [(2, 2, 1, 0), (3, 4, 1, 0), (8, 8, 1, 0), (8, 1, 1, 0), (2, 2, 3, 0), (8, 3, 8, 0), (5, 2, 4, 0), (8, 1, 2, 0),
                           (8, 3, 8, 65), (2, 2, 1, 30), (5, 2, 3, 85), (8, 2, 4, 1),
-                          (8, 4, 8, 30), (4, 4, 8, 77), (2, 4, 8, 100)])   # bench.py's defaults at 8 / 4 / 2 ranks
+                          # bench.py's root-share candidates (root_share_candidates: the emulated default, 0.6 x, 1.5 x) at 8 / 4 / 2 ranks,
+                          # one collective per frame and eight frames per collective
+                          (8, 4, 8, 30), (8, 4, 8, 18), (8, 4, 8, 45), (8, 4, 1, 30), (8, 4, 1, 18), (8, 4, 1, 45),
+                          (4, 4, 8, 77), (4, 4, 8, 46), (4, 4, 8, 100), (4, 4, 1, 77), (4, 4, 1, 46),
+                          (2, 4, 8, 100), (2, 4, 8, 60), (2, 4, 1, 60)])
 def test_native_pipeline_with_many_ranks_on_one_gpu(world, frames_in_flight, frames_per_launch, root_weight):
     if not os.path.exists(FAKE):
         pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
@@ -181,3 +185,62 @@ def test_edits_made_on_one_rank_reach_every_replica(world, no_broadcast):
         rt.deinit()
     assert shared["ranges"] and not np.array_equal(before[0], want)
     assert np.array_equal(after, want)
+
+
+def test_bench_root_share_candidates_are_the_tested_ones():
+    import bench
+    assert bench.root_share_candidates(8) == [18, 30, 45] and bench.root_share_candidates(4) == [46, 77, 100] and bench.root_share_candidates(2) == [60, 100]
+
+
+@pytest.mark.parametrize("world,frames_per_launch", [(2, 1), (4, 8)])
+def test_pipeline_stage_profile(world, frames_per_launch):
+    """vrt_dist_profile / vrt_dist_stats: per-launch stage times by events on the launch's own stream — what bench.py's per-rank
+    breakdown reads.  Every rank samples launches; kernel time is positive everywhere, only rank 0 un-swizzles; frames still equal
+    the single-context frame with the extra events in the stream."""
+    if not os.path.exists(FAKE):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
+    w = W.Workload("t", 332, 210, 64, 4, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    plain = W.make_renderer(w, grid)
+    W.set_view(plain, "V1")
+    plain.draw()
+    ref = plain.read_rgba8().copy()
+    plain.deinit()
+    uid = b"fake-rccl-prof" + bytes([world, frames_per_launch]) + os.urandom(16) + bytes(128 - 32)
+    ranks = [W.make_renderer(w, grid, shard_rank=r, shard_count=world) for r in range(world)]
+    for r, rt in enumerate(ranks):
+        W.set_view(rt, "V1")
+        rt.dist_init(uid, r, world, frames_in_flight=3, rccl_path=FAKE, frames_per_launch=frames_per_launch)
+    stats, errors = {}, []
+
+    def drive(r):
+        try:
+            rt = ranks[r]
+            for _ in range(2 * frames_per_launch):
+                rt.dist_frame()
+            rt.dist_wait()
+            assert rt.dist_stats()["launches_sampled"] == 0      # nothing sampled before it is asked for
+            rt.dist_profile(True)
+            for _ in range(6 * frames_per_launch):
+                rt.dist_frame()
+            rt.dist_wait()
+            stats[r] = rt.dist_stats()
+            rt.dist_profile(False)
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads) and not errors, errors
+    got = ranks[0].dist_read_frame()
+    for rt in ranks:
+        rt.deinit()
+    assert np.array_equal(got, ref)
+    for r in range(world):
+        st = stats[r]
+        assert 3 <= st["launches_sampled"] <= 6 and st["frames_sampled"] == st["launches_sampled"] * frames_per_launch
+        assert st["frames_per_launch"] == frames_per_launch and st["kernel_ms_per_launch"] > 0
+        assert (st["unswizzle_ms_per_launch"] > 0) == (r == 0)

@@ -426,8 +426,12 @@ def test_random_scenes_fuzz_slice():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.fuzz(60, 5, verbose=False) == 0
-    # grids the path kernel's block filter accepts, frames with bounces: the block-skipping walk (skip_empty_block)
+    # power-of-two grids, frames with bounces: the path kernel's walk loop on half-block words
     assert mod.fuzz(24, 11, big=True, verbose=False, pow2=True) == 0
+    from tests.helpers import dev_library_or_none
+    if dev_library_or_none():   # development build: the block-skipping walk (skip_empty_block) and the other variants join the draw
+        assert mod.fuzz(24, 11, big=True, verbose=False, pow2=True, library=dev_library_or_none()) == 0
+        assert mod.fuzz(30, 5, big=True, verbose=False, library=dev_library_or_none()) == 0
 
 
 def test_walk_ends_at_the_bounding_box_of_the_occupied_cells():

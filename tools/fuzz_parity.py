@@ -11,8 +11,14 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from zig_vulkan_amd import BrickGrid, Config, CameraConfig, SunConfig, VoxelRT, default_materials
 from helpers import O, oracle_scene_from_grid
 
-def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: bool = False) -> int:
-    """Returns the number of mismatching cases."""
+def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: bool = False, library=None) -> int:
+    """Returns the number of mismatching cases.  library: path of the development build (make dev) — the variants that lost their
+    A/B measurement then take part in the draw; without it only the kernels of the product build are drawn."""
+    dev = library is not None
+    PATH = 1 << 23
+    big_variants = ([0, 0, 6, 1, 0x10070000, 0x10070000, PATH, PATH | (1 << 22), PATH | (5 << 8), PATH | (2 << 24)] if dev
+                    else [0, 0, 9, 5, 0x10070000, 0x10070000, PATH, PATH | (3 << 24), PATH | (5 << 8), PATH | (2 << 24)])
+    pow2_variants = [PATH | (1 << 22), PATH | (1 << 22) | (5 << 8), PATH] if dev else [PATH, PATH | (5 << 8), PATH | (2 << 24)]
     rng = np.random.default_rng(seed)
     bad = 0
     for case in range(cases):
@@ -51,8 +57,9 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: b
         sun_on, radius = bool(rng.random() < 0.7), float(rng.choice([0.0, 5.0, 40.0]))
         rt = VoxelRT(grid, Config(internal_resolution_width=w, internal_resolution_height=h, camera=CameraConfig(samples_per_pixel=spp, max_bounce=bounce),
                                   sun=SunConfig(enabled=sun_on, radius=radius), want_float_output=True,
-                                  kernel_variant=int(rng.choice([0, 0, 6, 1, 0x10070000, 0x10070000, 1 << 23, (1 << 23) | (1 << 22), (1 << 23) | (5 << 8), (1 << 23) | (2 << 24)])) if big
-                                  else int(rng.choice([(1 << 23) | (1 << 22), (1 << 23) | (1 << 22) | (5 << 8), 1 << 23]) if pow2 else rng.choice([0, 0, 1 << 23]))))
+                                  library=library,
+                                  kernel_variant=int(rng.choice(big_variants)) if big
+                                  else int(rng.choice(pow2_variants) if pow2 else rng.choice([0, 0, PATH]))))
         rt.push_materials(mats)
         size = np.array(dims) * scale
         centre = np.array(min_point) + 0.5 * size

@@ -172,6 +172,8 @@ SIGNATURES = {
     "vrt_dist_wait": (C.c_int, [_ctx]),
     "vrt_dist_read_frame": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
     "vrt_dist_selftest": (C.c_int, [_ctx]),
+    "vrt_dist_profile": (C.c_int, [_ctx, C.c_uint32]),
+    "vrt_dist_stats": (C.c_int, [_ctx, _P(C.c_double)]),
     "vrt_dist_broadcast": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
     "vrt_dist_info": (C.c_int, [_ctx, _P(C.c_int32)]),
     "vrt_device_info": (C.c_int, [C.c_int, _P(C.c_int64)]),

@@ -108,6 +108,9 @@ struct DistSlot {
     uint64_t seen_upload = 0;
     uint32_t frames = 0;         // frames of the batch this slot holds
     bool used = false;
+    // vrt_dist_profile: events around the three stages of the slot's most recent launch (kernel | collective | un-swizzle)
+    hipEvent_t mark[4] = {};
+    bool marked = false;         // the most recent launch recorded its marks and they have not been read yet
 };
 
 struct Dist {
@@ -129,6 +132,10 @@ struct Dist {
     uint32_t npend = 0;
     vrt::PushConstants pend[vrt::kMaxBatchFrames];
     vrt::KernelFn pend_fn = nullptr;
+    // vrt_dist_profile / vrt_dist_stats: per-launch stage times, summed over the launches sampled
+    bool profile = false;
+    uint64_t prof_launches = 0, prof_frames = 0;
+    double prof_ms[3] = {0.0, 0.0, 0.0}; // kernel, collective, un-swizzle
 };
 
 struct vrt_ctx {
@@ -259,6 +266,8 @@ void free_ctx(vrt_ctx *c) {
             else if (sl.shard) (void)hipFree(sl.shard);
             if (sl.frame) (void)hipFree(sl.frame);
             if (sl.done) (void)hipEventDestroy(sl.done);
+            for (hipEvent_t e : sl.mark)
+                if (e) (void)hipEventDestroy(e);
         }
         if (d->comm && d->api.CommDestroy) (void)d->api.CommDestroy(d->comm);
         delete d;
@@ -1332,6 +1341,20 @@ int vrt_dist_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_
 } // extern "C"
 
 namespace {
+// vrt_dist_profile: add the stage times of the slot's most recent launch to the sums (wait: the launch is known to have
+// finished; otherwise only if it has)
+void dist_collect(Dist *d, DistSlot &sl, bool finished) {
+    if (!sl.marked) return;
+    sl.marked = false;
+    if (!finished && hipEventQuery(sl.mark[3]) != hipSuccess) return;
+    float ms[3] = {0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < 3; k++)
+        if (hipEventElapsedTime(&ms[k], sl.mark[k], sl.mark[k + 1]) != hipSuccess) return;
+    for (int k = 0; k < 3; k++) d->prof_ms[k] += (double)ms[k];
+    d->prof_launches++;
+    d->prof_frames += sl.frames;
+}
+
 // Launch the queued frames: one kernel over (tiles of this rank) x (frames), ONE collective, one un-swizzle per frame.
 int dist_flush(vrt_ctx *ctx) {
     Dist *d = ctx->dist;
@@ -1355,7 +1378,15 @@ int dist_flush(vrt_ctx *ctx) {
     pk.packed_tiles = 1u;
     pk.packed_rgb = 1u;
     pk.batch_target_stride = (uint32_t)d->shard_bytes;
+    if (sl.marked) dist_collect(d, sl, false); // (profile: the slot's previous launch, if it has finished; else that sample is dropped)
+    const bool mark = d->profile;
+    if (mark) {
+        for (hipEvent_t &e : sl.mark)
+            if (!e) VRT_HIP(ctx, hipEventCreate(&e));
+        VRT_HIP(ctx, hipEventRecord(sl.mark[0], sl.stream));
+    }
     VRT_HIP(ctx, vrt::launch_trace(d->pend_fn, pk, ctx->lds_bytes, sl.stream, n));
+    if (mark) VRT_HIP(ctx, hipEventRecord(sl.mark[1], sl.stream));
     // 2. the one collective of the batch: every rank's shards -> rank 0 (grouped point-to-point = gather)
     const size_t region = d->shard_bytes * d->batch;
     if (d->world > 1) {
@@ -1375,12 +1406,15 @@ int dist_flush(vrt_ctx *ctx) {
             return fail(ctx, VRT_E_RCCL, std::string("RCCL gather failed: ") + d->api.GetErrorString(first_bad != ncclSuccess ? first_bad : end));
         }
     }
+    if (mark) VRT_HIP(ctx, hipEventRecord(sl.mark[2], sl.stream));
     // 3. rank 0: tile-major shards -> row-major frames
     if (d->rank == 0) {
         // (one launch for the n frames of the batch: grid.z)
         VRT_HIP(ctx, vrt::launch_assemble_rgb(sl.gathered, sl.frame, ctx->cfg.width, ctx->cfg.height, ctx->shard.tiles_x, (uint32_t)d->world,
                                               ctx->shard.tiles_per_rank * d->batch, ctx->own, sl.stream, n, (uint32_t)d->shard_bytes));
     }
+    if (mark) VRT_HIP(ctx, hipEventRecord(sl.mark[3], sl.stream));
+    sl.marked = mark;
     VRT_HIP(ctx, hipEventRecord(sl.done, sl.stream));
     sl.used = true;
     sl.frames = n;
@@ -1399,6 +1433,31 @@ int vrt_dist_wait(vrt_ctx *ctx) {
     if (rcf != VRT_OK) return rcf;
     for (uint32_t i = 0; i < ctx->dist->nslots; i++) VRT_HIP(ctx, hipStreamSynchronize(ctx->dist->slots[i].stream));
     VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < ctx->dist->nslots; i++) dist_collect(ctx->dist, ctx->dist->slots[i], true);
+    return VRT_OK;
+}
+
+int vrt_dist_profile(vrt_ctx *ctx, uint32_t enable) {
+    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
+    Dist *d = ctx->dist;
+    d->profile = enable != 0u;
+    d->prof_launches = d->prof_frames = 0;
+    d->prof_ms[0] = d->prof_ms[1] = d->prof_ms[2] = 0.0;
+    return VRT_OK;
+}
+
+int vrt_dist_stats(vrt_ctx *ctx, double out[8]) {
+    if (!ctx || !ctx->dist || !out) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called / out NULL") : VRT_E_INVALID_ARG;
+    const Dist *d = ctx->dist;
+    const double n = d->prof_launches ? (double)d->prof_launches : 1.0;
+    out[0] = (double)d->prof_launches;
+    out[1] = (double)d->prof_frames;
+    out[2] = d->prof_ms[0] / n;
+    out[3] = d->prof_ms[1] / n;
+    out[4] = d->rank == 0 ? d->prof_ms[2] / n : 0.0; // (only rank 0 un-swizzles; elsewhere the interval holds two event records)
+    out[5] = (double)ctx->shard.owned_tiles;
+    out[6] = (double)d->shard_bytes;
+    out[7] = (double)d->batch;
     return VRT_OK;
 }
 

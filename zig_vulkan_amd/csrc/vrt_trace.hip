@@ -369,8 +369,11 @@ uint32_t resolve_variant(uint32_t variant) {
 // build compiles the variants the library itself chooses; the others live in the development build, make dev).
 KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, int shade) {
     variant = resolve_variant(variant);
-    const uint32_t vmode = variant & 0xFFu, mw = (variant >> 8) & 0xFFu;
-    if (mw != 0u && (mw < 4u || mw > 8u)) return nullptr;
+    const uint32_t vmode = variant & 0xFFu, mw_asked = (variant >> 8) & 0xFFu;
+    if (mw_asked != 0u && (mw_asked < 4u || mw_asked > 8u)) return nullptr;
+    // (min_waves 5 is vrt_path_kernel's own occupancy: every other kernel reads it as "the library's default")
+    const bool to_path = shade == 0 && !counters && vmode == kVariantLinearAlways && !(variant & kVariantLockstepBounce);
+    const uint32_t mw = (mw_asked == 5u && !to_path) ? 0u : mw_asked;
     int mode, block = 256;
     switch (vmode) {
         case kVariantLiteral: mode = kStatusLinear; break;

@@ -266,12 +266,18 @@ class VoxelRT:
         cfg.stream = config.stream or None
         cfg.external_target_rgba8 = config.external_target_rgba8 or None
         cfg.external_target_rgba32f = config.external_target_rgba32f or None
+        cfg.tuning_flags = config.tuning_flags
+        # (config.library: another build of the same library — the reference-lowering twin or the development build;
+        # host objects such as BrickGrid stay with the default build: same sources, same layout)
+        self._lib = L.load_library(config.library) if config.library else lib
         h = C.c_void_p()
-        self._check(self._lib.vrt_create(C.byref(cfg), C.byref(h)))
+        rc = self._lib.vrt_create(C.byref(cfg), C.byref(h))
+        if rc != L.VRT_OK:
+            raise L.VrtError(rc, (self._lib.vrt_last_error(None) or b"").decode())
         self._h = h
         self.width, self.height = cfg.width, cfg.height
         if upload_grid:
-            check(self._lib.vrt_upload_grid(self._h, brick_grid._h))  # VoxelRT.zig:62 (+ first full delta)
+            self._check(self._lib.vrt_upload_grid(self._h, brick_grid._h))  # VoxelRT.zig:62 (+ first full delta)
 
     init = classmethod(lambda cls, *a, **k: cls(*a, **k))
 
@@ -425,6 +431,16 @@ class VoxelRT:
         out = (C.c_int32 * 4)()
         self._check(self._lib.vrt_dist_info(self._h, out))
         return {"rank": out[0], "world": out[1], "frames_per_launch": out[2], "launches_in_flight": out[3]}
+
+    def dist_profile(self, enable: bool = True) -> None:
+        """Start (and clear) / stop the per-launch stage timing of the pipeline (vrt_dist_profile)."""
+        self._check(self._lib.vrt_dist_profile(self._h, 1 if enable else 0))
+
+    def dist_stats(self) -> dict:
+        out = (C.c_double * 8)()
+        self._check(self._lib.vrt_dist_stats(self._h, out))
+        return {"launches_sampled": int(out[0]), "frames_sampled": int(out[1]), "kernel_ms_per_launch": out[2], "collective_ms_per_launch": out[3],
+                "unswizzle_ms_per_launch": out[4], "owned_tiles": int(out[5]), "shard_bytes_per_frame": int(out[6]), "frames_per_launch": int(out[7])}
 
     def dist_selftest(self) -> None:
         self._check(self._lib.vrt_dist_selftest(self._h))
