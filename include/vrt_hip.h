@@ -150,7 +150,9 @@ typedef struct vrt_config {
 #define VRT_TUNE_NO_PATH_HALFBLOCKS (1u << 2) /* vrt_path_kernel: the shader's linear status words instead of the half-block words */
 #define VRT_TUNE_PATH_EAGER_START   (1u << 3) /* vrt_path_kernel: request brick_start_index together with the staged brick */
 #define VRT_TUNE_DIST_NO_BROADCAST  (1u << 4) /* vrt_dist_broadcast as grouped send / recv from the root (every rank alike) */
-#define VRT_TUNE_ALL                0x1Fu
+#define VRT_TUNE_NO_CELL_OCCUPANCY  (1u << 5) /* vrt_path_kernel: reach a brick's bits through brick_index instead of the by-cell copy */
+#define VRT_TUNE_NO_START_SHORTCUT  (1u << 6) /* always look brick_start_index up, even when it is slot * B^3 for every brick */
+#define VRT_TUNE_ALL                0x7Fu
 
 typedef struct vrt_ctx vrt_ctx;
 

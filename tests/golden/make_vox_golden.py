@@ -7,9 +7,10 @@ any row of SURVEY.md §8: assets/models/doom.vox, loaded by src/main.zig:84, and
 doom_scene.npz: the grid of src/main.zig:77-81 (128 x 64 x 128 bricks of 4^3, min_point (-32,-16,-32), scale 0.5, dense
 allocation) with doom.vox inserted exactly as src/main.zig:109-117 does (voxel (x, y, z) -> grid (x + 200, z + 50, y + 150),
 material = color_index + 8) and the material table of src/main.zig:87-106 (8 terrain materials, then the palette).  Stored:
-the parse results (sizes, voxel count, SHA-256 of the XYZI records and of the palette), the seven scene buffers, one
-camera (128 push-constant bytes, reference defaults: 2 samples, 2 bounces, sun on), and two frames of it — the oracle's
-(what the HIP path must reproduce bit for bit) and the reference shader's own under llvmpipe (oracle/_ref).
+the parse results (sizes, voxel count, SHA-256 of the XYZI records and of the palette), a SHA-256 of each of the seven scene
+buffers (NOT the buffers: they are the asset's voxel data re-encoded, and the reference states no licence for its assets), one
+camera (128 push-constant bytes, reference defaults: 2 samples, 2 bounces, sun on), and two frames of it — the oracle's and the
+reference shader's own under llvmpipe (oracle/_ref).  Tests that need the buffers rebuild them from /root/reference.
 The terrain that main.zig adds afterwards is not part of it (irreproducible in the reference: SURVEY.md §5).
 This pins the .vox loader and the palette mapping to reference-held data; the traversal is pinned by tests/golden/ref.
 monu10.npz: parse results only.
@@ -36,6 +37,14 @@ def parse_summary(v):
     xyzi = v.xyzi(0)
     return dict(num_models=np.int32(v.num_models), size=np.array(v.size(0), dtype=np.int32), voxels=np.int64(xyzi.shape[0]),
                 xyzi_sha256=np.array(hashlib.sha256(xyzi.tobytes()).hexdigest()), rgba_sha256=np.array(hashlib.sha256(v.rgba.tobytes()).hexdigest()))
+
+
+def buffer_digests(scene):
+    """SHA-256 of each of the seven scene buffers (bindings 1..7)."""
+    bufs = (("grid_state", scene.grid_state), ("materials", scene.materials.view(np.uint8).reshape(-1)), ("brick_status", scene.brick_status),
+            ("brick_index", scene.brick_index), ("brick_occupancy", scene.brick_occupancy), ("brick_start_index", scene.brick_start_index),
+            ("material_index", scene.material_index))
+    return {k + "_sha256": np.array(hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()) for k, a in bufs}
 
 
 def doom_scene():
@@ -68,10 +77,8 @@ def main():
         fl, ul, _ = O.render(scene, pc, lowering="llvmpipe")
         assert np.array_equal(rf.view(np.uint32), fl.view(np.uint32)) and np.array_equal(ru, ul)
         extra = dict(ref_rgba8=ru, ref_rgb32f=np.ascontiguousarray(rf[:, :, :3]))
-    np.savez_compressed(os.path.join(OUT, "doom_scene.npz"), **parse_summary(v),
-                        grid_state=scene.grid_state, materials=scene.materials.view(np.uint8).reshape(-1), brick_status=scene.brick_status,
-                        brick_index=scene.brick_index, brick_occupancy=scene.brick_occupancy, brick_start_index=scene.brick_start_index,
-                        material_index=scene.material_index, active_bricks=np.int64(grid.active_bricks),
+    np.savez_compressed(os.path.join(OUT, "doom_scene.npz"), **parse_summary(v), **buffer_digests(scene),
+                        active_bricks=np.int64(grid.active_bricks),
                         push_constants=pc, oracle_rgba8=u, oracle_rgb32f=np.ascontiguousarray(f[:, :, :3]), **extra)
     print("doom.vox", v.size(0), v.xyzi(0).shape[0], "voxels;", grid.active_bricks, "bricks;", c)
     m = vox.load(os.path.join(MODELS, "monu10.vox"), strict=False)

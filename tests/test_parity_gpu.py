@@ -624,3 +624,44 @@ def test_product_build_refuses_development_variants():
             W.make_renderer(w, grid, kernel_variant=variant)
         assert e.value.code == L.VRT_E_INVALID_ARG and "development" in str(e.value)
     assert L.lib.vrt_compiled_kernel_count() <= 40
+
+
+@pytest.mark.parametrize("variant,bounces", [(0, 0), (0, 2), (PATH, 2)])
+def test_start_index_shortcut_only_when_the_pattern_holds(variant, bounces):
+    """comp:422 reads a brick's start index from binding 6.  The reference's allocator hands out B^3 material entries per brick in
+    slot order (MaterialAllocator.zig:39), so the entry is slot * B^3 — the library checks that on every upload of binding 6 and
+    then multiplies instead of loading (TraceParams::start_is_slot).  A host is free to upload anything else: here the material
+    blocks of random pairs of bricks are swapped (start indices and material bytes; the scene means the same), some entries carry
+    the ignored top bit (quirk 7) — the check must fail and the look-up must be taken: frames equal the oracle's on the uploaded
+    buffers, and equal the unswapped scene's frames."""
+    b = 8
+    w = W.Workload("t", 200, 120, 128, b, 2 if bounces else 1, bounces, True, 0.0)
+    grid = W.build_grid(w)
+    start = grid.array(L.BUF_BRICK_START_INDEX).copy()
+    mat = grid.array(L.BUF_MATERIAL_INDEX).copy()
+    used = np.flatnonzero(start != 0xFFFFFFFF)
+    assert used.size > 100 and np.array_equal(start[used] & 0x7FFFFFFF, used.astype(np.uint32) * b ** 3)   # the canonical pattern
+    rng = np.random.default_rng(9)
+    perm = rng.permutation(used)[:200].reshape(-1, 2)
+    for i, j in perm:
+        si, sj = int(start[i] & 0x7FFFFFFF), int(start[j] & 0x7FFFFFFF)
+        bi, bj = mat[si:si + b ** 3].copy(), mat[sj:sj + b ** 3].copy()
+        mat[si:si + b ** 3], mat[sj:sj + b ** 3] = bj, bi
+        start[i], start[j] = sj | 0x80000000, si           # (one of the two with the LOD bit the shader masks off)
+    frames = {}
+    for name in ("canonical", "swapped"):
+        rt = W.make_renderer(w, grid, want_float_output=True, **variant_kwargs(variant))
+        if name == "swapped":
+            rt.upload(L.BUF_BRICK_START_INDEX, 0, start)
+            rt.upload(L.BUF_MATERIAL_INDEX, 0, mat)
+        W.set_view(rt, "V2")
+        rt.draw()
+        frames[name] = (rt.read_rgba32f().copy(), rt.read_rgba8().copy())
+        pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+        rt.deinit()
+    scene = oracle_scene_from_grid(grid)
+    swapped = O.OracleScene(bytes(grid.device_state), scene.materials, scene.brick_status, scene.brick_index, scene.brick_occupancy, start, mat, b)
+    fo, uo, co = O.render(swapped, pc)
+    assert co["hits"] > 1000
+    for name in frames:
+        assert np.array_equal(frames[name][0].view(np.uint32), fo.view(np.uint32)) and np.array_equal(frames[name][1], uo), name

@@ -36,17 +36,20 @@ if os.path.exists(log):
         db = sqlite3.connect(f)
         d = [r[0] / 1e3 for r in db.execute("select duration from kernels where name like '%vrt_trace_kernel<%, false,%' or name like '%vrt_path_kernel<%' order by start")]
         steps, warmup = line["steps"], line["warmup"]
+        pre = line.get("precondition_frames", 0)
         views = line["config"]["views"] + line["config"].get("views_reported_only", [])
         settle = line["roofline"]["settle_frames"]
-        reps = max(8, steps // len(line["config"]["views"]))
+        reps = line["roofline"].get("timed_frames_per_view") or max(8, steps // len(line["config"]["views"]))
         timed = min(reps, 512)
-        head = 2 * len(views) + 2 + 2 * (warmup + steps)
+        # bench.py's launch sequence of the PRODUCT kernel: 2 counting contexts x views x 1 frame | 2 probe frames, pre-conditioning,
+        # warm-up, timed region | (single-stream leg) warm-up, timed region | per view: settle, `reps` back to back, min(reps, 512) timed
+        head = 2 * len(views) + 2 + pre + 2 * (warmup + steps)
         want = head + len(views) * (settle + reps + timed)
         print(f"\n## {len(d)} launches of the traversal kernel by bench.py phase (us)")
         if len(d) != want:
             print(f"   (expected {want} launches from the bench line; phase breakdown skipped)")
             continue
-        a = 2 * len(views) + 2
+        a = 2 * len(views) + 2 + pre
         main = d[a + warmup:a + warmup + steps]
         single = d[a + warmup + steps + warmup:a + 2 * (warmup + steps)]
         two = "1 frame(s) in flight" not in line["config"]["parallelism"]

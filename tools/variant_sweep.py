@@ -1,19 +1,22 @@
 #!/usr/bin/env python3
 """Kernel time per view of one workload under several kernel_variant values (single stream, HIP events).
-usage: variant_sweep.py <workload> <variant,variant,...> [frames] [views]"""
+usage: variant_sweep.py <workload> <variant[/tuning_flags],variant,...> [frames] [views]      (e.g. 0,0/0x20,0/0x60)
+environment: VRT_SWEEP_LIB = path of another build of the library (the development build for its variants)"""
 import sys
 sys.path.insert(0, ".")
 from zig_vulkan_amd import workloads as W
 
 name = sys.argv[1]
-variants = [int(v, 0) for v in sys.argv[2].split(",")]
+import os
+variants = [tuple(int(x, 0) for x in (v.split("/") + ["0"])[:2]) for v in sys.argv[2].split(",")]
+library = os.environ.get("VRT_SWEEP_LIB")
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 views = sys.argv[4].split(",") if len(sys.argv) > 4 else ["V0", "V1", "V2", "V1x", "VG"]
 w = W.WORKLOADS[name]
 grid = W.build_grid(w)
-for variant in variants:
+for variant, flags in variants:
     try:
-        rt = W.make_renderer(w, grid, kernel_variant=variant)
+        rt = W.make_renderer(w, grid, kernel_variant=variant, tuning_flags=flags, **({"library": library} if library else {}))
     except Exception as e:  # noqa: BLE001
         print(f"variant {variant:#x}: {e}")
         continue
@@ -23,5 +26,5 @@ for variant in variants:
         rt.draw(frames=max(2, frames // 2))
         rt.draw(frames=frames)
         out.append(f"{v} {rt.last_kernel_ms():9.3f}")
-    print(f"variant {variant:#010x} {rt.kernel_name():70s} " + "  ".join(out), flush=True)
+    print(f"variant {variant:#010x} flags {flags:#04x} {rt.kernel_name():44s} " + "  ".join(out), flush=True)
     rt.deinit()

@@ -39,6 +39,8 @@ hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint
 hipError_t launch_build_status_bytes(const TraceParams &p, hipStream_t stream);
 hipError_t launch_build_status_halfblocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_build_cell_bounds(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
+hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, hipStream_t stream);
+hipError_t launch_check_start_is_slot(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, hipStream_t stream);
 hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
                           void *out_f32, hipStream_t stream);
 hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per_pixel, uint32_t width, uint32_t height, uint32_t tiles_x,
@@ -178,6 +180,10 @@ struct vrt_ctx {
     int *d_cell_bounds = nullptr;    // derived: bounding box of the occupied cells (TraceParams::cell_bounds)
     uint8_t *d_status_bytes = nullptr; // derived: one byte per grid cell (TraceParams::status_bytes)
     uint32_t *d_status_halfblocks = nullptr; // derived: status bits by 4 x 4 x 2 cells per word (vrt_path_kernel on eligible grids)
+    uint8_t *d_cell_occupancy = nullptr;     // derived: occupancy bits by cell (TraceParams::cell_occupancy; vrt_path_kernel, within a memory budget)
+    uint32_t *d_start_is_slot = nullptr;     // derived: 1 = binding 6 holds slot * B^3 for every allocated brick (TraceParams::start_is_slot)
+    bool occupancy_dirty = true;             // bindings 3-5 changed since the by-cell copy was built
+    bool start_dirty = true;                 // binding 6 changed since it was checked
     vrt::TileOwnership own{};        // weighted tile ownership (period 0: tile t belongs to rank t % shard_count)
     bool status_dirty = true;        // brick_status changed since the derived copy was built
     size_t lds_bytes = 0;
@@ -254,6 +260,8 @@ void free_ctx(vrt_ctx *c) {
     if (c->d_cell_bounds) (void)hipFree(c->d_cell_bounds);
     if (c->d_status_bytes) (void)hipFree(c->d_status_bytes);
     if (c->d_status_halfblocks) (void)hipFree(c->d_status_halfblocks);
+    if (c->d_cell_occupancy) (void)hipFree(c->d_cell_occupancy);
+    if (c->d_start_is_slot) (void)hipFree(c->d_start_is_slot);
     if (c->dist) {
         Dist *d = c->dist;
         for (uint32_t i = 0; i < d->nslots; i++) {
@@ -738,6 +746,19 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
             VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_status_halfblocks), bytes_hb));
             VRT_CREATE_HIP(hipMemsetAsync(c->d_status_halfblocks, 0, bytes_hb, c->stream));
         }
+        // the by-cell copy of the occupancy bits, for the persistent-lane kernel (scenes larger than the caches, where a brick entry
+        // is a chain of dependent misses): at most 2 GiB, and — walked in global memory instead of LDS — a 32-bit bit index
+        const uint64_t by_cell_bytes = cells * (bits / 8u);
+        const bool lds_walk = cfg->brick_dimension == 8u && !(cfg->tuning_flags & VRT_TUNE_NO_PATH_BRICK_LDS);
+        if (any_kernel([](const vrt::KernelEntry &e) { return e.path != 0; }) && !(cfg->tuning_flags & VRT_TUNE_NO_CELL_OCCUPANCY) &&
+            by_cell_bytes <= (2ull << 30) && (lds_walk || cells * bits <= (1ull << 32))) {
+            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_cell_occupancy), by_cell_bytes + 64u));
+            VRT_CREATE_HIP(hipMemsetAsync(c->d_cell_occupancy, 0, by_cell_bytes + 64u, c->stream));
+        }
+        if (!(cfg->tuning_flags & VRT_TUNE_NO_START_SHORTCUT)) {
+            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_start_is_slot), 64u));
+            VRT_CREATE_HIP(hipMemsetAsync(c->d_start_is_slot, 0, 64u, c->stream));
+        }
         if (any_kernel([](const vrt::KernelEntry &e) { return (e.path && e.filter) || (!e.path && (e.mode == vrt::kStatusBlocked || e.mode == vrt::kStatusBlockedLds)); })) {
             const size_t nblocks = (size_t)nbx * nby * nbz;
             const size_t status_blocks_bytes = nblocks * 8u + ((nblocks + 31u) / 32u) * 4u + 16u;
@@ -805,6 +826,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.cell_bounds = c->d_cell_bounds;
     p.status_bytes = c->d_status_bytes;
     p.status_halfblocks = c->d_status_halfblocks;
+    p.cell_occupancy = c->d_cell_occupancy;
+    p.start_is_slot = c->d_start_is_slot;
     p.status_cells = (uint32_t)cells;
     // (order_auto: frames that alternate between the two streams of a frames_in_flight = 2 context take reverse raster (3)
     // instead, see do_dispatch and DESIGN.md §4)
@@ -853,6 +876,13 @@ uint64_t vrt_buffer_size(const vrt_ctx *ctx, vrt_buffer_id id) {
     return ctx->dsize[id];
 }
 
+// which derived structures a write to scene buffer `id` invalidates (rebuilt before the next frame, pre_dispatch)
+static void mark_dirty(vrt_ctx *ctx, vrt_buffer_id id) {
+    if (id == VRT_BUF_BRICK_STATUS) ctx->status_dirty = true;
+    if (id == VRT_BUF_BRICK_STATUS || id == VRT_BUF_BRICK_INDEX || id == VRT_BUF_BRICK_OCCUPANCY) ctx->occupancy_dirty = true;
+    if (id == VRT_BUF_BRICK_START_INDEX) ctx->start_dirty = true;
+}
+
 static int check_range(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, const void *src, uint64_t nbytes) {
     if (!ctx) return VRT_E_INVALID_ARG;
     if ((int)id < 0 || id >= VRT_BUF_COUNT) return fail(ctx, VRT_E_INVALID_ARG, "bad buffer id");
@@ -870,7 +900,7 @@ int vrt_upload(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, const void 
         // the kernel takes the UBO through its argument block; keep the host mirror current
         std::memcpy(reinterpret_cast<uint8_t *>(&ctx->params.grid) + byte_offset, src, (size_t)nbytes);
     }
-    if (id == VRT_BUF_BRICK_STATUS) ctx->status_dirty = true;
+    mark_dirty(ctx, id);
     return copy_h2d(ctx, static_cast<uint8_t *>(ctx->dbuf[id]) + byte_offset, src, nbytes);
 }
 
@@ -883,7 +913,7 @@ int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, cons
                                     ctx->stream));
         VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    if (id == VRT_BUF_BRICK_STATUS) ctx->status_dirty = true;
+    mark_dirty(ctx, id);
     const int rcb = begin_scene_write(ctx);
     if (rcb != VRT_OK) return rcb;
     VRT_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->dbuf[id]) + byte_offset, dev_src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -932,6 +962,15 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
         if (rcw != VRT_OK) return rcw;
         ctx->status_dirty = false;
     }
+    if ((ctx->occupancy_dirty && ctx->d_cell_occupancy) || (ctx->start_dirty && ctx->d_start_is_slot)) {
+        int rcw = begin_scene_write(ctx);
+        if (rcw != VRT_OK) return rcw;
+        if (ctx->occupancy_dirty) VRT_HIP(ctx, vrt::launch_build_cell_occupancy(ctx->params, ctx->cfg.brick_dimension, ctx->cfg.brick_alloc, ctx->stream));
+        if (ctx->start_dirty) VRT_HIP(ctx, vrt::launch_check_start_is_slot(ctx->params, ctx->cfg.brick_dimension, ctx->cfg.brick_alloc, ctx->stream));
+        rcw = end_scene_write(ctx);
+        if (rcw != VRT_OK) return rcw;
+    }
+    ctx->occupancy_dirty = ctx->start_dirty = false;
     // max_bounce <= 1 ("only primary ray" + its shadow ray): the bounce loop runs at most once
     *fn = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? ctx->kernel_single1 : ctx->kernel_single) : ctx->kernel;
     return VRT_OK;
@@ -1571,7 +1610,7 @@ int vrt_dist_broadcast(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, uin
         VRT_HIP(ctx, hipMemcpyAsync(reinterpret_cast<uint8_t *>(&ctx->params.grid) + byte_offset, range, nbytes, hipMemcpyDeviceToHost, ctx->stream));
         VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    if (id == VRT_BUF_BRICK_STATUS) ctx->status_dirty = true;
+    mark_dirty(ctx, id);
     return end_scene_write(ctx);
 }
 

@@ -77,6 +77,14 @@ struct TraceParams {
     // derived from binding 3: one byte per grid cell, 1 = occupied (kVariantBytes: the walk loop reads the byte of the next cell)
     const uint8_t *status_bytes;
     uint32_t status_cells;               // grid cells = bytes of status_bytes
+    // derived from bindings 3-5 (vrt_path_kernel; nullptr: not built): the occupancy bits of every OCCUPIED cell's brick, stored by
+    // cell (cell * B^3 / 8 bytes) — a brick entry then needs no brick_index look-up before it can ask for the brick's bits
+    // (comp:337 -> comp:415 is one dependent miss less; the index is fetched only when a solid voxel was found)
+    const uint8_t *cell_occupancy;
+    // derived from binding 6: *start_is_slot == 1 when every allocated brick's start index is slot * B^3 — the pattern the
+    // reference's allocator produces (MaterialAllocator.zig:39 hands out B^3 entries per brick in slot order) — so that comp:422's
+    // look-up is replaced by a multiplication; nullptr or 0: look it up
+    const uint32_t *start_is_slot;
     // derived, device-built copy of brick_status: one 64-bit word per 4x4x4 block of grid cells,
     // block index bx + nbx*(bz + nbz*by), bit (x&3) + 4*(z&3) + 16*(y&3)  (x, z, y order as comp:318)
     const uint2 *status_blocks;

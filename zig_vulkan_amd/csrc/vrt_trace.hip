@@ -71,6 +71,30 @@ __global__ __launch_bounds__(256) void vrt_build_status_bytes(const uint32_t *__
     }
 }
 
+// The occupancy bits of every occupied cell's brick, stored by cell (TraceParams::cell_occupancy): one thread per 8-byte word of
+// the copy; words8 = B^3 / 64 words per brick.  Cells whose status bit is clear are never read by the kernels and are left alone.
+__global__ __launch_bounds__(256) void vrt_build_cell_occupancy(const uint32_t *__restrict__ status, const uint32_t *__restrict__ brick_index,
+                                                                const uint2 *__restrict__ occupancy, uint2 *__restrict__ out, uint32_t cells,
+                                                                uint32_t words8, uint64_t brick_alloc) {
+    const uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t cell = w / words8;
+    if (cell >= cells) return;
+    if (!((status[cell >> 5] >> (cell & 31u)) & 1u)) return;
+    const uint32_t slot = brick_index[cell];
+    if (slot >= brick_alloc) return; // (malformed scene: the shader would read outside binding 5)
+    out[w] = occupancy[(uint64_t)slot * words8 + (w % words8)];
+}
+
+// *flag = 1 iff every brick's start index (binding 6) is either unset (0xFFFFFFFF) or slot * bits in its low 31 bits
+// (TraceParams::start_is_slot).  The flag is set to 1 before the launch; violators clear it.
+__global__ __launch_bounds__(256) void vrt_check_start_is_slot(const uint32_t *__restrict__ start, uint32_t *__restrict__ flag, uint64_t brick_alloc,
+                                                               uint32_t bits) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= brick_alloc) return;
+    const uint32_t v = start[i];
+    if (v != 0xFFFFFFFFu && (uint64_t)(v & 0x7FFFFFFFu) != i * bits) *flag = 0u;
+}
+
 // Bounding box of the occupied grid cells (TraceParams::cell_bounds), from the status bits of binding 3: one thread per
 // status word, six atomic maxima over {-x, -y, -z, x, y, z}; bounds[] starts as 0x80808080 (hipMemsetAsync 0x80).
 __global__ __launch_bounds__(256) void vrt_build_cell_bounds(const uint32_t *__restrict__ status, int *__restrict__ bounds, uint32_t words,
@@ -403,7 +427,7 @@ KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t varian
         if (mode == kStatusLinearAlways && !(variant & kVariantLockstepBounce)) {
             // bit 22: behind the LDS block filter (development build); min_waves 5: 96 VGPRs
             const bool filter = (variant & kVariantPathFilter) != 0u;
-            e = find_path_kernel(brick_dimension, mw == 5u ? 5 : ((mw == 6u && !filter) ? 6 : kDefaultMinWaves), filter, false);
+            e = find_path_kernel(brick_dimension, mw == 5u ? 5 : ((mw >= 6u && !filter) ? (int)mw : kDefaultMinWaves), filter, false);
         } else {
             e = find_trace_kernel(brick_dimension, false, mode, mw == 8u ? 8 : kDefaultMinWaves, 0, block);
         }
@@ -487,6 +511,26 @@ hipError_t launch_build_status_halfblocks(const TraceParams &p, uint32_t dim_x, 
     const uint32_t words = (dim_x >> 2) * (dim_z >> 2) * (dim_y >> 1);
     hipLaunchKernelGGL(vrt_build_status_halfblocks, dim3((words + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
                        const_cast<uint32_t *>(p.status_halfblocks), dim_x, dim_y, dim_z);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, hipStream_t stream) {
+    if (!p.cell_occupancy) return hipSuccess;
+    const uint32_t words8 = brick_dimension * brick_dimension * brick_dimension / 64u;
+    const uint64_t words = (uint64_t)p.status_cells * words8;
+    hipLaunchKernelGGL(vrt_build_cell_occupancy, dim3((uint32_t)((words + 255u) / 256u)), dim3(256), 0, stream, p.brick_status, p.brick_index,
+                       reinterpret_cast<const uint2 *>(p.brick_occupancy), reinterpret_cast<uint2 *>(const_cast<uint8_t *>(p.cell_occupancy)), p.status_cells,
+                       words8, brick_alloc);
+    return hipGetLastError();
+}
+
+hipError_t launch_check_start_is_slot(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, hipStream_t stream) {
+    if (!p.start_is_slot) return hipSuccess;
+    uint32_t *flag = const_cast<uint32_t *>(p.start_is_slot);
+    const hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flag), 1, 1, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(vrt_check_start_is_slot, dim3((uint32_t)((brick_alloc + 255u) / 256u)), dim3(256), 0, stream, p.brick_start_index, flag, brick_alloc,
+                       brick_dimension * brick_dimension * brick_dimension);
     return hipGetLastError();
 }
 

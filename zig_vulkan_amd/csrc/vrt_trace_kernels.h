@@ -583,8 +583,9 @@ VRT_DI f3 initial_side_dist(f3 fstep, f3 fposition, f3 ray_delta) {
 }
 
 struct RaySetup {
-    f3 ray_delta; // |1/dir|
-    f3 inv_dir;   // 1/dir (safeInverse), kept for the |abs|-modifier form of the hand-scheduled step
+    f3 inv_dir;   // 1/dir (safeInverse); ray_delta = |1/dir| (comp:295) is formed where it is used: |x| is a free source modifier of the
+                  // vector instructions, and three registers fewer stay live across both walks
+    VRT_DI f3 ray_delta() const { return abs3(inv_dir); }
     int entry_code; // slab-entry normal (comp:529-531): axis index | sign bits, see axis_normal()
     int sx, sy, sz;
     float grid_t_min, grid_t_max;
@@ -611,7 +612,6 @@ VRT_DI bool grid_slab(const TraceParams &p, const Ray &r, float t_min, float t_m
     s.entry_code = (iz ? 2 : (iy ? 1 : 0)) | (inv_i < 0.0f ? 4 : 0) | (!(inv_i < 0.0f) && !(inv_i > 0.0f) ? 8 : 0);
     s.grid_t_min = gl_max(t_min, tmin_i);
     s.grid_t_max = gl_min(t_max, gl_min(gl_min(t_maxes.x, t_maxes.y), t_maxes.z));
-    s.ray_delta = abs3(inv);
     s.inv_dir = inv;
     s.sx = (int)sign1(r.direction.x);
     s.sy = (int)sign1(r.direction.y);
@@ -663,7 +663,7 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
     const float voxel_scale = g_scale * brick_voxel_scale;
     const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
     Walk w;
-    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
+    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta());
     const int px = f2i_clamp(__builtin_floorf(fposition.x));
     const int py = f2i_clamp(__builtin_floorf(fposition.y));
     const int pz = f2i_clamp(__builtin_floorf(fposition.z));
@@ -738,7 +738,7 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
             }
         }
         // (after a hit this step is dead work, once per ray; its results are never read)
-        dda_step<false>(w, s.ray_delta, voxel_scale, axis, voxel_index, stride_x, stride_y, stride_z);
+        dda_step<false>(w, s.ray_delta(), voxel_scale, axis, voxel_index, stride_x, stride_y, stride_z);
         more = !found && min3i(w.rx, w.ry, w.rz) >= 0 && w.t_value <= local_t_max;
     }
     VRT_PROF_END(2, tp2);
@@ -756,7 +756,7 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
     const float voxel_scale = g_scale * brick_voxel_scale;
     const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
     Walk w;
-    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
+    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta());
     const int px = f2i_clamp(__builtin_floorf(fposition.x));
     const int py = f2i_clamp(__builtin_floorf(fposition.y));
     const int pz = f2i_clamp(__builtin_floorf(fposition.z));
@@ -784,7 +784,8 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
     // every request is a 128-byte line from HBM, and four of five brick walks of the path-trace configuration end without
     // a solid voxel (K = 3.2 bricks entered, H = 0.7 hits per ray).
     uint32_t brick_material_index = 0u;
-    if constexpr (EAGER) brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu;
+    const bool start_is_slot = p.start_is_slot != nullptr && __builtin_amdgcn_readfirstlane((int)*p.start_is_slot) != 0; // (TraceParams; wave-uniform)
+    if constexpr (EAGER) brick_material_index = start_is_slot ? brick_index * (uint32_t)(B * B * B) : (p.brick_start_index[brick_index] & 0x7FFFFFFFu);
     GridWalkRegs g;
     g.alive = __builtin_amdgcn_ballot_w64(more);
     g.out_x = 0ull;
@@ -801,7 +802,7 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
         if (__builtin_amdgcn_inverse_ballot_w64(g.occ)) {
             VRT_PROF_BEGIN(tp4);
             const uint32_t voxel_index = solid_bit - base;
-            if constexpr (!EAGER) brick_material_index = p.brick_start_index[brick_index] & 0x7FFFFFFFu;
+            if constexpr (!EAGER) brick_material_index = start_is_slot ? brick_index * (uint32_t)(B * B * B) : (p.brick_start_index[brick_index] & 0x7FFFFFFFu);
             const uint32_t mi = p.material_index[brick_material_index + voxel_index];
             const vrt_material *m = p.materials + mi;
             const uint32_t mtype = m->type;
@@ -834,15 +835,18 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
 // tools/path_profile.py).  A lane whose voxel is to be ignored (comp:427) walks on in the next pass.
 // LDS (8^3 bricks): the lane's brick is staged at LDS byte address wave_lds + 1024 c + 16 lane (c = 0..3) and walked there
 // (voxel_walk_park_lds_gfx950).
+// occ_slot: where the brick's bits lie, in bricks of the array `occupancy` — the brick's slot in binding 5, or (by_cell) the grid
+// cell in the by-cell copy TraceParams::cell_occupancy, in which case the slot (brick_index[cell], comp:337) is looked up only by
+// the lanes that have found a solid voxel.  start_is_slot: comp:422's look-up is slot * B^3 for every brick (TraceParams).
 template <int B, bool LDS = false>
-VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t brick_index, f3 brick_min, Hit &hit,
-                                   int axis_in, int &hit_axis, uint32_t wave_lds = 0u) {
+VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t occ_slot, uint32_t cell, bool by_cell,
+                                   bool start_is_slot, f3 brick_min, Hit &hit, int axis_in, int &hit_axis, uint32_t wave_lds = 0u) {
     static_assert(!LDS || B == 8, "the LDS layout is written for 64-byte bricks");
     const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
     const float voxel_scale = g_scale * brick_voxel_scale;
     const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
     Walk w;
-    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
+    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta());
     const int px = f2i_clamp(__builtin_floorf(fposition.x));
     const int py = f2i_clamp(__builtin_floorf(fposition.y));
     const int pz = f2i_clamp(__builtin_floorf(fposition.z));
@@ -852,25 +856,27 @@ VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const Ray
     w.rz = steps_left(s.sz, pz, B, kZeroBudget);
     w.t_value = 0;
     const float local_t_max = s.grid_t_max - hit.t;
-    const uint32_t base = brick_index * (uint32_t)(B * B * B);
+    // (staged in LDS, only the voxel's nine index bits are ever used: no base, and no 32-bit limit on cells * B^3 for the by-cell copy)
+    const uint32_t base = LDS ? 0u : occ_slot * (uint32_t)(B * B * B);
     uint32_t bit_index = base + ((uint32_t)px + (uint32_t)B * ((uint32_t)pz + (uint32_t)B * (uint32_t)py));
     const uint32_t stride_x = (uint32_t)s.sx, stride_y = (uint32_t)(s.sy * (B * B)), stride_z = (uint32_t)(s.sz * B);
     const bool more = more_init(px, py, pz, B) && (0.0f <= local_t_max); // comp:409 with t_value = 0
 
-    const unsigned long long occ_addr = (unsigned long long)p.brick_occupancy;
+    const uint8_t *const occupancy = by_cell ? p.cell_occupancy : p.brick_occupancy;
+    const unsigned long long occ_addr = (unsigned long long)occupancy;
     u32x4 rsrc;
     rsrc.x = (uint32_t)occ_addr;
     rsrc.y = (uint32_t)(occ_addr >> 32) | (4u << 16);
-    rsrc.z = p.occupancy_words;
+    rsrc.z = by_cell ? p.status_cells * (uint32_t)(B * B * B / 32) : p.occupancy_words; // (by_cell without LDS: vrt_create keeps cells * B^3 below 2^32)
     rsrc.w = 0x00020000u;
-    const uint32_t *occ_words = reinterpret_cast<const uint32_t *>(p.brick_occupancy);
+    const uint32_t *occ_words = reinterpret_cast<const uint32_t *>(occupancy);
     typedef __attribute__((address_space(3))) const uint32_t lds_u32;
     [[maybe_unused]] const uint32_t lane_base = wave_lds + ((threadIdx.x & 63u) << 4);
     uint32_t word;
     [[maybe_unused]] uint32_t eager_start = 0u;
     VRT_PROF_BEGIN(tp5);
     if constexpr (LDS) {
-        const uint32_t *src = occ_words + (size_t)brick_index * 16u;
+        const uint32_t *src = occ_words + (size_t)occ_slot * 16u;
         typedef __attribute__((address_space(3))) void lds_void;
         typedef const __attribute__((address_space(1))) void glb_void;
         lds_void *dst = reinterpret_cast<lds_void *>((size_t)__builtin_amdgcn_readfirstlane(wave_lds));
@@ -878,7 +884,7 @@ VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const Ray
         for (int c = 0; c < 4; c++)
             __builtin_amdgcn_global_load_lds((glb_void *)(src + 4 * c), (lds_void *)((__attribute__((address_space(3))) char *)dst + 1024 * c), 16, 0, 0);
         // (path_eager_start: the brick's start index travels with the four chunks instead of after the walk)
-        if (p.path_eager_start) eager_start = p.brick_start_index[brick_index];
+        if (p.path_eager_start) eager_start = p.brick_start_index[by_cell ? p.brick_index[cell] : occ_slot];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         word = reinterpret_cast<lds_u32 *>(0)[brick_lds_address(lane_base, bit_index) >> 2];
     } else {
@@ -907,7 +913,9 @@ VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const Ray
         VRT_PROF_BEGIN(tp4);
         if (parked) {
             const uint32_t voxel_index = solid_bit - base;
-            const uint32_t brick_material_index = ((LDS && p.path_eager_start) ? eager_start : p.brick_start_index[brick_index]) & 0x7FFFFFFFu; // comp:422
+            const uint32_t brick_index = by_cell ? p.brick_index[cell] : occ_slot; // comp:337, by the lanes that need it
+            const uint32_t brick_material_index = start_is_slot ? brick_index * (uint32_t)(B * B * B)
+                                                                : (((LDS && p.path_eager_start) ? eager_start : p.brick_start_index[brick_index]) & 0x7FFFFFFFu); // comp:422
             const uint32_t mi = p.material_index[brick_material_index + voxel_index];
             const vrt_material *m = p.materials + mi;
             const uint32_t mtype = m->type;
@@ -1007,7 +1015,7 @@ VRT_DI void skip_axis(Walk &w, const RaySetup &s, int need, float t, uint32_t &i
     const float t_strict = next_below(t); // c < t  <=>  c <= t_strict
     const int n1 = skip_merge_gfx950(comp3(w.side_dist, B1), comp3(s.inv_dir, B1), *r[B1], B1 > A ? t : t_strict);
     const int n2 = skip_merge_gfx950(comp3(w.side_dist, B2), comp3(s.inv_dir, B2), *r[B2], B2 > A ? t : t_strict);
-    comp3(w.side_dist, A) = t + comp3(s.ray_delta, A);
+    comp3(w.side_dist, A) = t + comp3(s.ray_delta(), A);
     *r[A] -= need;
     *r[B1] -= n1;
     *r[B2] -= n2;
@@ -1056,9 +1064,9 @@ VRT_DI void skip_empty_block(Walk &w, const RaySetup &s, uint32_t bx, uint32_t b
         const float t = e == 1 ? sd : (e == 2 ? a1 : (e == 3 ? a2 : a3));
         return step != 0 ? t : __builtin_inff(); // an axis the ray does not move along is never crossed
     };
-    const float tx = exit_distance(w.side_dist.x, s.ray_delta.x, ex, s.sx);
-    const float ty = exit_distance(w.side_dist.y, s.ray_delta.y, ey, s.sy);
-    const float tz = exit_distance(w.side_dist.z, s.ray_delta.z, ez, s.sz);
+    const float tx = exit_distance(w.side_dist.x, s.ray_delta().x, ex, s.sx);
+    const float ty = exit_distance(w.side_dist.y, s.ray_delta().y, ey, s.sy);
+    const float tz = exit_distance(w.side_dist.z, s.ray_delta().z, ez, s.sz);
     const bool az = tz <= tx && tz <= ty, ay = !az && ty <= tx, ax = !az && !ay;
     const float t = ax ? tx : (ay ? ty : tz);
     const float t_strict = next_below(t); // c < t  <=>  c <= t_strict
@@ -1075,12 +1083,12 @@ VRT_DI void skip_empty_block(Walk &w, const RaySetup &s, uint32_t bx, uint32_t b
     };
     float cx = w.side_dist.x, cy = w.side_dist.y, cz = w.side_dist.z;
     int nx = 0, ny = 0, nz = 0;
-    consume(cx, s.ray_delta.x, ax ? never : t_strict, nx);
-    consume(cy, s.ray_delta.y, ay ? never : (ax ? t : t_strict), ny);
-    consume(cz, s.ray_delta.z, az ? never : t, nz);
-    w.side_dist.x = ax ? t + s.ray_delta.x : cx;
-    w.side_dist.y = ay ? t + s.ray_delta.y : cy;
-    w.side_dist.z = az ? t + s.ray_delta.z : cz;
+    consume(cx, s.ray_delta().x, ax ? never : t_strict, nx);
+    consume(cy, s.ray_delta().y, ay ? never : (ax ? t : t_strict), ny);
+    consume(cz, s.ray_delta().z, az ? never : t, nz);
+    w.side_dist.x = ax ? t + s.ray_delta().x : cx;
+    w.side_dist.y = ay ? t + s.ray_delta().y : cy;
+    w.side_dist.z = az ? t + s.ray_delta().z : cz;
     nx = ax ? ex : nx;
     ny = ay ? ey : ny;
     nz = az ? ez : nz;
@@ -1120,7 +1128,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
     const f3 fposition = p.scale_pow2 ? (ray_at(r, global_t_value) - g_min) * p.inv_grid_scale : (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
     Walk w;
-    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
+    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta());
     const int px = f2i_clamp(__builtin_floorf(fposition.x));
     const int py = f2i_clamp(__builtin_floorf(fposition.y));
     const int pz = f2i_clamp(__builtin_floorf(fposition.z));
@@ -1310,7 +1318,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
                 }
             }
             if (state == 3) {
-                dda_step<true>(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
+                dda_step<true>(w, s.ray_delta(), g_scale, axis, grid_index, stride_x, stride_y, stride_z);
                 state = (min3i(w.rx, w.ry, w.rz) >= 0) ? 0 : 2;
             }
         }
@@ -1335,7 +1343,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
             const bool occupied = status_bit(word, grid_index);
             const float t_here = w.t_value; // crossed distance of the step INTO the current cell
             int axis_here = axis;
-            dda_step<true>(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
+            dda_step<true>(w, s.ray_delta(), g_scale, axis, grid_index, stride_x, stride_y, stride_z);
             const bool inside = min3i(w.rx, w.ry, w.rz) >= 0;
             word = inside ? p.brick_status[grid_index >> 5] : 0u;
             if (occupied) {
@@ -1396,7 +1404,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     } else {
         while (more) { // single-exit loop, see brick_walk
             if (cell_occupied()) enter_brick();
-            dda_step<true>(w, s.ray_delta, g_scale, axis, grid_index, stride_x, stride_y, stride_z);
+            dda_step<true>(w, s.ray_delta(), g_scale, axis, grid_index, stride_x, stride_y, stride_z);
             more = (min3i(w.rx, w.ry, w.rz) | stop) >= 0;
         }
         return stop == -1;
@@ -1451,17 +1459,24 @@ VRT_DI f3 ray_color_single(const TraceParams &p, const PushConstants &pc, const 
     int loop_count = 0;
     Hit hit;
     if (pc.cam.max_bounce > 0 && grid_hit<B, COUNT, MODE>(p, lds_filter, ray, hit, c)) {
-        const vrt_material *m = p.materials + hit.index;
-        const uint32_t mtype = m->type;
-        const f3 attenuation = mk3(m->albedo_r, m->albedo_g, m->albedo_b);
-        loop_count = (mtype <= MAT_DIELECTRIC) ? 1 : 0; // unknown type: loop_count -= 1 (comp:235-238)
+        // (the material record is read AFTER the shadow ray: only its index stays live across the second walk — three registers
+        // fewer at the kernel's point of highest pressure; the record sits in the scalar / L1 cache)
+        const uint32_t material = hit.index;
+        bool lit = true;
         if (sun_enabled) {
             const f3 sun_position = mk3(pc.sun.position[0], pc.sun.position[1], pc.sun.position[2]);
             const f3 rv = rand_vec3_range(ray.direction.x + ray.direction.z, ray.direction.y + ray.direction.z, -pc.sun.radius,
                                           pc.sun.radius);
             const Ray shadow_ray = create_ray(hit.point, (sun_position + rv) - hit.point);
             Hit shadow_hit;
-            if (!grid_hit<B, COUNT, MODE>(p, lds_filter, shadow_ray, shadow_hit, c)) color = color + attenuation * sun_color;
+            lit = !grid_hit<B, COUNT, MODE>(p, lds_filter, shadow_ray, shadow_hit, c);
+        }
+        const vrt_material *m = p.materials + material;
+        const uint32_t mtype = m->type;
+        const f3 attenuation = mk3(m->albedo_r, m->albedo_g, m->albedo_b);
+        loop_count = (mtype <= MAT_DIELECTRIC) ? 1 : 0; // unknown type: loop_count -= 1 (comp:235-238)
+        if (sun_enabled) {
+            if (lit) color = color + attenuation * sun_color;
         } else {
             color = color + attenuation;
         }
@@ -1830,6 +1845,10 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
     // the status word of a cell, in the layout the walk loop reads
     auto status_word = [&](uint32_t index) { return halfblocks ? p.status_halfblocks[halfblock_word(hb, index)] : p.brick_status[index >> 5]; };
 
+    // the by-cell copy of the occupancy bits and the start-index shortcut (derived structures, TraceParams), wave-uniform
+    const bool by_cell = p.cell_occupancy != nullptr;
+    const bool start_is_slot = p.start_is_slot != nullptr && __builtin_amdgcn_readfirstlane((int)*p.start_is_slot) != 0;
+
     // ---- per-lane state ----
     int st = kLaneFetch;
     uint32_t work = 0u;          // pixel: index into this context's tiles, 256 per tile, 8x8 blocks inside
@@ -1852,7 +1871,7 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
     bool scattered_ok = false;
     // the walk (grid_hit's locals)
     RaySetup s;
-    s.ray_delta = s.inv_dir = mk3(1, 1, 1);
+    s.inv_dir = mk3(1, 1, 1);
     s.entry_code = 0;
     s.sx = s.sy = s.sz = 0;
     s.grid_t_min = s.grid_t_max = 0.0f;
@@ -2058,7 +2077,7 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                 if (grid_slab(p, r, 0.00001f, t_max, s)) {
                     const float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
                     const f3 fposition = p.scale_pow2 ? (ray_at(r, global_t_value) - g_min) * p.inv_grid_scale : (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
-                    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta);
+                    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta());
                     const int px = f2i_clamp(__builtin_floorf(fposition.x));
                     const int py = f2i_clamp(__builtin_floorf(fposition.y));
                     const int pz = f2i_clamp(__builtin_floorf(fposition.z));
@@ -2165,13 +2184,13 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                 const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min);  // comp:331
                 const float global_t_value = g.t_in * g_scale + s.grid_t_min + 0.01f * g_scale;          // comp:347 (deferred) + comp:332
                 hit.t = global_t_value;
-                const uint32_t brick_index = p.brick_index[cell]; // comp:337
+                const uint32_t occ_slot = by_cell ? cell : p.brick_index[cell]; // comp:337 (by_cell: only on a solid voxel)
                 bool hit_voxel;
                 if constexpr (B == 8) {
-                    hit_voxel = p.path_brick_lds ? brick_walk_park_gfx950<B, true>(p, r, s, g_scale, brick_index, brick_min, hit, a, hit_axis, wave_lds)
-                                                 : brick_walk_park_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, a, hit_axis);
+                    hit_voxel = p.path_brick_lds ? brick_walk_park_gfx950<B, true>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis, wave_lds)
+                                                 : brick_walk_park_gfx950<B>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis);
                 } else {
-                    hit_voxel = brick_walk_park_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, a, hit_axis);
+                    hit_voxel = brick_walk_park_gfx950<B>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis);
                 }
                 if (hit_voxel) {
                     found = true;

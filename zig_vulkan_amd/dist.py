@@ -50,7 +50,9 @@ def broadcast_grid_delta(grid, upload, rank: int, root: int = 0, group=None) -> 
     host BrickGrid reach every rank's device buffers.  Root packs its dirty ranges (Grid.zig:129-194) as (buffer id, byte
     offset, bytes), one broadcast_object_list carries them, and EVERY rank — root too — applies them with `upload(buffer_id,
     byte_offset, uint8 array)` (VoxelRT.upload); root's deltas are reset as VoxelRT.updateGridDelta does (VoxelRT.zig:107-172).
-    Collective; any backend.  Returns the ranges applied as (buffer id, byte offset, bytes)."""
+    Collective; any backend.  Returns the ranges applied as (buffer id, byte offset, bytes).
+    Only the DEVICE replicas are brought up to date: the host BrickGrid objects of the other ranks are not edited (a host that wants
+    them in step applies the same edits to them, or keeps no grid at all on those ranks — the renderer needs none after the upload)."""
     import torch.distributed as dist
     from . import _lib as L
     # the five buffers BrickGrid tracks deltas for, with their element sizes
@@ -61,8 +63,9 @@ def broadcast_grid_delta(grid, upload, rank: int, root: int = 0, group=None) -> 
         for buf_id, es in tracked:
             active, a, b = grid.delta(buf_id)
             if active and b > a:
-                data = np.ascontiguousarray(grid.array(buf_id)).view(np.uint8).reshape(-1)
-                pieces.append((buf_id, a * es, data[a * es:b * es].tobytes()))
+                # (a view of the host array: only the dirty range is copied, not the whole buffer — gigabytes on the large grids)
+                view = grid.array_view(buf_id).view(np.uint8).reshape(-1)
+                pieces.append((buf_id, a * es, view[a * es:b * es].tobytes()))
         box[0] = pieces
     dist.broadcast_object_list(box, src=root, group=group)
     for buf_id, off, payload in box[0]:
