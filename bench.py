@@ -806,7 +806,9 @@ def main(argv=None) -> None:
         rt1 = leg.rt
         leg.run(args.warmup)
         single = leg.timed(args.steps) / args.steps * 1e3
-        reps = max(100, args.steps // len(VIEW_ORDER))   # >= 100 timed frames per view, whatever --steps says
+        # >= 100 timed frames per view, whatever --steps says — as long as a view's leg stays within about ten
+        # seconds (frames of the 2048^3 path trace take 0.15 s each: 100 of them per view and pass would be minutes)
+        reps = max(args.steps // len(VIEW_ORDER), min(100, max(8, int(5000.0 / frame_ms_est))))
         kernel_ms_view, frame_stats = {}, {}
         for v in all_views:
             leg.set_cam(v)
