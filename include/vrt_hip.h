@@ -152,7 +152,8 @@ typedef struct vrt_config {
 #define VRT_TUNE_DIST_NO_BROADCAST  (1u << 4) /* vrt_dist_broadcast as grouped send / recv from the root (every rank alike) */
 #define VRT_TUNE_NO_CELL_OCCUPANCY  (1u << 5) /* vrt_path_kernel: reach a brick's bits through brick_index instead of the by-cell copy */
 #define VRT_TUNE_NO_START_SHORTCUT  (1u << 6) /* always look brick_start_index up, even when it is slot * B^3 for every brick */
-#define VRT_TUNE_ALL                0x7Fu
+#define VRT_TUNE_PATH_AHEAD          (1u << 7) /* development build only: vrt_path_kernel's walk loop pipelined two trips ahead (measured slower) */
+#define VRT_TUNE_ALL                0xFFu
 
 typedef struct vrt_ctx vrt_ctx;
 

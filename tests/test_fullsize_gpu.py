@@ -288,6 +288,10 @@ def test_path_kernel_memory_layouts_change_no_pixel():
             assert np.array_equal(a, b), (flags, v)
     for v, a, b in zip(views, base, _frames_with_flags(w, views, 0, kernel_variant=1 << 21)):
         assert np.array_equal(a, b), ("lockstep", v)
+    if dev_library_or_none():  # the two-trips-ahead walk loop lives in the development build
+        for flags in (L.TUNE_PATH_AHEAD, L.TUNE_PATH_AHEAD | L.TUNE_NO_CELL_OCCUPANCY | L.TUNE_NO_PATH_BRICK_LDS | L.TUNE_NO_SKIP_TO_BOX):
+            for v, a, b in zip(views, base, _frames_with_flags(w, views, flags, kernel_variant=path, library=dev_library_or_none())):
+                assert np.array_equal(a, b), ("two trips ahead", flags, v)
     if dev_library_or_none():  # the block-skipping walk lives in the development build
         for v, a, b in zip(views, base, _frames_with_flags(w, views, 0, **variant_kwargs(path | (1 << 22)))):
             assert np.array_equal(a, b), ("block-skipping walk", v)

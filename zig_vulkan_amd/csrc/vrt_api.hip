@@ -26,6 +26,7 @@
 namespace vrt {
 KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, int shade);
 KernelFn path_kernel_halfblock_twin(KernelFn fn);
+KernelFn path_kernel_ahead_twin(KernelFn fn);
 bool is_path_halfblock_kernel(KernelFn fn);
 const char *kernel_name_of(KernelFn fn);
 uint32_t resolve_variant(uint32_t variant);
@@ -464,6 +465,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     const uint32_t shard_count = cfg->shard_count ? cfg->shard_count : 1u;
     if (cfg->shard_rank >= shard_count) return fail(nullptr, VRT_E_INVALID_ARG, "shard_rank >= shard_count");
     if (cfg->tuning_flags & ~VRT_TUNE_ALL) return fail(nullptr, VRT_E_INVALID_ARG, "unknown tuning_flags bit");
+#ifndef VRT_DEV_VARIANTS
+    if (cfg->tuning_flags & VRT_TUNE_PATH_AHEAD)
+        return fail(nullptr, VRT_E_INVALID_ARG, "VRT_TUNE_PATH_AHEAD selects a development kernel: not in the product build of libvrt_hip (make dev)");
+#endif
     if ((cfg->kernel_variant & 0xFFu) >= vrt::kVariantCount || ((cfg->kernel_variant >> 28) && ((cfg->kernel_variant >> 16) & 0xFu) != 7u)) return fail(nullptr, VRT_E_INVALID_ARG, "unknown kernel_variant");
 
     int ndev = 0;
@@ -726,7 +731,9 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     auto select_all = [&]() {
         const bool cnt = cfg->enable_counters != 0;
         c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cnt, c->bounce_variant, 0);
-        if (want_halfblocks) c->kernel = vrt::path_kernel_halfblock_twin(c->kernel);
+        const bool ahead = (cfg->tuning_flags & VRT_TUNE_PATH_AHEAD) != 0u; // (development build: the product holds no such kernel)
+        if (ahead) c->kernel = vrt::path_kernel_ahead_twin(c->kernel);
+        else if (want_halfblocks) c->kernel = vrt::path_kernel_halfblock_twin(c->kernel);
         c->kernel_lockstep = vrt::select_trace_kernel((int)cfg->brick_dimension, cnt, lockstep_variant, 0);
         c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cnt, single_variant, 1);
         c->kernel_single1 = vrt::select_trace_kernel((int)cfg->brick_dimension, cnt, single_variant, 2);
@@ -735,7 +742,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
             c->product[shade] = nullptr;
             if (!cnt) continue;
             c->product[shade] = vrt::select_trace_kernel((int)cfg->brick_dimension, false, shade == 0 ? c->bounce_variant : single_variant, shade);
-            if (shade == 0 && want_halfblocks) c->product[shade] = vrt::path_kernel_halfblock_twin(c->product[shade]);
+            if (shade == 0 && ahead) c->product[shade] = vrt::path_kernel_ahead_twin(c->product[shade]);
+            else if (shade == 0 && want_halfblocks) c->product[shade] = vrt::path_kernel_halfblock_twin(c->product[shade]);
         }
     };
     select_all();

@@ -8,6 +8,10 @@ const KernelEntry kEntries[] = {
     VRT_PATH_ENTRY(4, 5, false, false), VRT_PATH_ENTRY(4, 5, false, true),
     VRT_PATH_ENTRY(8, 5, false, false), VRT_PATH_ENTRY(8, 5, false, true),
 #ifdef VRT_DEV_VARIANTS
+    // AHEAD: the walk loop pipelined two trips ahead, on the shader's linear status words (round 3; measured 12 % slower than the
+    // one-trip-ahead loop on the same words, 176 vs 157 ms on the 2048^3 path trace: the walk is bound by the L1's rate of scattered
+    // requests, not by the latency of the one word a lane has in flight — DESIGN.md §4)
+    VRT_PATH_ENTRY_S(4, 5, false, false, true), VRT_PATH_ENTRY_S(8, 5, false, false, true),
     VRT_PATH_ENTRY(4, 4, false, false), VRT_PATH_ENTRY(4, 4, false, true), VRT_PATH_ENTRY(8, 4, false, false), VRT_PATH_ENTRY(8, 4, false, true),
     VRT_PATH_ENTRY(4, 6, false, false), VRT_PATH_ENTRY(8, 6, false, false), VRT_PATH_ENTRY(8, 6, false, true),
     VRT_PATH_ENTRY(8, 7, false, false), VRT_PATH_ENTRY(8, 7, false, true), VRT_PATH_ENTRY(8, 8, false, false), VRT_PATH_ENTRY(8, 8, false, true),

@@ -25,7 +25,7 @@ enum StatusMode : int {
 struct KernelEntry {
     KernelFn fn;
     const char *name;
-    uint8_t path;      // 0: vrt_trace_kernel<B, COUNT, MODE, MIN_WAVES, SHADE, BLOCK>   1: vrt_path_kernel<B, MIN_WAVES, FILTER, HALF>
+    uint8_t path;      // 0: vrt_trace_kernel<B, COUNT, MODE, MIN_WAVES, SHADE, BLOCK>   1: vrt_path_kernel<B, MIN_WAVES, FILTER, HALF, AHEAD>
     uint8_t b;         // brick dimension
     uint8_t count;     // trace: counting build
     uint8_t mode;      // trace: StatusMode
@@ -34,6 +34,7 @@ struct KernelEntry {
     uint16_t block;    // trace: threads per workgroup (256; 512 for the two-tiles-per-LDS-copy development variant)
     uint8_t filter;    // path: block-skipping walk behind the LDS block filter (development)
     uint8_t half;      // path: walk loop on half-block words
+    uint8_t ahead;     // path: the walk loop pipelined two trips ahead (on the shader's linear words)
 };
 struct KernelTable {
     const KernelEntry *entries;
@@ -45,7 +46,7 @@ KernelTable inst_trace_count();
 KernelTable inst_path();
 
 const KernelEntry *find_trace_kernel(int b, bool count, int mode, int min_waves, int shade, int block = 256);
-const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half);
+const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead = false);
 const KernelEntry *kernel_entry_of(KernelFn fn);
 int compiled_kernel_count();
 

@@ -369,8 +369,10 @@ const KernelEntry *find_trace_kernel(int b, bool count, int mode, int min_waves,
         return !e.path && e.b == b && (e.count != 0) == count && e.mode == mode && e.min_waves == min_waves && e.shade == shade && e.block == block;
     });
 }
-const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half) {
-    return find_entry([&](const KernelEntry &e) { return e.path && e.b == b && e.min_waves == min_waves && (e.filter != 0) == filter && (e.half != 0) == half; });
+const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead) {
+    return find_entry([&](const KernelEntry &e) {
+        return e.path && e.b == b && e.min_waves == min_waves && (e.filter != 0) == filter && (e.half != 0) == half && (e.ahead != 0) == ahead;
+    });
 }
 const KernelEntry *kernel_entry_of(KernelFn fn) {
     return find_entry([&](const KernelEntry &e) { return e.fn == fn; });
@@ -461,8 +463,15 @@ bool is_path_kernel(KernelFn fn) {
 // the same kernel with the walk loop on half-block words (TraceParams::status_halfblocks); fn itself if it has none
 KernelFn path_kernel_halfblock_twin(KernelFn fn) {
     const KernelEntry *e = kernel_entry_of(fn);
-    if (!e || !e->path || e->filter || e->half) return fn;
+    if (!e || !e->path || e->filter || e->half || e->ahead) return fn;
     const KernelEntry *t = find_path_kernel(e->b, e->min_waves, false, true);
+    return t ? t->fn : fn;
+}
+// the plain path kernel's twin with the walk loop two trips ahead; fn itself if it has none
+KernelFn path_kernel_ahead_twin(KernelFn fn) {
+    const KernelEntry *e = kernel_entry_of(fn);
+    if (!e || !e->path || e->half || e->filter || e->ahead) return fn;
+    const KernelEntry *t = find_path_kernel(e->b, e->min_waves, false, false, true);
     return t ? t->fn : fn;
 }
 bool is_path_halfblock_kernel(KernelFn fn) {

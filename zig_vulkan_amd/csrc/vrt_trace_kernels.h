@@ -550,6 +550,143 @@ VRT_DI uint32_t halfblock_word(const HalfBlockConsts &hb, uint32_t index) {
 #undef VRT_PARK_WALK_ASM
 #undef VRT_PARK_WALK_OPERANDS
 #undef VRT_PARK_WALK_INPUTS
+// ---- the park loop pipelined TWO trips ahead (vrt_path_kernel<AHEAD>) ---------------------------------------------------------
+// The loops above keep ONE status word in flight per lane: the word of the next cell is requested a trip ahead, and on a scene
+// larger than the caches a wave then waits ~670 cycles per trip for it (tools/path_profile.py: 13 400 cycles per call of ~20 trips,
+// 27 vector instructions per trip, 5 waves per SIMD).  Here the DDA runs two cells ahead of the test: a lane carries a ring of three
+// cells (q0, q1, q2) with their words (w0, w1, w2) and the crossed distances of the steps INTO them (ts0, ts1, ts2); a trip rotates
+// the ring, takes the step out of q1 into the new q2, requests q2's word, waits until at most TWO requests are outstanding — i.e.
+// for the word of q0, asked for two trips ago — and tests q0.  Per lane the sequence of DDA operations is the shader's (comp:345-372),
+// run two steps early.  What that takes:
+//   * a lane whose q0 is occupied PARKS as it is: ring and DDA state stay, the caller walks the brick of q0 (entered through the axis
+//     in `hist` bits 4-5 at distance ts0; the counters of q0 = the current ones with the two later steps' decrements undone) and, if
+//     the brick holds nothing for the ray, the lane simply walks on: its next trip rotates q1 into place.  No roll-back, no re-request;
+//   * a step that leaves the box of the occupied cells puts the SENTINEL ~0 into q2, and so does every later step (q1 == ~0): the
+//     word index of ~0 lies outside the buffer, its word reads 0, its test fails, and when the sentinel reaches q0 the lane has tested
+//     every cell up to the box's face and leaves (`left`).  The cells a lane would "enter" beyond the face are thus never tested
+//     (at a face of the grid the next linear index would be a real cell of the next row);
+//   * `hist`: two bits per step, the axis of the step into q2 in bits 0-1, into q1 in bits 2-3, into q0 in bits 4-5 (3: q0 was entered
+//     without a step — the slab test — at the start of a ray).
+// Canonical state between calls, for every lane: [q0 tested, q1 next to be tested, q2 newest], the DDA state (side distances,
+// counters) that of q2, w1 / w2 arrived.  A new ray is primed in C++ with one step (path kernel, START).
+struct AheadWalkRegs {
+    unsigned long long alive;  // in: lanes to walk; out: lanes still moving when the call ended
+    unsigned long long parked; // out: lanes whose q0 is occupied
+    unsigned long long left;   // out: lanes that have tested every cell up to the face of the box
+    uint32_t batch;            // in: the call returns once this many lanes are parked (or nobody is moving)
+    uint32_t min_alive;        // in: ... or, at the back edge, once fewer than this many lanes are still moving
+};
+// The words travel in THREE registers used in turn (a register with a request in flight cannot be moved): trip k of the unrolled
+// body (k = 0, 1, 2) requests into W[k] and tests W[(k + 1) % 3].  A lane leaves the loop after some trip k — parked, or still
+// moving when the call ends — and `phase` records that k; the caller then puts word(q1) into w1 and word(q2) into w2
+// (AheadRing::settle), which is where trip 0 of the next call expects them.  The cells and distances are moved (computed values).
+struct AheadRing {
+    uint32_t q0, q1, q2, w0, w1, w2, hist, phase;
+    float ts0, ts1, ts2;
+    VRT_DI void settle() { // after a call: phase k -> word(q1) is in W[(k + 2) % 3], word(q2) in W[k]
+        const uint32_t a = phase == 0u ? w2 : (phase == 1u ? w0 : w1), b = phase == 0u ? w0 : (phase == 1u ? w1 : w2);
+        w1 = a;
+        w2 = b;
+        phase = 2u;
+    }
+};
+#define VRT_AHEAD_TRIP(WL, WT, K, NEXT)                                                        \
+        /* rotate the cells and the crossed distances */                                        \
+        "v_mov_b32_e32 %[q0], %[q1]\n\t"                                                        \
+        "v_mov_b32_e32 %[q1], %[q2]\n\t"                                                        \
+        "v_mov_b32_e32 %[ts0], %[ts1]\n\t"                                                      \
+        "v_mov_b32_e32 %[ts1], %[ts2]\n\t"                                                      \
+        /* the step out of q1 (comp:345-372), as in VRT_TRIP_T */                               \
+        "v_min3_f32 %[ts2], %[sdx], %[sdy], %[sdz]\n\t"                                         \
+        "v_cmp_eq_f32_e64 %[mxy], %[sdz], %[ts2]\n\t"                                           \
+        "v_cmp_eq_f32_e64 %[my], %[sdy], %[ts2]\n\t"                                            \
+        "s_andn2_b64 %[my], %[my], %[mxy]\n\t"                                                  \
+        "s_andn2_b64 %[mxy], exec, %[mxy]\n\t"                                                  \
+        "s_andn2_b64 %[mx], %[mxy], %[my]\n\t"                                                  \
+        "s_mov_b64 %[ex], exec\n\t"                                                             \
+        "s_mov_b64 exec, %[mx]\n\t"                                                             \
+        "v_add_f32_e64 %[sdx], %[sdx], |%[ix]|\n\t"                                             \
+        "s_mov_b64 exec, %[my]\n\t"                                                             \
+        "v_add_f32_e64 %[sdy], %[sdy], |%[iy]|\n\t"                                             \
+        "s_andn2_b64 exec, %[ex], %[mxy]\n\t"                                                   \
+        "v_add_f32_e64 %[sdz], %[sdz], |%[iz]|\n\t"                                             \
+        "s_mov_b64 exec, %[ex]\n\t"                                                             \
+        "v_cndmask_b32_e64 %[t1], 2, 1, %[my]\n\t"                                              \
+        "v_cndmask_b32_e64 %[t1], %[t1], 0, %[mx]\n\t"                                          \
+        "v_lshl_or_b32 %[hist], %[hist], 2, %[t1]\n\t"                                          \
+        "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[my]\n\t"                                    \
+        "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[mx]\n\t"                                     \
+        "v_add_u32_e32 %[t2], %[q1], %[t0]\n\t"                                                 \
+        "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[mx]\n\t"                                \
+        "v_subbrev_co_u32_e64 %[ry], %[by], 0, %[ry], %[my]\n\t"                                \
+        "v_addc_co_u32_e64 %[rz], %[cz], -1, %[rz], %[mxy]\n\t"                                 \
+        "s_or_b64 %[ex], %[ex], %[by]\n\t"                                                      \
+        "s_orn2_b64 %[ex], %[ex], %[cz]\n\t"    /* z: carry-out 0 = borrow; the step left the box ... */ \
+        "v_cmp_eq_u32_e64 %[by], -1, %[q1]\n\t" /* ... or an earlier one did */                  \
+        "s_or_b64 %[ex], %[ex], %[by]\n\t"                                                      \
+        "v_cndmask_b32_e64 %[q2], %[t2], -1, %[ex]\n\t"                                         \
+        /* q2's word; the word of q0, asked for two trips ago, has arrived when at most two requests are outstanding */ \
+        "v_lshrrev_b32_e32 %[t0], 5, %[q2]\n\t"                                                 \
+        "buffer_load_dword %[" WL "], %[t0], %[rsrc], 0 idxen\n\t"                              \
+        "s_waitcnt vmcnt(2)\n\t"                                                                \
+        "v_bfe_u32 %[t1], %[" WT "], %[q0], 1\n\t"                                              \
+        "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"                                                    \
+        "v_cmp_eq_u32_e64 %[by], -1, %[q0]\n\t" /* the sentinel has arrived: every cell up to the face has been tested */ \
+        "s_or_b64 %[left], %[left], %[by]\n\t"                                                  \
+        "s_andn2_b64 exec, exec, %[by]\n\t"                                                     \
+        "s_cbranch_vccz " NEXT "f\n\t"                                                          \
+        "s_mov_b64 %[ex], exec\n\t"                                                             \
+        "s_mov_b64 exec, vcc\n\t"                                                               \
+        "v_mov_b32_e32 %[phase], " K "\n\t"                                                     \
+        "s_andn2_b64 exec, %[ex], vcc\n\t"                                                      \
+        "s_or_b64 %[parked], %[parked], vcc\n\t"                                                \
+        "s_bcnt1_i32_b64 %[n], %[parked]\n\t"                                                   \
+        "s_cmp_ge_u32 %[n], %[batch]\n\t"                                                       \
+        "s_cbranch_scc1 9" K "f\n\t"                                                            \
+        NEXT ":\n\t"
+VRT_DI void grid_walk_ahead_gfx950(Walk &w, const f3 &inv_dir, AheadRing &a, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z, u32x4 rsrc,
+                                   AheadWalkRegs &g) {
+    unsigned long long mx, my, mxy, ex, by, cz, save;
+    float t0, t1, t2;
+    uint32_t n;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "s_mov_b64 exec, %[alive]\n\t"
+        "s_mov_b64 %[parked], 0\n\t"
+        "s_mov_b64 %[left], 0\n\t"
+        "0:\n\t"
+        VRT_AHEAD_TRIP("w0", "w1", "0", "20")
+        "s_cbranch_execz 90f\n\t"
+        VRT_AHEAD_TRIP("w1", "w2", "1", "21")
+        "s_cbranch_execz 91f\n\t"
+        VRT_AHEAD_TRIP("w2", "w0", "2", "22")
+        "s_cbranch_execz 92f\n\t"
+        "s_bcnt1_i32_b64 %[n], exec\n\t"
+        "s_cmp_ge_u32 %[n], %[minalive]\n\t"
+        "s_cbranch_scc1 0b\n\t"
+        "92:\n\t"
+        "v_mov_b32_e32 %[phase], 2\n\t"
+        "s_branch 99f\n\t"
+        "90:\n\t"
+        "v_mov_b32_e32 %[phase], 0\n\t"
+        "s_branch 99f\n\t"
+        "91:\n\t"
+        "v_mov_b32_e32 %[phase], 1\n\t"
+        "99:\n\t"
+        "s_mov_b64 %[alive], exec\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        "s_waitcnt vmcnt(0)"
+        : [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),
+          [q0] "+v"(a.q0), [q1] "+v"(a.q1), [q2] "+v"(a.q2), [w0] "+v"(a.w0), [w1] "+v"(a.w1), [w2] "+v"(a.w2), [ts0] "+v"(a.ts0), [ts1] "+v"(a.ts1),
+          [ts2] "+v"(a.ts2), [hist] "+v"(a.hist), [phase] "+v"(a.phase), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mx] "=&s"(mx), [my] "=&s"(my),
+          [mxy] "=&s"(mxy), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz), [save] "=&s"(save), [parked] "=&s"(g.parked), [left] "=&s"(g.left),
+          [alive] "+s"(g.alive), [n] "=&s"(n)
+        : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z), [rsrc] "s"(rsrc),
+          [batch] "s"(g.batch), [minalive] "s"(g.min_alive)
+        : "vcc", "scc", "memory");
+    a.settle();
+}
+#undef VRT_AHEAD_TRIP
 // ---- block filter (vrt_path_kernel<FILTER>) ---------------------------------------------------------------------------
 // The 1-bit-per-4x4x4-cells filter that vrt_build_status_blocks derives from binding 3 ("some cell of the block is occupied"),
 // staged in LDS once per workgroup.  The block index is formed from the linear cell index by bit fields, so the grid's x and z
@@ -1775,8 +1912,10 @@ enum : int { kLaneFetch = 0, kLaneSample, kLaneStart, kLaneWalk, kLaneDone, kLan
 // FILTER: 512-thread workgroups (eight waves, two per SIMD, share one LDS copy of the block filter); two workgroups per CU:
 // 2 x (32 KiB filter + 8 x 4 KiB of staged bricks) = 128 of the CU's 160 KiB, four waves per SIMD.  (640-thread groups for five
 // waves per SIMD do not pair up: ten waves leave the SIMDs 3/3/2/2, and 96 registers do not admit a sixth wave.)
-template <int B, int MIN_WAVES, bool FILTER, bool HALF = false>
+// AHEAD (round 3): the walk loop pipelined two trips ahead (grid_walk_ahead_gfx950), on the shader's linear status words.
+template <int B, int MIN_WAVES, bool FILTER, bool HALF = false, bool AHEAD = false>
 __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN_WAVES) void vrt_path_kernel(const TraceParams p) {
+    static_assert(!AHEAD || (!HALF && !FILTER), "the two-trips-ahead loop reads the linear status words");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_block_filter[];
     FilterConsts fc{};
     if constexpr (FILTER) {
@@ -1893,6 +2032,7 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
     g.t_out = g.t_in = 0.0f;
     g.code = 3u << 4;
     g.batch = p.path_brick_batch;
+    [[maybe_unused]] AheadRing ring{0u, ~0u, ~0u, 0u, 0u, 0u, 0u, 2u, 0.0f, 0.0f, 0.0f}; // (AHEAD: the lane's three cells in flight)
     // FILTER: a walking lane is `ready` once its cell is known to lie in a block that holds occupied cells (it takes trips);
     // otherwise its block is looked up, and jumped over if empty.  `stale`: the lane has jumped since `word` was loaded.
     [[maybe_unused]] bool ready = false, stale = false;
@@ -2100,6 +2240,17 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                         if constexpr (FILTER) {
                             ready = false;
                             stale = true; // (the word is requested when the lane is about to take trips)
+                        } else if constexpr (AHEAD) {
+                            // prime the ring: q1 = the ray's first cell, q2 = the cell behind one step (comp:345-372), both words asked for
+                            ring.q1 = grid_index;
+                            ring.w1 = p.brick_status[grid_index >> 5];
+                            ring.ts1 = skip_t;
+                            int ax = 0;
+                            dda_step<true>(w, s.ray_delta(), g_scale, ax, grid_index, stride_x, stride_y, stride_z);
+                            ring.ts2 = w.t_value;
+                            ring.hist = ((uint32_t)in_axis << 2) | (uint32_t)ax;
+                            ring.q2 = (min3i(w.rx, w.ry, w.rz) < 0) ? ~0u : grid_index; // (the step left the box: the sentinel)
+                            ring.w2 = (ring.q2 != ~0u) ? p.brick_status[ring.q2 >> 5] : 0u;
                         } else {
                             word = status_word(grid_index);
                         }
@@ -2155,7 +2306,16 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
         // (FILTER: five trips per call, the way through a block of four cells; then the blocks are looked up again)
         g.min_alive = FILTER ? 65u : (n_walking >= fin ? n_walking - fin + 1u : 1u);
         uint32_t cell; // the occupied cell each parked lane stood on before its last step
-        if constexpr (halfblocks) grid_walk_park_halfblocks_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, hb);
+        if constexpr (AHEAD) {
+            AheadWalkRegs ga;
+            ga.alive = g.alive;
+            ga.batch = g.batch;
+            ga.min_alive = g.min_alive;
+            grid_walk_ahead_gfx950(w, s.inv_dir, ring, stride_x, stride_y, stride_z, rsrc, ga);
+            g.alive = ga.alive;
+            g.parked = ga.parked;
+            cell = ring.q0;
+        } else if constexpr (halfblocks) grid_walk_park_halfblocks_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, hb);
         else grid_walk_park_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
         VRT_PF_T(1, pf1);
         VRT_PF_N(2, 1);
@@ -2176,13 +2336,16 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
             VRT_PF_N(5, 1);
             VRT_PF_N(6, __builtin_popcountll(g.parked));
             if (parked) {
-                int a = (int)(g.code & 3u);
-                const uint32_t out = (g.code >> 2) & 3u;
-                // the counters as they were on the occupied cell: undo the decrement of the step out of it
-                const int rx = w.rx + (out == 0u ? 1 : 0), ry = w.ry + (out == 1u ? 1 : 0), rz = w.rz + (out == 2u ? 1 : 0);
+                // AHEAD: the lane's DDA state is two steps beyond the occupied cell q0: undo both decrements; q0 was entered through
+                // the axis in hist bits 4-5 at distance ts0.  Otherwise the lane has taken one step out of the cell.
+                int a = AHEAD ? (int)((ring.hist >> 4) & 3u) : (int)(g.code & 3u);
+                const uint32_t out = AHEAD ? ((ring.hist >> 2) & 3u) : ((g.code >> 2) & 3u), out2 = AHEAD ? (ring.hist & 3u) : 3u;
+                const float t_into = AHEAD ? ring.ts0 : g.t_in;
+                const int rx = w.rx + (out == 0u ? 1 : 0) + (out2 == 0u ? 1 : 0), ry = w.ry + (out == 1u ? 1 : 0) + (out2 == 1u ? 1 : 0),
+                          rz = w.rz + (out == 2u ? 1 : 0) + (out2 == 2u ? 1 : 0);
                 const int cx = base_x - __mul24(s.sx, rx), cy = base_y - __mul24(s.sy, ry), cz = base_z - __mul24(s.sz, rz); // cell position
                 const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min);  // comp:331
-                const float global_t_value = g.t_in * g_scale + s.grid_t_min + 0.01f * g_scale;          // comp:347 (deferred) + comp:332
+                const float global_t_value = t_into * g_scale + s.grid_t_min + 0.01f * g_scale;          // comp:347 (deferred) + comp:332
                 hit.t = global_t_value;
                 const uint32_t occ_slot = by_cell ? cell : p.brick_index[cell]; // comp:337 (by_cell: only on a solid voxel)
                 bool hit_voxel;
@@ -2195,16 +2358,16 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                 if (hit_voxel) {
                     found = true;
                     st = kLaneDone;
-                } else if (!(global_t_value <= t_max) || min3i(w.rx, w.ry, w.rz) < 0) {
+                } else if (!(global_t_value <= t_max) || (!AHEAD && min3i(w.rx, w.ry, w.rz) < 0)) {
                     found = false; // t became NaN (comp:316), or the step out of this cell left the box
                     st = kLaneDone;
-                } else {
+                } else if constexpr (!AHEAD) {
                     word = status_word(grid_index); // (an A-trip park left the lane's word in the other register set)
-                }
+                }   // (AHEAD: the lane walks on as it is; a step that left the box has put the sentinel into its ring)
             }
         }
         // every lane of the call: the axis of its last step, for its first trip in the next call
-        if (was_walking)
+        if (!AHEAD && was_walking)
             g.code = parked ? ((g.code >> 2) & 3u) << 4
                             : (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
         VRT_PF_T(2, pf2);
