@@ -15,6 +15,7 @@ const KernelEntry kEntries[] = {
     VRT_TRACE_ALL_MODES(4, false, 7, 2), VRT_TRACE_ALL_MODES(4, false, 8, 2), VRT_TRACE_ALL_MODES(4, false, 4, 2),
     VRT_TRACE_ALL_MODES(4, false, 6, 1),
     VRT_TRACE_ALL_MODES(4, false, 4, 0), VRT_TRACE_ALL_MODES(4, false, 8, 0),
+    VRT_TRACE_ENTRY(4, false, 4, 5, 0, 256), VRT_TRACE_ENTRY(4, false, 4, 6, 0, 256),   // (tuning builds of the lockstep bounce kernel)
 #endif
 };
 } // namespace

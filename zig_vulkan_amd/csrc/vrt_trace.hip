@@ -431,7 +431,8 @@ KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t varian
             const bool filter = (variant & kVariantPathFilter) != 0u;
             e = find_path_kernel(brick_dimension, mw == 5u ? 5 : ((mw >= 6u && !filter) ? (int)mw : kDefaultMinWaves), filter, false);
         } else {
-            e = find_trace_kernel(brick_dimension, false, mode, mw == 8u ? 8 : kDefaultMinWaves, 0, block);
+            e = find_trace_kernel(brick_dimension, false, mode, (mw == 8u || mw == 6u || (mw_asked == 5u)) ? (int)(mw_asked == 5u ? 5u : mw) : kDefaultMinWaves, 0, block);
+            if (!e && mw_asked == 5u) e = find_trace_kernel(brick_dimension, false, mode, kDefaultMinWaves, 0, block); // (5 is the path kernel's: product default)
         }
     } else {
         // (the several-samples-per-pixel kernel, shade 1, needs 87 VGPRs left to itself = 5 waves per SIMD; held to 80 it spills
