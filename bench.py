@@ -926,13 +926,13 @@ def main(argv=None) -> None:
             out["root_share_tuning"] = tune_reports
             out["secondary"] = secondary
         if world == 1 and not sharded and not args.no_cpu_baseline and not stub:
-            # frames of this library for the parity certificate: the product build, and its reference-lowering twin where built
+            # frames of this library for the parity certificate: the product build, and its fused-arithmetic twin where built
             hip_frames = {}
             try:
                 from zig_vulkan_amd import _lib as VL
                 builds = {"product": None}
-                if os.path.exists(VL.REFLOW_LIB_PATH):
-                    builds["reflow"] = VL.REFLOW_LIB_PATH
+                if os.path.exists(VL.FUSED_LIB_PATH):
+                    builds["fused"] = VL.FUSED_LIB_PATH
                 for build, path in builds.items():
                     rtf = W.make_renderer(w, grid, device_id=local_rank, want_float_output=True, kernel_variant=args.variant,
                                           **({"library": path} if path else {}))
@@ -951,9 +951,9 @@ def main(argv=None) -> None:
                 out["cpu_baseline"] = ref
                 out["cpu_baseline_port"] = port
                 if parity is not None:
-                    parity["note"] = ("product = libvrt_hip.so (fma fused, dot as an fma chain: what GLSL leaves to the implementation); reflow = the same "
-                                      "kernel source compiled with llvmpipe's lowering of fma / dot (libvrt_hip_reflow.so, test infrastructure): "
-                                      "expected bit-equal to the reference frame, every pixel")
+                    parity["note"] = ("product = libvrt_hip.so: its arithmetic contract is the reference shader's as Mesa gallivm executes it, so every pixel "
+                                      "is expected bit-equal to the reference frame; fused = the same kernel source with fma fused and dot as an fma "
+                                      "chain (libvrt_hip_fused.so, test infrastructure): what GLSL would also allow, and how far it moves the frame")
                     out["parity_vs_reference"] = parity
             else:
                 port["reference_unavailable"] = why

@@ -15,15 +15,14 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvrt_oracle.so")
-# the same restatement with Mesa llvmpipe's lowering of fma / dot / sin: only ever compared with oracle/_ref
-LIB_PATH_LLVMPIPE = os.path.join(_HERE, "libvrt_oracle_llvmpipe.so")
+LIB_PATH = os.path.join(_HERE, "libvrt_oracle.so")                # the oracle: the reference shader as Mesa llvmpipe executes it
+LIB_PATH_FUSED = os.path.join(_HERE, "libvrt_oracle_fused.so")    # fma fused, dot as an fma chain (libvrt_hip_fused.so's counterpart)
 
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("vrt_oracle.c", "denoise_oracle.c")]
     if force or any(not os.path.exists(p) or os.path.getmtime(p) < max(os.path.getmtime(s) for s in srcs)
-                    for p in (LIB_PATH, LIB_PATH_LLVMPIPE)):
+                    for p in (LIB_PATH, LIB_PATH_FUSED)):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return LIB_PATH
 
@@ -54,12 +53,17 @@ _lib = None
 _libs = {}
 
 
-def lib(lowering: str = "hw") -> C.CDLL:
-    """lowering "hw": the oracle proper.  "llvmpipe": built-ins lowered as Mesa llvmpipe does (see vrt_oracle.c)."""
+_LOWERINGS = {"ref": "ref", "llvmpipe": "ref", "fused": "fused", "hw": "fused"}
+
+
+def lib(lowering: Optional[str] = None) -> C.CDLL:
+    """lowering "ref" (default; alias "llvmpipe"): the oracle — the GLSL built-ins lowered as Mesa llvmpipe lowers them, bit-equal
+    to the reference's own shader.  "fused" (alias "hw"): fma fused, dot as an fma chain (see vrt_oracle.c)."""
     global _lib
+    lowering = _LOWERINGS[lowering or "ref"]
     if lowering not in _libs:
         build()
-        L = C.CDLL({"hw": LIB_PATH, "llvmpipe": LIB_PATH_LLVMPIPE}[lowering])
+        L = C.CDLL({"ref": LIB_PATH, "fused": LIB_PATH_FUSED}[lowering])
         L.oracle_render_rows.restype = None
         L.oracle_render_rows.argtypes = [C.POINTER(Scene), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_render_pixels.restype = None
@@ -86,7 +90,7 @@ def lib(lowering: str = "hw") -> C.CDLL:
         L.oracle_denoise_rows.restype = None
         L.oracle_denoise_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _libs[lowering] = L
-        if lowering == "hw":
+        if lowering == "ref":
             _lib = L
     return _libs[lowering]
 
@@ -126,7 +130,7 @@ def push_constants(camera_blob: bytes, sun_blob: bytes) -> np.ndarray:
 
 
 def render(scene: OracleScene, pc: np.ndarray, *, rows: Optional[Tuple[int, int]] = None, threads: int = 0,
-           want_counters: bool = True, lowering: str = "hw"):
+           want_counters: bool = True, lowering: Optional[str] = None):
     """Render image rows [y0,y1) (default: all) with the oracle.  Returns
     (rgba32f[H,W,4], rgba8[H,W,4], counters dict) — rows outside the range stay zero."""
     L = lib(lowering)

@@ -10,21 +10,19 @@
  * PARITY PINNED against the reference's own shader: the image holds Mesa 23.2.1 (llvmpipe), so
  * brick_raytracer.comp itself is compiled by Mesa's GLSL compiler and run on the host cores
  * (oracle/_ref, recipe oracle/ref_gl/recipe.py; the reference's own build — zig + a network-fetched
- * glslang + Vulkan — cannot run here).  Built with -DORACLE_LOWERING_LLVMPIPE (fma/dot lowered as
- * llvmpipe lowers them) this file reproduces the shader's frames BIT FOR BIT: the committed vectors
- * tests/golden/ref/ and random scenes (tests/test_ref_gl.py) — primary and shadow rays, soft sun,
- * several samples, bounces, every scatter function, 4^3 and 8^3 bricks.  The default build differs from
- * that one ONLY in the lowering rules below (implementation-defined in GLSL; hardware fuses fma), and
- * agrees with the shader's frames within 1e-4 per channel except at isolated pixels where a last-bit
- * difference flips a DDA tie (counted in the tests).  The reference itself holds no golden vectors for
- * this path (its only tests are three .vox header checks, src/modules/voxel_rt/vox/loader.zig:265-281).
+ * glslang + Vulkan — cannot run here).  This file, built as it stands, reproduces the shader's frames BIT FOR BIT:
+ * the committed vectors tests/golden/ref/ and tests/golden/ref_full/ and random scenes (tests/test_ref_gl.py) — primary
+ * and shadow rays, soft sun, several samples, bounces, every scatter function, 4^3 and 8^3 bricks, up to the headline
+ * workload's full 1920x1080 frame.  The reference itself holds no golden vectors for this path (its only tests are three
+ * .vox header checks, src/modules/voxel_rt/vox/loader.zig:265-281).
  *
- * Arithmetic rules (the same rules the HIP kernel follows, so that kernel ==
- * oracle bit-for-bit on the float target):
- *   - GLSL fma(a,b,c)      -> fmaf(a,b,c)        (one rounding)
+ * Arithmetic rules — the ones Mesa's gallivm applies to the shader (measured on Mesa itself, tests/test_ref_gl.py), and the
+ * ones the HIP kernels follow (zig_vulkan_amd/csrc/vrt_math.h), so that kernel == oracle == reference shader bit for bit:
+ *   - GLSL fma(a,b,c)      -> a*b + c            (two roundings: nir lower_ffma32)
  *   - every other * + - /  -> separate IEEE-754 binary32 operations in source
  *                             order; compiled with -ffp-contract=off
- *   - dot(a,b)             -> fmaf(a.z,b.z, fmaf(a.y,b.y, a.x*b.x))
+ *   - dot(a,b)             -> (a.z*b.z + a.y*b.y) + a.x*b.x   (nir lower_fdot, from the last channel)
+ *   - hash12               -> Mesa's two algebraic rewrites, see hash12() / hash12_jitter()
  *   - normalize(v)         -> v * (1.0f / sqrtf(dot(v,v)))
  *   - fract(x)             -> x - floorf(x)
  *   - reflect(I,N)         -> I - (2*dot(N,I))*N
@@ -34,6 +32,11 @@
  *   - int(x)               -> (int)clamp(x, -2^31, 2147483520) (vrt_f2i; GLSL leaves the
  *                             out-of-range conversion undefined, C makes it UB)
  *   - Rgba8 imageStore     -> rintf(clamp(c,0,1)*255)
+ * -DORACLE_LOWERING_FUSED builds libvrt_oracle_fused.so: fma fused (one rounding), dot as
+ * fmaf(a.z,b.z, fmaf(a.y,b.y, a.x*b.x)) — what a GPU driver's compiler typically emits for the same GLSL, this repo's
+ * contract until round 3, and the counterpart of libvrt_hip_fused.so.  It agrees with the shader's frames within 1e-4 per
+ * channel except at isolated pixels where a last-bit difference flips a DDA tie, and as images only where the sin-hash RNG
+ * is reached (one ulp in its argument is another random number).
  * Hang guard: a DDA step along an axis whose ray_step is 0 does not move the
  * position, so a degenerate ray (NaN side distances with a zero step) would spin
  * forever in the reference's loops.  Both loops here allow such a zero-step
@@ -122,14 +125,11 @@ typedef struct {
 } Env;
 
 /* ------------------------------------------------------------------ lowering of the GLSL built-ins
- * Default ("hardware" lowering, the one the HIP kernel matches bit for bit): fused fma, dot as an fma chain.
- * -DORACLE_LOWERING_LLVMPIPE builds a second library, libvrt_oracle_llvmpipe.so, whose built-ins are lowered
- * exactly as Mesa 23.2.1 llvmpipe lowers them (measured through oracle/_ref, tests/test_ref_gl.py):
+ * Default: exactly as Mesa 23.2.1 llvmpipe lowers them (measured through oracle/_ref, tests/test_ref_gl.py):
  *   fma(a,b,c) -> a*b + c with two roundings (nir lower_ffma32), dot(a,b) -> (a.z*b.z + a.y*b.y) + a.x*b.x
  *   (nir lower_fdot, reduction from the last channel); sin is gallivm's in both builds.
- * It exists for ONE purpose: to be compared with the reference shader run under llvmpipe (oracle/_ref) bit for
- * bit, which checks every statement of the restatement except the lowering rules themselves. */
-#ifdef ORACLE_LOWERING_LLVMPIPE
+ * -DORACLE_LOWERING_FUSED: fused fma, dot as an fma chain (libvrt_oracle_fused.so). */
+#ifndef ORACLE_LOWERING_FUSED
 #define FMA(a, b, c) ((a) * (b) + (c))
 #define DOT3(a, b) (((a).z * (b).z + (a).y * (b).y) + (a).x * (b).x)
 #define DOT2(ax, ay, bx, by) ((ay) * (by) + (ax) * (bx))
@@ -234,7 +234,7 @@ static inline v3 RandVec3mm(float cx, float cy, float mn, float mx) {
 static inline float hash12(float px, float py) {
     v3 p3 = V3(fract(px * .1031f), fract(py * .1031f), fract(px * .1031f));
     const v3 q = V3(p3.y + 33.33f, p3.z + 33.33f, p3.x + 33.33f);
-#ifdef ORACLE_LOWERING_LLVMPIPE
+#ifndef ORACLE_LOWERING_FUSED
     /* p3.z == p3.x (p.xyx), so the dot is A*(B+k) + B*(A+k) + A*(A+k); Mesa's nir_opt_algebraic factors the
      * inexact a*b + a*c -> a*(b+c) out of the first two terms of its reduction (measured, tests/test_ref_gl.py) */
     (void)q;
@@ -248,7 +248,7 @@ static inline float hash12(float px, float py) {
 
 /* comp:167,169: hash12(vec2(ax, ay) * 0.2 * float(sample_i > 0)) */
 static inline float hash12_jitter(float ax, float ay, float flag) {
-#ifdef ORACLE_LOWERING_LLVMPIPE
+#ifndef ORACLE_LOWERING_FUSED
     /* Mesa folds ((a * 0.2) * flag) * .1031 of the inlined hash12 into a * (0.2 * .1031) (flag == 1; the product is 0
      * for flag == 0) and factors the dot as in hash12 above (measured, tests/test_ref_gl.py) */
     if (flag == 0.0f) return hash12(0.0f, 0.0f);

@@ -40,6 +40,8 @@ def needs_dev_build(variant: int) -> bool:
 
 
 def dev_library_or_none():
+    if os.environ.get("VRT_NO_DEV_LIB"):   # (run the suite as a box without the development build would)
+        return None
     return L.DEV_LIB_PATH if os.path.exists(L.DEV_LIB_PATH) else None
 
 

@@ -10,11 +10,10 @@ rays and demands identical hit flag, distance, point, normal and material index,
 Follows assets/shaders/brick_raytracer.comp: safeInverse :267, GridHit :271-376, BrickHit :378-471,
 indexOfMaxComponent :501-503, AdvNormIntersect :522-536, RayAt :192-195.
 Conventions shared with the oracle because GLSL leaves them open (oracle header): float->int
-conversion clamps, min/max are the GLSL `y < x ? y : x` / `x < y ? y : x` forms, fma is the exact fused operation.
+conversion clamps, min/max are the GLSL `y < x ? y : x` / `x < y ? y : x` forms, fma is a*b + c with two roundings and dot is
+reduced from the last channel (Mesa llvmpipe's lowering: the reference as it executes).
 """
 from __future__ import annotations
-
-from fractions import Fraction
 
 import numpy as np
 
@@ -22,37 +21,11 @@ f32 = np.float32
 INF = f32(np.inf)
 
 
-def _round_to_f32(x: Fraction) -> np.float32:
-    """Correctly rounded (nearest, ties to even) float32 of an exact rational."""
-    if x == 0:
-        return f32(0.0)
-    d = f32(float(x))  # double rounding possible: repair against the neighbours
-    if not np.isfinite(d):
-        return d
-    best = d
-    for cand in (np.nextafter(d, -INF, dtype=np.float32), np.nextafter(d, INF, dtype=np.float32)):
-        if not np.isfinite(cand):
-            continue
-        e_c, e_b = abs(Fraction(float(cand)) - x), abs(Fraction(float(best)) - x)
-        if e_c < e_b or (e_c == e_b and (int(cand.view(np.uint32)) & 1) == 0 and (int(best.view(np.uint32)) & 1) == 1):
-            best = cand
-    return best
-
-
 def fma(a, b, c) -> np.float32:
-    a, b, c = f32(a), f32(b), f32(c)
-    if not (np.isfinite(a) and np.isfinite(b) and np.isfinite(c)):
-        with np.errstate(all="ignore"):
-            return f32(np.float64(a) * np.float64(b) + np.float64(c))  # inf/nan propagate the same way
-    r = _round_to_f32(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))
-    if r == 0:
-        # an exact zero: -0 only when the product and the addend are both negative zeros; exact cancellation gives +0
-        product_is_zero = (a == 0) or (b == 0)
-        product_negative = bool(np.signbit(a)) != bool(np.signbit(b))
-        if product_is_zero and c == 0 and product_negative and bool(np.signbit(c)):
-            return f32(-0.0)
-        return f32(0.0)
-    return r
+    """GLSL fma as the reference's executable implementation lowers it (Mesa llvmpipe, nir lower_ffma32): a*b + c, two roundings —
+    the arithmetic contract of the oracle and of the kernels since round 3."""
+    with np.errstate(all="ignore"):
+        return f32(f32(f32(a) * f32(b)) + f32(c))
 
 
 def gl_min(x, y):
@@ -206,10 +179,10 @@ def grid_hit(sc: Scene, origin, direction, ignore_type=3, internal_reflection=1.
 # main :153-178, CameraGetRay :474-477, CreateRay/CreateShadowRay :180-190, BackgroundColor :197-201, RayColor :203-265.
 # With one sample the jitter is hash12(0) = 0; with sun radius 0 RandVec3 is the zero vector; with max_bounce <= 1 the
 # scatter functions' only products (the next ray, the continue flag) are never read.  normalize(v) = v * (1 / sqrt(dot))
-# with dot as the fma chain z*z + (y*y + x*x): the contract of DESIGN.md §3.
+# with dot reduced from the last channel, (z*z + y*y) + x*x: the contract of DESIGN.md §3.
 
 def normalize(v):
-    d = fma(v[2], v[2], fma(v[1], v[1], v[0] * v[0]))
+    d = f32(f32(f32(v[2] * v[2]) + f32(v[1] * v[1])) + f32(v[0] * v[0]))
     inv = f32(1.0) / f32(np.sqrt(d))
     return [c * inv for c in v]
 

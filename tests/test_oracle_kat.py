@@ -19,16 +19,14 @@ def np_fract(x):
     return f32(x - np.floor(x))
 
 
-def np_hash12(px, py):  # rand.comp:22-26 in numpy float32, dot as fma chain per the arithmetic contract
+def np_hash12(px, py):  # rand.comp:22-26 in numpy float32, lowered as the reference's executable implementation lowers it
+    # (Mesa llvmpipe: p3 = p.xyx, so dot(p3, p3.yzx + k) = A*(B+k) + B*(A+k) + A*(A+k), reduced from the last channel with the first two
+    # terms factored by nir_opt_algebraic: (A+B)*(A+k) + A*(B+k), every operation rounded; measured in tests/test_ref_gl.py)
     px, py = f32(px), f32(py)
     k = f32(.1031)
-    p3 = [np_fract(f32(px * k)), np_fract(f32(py * k)), np_fract(f32(px * k))]
-    q = [f32(p3[1] + f32(33.33)), f32(p3[2] + f32(33.33)), f32(p3[0] + f32(33.33))]
-    d = f32(np.float64(p3[0]) * np.float64(q[0]))                      # x*x' rounded
-    d = f32(np.float64(p3[1]) * np.float64(q[1]) + np.float64(d))      # fma: exact product + add, one rounding
-    d = f32(np.float64(p3[2]) * np.float64(q[2]) + np.float64(d))
-    p3 = [f32(v + d) for v in p3]
-    return np_fract(f32(f32(p3[0] + p3[1]) * p3[2]))
+    A, B = np_fract(f32(px * k)), np_fract(f32(py * k))
+    d = f32(f32(f32(A + B) * f32(A + f32(33.33))) + f32(A * f32(B + f32(33.33))))
+    return np_fract(f32(f32(f32(A + d) + f32(B + d)) * f32(A + d)))
 
 
 def test_hash12_zero_and_independent_restatement():
@@ -37,7 +35,6 @@ def test_hash12_zero_and_independent_restatement():
     rng = np.random.default_rng(1)
     for _ in range(2000):
         px, py = f32(rng.uniform(0, 800)), f32(rng.uniform(0, 450))
-        # products of two float32 are exact in float64, so the numpy fma emulation above is exact
         assert L.oracle_hash12(px, py) == np_hash12(px, py)
 
 
@@ -63,7 +60,7 @@ def test_specified_sin_is_the_cephes_single_precision_kernel():
 def test_rand_is_fract_of_sine_product():
     L = O.lib()
     for cx, cy in [(0.5, 0.25), (12.0, -7.5), (100.25, 33.0)]:
-        d = f32(np.float64(f32(cy)) * np.float64(f32(78.233)) + np.float64(f32(f32(cx) * f32(12.9898))))
+        d = f32(f32(f32(cy) * f32(78.233)) + f32(f32(cx) * f32(12.9898)))   # dot(co, vec2(12.9898, 78.233)) from the last channel
         want = np_fract(f32(f32(L.oracle_sinf(d)) * f32(43758.5453)))  # rand.comp:4
         assert L.oracle_rand2(cx, cy) == want
     out = np.zeros(3, dtype=np.float32)

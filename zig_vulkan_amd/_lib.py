@@ -254,7 +254,7 @@ def load_library(path: str) -> C.CDLL:
 _loaded: dict = {}
 lib = load_library(LIB_PATH)
 # test-infrastructure twins of the product library (zig_vulkan_amd/csrc/Makefile); absent unless built
-REFLOW_LIB_PATH = os.path.join(_HERE, "libvrt_hip_reflow.so")  # GLSL built-ins lowered as Mesa llvmpipe lowers them (make reflow)
+FUSED_LIB_PATH = os.path.join(_HERE, "libvrt_hip_fused.so")    # fma fused, dot as an fma chain (make fused): how far fusing moves the frames
 DEV_LIB_PATH = os.path.join(_HERE, "libvrt_hip_dev.so")        # + the variants that lost their A/B measurement (make dev)
 
 
