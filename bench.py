@@ -97,7 +97,7 @@ def cpu_baseline_reference(w, grid, min_wall_s: float, per_view, hip_frames=None
     (oracle/_ref; north_star's "reference under lavapipe": same gallivm back end, OpenGL instead of Vulkan front end).
     Scene buffers are uploaded once; each frame pushes the 128 constant bytes and dispatches ceil(W/32) x ceil(H/32)
     workgroups, timed to glFinish.  Returns (dict, parity, None) or (None, None, reason).
-    hip_frames: {"product": {view: (f32, u8)}, "reflow": {...}} — frames libvrt_hip rendered for the same 128 push-constant
+    hip_frames: {"product": {view: (f32, u8)}, "fused": {...}} — frames libvrt_hip rendered for the same 128 push-constant
     bytes; one reference frame per view is then read back (untimed) and compared pixel by pixel: the on-box parity
     certificate (`parity_vs_reference`)."""
     try:

@@ -14,7 +14,7 @@
 //   sin(x)        = vrt_sin (the Cephes single-precision kernel as gallivm lowers it, its multiply-adds fused as on an FMA host)
 //   int(x)        = (int)clamp(x, -2^31, 2147483520)  (f2i_clamp)
 // With these rules the frames are the reference shader's BIT FOR BIT — bounces, soft sun and every scatter function included
-// (tests/test_reflow_gpu.py, tests/golden/ref/, tests/golden/ref_full/, bench.py's parity_vs_reference) — at no measurable cost
+// (tests/test_reference_parity_gpu.py, tests/golden/ref/, tests/golden/ref_full/, bench.py's parity_vs_reference) — at no measurable cost
 // (same-box A/B of the two lowerings: 0.059 / 0.087 / 0.088 ms either way on the headline).
 //
 // -DVRT_LOWERING_FUSED (make fused -> libvrt_hip_fused.so, test infrastructure): fma fused, dot as an fma chain — what a GPU

@@ -234,7 +234,7 @@ class Config:  # VoxelRT.Config, VoxelRT.zig:22-28 (+ the knobs of this implemen
     external_target_rgba8: int = 0
     external_target_rgba32f: int = 0
     tuning_flags: int = 0      # VRT_TUNE_* (include/vrt_hip.h): A/B switches, every setting renders the same frame
-    library: Optional[str] = None  # path of another build of libvrt_hip (reflow / dev twins); None: the product library
+    library: Optional[str] = None  # path of another build of libvrt_hip (fused / dev twins); None: the product library
 
 
 class VoxelRT:
