@@ -157,3 +157,34 @@ def test_compiled_host_on_the_c_abi_renders_the_same_frame(tmp_path):
     assert digest == f"{h:016x}"
     ppm = (tmp_path / "frame.ppm").read_bytes()
     assert ppm.startswith(b"P6\n640 360\n255\n") and len(ppm) == len(b"P6\n640 360\n255\n") + 640 * 360 * 3
+
+
+def test_kernel_name_is_the_symbol_that_ran():
+    """vrt_kernel_name(): the template-id of the kernel of the most recent frame, as rocprofv3 prints it (it used
+    to format the variant "as asked").  One context, three kinds of frame."""
+    import re
+    from zig_vulkan_amd import workloads as W
+    w = W.Workload("t", 96, 64, 64, 8, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    rt = W.make_renderer(w, grid)
+    rt.draw()
+    rt.wait()
+    assert rt.kernel_name() == "vrt_trace_kernel<8, false, 7, 7, 2, 256>"      # one sample, no bounce, grid <= 64^3 cells: byte status, 7 waves
+    rt.camera.d_camera.samples_per_pixel = 3
+    rt.draw()
+    rt.wait()
+    assert rt.kernel_name() == "vrt_trace_kernel<8, false, 7, 6, 1, 256>"      # several samples
+    rt.camera.d_camera.max_bounce = 3
+    rt.draw()
+    rt.wait()
+    assert rt.kernel_name() == "vrt_trace_kernel<8, false, 4, 4, 0, 256>"      # bounces on a small scene: the lockstep kernel on the shader's words
+    rt.deinit()
+    rt = W.make_renderer(w, grid, kernel_variant=1 << 23)                         # persistent lanes forced; power-of-two grid: half-block walk
+    rt.camera.d_camera.max_bounce = 3
+    rt.draw()
+    rt.wait()
+    assert rt.kernel_name() == "vrt_path_kernel<8, 5, false, true, false>"
+    rt.deinit()
+    from zig_vulkan_amd import _lib as L
+    assert L.lib.vrt_compiled_kernel_count() == 22
+    assert re.fullmatch(r"vrt_(trace|path)_kernel<[^>]+>", "vrt_trace_kernel<8, false, 7, 7, 2, 256>")
