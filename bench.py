@@ -712,12 +712,17 @@ def main(argv=None) -> None:
         return {v: {"rays": 1000, "bytes": 4000, "issued_bytes": 2000, "counters": {}, "issued": {}, "primary_hit_fraction": 0.5} for v in all_views}
 
     # ---- rays and bytes per view, counted by counting builds of the kernel (untimed) ----
-    per_view = {}
+    per_view, count_err = {}, None
     if stub:
         per_view = stub_counts()
     elif rank == 0:
-        per_view = count_rays(W, w, grid, all_views, args.variant, local_rank)
-    per_view = env.bcast(per_view)
+        try:
+            per_view = count_rays(W, w, grid, all_views, args.variant, local_rank)
+        except Exception as e:  # noqa: BLE001 - the other ranks wait in the broadcast below: tell them
+            count_err = f"{type(e).__name__}: {e}"
+    per_view, count_err = env.bcast((per_view, count_err))
+    if count_err:
+        raise SystemExit(f"bench.py: counting the rays failed on rank 0: {count_err}")
 
     def rays_of(pv, n):
         return sum(pv[view_of(i, n)]["rays"] for i in range(n))
@@ -773,14 +778,29 @@ def main(argv=None) -> None:
     for name, other in plan[:-1]:
         other.close()
 
+    if rank == 0 and sharded:
+        # (to stderr, before the secondary leg: should that leg hang in a collective, the headline legs are on record)
+        print("[bench] headline legs: " + json.dumps({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "legs": legs_out,
+                                                      "root_share_tuning": tune_reports}), file=sys.stderr, flush=True)
+
     # ---- N > 1: the same pipeline on BASELINE.json's sharded configuration (configs[3]: 3840x2160, 1024^3, 4 rays per pixel) ----
     secondary = None
     if sharded and world > 1 and native and not args.no_secondary and (args.workload or W.HEADLINE) == W.HEADLINE:
         try:
             w2 = W.WORKLOADS["cfg3_4k_1024c_b8"]
             grid2 = None if stub else W.build_grid(w2)
-            pv2 = stub_counts() if stub else (count_rays(W, w2, grid2, VIEW_ORDER, args.variant, local_rank) if rank == 0 else None)
-            pv2 = env.bcast(pv2)
+            # (rank 0 counts alone: a failure there must reach every rank, or the others would wait in the broadcast for ever)
+            pv2, err2 = None, None
+            if stub:
+                pv2 = stub_counts()
+            elif rank == 0:
+                try:
+                    pv2 = count_rays(W, w2, grid2, VIEW_ORDER, args.variant, local_rank)
+                except Exception as e:  # noqa: BLE001
+                    err2 = f"{type(e).__name__}: {e}"
+            pv2, err2 = env.bcast((pv2, err2))
+            if err2:
+                raise RuntimeError(f"counting the rays of {w2.name} failed on rank 0: {err2}")
             leg2, rep2 = tuned_leg(env, W, w2, grid2, args.dist_batch, True)
             est2 = leg2.estimate_frame_ms()
             steps2 = int(min(args.steps, max(6, 2000.0 / est2)))
