@@ -183,8 +183,8 @@ def hbm_achievable(dev):
 
 # ------------------------------------------------------------------------------------------------ PMC (rocprofv3)
 PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
-              ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVES",
-               "SQ_BUSY_CYCLES"]]
+              ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH",
+               "SQ_INSTS"]]
 
 
 def pmc_child(args) -> None:
@@ -856,7 +856,7 @@ def main(argv=None) -> None:
             pmc, pmc_note = pmc_from_profile(w.brick_dimension)
             if args.pmc == "auto":
                 pmc_note = f"{pmc_note} (live measurement failed: {why})"
-        traffic = issue_ipc = valu_frac = None
+        traffic = issue_ipc = valu_frac = issue_slots_frac = None
         insts = None
         clock_hz = None
         if pmc is not None:
@@ -874,6 +874,12 @@ def main(argv=None) -> None:
                 simds = int(di[1]) * 4
                 issue_ipc = sum(insts.values()) / (simds * avg_ms * 1e-3 * clock_hz)
                 valu_frac = insts["SQ_INSTS_VALU"] * 2.0 / (simds * avg_ms * 1e-3 * clock_hz)
+                # every instruction takes one issue slot of its SIMD, a wave64 vector instruction two ("issue slots")
+                issued = pmc.get("SQ_INSTS") or (sum(insts.values()) + pmc.get("SQ_INSTS_BRANCH", 0.0))
+                issue_slots_frac = (issued + insts["SQ_INSTS_VALU"]) / (simds * avg_ms * 1e-3 * clock_hz)
+                for k in ("SQ_INSTS_BRANCH", "SQ_INSTS"):
+                    if k in pmc:
+                        insts[k] = pmc[k]
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_note": pmc_note,
@@ -890,6 +896,11 @@ def main(argv=None) -> None:
             "algorithmic_bytes_per_launch": avg_bytes,
             "issued_bytes": avg_issued, "issued_GBps": avg_issued / (avg_ms * 1e-3) / 1e9,
             "frac_issued": avg_issued / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "issue_slots_frac": issue_slots_frac,
+            "issue_slots_note": "(SQ_INSTS + SQ_INSTS_VALU) / (SIMDs x kernel_ms_avg x engine clock): a SIMD issues about one instruction per clock "
+                                "in total, a wave64 vector instruction taking two slots (tools/ubench/issue_probe.hip; every same-box A/B of the walk "
+                                "loops agrees with cost = 2 V + S + rest, DESIGN.md 4) - the share of its issue slots the launch fills is the "
+                                "ceiling this path runs against, not HBM",
             "valu_frac": valu_frac,
             "valu_frac_note": "SQ_INSTS_VALU x 2 cycles (a wave64 vector instruction holds its SIMD's pipe for two) / (SIMDs x kernel_ms_avg x "
                               "engine clock): the share of the vector pipe the launch keeps busy — the ceiling that binds this path; "

@@ -185,7 +185,8 @@ struct GridWalkRegs {
     "s_andn2_b64 %[" MXY "], exec, %[" MXY "]\n\t"      /* x or y crossed */ \
     "s_andn2_b64 %[" MX "], %[" MXY "], %[" MY "]\n\t"  /* x crossed */    \
     /* side_dist of the crossed axis += |1/dir|: one add under the axis' lane mask as EXEC instead of three adds and three  \
-       selects (the loop is bound by the vector pipe; the scalar unit has slots to spare) */                                  \
+       selects (a SIMD issues one instruction per clock in total and a vector instruction takes two slots: 3 V + 5 S = 11     \
+       slots against 12; the all-vector form of round 3, 5 S + 16 V per trip, measured the same: DESIGN.md 4 "issue slots") */ \
     "s_mov_b64 %[ex], exec\n\t"                                           \
     "s_mov_b64 exec, %[" MX "]\n\t"                                       \
     "v_add_f32_e64 %[sdx], %[sdx], |%[ix]|\n\t"                           \
