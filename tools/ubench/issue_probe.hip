@@ -1,7 +1,10 @@
 // issue_probe.hip — how many scalar and vector instructions a gfx950 CU issues per clock, alone and mixed ("issue slots")
-// the CU's four SIMDs (measurement tool; hipcc --offload-arch=gfx950 -O2 issue_probe.hip -o issue_probe).
-// Each wave runs ITER iterations of a block of 32 instructions: mode 0 scalar only, 1 vector only, 2 one scalar per vector,
-// 3 one scalar per two vectors.  Workgroups of 256 threads (one wave per SIMD), k workgroups per CU.
+// and whether the scalar unit is shared by the CU's four SIMDs (measurement tool; hipcc --offload-arch=gfx950 -O2 issue_probe.hip -o issue_probe).
+// Each wave runs 20 000 iterations of a block of ~32 independent adds (four chains per kind): scalar only, vector only, and mixes
+// 1:1, 1:2, 1:3, 2:1.  One or two workgroups per CU (an LDS request makes exactly that many fit) of 1-4 waves per SIMD.  Rates are per
+// tick of s_memtime over a wave's own loop (printed beside the 100 MHz counter: the tick is the 2.4 GHz shader clock); the waves of a
+// CU do not run side by side for the whole launch (the oldest is served first), so for rates of the WHOLE launch divide the instruction
+// totals by the event time instead: vector only 0.42 / clock / SIMD, scalar only 0.92 / clock / CU, 1:2 -> 0.70 per CU + 0.35 per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
