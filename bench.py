@@ -265,6 +265,70 @@ def pmc_from_profile(brick_dimension: int):
     return None, "traversal kernel not found in " + os.path.basename(files[-1])
 
 
+# ------------------------------------------------------------------------------------------------ N > 1: probe of the native pipeline
+PROBE_FRAMES = ["V0", "V1", "V2", "V1", "V2", "V0", "V0", "V2", "V1", "V1", "V0", "V2", "V2", "V0", "V1", "V2"]
+
+
+def dist_probe_child(args) -> None:
+    """`bench.py --dist-probe`: one rank of a short run of the native RCCL pipeline (a 332 x 210 frame, batches of 1 and of 8 frames
+    per collective, each on its own communicator), in a process of its own.  Rank 0 compares the assembled frame with the frame one
+    context renders alone.  Exit code 0 = this rank got through.  No torch import; nothing on stdout."""
+    import numpy as np
+    from zig_vulkan_amd import workloads as W
+    uids = bytes.fromhex(args.probe_uid)
+    rank, world, device = args.probe_rank, args.probe_world, args.probe_device
+    w = W.Workload("probe", 332, 210, 64, 4, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    ref = None
+    if rank == 0:
+        plain = W.make_renderer(w, grid, device_id=device)
+        W.set_view(plain, PROBE_FRAMES[-1])
+        plain.draw()
+        ref = plain.read_rgba8().copy()
+        plain.deinit()
+    for i, batch in enumerate((1, 8)):
+        rt = W.make_renderer(w, grid, device_id=device, shard_rank=rank, shard_count=world)
+        rt.dist_init(uids[128 * i:128 * (i + 1)], rank, world, 4, frames_per_launch=batch)
+        for v in PROBE_FRAMES:
+            W.set_view(rt, v)
+            rt.dist_frame()
+        rt.dist_wait()
+        if rank == 0 and not np.array_equal(rt.dist_read_frame(), ref):
+            print(f"[bench probe] batch {batch}: the assembled frame differs from the single-context frame", file=sys.stderr)
+            sys.exit(3)
+        rt.deinit()
+    sys.exit(0)
+
+
+def native_probe(env, timeout: float):
+    """Before any timed leg at N > 1: every rank runs dist_probe_child in a child process (the children form their own
+    communicators on the same GPUs).  A hang inside a collective cannot be recovered from in-process; in a child it is a
+    timeout, the child is killed, and every rank takes the torch.distributed path instead.  Returns (ok on every rank, report)."""
+    from zig_vulkan_amd import VoxelRT
+    uids = (VoxelRT.dist_unique_id() + VoxelRT.dist_unique_id()) if env.rank == 0 else None
+    uids = env.bcast(uids)
+    cmd = [sys.executable, os.path.abspath(__file__), "--dist-probe", "--probe-uid", uids.hex(), "--probe-rank", str(env.rank),
+           "--probe-world", str(env.world), "--probe-device", str(env.local_rank)]
+    child_env = {k: v for k, v in os.environ.items()
+                 if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
+                 and not k.startswith("TORCHELASTIC_")}
+    t0 = time.perf_counter()
+    why = ""
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=child_env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+        ok = int(r.returncode == 0)
+        if not ok:
+            why = f"exit code {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"
+    except subprocess.TimeoutExpired:   # (subprocess.run has killed the child)
+        ok, why = 0, f"no answer within {timeout:.0f} s"
+    except Exception as e:  # noqa: BLE001
+        ok, why = 0, f"{type(e).__name__}: {e}"
+    if not ok:
+        print(f"[bench rank {env.rank}] probe of the native RCCL pipeline failed: {why}", file=sys.stderr)
+    all_ok = bool(env.all_min_int(ok))
+    return all_ok, {"ok": all_ok, "seconds": time.perf_counter() - t0, "this_rank": "ok" if ok else why}
+
+
 # ------------------------------------------------------------------------------------------------ launch plumbing
 def ensure_ranks(args, argv) -> None:
     """`--gpus N` with N > 1 and no rank environment: re-execute under torch.distributed.run with N ranks on this node.
@@ -652,12 +716,23 @@ def main(argv=None) -> None:
                          "auto-tune over three candidates around 100 - 70 (world - 2) / 6")
     ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the secondary leg on BASELINE's sharded config (4K, 1024^3)")
     ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")
+    ap.add_argument("--no-native-probe", action="store_true",
+                    help="N > 1: skip the child-process probe of the native RCCL pipeline that decides between it and the torch path")
+    ap.add_argument("--probe-timeout", type=float, default=120.0)
+    ap.add_argument("--dist-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--probe-uid", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--probe-rank", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--probe-world", type=int, default=1, help=argparse.SUPPRESS)
+    ap.add_argument("--probe-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)            # tests/test_bench_plumbing.py
     ap.add_argument("--stub-fail-native-on", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
 
     if args.pmc_child:
         pmc_child(args)
+        return
+    if args.dist_probe:
+        dist_probe_child(args)
         return
     ensure_ranks(args, argv)
 
@@ -729,6 +804,9 @@ def main(argv=None) -> None:
 
     # ---- the timed legs ----
     want_native = args.dist == "native"
+    probe_report = None
+    if sharded and world > 1 and want_native and not stub and not args.no_native_probe:
+        want_native, probe_report = native_probe(env, args.probe_timeout)
     legs_out = {}
     tune_reports = {}
     if not sharded:
@@ -955,6 +1033,7 @@ def main(argv=None) -> None:
                                 "with one collective (N frames of latency for 2-3x the frame rate at 8 ranks: a rank's 1/R of the tiles does not "
                                 "fill a GPU); `value` is the last leg's")
             out["root_share_tuning"] = tune_reports
+            out["native_probe"] = probe_report   # None: not run (one rank, --dist torch, --no-native-probe)
             out["secondary"] = secondary
         if world == 1 and not sharded and not args.no_cpu_baseline and not stub:
             # frames of this library for the parity certificate: the product build, and its fused-arithmetic twin where built

@@ -105,3 +105,48 @@ def test_metric_string_follows_the_workload():
     assert "1920x1080 on 512^3" in bench.metric_name(W.WORKLOADS[W.HEADLINE])
     assert "256x256 on 64^3" in bench.metric_name(W.WORKLOADS["cfg0_256x256_64c_b4"])
     assert "3840x2160 on 2048^3" in bench.metric_name(W.WORKLOADS["cfg4_4k_2048c_b8_sparse"])
+
+
+def _import_bench():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+class _ProbeEnv:
+    """The slice of bench.Env that native_probe uses, for one rank."""
+    rank, world, local_rank = 0, 2, 0
+
+    def bcast(self, obj):
+        return obj
+
+    def all_min_int(self, v):
+        return v
+
+
+@pytest.mark.parametrize("child, expect_ok, expect_text", [
+    ("import sys; sys.exit(0)", True, "ok"),
+    ("import sys; print('the shard of rank 1 never arrived', file=sys.stderr); sys.exit(3)", False, "never arrived"),
+    ("import time; time.sleep(60)", False, "no answer within"),
+])
+def test_native_probe_turns_a_failing_or_hanging_child_into_the_torch_path(monkeypatch, child, expect_ok, expect_text):
+    """N > 1: the native RCCL pipeline is first run by a child process of every rank (bench.native_probe).  A child that fails, or
+    hangs in a collective, must cost a bounded wait and send every rank to the torch.distributed path — never hang the bench."""
+    import subprocess
+    import zig_vulkan_amd
+    bench = _import_bench()
+    monkeypatch.setattr(zig_vulkan_amd.VoxelRT, "dist_unique_id", staticmethod(lambda: bytes(128)))
+    real_run = subprocess.run
+
+    def fake_run(cmd, **kw):
+        assert "--dist-probe" in cmd and "--probe-world" in cmd
+        assert "RANK" not in kw["env"] and "WORLD_SIZE" not in kw["env"]   # the child must not join the parent's process group
+        return real_run([sys.executable, "-c", child], **{k: v for k, v in kw.items() if k != "cwd"})
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    ok, report = bench.native_probe(_ProbeEnv(), timeout=2.0)
+    assert ok is expect_ok and report["ok"] is expect_ok
+    assert expect_text in report["this_rank"]
+    assert report["seconds"] < 30

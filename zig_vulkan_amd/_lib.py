@@ -260,9 +260,15 @@ DEV_LIB_PATH = os.path.join(_HERE, "libvrt_hip_dev.so")        # + the variants 
 
 def rccl_library_path() -> str:
     """The RCCL the process already uses: PyTorch's bundled librccl.so (backend "nccl" on ROCm)."""
-    import torch
-    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-    return path if os.path.exists(path) else "librccl.so"
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        origin = sys.modules["torch"].__file__
+    else:   # (located, not imported: a process that only needs the library's path does not pay for `import torch`)
+        spec = importlib.util.find_spec("torch")
+        origin = spec.origin if spec is not None else None
+    path = os.path.join(os.path.dirname(origin), "lib", "librccl.so") if origin else ""
+    return path if path and os.path.exists(path) else "librccl.so"
 
 
 def check(rc: int, ctx=None) -> None:
