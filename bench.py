@@ -981,7 +981,8 @@ def main(argv=None) -> None:
                                 "ceiling this path runs against, not HBM",
             "valu_frac": valu_frac,
             "valu_frac_note": "SQ_INSTS_VALU x 2 cycles (a wave64 vector instruction holds its SIMD's pipe for two) / (SIMDs x kernel_ms_avg x "
-                              "engine clock): the share of the vector pipe the launch keeps busy — the ceiling that binds this path; "
+                              "engine clock): the share of the vector pipe the launch keeps busy (the ceiling is issue_slots_frac: vector instructions share "
+                              "their SIMD's one issue slot per clock with everything else); "
                               "frac_issued = issued_GBps / HBM peak; hbm_traffic_GBps = traffic / kernel time: what HBM really carries",
             "hbm_traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
             "hbm_achievable": hbm,

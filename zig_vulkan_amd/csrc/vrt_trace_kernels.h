@@ -216,7 +216,7 @@ struct GridWalkRegs {
     "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"
 // ... or, with the status expanded to ONE BYTE PER CELL (TraceParams::status_bytes, derived from binding 3 on every status
 // upload), the byte itself: no shift for the address, no bit-field extract for the test — 16 instead of 18 vector instructions
-// per trip of a loop that is bound by the vector pipe (two cycles per wave64 instruction per SIMD)
+// per trip of a loop that is bound by instruction issue (a wave64 vector instruction takes two of its SIMD's issue slots)
 #define VRT_TEST_BYTE(WORD, IDX) "v_cmp_ne_u32_e32 vcc, 0, %[" WORD "]\n\t"
 #define VRT_LOAD_BYTE(IDX, IDXN, WORD, WORDN)                                        \
     "buffer_load_ubyte %[" WORDN "], %[" IDXN "], %[rsrc], 0 offen\n\t"   \
