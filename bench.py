@@ -363,7 +363,7 @@ class _StubRT:
         self.camera = types.SimpleNamespace(d_camera=(bytearray(96)))
         self.frames = 0
         self.batch = batch
-        self.frame_s = 0.0004 * (1.0 + abs(root_share - 60) / 100.0) / (1.0 + 0.25 * (batch > 1))
+        self.frame_s = 0.0004 * (1.0 + 4.0 * abs(root_share - 60) / 100.0) / (1.0 + 0.25 * (batch > 1))   # 2.6 x between the candidates: clear of a loaded host's sleep jitter
 
     def draw(self, frames: int = 1):
         self.frames += frames
