@@ -193,6 +193,8 @@ pub const TUNE_DIST_NO_BROADCAST: u32 = 1 << 4;
 pub const TUNE_NO_CELL_OCCUPANCY: u32 = 1 << 5;
 pub const TUNE_NO_START_SHORTCUT: u32 = 1 << 6;
 pub const TUNE_PATH_AHEAD: u32 = 1 << 7;
+pub const TUNE_PATH_DISTANCE: u32 = 1 << 8;
+pub const TUNE_NO_PATH_DILATED: u32 = 1 << 9;
 
 pub const GridConfig = extern struct { // Grid.zig:13-20
     brick_alloc: u64 = 0,

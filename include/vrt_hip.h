@@ -153,7 +153,9 @@ typedef struct vrt_config {
 #define VRT_TUNE_NO_CELL_OCCUPANCY  (1u << 5) /* vrt_path_kernel: reach a brick's bits through brick_index instead of the by-cell copy */
 #define VRT_TUNE_NO_START_SHORTCUT  (1u << 6) /* always look brick_start_index up, even when it is slot * B^3 for every brick */
 #define VRT_TUNE_PATH_AHEAD          (1u << 7) /* development build only: vrt_path_kernel's walk loop pipelined two trips ahead (measured slower) */
-#define VRT_TUNE_ALL                0xFFu
+#define VRT_TUNE_PATH_DISTANCE       (1u << 8) /* development build only: vrt_path_kernel's walk loop on the L1 distance field of the occupied cells, a byte per cell (measured slower) */
+#define VRT_TUNE_NO_PATH_DILATED     (1u << 9) /* vrt_path_kernel: the half-block walk loop on the linear cell index instead of the dilated one */
+#define VRT_TUNE_ALL                0x3FFu
 
 typedef struct vrt_ctx vrt_ctx;
 

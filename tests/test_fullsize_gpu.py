@@ -274,14 +274,16 @@ def test_skip_to_the_box_changes_no_pixel_at_full_size(name):
 
 def test_path_kernel_memory_layouts_change_no_pixel():
     """vrt_path_kernel on a scene of the path-trace configuration's kind (sparse 1024^3, 8^3 bricks, 4 samples, 3 bounces) at 720p:
-    bricks staged in LDS or read through the L1, walk loop on half-block words or on the linear words, jump to the box or not,
+    bricks staged in LDS or read through the L1, walk loop on half-block words (dilated or linear cell index) or on the linear words,
+    jump to the box or not,
     brick bits reached by cell or through brick_index, start index multiplied or looked up — all the same frame; so is the
     lockstep kernel's."""
     w = W.Workload("path_layouts", 1280, 720, 1024, 8, 4, 2, True, 5.0, "sparse", 0.08, 200000)
     views = ["V0", "V1x"]
     path = 1 << 23
     base = _frames_with_flags(w, views, 0, kernel_variant=path)
-    for flags in (L.TUNE_NO_PATH_BRICK_LDS, L.TUNE_NO_PATH_HALFBLOCKS, L.TUNE_PATH_EAGER_START, L.TUNE_NO_CELL_OCCUPANCY, L.TUNE_NO_START_SHORTCUT,
+    for flags in (L.TUNE_NO_PATH_DILATED, L.TUNE_NO_PATH_DILATED | L.TUNE_NO_SKIP_TO_BOX | L.TUNE_NO_CELL_OCCUPANCY, L.TUNE_NO_SKIP_TO_BOX,
+                  L.TUNE_NO_PATH_BRICK_LDS, L.TUNE_NO_PATH_HALFBLOCKS, L.TUNE_PATH_EAGER_START, L.TUNE_NO_CELL_OCCUPANCY, L.TUNE_NO_START_SHORTCUT,
                   L.TUNE_NO_CELL_OCCUPANCY | L.TUNE_NO_START_SHORTCUT | L.TUNE_PATH_EAGER_START,
                   L.TUNE_NO_PATH_BRICK_LDS | L.TUNE_NO_PATH_HALFBLOCKS | L.TUNE_NO_SKIP_TO_BOX):
         for v, a, b in zip(views, base, _frames_with_flags(w, views, flags, kernel_variant=path)):
@@ -292,6 +294,10 @@ def test_path_kernel_memory_layouts_change_no_pixel():
         for flags in (L.TUNE_PATH_AHEAD, L.TUNE_PATH_AHEAD | L.TUNE_NO_CELL_OCCUPANCY | L.TUNE_NO_PATH_BRICK_LDS | L.TUNE_NO_SKIP_TO_BOX):
             for v, a, b in zip(views, base, _frames_with_flags(w, views, flags, kernel_variant=path, library=dev_library_or_none())):
                 assert np.array_equal(a, b), ("two trips ahead", flags, v)
+    if dev_library_or_none():  # the distance-field walk lives in the development build
+        for flags in (L.TUNE_PATH_DISTANCE, L.TUNE_PATH_DISTANCE | L.TUNE_NO_SKIP_TO_BOX | L.TUNE_NO_PATH_BRICK_LDS):
+            for v, a, b in zip(views, base, _frames_with_flags(w, views, flags, kernel_variant=path, library=dev_library_or_none())):
+                assert np.array_equal(a, b), ("distance field", flags, v)
     if dev_library_or_none():  # the block-skipping walk lives in the development build
         for v, a, b in zip(views, base, _frames_with_flags(w, views, 0, **variant_kwargs(path | (1 << 22)))):
             assert np.array_equal(a, b), ("block-skipping walk", v)

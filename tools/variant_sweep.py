@@ -25,6 +25,7 @@ for variant, flags in variants:
         W.set_view(rt, v)
         rt.draw(frames=max(2, frames // 2))
         rt.draw(frames=frames)
-        out.append(f"{v} {rt.last_kernel_ms():9.3f}")
+        import hashlib
+        out.append(f"{v} {rt.last_kernel_ms():9.3f} [{hashlib.sha256(rt.read_rgba8().tobytes()).hexdigest()[:8]}]")
     print(f"variant {variant:#010x} flags {flags:#04x} {rt.kernel_name():44s} " + "  ".join(out), flush=True)
     rt.deinit()

@@ -27,6 +27,8 @@ namespace vrt {
 KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, int shade);
 KernelFn path_kernel_halfblock_twin(KernelFn fn);
 KernelFn path_kernel_ahead_twin(KernelFn fn);
+KernelFn path_kernel_dist_twin(KernelFn fn);
+KernelFn path_kernel_dilated_twin(KernelFn fn);
 bool is_path_halfblock_kernel(KernelFn fn);
 const char *kernel_name_of(KernelFn fn);
 uint32_t resolve_variant(uint32_t variant);
@@ -40,6 +42,7 @@ hipError_t launch_assemble_rgb(const void *gathered, void *frame, uint32_t width
 hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_build_status_bytes(const TraceParams &p, hipStream_t stream);
 hipError_t launch_build_status_halfblocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
+hipError_t launch_build_cell_distance(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_build_cell_bounds(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, hipStream_t stream);
 hipError_t launch_check_start_is_slot(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, hipStream_t stream);
@@ -181,6 +184,7 @@ struct vrt_ctx {
     void *d_status_blocks = nullptr; // derived: 4x4x4 block words + block filter (vrt_trace.hip)
     int *d_cell_bounds = nullptr;    // derived: bounding box of the occupied cells (TraceParams::cell_bounds)
     uint8_t *d_status_bytes = nullptr; // derived: one byte per grid cell (TraceParams::status_bytes)
+    uint8_t *d_cell_distance = nullptr;      // derived: L1 distance of every cell to the nearest occupied cell (vrt_path_kernel<DIST>)
     uint32_t *d_status_halfblocks = nullptr; // derived: status bits by 4 x 4 x 2 cells per word (vrt_path_kernel on eligible grids)
     uint8_t *d_cell_occupancy = nullptr;     // derived: occupancy bits by cell (TraceParams::cell_occupancy; vrt_path_kernel, within a memory budget)
     uint32_t *d_start_is_slot = nullptr;     // derived: 1 = binding 6 holds slot * B^3 for every allocated brick (TraceParams::start_is_slot)
@@ -262,6 +266,7 @@ void free_ctx(vrt_ctx *c) {
     if (c->d_cell_bounds) (void)hipFree(c->d_cell_bounds);
     if (c->d_status_bytes) (void)hipFree(c->d_status_bytes);
     if (c->d_status_halfblocks) (void)hipFree(c->d_status_halfblocks);
+    if (c->d_cell_distance) (void)hipFree(c->d_cell_distance);
     if (c->d_cell_occupancy) (void)hipFree(c->d_cell_occupancy);
     if (c->d_start_is_slot) (void)hipFree(c->d_start_is_slot);
     if (c->dist) {
@@ -468,6 +473,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
 #ifndef VRT_DEV_VARIANTS
     if (cfg->tuning_flags & VRT_TUNE_PATH_AHEAD)
         return fail(nullptr, VRT_E_INVALID_ARG, "VRT_TUNE_PATH_AHEAD selects a development kernel: not in the product build of libvrt_hip (make dev)");
+    if (cfg->tuning_flags & VRT_TUNE_PATH_DISTANCE)
+        return fail(nullptr, VRT_E_INVALID_ARG, "VRT_TUNE_PATH_DISTANCE selects a development kernel: not in the product build of libvrt_hip (make dev)");
 #endif
     if ((cfg->kernel_variant & 0xFFu) >= vrt::kVariantCount || ((cfg->kernel_variant >> 28) && ((cfg->kernel_variant >> 16) & 0xFu) != 7u)) return fail(nullptr, VRT_E_INVALID_ARG, "unknown kernel_variant");
 
@@ -691,7 +698,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         }
     }
     uint32_t lockstep_variant = c->bounce_variant | vrt::kVariantLockstepBounce; // (before the path kernel's occupancy is filled in below)
-    bool want_halfblocks = false;
+    bool want_halfblocks = false, want_distance = false, want_dilated = false;
     {
         auto pow2 = [](uint32_t v) { return v >= 4u && (v & (v - 1u)) == 0u; };
         // Development build only (kernel_variant bit 22): the block-skipping walk of vrt_path_kernel<FILTER> — lanes in empty
@@ -724,6 +731,13 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
             // powers of two >= 4, y even): a third of the L1 requests of the linear words (vrt_trace_kernels.h)
             want_halfblocks = pow2(cfg->dim_x) && pow2(cfg->dim_z) && cfg->dim_y % 2u == 0u && !block_skip &&
                               !(cfg->tuning_flags & VRT_TUNE_NO_PATH_HALFBLOCKS);
+            // ... or the L1 distance field of the occupied cells, one byte per cell (any dimensions; cells < 2^31: the byte offset is
+            // the walk's 32-bit cell index)
+            want_distance = (cfg->tuning_flags & VRT_TUNE_PATH_DISTANCE) != 0u && !block_skip && cells < (1ull << 31);
+            if (want_distance) want_halfblocks = false;
+            // the half-block words through a dilated cell index (22 instead of 29 vector instructions per trip): all three dimensions
+            // powers of two
+            want_dilated = want_halfblocks && pow2(cfg->dim_y) && !(cfg->tuning_flags & VRT_TUNE_NO_PATH_DILATED);
         } else {
             c->bounce_variant |= vrt::kVariantLockstepBounce;
         }
@@ -733,6 +747,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         c->kernel = vrt::select_trace_kernel((int)cfg->brick_dimension, cnt, c->bounce_variant, 0);
         const bool ahead = (cfg->tuning_flags & VRT_TUNE_PATH_AHEAD) != 0u; // (development build: the product holds no such kernel)
         if (ahead) c->kernel = vrt::path_kernel_ahead_twin(c->kernel);
+        else if (want_distance) c->kernel = vrt::path_kernel_dist_twin(c->kernel);
+        else if (want_dilated) c->kernel = vrt::path_kernel_dilated_twin(c->kernel);
         else if (want_halfblocks) c->kernel = vrt::path_kernel_halfblock_twin(c->kernel);
         c->kernel_lockstep = vrt::select_trace_kernel((int)cfg->brick_dimension, cnt, lockstep_variant, 0);
         c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cnt, single_variant, 1);
@@ -743,6 +759,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
             if (!cnt) continue;
             c->product[shade] = vrt::select_trace_kernel((int)cfg->brick_dimension, false, shade == 0 ? c->bounce_variant : single_variant, shade);
             if (shade == 0 && ahead) c->product[shade] = vrt::path_kernel_ahead_twin(c->product[shade]);
+            else if (shade == 0 && want_distance) c->product[shade] = vrt::path_kernel_dist_twin(c->product[shade]);
+            else if (shade == 0 && want_dilated) c->product[shade] = vrt::path_kernel_dilated_twin(c->product[shade]);
             else if (shade == 0 && want_halfblocks) c->product[shade] = vrt::path_kernel_halfblock_twin(c->product[shade]);
         }
     };
@@ -773,10 +791,14 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
             VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_status_bytes), status_bytes_size));
             VRT_CREATE_HIP(hipMemsetAsync(c->d_status_bytes, 0, status_bytes_size, c->stream));
         }
-        if (any_kernel([](const vrt::KernelEntry &e) { return e.path && e.half; })) {
+        if (any_kernel([](const vrt::KernelEntry &e) { return e.path && (e.half || e.dil); })) {
             const size_t bytes_hb = (size_t)(cells / 32u) * 4u + 64u;
             VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_status_halfblocks), bytes_hb));
             VRT_CREATE_HIP(hipMemsetAsync(c->d_status_halfblocks, 0, bytes_hb, c->stream));
+        }
+        if (any_kernel([](const vrt::KernelEntry &e) { return e.path && e.dist; })) {
+            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_cell_distance), (size_t)cells + 64u));
+            VRT_CREATE_HIP(hipMemsetAsync(c->d_cell_distance, 0xFF, (size_t)cells + 64u, c->stream));
         }
         // the by-cell copy of the occupancy bits, for the persistent-lane kernel (scenes larger than the caches, where a brick entry
         // is a chain of dependent misses): at most 2 GiB, and — walked in global memory instead of LDS — a 32-bit bit index
@@ -858,6 +880,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.cell_bounds = c->d_cell_bounds;
     p.status_bytes = c->d_status_bytes;
     p.status_halfblocks = c->d_status_halfblocks;
+    p.cell_distance = c->d_cell_distance;
     p.cell_occupancy = c->d_cell_occupancy;
     p.start_is_slot = c->d_start_is_slot;
     p.status_cells = (uint32_t)cells;
@@ -990,6 +1013,7 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
         VRT_HIP(ctx, vrt::launch_build_cell_bounds(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
         VRT_HIP(ctx, vrt::launch_build_status_bytes(ctx->params, ctx->stream));
         VRT_HIP(ctx, vrt::launch_build_status_halfblocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
+        VRT_HIP(ctx, vrt::launch_build_cell_distance(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
         rcw = end_scene_write(ctx);
         if (rcw != VRT_OK) return rcw;
         ctx->status_dirty = false;

@@ -77,6 +77,10 @@ struct TraceParams {
     // derived from binding 3: one byte per grid cell, 1 = occupied (kVariantBytes: the walk loop reads the byte of the next cell)
     const uint8_t *status_bytes;
     uint32_t status_cells;               // grid cells = bytes of status_bytes
+    // derived from binding 3 (vrt_path_kernel<DIST>; nullptr: not built): one byte per grid cell, its L1 (Manhattan) distance in
+    // cells to the nearest occupied cell, 0 = occupied, capped at 255 — a walk of n trips cannot reach an occupied cell from a cell
+    // whose byte is > n, so the walk loop asks only where it has to (grid_walk_park_dist_gfx950)
+    const uint8_t *cell_distance;
     // derived from bindings 3-5 (vrt_path_kernel; nullptr: not built): the occupancy bits of every OCCUPIED cell's brick, stored by
     // cell (cell * B^3 / 8 bytes) — a brick entry then needs no brick_index look-up before it can ask for the brick's bits
     // (comp:337 -> comp:415 is one dependent miss less; the index is fetched only when a solid voxel was found)

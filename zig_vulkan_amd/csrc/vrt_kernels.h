@@ -25,7 +25,7 @@ enum StatusMode : int {
 struct KernelEntry {
     KernelFn fn;
     const char *name;
-    uint8_t path;      // 0: vrt_trace_kernel<B, COUNT, MODE, MIN_WAVES, SHADE, BLOCK>   1: vrt_path_kernel<B, MIN_WAVES, FILTER, HALF, AHEAD>
+    uint8_t path;      // 0: vrt_trace_kernel<B, COUNT, MODE, MIN_WAVES, SHADE, BLOCK>   1: vrt_path_kernel<B, MIN_WAVES, FILTER, HALF, AHEAD, DIST, DIL>
     uint8_t b;         // brick dimension
     uint8_t count;     // trace: counting build
     uint8_t mode;      // trace: StatusMode
@@ -35,6 +35,8 @@ struct KernelEntry {
     uint8_t filter;    // path: block-skipping walk behind the LDS block filter (development)
     uint8_t half;      // path: walk loop on half-block words
     uint8_t ahead;     // path: the walk loop pipelined two trips ahead (on the shader's linear words)
+    uint8_t dist;      // path: the walk loop on the L1 distance field of the occupied cells (TraceParams::cell_distance; development)
+    uint8_t dil;       // path: the half-block walk loop on a dilated cell index (all three grid dimensions powers of two)
 };
 struct KernelTable {
     const KernelEntry *entries;
@@ -46,7 +48,7 @@ KernelTable inst_trace_count();
 KernelTable inst_path();
 
 const KernelEntry *find_trace_kernel(int b, bool count, int mode, int min_waves, int shade, int block = 256);
-const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead = false);
+const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead = false, bool dist = false, bool dil = false);
 const KernelEntry *kernel_entry_of(KernelFn fn);
 int compiled_kernel_count();
 

@@ -58,6 +58,49 @@ __global__ __launch_bounds__(256) void vrt_build_status_halfblocks(const uint32_
     out[wi] = word;
 }
 
+// The L1 distance field of the occupied cells (TraceParams::cell_distance; grid_walk_park_dist_gfx950): one byte per cell, 0 where
+// the status bit is set, else min(255, Manhattan distance in cells to the nearest set bit).  The L1 distance transform separates:
+// seed 0 / 255, then along each axis in turn a forward and a backward sweep d = min(d, neighbour + 1) — exact after x, z, y (the
+// cap commutes with min and + 1).  One thread per status word for the seed; one thread per line of cells for a sweep (the line of
+// thread t along axis a: the t-th combination of the other two coordinates; consecutive threads are consecutive in the fastest
+// remaining coordinate).
+__global__ __launch_bounds__(256) void vrt_build_distance_seed(const uint32_t *__restrict__ status, uint8_t *__restrict__ out, uint32_t words, uint32_t cells) {
+    const uint32_t wi = blockIdx.x * 256u + threadIdx.x;
+    if (wi >= words) return;
+    const uint32_t bits = status[wi];
+    for (uint32_t k = 0; k < 32u; k++) {
+        const uint32_t gi = wi * 32u + k;
+        if (gi < cells) out[gi] = ((bits >> k) & 1u) ? 0u : 255u;
+    }
+}
+__global__ __launch_bounds__(256) void vrt_build_distance_sweep(uint8_t *__restrict__ d, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, uint32_t axis) {
+    // cell index = x + dim_x * (z + dim_z * y)
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    uint32_t n, stride, first;
+    if (axis == 0u) { // lines along x: one per (z, y)
+        if (t >= dim_z * dim_y) return;
+        n = dim_x, stride = 1u, first = t * dim_x;
+    } else if (axis == 1u) { // lines along z: one per (x, y)
+        if (t >= dim_x * dim_y) return;
+        n = dim_z, stride = dim_x, first = (t % dim_x) + dim_x * dim_z * (t / dim_x);
+    } else { // lines along y: one per (x, z)
+        if (t >= dim_x * dim_z) return;
+        n = dim_y, stride = dim_x * dim_z, first = t;
+    }
+    uint32_t run = 255u;
+    for (uint32_t i = 0; i < n; i++) {
+        uint8_t *c = d + (size_t)first + (size_t)i * stride;
+        run = min(min(run + 1u, 255u), (uint32_t)*c);
+        *c = (uint8_t)run;
+    }
+    run = 255u;
+    for (uint32_t i = n; i-- > 0u;) {
+        uint8_t *c = d + (size_t)first + (size_t)i * stride;
+        run = min(min(run + 1u, 255u), (uint32_t)*c);
+        *c = (uint8_t)run;
+    }
+}
+
 // One byte per grid cell (TraceParams::status_bytes): 1 where the cell's status bit is set.  One thread per status word.
 __global__ __launch_bounds__(256) void vrt_build_status_bytes(const uint32_t *__restrict__ status, uint8_t *__restrict__ out, uint32_t words, uint32_t /*cells*/) {
     const uint32_t wi = blockIdx.x * 256u + threadIdx.x;
@@ -369,9 +412,10 @@ const KernelEntry *find_trace_kernel(int b, bool count, int mode, int min_waves,
         return !e.path && e.b == b && (e.count != 0) == count && e.mode == mode && e.min_waves == min_waves && e.shade == shade && e.block == block;
     });
 }
-const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead) {
+const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead, bool dist, bool dil) {
     return find_entry([&](const KernelEntry &e) {
-        return e.path && e.b == b && e.min_waves == min_waves && (e.filter != 0) == filter && (e.half != 0) == half && (e.ahead != 0) == ahead;
+        return e.path && e.b == b && e.min_waves == min_waves && (e.filter != 0) == filter && (e.half != 0) == half && (e.ahead != 0) == ahead &&
+               (e.dist != 0) == dist && (e.dil != 0) == dil;
     });
 }
 const KernelEntry *kernel_entry_of(KernelFn fn) {
@@ -464,14 +508,28 @@ bool is_path_kernel(KernelFn fn) {
 // the same kernel with the walk loop on half-block words (TraceParams::status_halfblocks); fn itself if it has none
 KernelFn path_kernel_halfblock_twin(KernelFn fn) {
     const KernelEntry *e = kernel_entry_of(fn);
-    if (!e || !e->path || e->filter || e->half || e->ahead) return fn;
+    if (!e || !e->path || e->filter || e->half || e->ahead || e->dist || e->dil) return fn;
     const KernelEntry *t = find_path_kernel(e->b, e->min_waves, false, true);
+    return t ? t->fn : fn;
+}
+// the same kernel with the half-block walk loop on a dilated cell index; fn itself if it has none
+KernelFn path_kernel_dilated_twin(KernelFn fn) {
+    const KernelEntry *e = kernel_entry_of(fn);
+    if (!e || !e->path || e->filter || e->half || e->ahead || e->dist || e->dil) return fn;
+    const KernelEntry *t = find_path_kernel(e->b, e->min_waves, false, false, false, false, true);
+    return t ? t->fn : fn;
+}
+// the same kernel with the walk loop on the distance field (TraceParams::cell_distance); fn itself if it has none
+KernelFn path_kernel_dist_twin(KernelFn fn) {
+    const KernelEntry *e = kernel_entry_of(fn);
+    if (!e || !e->path || e->filter || e->half || e->ahead || e->dist || e->dil) return fn;
+    const KernelEntry *t = find_path_kernel(e->b, e->min_waves, false, false, false, true);
     return t ? t->fn : fn;
 }
 // the plain path kernel's twin with the walk loop two trips ahead; fn itself if it has none
 KernelFn path_kernel_ahead_twin(KernelFn fn) {
     const KernelEntry *e = kernel_entry_of(fn);
-    if (!e || !e->path || e->half || e->filter || e->ahead) return fn;
+    if (!e || !e->path || e->half || e->filter || e->ahead || e->dist || e->dil) return fn;
     const KernelEntry *t = find_path_kernel(e->b, e->min_waves, false, false, true);
     return t ? t->fn : fn;
 }
@@ -521,6 +579,16 @@ hipError_t launch_build_status_halfblocks(const TraceParams &p, uint32_t dim_x, 
     const uint32_t words = (dim_x >> 2) * (dim_z >> 2) * (dim_y >> 1);
     hipLaunchKernelGGL(vrt_build_status_halfblocks, dim3((words + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
                        const_cast<uint32_t *>(p.status_halfblocks), dim_x, dim_y, dim_z);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_cell_distance(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
+    if (!p.cell_distance) return hipSuccess;
+    uint8_t *d = const_cast<uint8_t *>(p.cell_distance);
+    hipLaunchKernelGGL(vrt_build_distance_seed, dim3((p.status_words + 255u) / 256u), dim3(256), 0, stream, p.brick_status, d, p.status_words, p.status_cells);
+    const uint32_t lines[3] = {dim_z * dim_y, dim_x * dim_y, dim_x * dim_z};
+    for (uint32_t axis = 0; axis < 3u; axis++)
+        hipLaunchKernelGGL(vrt_build_distance_sweep, dim3((lines[axis] + 255u) / 256u), dim3(256), 0, stream, d, dim_x, dim_y, dim_z, axis);
     return hipGetLastError();
 }
 

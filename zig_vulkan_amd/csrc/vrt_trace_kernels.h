@@ -173,7 +173,23 @@ struct GridWalkRegs {
     uint32_t stub;                   // out: 0 the call ended in its first trip, 1/2 in a later trip, 3 every lane left
 };
 
+// the next cell's index: the linear cell index advances by the crossed axis' stride ...
+#define VRT_STEP_LINEAR(IDX, IDXN, MX, MY)                                \
+    "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[" MY "]\n\t"              \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[" MX "]\n\t"               \
+    "v_add_u32_e32 %[" IDXN "], %[" IDX "], %[t0]\n\t"
+// ... or, in the DILATED form (grid_walk_park_dilated_gfx950), the crossed axis' bit field is incremented: stx / sty / stz hold the
+// complement of that field's mask (all ones for an axis the ray does not move along: nothing changes), the carry runs through the
+// ones filled into the other fields, and the other fields are put back
+#define VRT_STEP_DILATED(IDX, IDXN, MX, MY)                               \
+    "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[" MY "]\n\t"              \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[" MX "]\n\t"               \
+    "v_or_b32_e32 %[t1], %[" IDX "], %[t0]\n\t"                           \
+    "v_add_u32_e32 %[t1], 1, %[t1]\n\t"                                   \
+    "v_bfi_b32 %[" IDXN "], %[t0], %[" IDX "], %[t1]\n\t"
 #define VRT_TRIP_T(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT) \
+    VRT_TRIP_S(VRT_STEP_LINEAR, TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT)
+#define VRT_TRIP_S(STEP, TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT) \
     /* The crossed distance = the smallest side distance, and the crossed axis from it: the shader's                       \
        x<y ? (x<z ? X : Z) : (y<z ? Y : Z) picks Z whenever z is minimal (ties included), else Y whenever y is, else X —    \
        one min3 and two equality tests instead of three compares and two selects.  (A walk never holds a NaN side          \
@@ -195,9 +211,7 @@ struct GridWalkRegs {
     "s_andn2_b64 exec, %[ex], %[" MXY "]\n\t"                             \
     "v_add_f32_e64 %[sdz], %[sdz], |%[iz]|\n\t"                           \
     "s_mov_b64 exec, %[ex]\n\t"                                           \
-    "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[" MY "]\n\t"              \
-    "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[" MX "]\n\t"               \
-    "v_add_u32_e32 %[" IDXN "], %[" IDX "], %[t0]\n\t"                    \
+    STEP(IDX, IDXN, MX, MY)                                               \
     LOAD(IDX, IDXN, WORD, WORDN) /* request the next cell's word; wait for the one requested a trip ago */ \
     TEST(WORD, IDX)                                                       \
     "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[" MX "]\n\t"          \
@@ -390,19 +404,20 @@ struct GridParkRegs {
 #define VRT_IN_FROM(MX, MY) "v_cndmask_b32_e64 %[t0], 2, 1, %[" MY "]\n\t" "v_cndmask_b32_e64 %[t0], %[t0], 0, %[" MX "]\n\t"
 #define VRT_SWAP_SETS "v_swap_b32 %[tsa], %[tsb]\n\t" "v_swap_b32 %[idxa], %[idxb]\n\t"
 
-#define VRT_PARK_WALK_ASM(LIMIT, LOAD, TEST, WAITALL) \
+#define VRT_PARK_WALK_ASM(LIMIT, LOAD, TEST, WAITALL, AT30) VRT_PARK_WALK_ASM_S(VRT_STEP_LINEAR, LIMIT, LOAD, TEST, WAITALL, AT30)
+#define VRT_PARK_WALK_ASM_S(STEP, LIMIT, LOAD, TEST, WAITALL, AT30) \
         "s_mov_b64 %[save], exec\n\t" \
         "s_mov_b64 exec, %[alive]\n\t" \
         "s_mov_b64 %[parked], 0\n\t" \
-        VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "10f") \
+        VRT_TRIP_S(STEP, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "10f") \
         "0:\n\t" \
-        VRT_TRIP_T("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "11f") \
+        VRT_TRIP_S(STEP, "tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "11f") \
         "21:\n\t" \
-        VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "12f") \
+        VRT_TRIP_S(STEP, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "12f") \
         "22:\n\t" \
-        VRT_TRIP_T("tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "13f") \
+        VRT_TRIP_S(STEP, "tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "13f") \
         "23:\n\t" \
-        VRT_TRIP_T("tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "14f") \
+        VRT_TRIP_S(STEP, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "14f") \
         "24:\n\t" \
         "s_cbranch_execz 31f\n\t" \
         /* back edge (after an A trip): keep walking while at least min_alive lanes are moving; fewer -> hand the wave back \
@@ -421,6 +436,7 @@ struct GridParkRegs {
         WAITALL \
         VRT_SWAP_SETS \
         "v_mov_b32_e32 %[worda], %[wordb]\n\t" \
+        AT30 \
         "s_mov_b64 %[mxb], %[mxa]\n\t" \
         "s_mov_b64 %[myb], %[mya]\n\t" \
         "s_branch 32f\n\t" \
@@ -444,7 +460,7 @@ VRT_DI void grid_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, u
     unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb, n;
-    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_BUFFER, VRT_TEST_BIT, VRT_WAIT_BUFFER) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS : "vcc", "scc");
+    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_BUFFER, VRT_TEST_BIT, VRT_WAIT_BUFFER, "") : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS : "vcc", "scc");
 }
 
 // The voxel level on the same park loop (vrt_path_kernel): voxels of one brick, bits of brick_occupancy by their global bit
@@ -456,7 +472,7 @@ VRT_DI void voxel_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, 
     unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb, n;
-    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_BUFFER, VRT_TEST_BIT, VRT_WAIT_BUFFER) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
+    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_BUFFER, VRT_TEST_BIT, VRT_WAIT_BUFFER, "") : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max) : "vcc", "scc");
 }
 
 // The same with the brick's occupancy bits staged in LDS (8^3 bricks: 64 bytes = 16 words per lane).  On a scene larger than
@@ -478,7 +494,7 @@ VRT_DI void voxel_walk_park_lds_gfx950(Walk &w, const f3 &inv_dir, uint32_t &ind
     float t0, t1, t2;
     uint32_t wordb, n;
     const uint32_t rsrc = 0u; // (operand of the shared input list; unused)
-    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_LDS_BRICK, VRT_TEST_BIT, VRT_WAIT_LDS) : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max), [lb] "v"(lane_base) : "vcc", "scc");
+    asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_LDS_BRICK, VRT_TEST_BIT, VRT_WAIT_LDS, "") : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max), [lb] "v"(lane_base) : "vcc", "scc");
 }
 #undef VRT_LOAD_LDS_BRICK
 // byte address (LDS) of the word that holds bit `bit_index` of the lane's staged brick
@@ -537,18 +553,102 @@ VRT_DI void grid_walk_park_halfblocks_gfx950(Walk &w, const f3 &inv_dir, uint32_
     unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
     float t0, t1, t2;
     uint32_t wordb, n;
-    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_HALFBLOCK, VRT_TEST_HALFBLOCK, VRT_WAIT_BUFFER)
+    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_HALFBLOCK, VRT_TEST_HALFBLOCK, VRT_WAIT_BUFFER, "")
                  : VRT_PARK_WALK_OPERANDS
                  : VRT_PARK_WALK_INPUTS, [nmask] "s"(hb.nmask), [mx] "s"(hb.mx), [mzs] "s"(hb.mzs), [mys] "s"(hb.mys), [lx] "s"(hb.lx), [lxz] "s"(hb.lxz)
                  : "vcc", "scc");
 }
 #undef VRT_LOAD_HALFBLOCK
 #undef VRT_TEST_HALFBLOCK
+// ---- the half-block park loop on a DILATED cell index (vrt_path_kernel<DIL>, round 3) ------------------------------------------
+// The half-block loop above pays 17 of its 29 vector instructions per trip for turning a linear cell index into a half-block word
+// index and a bit position.  Here the walk's index IS that pair: bits 0-4 = the cell's place in its half-block
+// (x&3 | (z&3) << 2 | (y&1) << 4), the bits above = the half-block word's index (x>>2 | (z>>2) << (lx-2) | (y>>1) << (lx+lz-4)) —
+// three bit fields per axis interleaved.  A step increments the crossed axis' field (VRT_STEP_DILATED: the carry runs through ones
+// filled into the other fields); so that every step is an increment, an axis the ray walks DOWN is stored mirrored (dim-1-c = ~c
+// inside the field: all three dimensions powers of two), and `flip` (per lane: the field masks of those axes) turns the index into
+// the real one: word = real >> 5, bit = real & 31 (v_bfe takes it from the low five bits).  Two cells lie in the same half-block
+// iff their indices agree above bit 4 — mirrored or not.  22 vector instructions per trip; same words, same requests, same
+// sequence of DDA operations per lane.
+#define VRT_LOAD_DILATED(IDX, IDXN, WORD, WORDN)                           \
+    "v_xor_b32_e32 %[t2], %[" IDXN "], %[" IDX "]\n\t"                     \
+    "v_cmp_lt_u32_e64 %[by], 31, %[t2]\n\t" /* lanes whose step enters another half-block */ \
+    "s_cmp_eq_u64 %[by], 0\n\t"                                            \
+    "s_cselect_b64 %[by], exec, %[by]\n\t" /* nobody: everybody asks again (one request per trip, always) */ \
+    "s_and_saveexec_b64 %[cz], %[by]\n\t"                                  \
+    "v_xor_b32_e32 %[t2], %[" IDXN "], %[flip]\n\t"                        \
+    "v_lshrrev_b32_e32 %[t2], 5, %[t2]\n\t"                                \
+    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"          \
+    "s_andn2_b64 exec, %[cz], %[by]\n\t"   /* the lanes that stay in their half-block keep its word */ \
+    "s_waitcnt vmcnt(1)\n\t"                                               \
+    "v_mov_b32_e32 %[" WORDN "], %[" WORD "]\n\t"                          \
+    "s_mov_b64 exec, %[cz]\n\t"
+#define VRT_TEST_DILATED(WORD, IDX)                                        \
+    "v_xor_b32_e32 %[t1], %[" IDX "], %[flip]\n\t"                         \
+    "v_bfe_u32 %[t1], %[" WORD "], %[t1], 1\n\t"                           \
+    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"
+// nm_x / nm_y / nm_z: per lane, the complement of the axis' field mask (all ones for an axis with ray_step == 0)
+VRT_DI void grid_walk_park_dilated_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t nm_x, uint32_t nm_y, uint32_t nm_z,
+                                          uint32_t &word, u32x4 rsrc, GridParkRegs &g, uint32_t flip) {
+    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
+    float t0, t1, t2;
+    uint32_t wordb, n;
+    const uint32_t stride_x = nm_x, stride_y = nm_y, stride_z = nm_z; // (the operand list's names)
+    asm volatile(VRT_PARK_WALK_ASM_S(VRT_STEP_DILATED, VRT_NO_LIMIT, VRT_LOAD_DILATED, VRT_TEST_DILATED, VRT_WAIT_BUFFER, "")
+                 : VRT_PARK_WALK_OPERANDS
+                 : VRT_PARK_WALK_INPUTS, [flip] "v"(flip)
+                 : "vcc", "scc");
+}
+#undef VRT_LOAD_DILATED
+#undef VRT_TEST_DILATED
+// ---- the brick-level park loop on a DISTANCE FIELD (vrt_path_kernel<DIST>, round 3) ---------------------------------------------
+// A DDA trip moves one cell along one axis, so n trips reach exactly the cells within L1 (Manhattan) distance n of where they
+// started.  TraceParams::cell_distance holds, per cell, its L1 distance in cells to the nearest occupied cell (0 = occupied, capped
+// at 255; derived from binding 3 at every status upload).  A lane that has read d > 0 at cell P knows the next d - 1 cells of ANY walk
+// to be empty: it takes those trips without asking — same DDA operations, same order, fewer tests — and asks again for the cell
+// d trips behind P.  Per lane: `k` = trips it may still take before it has to ask (<= 0: ask in this trip), and the usual one-trip
+// pipeline: the byte of the cell entered is requested in the trip that enters it and tested in the next, after that trip's step
+// (a lane that asks keeps asking every trip until an answer > 1 arrives: the answer for P is only there when P + 1 has been asked).
+// Against the half-block words (27 vector instructions per trip, a request per lane every third trip) a trip is 17 vector
+// instructions and, in the 2048^3 sparse field, a lane asks about twice per d cells.  The index is the plain linear cell index =
+// the byte offset: any grid dimensions.  If no lane of the wave has to ask, all do (a trip always issues one request, so that
+// vmcnt(1) keeps its meaning); `nd<word>` = the lanes whose <word> register holds an answer.
+#define VRT_LOAD_DIST(IDX, IDXN, WORD, WORDN)                                      \
+    "v_cmp_gt_i32_e64 %[nd" WORDN "], 1, %[k]\n\t"  /* lanes that have to ask: k <= 0 */ \
+    "v_add_u32_e32 %[k], -1, %[k]\n\t"                                             \
+    "s_cmp_eq_u64 %[nd" WORDN "], 0\n\t"                                           \
+    "s_cselect_b64 %[nd" WORDN "], exec, %[nd" WORDN "]\n\t"                       \
+    "s_and_saveexec_b64 %[cz], %[nd" WORDN "]\n\t"                                 \
+    "buffer_load_ubyte %[" WORDN "], %[" IDXN "], %[rsrc], 0 offen\n\t"            \
+    "s_mov_b64 exec, %[cz]\n\t"                                                    \
+    "s_waitcnt vmcnt(1)\n\t"
+#define VRT_TEST_DIST(WORD, IDX)                                                   \
+    "v_cmp_eq_u32_e32 vcc, 0, %[" WORD "]\n\t"                                     \
+    "v_add_u32_e32 %[t1], -2, %[" WORD "]\n\t"                                     \
+    "s_and_b64 vcc, vcc, %[nd" WORD "]\n\t"         /* occupied: an answer, and it is 0 */ \
+    "v_cndmask_b32_e64 %[k], %[k], %[t1], %[nd" WORD "]\n\t"
+struct DistRegs {
+    unsigned long long pend; // in/out: lanes whose `word` is an answer for their current cell (the others know it to be empty)
+    int k;                   // per lane, in/out: trips the lane may take before it asks again
+};
+VRT_DI void grid_walk_park_dist_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
+                                       uint32_t &word, u32x4 rsrc, GridParkRegs &g, DistRegs &d) {
+    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save, ndwordb;
+    float t0, t1, t2;
+    uint32_t wordb, n;
+    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_DIST, VRT_TEST_DIST, VRT_WAIT_BUFFER, "s_mov_b64 %[ndworda], %[ndwordb]\n\t")
+                 : VRT_PARK_WALK_OPERANDS, [ndworda] "+s"(d.pend), [ndwordb] "=&s"(ndwordb), [k] "+v"(d.k)
+                 : VRT_PARK_WALK_INPUTS
+                 : "vcc", "scc");
+}
+#undef VRT_LOAD_DIST
+#undef VRT_TEST_DIST
 // index of the half-block word that holds cell `index`
 VRT_DI uint32_t halfblock_word(const HalfBlockConsts &hb, uint32_t index) {
     return ((index >> 2) & hb.mx) | ((index >> 4) & hb.mzs) | ((index >> 5) & hb.mys);
 }
 #undef VRT_PARK_WALK_ASM
+#undef VRT_PARK_WALK_ASM_S
 #undef VRT_PARK_WALK_OPERANDS
 #undef VRT_PARK_WALK_INPUTS
 // ---- the park loop pipelined TWO trips ahead (vrt_path_kernel<AHEAD>) ---------------------------------------------------------
@@ -1914,9 +2014,13 @@ enum : int { kLaneFetch = 0, kLaneSample, kLaneStart, kLaneWalk, kLaneDone, kLan
 // 2 x (32 KiB filter + 8 x 4 KiB of staged bricks) = 128 of the CU's 160 KiB, four waves per SIMD.  (640-thread groups for five
 // waves per SIMD do not pair up: ten waves leave the SIMDs 3/3/2/2, and 96 registers do not admit a sixth wave.)
 // AHEAD (round 3): the walk loop pipelined two trips ahead (grid_walk_ahead_gfx950), on the shader's linear status words.
-template <int B, int MIN_WAVES, bool FILTER, bool HALF = false, bool AHEAD = false>
+// DIST (round 3): the walk loop on the L1 distance field of the occupied cells (grid_walk_park_dist_gfx950).
+// DIL (round 3): the half-block walk loop on a dilated cell index (grid_walk_park_dilated_gfx950; all three dimensions powers of two).
+template <int B, int MIN_WAVES, bool FILTER, bool HALF = false, bool AHEAD = false, bool DIST = false, bool DIL = false>
 __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN_WAVES) void vrt_path_kernel(const TraceParams p) {
     static_assert(!AHEAD || (!HALF && !FILTER), "the two-trips-ahead loop reads the linear status words");
+    static_assert(!DIST || (!HALF && !FILTER && !AHEAD), "the distance-field loop has its own status structure");
+    static_assert(!DIL || (!HALF && !FILTER && !AHEAD && !DIST), "the dilated-index loop is a walk kind of its own (it reads the half-block words)");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_block_filter[];
     FilterConsts fc{};
     if constexpr (FILTER) {
@@ -1982,8 +2086,26 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
         hb_rsrc.z = uni(p.status_words);
         hb_rsrc.w = 0x00020000u;
     }
-    // the status word of a cell, in the layout the walk loop reads
-    auto status_word = [&](uint32_t index) { return halfblocks ? p.status_halfblocks[halfblock_word(hb, index)] : p.brick_status[index >> 5]; };
+    // the walk loop on the distance field (p.cell_distance: derived, one byte per cell; a raw buffer, num_records = cells)
+    [[maybe_unused]] u32x4 dist_rsrc;
+    if constexpr (DIST) {
+        auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+        const unsigned long long a = (unsigned long long)p.cell_distance;
+        dist_rsrc.x = uni((uint32_t)a);
+        dist_rsrc.y = uni((uint32_t)(a >> 32));
+        dist_rsrc.z = uni(p.status_cells);
+        dist_rsrc.w = 0x00020000u;
+    }
+    // the status word of a cell, in the layout the walk loop reads (DIST: the cell's distance byte; such a lane's word is an answer
+    // for the cell it stands on and it has to ask in its next trip: fresh_word)
+    [[maybe_unused]] uint32_t flip = 0u; // DIL, per lane: the field masks of the axes the ray walks down (index ^ flip = the real dilated index)
+    auto status_word = [&](uint32_t index) {
+        if constexpr (DIST) return (uint32_t)p.cell_distance[index];
+        else if constexpr (DIL) return p.status_halfblocks[(index ^ flip) >> 5];
+        else return halfblocks ? p.status_halfblocks[halfblock_word(hb, index)] : p.brick_status[index >> 5];
+    };
+    [[maybe_unused]] DistRegs dr{0ull, 0};
+    [[maybe_unused]] bool fresh_word = false; // DIST: the lane's word was loaded outside the walk loop since the last call
 
     // the by-cell copy of the occupancy bits and the start-index shortcut (derived structures, TraceParams), wave-uniform
     const bool by_cell = p.cell_occupancy != nullptr;
@@ -2237,6 +2359,24 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                     if (p.cell_bounds && p.skip_to_box)
                         skip_to_box(w, s, (int)((uint32_t)hix - (uint32_t)lox), (int)((uint32_t)hiy - (uint32_t)loy), (int)((uint32_t)hiz - (uint32_t)loz), grid_index,
                                     stride_x, stride_y, stride_z, more, in_axis, skip_t);
+                    if constexpr (DIL) {
+                        if (more) {
+                            // the walk's index in dilated form, from the cell the lane stands on (= base - step * steps left, after the
+                            // jump to the box as well); axes walked down are stored mirrored; stride_* become the loop's per-axis
+                            // "everything but this axis' field" masks (all ones: the axis is never stepped along)
+                            const uint32_t lx = hb.lx, lz = hb.lxz - hb.lx;
+                            const uint32_t ly = 31u - (uint32_t)__builtin_clz(p.grid.dim_y);
+                            const uint32_t cx = (uint32_t)(base_x - __mul24(s.sx, w.rx)), cy = (uint32_t)(base_y - __mul24(s.sy, w.ry)),
+                                           cz = (uint32_t)(base_z - __mul24(s.sz, w.rz));
+                            const uint32_t mx = s.sx < 0 ? ((uint32_t)dx - 1u - cx) : cx, my = s.sy < 0 ? ((uint32_t)dy - 1u - cy) : cy,
+                                           mz = s.sz < 0 ? ((uint32_t)dz - 1u - cz) : cz;
+                            const uint32_t fx = 3u | (((1u << (lx - 2u)) - 1u) << 5), fz = (3u << 2) | (((1u << (lz - 2u)) - 1u) << (lx + 3u)),
+                                           fy = (1u << 4) | (((1u << (ly - 1u)) - 1u) << (lx + lz + 1u));
+                            grid_index = (mx & 3u) | ((mz & 3u) << 2) | ((my & 1u) << 4) | ((mx >> 2) << 5) | ((mz >> 2) << (lx + 3u)) | ((my >> 1) << (lx + lz + 1u));
+                            flip = (s.sx < 0 ? fx : 0u) | (s.sy < 0 ? fy : 0u) | (s.sz < 0 ? fz : 0u);
+                            stride_x = s.sx != 0 ? ~fx : ~0u, stride_y = s.sy != 0 ? ~fy : ~0u, stride_z = s.sz != 0 ? ~fz : ~0u;
+                        }
+                    }
                     if (more) {
                         if constexpr (FILTER) {
                             ready = false;
@@ -2254,6 +2394,7 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                             ring.w2 = (ring.q2 != ~0u) ? p.brick_status[ring.q2 >> 5] : 0u;
                         } else {
                             word = status_word(grid_index);
+                            fresh_word = true;
                         }
                         g.t_out = skip_t;
                         g.code = (uint32_t)in_axis << 4;
@@ -2316,6 +2457,14 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
             g.alive = ga.alive;
             g.parked = ga.parked;
             cell = ring.q0;
+        } else if constexpr (DIL) {
+            grid_walk_park_dilated_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, flip);
+        } else if constexpr (DIST) {
+            const unsigned long long fresh = __builtin_amdgcn_ballot_w64(fresh_word);
+            dr.pend |= fresh;
+            if (fresh_word) dr.k = 0;
+            fresh_word = false;
+            grid_walk_park_dist_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, dist_rsrc, g, dr);
         } else if constexpr (halfblocks) grid_walk_park_halfblocks_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, hb);
         else grid_walk_park_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
         VRT_PF_T(1, pf1);
@@ -2348,6 +2497,7 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                 const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min);  // comp:331
                 const float global_t_value = t_into * g_scale + s.grid_t_min + 0.01f * g_scale;          // comp:347 (deferred) + comp:332
                 hit.t = global_t_value;
+                if constexpr (DIL) cell = (uint32_t)cx + (uint32_t)dx * ((uint32_t)cz + (uint32_t)dz * (uint32_t)cy); // (the loop's index is dilated)
                 const uint32_t occ_slot = by_cell ? cell : p.brick_index[cell]; // comp:337 (by_cell: only on a solid voxel)
                 bool hit_voxel;
                 if constexpr (B == 8) {
@@ -2364,6 +2514,7 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                     st = kLaneDone;
                 } else if constexpr (!AHEAD) {
                     word = status_word(grid_index); // (an A-trip park left the lane's word in the other register set)
+                    fresh_word = true;
                 }   // (AHEAD: the lane walks on as it is; a step that left the box has put the sentinel into its ring)
             }
         }
