@@ -195,6 +195,7 @@ pub const TUNE_NO_START_SHORTCUT: u32 = 1 << 6;
 pub const TUNE_PATH_AHEAD: u32 = 1 << 7;
 pub const TUNE_PATH_DISTANCE: u32 = 1 << 8;
 pub const TUNE_NO_PATH_DILATED: u32 = 1 << 9;
+pub const TUNE_NO_PATH_GRID_EXIT: u32 = 1 << 10;
 
 pub const GridConfig = extern struct { // Grid.zig:13-20
     brick_alloc: u64 = 0,

@@ -155,7 +155,8 @@ typedef struct vrt_config {
 #define VRT_TUNE_PATH_AHEAD          (1u << 7) /* development build only: vrt_path_kernel's walk loop pipelined two trips ahead (measured slower) */
 #define VRT_TUNE_PATH_DISTANCE       (1u << 8) /* development build only: vrt_path_kernel's walk loop on the L1 distance field of the occupied cells, a byte per cell (measured slower) */
 #define VRT_TUNE_NO_PATH_DILATED     (1u << 9) /* vrt_path_kernel: the half-block walk loop on the linear cell index instead of the dilated one */
-#define VRT_TUNE_ALL                0x3FFu
+#define VRT_TUNE_NO_PATH_GRID_EXIT   (1u << 10) /* vrt_path_kernel, dilated index: keep the steps-left counters in the walk loop (the walk ends at the box of the occupied cells) even when that box is, or nearly is, the grid */
+#define VRT_TUNE_ALL                0x7FFu
 
 typedef struct vrt_ctx vrt_ctx;
 

@@ -181,13 +181,14 @@ def test_kernel_name_is_the_symbol_that_ran():
     rt.deinit()
     from zig_vulkan_amd import _lib as L
     # persistent lanes forced; power-of-two grid: the half-block walk on a dilated cell index, or (flag) on the linear one
-    for flags, name in ((0, "vrt_path_kernel<8, 5, false, false, false, false, true>"), (L.TUNE_NO_PATH_DILATED, "vrt_path_kernel<8, 5, false, true, false, false, false>"),
-                        (L.TUNE_NO_PATH_HALFBLOCKS, "vrt_path_kernel<8, 5, false, false, false, false, false>")):
+    # (a terrain: its occupied cells do not reach the grid's top, so the walk keeps its steps-left counters — kind 1, not 2)
+    for flags, name in ((0, "vrt_path_kernel<8, 5, false, false, false, false, 1>"), (L.TUNE_NO_PATH_DILATED, "vrt_path_kernel<8, 5, false, true, false, false, 0>"),
+                        (L.TUNE_NO_PATH_HALFBLOCKS, "vrt_path_kernel<8, 5, false, false, false, false, 0>")):
         rt = W.make_renderer(w, grid, kernel_variant=1 << 23, tuning_flags=flags)
         rt.camera.d_camera.max_bounce = 3
         rt.draw()
         rt.wait()
         assert rt.kernel_name() == name
         rt.deinit()
-    assert L.lib.vrt_compiled_kernel_count() == 24
+    assert L.lib.vrt_compiled_kernel_count() == 26
     assert re.fullmatch(r"vrt_(trace|path)_kernel<[^>]+>", "vrt_trace_kernel<8, false, 7, 7, 2, 256>")

@@ -243,16 +243,23 @@ def test_issued_counters_walk_to_the_occupied_box():
     assert got[2]["status_loads"] <= got[1]["status_loads"]
 
 
-def _frames_with_flags(name, views, tuning_flags, **overrides):
+def _frames_with_flags(name, views, tuning_flags, kernel_names=None, **overrides):
     """Whole RGBA8 frames of a workload with vrt_config.tuning_flags set (VRT_TUNE_*: the library reads no environment)."""
     w = W.WORKLOADS[name] if isinstance(name, str) else name
     grid = _GRIDS.setdefault(w.name, W.build_grid(w))
     rt = W.make_renderer(w, grid, tuning_flags=tuning_flags, **overrides)
     out = []
+    # (a first frame and a wait: the library learns the box of the occupied cells behind the scene upload without ever waiting for
+    # it, and from then on may trace bounce frames of a scene that fills its grid with the counter-free walk loop)
+    W.set_view(rt, views[0])
+    rt.draw()
+    rt.wait()
     for v in views:
         W.set_view(rt, v)
         rt.draw()
         out.append(rt.read_rgba8().copy())
+        if kernel_names is not None:
+            kernel_names.append(rt.kernel_name())
     rt.deinit()
     return out
 
@@ -281,8 +288,15 @@ def test_path_kernel_memory_layouts_change_no_pixel():
     w = W.Workload("path_layouts", 1280, 720, 1024, 8, 4, 2, True, 5.0, "sparse", 0.08, 200000)
     views = ["V0", "V1x"]
     path = 1 << 23
-    base = _frames_with_flags(w, views, 0, kernel_variant=path)
-    for flags in (L.TUNE_NO_PATH_DILATED, L.TUNE_NO_PATH_DILATED | L.TUNE_NO_SKIP_TO_BOX | L.TUNE_NO_CELL_OCCUPANCY, L.TUNE_NO_SKIP_TO_BOX,
+    names = []
+    base = _frames_with_flags(w, views, 0, kernel_names=names, kernel_variant=path)
+    # the spheres reach the grid's faces: the dilated-index walk without steps-left counters; with the flag, the one with them
+    assert set(names) == {"vrt_path_kernel<8, 5, false, false, false, false, 2>"}, names
+    names = []
+    _frames_with_flags(w, views[:1], L.TUNE_NO_PATH_GRID_EXIT, kernel_names=names, kernel_variant=path)
+    assert set(names) == {"vrt_path_kernel<8, 5, false, false, false, false, 1>"}, names
+    for flags in (L.TUNE_NO_PATH_GRID_EXIT, L.TUNE_NO_PATH_GRID_EXIT | L.TUNE_NO_SKIP_TO_BOX | L.TUNE_NO_PATH_BRICK_LDS,
+                  L.TUNE_NO_PATH_DILATED, L.TUNE_NO_PATH_DILATED | L.TUNE_NO_SKIP_TO_BOX | L.TUNE_NO_CELL_OCCUPANCY, L.TUNE_NO_SKIP_TO_BOX,
                   L.TUNE_NO_PATH_BRICK_LDS, L.TUNE_NO_PATH_HALFBLOCKS, L.TUNE_PATH_EAGER_START, L.TUNE_NO_CELL_OCCUPANCY, L.TUNE_NO_START_SHORTCUT,
                   L.TUNE_NO_CELL_OCCUPANCY | L.TUNE_NO_START_SHORTCUT | L.TUNE_PATH_EAGER_START,
                   L.TUNE_NO_PATH_BRICK_LDS | L.TUNE_NO_PATH_HALFBLOCKS | L.TUNE_NO_SKIP_TO_BOX):

@@ -42,7 +42,7 @@ def test_the_product_binary_holds_only_shipped_kernels():
     ks = _kernels()
     assert len(ks) <= 40, sorted(ks)
     traversal = [n for n in ks if "vrt_trace_kernel" in n or "vrt_path_kernel" in n]
-    assert len(traversal) == 24, sorted(traversal)
+    assert len(traversal) == 26, sorted(traversal)
 
 
 def test_no_kernel_owns_static_lds_except_the_schedule_kernel():
@@ -62,6 +62,6 @@ def test_one_sample_kernels_hold_7_waves_without_scratch():
 
 def test_path_kernel_holds_5_waves():
     ks = {n: k for n, k in _kernels().items() if re.search(r"vrt_path_kernelILi[48]ELi5ELb0E", n)}   # plain, half-block and dilated-index walk
-    assert len(ks) == 6
+    assert len(ks) == 8
     for name, k in ks.items():
         assert k["vgpr"] <= 96 and k["scratch"] <= 128, (name, k)

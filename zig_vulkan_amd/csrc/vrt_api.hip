@@ -28,7 +28,8 @@ KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t varian
 KernelFn path_kernel_halfblock_twin(KernelFn fn);
 KernelFn path_kernel_ahead_twin(KernelFn fn);
 KernelFn path_kernel_dist_twin(KernelFn fn);
-KernelFn path_kernel_dilated_twin(KernelFn fn);
+KernelFn path_kernel_dilated_twin(KernelFn fn, int kind);
+int path_kernel_dilated_kind(KernelFn fn);
 bool is_path_halfblock_kernel(KernelFn fn);
 const char *kernel_name_of(KernelFn fn);
 uint32_t resolve_variant(uint32_t variant);
@@ -183,6 +184,12 @@ struct vrt_ctx {
     hipStream_t denoised_stream = nullptr;
     void *d_status_blocks = nullptr; // derived: 4x4x4 block words + block filter (vrt_trace.hip)
     int *d_cell_bounds = nullptr;    // derived: bounding box of the occupied cells (TraceParams::cell_bounds)
+    // The host's copy of that box (read back behind every rebuild, never waited for): when it is, or nearly is, the grid, bounce
+    // frames of a context whose kernel is the dilated-index path kernel are traced by its twin without steps-left counters.
+    int *h_cell_bounds = nullptr;
+    hipEvent_t ev_bounds = nullptr;
+    bool bounds_pending = false, box_is_grid = false;
+    vrt::KernelFn kernel_grid_exit = nullptr, product_grid_exit = nullptr;
     uint8_t *d_status_bytes = nullptr; // derived: one byte per grid cell (TraceParams::status_bytes)
     uint8_t *d_cell_distance = nullptr;      // derived: L1 distance of every cell to the nearest occupied cell (vrt_path_kernel<DIST>)
     uint32_t *d_status_halfblocks = nullptr; // derived: status bits by 4 x 4 x 2 cells per word (vrt_path_kernel on eligible grids)
@@ -264,6 +271,8 @@ void free_ctx(vrt_ctx *c) {
     if (c->d_work_counter) (void)hipFree(c->d_work_counter);
     if (c->d_status_blocks) (void)hipFree(c->d_status_blocks);
     if (c->d_cell_bounds) (void)hipFree(c->d_cell_bounds);
+    if (c->h_cell_bounds) (void)hipHostFree(c->h_cell_bounds);
+    if (c->ev_bounds) (void)hipEventDestroy(c->ev_bounds);
     if (c->d_status_bytes) (void)hipFree(c->d_status_bytes);
     if (c->d_status_halfblocks) (void)hipFree(c->d_status_halfblocks);
     if (c->d_cell_distance) (void)hipFree(c->d_cell_distance);
@@ -748,7 +757,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         const bool ahead = (cfg->tuning_flags & VRT_TUNE_PATH_AHEAD) != 0u; // (development build: the product holds no such kernel)
         if (ahead) c->kernel = vrt::path_kernel_ahead_twin(c->kernel);
         else if (want_distance) c->kernel = vrt::path_kernel_dist_twin(c->kernel);
-        else if (want_dilated) c->kernel = vrt::path_kernel_dilated_twin(c->kernel);
+        else if (want_dilated) c->kernel = vrt::path_kernel_dilated_twin(c->kernel, 1);
         else if (want_halfblocks) c->kernel = vrt::path_kernel_halfblock_twin(c->kernel);
         c->kernel_lockstep = vrt::select_trace_kernel((int)cfg->brick_dimension, cnt, lockstep_variant, 0);
         c->kernel_single = vrt::select_trace_kernel((int)cfg->brick_dimension, cnt, single_variant, 1);
@@ -760,11 +769,18 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
             c->product[shade] = vrt::select_trace_kernel((int)cfg->brick_dimension, false, shade == 0 ? c->bounce_variant : single_variant, shade);
             if (shade == 0 && ahead) c->product[shade] = vrt::path_kernel_ahead_twin(c->product[shade]);
             else if (shade == 0 && want_distance) c->product[shade] = vrt::path_kernel_dist_twin(c->product[shade]);
-            else if (shade == 0 && want_dilated) c->product[shade] = vrt::path_kernel_dilated_twin(c->product[shade]);
+            else if (shade == 0 && want_dilated) c->product[shade] = vrt::path_kernel_dilated_twin(c->product[shade], 1);
             else if (shade == 0 && want_halfblocks) c->product[shade] = vrt::path_kernel_halfblock_twin(c->product[shade]);
         }
     };
     select_all();
+    if (!(cfg->tuning_flags & VRT_TUNE_NO_PATH_GRID_EXIT)) {
+        // (chosen per dispatch, once the host knows the box of the occupied cells: pre_dispatch)
+        if (vrt::path_kernel_dilated_kind(c->kernel) == 1) c->kernel_grid_exit = vrt::path_kernel_dilated_twin(c->kernel, 2);
+        if (c->product[0] && vrt::path_kernel_dilated_kind(c->product[0]) == 1) c->product_grid_exit = vrt::path_kernel_dilated_twin(c->product[0], 2);
+        if (c->kernel_grid_exit == c->kernel) c->kernel_grid_exit = nullptr;
+        if (c->product_grid_exit == c->product[0]) c->product_grid_exit = nullptr;
+    }
     c->single_variant = single_variant;
     {
         const bool cnt = cfg->enable_counters != 0;
@@ -1011,6 +1027,15 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
         if (rcw != VRT_OK) return rcw;
         VRT_HIP(ctx, vrt::launch_build_status_blocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
         VRT_HIP(ctx, vrt::launch_build_cell_bounds(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
+        if (ctx->kernel_grid_exit || ctx->product_grid_exit) {
+            if (!ctx->h_cell_bounds) VRT_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_cell_bounds), 6 * sizeof(int), hipHostMallocDefault));
+            if (!ctx->ev_bounds) VRT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_bounds, hipEventDisableTiming));
+            if (ctx->bounds_pending) VRT_HIP(ctx, hipEventSynchronize(ctx->ev_bounds)); // (the copy before this one still owns the buffer)
+            VRT_HIP(ctx, hipMemcpyAsync(ctx->h_cell_bounds, ctx->d_cell_bounds, 6 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            VRT_HIP(ctx, hipEventRecord(ctx->ev_bounds, ctx->stream));
+            ctx->bounds_pending = true;
+            ctx->box_is_grid = false; // until the new box is known
+        }
         VRT_HIP(ctx, vrt::launch_build_status_bytes(ctx->params, ctx->stream));
         VRT_HIP(ctx, vrt::launch_build_status_halfblocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
         VRT_HIP(ctx, vrt::launch_build_cell_distance(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
@@ -1029,6 +1054,16 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
     ctx->occupancy_dirty = ctx->start_dirty = false;
     // max_bounce <= 1 ("only primary ray" + its shadow ray): the bounce loop runs at most once
     *fn = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? ctx->kernel_single1 : ctx->kernel_single) : ctx->kernel;
+    if (ctx->bounds_pending && hipEventQuery(ctx->ev_bounds) == hipSuccess) {
+        // the box of the occupied cells {-min, max} per axis: "the grid, or nearly" = at most an eighth of the axis free on either side
+        const int *b = ctx->h_cell_bounds;
+        const int dim[3] = {(int)ctx->cfg.dim_x, (int)ctx->cfg.dim_y, (int)ctx->cfg.dim_z};
+        bool all = b[0] != (int)0x80808080;
+        for (int a = 0; a < 3 && all; a++) all = (-b[a]) * 8 <= dim[a] && (dim[a] - 1 - b[3 + a]) * 8 <= dim[a];
+        ctx->box_is_grid = all;
+        ctx->bounds_pending = false;
+    }
+    if (camera->max_bounce > 1 && ctx->box_is_grid && !ctx->d_counters && ctx->kernel_grid_exit) *fn = ctx->kernel_grid_exit;
     return VRT_OK;
 }
 
@@ -1048,6 +1083,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     if (ctx->d_counters) {
         product_fn = ctx->product[(camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? 2 : 1) : 0];
         if (!product_fn) return fail(ctx, VRT_E_STATE, "no product kernel for this configuration");
+        if (camera->max_bounce > 1 && ctx->box_is_grid && ctx->product_grid_exit) product_fn = ctx->product_grid_exit;
     }
     note_kernel(ctx, product_fn ? product_fn : fn);
     // (the persistent-lane kernel takes its pixels from a counter: it neither reads the tile schedule nor reports tile costs)

@@ -7,8 +7,10 @@ const KernelEntry kEntries[] = {
     // 5 waves per SIMD (96 VGPRs); HALF: the walk loop on half-block words (grids whose x / z dimensions are powers of two)
     VRT_PATH_ENTRY(4, 5, false, false), VRT_PATH_ENTRY(4, 5, false, true),
     VRT_PATH_ENTRY(8, 5, false, false), VRT_PATH_ENTRY(8, 5, false, true),
-    // DIL (round 3): the half-block walk loop on a dilated cell index (grids whose three dimensions are powers of two)
-    VRT_PATH_ENTRY_L(4, 5, false, false, false, false, true), VRT_PATH_ENTRY_L(8, 5, false, false, false, false, true),
+    // DIL (round 3): the half-block walk loop on a dilated cell index (grids whose three dimensions are powers of two); 2: without
+    // the steps-left counters, the walk ends at the grid's face (scenes whose occupied cells reach the grid's faces)
+    VRT_PATH_ENTRY_L(4, 5, false, false, false, false, 1), VRT_PATH_ENTRY_L(8, 5, false, false, false, false, 1),
+    VRT_PATH_ENTRY_L(4, 5, false, false, false, false, 2), VRT_PATH_ENTRY_L(8, 5, false, false, false, false, 2),
 #ifdef VRT_DEV_VARIANTS
     // DIST (round 3): the walk loop on the L1 distance field of the occupied cells, a byte per cell (any grid dimensions): 19 % fewer
     // vector instructions per frame of the 2048^3 path trace than the half-block words, 4.5 x the L2 misses (16 MiB against 2 MiB):

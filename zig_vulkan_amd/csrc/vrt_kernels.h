@@ -36,7 +36,8 @@ struct KernelEntry {
     uint8_t half;      // path: walk loop on half-block words
     uint8_t ahead;     // path: the walk loop pipelined two trips ahead (on the shader's linear words)
     uint8_t dist;      // path: the walk loop on the L1 distance field of the occupied cells (TraceParams::cell_distance; development)
-    uint8_t dil;       // path: the half-block walk loop on a dilated cell index (all three grid dimensions powers of two)
+    uint8_t dil;       // path: the half-block walk loop on a dilated cell index (all three grid dimensions powers of two): 1 = the walk
+                       // ends at the box of the occupied cells (steps-left counters), 2 = at the grid's face (no counters in the loop)
 };
 struct KernelTable {
     const KernelEntry *entries;
@@ -48,7 +49,7 @@ KernelTable inst_trace_count();
 KernelTable inst_path();
 
 const KernelEntry *find_trace_kernel(int b, bool count, int mode, int min_waves, int shade, int block = 256);
-const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead = false, bool dist = false, bool dil = false);
+const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead = false, bool dist = false, int dil = 0);
 const KernelEntry *kernel_entry_of(KernelFn fn);
 int compiled_kernel_count();
 

@@ -412,10 +412,10 @@ const KernelEntry *find_trace_kernel(int b, bool count, int mode, int min_waves,
         return !e.path && e.b == b && (e.count != 0) == count && e.mode == mode && e.min_waves == min_waves && e.shade == shade && e.block == block;
     });
 }
-const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead, bool dist, bool dil) {
+const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead, bool dist, int dil) {
     return find_entry([&](const KernelEntry &e) {
         return e.path && e.b == b && e.min_waves == min_waves && (e.filter != 0) == filter && (e.half != 0) == half && (e.ahead != 0) == ahead &&
-               (e.dist != 0) == dist && (e.dil != 0) == dil;
+               (e.dist != 0) == dist && (int)e.dil == dil;
     });
 }
 const KernelEntry *kernel_entry_of(KernelFn fn) {
@@ -513,11 +513,15 @@ KernelFn path_kernel_halfblock_twin(KernelFn fn) {
     return t ? t->fn : fn;
 }
 // the same kernel with the half-block walk loop on a dilated cell index; fn itself if it has none
-KernelFn path_kernel_dilated_twin(KernelFn fn) {
+KernelFn path_kernel_dilated_twin(KernelFn fn, int kind) {
     const KernelEntry *e = kernel_entry_of(fn);
-    if (!e || !e->path || e->filter || e->half || e->ahead || e->dist || e->dil) return fn;
-    const KernelEntry *t = find_path_kernel(e->b, e->min_waves, false, false, false, false, true);
+    if (!e || !e->path || e->filter || e->half || e->ahead || e->dist) return fn;
+    const KernelEntry *t = find_path_kernel(e->b, e->min_waves, false, false, false, false, kind);
     return t ? t->fn : fn;
+}
+int path_kernel_dilated_kind(KernelFn fn) {
+    const KernelEntry *e = kernel_entry_of(fn);
+    return (e && e->path) ? (int)e->dil : 0;
 }
 // the same kernel with the walk loop on the distance field (TraceParams::cell_distance); fn itself if it has none
 KernelFn path_kernel_dist_twin(KernelFn fn) {

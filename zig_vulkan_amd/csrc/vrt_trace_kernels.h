@@ -187,9 +187,29 @@ struct GridWalkRegs {
     "v_or_b32_e32 %[t1], %[" IDX "], %[t0]\n\t"                           \
     "v_add_u32_e32 %[t1], 1, %[t1]\n\t"                                   \
     "v_bfi_b32 %[" IDXN "], %[t0], %[" IDX "], %[t1]\n\t"
+// ... and, where the grid's face is the walk's end (VRT_EXIT_CARRY below), the carry out of bit 31 says that the crossed axis'
+// field has overflowed: the carry of a full field runs through the ones of every field above it
+#define VRT_STEP_DILATED_CARRY(IDX, IDXN, MX, MY)                         \
+    "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[" MY "]\n\t"              \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[" MX "]\n\t"               \
+    "v_or_b32_e32 %[t1], %[" IDX "], %[t0]\n\t"                           \
+    "v_add_co_u32_e64 %[t1], %[ex], 1, %[t1]\n\t"                         \
+    "v_bfi_b32 %[" IDXN "], %[t0], %[" IDX "], %[t1]\n\t"
+// How a lane learns that its step has left the walk's box (`ex` = those lanes at the end of the trip).  COUNTERS: the steps-left
+// counters are decremented with the crossed-axis lane masks as borrow-in; their borrow-out is the test.  CARRY (dilated index,
+// VRT_STEP_DILATED_CARRY): the step itself has produced it.
+#define VRT_EXIT_COUNTERS_A(MX, MY, MXY)                                  \
+    "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[" MX "]\n\t"          \
+    "v_subbrev_co_u32_e64 %[ry], %[by], 0, %[ry], %[" MY "]\n\t"          \
+    "v_addc_co_u32_e64 %[rz], %[cz], -1, %[rz], %[" MXY "]\n\t"
+#define VRT_EXIT_COUNTERS_B                                               \
+    "s_or_b64 %[ex], %[ex], %[by]\n\t"                                    \
+    "s_orn2_b64 %[ex], %[ex], %[cz]\n\t" /* z: carry-out 0 = borrow */
+#define VRT_EXIT_CARRY_A(MX, MY, MXY)
+#define VRT_EXIT_CARRY_B
 #define VRT_TRIP_T(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT) \
-    VRT_TRIP_S(VRT_STEP_LINEAR, TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT)
-#define VRT_TRIP_S(STEP, TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT) \
+    VRT_TRIP_X(VRT_STEP_LINEAR, VRT_EXIT_COUNTERS, TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT)
+#define VRT_TRIP_X(STEP, XKIND, TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT) \
     /* The crossed distance = the smallest side distance, and the crossed axis from it: the shader's                       \
        x<y ? (x<z ? X : Z) : (y<z ? Y : Z) picks Z whenever z is minimal (ties included), else Y whenever y is, else X —    \
        one min3 and two equality tests instead of three compares and two selects.  (A walk never holds a NaN side          \
@@ -214,12 +234,9 @@ struct GridWalkRegs {
     STEP(IDX, IDXN, MX, MY)                                               \
     LOAD(IDX, IDXN, WORD, WORDN) /* request the next cell's word; wait for the one requested a trip ago */ \
     TEST(WORD, IDX)                                                       \
-    "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[" MX "]\n\t"          \
-    "v_subbrev_co_u32_e64 %[ry], %[by], 0, %[ry], %[" MY "]\n\t"          \
-    "v_addc_co_u32_e64 %[rz], %[cz], -1, %[rz], %[" MXY "]\n\t"           \
+    XKIND##_A(MX, MY, MXY)                                                \
     LIMIT(TS, MXY)                                                        \
-    "s_or_b64 %[ex], %[ex], %[by]\n\t"                                    \
-    "s_orn2_b64 %[ex], %[ex], %[cz]\n\t" /* z: carry-out 0 = borrow */    \
+    XKIND##_B                                                             \
     "s_andn2_b64 exec, exec, %[ex]\n\t"                                   \
     "s_cbranch_vccnz " OUT "\n\t"
 
@@ -384,8 +401,9 @@ struct GridParkRegs {
     uint32_t min_alive = 0;          // in: ... or, at a back edge, once fewer than this many lanes are still moving (0: never)
 };
 
-#define VRT_PARK(LABEL, IN_AXIS, OUT_MX, OUT_MY, SWAP, NEXT, EXIT)                                       \
+#define VRT_PARK(LABEL, PRE, IN_AXIS, OUT_MX, OUT_MY, SWAP, NEXT, EXIT)                                  \
     LABEL ":\n\t"                                                                                         \
+    PRE                                                                                                   \
     "s_mov_b64 %[ex], exec\n\t"                                                                           \
     "s_mov_b64 exec, vcc\n\t"                                                                             \
     IN_AXIS                                                                                               \
@@ -405,19 +423,21 @@ struct GridParkRegs {
 #define VRT_SWAP_SETS "v_swap_b32 %[tsa], %[tsb]\n\t" "v_swap_b32 %[idxa], %[idxb]\n\t"
 
 #define VRT_PARK_WALK_ASM(LIMIT, LOAD, TEST, WAITALL, AT30) VRT_PARK_WALK_ASM_S(VRT_STEP_LINEAR, LIMIT, LOAD, TEST, WAITALL, AT30)
-#define VRT_PARK_WALK_ASM_S(STEP, LIMIT, LOAD, TEST, WAITALL, AT30) \
+#define VRT_PARK_WALK_ASM_S(STEP, LIMIT, LOAD, TEST, WAITALL, AT30) VRT_PARK_WALK_ASM_X(STEP, VRT_EXIT_COUNTERS, "", LIMIT, LOAD, TEST, WAITALL, AT30)
+// PARKPRE: what a trip's park code does first (VRT_EXIT_CARRY: note the parked lanes whose step out of their cell left the grid)
+#define VRT_PARK_WALK_ASM_X(STEP, XKIND, PARKPRE, LIMIT, LOAD, TEST, WAITALL, AT30) \
         "s_mov_b64 %[save], exec\n\t" \
         "s_mov_b64 exec, %[alive]\n\t" \
         "s_mov_b64 %[parked], 0\n\t" \
-        VRT_TRIP_S(STEP, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "10f") \
+        VRT_TRIP_X(STEP, XKIND, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "10f") \
         "0:\n\t" \
-        VRT_TRIP_S(STEP, "tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "11f") \
+        VRT_TRIP_X(STEP, XKIND, "tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "11f") \
         "21:\n\t" \
-        VRT_TRIP_S(STEP, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "12f") \
+        VRT_TRIP_X(STEP, XKIND, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "12f") \
         "22:\n\t" \
-        VRT_TRIP_S(STEP, "tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "13f") \
+        VRT_TRIP_X(STEP, XKIND, "tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "13f") \
         "23:\n\t" \
-        VRT_TRIP_S(STEP, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "14f") \
+        VRT_TRIP_X(STEP, XKIND, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "14f") \
         "24:\n\t" \
         "s_cbranch_execz 31f\n\t" \
         /* back edge (after an A trip): keep walking while at least min_alive lanes are moving; fewer -> hand the wave back \
@@ -426,11 +446,11 @@ struct GridParkRegs {
         "s_cmp_ge_u32 %[n], %[minalive]\n\t" \
         "s_cbranch_scc1 0b\n\t" \
         "s_branch 30f\n\t" \
-        VRT_PARK("10", VRT_IN_FROM_CODE, "mxa", "mya", VRT_SWAP_SETS, "0b", "30f") \
-        VRT_PARK("11", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "21b", "31f") \
-        VRT_PARK("12", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "22b", "30f") \
-        VRT_PARK("13", VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "23b", "31f") \
-        VRT_PARK("14", VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "24b", "30f") \
+        VRT_PARK("10", PARKPRE, VRT_IN_FROM_CODE, "mxa", "mya", VRT_SWAP_SETS, "0b", "30f") \
+        VRT_PARK("11", PARKPRE, VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "21b", "31f") \
+        VRT_PARK("12", PARKPRE, VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "22b", "30f") \
+        VRT_PARK("13", PARKPRE, VRT_IN_FROM("mxa", "mya"), "mxb", "myb", "", "23b", "31f") \
+        VRT_PARK("14", PARKPRE, VRT_IN_FROM("mxb", "myb"), "mxa", "mya", VRT_SWAP_SETS, "24b", "30f") \
         "30:\n\t" /* the last trip was an A trip: swap the sets of the lanes still moving */ \
         "s_mov_b64 %[alive], exec\n\t" \
         WAITALL \
@@ -599,6 +619,28 @@ VRT_DI void grid_walk_park_dilated_gfx950(Walk &w, const f3 &inv_dir, uint32_t &
                  : VRT_PARK_WALK_INPUTS, [flip] "v"(flip)
                  : "vcc", "scc");
 }
+// The same loop for a walk that ends at the GRID's face (the box of the occupied cells is, or nearly is, the grid): the steps-left
+// counters leave the loop (3 vector + 2 scalar instructions per trip, and six registers that no longer live across it) — a step
+// that overflows its field has left the grid, and the increment's carry-out says so (VRT_STEP_DILATED_CARRY).  A parked lane
+// whose step out of the occupied cell left the grid is noted in `gone`.  An axis the ray does not move along (mask all ones) "leaves"
+// the moment it is selected: with a finite unit direction that never happens before the lane has left along its dominant axis
+// (such an axis' side distance starts at 5e11, safe_inverse; the dominant axis' stays below 1.74 x (cells + 1)).
+VRT_DI void grid_walk_park_dilated_carry_gfx950(f3 &side_dist, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t nm_x, uint32_t nm_y, uint32_t nm_z,
+                                                uint32_t &word, u32x4 rsrc, GridParkRegs &g, uint32_t flip, unsigned long long &gone) {
+    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
+    float t0, t1, t2;
+    uint32_t wordb, n;
+    const uint32_t stride_x = nm_x, stride_y = nm_y, stride_z = nm_z; // (the operand list's names)
+    gone = 0ull;
+    asm volatile(VRT_PARK_WALK_ASM_X(VRT_STEP_DILATED_CARRY, VRT_EXIT_CARRY, "s_and_b64 %[by], %[ex], vcc\n\ts_or_b64 %[gone], %[gone], %[by]\n\t", VRT_NO_LIMIT,
+                                     VRT_LOAD_DILATED, VRT_TEST_DILATED, VRT_WAIT_BUFFER, "")
+                 : [sdx] "+v"(side_dist.x), [sdy] "+v"(side_dist.y), [sdz] "+v"(side_dist.z), [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(word),
+                   [wordb] "=&v"(wordb), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in), [code] "+v"(g.code), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+                   [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive), [mxa] "=&s"(mxa), [mya] "=&s"(mya), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb),
+                   [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz), [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n), [gone] "+s"(gone)
+                 : VRT_PARK_WALK_INPUTS, [flip] "v"(flip)
+                 : "vcc", "scc");
+}
 #undef VRT_LOAD_DILATED
 #undef VRT_TEST_DILATED
 // ---- the brick-level park loop on a DISTANCE FIELD (vrt_path_kernel<DIST>, round 3) ---------------------------------------------
@@ -649,6 +691,7 @@ VRT_DI uint32_t halfblock_word(const HalfBlockConsts &hb, uint32_t index) {
 }
 #undef VRT_PARK_WALK_ASM
 #undef VRT_PARK_WALK_ASM_S
+#undef VRT_PARK_WALK_ASM_X
 #undef VRT_PARK_WALK_OPERANDS
 #undef VRT_PARK_WALK_INPUTS
 // ---- the park loop pipelined TWO trips ahead (vrt_path_kernel<AHEAD>) ---------------------------------------------------------
@@ -2015,8 +2058,10 @@ enum : int { kLaneFetch = 0, kLaneSample, kLaneStart, kLaneWalk, kLaneDone, kLan
 // waves per SIMD do not pair up: ten waves leave the SIMDs 3/3/2/2, and 96 registers do not admit a sixth wave.)
 // AHEAD (round 3): the walk loop pipelined two trips ahead (grid_walk_ahead_gfx950), on the shader's linear status words.
 // DIST (round 3): the walk loop on the L1 distance field of the occupied cells (grid_walk_park_dist_gfx950).
-// DIL (round 3): the half-block walk loop on a dilated cell index (grid_walk_park_dilated_gfx950; all three dimensions powers of two).
-template <int B, int MIN_WAVES, bool FILTER, bool HALF = false, bool AHEAD = false, bool DIST = false, bool DIL = false>
+// DIL (round 3): the half-block walk loop on a dilated cell index (all three dimensions powers of two): 1 = with the steps-left
+// counters (grid_walk_park_dilated_gfx950: the walk ends at the box of the occupied cells), 2 = without them
+// (grid_walk_park_dilated_carry_gfx950: the walk ends at the grid's face; chosen when the box is, or nearly is, the grid).
+template <int B, int MIN_WAVES, bool FILTER, bool HALF = false, bool AHEAD = false, bool DIST = false, int DIL = 0>
 __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN_WAVES) void vrt_path_kernel(const TraceParams p) {
     static_assert(!AHEAD || (!HALF && !FILTER), "the two-trips-ahead loop reads the linear status words");
     static_assert(!DIST || (!HALF && !FILTER && !AHEAD), "the distance-field loop has its own status structure");
@@ -2448,6 +2493,7 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
         // (FILTER: five trips per call, the way through a block of four cells; then the blocks are looked up again)
         g.min_alive = FILTER ? 65u : (n_walking >= fin ? n_walking - fin + 1u : 1u);
         uint32_t cell; // the occupied cell each parked lane stood on before its last step
+        [[maybe_unused]] unsigned long long gone = 0ull; // DIL 2: the parked lanes whose step out of that cell left the grid
         if constexpr (AHEAD) {
             AheadWalkRegs ga;
             ga.alive = g.alive;
@@ -2457,7 +2503,9 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
             g.alive = ga.alive;
             g.parked = ga.parked;
             cell = ring.q0;
-        } else if constexpr (DIL) {
+        } else if constexpr (DIL == 2) {
+            grid_walk_park_dilated_carry_gfx950(w.side_dist, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, flip, gone);
+        } else if constexpr (DIL == 1) {
             grid_walk_park_dilated_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, flip);
         } else if constexpr (DIST) {
             const unsigned long long fresh = __builtin_amdgcn_ballot_w64(fresh_word);
@@ -2493,7 +2541,13 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                 const float t_into = AHEAD ? ring.ts0 : g.t_in;
                 const int rx = w.rx + (out == 0u ? 1 : 0) + (out2 == 0u ? 1 : 0), ry = w.ry + (out == 1u ? 1 : 0) + (out2 == 1u ? 1 : 0),
                           rz = w.rz + (out == 2u ? 1 : 0) + (out2 == 2u ? 1 : 0);
-                const int cx = base_x - __mul24(s.sx, rx), cy = base_y - __mul24(s.sy, ry), cz = base_z - __mul24(s.sz, rz); // cell position
+                int cx = base_x - __mul24(s.sx, rx), cy = base_y - __mul24(s.sy, ry), cz = base_z - __mul24(s.sz, rz); // cell position
+                if constexpr (DIL == 2) { // (no counters: the position is the loop's own index, un-mirrored and un-dilated)
+                    const uint32_t real = cell ^ flip, lx = hb.lx, lz = hb.lxz - hb.lx;
+                    cx = (int)((real & 3u) | ((real >> 3) & (((1u << (lx - 2u)) - 1u) << 2)));
+                    cz = (int)(((real >> 2) & 3u) | ((real >> (lx + 1u)) & (((1u << (lz - 2u)) - 1u) << 2)));
+                    cy = (int)(((real >> 4) & 1u) | ((real >> (lx + lz + 1u)) << 1));
+                }
                 const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min);  // comp:331
                 const float global_t_value = t_into * g_scale + s.grid_t_min + 0.01f * g_scale;          // comp:347 (deferred) + comp:332
                 hit.t = global_t_value;
@@ -2509,7 +2563,7 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                 if (hit_voxel) {
                     found = true;
                     st = kLaneDone;
-                } else if (!(global_t_value <= t_max) || (!AHEAD && min3i(w.rx, w.ry, w.rz) < 0)) {
+                } else if (!(global_t_value <= t_max) || (DIL == 2 ? __builtin_amdgcn_inverse_ballot_w64(gone) : (!AHEAD && min3i(w.rx, w.ry, w.rz) < 0))) {
                     found = false; // t became NaN (comp:316), or the step out of this cell left the box
                     st = kLaneDone;
                 } else if constexpr (!AHEAD) {
