@@ -21,6 +21,7 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: b
     pow2_variants = [PATH | (1 << 22), PATH | (1 << 22) | (5 << 8), PATH] if dev else [PATH, PATH | (5 << 8), PATH | (2 << 24)]
     rng = np.random.default_rng(seed)
     bad = 0
+    used = {}
     for case in range(cases):
         b = int(rng.choice([4, 8]))
         dims = [int(rng.integers(1, 25 if big else 9)) for _ in range(3)]
@@ -68,10 +69,16 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: b
         if (rt.config.kernel_variant >> 16) & 0xF == 7:
             # cost-ordered launch, re-sorted every 2 frames: the compared frame comes after three re-sorts, with split tiles
             rt.draw(frames=7)
+        if pow2:
+            # (the library learns the box of the occupied cells behind the upload and never waits for it: with a frame and a wait
+            # behind it, a scene that fills its grid takes the dilated-index walk without steps-left counters)
+            rt.draw()
+            rt.wait()
         rt.draw()
         f, u = rt.read_rgba32f(), rt.read_rgba8()
         pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
         name = rt.kernel_name()
+        used[name] = used.get(name, 0) + 1
         rt.deinit()
         fo, uo, co = O.render(oracle_scene_from_grid(grid, mats), pc)
         # bit for bit, except that any NaN equals any NaN (a 1-pixel-wide image divides 0 by 0 in comp:168-170; the sign and
@@ -97,7 +104,7 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: b
         elif verbose and case % 10 == 0:
             print(f"case {case}: ok  b={b} dims={dims} scale={scale} {w}x{h} spp={spp} bounce={bounce} sun={sun_on}/{radius} rays={co['rays']} hits={co['hits']}")
     if verbose:
-        print(f"{cases} cases, {bad} mismatching")
+        print(f"{cases} cases, {bad} mismatching; kernels: " + ", ".join(f"{k} x{v}" for k, v in sorted(used.items())))
     return bad
 
 
