@@ -208,31 +208,33 @@ struct GridWalkRegs {
 #define VRT_EXIT_CARRY_A(MX, MY, MXY)
 #define VRT_EXIT_CARRY_B
 #define VRT_TRIP_T(TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT) \
-    VRT_TRIP_X(VRT_STEP_LINEAR, VRT_EXIT_COUNTERS, TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT)
-#define VRT_TRIP_X(STEP, XKIND, TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT) \
-    /* The crossed distance = the smallest side distance, and the crossed axis from it: the shader's                       \
-       x<y ? (x<z ? X : Z) : (y<z ? Y : Z) picks Z whenever z is minimal (ties included), else Y whenever y is, else X —    \
-       one min3 and two equality tests instead of three compares and two selects.  (A walk never holds a NaN side          \
-       distance: safeInverse keeps 1/dir finite and NaN rays fail the slab test.) */                                        \
+    VRT_TRIP_E(VRT_STEP_LINEAR, VRT_EXIT_COUNTERS, TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT)
+// VRT_TRIP_E, the trip.  The crossed distance = the smallest side distance, and the crossed axis from it: the shader's
+// x<y ? (x<z ? X : Z) : (y<z ? Y : Z) picks Z whenever z is minimal (ties included), else Y whenever y is, else X — one min3 and two
+// equality tests instead of three compares and two selects.  (A walk never holds a NaN side distance: safeInverse keeps 1/dir finite
+// and NaN rays fail the slab test.)  The step and the request for the next cell's word depend on the crossed-axis masks only, so
+// they come BEFORE the side distance is advanced (round 3: the request leaves nine instructions earlier and the adds run while the
+// word asked for a trip ago arrives; 2048^3 path trace 133.9 -> 131.0 ms, 4K / 1024^3 -1.5 %, headline -1 %, same box):
+// LOAD##_A issues the request and leaves the trip's lanes in `cz`, LOAD##_B waits for the word asked for a trip ago and restores
+// EXEC.  side_dist of the crossed axis += |1/dir| is ONE add under the axis' lane mask as EXEC instead of three adds and three
+// selects (a SIMD issues one instruction per clock in total and a vector instruction takes two slots; the all-vector form of
+// round 3, 5 S + 16 V per trip, measured the same: DESIGN.md 4 "issue slots").
+#define VRT_TRIP_E(STEP, XKIND, TS, MX, MY, MXY, IDX, IDXN, WORD, WORDN, LIMIT, LOAD, TEST, OUT) \
     "v_min3_f32 %[" TS "], %[sdx], %[sdy], %[sdz]\n\t"                    \
-    "v_cmp_eq_f32_e64 %[" MXY "], %[sdz], %[" TS "]\n\t" /* z crossed */   \
+    "v_cmp_eq_f32_e64 %[" MXY "], %[sdz], %[" TS "]\n\t"                  \
     "v_cmp_eq_f32_e64 %[" MY "], %[sdy], %[" TS "]\n\t"                   \
-    "s_andn2_b64 %[" MY "], %[" MY "], %[" MXY "]\n\t"  /* y crossed: y minimal, z not */ \
-    "s_andn2_b64 %[" MXY "], exec, %[" MXY "]\n\t"      /* x or y crossed */ \
-    "s_andn2_b64 %[" MX "], %[" MXY "], %[" MY "]\n\t"  /* x crossed */    \
-    /* side_dist of the crossed axis += |1/dir|: one add under the axis' lane mask as EXEC instead of three adds and three  \
-       selects (a SIMD issues one instruction per clock in total and a vector instruction takes two slots: 3 V + 5 S = 11     \
-       slots against 12; the all-vector form of round 3, 5 S + 16 V per trip, measured the same: DESIGN.md 4 "issue slots") */ \
-    "s_mov_b64 %[ex], exec\n\t"                                           \
+    "s_andn2_b64 %[" MY "], %[" MY "], %[" MXY "]\n\t"                    \
+    "s_andn2_b64 %[" MXY "], exec, %[" MXY "]\n\t"                        \
+    "s_andn2_b64 %[" MX "], %[" MXY "], %[" MY "]\n\t"                    \
+    STEP(IDX, IDXN, MX, MY)                                               \
+    LOAD##_A(IDX, IDXN, WORD, WORDN)                                      \
     "s_mov_b64 exec, %[" MX "]\n\t"                                       \
     "v_add_f32_e64 %[sdx], %[sdx], |%[ix]|\n\t"                           \
     "s_mov_b64 exec, %[" MY "]\n\t"                                       \
     "v_add_f32_e64 %[sdy], %[sdy], |%[iy]|\n\t"                           \
-    "s_andn2_b64 exec, %[ex], %[" MXY "]\n\t"                             \
+    "s_andn2_b64 exec, %[cz], %[" MXY "]\n\t"                             \
     "v_add_f32_e64 %[sdz], %[sdz], |%[iz]|\n\t"                           \
-    "s_mov_b64 exec, %[ex]\n\t"                                           \
-    STEP(IDX, IDXN, MX, MY)                                               \
-    LOAD(IDX, IDXN, WORD, WORDN) /* request the next cell's word; wait for the one requested a trip ago */ \
+    LOAD##_B(IDX, IDXN, WORD, WORDN)                                      \
     TEST(WORD, IDX)                                                       \
     XKIND##_A(MX, MY, MXY)                                                \
     LIMIT(TS, MXY)                                                        \
@@ -249,8 +251,12 @@ struct GridWalkRegs {
 // upload), the byte itself: no shift for the address, no bit-field extract for the test — 16 instead of 18 vector instructions
 // per trip of a loop that is bound by instruction issue (a wave64 vector instruction takes two of its SIMD's issue slots)
 #define VRT_TEST_BYTE(WORD, IDX) "v_cmp_ne_u32_e32 vcc, 0, %[" WORD "]\n\t"
-#define VRT_LOAD_BYTE(IDX, IDXN, WORD, WORDN)                                        \
-    "buffer_load_ubyte %[" WORDN "], %[" IDXN "], %[rsrc], 0 offen\n\t"   \
+
+#define VRT_LOAD_BYTE_A(IDX, IDXN, WORD, WORDN)                                      \
+    "s_mov_b64 %[cz], exec\n\t"                                          \
+    "buffer_load_ubyte %[" WORDN "], %[" IDXN "], %[rsrc], 0 offen\n\t"
+#define VRT_LOAD_BYTE_B(IDX, IDXN, WORD, WORDN)                                      \
+    "s_mov_b64 exec, %[cz]\n\t"                                          \
     "s_waitcnt vmcnt(1)\n\t"
 
 // Where the bitmap words come from.  Global memory: a stride-4 buffer resource indexed by the word index (an
@@ -258,15 +264,21 @@ struct GridWalkRegs {
 // LDS address 0, byte address masked into the power-of-two allocation.  The vector memory pipeline takes
 // one wave-wide scattered dword request per ~16 cycles per CU (tools/ubench/step_bench.hip: the trip runs at 63
 // cycles per SIMD with the buffer load, 40-44 without); LDS serves the same request several times faster.
-#define VRT_LOAD_BUFFER(IDX, IDXN, WORD, WORDN)                                      \
+#define VRT_LOAD_BUFFER_A(IDX, IDXN, WORD, WORDN)                                    \
+    "s_mov_b64 %[cz], exec\n\t"                                          \
     "v_lshrrev_b32_e32 %[t2], 5, %[" IDXN "]\n\t"                         \
-    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"         \
+    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"
+#define VRT_LOAD_BUFFER_B(IDX, IDXN, WORD, WORDN)                                    \
+    "s_mov_b64 exec, %[cz]\n\t"                                          \
     "s_waitcnt vmcnt(1)\n\t"
 #define VRT_WAIT_BUFFER "s_waitcnt vmcnt(0)\n\t"
-#define VRT_LOAD_LDS(IDX, IDXN, WORD, WORDN)                                         \
+#define VRT_LOAD_LDS_A(IDX, IDXN, WORD, WORDN)                                       \
+    "s_mov_b64 %[cz], exec\n\t"                                          \
     "v_lshrrev_b32_e32 %[t2], 3, %[" IDXN "]\n\t"                         \
     "v_and_b32_e32 %[t2], %[rsrc], %[t2]\n\t"                             \
-    "ds_read_b32 %[" WORDN "], %[t2]\n\t"                                 \
+    "ds_read_b32 %[" WORDN "], %[t2]\n\t"
+#define VRT_LOAD_LDS_B(IDX, IDXN, WORD, WORDN)                                       \
+    "s_mov_b64 exec, %[cz]\n\t"                                          \
     "s_waitcnt lgkmcnt(1)\n\t"
 #define VRT_WAIT_LDS "s_waitcnt lgkmcnt(0)\n\t"
 
@@ -423,21 +435,21 @@ struct GridParkRegs {
 #define VRT_SWAP_SETS "v_swap_b32 %[tsa], %[tsb]\n\t" "v_swap_b32 %[idxa], %[idxb]\n\t"
 
 #define VRT_PARK_WALK_ASM(LIMIT, LOAD, TEST, WAITALL, AT30) VRT_PARK_WALK_ASM_S(VRT_STEP_LINEAR, LIMIT, LOAD, TEST, WAITALL, AT30)
-#define VRT_PARK_WALK_ASM_S(STEP, LIMIT, LOAD, TEST, WAITALL, AT30) VRT_PARK_WALK_ASM_X(STEP, VRT_EXIT_COUNTERS, "", LIMIT, LOAD, TEST, WAITALL, AT30)
+#define VRT_PARK_WALK_ASM_S(STEP, LIMIT, LOAD, TEST, WAITALL, AT30) VRT_PARK_WALK_ASM_T(VRT_TRIP_E, STEP, VRT_EXIT_COUNTERS, "", LIMIT, LOAD, TEST, WAITALL, AT30)
 // PARKPRE: what a trip's park code does first (VRT_EXIT_CARRY: note the parked lanes whose step out of their cell left the grid)
-#define VRT_PARK_WALK_ASM_X(STEP, XKIND, PARKPRE, LIMIT, LOAD, TEST, WAITALL, AT30) \
+#define VRT_PARK_WALK_ASM_T(TRIP, STEP, XKIND, PARKPRE, LIMIT, LOAD, TEST, WAITALL, AT30) \
         "s_mov_b64 %[save], exec\n\t" \
         "s_mov_b64 exec, %[alive]\n\t" \
         "s_mov_b64 %[parked], 0\n\t" \
-        VRT_TRIP_X(STEP, XKIND, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "10f") \
+        TRIP(STEP, XKIND, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "10f") \
         "0:\n\t" \
-        VRT_TRIP_X(STEP, XKIND, "tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "11f") \
+        TRIP(STEP, XKIND, "tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "11f") \
         "21:\n\t" \
-        VRT_TRIP_X(STEP, XKIND, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "12f") \
+        TRIP(STEP, XKIND, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "12f") \
         "22:\n\t" \
-        VRT_TRIP_X(STEP, XKIND, "tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "13f") \
+        TRIP(STEP, XKIND, "tsb", "mxb", "myb", "mxyb", "idxb", "idxa", "wordb", "worda", LIMIT, LOAD, TEST, "13f") \
         "23:\n\t" \
-        VRT_TRIP_X(STEP, XKIND, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "14f") \
+        TRIP(STEP, XKIND, "tsa", "mxa", "mya", "mxya", "idxa", "idxb", "worda", "wordb", LIMIT, LOAD, TEST, "14f") \
         "24:\n\t" \
         "s_cbranch_execz 31f\n\t" \
         /* back edge (after an A trip): keep walking while at least min_alive lanes are moving; fewer -> hand the wave back \
@@ -501,12 +513,15 @@ VRT_DI void voxel_walk_park_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, 
 // cycles x ~15 trips of the longest lane.  Here the lane's whole brick is fetched ONCE by four global_load_lds_dwordx4 in flight
 // together (chunk c of lane l lands at wave base + 1024 c + 16 l: the layout the instruction dictates; tools/ubench/glds_probe.hip)
 // and the trips read LDS: word w of the brick at lane base + ((w >> 2) << 10) + ((w & 3) << 2), w = (bit index >> 5) & 15.
-#define VRT_LOAD_LDS_BRICK(IDX, IDXN, WORD, WORDN)                                   \
+#define VRT_LOAD_LDS_BRICK_A(IDX, IDXN, WORD, WORDN)                                 \
+    "s_mov_b64 %[cz], exec\n\t"                                         \
     "v_lshrrev_b32_e32 %[t2], 3, %[" IDXN "]\n\t"                         \
     "v_and_b32_e32 %[t0], 48, %[t2]\n\t"                                 \
     "v_and_or_b32 %[t2], %[t2], 12, %[lb]\n\t"                           \
     "v_lshl_add_u32 %[t2], %[t0], 6, %[t2]\n\t"                          \
-    "ds_read_b32 %[" WORDN "], %[t2]\n\t"                                \
+    "ds_read_b32 %[" WORDN "], %[t2]\n\t"
+#define VRT_LOAD_LDS_BRICK_B(IDX, IDXN, WORD, WORDN)                                 \
+    "s_mov_b64 exec, %[cz]\n\t"                                         \
     "s_waitcnt lgkmcnt(1)\n\t"
 VRT_DI void voxel_walk_park_lds_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
                                        uint32_t &word, uint32_t lane_base, GridParkRegs &g, float scale, float t_max) {
@@ -516,7 +531,8 @@ VRT_DI void voxel_walk_park_lds_gfx950(Walk &w, const f3 &inv_dir, uint32_t &ind
     const uint32_t rsrc = 0u; // (operand of the shared input list; unused)
     asm volatile(VRT_PARK_WALK_ASM(VRT_T_LIMIT, VRT_LOAD_LDS_BRICK, VRT_TEST_BIT, VRT_WAIT_LDS, "") : VRT_PARK_WALK_OPERANDS : VRT_PARK_WALK_INPUTS, [scale] "s"(scale), [tmax] "v"(t_max), [lb] "v"(lane_base) : "vcc", "scc");
 }
-#undef VRT_LOAD_LDS_BRICK
+#undef VRT_LOAD_LDS_BRICK_A
+#undef VRT_LOAD_LDS_BRICK_B
 // byte address (LDS) of the word that holds bit `bit_index` of the lane's staged brick
 VRT_DI uint32_t brick_lds_address(uint32_t lane_base, uint32_t bit_index) {
     const uint32_t w = (bit_index >> 5) & 15u;
@@ -542,12 +558,12 @@ struct HalfBlockConsts {
     uint32_t lx;    // log2(dim_x): z & 3 starts here
     uint32_t lxz;   // log2(dim_x) + log2(dim_z): y & 1 is this bit
 };
-#define VRT_LOAD_HALFBLOCK(IDX, IDXN, WORD, WORDN)                         \
+#define VRT_LOAD_HALFBLOCK_A(IDX, IDXN, WORD, WORDN)                       \
     "v_xor_b32_e32 %[t2], %[" IDXN "], %[" IDX "]\n\t"                     \
     "v_and_b32_e32 %[t2], %[nmask], %[t2]\n\t"                             \
-    "v_cmp_ne_u32_e64 %[by], 0, %[t2]\n\t" /* lanes whose step enters another half-block */ \
+    "v_cmp_ne_u32_e64 %[by], 0, %[t2]\n\t"                                 \
     "s_cmp_eq_u64 %[by], 0\n\t"                                            \
-    "s_cselect_b64 %[by], exec, %[by]\n\t" /* nobody: everybody asks again (one request per trip, always) */ \
+    "s_cselect_b64 %[by], exec, %[by]\n\t"                                 \
     "s_and_saveexec_b64 %[cz], %[by]\n\t"                                  \
     "v_lshrrev_b32_e32 %[t2], 2, %[" IDXN "]\n\t"                          \
     "v_and_b32_e32 %[t2], %[mx], %[t2]\n\t"                                \
@@ -555,8 +571,9 @@ struct HalfBlockConsts {
     "v_and_or_b32 %[t2], %[t0], %[mzs], %[t2]\n\t"                         \
     "v_lshrrev_b32_e32 %[t0], 5, %[" IDXN "]\n\t"                          \
     "v_and_or_b32 %[t2], %[t0], %[mys], %[t2]\n\t"                         \
-    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"          \
-    "s_andn2_b64 exec, %[cz], %[by]\n\t"   /* the lanes that stay in their half-block keep its word */ \
+    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"
+#define VRT_LOAD_HALFBLOCK_B(IDX, IDXN, WORD, WORDN)                       \
+    "s_andn2_b64 exec, %[cz], %[by]\n\t"                                   \
     "s_waitcnt vmcnt(1)\n\t"                                               \
     "v_mov_b32_e32 %[" WORDN "], %[" WORD "]\n\t"                          \
     "s_mov_b64 exec, %[cz]\n\t"
@@ -578,7 +595,8 @@ VRT_DI void grid_walk_park_halfblocks_gfx950(Walk &w, const f3 &inv_dir, uint32_
                  : VRT_PARK_WALK_INPUTS, [nmask] "s"(hb.nmask), [mx] "s"(hb.mx), [mzs] "s"(hb.mzs), [mys] "s"(hb.mys), [lx] "s"(hb.lx), [lxz] "s"(hb.lxz)
                  : "vcc", "scc");
 }
-#undef VRT_LOAD_HALFBLOCK
+#undef VRT_LOAD_HALFBLOCK_A
+#undef VRT_LOAD_HALFBLOCK_B
 #undef VRT_TEST_HALFBLOCK
 // ---- the half-block park loop on a DILATED cell index (vrt_path_kernel<DIL>, round 3) ------------------------------------------
 // The half-block loop above pays 17 of its 29 vector instructions per trip for turning a linear cell index into a half-block word
@@ -590,16 +608,17 @@ VRT_DI void grid_walk_park_halfblocks_gfx950(Walk &w, const f3 &inv_dir, uint32_
 // the real one: word = real >> 5, bit = real & 31 (v_bfe takes it from the low five bits).  Two cells lie in the same half-block
 // iff their indices agree above bit 4 — mirrored or not.  22 vector instructions per trip; same words, same requests, same
 // sequence of DDA operations per lane.
-#define VRT_LOAD_DILATED(IDX, IDXN, WORD, WORDN)                           \
+#define VRT_LOAD_DILATED_A(IDX, IDXN, WORD, WORDN)                          \
     "v_xor_b32_e32 %[t2], %[" IDXN "], %[" IDX "]\n\t"                     \
-    "v_cmp_lt_u32_e64 %[by], 31, %[t2]\n\t" /* lanes whose step enters another half-block */ \
+    "v_cmp_lt_u32_e64 %[by], 31, %[t2]\n\t"                                \
     "s_cmp_eq_u64 %[by], 0\n\t"                                            \
-    "s_cselect_b64 %[by], exec, %[by]\n\t" /* nobody: everybody asks again (one request per trip, always) */ \
-    "s_and_saveexec_b64 %[cz], %[by]\n\t"                                  \
+    "s_cselect_b64 %[by], exec, %[by]\n\t"                                 \
+    "s_and_saveexec_b64 %[cz], %[by]\n\t" /* cz: the trip's lanes, until LOADB */ \
     "v_xor_b32_e32 %[t2], %[" IDXN "], %[flip]\n\t"                        \
     "v_lshrrev_b32_e32 %[t2], 5, %[t2]\n\t"                                \
-    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"          \
-    "s_andn2_b64 exec, %[cz], %[by]\n\t"   /* the lanes that stay in their half-block keep its word */ \
+    "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"
+#define VRT_LOAD_DILATED_B(IDX, IDXN, WORD, WORDN)                          \
+    "s_andn2_b64 exec, %[cz], %[by]\n\t"                                   \
     "s_waitcnt vmcnt(1)\n\t"                                               \
     "v_mov_b32_e32 %[" WORDN "], %[" WORD "]\n\t"                          \
     "s_mov_b64 exec, %[cz]\n\t"
@@ -614,7 +633,7 @@ VRT_DI void grid_walk_park_dilated_gfx950(Walk &w, const f3 &inv_dir, uint32_t &
     float t0, t1, t2;
     uint32_t wordb, n;
     const uint32_t stride_x = nm_x, stride_y = nm_y, stride_z = nm_z; // (the operand list's names)
-    asm volatile(VRT_PARK_WALK_ASM_S(VRT_STEP_DILATED, VRT_NO_LIMIT, VRT_LOAD_DILATED, VRT_TEST_DILATED, VRT_WAIT_BUFFER, "")
+    asm volatile(VRT_PARK_WALK_ASM_T(VRT_TRIP_E, VRT_STEP_DILATED, VRT_EXIT_COUNTERS, "", VRT_NO_LIMIT, VRT_LOAD_DILATED, VRT_TEST_DILATED, VRT_WAIT_BUFFER, "")
                  : VRT_PARK_WALK_OPERANDS
                  : VRT_PARK_WALK_INPUTS, [flip] "v"(flip)
                  : "vcc", "scc");
@@ -632,8 +651,8 @@ VRT_DI void grid_walk_park_dilated_carry_gfx950(f3 &side_dist, const f3 &inv_dir
     uint32_t wordb, n;
     const uint32_t stride_x = nm_x, stride_y = nm_y, stride_z = nm_z; // (the operand list's names)
     gone = 0ull;
-    asm volatile(VRT_PARK_WALK_ASM_X(VRT_STEP_DILATED_CARRY, VRT_EXIT_CARRY, "s_and_b64 %[by], %[ex], vcc\n\ts_or_b64 %[gone], %[gone], %[by]\n\t", VRT_NO_LIMIT,
-                                     VRT_LOAD_DILATED, VRT_TEST_DILATED, VRT_WAIT_BUFFER, "")
+    asm volatile(VRT_PARK_WALK_ASM_T(VRT_TRIP_E, VRT_STEP_DILATED_CARRY, VRT_EXIT_CARRY, "s_and_b64 %[by], %[ex], vcc\n\ts_or_b64 %[gone], %[gone], %[by]\n\t",
+                                     VRT_NO_LIMIT, VRT_LOAD_DILATED, VRT_TEST_DILATED, VRT_WAIT_BUFFER, "")
                  : [sdx] "+v"(side_dist.x), [sdy] "+v"(side_dist.y), [sdz] "+v"(side_dist.z), [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(word),
                    [wordb] "=&v"(wordb), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in), [code] "+v"(g.code), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
                    [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive), [mxa] "=&s"(mxa), [mya] "=&s"(mya), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb),
@@ -641,7 +660,8 @@ VRT_DI void grid_walk_park_dilated_carry_gfx950(f3 &side_dist, const f3 &inv_dir
                  : VRT_PARK_WALK_INPUTS, [flip] "v"(flip)
                  : "vcc", "scc");
 }
-#undef VRT_LOAD_DILATED
+#undef VRT_LOAD_DILATED_A
+#undef VRT_LOAD_DILATED_B
 #undef VRT_TEST_DILATED
 // ---- the brick-level park loop on a DISTANCE FIELD (vrt_path_kernel<DIST>, round 3) ---------------------------------------------
 // A DDA trip moves one cell along one axis, so n trips reach exactly the cells within L1 (Manhattan) distance n of where they
@@ -655,13 +675,14 @@ VRT_DI void grid_walk_park_dilated_carry_gfx950(f3 &side_dist, const f3 &inv_dir
 // instructions and, in the 2048^3 sparse field, a lane asks about twice per d cells.  The index is the plain linear cell index =
 // the byte offset: any grid dimensions.  If no lane of the wave has to ask, all do (a trip always issues one request, so that
 // vmcnt(1) keeps its meaning); `nd<word>` = the lanes whose <word> register holds an answer.
-#define VRT_LOAD_DIST(IDX, IDXN, WORD, WORDN)                                      \
-    "v_cmp_gt_i32_e64 %[nd" WORDN "], 1, %[k]\n\t"  /* lanes that have to ask: k <= 0 */ \
+#define VRT_LOAD_DIST_A(IDX, IDXN, WORD, WORDN)                                    \
+    "v_cmp_gt_i32_e64 %[nd" WORDN "], 1, %[k]\n\t"                                 \
     "v_add_u32_e32 %[k], -1, %[k]\n\t"                                             \
     "s_cmp_eq_u64 %[nd" WORDN "], 0\n\t"                                           \
     "s_cselect_b64 %[nd" WORDN "], exec, %[nd" WORDN "]\n\t"                       \
     "s_and_saveexec_b64 %[cz], %[nd" WORDN "]\n\t"                                 \
-    "buffer_load_ubyte %[" WORDN "], %[" IDXN "], %[rsrc], 0 offen\n\t"            \
+    "buffer_load_ubyte %[" WORDN "], %[" IDXN "], %[rsrc], 0 offen\n\t"
+#define VRT_LOAD_DIST_B(IDX, IDXN, WORD, WORDN)                                    \
     "s_mov_b64 exec, %[cz]\n\t"                                                    \
     "s_waitcnt vmcnt(1)\n\t"
 #define VRT_TEST_DIST(WORD, IDX)                                                   \
@@ -683,7 +704,8 @@ VRT_DI void grid_walk_park_dist_gfx950(Walk &w, const f3 &inv_dir, uint32_t &ind
                  : VRT_PARK_WALK_INPUTS
                  : "vcc", "scc");
 }
-#undef VRT_LOAD_DIST
+#undef VRT_LOAD_DIST_A
+#undef VRT_LOAD_DIST_B
 #undef VRT_TEST_DIST
 // index of the half-block word that holds cell `index`
 VRT_DI uint32_t halfblock_word(const HalfBlockConsts &hb, uint32_t index) {
@@ -691,7 +713,7 @@ VRT_DI uint32_t halfblock_word(const HalfBlockConsts &hb, uint32_t index) {
 }
 #undef VRT_PARK_WALK_ASM
 #undef VRT_PARK_WALK_ASM_S
-#undef VRT_PARK_WALK_ASM_X
+#undef VRT_PARK_WALK_ASM_T
 #undef VRT_PARK_WALK_OPERANDS
 #undef VRT_PARK_WALK_INPUTS
 // ---- the park loop pipelined TWO trips ahead (vrt_path_kernel<AHEAD>) ---------------------------------------------------------
@@ -855,7 +877,8 @@ struct FilterConsts {
 #undef VRT_TRIP_T
 #undef VRT_TEST_BIT
 #undef VRT_TEST_BYTE
-#undef VRT_LOAD_BYTE
+#undef VRT_LOAD_BYTE_A
+#undef VRT_LOAD_BYTE_B
 
 // comp:298 / comp:395
 VRT_DI f3 initial_side_dist(f3 fstep, f3 fposition, f3 ray_delta) {
