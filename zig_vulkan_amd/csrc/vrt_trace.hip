@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void vrt_build_status_halfblocks(const uint32_
 // cap commutes with min and + 1).  One thread per status word for the seed; one thread per line of cells for a sweep (the line of
 // thread t along axis a: the t-th combination of the other two coordinates; consecutive threads are consecutive in the fastest
 // remaining coordinate).
+#ifdef VRT_DEV_VARIANTS // (only vrt_path_kernel<DIST>, a development variant, reads the field)
 __global__ __launch_bounds__(256) void vrt_build_distance_seed(const uint32_t *__restrict__ status, uint8_t *__restrict__ out, uint32_t words, uint32_t cells) {
     const uint32_t wi = blockIdx.x * 256u + threadIdx.x;
     if (wi >= words) return;
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void vrt_build_distance_sweep(uint8_t *__restr
         *c = (uint8_t)run;
     }
 }
+#endif
 
 // One byte per grid cell (TraceParams::status_bytes): 1 where the cell's status bit is set.  One thread per status word.
 __global__ __launch_bounds__(256) void vrt_build_status_bytes(const uint32_t *__restrict__ status, uint8_t *__restrict__ out, uint32_t words, uint32_t /*cells*/) {
@@ -588,12 +590,17 @@ hipError_t launch_build_status_halfblocks(const TraceParams &p, uint32_t dim_x, 
 
 hipError_t launch_build_cell_distance(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
     if (!p.cell_distance) return hipSuccess;
+#ifndef VRT_DEV_VARIANTS
+    (void)dim_x, (void)dim_y, (void)dim_z, (void)stream;
+    return hipErrorNotSupported; // (no kernel of the product build reads the field: vrt_create never allocates it there)
+#else
     uint8_t *d = const_cast<uint8_t *>(p.cell_distance);
     hipLaunchKernelGGL(vrt_build_distance_seed, dim3((p.status_words + 255u) / 256u), dim3(256), 0, stream, p.brick_status, d, p.status_words, p.status_cells);
     const uint32_t lines[3] = {dim_z * dim_y, dim_x * dim_y, dim_x * dim_z};
     for (uint32_t axis = 0; axis < 3u; axis++)
         hipLaunchKernelGGL(vrt_build_distance_sweep, dim3((lines[axis] + 255u) / 256u), dim3(256), 0, stream, d, dim_x, dim_y, dim_z, axis);
     return hipGetLastError();
+#endif
 }
 
 hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, hipStream_t stream) {
