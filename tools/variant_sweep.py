@@ -26,6 +26,6 @@ for variant, flags in variants:
         rt.draw(frames=max(2, frames // 2))
         rt.draw(frames=frames)
         import hashlib
-        out.append(f"{v} {rt.last_kernel_ms():9.3f} [{hashlib.sha256(rt.read_rgba8().tobytes()).hexdigest()[:8]}]")
+        out.append(f"{v} {rt.last_kernel_ms():9.4f} [{hashlib.sha256(rt.read_rgba8().tobytes()).hexdigest()[:8]}]")
     print(f"variant {variant:#010x} flags {flags:#04x} {rt.kernel_name():44s} " + "  ".join(out), flush=True)
     rt.deinit()
