@@ -1142,7 +1142,18 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
 // occ_slot: where the brick's bits lie, in bricks of the array `occupancy` — the brick's slot in binding 5, or (by_cell) the grid
 // cell in the by-cell copy TraceParams::cell_occupancy, in which case the slot (brick_index[cell], comp:337) is looked up only by
 // the lanes that have found a solid voxel.  start_is_slot: comp:422's look-up is slot * B^3 for every brick (TraceParams).
-template <int B, bool LDS = false>
+// The request for a lane's brick (LDS walk): four 16-byte chunks into the wave's staging area.  vrt_path_kernel issues it as soon as
+// it knows the cell (PRESTAGED) — the position arithmetic of the brick entry then runs while the 64 bytes are on their way.
+VRT_DI void stage_brick_lds(const TraceParams &p, uint32_t occ_slot, bool by_cell, uint32_t wave_lds) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(by_cell ? p.cell_occupancy : p.brick_occupancy) + (size_t)occ_slot * 16u;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    lds_void *dst = reinterpret_cast<lds_void *>((size_t)__builtin_amdgcn_readfirstlane(wave_lds));
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        __builtin_amdgcn_global_load_lds((glb_void *)(src + 4 * c), (lds_void *)((__attribute__((address_space(3))) char *)dst + 1024 * c), 16, 0, 0);
+}
+template <int B, bool LDS = false, bool PRESTAGED = false>
 VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t occ_slot, uint32_t cell, bool by_cell,
                                    bool start_is_slot, f3 brick_min, Hit &hit, int axis_in, int &hit_axis, uint32_t wave_lds = 0u) {
     static_assert(!LDS || B == 8, "the LDS layout is written for 64-byte bricks");
@@ -1180,13 +1191,7 @@ VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const Ray
     [[maybe_unused]] uint32_t eager_start = 0u;
     VRT_PROF_BEGIN(tp5);
     if constexpr (LDS) {
-        const uint32_t *src = occ_words + (size_t)occ_slot * 16u;
-        typedef __attribute__((address_space(3))) void lds_void;
-        typedef const __attribute__((address_space(1))) void glb_void;
-        lds_void *dst = reinterpret_cast<lds_void *>((size_t)__builtin_amdgcn_readfirstlane(wave_lds));
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-            __builtin_amdgcn_global_load_lds((glb_void *)(src + 4 * c), (lds_void *)((__attribute__((address_space(3))) char *)dst + 1024 * c), 16, 0, 0);
+        if constexpr (!PRESTAGED) stage_brick_lds(p, occ_slot, by_cell, wave_lds);
         // (path_eager_start: the brick's start index travels with the four chunks instead of after the walk)
         if (p.path_eager_start) eager_start = p.brick_start_index[by_cell ? p.brick_index[cell] : occ_slot];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2571,14 +2576,17 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                     cz = (int)(((real >> 2) & 3u) | ((real >> (lx + 1u)) & (((1u << (lz - 2u)) - 1u) << 2)));
                     cy = (int)(((real >> 4) & 1u) | ((real >> (lx + lz + 1u)) << 1));
                 }
+                if constexpr (DIL) cell = (uint32_t)cx + (uint32_t)dx * ((uint32_t)cz + (uint32_t)dz * (uint32_t)cy); // (the loop's index is dilated)
+                const uint32_t occ_slot = by_cell ? cell : p.brick_index[cell]; // comp:337 (by_cell: only on a solid voxel)
+                if constexpr (B == 8) {
+                    if (p.path_brick_lds) stage_brick_lds(p, occ_slot, by_cell, wave_lds); // (first: the arithmetic below runs while the brick arrives)
+                }
                 const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min);  // comp:331
                 const float global_t_value = t_into * g_scale + s.grid_t_min + 0.01f * g_scale;          // comp:347 (deferred) + comp:332
                 hit.t = global_t_value;
-                if constexpr (DIL) cell = (uint32_t)cx + (uint32_t)dx * ((uint32_t)cz + (uint32_t)dz * (uint32_t)cy); // (the loop's index is dilated)
-                const uint32_t occ_slot = by_cell ? cell : p.brick_index[cell]; // comp:337 (by_cell: only on a solid voxel)
                 bool hit_voxel;
                 if constexpr (B == 8) {
-                    hit_voxel = p.path_brick_lds ? brick_walk_park_gfx950<B, true>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis, wave_lds)
+                    hit_voxel = p.path_brick_lds ? brick_walk_park_gfx950<B, true, true>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis, wave_lds)
                                                  : brick_walk_park_gfx950<B>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis);
                 } else {
                     hit_voxel = brick_walk_park_gfx950<B>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis);
