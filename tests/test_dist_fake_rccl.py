@@ -244,3 +244,59 @@ def test_pipeline_stage_profile(world, frames_per_launch):
         assert 3 <= st["launches_sampled"] <= 6 and st["frames_sampled"] == st["launches_sampled"] * frames_per_launch
         assert st["frames_per_launch"] == frames_per_launch and st["kernel_ms_per_launch"] > 0
         assert (st["unswizzle_ms_per_launch"] > 0) == (r == 0)
+
+
+def test_bounce_frames_of_a_path_kernel_context_go_through_the_pipeline_on_the_lockstep_kernel():
+    """A context whose bounce frames vrt_path_kernel traces (forced here; chosen by the library on scenes larger than the caches),
+    on a scene whose occupied cells reach the grid's faces: once the host knows the box, plain dispatches take the counter-free
+    dilated-index twin — and the multi-rank pipeline must still substitute the lockstep kernel for either (its RGB shard store
+    needs the fixed lane -> pixel map).  Frames with bounces, two ranks, assembled frame == the single-context frame."""
+    if not os.path.exists(FAKE):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
+    path = 1 << 23
+    w = W.Workload("t", 330, 210, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000)
+    grid = W.build_grid(w)
+    views = ["V0", "V1x", "V0", "V2", "V1x"]
+    plain = W.make_renderer(w, grid, kernel_variant=path)
+    W.set_view(plain, "V0")
+    plain.draw()
+    plain.wait()          # (the box of the occupied cells has reached the host)
+    ref = {}
+    for v in set(views):
+        W.set_view(plain, v)
+        plain.draw()
+        ref[v] = plain.read_rgba8().copy()
+    assert plain.kernel_name() == "vrt_path_kernel<8, 5, false, false, false, false, 2>"
+    plain.deinit()
+    world = 2
+    uid = b"fake-rccl-path" + os.urandom(16) + bytes(128 - 30)
+    ranks = [W.make_renderer(w, grid, kernel_variant=path, shard_rank=r, shard_count=world) for r in range(world)]
+    for r, rt in enumerate(ranks):
+        rt.dist_init(uid, r, world, frames_in_flight=2, rccl_path=FAKE, frames_per_launch=1)
+    got, errors = [], []
+
+    def drive(r):
+        try:
+            rt = ranks[r]
+            for v in views:
+                W.set_view(rt, v)
+                rt.dist_frame()
+                rt.dist_wait()
+                if r == 0:
+                    got.append((v, rt.dist_read_frame().copy(), rt.kernel_name()))
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    assert not errors, errors
+    for rt in ranks:
+        rt.deinit()
+    assert len(got) == len(views)
+    for v, frame, name in got:
+        assert name.startswith("vrt_trace_kernel<8, false,"), name
+        assert np.array_equal(frame, ref[v]), f"assembled frame of view {v} differs from the single-context frame"

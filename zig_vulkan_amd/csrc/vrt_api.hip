@@ -1456,7 +1456,7 @@ int vrt_dist_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_
     if (rcp != VRT_OK) return rcp;
     // the pipeline's launches overlap on several streams and write RGB shards with a row-of-eight-lanes shuffle: both
     // need the lockstep kernel (vrt_path_kernel has one pixel counter per stream and no fixed lane -> pixel map)
-    if (fn == ctx->kernel) fn = ctx->kernel_lockstep;
+    if (fn == ctx->kernel || (ctx->kernel_grid_exit && fn == ctx->kernel_grid_exit)) fn = ctx->kernel_lockstep;
     if (d->npend > 0 && d->pend_fn != fn) { // another kernel specialisation (bounces / samples changed): not in the same launch
         const int rcf = dist_flush(ctx);
         if (rcf != VRT_OK) return rcf;
