@@ -23,6 +23,9 @@ const KernelEntry kEntries[] = {
     VRT_PATH_ENTRY(4, 4, false, false), VRT_PATH_ENTRY(4, 4, false, true), VRT_PATH_ENTRY(8, 4, false, false), VRT_PATH_ENTRY(8, 4, false, true),
     VRT_PATH_ENTRY(4, 6, false, false), VRT_PATH_ENTRY(8, 6, false, false), VRT_PATH_ENTRY(8, 6, false, true),
     VRT_PATH_ENTRY(8, 7, false, false), VRT_PATH_ENTRY(8, 7, false, true), VRT_PATH_ENTRY(8, 8, false, false), VRT_PATH_ENTRY(8, 8, false, true),
+    // the dilated-index walks at other wave counts
+    VRT_PATH_ENTRY_L(8, 4, false, false, false, false, 1), VRT_PATH_ENTRY_L(8, 4, false, false, false, false, 2),
+    VRT_PATH_ENTRY_L(8, 6, false, false, false, false, 1), VRT_PATH_ENTRY_L(8, 6, false, false, false, false, 2),
     // the block-skipping walk behind the LDS block filter (measured slower: DESIGN.md §4)
     VRT_PATH_ENTRY(4, 4, true, false), VRT_PATH_ENTRY(8, 4, true, false), VRT_PATH_ENTRY(4, 5, true, false), VRT_PATH_ENTRY(8, 5, true, false),
 #endif
