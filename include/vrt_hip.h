@@ -156,7 +156,8 @@ typedef struct vrt_config {
 #define VRT_TUNE_PATH_DISTANCE       (1u << 8) /* development build only: vrt_path_kernel's walk loop on the L1 distance field of the occupied cells, a byte per cell (measured slower) */
 #define VRT_TUNE_NO_PATH_DILATED     (1u << 9) /* vrt_path_kernel: the half-block walk loop on the linear cell index instead of the dilated one */
 #define VRT_TUNE_NO_PATH_GRID_EXIT   (1u << 10) /* vrt_path_kernel, dilated index: keep the steps-left counters in the walk loop (the walk ends at the box of the occupied cells) even when that box is, or nearly is, the grid */
-#define VRT_TUNE_ALL                0x7FFu
+#define VRT_TUNE_PATH_BLOCKS64        (1u << 11) /* development build only: vrt_path_kernel's counter-free dilated-index walk on 4 x 4 x 4-cell words (64 bits) instead of half-block words (measured slower) */
+#define VRT_TUNE_ALL                0xFFFu
 
 typedef struct vrt_ctx vrt_ctx;
 

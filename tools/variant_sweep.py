@@ -21,6 +21,9 @@ for variant, flags in variants:
         print(f"variant {variant:#x}: {e}")
         continue
     out = []
+    W.set_view(rt, views[0])
+    rt.draw()
+    rt.wait()   # (behind the first frame the library knows the box of the occupied cells: kernel choices that depend on it have settled)
     for v in views:
         W.set_view(rt, v)
         rt.draw(frames=max(2, frames // 2))

@@ -484,6 +484,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         return fail(nullptr, VRT_E_INVALID_ARG, "VRT_TUNE_PATH_AHEAD selects a development kernel: not in the product build of libvrt_hip (make dev)");
     if (cfg->tuning_flags & VRT_TUNE_PATH_DISTANCE)
         return fail(nullptr, VRT_E_INVALID_ARG, "VRT_TUNE_PATH_DISTANCE selects a development kernel: not in the product build of libvrt_hip (make dev)");
+    if (cfg->tuning_flags & VRT_TUNE_PATH_BLOCKS64)
+        return fail(nullptr, VRT_E_INVALID_ARG, "VRT_TUNE_PATH_BLOCKS64 selects a development kernel: not in the product build of libvrt_hip (make dev)");
 #endif
     if ((cfg->kernel_variant & 0xFFu) >= vrt::kVariantCount || ((cfg->kernel_variant >> 28) && ((cfg->kernel_variant >> 16) & 0xFu) != 7u)) return fail(nullptr, VRT_E_INVALID_ARG, "unknown kernel_variant");
 
@@ -776,8 +778,9 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     select_all();
     if (!(cfg->tuning_flags & VRT_TUNE_NO_PATH_GRID_EXIT)) {
         // (chosen per dispatch, once the host knows the box of the occupied cells: pre_dispatch)
-        if (vrt::path_kernel_dilated_kind(c->kernel) == 1) c->kernel_grid_exit = vrt::path_kernel_dilated_twin(c->kernel, 2);
-        if (c->product[0] && vrt::path_kernel_dilated_kind(c->product[0]) == 1) c->product_grid_exit = vrt::path_kernel_dilated_twin(c->product[0], 2);
+        const int kind = ((cfg->tuning_flags & VRT_TUNE_PATH_BLOCKS64) && cfg->dim_y % 4u == 0u) ? 3 : 2;
+        if (vrt::path_kernel_dilated_kind(c->kernel) == 1) c->kernel_grid_exit = vrt::path_kernel_dilated_twin(c->kernel, kind);
+        if (c->product[0] && vrt::path_kernel_dilated_kind(c->product[0]) == 1) c->product_grid_exit = vrt::path_kernel_dilated_twin(c->product[0], kind);
         if (c->kernel_grid_exit == c->kernel) c->kernel_grid_exit = nullptr;
         if (c->product_grid_exit == c->product[0]) c->product_grid_exit = nullptr;
     }
@@ -795,7 +798,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         }
         // derived copies of the status bits, each only if a kernel of this context reads it
         auto any_kernel = [&](auto pred) {
-            const vrt::KernelFn fns[7] = {c->kernel, c->kernel_lockstep, c->kernel_single, c->kernel_single1, c->product[0], c->product[1], c->product[2]};
+            const vrt::KernelFn fns[9] = {c->kernel, c->kernel_lockstep, c->kernel_single, c->kernel_single1, c->product[0], c->product[1], c->product[2],
+                                          c->kernel_grid_exit, c->product_grid_exit};
             for (vrt::KernelFn fn : fns) {
                 const vrt::KernelEntry *e = fn ? vrt::kernel_entry_of(fn) : nullptr;
                 if (e && pred(*e)) return true;
@@ -829,7 +833,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
             VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_start_is_slot), 64u));
             VRT_CREATE_HIP(hipMemsetAsync(c->d_start_is_slot, 0, 64u, c->stream));
         }
-        if (any_kernel([](const vrt::KernelEntry &e) { return (e.path && e.filter) || (!e.path && (e.mode == vrt::kStatusBlocked || e.mode == vrt::kStatusBlockedLds)); })) {
+        if (any_kernel([](const vrt::KernelEntry &e) { return (e.path && (e.filter || e.dil == 3)) || (!e.path && (e.mode == vrt::kStatusBlocked || e.mode == vrt::kStatusBlockedLds)); })) {
             const size_t nblocks = (size_t)nbx * nby * nbz;
             const size_t status_blocks_bytes = nblocks * 8u + ((nblocks + 31u) / 32u) * 4u + 16u;
             VRT_CREATE_HIP(hipMalloc(&c->d_status_blocks, status_blocks_bytes));

@@ -436,8 +436,12 @@ struct GridParkRegs {
 
 #define VRT_PARK_WALK_ASM(LIMIT, LOAD, TEST, WAITALL, AT30) VRT_PARK_WALK_ASM_S(VRT_STEP_LINEAR, LIMIT, LOAD, TEST, WAITALL, AT30)
 #define VRT_PARK_WALK_ASM_S(STEP, LIMIT, LOAD, TEST, WAITALL, AT30) VRT_PARK_WALK_ASM_T(VRT_TRIP_E, STEP, VRT_EXIT_COUNTERS, "", LIMIT, LOAD, TEST, WAITALL, AT30)
-// PARKPRE: what a trip's park code does first (VRT_EXIT_CARRY: note the parked lanes whose step out of their cell left the grid)
+#define VRT_WORD_MOV32 "v_mov_b32_e32 %[worda], %[wordb]\n\t"
 #define VRT_PARK_WALK_ASM_T(TRIP, STEP, XKIND, PARKPRE, LIMIT, LOAD, TEST, WAITALL, AT30) \
+    VRT_PARK_WALK_ASM_W(TRIP, STEP, XKIND, PARKPRE, LIMIT, LOAD, TEST, WAITALL, VRT_WORD_MOV32 AT30)
+// PARKPRE: what a trip's park code does first (VRT_EXIT_CARRY: note the parked lanes whose step out of their cell left the grid)
+// (AT30: how worda takes wordb's content when a call ends in an A trip, and whatever else the variant has to swap there)
+#define VRT_PARK_WALK_ASM_W(TRIP, STEP, XKIND, PARKPRE, LIMIT, LOAD, TEST, WAITALL, AT30) \
         "s_mov_b64 %[save], exec\n\t" \
         "s_mov_b64 exec, %[alive]\n\t" \
         "s_mov_b64 %[parked], 0\n\t" \
@@ -467,7 +471,6 @@ struct GridParkRegs {
         "s_mov_b64 %[alive], exec\n\t" \
         WAITALL \
         VRT_SWAP_SETS \
-        "v_mov_b32_e32 %[worda], %[wordb]\n\t" \
         AT30 \
         "s_mov_b64 %[mxb], %[mxa]\n\t" \
         "s_mov_b64 %[myb], %[mya]\n\t" \
@@ -663,6 +666,51 @@ VRT_DI void grid_walk_park_dilated_carry_gfx950(f3 &side_dist, const f3 &inv_dir
 #undef VRT_LOAD_DILATED_A
 #undef VRT_LOAD_DILATED_B
 #undef VRT_TEST_DILATED
+// The counter-free dilated loop on 4 x 4 x 4-CELL words (vrt_path_kernel<..., DIL 3>): the 64-bit words of TraceParams::status_blocks,
+// index bits 0-5 = the cell's place in its block (x&3 | (z&3) << 2 | (y&3) << 4), the bits above = the block's number.  A lane asks
+// when its step enters another block: 0.265 times per trip in the 2048^3 sparse field against 0.333 for half-blocks
+// (tools/request_replay.py).  The word is a register pair; the test shifts the cell's bit into bit 63 (v_lshlrev_b64 by ~index, of
+// which the instruction reads the low six bits) and compares with 0.
+#define VRT_LOAD_DILATED64_A(IDX, IDXN, WORD, WORDN)                       \
+    "v_xor_b32_e32 %[t2], %[" IDXN "], %[" IDX "]\n\t"                     \
+    "v_cmp_lt_u32_e64 %[by], 63, %[t2]\n\t"                                \
+    "s_cmp_eq_u64 %[by], 0\n\t"                                            \
+    "s_cselect_b64 %[by], exec, %[by]\n\t"                                 \
+    "s_and_saveexec_b64 %[cz], %[by]\n\t"                                  \
+    "v_xor_b32_e32 %[t2], %[" IDXN "], %[flip]\n\t"                        \
+    "v_lshrrev_b32_e32 %[t2], 6, %[t2]\n\t"                                \
+    "buffer_load_dwordx2 %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"
+#define VRT_LOAD_DILATED64_B(IDX, IDXN, WORD, WORDN)                       \
+    "s_andn2_b64 exec, %[cz], %[by]\n\t"                                   \
+    "s_waitcnt vmcnt(1)\n\t"                                               \
+    "v_mov_b64_e32 %[" WORDN "], %[" WORD "]\n\t"                          \
+    "s_mov_b64 exec, %[cz]\n\t"
+#define VRT_TEST_DILATED64(WORD, IDX)                                      \
+    "v_xnor_b32_e32 %[t1], %[" IDX "], %[flip]\n\t"                        \
+    "v_lshlrev_b64 %[tp], %[t1], %[" WORD "]\n\t"                          \
+    "v_cmp_gt_i64_e64 vcc, 0, %[tp]\n\t"
+VRT_DI void grid_walk_park_dilated64_gfx950(f3 &side_dist, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t nm_x, uint32_t nm_y, uint32_t nm_z,
+                                            unsigned long long &word, u32x4 rsrc, GridParkRegs &g, uint32_t flip, unsigned long long &gone) {
+    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+    u32x2 wordb, tp, wa = __builtin_bit_cast(u32x2, word);
+    float t0, t1, t2;
+    uint32_t n;
+    const uint32_t stride_x = nm_x, stride_y = nm_y, stride_z = nm_z; // (the operand list's names)
+    gone = 0ull;
+    asm volatile(VRT_PARK_WALK_ASM_W(VRT_TRIP_E, VRT_STEP_DILATED_CARRY, VRT_EXIT_CARRY, "s_and_b64 %[by], %[ex], vcc\n\ts_or_b64 %[gone], %[gone], %[by]\n\t",
+                                     VRT_NO_LIMIT, VRT_LOAD_DILATED64, VRT_TEST_DILATED64, VRT_WAIT_BUFFER, "v_mov_b64_e32 %[worda], %[wordb]\n\t")
+                 : [sdx] "+v"(side_dist.x), [sdy] "+v"(side_dist.y), [sdz] "+v"(side_dist.z), [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(wa),
+                   [wordb] "=&v"(wordb), [tp] "=&v"(tp), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in), [code] "+v"(g.code), [t0] "=&v"(t0), [t1] "=&v"(t1),
+                   [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive), [mxa] "=&s"(mxa), [mya] "=&s"(mya), [mxya] "=&s"(mxya),
+                   [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz), [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n), [gone] "+s"(gone)
+                 : VRT_PARK_WALK_INPUTS, [flip] "v"(flip)
+                 : "vcc", "scc");
+    word = __builtin_bit_cast(unsigned long long, wa);
+}
+#undef VRT_LOAD_DILATED64_A
+#undef VRT_LOAD_DILATED64_B
+#undef VRT_TEST_DILATED64
 // ---- the brick-level park loop on a DISTANCE FIELD (vrt_path_kernel<DIST>, round 3) ---------------------------------------------
 // A DDA trip moves one cell along one axis, so n trips reach exactly the cells within L1 (Manhattan) distance n of where they
 // started.  TraceParams::cell_distance holds, per cell, its L1 distance in cells to the nearest occupied cell (0 = occupied, capped
@@ -714,6 +762,8 @@ VRT_DI uint32_t halfblock_word(const HalfBlockConsts &hb, uint32_t index) {
 #undef VRT_PARK_WALK_ASM
 #undef VRT_PARK_WALK_ASM_S
 #undef VRT_PARK_WALK_ASM_T
+#undef VRT_PARK_WALK_ASM_W
+#undef VRT_WORD_MOV32
 #undef VRT_PARK_WALK_OPERANDS
 #undef VRT_PARK_WALK_INPUTS
 // ---- the park loop pipelined TWO trips ahead (vrt_path_kernel<AHEAD>) ---------------------------------------------------------
@@ -2174,9 +2224,21 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
     [[maybe_unused]] uint32_t flip = 0u; // DIL, per lane: the field masks of the axes the ray walks down (index ^ flip = the real dilated index)
     auto status_word = [&](uint32_t index) {
         if constexpr (DIST) return (uint32_t)p.cell_distance[index];
+        else if constexpr (DIL == 3) return 0u; // (64-bit words: status_word64)
         else if constexpr (DIL) return p.status_halfblocks[(index ^ flip) >> 5];
         else return halfblocks ? p.status_halfblocks[halfblock_word(hb, index)] : p.brick_status[index >> 5];
     };
+    [[maybe_unused]] unsigned long long word64 = 0ull; // DIL 3: the lane's 4 x 4 x 4-cell word
+    auto status_word64 = [&](uint32_t index) { return reinterpret_cast<const unsigned long long *>(p.status_blocks)[(index ^ flip) >> 6]; };
+    [[maybe_unused]] u32x4 blk_rsrc;
+    if constexpr (DIL == 3) {
+        auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+        const unsigned long long a = (unsigned long long)p.status_blocks;
+        blk_rsrc.x = uni((uint32_t)a);
+        blk_rsrc.y = uni((uint32_t)(a >> 32) | (8u << 16)); // stride 8: one record per block word
+        blk_rsrc.z = uni(p.nbx * p.nby * p.nbz);
+        blk_rsrc.w = 0x00020000u;
+    }
     [[maybe_unused]] DistRegs dr{0ull, 0};
     [[maybe_unused]] bool fresh_word = false; // DIST: the lane's word was loaded outside the walk loop since the last call
 
@@ -2443,9 +2505,12 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                                            cz = (uint32_t)(base_z - __mul24(s.sz, w.rz));
                             const uint32_t mx = s.sx < 0 ? ((uint32_t)dx - 1u - cx) : cx, my = s.sy < 0 ? ((uint32_t)dy - 1u - cy) : cy,
                                            mz = s.sz < 0 ? ((uint32_t)dz - 1u - cz) : cz;
-                            const uint32_t fx = 3u | (((1u << (lx - 2u)) - 1u) << 5), fz = (3u << 2) | (((1u << (lz - 2u)) - 1u) << (lx + 3u)),
-                                           fy = (1u << 4) | (((1u << (ly - 1u)) - 1u) << (lx + lz + 1u));
-                            grid_index = (mx & 3u) | ((mz & 3u) << 2) | ((my & 1u) << 4) | ((mx >> 2) << 5) | ((mz >> 2) << (lx + 3u)) | ((my >> 1) << (lx + lz + 1u));
+                            // (DIL 3: 4 x 4 x 4-cell words: two y bits among the low six, and everything above one bit higher)
+                            constexpr uint32_t yb = DIL == 3 ? 2u : 1u, lo = 4u + yb;
+                            const uint32_t fx = 3u | (((1u << (lx - 2u)) - 1u) << lo), fz = (3u << 2) | (((1u << (lz - 2u)) - 1u) << (lx + lo - 2u)),
+                                           fy = (((1u << yb) - 1u) << 4) | (((1u << (ly - yb)) - 1u) << (lx + lz + lo - 4u));
+                            grid_index = (mx & 3u) | ((mz & 3u) << 2) | ((my & ((1u << yb) - 1u)) << 4) | ((mx >> 2) << lo) | ((mz >> 2) << (lx + lo - 2u)) |
+                                         ((my >> yb) << (lx + lz + lo - 4u));
                             flip = (s.sx < 0 ? fx : 0u) | (s.sy < 0 ? fy : 0u) | (s.sz < 0 ? fz : 0u);
                             stride_x = s.sx != 0 ? ~fx : ~0u, stride_y = s.sy != 0 ? ~fy : ~0u, stride_z = s.sz != 0 ? ~fz : ~0u;
                         }
@@ -2466,7 +2531,8 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                             ring.q2 = (min3i(w.rx, w.ry, w.rz) < 0) ? ~0u : grid_index; // (the step left the box: the sentinel)
                             ring.w2 = (ring.q2 != ~0u) ? p.brick_status[ring.q2 >> 5] : 0u;
                         } else {
-                            word = status_word(grid_index);
+                            if constexpr (DIL == 3) word64 = status_word64(grid_index);
+                            else word = status_word(grid_index);
                             fresh_word = true;
                         }
                         g.t_out = skip_t;
@@ -2521,7 +2587,7 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
         // (FILTER: five trips per call, the way through a block of four cells; then the blocks are looked up again)
         g.min_alive = FILTER ? 65u : (n_walking >= fin ? n_walking - fin + 1u : 1u);
         uint32_t cell; // the occupied cell each parked lane stood on before its last step
-        [[maybe_unused]] unsigned long long gone = 0ull; // DIL 2: the parked lanes whose step out of that cell left the grid
+        [[maybe_unused]] unsigned long long gone = 0ull; // DIL 2, 3: the parked lanes whose step out of that cell left the grid
         if constexpr (AHEAD) {
             AheadWalkRegs ga;
             ga.alive = g.alive;
@@ -2531,6 +2597,8 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
             g.alive = ga.alive;
             g.parked = ga.parked;
             cell = ring.q0;
+        } else if constexpr (DIL == 3) {
+            grid_walk_park_dilated64_gfx950(w.side_dist, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word64, blk_rsrc, g, flip, gone);
         } else if constexpr (DIL == 2) {
             grid_walk_park_dilated_carry_gfx950(w.side_dist, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, flip, gone);
         } else if constexpr (DIL == 1) {
@@ -2570,11 +2638,12 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                 const int rx = w.rx + (out == 0u ? 1 : 0) + (out2 == 0u ? 1 : 0), ry = w.ry + (out == 1u ? 1 : 0) + (out2 == 1u ? 1 : 0),
                           rz = w.rz + (out == 2u ? 1 : 0) + (out2 == 2u ? 1 : 0);
                 int cx = base_x - __mul24(s.sx, rx), cy = base_y - __mul24(s.sy, ry), cz = base_z - __mul24(s.sz, rz); // cell position
-                if constexpr (DIL == 2) { // (no counters: the position is the loop's own index, un-mirrored and un-dilated)
+                if constexpr (DIL >= 2) { // (no counters: the position is the loop's own index, un-mirrored and un-dilated)
+                    constexpr uint32_t yb = DIL == 3 ? 2u : 1u, lo = 4u + yb;
                     const uint32_t real = cell ^ flip, lx = hb.lx, lz = hb.lxz - hb.lx;
-                    cx = (int)((real & 3u) | ((real >> 3) & (((1u << (lx - 2u)) - 1u) << 2)));
-                    cz = (int)(((real >> 2) & 3u) | ((real >> (lx + 1u)) & (((1u << (lz - 2u)) - 1u) << 2)));
-                    cy = (int)(((real >> 4) & 1u) | ((real >> (lx + lz + 1u)) << 1));
+                    cx = (int)((real & 3u) | ((real >> (lo - 2u)) & (((1u << (lx - 2u)) - 1u) << 2)));
+                    cz = (int)(((real >> 2) & 3u) | ((real >> (lx + lo - 4u)) & (((1u << (lz - 2u)) - 1u) << 2)));
+                    cy = (int)(((real >> 4) & ((1u << yb) - 1u)) | ((real >> (lx + lz + lo - 4u)) << yb));
                 }
                 if constexpr (DIL) cell = (uint32_t)cx + (uint32_t)dx * ((uint32_t)cz + (uint32_t)dz * (uint32_t)cy); // (the loop's index is dilated)
                 const uint32_t occ_slot = by_cell ? cell : p.brick_index[cell]; // comp:337 (by_cell: only on a solid voxel)
@@ -2594,11 +2663,12 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                 if (hit_voxel) {
                     found = true;
                     st = kLaneDone;
-                } else if (!(global_t_value <= t_max) || (DIL == 2 ? __builtin_amdgcn_inverse_ballot_w64(gone) : (!AHEAD && min3i(w.rx, w.ry, w.rz) < 0))) {
+                } else if (!(global_t_value <= t_max) || (DIL >= 2 ? __builtin_amdgcn_inverse_ballot_w64(gone) : (!AHEAD && min3i(w.rx, w.ry, w.rz) < 0))) {
                     found = false; // t became NaN (comp:316), or the step out of this cell left the box
                     st = kLaneDone;
                 } else if constexpr (!AHEAD) {
-                    word = status_word(grid_index); // (an A-trip park left the lane's word in the other register set)
+                    if constexpr (DIL == 3) word64 = status_word64(grid_index);
+                    else word = status_word(grid_index); // (an A-trip park left the lane's word in the other register set)
                     fresh_word = true;
                 }   // (AHEAD: the lane walks on as it is; a step that left the box has put the sentinel into its ring)
             }
