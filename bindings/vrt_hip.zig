@@ -197,6 +197,7 @@ pub const TUNE_PATH_DISTANCE: u32 = 1 << 8;
 pub const TUNE_NO_PATH_DILATED: u32 = 1 << 9;
 pub const TUNE_NO_PATH_GRID_EXIT: u32 = 1 << 10;
 pub const TUNE_PATH_BLOCKS64: u32 = 1 << 11;
+pub const TUNE_PATH_TWO_AHEAD: u32 = 1 << 12;
 
 pub const GridConfig = extern struct { // Grid.zig:13-20
     brick_alloc: u64 = 0,

@@ -308,8 +308,9 @@ def test_path_kernel_memory_layouts_change_no_pixel():
         for flags in (L.TUNE_PATH_AHEAD, L.TUNE_PATH_AHEAD | L.TUNE_NO_CELL_OCCUPANCY | L.TUNE_NO_PATH_BRICK_LDS | L.TUNE_NO_SKIP_TO_BOX):
             for v, a, b in zip(views, base, _frames_with_flags(w, views, flags, kernel_variant=path, library=dev_library_or_none())):
                 assert np.array_equal(a, b), ("two trips ahead", flags, v)
-    if dev_library_or_none():  # the distance-field walk and the 4 x 4 x 4-cell words live in the development build
-        for flags in (L.TUNE_PATH_BLOCKS64, L.TUNE_PATH_BLOCKS64 | L.TUNE_NO_SKIP_TO_BOX | L.TUNE_NO_CELL_OCCUPANCY,
+    if dev_library_or_none():  # the two-cells-ahead dilated walk, the 4 x 4 x 4-cell words and the distance-field walk live in the development build
+        for flags in (L.TUNE_PATH_TWO_AHEAD, L.TUNE_PATH_TWO_AHEAD | L.TUNE_NO_SKIP_TO_BOX | L.TUNE_NO_PATH_BRICK_LDS,
+                      L.TUNE_PATH_BLOCKS64, L.TUNE_PATH_BLOCKS64 | L.TUNE_NO_SKIP_TO_BOX | L.TUNE_NO_CELL_OCCUPANCY,
                       L.TUNE_PATH_DISTANCE, L.TUNE_PATH_DISTANCE | L.TUNE_NO_SKIP_TO_BOX | L.TUNE_NO_PATH_BRICK_LDS):
             for v, a, b in zip(views, base, _frames_with_flags(w, views, flags, kernel_variant=path, library=dev_library_or_none())):
                 assert np.array_equal(a, b), ("distance field", flags, v)

@@ -484,6 +484,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         return fail(nullptr, VRT_E_INVALID_ARG, "VRT_TUNE_PATH_AHEAD selects a development kernel: not in the product build of libvrt_hip (make dev)");
     if (cfg->tuning_flags & VRT_TUNE_PATH_DISTANCE)
         return fail(nullptr, VRT_E_INVALID_ARG, "VRT_TUNE_PATH_DISTANCE selects a development kernel: not in the product build of libvrt_hip (make dev)");
+    if (cfg->tuning_flags & VRT_TUNE_PATH_TWO_AHEAD)
+        return fail(nullptr, VRT_E_INVALID_ARG, "VRT_TUNE_PATH_TWO_AHEAD selects a development kernel: not in the product build of libvrt_hip (make dev)");
     if (cfg->tuning_flags & VRT_TUNE_PATH_BLOCKS64)
         return fail(nullptr, VRT_E_INVALID_ARG, "VRT_TUNE_PATH_BLOCKS64 selects a development kernel: not in the product build of libvrt_hip (make dev)");
 #endif
@@ -778,7 +780,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     select_all();
     if (!(cfg->tuning_flags & VRT_TUNE_NO_PATH_GRID_EXIT)) {
         // (chosen per dispatch, once the host knows the box of the occupied cells: pre_dispatch)
-        const int kind = ((cfg->tuning_flags & VRT_TUNE_PATH_BLOCKS64) && cfg->dim_y % 4u == 0u) ? 3 : 2;
+        const int kind = ((cfg->tuning_flags & VRT_TUNE_PATH_BLOCKS64) && cfg->dim_y % 4u == 0u) ? 3 : ((cfg->tuning_flags & VRT_TUNE_PATH_TWO_AHEAD) ? 4 : 2);
         if (vrt::path_kernel_dilated_kind(c->kernel) == 1) c->kernel_grid_exit = vrt::path_kernel_dilated_twin(c->kernel, kind);
         if (c->product[0] && vrt::path_kernel_dilated_kind(c->product[0]) == 1) c->product_grid_exit = vrt::path_kernel_dilated_twin(c->product[0], kind);
         if (c->kernel_grid_exit == c->kernel) c->kernel_grid_exit = nullptr;

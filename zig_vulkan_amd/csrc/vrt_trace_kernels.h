@@ -666,6 +666,161 @@ VRT_DI void grid_walk_park_dilated_carry_gfx950(f3 &side_dist, const f3 &inv_dir
 #undef VRT_LOAD_DILATED_A
 #undef VRT_LOAD_DILATED_B
 #undef VRT_TEST_DILATED
+// ---- the counter-free dilated loop with the DDA TWO cells ahead of the test (vrt_path_kernel<..., DIL 4>, round 3) -----------------
+// The trip of the loops above lasts as long as the round trip of its one request plus the instructions between a word's arrival and
+// the next request: the word of the cell entered in trip k is tested in trip k + 1.  Here it is tested in trip k + 2 —
+// two requests in flight per lane — and the round trip leaves the chain.  Three register sets (x, y, z: cell, word, crossed
+// distance, crossed-axis masks, carry, keep mask) are used in turn, so nothing rotates inside the loop:
+//   trip k (sets K = k % 3, N = next, J = previous):  step c_k -> c_k+1 (idxN), request word(c_k+1) -> wN by the lanes that enter
+//   another half-block (the others, kpN, take it from wK one trip later: a register with a request in flight cannot be read),
+//   advance the side distance; wait until at most two requests are outstanding (word(c_k-1) has arrived); wK <- wJ for kpK;
+//   test c_k-1 in wJ; lanes whose step k - 1 left the grid (cyJ) have now had their last cell tested and leave.
+// Between calls, and for parked lanes, the state is the ONE-ahead loops' (the caller cannot tell the difference): whoever leaves
+// the loop after trip k — parked on c_k-1, or still moving when the call ends — takes step k back (the crossed axis' side distance
+// := the crossed distance of trip k, which IS its old value; the cell := c_k; the carry of that step is forgotten), and a call
+// starts with a trip that tests nothing.  One trip per lane per call and per brick entered is walked twice (about 7 % of the trips
+// of the 2048^3 path trace); per lane the sequence of DDA operations is unchanged.
+#define VRT_A2_HEAD(K, N)                                                                                   \
+    "v_min3_f32 %[ts" K "], %[sdx], %[sdy], %[sdz]\n\t"                                                     \
+    "v_cmp_eq_f32_e64 %[mt], %[sdz], %[ts" K "]\n\t"                                                        \
+    "v_cmp_eq_f32_e64 %[mY" K "], %[sdy], %[ts" K "]\n\t"                                                   \
+    "s_andn2_b64 %[mY" K "], %[mY" K "], %[mt]\n\t"                                                         \
+    "s_andn2_b64 %[mt], exec, %[mt]\n\t"                                                                    \
+    "s_andn2_b64 %[mX" K "], %[mt], %[mY" K "]\n\t"                                                         \
+    "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[mY" K "]\n\t"                                               \
+    "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[mX" K "]\n\t"                                                \
+    "v_or_b32_e32 %[t1], %[idx" K "], %[t0]\n\t"                                                            \
+    "v_add_co_u32_e64 %[t1], %[cy" K "], 1, %[t1]\n\t"                                                      \
+    "v_bfi_b32 %[idx" N "], %[t0], %[idx" K "], %[t1]\n\t"                                                  \
+    "v_xor_b32_e32 %[t2], %[idx" N "], %[idx" K "]\n\t"                                                     \
+    "v_cmp_lt_u32_e64 %[by], 31, %[t2]\n\t"                                                                 \
+    "s_cmp_eq_u64 %[by], 0\n\t"                                                                             \
+    "s_cselect_b64 %[by], exec, %[by]\n\t"                                                                  \
+    "s_and_saveexec_b64 %[cz], %[by]\n\t"                                                                   \
+    "v_xor_b32_e32 %[t2], %[idx" N "], %[flip]\n\t"                                                         \
+    "v_lshrrev_b32_e32 %[t2], 5, %[t2]\n\t"                                                                 \
+    "buffer_load_dword %[w" N "], %[t2], %[rsrc], 0 idxen\n\t"                                              \
+    "s_andn2_b64 %[kp" N "], %[cz], %[by]\n\t"                                                              \
+    "s_mov_b64 exec, %[mX" K "]\n\t"                                                                        \
+    "v_add_f32_e64 %[sdx], %[sdx], |%[ix]|\n\t"                                                             \
+    "s_mov_b64 exec, %[mY" K "]\n\t"                                                                        \
+    "v_add_f32_e64 %[sdy], %[sdy], |%[iy]|\n\t"                                                             \
+    "s_andn2_b64 exec, %[cz], %[mt]\n\t"                                                                    \
+    "v_add_f32_e64 %[sdz], %[sdz], |%[iz]|\n\t"
+#define VRT_A2_TAIL(K, J, PARK)                                                                             \
+    "s_and_b64 exec, %[cz], %[kp" K "]\n\t"                                                                 \
+    "s_waitcnt vmcnt(2)\n\t"                                                                                \
+    "v_mov_b32_e32 %[w" K "], %[w" J "]\n\t"                                                                \
+    "s_mov_b64 exec, %[cz]\n\t"                                                                             \
+    "v_xor_b32_e32 %[t1], %[idx" J "], %[flip]\n\t"                                                         \
+    "v_bfe_u32 %[t1], %[w" J "], %[t1], 1\n\t"                                                              \
+    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"                                                                    \
+    "s_andn2_b64 exec, exec, %[cy" J "]\n\t"                                                                \
+    "s_cbranch_vccnz " PARK "\n\t"
+// take step K back for the lanes in MASK (a scalar pair; clobbers by, EXEC)
+#define VRT_A2_UNSTEP(K, MASK)                                                                              \
+    "s_and_b64 exec, " MASK ", %[mX" K "]\n\t"                                                              \
+    "v_mov_b32_e32 %[sdx], %[ts" K "]\n\t"                                                                  \
+    "s_and_b64 exec, " MASK ", %[mY" K "]\n\t"                                                              \
+    "v_mov_b32_e32 %[sdy], %[ts" K "]\n\t"                                                                  \
+    "s_or_b64 %[by], %[mX" K "], %[mY" K "]\n\t"                                                            \
+    "s_andn2_b64 exec, " MASK ", %[by]\n\t"                                                                 \
+    "v_mov_b32_e32 %[sdz], %[ts" K "]\n\t"
+// the lanes in vcc have their cell c_k-1 occupied: the one-ahead loops' parked state (see GridParkRegs), step k taken back
+#define VRT_A2_PARK(LABEL, K, J, INAXIS, TSIN, MOVIDX, NEXT, EXIT)                                          \
+    LABEL ":\n\t"                                                                                           \
+    "s_and_b64 %[by], %[cy" J "], vcc\n\t"                                                                  \
+    "s_or_b64 %[gone], %[gone], %[by]\n\t"                                                                  \
+    "s_mov_b64 %[ex], exec\n\t"                                                                             \
+    "s_mov_b64 exec, vcc\n\t"                                                                               \
+    INAXIS                                                                                                  \
+    "v_cndmask_b32_e64 %[t1], 2, 1, %[mY" J "]\n\t"                                                         \
+    "v_cndmask_b32_e64 %[t1], %[t1], 0, %[mX" J "]\n\t"                                                     \
+    "v_lshl_or_b32 %[code], %[t1], 2, %[t0]\n\t"                                                            \
+    "v_mov_b32_e32 %[cell], %[idx" J "]\n\t"                                                                \
+    MOVIDX                                                                                                  \
+    "v_mov_b32_e32 %[tin], " TSIN "\n\t"                                                                    \
+    "v_mov_b32_e32 %[tout], %[ts" J "]\n\t"                                                                 \
+    VRT_A2_UNSTEP(K, "vcc")                                                                                 \
+    "s_or_b64 %[parked], %[parked], vcc\n\t"                                                                \
+    "s_andn2_b64 exec, %[ex], vcc\n\t"                                                                      \
+    "s_bcnt1_i32_b64 %[n], %[parked]\n\t"                                                                   \
+    "s_cmp_ge_u32 %[n], %[batch]\n\t"                                                                       \
+    "s_cbranch_scc1 " EXIT "\n\t"                                                                           \
+    "s_cbranch_execnz " NEXT "\n\t"                                                                         \
+    "s_branch " EXIT "\n\t"
+#define VRT_A2_IN_CODE "v_bfe_u32 %[t0], %[code], 4, 2\n\t"
+#define VRT_A2_IN_SET(I) "v_cndmask_b32_e64 %[t0], 2, 1, %[mY" I "]\n\t" "v_cndmask_b32_e64 %[t0], %[t0], 0, %[mX" I "]\n\t"
+// the call ends after trip K with the lanes in EXEC still moving: step k back, their cell, its word and their last step where the caller looks for them
+#define VRT_A2_EXIT(LABEL, K, J, MOVIDX)                                                                    \
+    LABEL ":\n\t"                                                                                           \
+    "s_mov_b64 %[alive], exec\n\t"                                                                          \
+    "s_waitcnt vmcnt(0)\n\t"                                                                                \
+    VRT_A2_UNSTEP(K, "%[alive]")                                                                            \
+    "s_mov_b64 exec, %[alive]\n\t"                                                                          \
+    MOVIDX                                                                                                  \
+    "v_mov_b32_e32 %[tout], %[ts" J "]\n\t"                                                                 \
+    "s_mov_b64 %[mxb], %[mX" J "]\n\t"                                                                      \
+    "s_mov_b64 %[myb], %[mY" J "]\n\t"                                                                      \
+    "s_branch 99f\n\t"
+VRT_DI void grid_walk_park_dilated_ahead_gfx950(f3 &side_dist, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t nm_x, uint32_t nm_y, uint32_t nm_z,
+                                                uint32_t &word, u32x4 rsrc, GridParkRegs &g, uint32_t flip, unsigned long long &gone) {
+    unsigned long long mXx, mYx, mXy, mYy, mXz, mYz, cyx, cyy, cyz, kpx, kpy, kpz, mt, ex, by, cz, save;
+    float tsx, tsy, tsz, t0, t1, t2;
+    uint32_t idxy, idxz, wy, wz, n;
+    gone = 0ull;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "s_mov_b64 exec, %[alive]\n\t"
+        "s_mov_b64 %[parked], 0\n\t"
+        "s_mov_b64 %[kpx], 0\n\t"
+        /* trip 0: nothing to test yet */
+        VRT_A2_HEAD("x", "y")
+        "s_mov_b64 exec, %[cz]\n\t"
+        /* trip 1: tests c_0 (its word came with the call; it was entered by the lane's last step before the call: code, tout) */
+        VRT_A2_HEAD("y", "z")
+        VRT_A2_TAIL("y", "x", "10f")
+        "0:\n\t"
+        VRT_A2_HEAD("z", "x")
+        VRT_A2_TAIL("z", "y", "11f")
+        "21:\n\t"
+        VRT_A2_HEAD("x", "y")
+        VRT_A2_TAIL("x", "z", "12f")
+        "22:\n\t"
+        VRT_A2_HEAD("y", "z")
+        VRT_A2_TAIL("y", "x", "13f")
+        "23:\n\t"
+        "s_cbranch_execz 31f\n\t"
+        "s_bcnt1_i32_b64 %[n], exec\n\t"
+        "s_cmp_ge_u32 %[n], %[minalive]\n\t"
+        "s_cbranch_scc1 0b\n\t"
+        "s_branch 31f\n\t"
+        VRT_A2_PARK("10", "y", "x", VRT_A2_IN_CODE, "%[tout]", "v_mov_b32_e32 %[idxx], %[idxy]\n\t", "0b", "31f")
+        VRT_A2_PARK("11", "z", "y", VRT_A2_IN_SET("x"), "%[tsx]", "v_mov_b32_e32 %[idxx], %[idxz]\n\t", "21b", "32f")
+        VRT_A2_PARK("12", "x", "z", VRT_A2_IN_SET("y"), "%[tsy]", "", "22b", "30f")
+        VRT_A2_PARK("13", "y", "x", VRT_A2_IN_SET("z"), "%[tsz]", "v_mov_b32_e32 %[idxx], %[idxy]\n\t", "23b", "31f")
+        VRT_A2_EXIT("30", "x", "z", "")
+        VRT_A2_EXIT("31", "y", "x", "v_mov_b32_e32 %[idxx], %[idxy]\n\t" "v_mov_b32_e32 %[wx], %[wy]\n\t")
+        VRT_A2_EXIT("32", "z", "y", "v_mov_b32_e32 %[idxx], %[idxz]\n\t" "v_mov_b32_e32 %[wx], %[wz]\n\t")
+        "99:\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [sdx] "+v"(side_dist.x), [sdy] "+v"(side_dist.y), [sdz] "+v"(side_dist.z), [idxx] "+v"(index), [idxy] "=&v"(idxy), [idxz] "=&v"(idxz),
+          [cell] "=&v"(cell), [wx] "+v"(word), [wy] "=&v"(wy), [wz] "=&v"(wz), [tsx] "=&v"(tsx), [tsy] "=&v"(tsy), [tsz] "=&v"(tsz), [tout] "+v"(g.t_out),
+          [tin] "=&v"(g.t_in), [code] "+v"(g.code), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y),
+          [alive] "+s"(g.alive), [mXx] "=&s"(mXx), [mYx] "=&s"(mYx), [mXy] "=&s"(mXy), [mYy] "=&s"(mYy), [mXz] "=&s"(mXz), [mYz] "=&s"(mYz), [cyx] "=&s"(cyx),
+          [cyy] "=&s"(cyy), [cyz] "=&s"(cyz), [kpx] "=&s"(kpx), [kpy] "=&s"(kpy), [kpz] "=&s"(kpz), [mt] "=&s"(mt), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz),
+          [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n), [gone] "+s"(gone)
+        : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(nm_x), [sty] "v"(nm_y), [stz] "v"(nm_z), [rsrc] "s"(rsrc), [batch] "s"(g.batch),
+          [minalive] "s"(g.min_alive), [flip] "v"(flip)
+        : "vcc", "scc");
+}
+#undef VRT_A2_HEAD
+#undef VRT_A2_TAIL
+#undef VRT_A2_UNSTEP
+#undef VRT_A2_PARK
+#undef VRT_A2_IN_CODE
+#undef VRT_A2_IN_SET
+#undef VRT_A2_EXIT
 // The counter-free dilated loop on 4 x 4 x 4-CELL words (vrt_path_kernel<..., DIL 3>): the 64-bit words of TraceParams::status_blocks,
 // index bits 0-5 = the cell's place in its block (x&3 | (z&3) << 2 | (y&3) << 4), the bits above = the block's number.  A lane asks
 // when its step enters another block: 0.265 times per trip in the 2048^3 sparse field against 0.333 for half-blocks
@@ -2138,7 +2293,8 @@ enum : int { kLaneFetch = 0, kLaneSample, kLaneStart, kLaneWalk, kLaneDone, kLan
 // DIST (round 3): the walk loop on the L1 distance field of the occupied cells (grid_walk_park_dist_gfx950).
 // DIL (round 3): the half-block walk loop on a dilated cell index (all three dimensions powers of two): 1 = with the steps-left
 // counters (grid_walk_park_dilated_gfx950: the walk ends at the box of the occupied cells), 2 = without them
-// (grid_walk_park_dilated_carry_gfx950: the walk ends at the grid's face; chosen when the box is, or nearly is, the grid).
+// (grid_walk_park_dilated_carry_gfx950: the walk ends at the grid's face; chosen when the box is, or nearly is, the grid);
+// 3 = 2 on 4 x 4 x 4-cell words (development); 4 = 2 with the DDA two cells ahead of the test (grid_walk_park_dilated_ahead_gfx950).
 template <int B, int MIN_WAVES, bool FILTER, bool HALF = false, bool AHEAD = false, bool DIST = false, int DIL = 0>
 __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN_WAVES) void vrt_path_kernel(const TraceParams p) {
     static_assert(!AHEAD || (!HALF && !FILTER), "the two-trips-ahead loop reads the linear status words");
@@ -2597,6 +2753,8 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
             g.alive = ga.alive;
             g.parked = ga.parked;
             cell = ring.q0;
+        } else if constexpr (DIL == 4) {
+            grid_walk_park_dilated_ahead_gfx950(w.side_dist, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, flip, gone);
         } else if constexpr (DIL == 3) {
             grid_walk_park_dilated64_gfx950(w.side_dist, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word64, blk_rsrc, g, flip, gone);
         } else if constexpr (DIL == 2) {
