@@ -616,9 +616,9 @@ VRT_DI void grid_walk_park_halfblocks_gfx950(Walk &w, const f3 &inv_dir, uint32_
     "v_cmp_lt_u32_e64 %[by], 31, %[t2]\n\t"                                \
     "s_cmp_eq_u64 %[by], 0\n\t"                                            \
     "s_cselect_b64 %[by], exec, %[by]\n\t"                                 \
+    "v_xor_b32_e32 %[r" IDXN "], %[" IDXN "], %[flip]\n\t" /* the real index: kept for the test a trip later */ \
     "s_and_saveexec_b64 %[cz], %[by]\n\t" /* cz: the trip's lanes, until LOADB */ \
-    "v_xor_b32_e32 %[t2], %[" IDXN "], %[flip]\n\t"                        \
-    "v_lshrrev_b32_e32 %[t2], 5, %[t2]\n\t"                                \
+    "v_lshrrev_b32_e32 %[t2], 5, %[r" IDXN "]\n\t"                         \
     "buffer_load_dword %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"
 #define VRT_LOAD_DILATED_B(IDX, IDXN, WORD, WORDN)                          \
     "s_andn2_b64 exec, %[cz], %[by]\n\t"                                   \
@@ -626,8 +626,7 @@ VRT_DI void grid_walk_park_halfblocks_gfx950(Walk &w, const f3 &inv_dir, uint32_
     "v_mov_b32_e32 %[" WORDN "], %[" WORD "]\n\t"                          \
     "s_mov_b64 exec, %[cz]\n\t"
 #define VRT_TEST_DILATED(WORD, IDX)                                        \
-    "v_xor_b32_e32 %[t1], %[" IDX "], %[flip]\n\t"                         \
-    "v_bfe_u32 %[t1], %[" WORD "], %[t1], 1\n\t"                           \
+    "v_bfe_u32 %[t1], %[" WORD "], %[r" IDX "], 1\n\t"                     \
     "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"
 // nm_x / nm_y / nm_z: per lane, the complement of the axis' field mask (all ones for an axis with ray_step == 0)
 VRT_DI void grid_walk_park_dilated_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t nm_x, uint32_t nm_y, uint32_t nm_z,
@@ -636,8 +635,10 @@ VRT_DI void grid_walk_park_dilated_gfx950(Walk &w, const f3 &inv_dir, uint32_t &
     float t0, t1, t2;
     uint32_t wordb, n;
     const uint32_t stride_x = nm_x, stride_y = nm_y, stride_z = nm_z; // (the operand list's names)
-    asm volatile(VRT_PARK_WALK_ASM_T(VRT_TRIP_E, VRT_STEP_DILATED, VRT_EXIT_COUNTERS, "", VRT_NO_LIMIT, VRT_LOAD_DILATED, VRT_TEST_DILATED, VRT_WAIT_BUFFER, "")
-                 : VRT_PARK_WALK_OPERANDS
+    uint32_t ridxa, ridxb; // (the real — un-mirrored — indices of the two cells in flight)
+    asm volatile("v_xor_b32_e32 %[ridxa], %[idxa], %[flip]\n\t"
+                 VRT_PARK_WALK_ASM_T(VRT_TRIP_E, VRT_STEP_DILATED, VRT_EXIT_COUNTERS, "", VRT_NO_LIMIT, VRT_LOAD_DILATED, VRT_TEST_DILATED, VRT_WAIT_BUFFER, "")
+                 : VRT_PARK_WALK_OPERANDS, [ridxa] "=&v"(ridxa), [ridxb] "=&v"(ridxb)
                  : VRT_PARK_WALK_INPUTS, [flip] "v"(flip)
                  : "vcc", "scc");
 }
@@ -654,12 +655,15 @@ VRT_DI void grid_walk_park_dilated_carry_gfx950(f3 &side_dist, const f3 &inv_dir
     uint32_t wordb, n;
     const uint32_t stride_x = nm_x, stride_y = nm_y, stride_z = nm_z; // (the operand list's names)
     gone = 0ull;
-    asm volatile(VRT_PARK_WALK_ASM_T(VRT_TRIP_E, VRT_STEP_DILATED_CARRY, VRT_EXIT_CARRY, "s_and_b64 %[by], %[ex], vcc\n\ts_or_b64 %[gone], %[gone], %[by]\n\t",
+    uint32_t ridxa, ridxb; // (the real — un-mirrored — indices of the two cells in flight)
+    asm volatile("v_xor_b32_e32 %[ridxa], %[idxa], %[flip]\n\t"
+                 VRT_PARK_WALK_ASM_T(VRT_TRIP_E, VRT_STEP_DILATED_CARRY, VRT_EXIT_CARRY, "s_and_b64 %[by], %[ex], vcc\n\ts_or_b64 %[gone], %[gone], %[by]\n\t",
                                      VRT_NO_LIMIT, VRT_LOAD_DILATED, VRT_TEST_DILATED, VRT_WAIT_BUFFER, "")
                  : [sdx] "+v"(side_dist.x), [sdy] "+v"(side_dist.y), [sdz] "+v"(side_dist.z), [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(word),
                    [wordb] "=&v"(wordb), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in), [code] "+v"(g.code), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
                    [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive), [mxa] "=&s"(mxa), [mya] "=&s"(mya), [mxya] "=&s"(mxya), [mxyb] "=&s"(mxyb),
-                   [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz), [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n), [gone] "+s"(gone)
+                   [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz), [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n), [gone] "+s"(gone),
+                   [ridxa] "=&v"(ridxa), [ridxb] "=&v"(ridxb)
                  : VRT_PARK_WALK_INPUTS, [flip] "v"(flip)
                  : "vcc", "scc");
 }
