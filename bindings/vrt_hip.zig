@@ -291,6 +291,7 @@ pub extern fn vrt_denoise(ctx: ?*Ctx, cfg: [*c]const DenoiseConfig, out_w: u32, 
 pub extern fn vrt_read_denoised_rgba8(ctx: ?*Ctx, dst: ?*anyopaque, nbytes: u64) c_int;
 pub extern fn vrt_read_denoised_rgba32f(ctx: ?*Ctx, dst: ?*anyopaque, nbytes: u64) c_int;
 pub extern fn vrt_device_denoised_rgba8(ctx: ?*Ctx) ?*anyopaque;
+pub extern fn vrt_last_denoise_ms(ctx: ?*Ctx) f64;
 pub extern fn vrt_vox_validate_header(buffer: ?*const anyopaque, nbytes: u64) c_int;
 pub extern fn vrt_vox_parse(buffer: ?*const anyopaque, nbytes: u64, strict: c_int, out: *?*Vox) c_int;
 pub extern fn vrt_vox_destroy(v: ?*Vox) void;

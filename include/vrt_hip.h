@@ -412,6 +412,9 @@ int vrt_denoise(vrt_ctx *ctx, const vrt_denoise_config *cfg /* NULL => reference
 int vrt_read_denoised_rgba8(vrt_ctx *ctx, void *dst, uint64_t nbytes);
 int vrt_read_denoised_rgba32f(vrt_ctx *ctx, void *dst, uint64_t nbytes);
 void *vrt_device_denoised_rgba8(vrt_ctx *ctx);
+/* hipEvent time of the most recent vrt_denoise launch in milliseconds (waits for it); <0 if none was issued.  With
+ * vrt_last_kernel_ms this is the app's whole frame: trace (ComputePipeline.zig:417-463) + present (GraphicsPipeline.zig:27-39). */
+double vrt_last_denoise_ms(vrt_ctx *ctx);
 
 /* ---- MagicaVoxel .vox input --------------------------------------------
  * Host-side parser with the reference's semantics (src/modules/voxel_rt/vox/loader.zig:41-229,

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """The reference's own benchmark protocol on the HIP path: the scripted 60 s fly-through of
-src/modules/voxel_rt/Benchmark.zig replayed at a fixed simulated frame rate; reports the
+src/modules/voxel_rt/Benchmark.zig:141-172 replayed at a fixed simulated frame rate; reports the
 min / max / avg frame time like Benchmark.Report.print (Benchmark.zig:109-136), from HIP events.
+A frame of the app is the trace (ComputePipeline.zig:417-463) followed by the present / denoise pass at the
+window resolution (image.frag:18-78, GraphicsPipeline.zig:27-39; Pipeline.draw, Pipeline.zig:432-541): both
+are timed, per frame, and reported apart and summed.
 
-    python tools/flythrough.py [workload] [simulated_fps]
+    python tools/flythrough.py [workload] [simulated_fps] [present_w present_h] [--out profiles/x.json]
 """
 import json
 import os
@@ -12,29 +15,55 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zig_vulkan_amd import workloads as W  # noqa: E402
 
-name = sys.argv[1] if len(sys.argv) > 1 else W.HEADLINE
-fps = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
+argv = [a for a in sys.argv[1:]]
+out_path = None
+if "--out" in argv:
+    i = argv.index("--out")
+    out_path = argv[i + 1]
+    del argv[i:i + 2]
+name = argv[0] if len(argv) > 0 else W.HEADLINE
+fps = float(argv[1]) if len(argv) > 1 else 30.0
 w = W.WORKLOADS[name]
+# the reference presents its 1024x576 internal image in a 1920x1080 window (src/main.zig:23,58-75); other workloads present 1:1
+pw = int(argv[2]) if len(argv) > 3 else (1920 if w.width == 1024 else w.width)
+ph = int(argv[3]) if len(argv) > 3 else (1080 if w.height == 576 else w.height)
 grid = W.build_grid(w)
+
+
+def stats(v):
+    return {"min_ms": min(v), "max_ms": max(v), "avg_ms": sum(v) / len(v)}
+
+
+# pass 1 (counting build, slow): rays per frame along the path
 rt = W.make_renderer(w, grid, enable_counters=True)
 bench = rt.create_benchmark()
-times, rays = [], 0
-done = False
+rays, done = 0, False
 while not done:
     rt.draw()
-    times.append(rt.last_kernel_ms())
     rays += rt.counters()["rays"]
     done = bench.update(1.0 / fps)
 rt.deinit()
-# the counters build is slow; time the same path again without counters
+# pass 2: the same path on the product kernels, trace + present per frame, HIP events around each
 rt = W.make_renderer(w, grid)
 bench = rt.create_benchmark()
-times = []
-done = False
+trace, present, done = [], [], False
 while not done:
     rt.draw()
-    times.append(rt.last_kernel_ms())
+    rt.present(pw, ph)
+    trace.append(rt.last_kernel_ms())
+    present.append(rt.last_denoise_ms())
     done = bench.update(1.0 / fps)
+kernel = rt.kernel_name()
 rt.deinit()
-print(json.dumps({"workload": w.name, "frames": len(times), "simulated_fps": fps, "min_frame_ms": min(times), "max_frame_ms": max(times),
-                  "avg_frame_ms": sum(times) / len(times), "rays": rays, "Mrays_per_s": rays / (sum(times) * 1e-3) / 1e6}))
+frame = [a + b for a, b in zip(trace, present)]
+rec = {"workload": w.name, "protocol": "Benchmark.zig:141-172 scripted path, 60 s at a fixed simulated frame rate; Report = min / max / avg frame ms (Benchmark.zig:109-136)",
+       "frames": len(trace), "simulated_fps": fps, "present_size": [pw, ph], "timing": "hipEventElapsedTime around each launch",
+       "trace": stats(trace), "present": stats(present), "frame_trace_plus_present": stats(frame),
+       "min_frame_ms": min(trace), "max_frame_ms": max(trace), "avg_frame_ms": sum(trace) / len(trace),
+       "rays": rays, "Mrays_per_s_trace": rays / (sum(trace) * 1e-3) / 1e6, "kernel": kernel}
+line = json.dumps(rec)
+print(line)
+if out_path:
+    os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
+    with open(out_path, "w") as f:
+        f.write(line + "\n")

@@ -164,6 +164,7 @@ SIGNATURES = {
     "vrt_read_denoised_rgba8": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
     "vrt_read_denoised_rgba32f": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
     "vrt_device_denoised_rgba8": (C.c_void_p, [_ctx]),
+    "vrt_last_denoise_ms": (C.c_double, [_ctx]),
     "vrt_get_shard_info": (C.c_int, [_ctx, _P(ShardInfo)]),
     "vrt_assemble_frame": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_uint32]),
     "vrt_dist_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),

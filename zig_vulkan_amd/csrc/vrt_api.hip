@@ -201,6 +201,8 @@ struct vrt_ctx {
     bool status_dirty = true;        // brick_status changed since the derived copy was built
     size_t lds_bytes = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_post_start = nullptr, ev_post_stop = nullptr; // around the most recent present / denoise pass (vrt_last_denoise_ms)
+    bool post_timed = false;
     bool in_flight = false;
     bool timing_valid = false;
     uint32_t timed_frames = 0;
@@ -309,6 +311,8 @@ void free_ctx(vrt_ctx *c) {
     }
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->ev_post_start) (void)hipEventDestroy(c->ev_post_start);
+    if (c->ev_post_stop) (void)hipEventDestroy(c->ev_post_stop);
     if (c->stream_b) {
         (void)hipStreamSynchronize(c->stream_b);
         (void)hipStreamDestroy(c->stream_b);
@@ -532,6 +536,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     }
     VRT_CREATE_HIP(hipEventCreate(&c->ev_start));
     VRT_CREATE_HIP(hipEventCreate(&c->ev_stop));
+    VRT_CREATE_HIP(hipEventCreate(&c->ev_post_start));
+    VRT_CREATE_HIP(hipEventCreate(&c->ev_post_stop));
 
     // buffer sizes as Pipeline.zig:273-283 derives them from the State slices
     c->dsize[VRT_BUF_GRID_STATE] = sizeof(vrt_grid_state);
@@ -1304,10 +1310,22 @@ int vrt_denoise(vrt_ctx *ctx, const vrt_denoise_config *cfg, uint32_t out_w, uin
         ctx->denoised_h = out_h;
     }
     const void *img = (ctx->last_slot == 1) ? ctx->target8_b : ctx->target8;
+    VRT_HIP(ctx, hipEventRecord(ctx->ev_post_start, s));
     VRT_HIP(ctx, vrt::launch_denoise(img, (int)ctx->cfg.width, (int)ctx->cfg.height, c.samples, c.distribution_bias, c.pixel_multiplier,
                                      c.inverse_hue_tolerance, (int)out_w, (int)out_h, ctx->d_denoised8, want_float ? ctx->d_denoised32f : nullptr, s));
+    VRT_HIP(ctx, hipEventRecord(ctx->ev_post_stop, s));
+    ctx->post_timed = true;
     ctx->denoised_stream = s;
     return VRT_OK;
+}
+
+double vrt_last_denoise_ms(vrt_ctx *ctx) {
+    if (!ctx || !ctx->post_timed) return -1.0;
+    DeviceGuard dg(ctx->device);
+    if (wait_event(ctx->ev_post_stop) != hipSuccess) return -1.0;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev_post_start, ctx->ev_post_stop) != hipSuccess) return -1.0;
+    return (double)ms;
 }
 
 static int read_denoised(vrt_ctx *ctx, void *dst, uint64_t nbytes, const void *src, uint64_t avail) {

@@ -371,6 +371,15 @@ class VoxelRT:
         self._check(self._lib.vrt_read_denoised_rgba32f(self._h, f32.ctypes.data, f32.nbytes))
         return u8, f32
 
+    def present(self, out_w: int, out_h: int, *, samples: int = 20, distribution_bias: float = 0.6, pixel_multiplier: float = 1.5,
+                inverse_hue_tolerance: float = 20.0) -> None:
+        """The present/denoise pass without the read-back (GraphicsPipeline.zig:27-39 after every trace, Pipeline.zig:432-541)."""
+        dc = L.DenoiseConfig(samples, distribution_bias, pixel_multiplier, inverse_hue_tolerance)
+        self._check(self._lib.vrt_denoise(self._h, C.byref(dc), out_w, out_h, 0))
+
+    def last_denoise_ms(self) -> float:
+        return float(self._lib.vrt_last_denoise_ms(self._h))
+
     def device_target_rgba8(self) -> int:
         return self._lib.vrt_device_target_rgba8(self._h)
 
