@@ -215,6 +215,8 @@ struct vrt_ctx {
     vrt::KernelFn kernel = nullptr;        // frames with bounces: persistent lanes (vrt_path_kernel) unless kernel_variant bit 21
     vrt::KernelFn kernel_lockstep = nullptr; // ... the lockstep bounce loop (always used by the multi-GPU pipeline: RGB shards)
     uint32_t *d_work_counter = nullptr;    // vrt_path_kernel's pixel counters: [2 streams][kMaxBatchFrames]
+    uint32_t *d_pool_paths = nullptr;      // vrt_pool_kernel's path records: [2 streams][pool_groups * 4 waves][16 dwords][128 paths]
+    size_t pool_stream_dwords = 0;
     uint32_t path_lds_bytes = 0;           // LDS block filter of vrt_path_kernel (0: grid not eligible)
     vrt::KernelFn kernel_single = nullptr; // specialisation for max_bounce <= 1
     vrt::KernelFn kernel_single1 = nullptr; // ... and samples_per_pixel == 1
@@ -271,6 +273,7 @@ void free_ctx(vrt_ctx *c) {
     if (c->own_t32 && c->target32f) (void)hipFree(c->target32f);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_work_counter) (void)hipFree(c->d_work_counter);
+    if (c->d_pool_paths) (void)hipFree(c->d_pool_paths);
     if (c->d_status_blocks) (void)hipFree(c->d_status_blocks);
     if (c->d_cell_bounds) (void)hipFree(c->d_cell_bounds);
     if (c->h_cell_bounds) (void)hipHostFree(c->h_cell_bounds);
@@ -791,6 +794,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (c->product[0] && vrt::path_kernel_dilated_kind(c->product[0]) == 1) c->product_grid_exit = vrt::path_kernel_dilated_twin(c->product[0], kind);
         if (c->kernel_grid_exit == c->kernel) c->kernel_grid_exit = nullptr;
         if (c->product_grid_exit == c->product[0]) c->product_grid_exit = nullptr;
+        // round 4: where that kernel would run on 8^3 bricks staged in LDS, a pool of rays per wave runs instead (vrt_pool_kernel.h)
+        const vrt::KernelEntry *pool = (kind == 2 && cfg->brick_dimension == 8u && !(cfg->tuning_flags & (VRT_TUNE_NO_PATH_BRICK_LDS | VRT_TUNE_NO_PATH_POOL)))
+                                           ? vrt::find_pool_kernel((int)cfg->brick_dimension) : nullptr;
+        if (pool && c->kernel_grid_exit) c->kernel_grid_exit = pool->fn;
+        if (pool && c->product_grid_exit) c->product_grid_exit = pool->fn;
     }
     c->single_variant = single_variant;
     {
@@ -848,6 +856,17 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
             VRT_CREATE_HIP(hipMemsetAsync(c->d_status_blocks, 0, status_blocks_bytes, c->stream));
         }
     }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
+    {
+        const vrt::KernelEntry *e1 = c->kernel_grid_exit ? vrt::kernel_entry_of(c->kernel_grid_exit) : nullptr;
+        const vrt::KernelEntry *e2 = c->product_grid_exit ? vrt::kernel_entry_of(c->product_grid_exit) : nullptr;
+        if ((e1 && e1->path == 2) || (e2 && e2->path == 2)) {
+            // (never read before it is written: a path's record is filled by the transition that gives the path its first pixel)
+            c->pool_stream_dwords = (size_t)(4 * cus) * 4u * vrt::kPoolPaths * vrt::kPoolPathDwords;
+            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_pool_paths), 2u * c->pool_stream_dwords * sizeof(uint32_t)));
+        }
+    }
     VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_work_counter), 2u * vrt::kMaxBatchFrames * sizeof(uint32_t)));
     VRT_CREATE_HIP(hipMemsetAsync(c->d_work_counter, 0, 2u * vrt::kMaxBatchFrames * sizeof(uint32_t), c->stream));
 
@@ -867,8 +886,12 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.work_counter = c->d_work_counter;
     p.path_lds_bytes = c->path_lds_bytes;
     {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
+        p.pool_paths = c->d_pool_paths;
+        p.pool_groups = 4u * (uint32_t)cus; // four 256-thread workgroups per CU (LDS)
+        p.pool_walk_k = 16u;
+        p.pool_brick_thr = 56u;
+        p.pool_trans_thr = 56u;
+        p.pool_walk_min = 24u;
         p.path_groups = 8u * (uint32_t)cus; // twice what 4 waves per SIMD hold: late groups find the counter exhausted and leave
         p.path_fin_batch = 32u;
         p.path_brick_lds = (cfg->brick_dimension == 8u && !(cfg->tuning_flags & VRT_TUNE_NO_PATH_BRICK_LDS)) ? 1u : 0u;
@@ -884,6 +907,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         dev_knob("VRT_DEV_PATH_SKIP_ROUNDS", p.path_skip_rounds);
         dev_knob("VRT_DEV_PATH_READY_BATCH", p.path_ready_batch);
         dev_knob("VRT_DEV_PATH_GROUPS", p.path_groups);
+        dev_knob("VRT_DEV_POOL_WALK_K", p.pool_walk_k);
+        dev_knob("VRT_DEV_POOL_BRICK_THR", p.pool_brick_thr);
+        dev_knob("VRT_DEV_POOL_TRANS_THR", p.pool_trans_thr);
+        dev_knob("VRT_DEV_POOL_WALK_MIN", p.pool_walk_min);
 #endif
     }
     p.width = cfg->width;
@@ -1005,6 +1032,12 @@ int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, cons
 
 // Common front part of a frame: argument checks, push constants, derived-structure refresh.  Leaves the
 // kernel to launch in *fn.  Runs on the primary stream.
+// vrt_pool_kernel packs a path's sample index into 16 bits and its bounce count into 4; frames beyond that keep vrt_path_kernel
+static bool grid_exit_fits(vrt::KernelFn fn, const vrt_camera_device *camera) {
+    const vrt::KernelEntry *e = vrt::kernel_entry_of(fn);
+    return !(e && e->path == 2) || (camera->samples_per_pixel <= 65535 && camera->max_bounce <= 15);
+}
+
 static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, vrt::KernelFn *fn) {
     if (!ctx || !camera || !sun) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL camera/sun") : VRT_E_INVALID_ARG;
     if (camera->image_width != ctx->cfg.width || camera->image_height != ctx->cfg.height)
@@ -1075,7 +1108,8 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
         ctx->box_is_grid = all;
         ctx->bounds_pending = false;
     }
-    if (camera->max_bounce > 1 && ctx->box_is_grid && !ctx->d_counters && ctx->kernel_grid_exit) *fn = ctx->kernel_grid_exit;
+    if (camera->max_bounce > 1 && ctx->box_is_grid && !ctx->d_counters && ctx->kernel_grid_exit && grid_exit_fits(ctx->kernel_grid_exit, camera))
+        *fn = ctx->kernel_grid_exit;
     return VRT_OK;
 }
 
@@ -1095,7 +1129,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     if (ctx->d_counters) {
         product_fn = ctx->product[(camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? 2 : 1) : 0];
         if (!product_fn) return fail(ctx, VRT_E_STATE, "no product kernel for this configuration");
-        if (camera->max_bounce > 1 && ctx->box_is_grid && ctx->product_grid_exit) product_fn = ctx->product_grid_exit;
+        if (camera->max_bounce > 1 && ctx->box_is_grid && ctx->product_grid_exit && grid_exit_fits(ctx->product_grid_exit, camera)) product_fn = ctx->product_grid_exit;
     }
     note_kernel(ctx, product_fn ? product_fn : fn);
     // (the persistent-lane kernel takes its pixels from a counter: it neither reads the tile schedule nor reports tile costs)
@@ -1120,6 +1154,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         pb.target_rgba8 = ctx->target8_b;
         pb.target_rgba32f = ctx->target32f_b;
         pb.work_counter = ctx->d_work_counter + vrt::kMaxBatchFrames; // its frames run beside the primary stream's
+        if (pb.pool_paths) pb.pool_paths += ctx->pool_stream_dwords;
         VRT_HIP(ctx, vrt::launch_trace(fn, pb, ctx->lds_bytes, ctx->stream_b));
         if (product_fn) VRT_HIP(ctx, vrt::launch_trace(product_fn, pb, ctx->lds_bytes, ctx->stream_b));
         VRT_HIP(ctx, hipEventRecord(ctx->ev_b_done, ctx->stream_b));

@@ -1,4 +1,5 @@
 // vrt_inst_path.hip — vrt_path_kernel (frames with bounces on scenes larger than the caches: persistent lanes).
+#include "vrt_pool_kernel.h"
 #include "vrt_inst_common.h"
 
 namespace vrt {
@@ -11,6 +12,8 @@ const KernelEntry kEntries[] = {
     // the steps-left counters, the walk ends at the grid's face (scenes whose occupied cells reach the grid's faces)
     VRT_PATH_ENTRY_L(4, 5, false, false, false, false, 1), VRT_PATH_ENTRY_L(8, 5, false, false, false, false, 1),
     VRT_PATH_ENTRY_L(4, 5, false, false, false, false, 2), VRT_PATH_ENTRY_L(8, 5, false, false, false, false, 2),
+    // round 4: a pool of 128 rays per wave (vrt_pool_kernel.h): 8^3 bricks, the counter-free dilated-index walk, 4 waves per SIMD
+    VRT_POOL_ENTRY(8, 4),
 #ifdef VRT_DEV_VARIANTS
     // DIL 4 (round 3): the counter-free dilated-index walk with the DDA two cells ahead of the test (two requests in flight per lane;
     // whoever leaves the loop takes a step back, ~7 % of the trips are walked twice): 128.5 vs 129.8 ms from inside the 2048^3 field,

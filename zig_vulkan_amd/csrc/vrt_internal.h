@@ -116,6 +116,14 @@ struct TraceParams {
     uint32_t path_ready_batch;           // ... unless this many lanes already stand in blocks that hold occupied cells
     uint32_t path_brick_lds;             // vrt_path_kernel, 8^3 bricks: 1 = a lane's brick is staged in LDS for the voxel-level walk (16 KiB per workgroup)
     uint32_t path_eager_start;           // ... and its brick_start_index entry is requested together with the brick (one dependent miss less per hit)
+    // vrt_pool_kernel (round 4: a pool of 128 rays per wave, vrt_pool_kernel.h): the paths' records in global memory, 16 dwords per
+    // path by field, one block of 128 paths per wave of the launch; and the phase rule's four numbers
+    uint32_t *pool_paths;
+    uint32_t pool_groups;                // workgroups to launch: what the GPU holds at four per CU (39 KiB of LDS each)
+    uint32_t pool_walk_k;                // a call of the walk loop returns once this many of its lanes have parked or left
+    uint32_t pool_brick_thr;             // a brick round runs once this many of the wave's 128 rays wait for one
+    uint32_t pool_trans_thr;             // a round of transitions once this many wait for one
+    uint32_t pool_walk_min;              // below this many rays to walk the fuller of the two other queues is served first
     uint32_t count_box;                  // counting build only: 1 = walk to the occupied-cell box like the product kernel (issued loads)
     uint32_t skip_to_box;                // 1: rays that enter the grid in front of the occupied-cell box jump to its near face (skip_to_box())
     uint32_t tile_order;                 // workgroup -> tile mapping: 1 row bands per XCD, 2 column bands per XCD, 3 reverse raster, 4 strided,

@@ -26,6 +26,7 @@ struct KernelEntry {
     KernelFn fn;
     const char *name;
     uint8_t path;      // 0: vrt_trace_kernel<B, COUNT, MODE, MIN_WAVES, SHADE, BLOCK>   1: vrt_path_kernel<B, MIN_WAVES, FILTER, HALF, AHEAD, DIST, DIL>
+                       // 2: vrt_pool_kernel<B, MIN_WAVES> (persistent waves like 1: pixels from TraceParams::work_counter)
     uint8_t b;         // brick dimension
     uint8_t count;     // trace: counting build
     uint8_t mode;      // trace: StatusMode
@@ -50,8 +51,17 @@ KernelTable inst_path();
 
 const KernelEntry *find_trace_kernel(int b, bool count, int mode, int min_waves, int shade, int block = 256);
 const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead = false, bool dist = false, int dil = 0);
+const KernelEntry *find_pool_kernel(int b);
 const KernelEntry *kernel_entry_of(KernelFn fn);
 int compiled_kernel_count();
+
+// vrt_pool_kernel (vrt_pool_kernel.h): per wave 64 ray records of 21 dwords in LDS beside 4 KiB of staged bricks, 256 B of slot
+// states and 256 B of scratch; 128 paths per wave, 16 dwords each in global memory (TraceParams::pool_paths)
+constexpr uint32_t kPoolRecDwords = 21u;
+constexpr uint32_t kPoolStageBytes = 4096u;
+constexpr uint32_t kPoolWaveLdsBytes = kPoolStageBytes + kPoolRecDwords * 256u + 256u + 256u; // 9 984
+constexpr uint32_t kPoolPaths = 128u;
+constexpr uint32_t kPoolPathDwords = 16u;
 
 constexpr int kPathFilterThreads = 512; // vrt_path_kernel<FILTER>: eight waves share one LDS copy of the block filter
 

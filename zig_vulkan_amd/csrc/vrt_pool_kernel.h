@@ -1,0 +1,522 @@
+// vrt_pool_kernel.h — frames with bounces on scenes larger than the caches, round 4: every wave keeps a POOL of rays.
+// Included by vrt_inst_path.hip only.
+#pragma once
+//
+// vrt_path_kernel ties a ray to a lane: a lane whose ray waits for a brick round or for its next ray idles while its neighbours
+// walk, and the rounds it waits for run for the lanes that happen to wait — measured on the 2048^3 path trace
+// (profiles/r03_cfg4_phase_profile_dilated.txt): 54 lanes enter a call of the walk loop and 26 still move when it returns, a brick
+// round serves 25 lanes, a round of transitions 24, and a wave instruction costs the same for one lane as for 64.  Every batching
+// parameter of that kernel sits on a plateau; what is left is to take the ray OFF the lane.
+//
+// Here a wave owns 128 paths.  64 rays are in the registers of its lanes, the other 64 lie in ray records in the wave's own LDS
+// (21 dwords each, kept by field: dword k of slot j at rec[64 k + j], so that exchanging a lane's ray with a slot's is 21 reads and
+// 21 writes without bank conflicts).  The wave's loop picks a phase — WALK (comp:314-375, the hand-written park loop), BRICK
+// (comp:378-471 for the rays that stand in front of an occupied cell) or TRANSITION (comp:153-265 around GridHit: shade, scatter,
+// shadow ray, next sample, next pixel, ray set-up) — by how many of its 128 rays wait for each; lanes whose ray is in another
+// state exchange it with a slot whose ray is in that state; the phase then runs on (nearly) 64 lanes.  The walk loop returns once
+// `pool_walk_k` of its lanes have parked or left, and is re-entered with fresh rays in those lanes.
+// What belongs to the PATH rather than to its current ray (pixel, sample index, the sample sum, RayColor's locals) is needed by
+// the transitions only and lies in global memory (16 dwords per path, by field, wave-private: TraceParams::pool_paths), loaded and
+// stored once per transition.
+// Per ray the sequence of arithmetic operations is ray_color's / main()'s exactly as in vrt_path_kernel (the same functions are
+// called); the samples of a pixel are traced one after the other by the path that owns the pixel and summed in order: frames are
+// bit-identical.  No cross-wave communication (no barrier, no atomics but the pixel counter): a wave's LDS is its own.
+// LDS per wave: 4 KiB staged bricks + 21 x 256 B records + 256 B slot states + 256 B scratch = 9 984 B; four 256-thread workgroups
+// per CU = 156 KiB of the CU's 160, four waves per SIMD (128 VGPRs).
+// Only the configuration the 2048^3 path trace runs: 8^3 bricks staged in LDS, the counter-free dilated-index walk (all three grid
+// dimensions powers of two, the walk ends at the grid's face: vrt_path_kernel<..., DIL 2>'s loop).  Everything else keeps
+// vrt_path_kernel.
+#include "vrt_trace_kernels.h"
+
+namespace vrt {
+
+// (kPoolRecDwords, kPoolStageBytes, kPoolWaveLdsBytes, kPoolPaths, kPoolPathDwords: vrt_kernels.h — the launcher sizes LDS and the
+// paths' buffer by them)
+
+// state of a ray.  class 0 (<= 2): waits for a transition; 1: walks; 2: waits in front of an occupied cell; 3: its path is over
+enum : uint32_t { kRayFetch = 0u, kRayMiss = 1u, kRayHit = 2u, kRayWalk = 3u, kRayParked = 4u, kRayExit = 5u };
+VRT_DI uint32_t pool_class(uint32_t st) { return st <= 2u ? 0u : st - 2u; }
+
+VRT_DI uint32_t pool_mbcnt(unsigned long long m) { // set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+VRT_DI uint32_t f2u(float v) { return __builtin_bit_cast(uint32_t, v); }
+VRT_DI float u2f(uint32_t v) { return __builtin_bit_cast(float, v); }
+
+template <int B, int MIN_WAVES>
+__global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TraceParams p) {
+    static_assert(B == 8, "bricks of 8^3 voxels staged in LDS");
+    extern __shared__ __attribute__((aligned(16))) uint32_t pool_lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *const wl = pool_lds + wave * (kPoolWaveLdsBytes / 4u);
+    // this wave's staging area for bricks (LDS byte address; layout dictated by global_load_lds: vrt_trace_kernels.h)
+    const uint32_t wave_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)pool_lds + wave * kPoolWaveLdsBytes;
+    uint32_t *const rec = wl + kPoolStageBytes / 4u; // rec[64 k + j]: dword k of the ray in slot j
+    uint32_t *const sstate = rec + kPoolRecDwords * 64u; // state of the ray in slot j
+    uint32_t *const tmp = sstate + 64u;
+    uint32_t *const path = p.pool_paths + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave) * (size_t)(kPoolPaths * kPoolPathDwords);
+
+    const PushConstants &pc = p.pcs[blockIdx.y];
+    const uint32_t total = p.owned_tiles * (uint32_t)(kTileW * kTileH);
+    uint32_t *const counter = p.work_counter + blockIdx.y;
+    const bool sun_enabled = pc.sun.enabled > 0;
+    const int spp = pc.cam.samples_per_pixel;
+    const int max_bounce = pc.cam.max_bounce;
+    const float t_max = __builtin_inff();
+    const f3 g_min = mk3(p.grid.min_point_base_t[0], p.grid.min_point_base_t[1], p.grid.min_point_base_t[2]);
+    const float g_scale = p.grid.max_point_scale[3];
+    const int dx = (int)p.grid.dim_x, dy = (int)p.grid.dim_y, dz = (int)p.grid.dim_z;
+    int lox = 0, loy = 0, loz = 0, hix = dx - 1, hiy = dy - 1, hiz = dz - 1;
+    if (p.cell_bounds) {
+        lox = -p.cell_bounds[0], loy = -p.cell_bounds[1], loz = -p.cell_bounds[2];
+        hix = p.cell_bounds[3], hiy = p.cell_bounds[4], hiz = p.cell_bounds[5];
+    }
+    const int zero_budget = dx + dy + dz + 8;
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    // the dilated cell index (vrt_trace_kernels.h, grid_walk_park_dilated_gfx950): the three axes' bit fields
+    const uint32_t lx = uni(31u - (uint32_t)__builtin_clz(p.grid.dim_x)), lz = uni(31u - (uint32_t)__builtin_clz(p.grid.dim_z)),
+                   ly = uni(31u - (uint32_t)__builtin_clz(p.grid.dim_y));
+    const uint32_t fx = uni(3u | (((1u << (lx - 2u)) - 1u) << 5)), fz = uni((3u << 2) | (((1u << (lz - 2u)) - 1u) << (lx + 3u))),
+                   fy = uni((1u << 4) | (((1u << (ly - 1u)) - 1u) << (lx + lz + 1u)));
+    u32x4 hb_rsrc;
+    {
+        const unsigned long long a = (unsigned long long)p.status_halfblocks;
+        hb_rsrc.x = uni((uint32_t)a);
+        hb_rsrc.y = uni((uint32_t)(a >> 32) | (4u << 16));
+        hb_rsrc.z = uni(p.status_words);
+        hb_rsrc.w = 0x00020000u;
+    }
+    const bool by_cell = p.cell_occupancy != nullptr;
+    const bool start_is_slot = p.start_is_slot != nullptr && __builtin_amdgcn_readfirstlane((int)*p.start_is_slot) != 0;
+    const uint32_t walk_k = max(1u, p.pool_walk_k), brick_thr = p.pool_brick_thr, trans_thr = p.pool_trans_thr, walk_min = p.pool_walk_min;
+
+    // ---- the ray in this lane's registers (the record's 21 dwords) + its state ----
+    f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), inv = mk3(1, 1, 1), sd = mk3(0, 0, 0);
+    uint32_t idx = 0u;  // the cell the walk stands on (dilated index; axes walked down mirrored)
+    uint32_t cw = 0u;   // kRayWalk: the half-block word of that cell; kRayParked: the occupied cell left behind (dilated index)
+    float t_in = 0.0f;  // crossed distance of the step into the parked cell; kRayHit: hit.t
+    float t_out = 0.0f; // crossed distance of the ray's last step; kRayHit: hit.index (bits)
+    float gtmin = 0.0f, gtmax = 0.0f, ir = 1.0f;
+    // flags: bits 0-6 the path (slot of `path`), 8-9 / 10-11 / 12-13 ray step x / y / z + 1, 14-17 slab-entry code, 18-19 ignored
+    // material type, 20 the step out of the parked cell left the grid, 21-22 kRayHit: the face of the voxel hit
+    uint32_t fl = lane;
+    uint32_t code = 3u << 4; // GridParkRegs::code
+    uint32_t st = kRayFetch;
+    sstate[lane] = kRayFetch;
+#pragma unroll
+    for (uint32_t k = 0; k < kPoolRecDwords; k++) rec[64u * k + lane] = (k == 19u) ? 64u + lane : 0u;
+
+    auto sx_of = [](uint32_t f) { return (int)((f >> 8) & 3u) - 1; };
+    auto sy_of = [](uint32_t f) { return (int)((f >> 10) & 3u) - 1; };
+    auto sz_of = [](uint32_t f) { return (int)((f >> 12) & 3u) - 1; };
+
+    // lanes whose ray is not of class X take the ray of a slot that is, as many as there are on either side
+    auto exchange = [&](uint32_t X) {
+        const uint32_t sst = sstate[lane];
+        const unsigned long long offer = __builtin_amdgcn_ballot_w64(pool_class(sst) == X);
+        const unsigned long long want = __builtin_amdgcn_ballot_w64(pool_class(st) != X);
+        const uint32_t n = min((uint32_t)__builtin_popcountll(offer), (uint32_t)__builtin_popcountll(want));
+        if (n == 0u) return;
+        const uint32_t q = pool_mbcnt(offer), r = pool_mbcnt(want);
+        if (((offer >> lane) & 1ull) && q < n) tmp[q] = lane;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (((want >> lane) & 1ull) && r < n) {
+            const uint32_t j = tmp[r];
+            uint32_t *const s = rec + j;
+#define VRT_XCH_F(k, v) { const uint32_t t_ = s[64u * (k)]; s[64u * (k)] = f2u(v); v = u2f(t_); }
+#define VRT_XCH_U(k, v) { const uint32_t t_ = s[64u * (k)]; s[64u * (k)] = v; v = t_; }
+            VRT_XCH_F(0, ro.x) VRT_XCH_F(1, ro.y) VRT_XCH_F(2, ro.z) VRT_XCH_F(3, rd.x) VRT_XCH_F(4, rd.y) VRT_XCH_F(5, rd.z)
+            VRT_XCH_F(6, inv.x) VRT_XCH_F(7, inv.y) VRT_XCH_F(8, inv.z) VRT_XCH_F(9, sd.x) VRT_XCH_F(10, sd.y) VRT_XCH_F(11, sd.z)
+            VRT_XCH_U(12, idx) VRT_XCH_U(13, cw) VRT_XCH_F(14, t_in) VRT_XCH_F(15, t_out) VRT_XCH_F(16, gtmin) VRT_XCH_F(17, gtmax)
+            VRT_XCH_F(18, ir) VRT_XCH_U(19, fl) VRT_XCH_U(20, code)
+#undef VRT_XCH_F
+#undef VRT_XCH_U
+            const uint32_t mine = st;
+            st = sstate[j];
+            sstate[j] = mine;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    bool work_left = true; // wave-uniform
+#ifdef VRT_DEV_PROFILE
+    if (threadIdx.x < 8) vrt_prof[threadIdx.x] = 0ull;
+    __syncthreads();
+    unsigned long long pf_t[3] = {0ull, 0ull, 0ull};
+    unsigned long long pf_n[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+#define VRT_PF_T(k, t0) pf_t[k] += __builtin_readcyclecounter() - (t0)
+#define VRT_PF_N(k, v) pf_n[k] += (unsigned long long)(v)
+#define VRT_PF_NOW() __builtin_readcyclecounter()
+#else
+#define VRT_PF_T(k, t0)
+#define VRT_PF_N(k, v)
+#define VRT_PF_NOW() 0ull
+#endif
+    // (the guard bounds a wave whose state machine stalls — a bug — to a finite run instead of a hung GPU; a wave of the 4K /
+    // 2048^3 / 16 spp frame takes ~40 000 rounds)
+    for (uint32_t round = 0u; round < (1u << 23); round++) {
+        // how many of the wave's rays wait for what
+        const uint32_t sst = sstate[lane];
+        const uint32_t n_walk = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kRayWalk)) +
+                                (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sst == kRayWalk));
+        const uint32_t n_brick = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kRayParked)) +
+                                 (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sst == kRayParked));
+        const uint32_t n_trans = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st <= kRayHit)) +
+                                 (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sst <= kRayHit));
+        if (n_walk + n_brick + n_trans == 0u) break;
+        uint32_t phase; // 0 transitions, 1 walk, 2 bricks
+        if (n_brick >= brick_thr) phase = 2u;
+        else if (n_trans >= trans_thr) phase = 0u;
+        else if (n_walk >= walk_min) phase = 1u;
+        else if (n_brick != 0u && n_brick >= n_trans) phase = 2u;
+        else if (n_trans != 0u) phase = 0u;
+        else phase = 1u;
+
+        if (phase == 0u) {
+            [[maybe_unused]] const unsigned long long pf0 = VRT_PF_NOW();
+            exchange(0u);
+            VRT_PF_N(0, 1);
+            VRT_PF_N(1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(st <= kRayHit)));
+            if (st <= kRayHit) {
+                const uint32_t ps = fl & 127u;
+                uint32_t *const pr = path + ps;
+                // the path: pixel, sample index, the sample sum (comp:173), RayColor's locals (comp:203-216) and what it keeps while the
+                // shadow ray is walked (comp:221-239)
+                uint32_t work = pr[0];
+                uint32_t pf = pr[128];
+                f3 acc = mk3(u2f(pr[2 * 128]), u2f(pr[3 * 128]), u2f(pr[4 * 128]));
+                f3 color = mk3(u2f(pr[5 * 128]), u2f(pr[6 * 128]), u2f(pr[7 * 128]));
+                float cur_dir_y = u2f(pr[8 * 128]);
+                f3 sc_dir = mk3(u2f(pr[9 * 128]), u2f(pr[10 * 128]), u2f(pr[11 * 128]));
+                float sc_ir = u2f(pr[12 * 128]);
+                f3 attenuation = mk3(u2f(pr[13 * 128]), u2f(pr[14 * 128]), u2f(pr[15 * 128]));
+                int sample_i = (int)(pf & 0xFFFFu);
+                int loop_count = (int)((pf >> 16) & 15u);
+                int kind = (int)((pf >> 20) & 1u);
+                bool scattered_ok = ((pf >> 21) & 1u) != 0u;
+                uint32_t sc_ignore = (pf >> 22) & 3u;
+
+                Ray r = Ray{ro, rd, ir, (fl >> 18) & 3u};
+                RaySetup s;
+                s.inv_dir = inv;
+                s.entry_code = (int)((fl >> 14) & 15u);
+                s.sx = sx_of(fl), s.sy = sy_of(fl), s.sz = sz_of(fl);
+                s.grid_t_min = gtmin, s.grid_t_max = gtmax;
+                const bool found = st == kRayHit;
+                int ls = (st == kRayFetch) ? kLaneFetch : kLaneDone;
+                // (1) a ray has finished: comp:218-258 from the loop condition's GridHit onwards
+                if (ls == kLaneDone) {
+                    bool after_shadow = false;
+                    if (kind == 0) {
+                        if (found) {
+                            Hit hit;
+                            hit.t = t_in;
+                            hit.index = f2u(t_out);
+                            const float t_offset = (g_scale * (1.0f / (float)B)) * 0.05f;
+                            hit.normal = axis_normal(s, (int)((fl >> 21) & 3u));
+                            hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
+                            loop_count += 1;
+                            Ray scattered = r;
+                            bool result = false;
+                            const vrt_material *m = p.materials + hit.index;
+                            const uint32_t mtype = m->type;
+                            attenuation = mk3(m->albedo_r, m->albedo_g, m->albedo_b);
+                            const float mdata = m->type_data;
+                            switch (mtype) {
+                                case MAT_LAMBERTIAN: result = scatter_lambertian(hit, scattered); break;
+                                case MAT_METAL: result = scatter_metal(mdata, r, hit, scattered); break;
+                                case MAT_DIELECTRIC: result = scatter_dielectric(mdata, r, hit, scattered); break;
+                                default:
+                                    loop_count -= 1;
+                                    result = false;
+                                    break;
+                            }
+                            scattered_ok = result;
+                            sc_dir = scattered.direction;
+                            sc_ir = scattered.internal_reflection;
+                            sc_ignore = scattered.ignore_type_material;
+                            cur_dir_y = r.direction.y;
+                            if (sun_enabled) {
+                                const f3 sun_position = mk3(pc.sun.position[0], pc.sun.position[1], pc.sun.position[2]);
+                                const f3 rv = rand_vec3_range(r.direction.x + r.direction.z, r.direction.y + r.direction.z, -pc.sun.radius, pc.sun.radius);
+                                const f3 shadow_ray_dir = (sun_position + rv) - hit.point;
+                                r = create_ray(hit.point, shadow_ray_dir); // CreateShadowRay, comp:186-190 (ignore type MAT_NONE)
+                                kind = 1;
+                                ls = kLaneStart;
+                            } else {
+                                color = color + attenuation;
+                                r.origin = hit.point; // the scattered ray starts where the shadow ray would have
+                                after_shadow = true;
+                            }
+                        } else {
+                            cur_dir_y = r.direction.y;
+                            ls = kLaneEnd; // the while condition failed (comp:218)
+                        }
+                    } else {
+                        if (!found) color = color + attenuation * mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
+                        after_shadow = true;
+                    }
+                    if (after_shadow) {
+                        if (!scattered_ok) {
+                            ls = kLaneEnd; // comp:253-255
+                        } else {
+                            r.direction = sc_dir; // current_ray = scattered (its origin, hit.point, is r.origin already)
+                            r.internal_reflection = sc_ir;
+                            r.ignore_type_material = sc_ignore;
+                            cur_dir_y = sc_dir.y;
+                            kind = 0;
+                            ls = (loop_count < max_bounce) ? kLaneStart : kLaneEnd;
+                        }
+                    }
+                }
+                // (2) the path is over: comp:260-264, then the sample loop's accumulation (comp:173)
+                if (ls == kLaneEnd) {
+                    if (loop_count == 0) {
+                        const f3 sun_color = mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
+                        const float t = 0.5f * (cur_dir_y + 1.0f);
+                        const f3 bg = fma3(splat3(1.0f - t), splat3(1.0f), mk3(0.5f, 0.7f, 1.0f) * t);
+                        color = color + bg * (sun_enabled ? sun_color : splat3(1.0f));
+                    }
+                    acc = acc + color / (color + splat3(1.0f));
+                    sample_i += 1;
+                    ls = (sample_i < spp) ? kLaneSample : kLaneStore;
+                }
+                // (3) the pixel is finished: comp:176-177
+                if (ls == kLaneStore) {
+                    const uint32_t owned = p.owned_tiles - 1u - (work >> 8);
+                    const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
+                    const uint32_t j = work & 255u;
+                    const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
+                    const uint32_t px = (tile % p.tiles_x) * kTileW + in_x, py = (tile / p.tiles_x) * kTileH + in_y;
+                    const float fspp = (float)spp;
+                    const f3 c = mk3(__builtin_sqrtf(acc.x / fspp), __builtin_sqrtf(acc.y / fspp), __builtin_sqrtf(acc.z / fspp));
+                    const size_t o = (p.shard_count > 1u || p.packed_tiles) ? (size_t)owned * (kTileW * kTileH) + in_y * kTileW + in_x : (size_t)py * p.width + px;
+                    reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] =
+                        unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
+                    if (p.target_rgba32f) reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(c.x, c.y, c.z, 1.0f);
+                    ls = kLaneFetch;
+                }
+                // (4) next pixel: one atomic per wave for all the lanes that ask
+                {
+                    const unsigned long long asking = __builtin_amdgcn_ballot_w64(ls == kLaneFetch);
+                    if (asking != 0ull) {
+                        if (work_left) {
+                            const uint32_t n = (uint32_t)__builtin_popcountll(asking);
+                            uint32_t first = 0u;
+                            if (lane == (uint32_t)__builtin_ctzll(asking)) first = atomicAdd(counter, n);
+                            first = (uint32_t)__builtin_amdgcn_readlane((int)first, __builtin_ctzll(asking));
+                            if (ls == kLaneFetch) {
+                                const uint32_t mine = first + pool_mbcnt(asking);
+                                if (mine < total) {
+                                    work = mine;
+                                    sample_i = 0;
+                                    acc = mk3(0, 0, 0);
+                                    ls = kLaneSample;
+                                } else {
+                                    ls = kLaneExit;
+                                }
+                            }
+                            work_left = first + n < total;
+                        } else if (ls == kLaneFetch) {
+                            ls = kLaneExit;
+                        }
+                    }
+                }
+                // (5) next sample of the pixel: comp:162-171
+                if (ls == kLaneSample) {
+                    const uint32_t owned = p.owned_tiles - 1u - (work >> 8);
+                    const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
+                    const uint32_t j = work & 255u;
+                    const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
+                    const uint32_t px = (tile % p.tiles_x) * kTileW + in_x, py = (tile / p.tiles_x) * kTileH + in_y;
+                    if (px >= p.width || py >= p.height) {
+                        ls = kLaneFetch; // outside the image (comp:155-159): nothing to trace, nothing to store; asks again next round
+                    } else {
+                        const float x = (float)px, y = (float)py;
+                        const f3 horizontal = mk3(pc.cam.horizontal[0], pc.cam.horizontal[1], pc.cam.horizontal[2]);
+                        const f3 vertical = mk3(pc.cam.vertical[0], pc.cam.vertical[1], pc.cam.vertical[2]);
+                        const f3 llc = mk3(pc.cam.lower_left_corner[0], pc.cam.lower_left_corner[1], pc.cam.lower_left_corner[2]);
+                        const f3 origin = mk3(pc.cam.origin[0], pc.cam.origin[1], pc.cam.origin[2]);
+                        const float flag = (sample_i > 0) ? 1.0f : 0.0f;
+                        const float noise_x = hash_12_jitter(x + (float)sample_i, y, flag);
+                        const float u = (x + noise_x) / (float)(pc.cam.image_width - 1u);
+                        const float noise_y = hash_12_jitter(x, y + (float)sample_i, flag);
+                        const float v = (y + noise_y) / (float)(pc.cam.image_height - 1u);
+                        const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
+                        r = create_ray(origin, ray_dir);
+                        kind = 0;
+                        loop_count = 0;
+                        color = mk3(0, 0, 0);
+                        cur_dir_y = r.direction.y;
+                        ls = (loop_count < max_bounce) ? kLaneStart : kLaneEnd;
+                    }
+                }
+                // (6) a new ray: comp:271-312 (GridHit up to its loop)
+                uint32_t nst = (ls == kLaneExit) ? kRayExit : ((ls == kLaneFetch) ? kRayFetch : kRayMiss); // (kLaneEnd: max_bounce 0, next round)
+                if (ls == kLaneStart) {
+                    nst = kRayMiss;
+                    if (grid_slab(p, r, 0.00001f, t_max, s)) {
+                        const float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
+                        const f3 fposition = p.scale_pow2 ? (ray_at(r, global_t_value) - g_min) * p.inv_grid_scale : (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
+                        Walk w;
+                        w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta());
+                        const int px = f2i_clamp(__builtin_floorf(fposition.x));
+                        const int py = f2i_clamp(__builtin_floorf(fposition.y));
+                        const int pz = f2i_clamp(__builtin_floorf(fposition.z));
+                        w.rx = steps_left_box(s.sx, px, lox, hix, zero_budget);
+                        w.ry = steps_left_box(s.sy, py, loy, hiy, zero_budget);
+                        w.rz = steps_left_box(s.sz, pz, loz, hiz, zero_budget);
+                        const int base_x = walk_base_box(s.sx, px, lox, hix), base_y = walk_base_box(s.sy, py, loy, hiy), base_z = walk_base_box(s.sz, pz, loz, hiz);
+                        w.t_value = 0;
+                        uint32_t grid_index = (uint32_t)px + (uint32_t)dx * ((uint32_t)pz + (uint32_t)dz * (uint32_t)py);
+                        const uint32_t stride_x = (uint32_t)s.sx, stride_y = (uint32_t)s.sy * (uint32_t)dx * (uint32_t)dz, stride_z = (uint32_t)s.sz * (uint32_t)dx;
+                        bool more = (global_t_value <= t_max) && (unsigned)px < (unsigned)dx && (unsigned)py < (unsigned)dy && (unsigned)pz < (unsigned)dz &&
+                                    (w.rx | w.ry | w.rz) >= 0;
+                        int in_axis = 3; // the first cell of the walk was entered through the slab test, not by a step ...
+                        float skip_t = 0.0f;
+                        // ... unless the ray enters the grid in front of the occupied-cell box and jumps to its near face
+                        if (p.cell_bounds && p.skip_to_box)
+                            skip_to_box(w, s, (int)((uint32_t)hix - (uint32_t)lox), (int)((uint32_t)hiy - (uint32_t)loy), (int)((uint32_t)hiz - (uint32_t)loz), grid_index,
+                                        stride_x, stride_y, stride_z, more, in_axis, skip_t);
+                        if (more) {
+                            // the walk's index in dilated form, from the cell the lane stands on; axes walked down are stored mirrored
+                            const uint32_t cx = (uint32_t)(base_x - __mul24(s.sx, w.rx)), cy = (uint32_t)(base_y - __mul24(s.sy, w.ry)),
+                                           cz = (uint32_t)(base_z - __mul24(s.sz, w.rz));
+                            const uint32_t mx = s.sx < 0 ? ((uint32_t)dx - 1u - cx) : cx, my = s.sy < 0 ? ((uint32_t)dy - 1u - cy) : cy,
+                                           mz = s.sz < 0 ? ((uint32_t)dz - 1u - cz) : cz;
+                            idx = (mx & 3u) | ((mz & 3u) << 2) | ((my & 1u) << 4) | ((mx >> 2) << 5) | ((mz >> 2) << (lx + 3u)) | ((my >> 1) << (lx + lz + 1u));
+                            const uint32_t flip = (s.sx < 0 ? fx : 0u) | (s.sy < 0 ? fy : 0u) | (s.sz < 0 ? fz : 0u);
+                            cw = p.status_halfblocks[(idx ^ flip) >> 5];
+                            sd = w.side_dist;
+                            t_out = skip_t;
+                            t_in = 0.0f;
+                            code = (uint32_t)in_axis << 4;
+                            nst = kRayWalk;
+                        }
+                    }
+                    // the ray as the walk and the next transition need it
+                    ro = r.origin, rd = r.direction, ir = r.internal_reflection;
+                    inv = s.inv_dir;
+                    gtmin = s.grid_t_min, gtmax = s.grid_t_max;
+                    fl = ps | ((uint32_t)(s.sx + 1) << 8) | ((uint32_t)(s.sy + 1) << 10) | ((uint32_t)(s.sz + 1) << 12) | (((uint32_t)s.entry_code & 15u) << 14) |
+                         ((r.ignore_type_material & 3u) << 18);
+                }
+                st = nst;
+                pr[0] = work;
+                pr[128] = ((uint32_t)sample_i & 0xFFFFu) | (((uint32_t)loop_count & 15u) << 16) | ((uint32_t)kind << 20) | ((scattered_ok ? 1u : 0u) << 21) | ((sc_ignore & 3u) << 22);
+                pr[2 * 128] = f2u(acc.x), pr[3 * 128] = f2u(acc.y), pr[4 * 128] = f2u(acc.z);
+                pr[5 * 128] = f2u(color.x), pr[6 * 128] = f2u(color.y), pr[7 * 128] = f2u(color.z);
+                pr[8 * 128] = f2u(cur_dir_y);
+                pr[9 * 128] = f2u(sc_dir.x), pr[10 * 128] = f2u(sc_dir.y), pr[11 * 128] = f2u(sc_dir.z);
+                pr[12 * 128] = f2u(sc_ir);
+                pr[13 * 128] = f2u(attenuation.x), pr[14 * 128] = f2u(attenuation.y), pr[15 * 128] = f2u(attenuation.z);
+            }
+            VRT_PF_T(0, pf0);
+        } else if (phase == 1u) {
+            // every lane that has a ray to walk walks (comp:314-375), until pool_walk_k of them have parked or left
+            [[maybe_unused]] const unsigned long long pf1 = VRT_PF_NOW();
+            exchange(1u);
+            const unsigned long long walking = __builtin_amdgcn_ballot_w64(st == kRayWalk);
+            if (walking == 0ull) continue;
+            const uint32_t n_walking = (uint32_t)__builtin_popcountll(walking);
+            const int sx = sx_of(fl), sy = sy_of(fl), sz = sz_of(fl);
+            const uint32_t flip = (sx < 0 ? fx : 0u) | (sy < 0 ? fy : 0u) | (sz < 0 ? fz : 0u);
+            const uint32_t nm_x = sx != 0 ? ~fx : ~0u, nm_y = sy != 0 ? ~fy : ~0u, nm_z = sz != 0 ? ~fz : ~0u;
+            GridParkRegs g;
+            g.alive = walking;
+            g.out_x = g.out_y = 0ull;
+            g.t_out = t_out;
+            g.t_in = t_in;
+            g.code = code;
+            g.batch = uni(walk_k);
+            g.min_alive = uni(n_walking >= walk_k ? n_walking - walk_k + 1u : 1u);
+            const float t_in_keep = t_in; // (the loop's output register: lanes outside the call keep theirs)
+            uint32_t word = cw, cell;
+            unsigned long long gone = 0ull;
+            grid_walk_park_dilated_carry_gfx950(sd, inv, idx, cell, nm_x, nm_y, nm_z, word, hb_rsrc, g, flip, gone);
+            const bool was_walking = (walking >> lane) & 1ull;
+            const bool parked = __builtin_amdgcn_inverse_ballot_w64(g.parked);
+            const bool moving = __builtin_amdgcn_inverse_ballot_w64(g.alive);
+            VRT_PF_T(1, pf1);
+            VRT_PF_N(2, 1);
+            VRT_PF_N(3, n_walking);
+            VRT_PF_N(4, __builtin_popcountll(g.alive));
+            t_in = was_walking ? g.t_in : t_in_keep;
+            if (was_walking) {
+                t_out = g.t_out;
+                if (parked) {
+                    st = kRayParked;
+                    cw = cell;
+                    code = g.code; // bits 0-1 the axis INTO the occupied cell, 2-3 the axis out of it
+                    fl = (fl & ~(1u << 20)) | (__builtin_amdgcn_inverse_ballot_w64(gone) ? (1u << 20) : 0u);
+                } else if (moving) {
+                    cw = word;
+                    code = (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
+                } else {
+                    st = kRayMiss; // left the grid
+                }
+            }
+        } else {
+            // the rays that stand in front of an occupied cell walk its brick (comp:378-471)
+            [[maybe_unused]] const unsigned long long pf2 = VRT_PF_NOW();
+            exchange(2u);
+            VRT_PF_N(5, 1);
+            VRT_PF_N(6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kRayParked)));
+            if (st == kRayParked) {
+                const int sx = sx_of(fl), sy = sy_of(fl), sz = sz_of(fl);
+                const uint32_t flip = (sx < 0 ? fx : 0u) | (sy < 0 ? fy : 0u) | (sz < 0 ? fz : 0u);
+                // the cell's position from the walk's index, un-mirrored and un-dilated
+                const uint32_t real = cw ^ flip;
+                const int cx = (int)((real & 3u) | ((real >> 3) & (((1u << (lx - 2u)) - 1u) << 2)));
+                const int cz = (int)(((real >> 2) & 3u) | ((real >> (lx + 1u)) & (((1u << (lz - 2u)) - 1u) << 2)));
+                const int cy = (int)(((real >> 4) & 1u) | ((real >> (lx + lz + 1u)) << 1));
+                const uint32_t cell = (uint32_t)cx + (uint32_t)dx * ((uint32_t)cz + (uint32_t)dz * (uint32_t)cy);
+                const uint32_t occ_slot = by_cell ? cell : p.brick_index[cell]; // comp:337 (by_cell: only on a solid voxel)
+                stage_brick_lds(p, occ_slot, by_cell, wave_lds); // (first: the arithmetic below runs while the brick arrives)
+                Ray r = Ray{ro, rd, ir, (fl >> 18) & 3u};
+                RaySetup s;
+                s.inv_dir = inv;
+                s.entry_code = (int)((fl >> 14) & 15u);
+                s.sx = sx, s.sy = sy, s.sz = sz;
+                s.grid_t_min = gtmin, s.grid_t_max = gtmax;
+                const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min); // comp:331
+                const float global_t_value = t_in * g_scale + gtmin + 0.01f * g_scale;                    // comp:347 (deferred) + comp:332
+                Hit hit;
+                hit.t = global_t_value;
+                hit.index = 0u;
+                int hit_axis = 0;
+                const int a = (int)(code & 3u);
+                const bool hit_voxel = brick_walk_park_gfx950<B, true, true>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis, wave_lds);
+                if (hit_voxel) {
+                    st = kRayHit;
+                    t_in = hit.t;
+                    t_out = u2f(hit.index);
+                    fl = (fl & ~(3u << 21)) | (((uint32_t)hit_axis & 3u) << 21);
+                } else if (!(global_t_value <= t_max) || ((fl >> 20) & 1u)) {
+                    st = kRayMiss; // t became NaN (comp:316), or the step out of this cell left the grid
+                } else {
+                    st = kRayWalk;
+                    cw = p.status_halfblocks[(idx ^ flip) >> 5]; // (an A-trip park left the lane's word in the other register set)
+                    code = ((code >> 2) & 3u) << 4;              // the axis of its last step, for its first trip in the next call
+                }
+            }
+            VRT_PF_T(2, pf2);
+        }
+    }
+#ifdef VRT_DEV_PROFILE
+    if (p.wave_timeline && lane == 0u) {
+        for (int k = 0; k < 3; k++) atomicAdd(&p.wave_timeline[k], pf_t[k]);
+        for (int k = 0; k < 8; k++) atomicAdd(&p.wave_timeline[3 + k], pf_n[k]);
+        atomicAdd(&p.wave_timeline[11], 1ull);
+    }
+    __syncthreads();
+    if (p.wave_timeline && threadIdx.x < 8) atomicAdd(&p.wave_timeline[12 + threadIdx.x], vrt_prof[threadIdx.x]);
+#endif
+#undef VRT_PF_T
+#undef VRT_PF_N
+#undef VRT_PF_NOW
+}
+
+} // namespace vrt

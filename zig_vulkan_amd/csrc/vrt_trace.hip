@@ -416,9 +416,12 @@ const KernelEntry *find_trace_kernel(int b, bool count, int mode, int min_waves,
 }
 const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead, bool dist, int dil) {
     return find_entry([&](const KernelEntry &e) {
-        return e.path && e.b == b && e.min_waves == min_waves && (e.filter != 0) == filter && (e.half != 0) == half && (e.ahead != 0) == ahead &&
+        return e.path == 1 && e.b == b && e.min_waves == min_waves && (e.filter != 0) == filter && (e.half != 0) == half && (e.ahead != 0) == ahead &&
                (e.dist != 0) == dist && (int)e.dil == dil;
     });
+}
+const KernelEntry *find_pool_kernel(int b) {
+    return find_entry([&](const KernelEntry &e) { return e.path == 2 && e.b == b; });
 }
 const KernelEntry *kernel_entry_of(KernelFn fn) {
     return find_entry([&](const KernelEntry &e) { return e.fn == fn; });
@@ -510,42 +513,42 @@ bool is_path_kernel(KernelFn fn) {
 // the same kernel with the walk loop on half-block words (TraceParams::status_halfblocks); fn itself if it has none
 KernelFn path_kernel_halfblock_twin(KernelFn fn) {
     const KernelEntry *e = kernel_entry_of(fn);
-    if (!e || !e->path || e->filter || e->half || e->ahead || e->dist || e->dil) return fn;
+    if (!e || e->path != 1 || e->filter || e->half || e->ahead || e->dist || e->dil) return fn;
     const KernelEntry *t = find_path_kernel(e->b, e->min_waves, false, true);
     return t ? t->fn : fn;
 }
 // the same kernel with the half-block walk loop on a dilated cell index; fn itself if it has none
 KernelFn path_kernel_dilated_twin(KernelFn fn, int kind) {
     const KernelEntry *e = kernel_entry_of(fn);
-    if (!e || !e->path || e->filter || e->half || e->ahead || e->dist) return fn;
+    if (!e || e->path != 1 || e->filter || e->half || e->ahead || e->dist) return fn;
     const KernelEntry *t = find_path_kernel(e->b, e->min_waves, false, false, false, false, kind);
     return t ? t->fn : fn;
 }
 int path_kernel_dilated_kind(KernelFn fn) {
     const KernelEntry *e = kernel_entry_of(fn);
-    return (e && e->path) ? (int)e->dil : 0;
+    return (e && e->path == 1) ? (int)e->dil : 0;
 }
 // the same kernel with the walk loop on the distance field (TraceParams::cell_distance); fn itself if it has none
 KernelFn path_kernel_dist_twin(KernelFn fn) {
     const KernelEntry *e = kernel_entry_of(fn);
-    if (!e || !e->path || e->filter || e->half || e->ahead || e->dist || e->dil) return fn;
+    if (!e || e->path != 1 || e->filter || e->half || e->ahead || e->dist || e->dil) return fn;
     const KernelEntry *t = find_path_kernel(e->b, e->min_waves, false, false, false, true);
     return t ? t->fn : fn;
 }
 // the plain path kernel's twin with the walk loop two trips ahead; fn itself if it has none
 KernelFn path_kernel_ahead_twin(KernelFn fn) {
     const KernelEntry *e = kernel_entry_of(fn);
-    if (!e || !e->path || e->half || e->filter || e->ahead || e->dist || e->dil) return fn;
+    if (!e || e->path != 1 || e->half || e->filter || e->ahead || e->dist || e->dil) return fn;
     const KernelEntry *t = find_path_kernel(e->b, e->min_waves, false, false, true);
     return t ? t->fn : fn;
 }
 bool is_path_halfblock_kernel(KernelFn fn) {
     const KernelEntry *e = kernel_entry_of(fn);
-    return e && e->path && e->half;
+    return e && e->path == 1 && e->half;
 }
 static bool is_path_filter_kernel(KernelFn fn) {
     const KernelEntry *e = kernel_entry_of(fn);
-    return e && e->path && e->filter;
+    return e && e->path == 1 && e->filter;
 }
 const char *kernel_name_of(KernelFn fn) {
     const KernelEntry *e = kernel_entry_of(fn);
@@ -554,6 +557,16 @@ const char *kernel_name_of(KernelFn fn) {
 
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream, uint32_t frames) {
     if (p.owned_tiles == 0 || frames == 0) return hipSuccess;
+    if (const KernelEntry *pe = kernel_entry_of(fn); pe && pe->path == 2) {
+        // a pool of rays per wave (vrt_pool_kernel.h): as many workgroups as the GPU holds, or as the frame has pixels for
+        if (!p.work_counter || !p.pool_paths || frames != 1u) return hipErrorInvalidValue;
+        hipError_t e = hipMemsetAsync(p.work_counter, 0, kMaxBatchFrames * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        const uint32_t fit = (p.owned_tiles * 256u + 4u * kPoolPaths - 1u) / (4u * kPoolPaths);
+        const uint32_t groups = fit < p.pool_groups ? (fit ? fit : 1u) : p.pool_groups;
+        hipLaunchKernelGGL(fn, dim3(groups, 1), dim3(256), 4u * kPoolWaveLdsBytes, stream, p);
+        return hipGetLastError();
+    }
     if (is_path_kernel(fn)) {
         // persistent lanes: as many workgroups as the GPU holds a few times over; they take pixels from p.work_counter
         if (!p.work_counter) return hipErrorInvalidValue;
