@@ -28,7 +28,8 @@ HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VIEW_ORDER = ["V0", "V1", "V2"]          # cycled by the timed region
 EXTRA_VIEWS = ["V1x", "VG"]              # reported per view only: outside-the-box view of round 1, all-ground view
 SETTLE_FRAMES = 128                      # untimed frames after a camera jump (the tile schedule follows with a lag)
-PRECONDITION_MS = 150.0                  # untimed GPU work before the warm-up steps: brings the clocks to their sustained state
+PRECONDITION_MS = 150.0                  # `value_sustained` only: untimed GPU work that brings the clocks to their sustained state
+WALL_BUDGET_S = 900.0                    # N > 1: the whole run's wall-clock budget; the secondary leg is skipped when it would not fit
 
 
 def metric_name(w) -> str:
@@ -184,7 +185,10 @@ def hbm_achievable(dev):
 # ------------------------------------------------------------------------------------------------ PMC (rocprofv3)
 PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
               ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH",
-               "SQ_INSTS"]]
+               "SQ_INSTS"],
+              # lane utilisation of the vector instructions: thread-cycles / (64 x instruction-cycles)
+              ["SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"]]
+PMC_OPTIONAL_PASSES = 1   # (the last pass may fail without taking the HBM / instruction counters down)
 
 
 def pmc_child(args) -> None:
@@ -210,7 +214,8 @@ def _pmc_read(dirs, kernel_substr: str):
         for f in sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)):
             db = sqlite3.connect(f)
             for c, v, n in db.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like ? "
-                                      "or kernel_name like ? group by counter_name", (f"%vrt_trace_kernel<{kernel_substr}, false%", f"%vrt_path_kernel<{kernel_substr},%")):
+                                      "or kernel_name like ? or kernel_name like ? group by counter_name",
+                                      (f"%vrt_trace_kernel<{kernel_substr}, false%", f"%vrt_path_kernel<{kernel_substr},%", f"%vrt_pool_kernel<{kernel_substr},%")):
                 out[c] = v
                 out["_dispatches"] = n
     return out
@@ -238,6 +243,8 @@ def pmc_live(args, w):
                    "--pmc-child", "--workload", w.name, "--variant", str(args.variant), "--pmc-frames", str(args.pmc_frames)]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=args.pmc_timeout)
             if r.returncode != 0:
+                if i >= len(PMC_PASSES) - PMC_OPTIONAL_PASSES:
+                    continue
                 return None, f"rocprofv3 pass {group} exited {r.returncode}: {r.stdout.decode(errors='replace')[-300:]}"
             dirs.append(d)
         c = _pmc_read(dirs, str(w.brick_dimension))   # the product kernel: vrt_trace_kernel<B, false, ...> or vrt_path_kernel<B, ...>
@@ -304,9 +311,16 @@ def native_probe(env, timeout: float):
     """Before any timed leg at N > 1: every rank runs dist_probe_child in a child process (the children form their own
     communicators on the same GPUs).  A hang inside a collective cannot be recovered from in-process; in a child it is a
     timeout, the child is killed, and every rank takes the torch.distributed path instead.  Returns (ok on every rank, report)."""
-    from zig_vulkan_amd import VoxelRT
-    uids = (VoxelRT.dist_unique_id() + VoxelRT.dist_unique_id()) if env.rank == 0 else None
+    uids = None
+    if env.rank == 0:
+        try:
+            from zig_vulkan_amd import VoxelRT
+            uids = VoxelRT.dist_unique_id() + VoxelRT.dist_unique_id()
+        except Exception as e:  # noqa: BLE001 - the other ranks wait in the broadcast below: it must happen either way
+            print(f"[bench rank 0] no RCCL unique id for the probe: {type(e).__name__}: {e}", file=sys.stderr)
     uids = env.bcast(uids)
+    if uids is None:
+        return False, {"ok": False, "seconds": 0.0, "this_rank": "rank 0 could not make a RCCL unique id"}
     cmd = [sys.executable, os.path.abspath(__file__), "--dist-probe", "--probe-uid", uids.hex(), "--probe-rank", str(env.rank),
            "--probe-world", str(env.world), "--probe-device", str(env.local_rank)]
     child_env = {k: v for k, v in os.environ.items()
@@ -518,14 +532,24 @@ class Leg:
         if sharded and want_native:
             # RCCL inside libvrt_hip.so: kernel -> grouped send/recv to rank 0 -> un-swizzle, several launches in flight
             ok = 1
+            # (rank 0 makes the id inside its own guard and every rank executes the broadcast whatever happened: a rank that skipped
+            # it would sit in all_min_int's all-reduce while the others sit in the broadcast — ADVICE r03)
+            uid = None
+            if rank == 0:
+                try:
+                    if stub:
+                        uid = b"stub"
+                    else:
+                        from zig_vulkan_amd import VoxelRT
+                        uid = VoxelRT.dist_unique_id()
+                except Exception as e:  # noqa: BLE001
+                    print(f"[bench rank 0] no RCCL unique id: {type(e).__name__}: {e}", file=sys.stderr)
+            uid = env.bcast(uid)
             try:
+                if uid is None:
+                    raise RuntimeError("rank 0 could not make a RCCL unique id")
                 if stub:
-                    uid = b"stub"
                     self.rt = _StubRT(fail_native=(rank == args.stub_fail_native_on), root_share=root_share, batch=batch)
-                else:
-                    from zig_vulkan_amd import VoxelRT
-                    uid = VoxelRT.dist_unique_id() if rank == 0 else None
-                uid = env.bcast(uid)
                 if not stub:
                     self.rt = W.make_renderer(w, grid, device_id=env.local_rank, shard_rank=rank, shard_count=world, kernel_variant=args.variant,
                                               shard_root_weight=(root_share if (2 <= world <= 8 and root_share < 100) else 0))
@@ -606,15 +630,22 @@ class Leg:
     def timed(self, n: int) -> float:
         """EXACTLY n steps between barrier + synchronize on both sides; the maximum over ranks."""
         env = self.env
+        events = (not self.sharded) and (not env.stub) and hasattr(self.rt, "region_begin")
+        self.device_ms = None
         env.barrier()
         t0 = time.perf_counter()
+        if events:
+            self.rt.region_begin()   # (SURVEY.md 8(d): HIP events around the same steps, on both streams: `value_device_events`)
         for i in range(n):
             self.step(i, n)
         self.drain()  # the last frame's gather + un-swizzle belong to the timed region
         if not self.native:
             self.rt.wait()
         env.barrier()
-        return env.all_max(time.perf_counter() - t0)
+        dt = env.all_max(time.perf_counter() - t0)
+        if events:
+            self.device_ms = self.rt.region_end()
+        return dt
 
     def estimate_frame_ms(self) -> float:
         env = self.env
@@ -698,6 +729,10 @@ def main(argv=None) -> None:
     ap.add_argument("--variant", type=lambda x: int(x, 0), default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="minimum wall time of each CPU baseline sample")
+    ap.add_argument("--precondition-ms", type=float, default=0.0,
+                    help="untimed GPU work before the warm-up steps of `value` (0: the protocol is W warm-up steps and K timed steps, nothing else; "
+                         "`value_sustained` always reports the same steps behind 150 ms of frames)")
+    ap.add_argument("--wall-budget", type=float, default=WALL_BUDGET_S, help="N > 1: seconds the whole run may take; the secondary leg is skipped if it would not fit")
     ap.add_argument("--frames-in-flight", type=int, default=2, help="1: frames strictly one after another; 2: two frames in flight")
     ap.add_argument("--pmc", choices=["auto", "live", "profile", "off"], default="auto",
                     help="HBM traffic / instruction counters of the roofline object: live = rocprofv3 passes over a child run now; "
@@ -735,6 +770,12 @@ def main(argv=None) -> None:
         dist_probe_child(args)
         return
     ensure_ranks(args, argv)
+    t_run0 = time.perf_counter()
+    phase_seconds = {}
+
+    def phase(name, t_from):
+        phase_seconds[name] = phase_seconds.get(name, 0.0) + (time.perf_counter() - t_from)
+        return time.perf_counter()
 
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio (flushed at exit, i.e.
     # after anything Python printed), so everything else written to fd 1 by any library is sent to stderr and the
@@ -786,6 +827,7 @@ def main(argv=None) -> None:
     def stub_counts():
         return {v: {"rays": 1000, "bytes": 4000, "issued_bytes": 2000, "counters": {}, "issued": {}, "primary_hit_fraction": 0.5} for v in all_views}
 
+    t_ph = phase("startup", t_run0)
     # ---- rays and bytes per view, counted by counting builds of the kernel (untimed) ----
     per_view, count_err = {}, None
     if stub:
@@ -802,11 +844,13 @@ def main(argv=None) -> None:
     def rays_of(pv, n):
         return sum(pv[view_of(i, n)]["rays"] for i in range(n))
 
+    t_ph = phase("count_rays", t_ph)
     # ---- the timed legs ----
     want_native = args.dist == "native"
     probe_report = None
     if sharded and world > 1 and want_native and not stub and not args.no_native_probe:
         want_native, probe_report = native_probe(env, args.probe_timeout)
+    t_ph = phase("native_probe", t_ph)
     legs_out = {}
     tune_reports = {}
     if not sharded:
@@ -823,6 +867,7 @@ def main(argv=None) -> None:
             plan.append((f"batch{leg.batch}" if leg.native else "torch", leg))
             if not leg.native:
                 break       # the torch fallback has one form only
+    t_ph = phase("contexts_and_root_share_tuning", t_ph)
 
     # a first look at the frame time (two untimed frames): sizes the run when --steps / --warmup were left to the script
     # and the settling / PMC legs for workloads whose frames take milliseconds instead of microseconds
@@ -835,26 +880,42 @@ def main(argv=None) -> None:
         args.pmc_frames = int(min(24, max(2, 600.0 / frame_ms_est)))
     settle_frames = int(min(SETTLE_FRAMES, max(3, 1500.0 / frame_ms_est)))
 
-    # Untimed pre-conditioning, before the W warm-up steps: the GPU reaches its sustained clocks only after tens of milliseconds of
-    # continuous work (tools/short_run.py, same box, same kernel: 20 frames timed cold 0.083 ms per frame, the same 20 frames right
-    # after 40 ms of frames 0.077, 600 frames 0.071), and a 25-frame run is 2 ms long.  A renderer runs continuously; the warm-up
-    # of a short protocol does not get it there.  Nothing inside the timed region changes.
-    precondition = 0 if stub else int(min(4000, PRECONDITION_MS / frame_ms_est))
-    primary_name = plan[-1][0]
+    # `value` is the protocol's: W untimed warm-up steps, then exactly K timed steps (round 3 ran ~150 ms of untimed frames
+    # first; --precondition-ms brings that back for A/B, default 0).  The GPU reaches its sustained clocks only after tens of milliseconds
+    # of continuous work (tools/short_run.py: 20 frames timed cold 0.083 ms per frame, right after 40 ms of frames 0.077, 600 frames
+    # 0.071), which a renderer — it runs continuously — has behind it: `value_sustained` (N = 1) times the same K steps again behind
+    # PRECONDITION_MS of frames, and says so.
+    precondition = 0 if stub else int(min(4000, args.precondition_ms / frame_ms_est))
+    # N > 1: `value` is north_star's literal leg, one RCCL gather per frame (the first of the plan); the batched leg is reported beside it
+    primary_name = plan[0][0]
+    device_ms = None
     for name, leg in plan:
         if precondition:
             leg.run(precondition)
         leg.run(args.warmup)
         dt = leg.timed(args.steps)
+        if name == primary_name:
+            device_ms = getattr(leg, "device_ms", None)
         legs_out[name] = {"value": rays_of(per_view, args.steps) / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt / args.steps * 1e3,
                           "frames_per_collective": leg.batch, "root_share_percent": leg.root_share if leg.native else None,
                           "dist_path": ("native" if leg.native else "torch") if sharded else None,
                           "breakdown": leg.breakdown(2 * args.dist_frames)}
-    leg = plan[-1][1]
+    sustained = None
+    if not sharded and not stub:
+        lg = plan[0][1]
+        lg.run(int(min(4000, PRECONDITION_MS / frame_ms_est)))
+        lg.run(args.warmup)
+        dts = lg.timed(args.steps)
+        sustained = {"value": rays_of(per_view, args.steps) / dts / 1e6, "ms_per_step": dts / args.steps * 1e3,
+                     "value_device_events": (rays_of(per_view, args.steps) / (lg.device_ms * 1e-3) / 1e6) if lg.device_ms else None,
+                     "note": f"the same {args.steps} steps timed again behind {PRECONDITION_MS:.0f} ms of untimed frames + the warm-up: the rate of a renderer that runs "
+                             "continuously (the clocks ramp for tens of milliseconds); `value` is the cold protocol's"}
+    leg = plan[-1][1]          # (kept open for the N = 1 roofline leg / the N > 1 line's pipeline description)
     dt = legs_out[primary_name]["ms_per_step"] * args.steps * 1e-3
     native, rccl_world = leg.native, leg.rccl_world
     for name, other in plan[:-1]:
         other.close()
+    t_ph = phase("timed_legs", t_ph)
 
     if rank == 0 and sharded:
         # (to stderr, before the secondary leg: should that leg hang in a collective, the headline legs are on record)
@@ -863,7 +924,14 @@ def main(argv=None) -> None:
 
     # ---- N > 1: the same pipeline on BASELINE.json's sharded configuration (configs[3]: 3840x2160, 1024^3, 4 rays per pixel) ----
     secondary = None
-    if sharded and world > 1 and native and not args.no_secondary and (args.workload or W.HEADLINE) == W.HEADLINE:
+    # (the secondary leg builds a 1024^3 grid per rank — ~13 s — tunes three root shares and times up to `steps` 4K frames: budgeted as
+    # what the headline's contexts + tuning + legs took, twice over, + 60 s; if that does not fit the wall budget it is skipped, and says so)
+    spent = time.perf_counter() - t_run0
+    secondary_estimate = 2.0 * (phase_seconds.get("contexts_and_root_share_tuning", 0.0) + phase_seconds.get("timed_legs", 0.0)) + 60.0
+    secondary_fits = bool(env.all_min_int(int(spent + secondary_estimate <= args.wall_budget)))
+    if sharded and world > 1 and native and not args.no_secondary and (args.workload or W.HEADLINE) == W.HEADLINE and not secondary_fits:
+        secondary = {"skipped": f"wall budget: {spent:.0f} s spent + ~{secondary_estimate:.0f} s estimated > {args.wall_budget:.0f} s"}
+    elif sharded and world > 1 and native and not args.no_secondary and (args.workload or W.HEADLINE) == W.HEADLINE:
         try:
             w2 = W.WORKLOADS["cfg3_4k_1024c_b8"]
             grid2 = None if stub else W.build_grid(w2)
@@ -893,6 +961,7 @@ def main(argv=None) -> None:
             print(f"[bench rank {rank}] secondary leg failed: {type(e).__name__}: {e}", file=sys.stderr)
             secondary = {"error": f"{type(e).__name__}: {e}"}
 
+    t_ph = phase("secondary_leg", t_ph)
     # ---- N = 1: the same steps strictly one frame after another, and the dominant kernel by HIP events ----
     roofline = None
     single = None
@@ -934,7 +1003,7 @@ def main(argv=None) -> None:
             pmc, pmc_note = pmc_from_profile(w.brick_dimension)
             if args.pmc == "auto":
                 pmc_note = f"{pmc_note} (live measurement failed: {why})"
-        traffic = issue_ipc = valu_frac = issue_slots_frac = None
+        traffic = issue_ipc = valu_frac = issue_slots_frac = lane_util = None
         insts = None
         clock_hz = None
         if pmc is not None:
@@ -958,8 +1027,44 @@ def main(argv=None) -> None:
                 for k in ("SQ_INSTS_BRANCH", "SQ_INSTS"):
                     if k in pmc:
                         insts[k] = pmc[k]
+            if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("SQ_THREAD_CYCLES_VALU"):
+                # how many of its 64 lanes the average vector instruction serves (EXEC's population, weighted by the instruction's cycles)
+                lane_util = pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
+        # the present / denoise pass that follows every trace in the reference's frame (image.frag:18-78 at GraphicsPipeline.zig:34-39's
+        # defaults; Pipeline.draw, Pipeline.zig:432-541): the app's 1024x576 image goes to a 1920x1080 window, other workloads 1:1
+        present = None
+        try:
+            pw, ph = (1920, 1080) if (w.width, w.height) == (1024, 576) else (w.width, w.height)
+            leg.set_cam("V1")
+            p_ms, t_ms = [], []
+            for _ in range(64):
+                rt1.draw()
+                rt1.present(pw, ph)
+                t_ms.append(rt1.last_kernel_ms())
+                p_ms.append(rt1.last_denoise_ms())
+            p_ms, t_ms = sorted(p_ms), sorted(t_ms)
+            p_med = p_ms[len(p_ms) // 2]
+            p_bytes = ((20 + 2) * 16 + 4) * pw * ph
+            present = {"kernel": "vrt_denoise_kernel", "from": [w.width, w.height], "to": [pw, ph], "samples": 20, "us_median": p_med * 1e3, "us_min": p_ms[0] * 1e3,
+                       "algorithmic_bytes": p_bytes, "bytes_note": "(samples + 2) bilinear taps of 4 texels x 4 B + 4 B written, per output pixel",
+                       "achieved_GBps": p_bytes / (p_med * 1e-3) / 1e9, "frac": p_bytes / (p_med * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                       "trace_us_median_same_frames": t_ms[len(t_ms) // 2] * 1e3, "frame_trace_plus_present_us": (t_ms[len(t_ms) // 2] + p_med) * 1e3,
+                       "note": "view V1, 64 frames, one frame at a time, HIP events around each launch; the source image stays in L2: bound by its gathers and pow(), not by HBM"}
+        except Exception as e:  # noqa: BLE001
+            present = {"error": f"{type(e).__name__}: {e}"}
+        # frac > 1: the kernel is not doing the modelled work (it never asks for the status words of cells it knows to be empty), so the
+        # HBM model does not describe it: the governing figure is then the share of the issue slots the launch fills (VERDICT r03 #5a)
+        frac = achieved / HBM_PEAK_GBPS
+        model_valid = frac <= 1.0
         roofline = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "bound": "hbm" if model_valid else "issue", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": frac,
+            "frac_model_valid": model_valid,
+            "governing_frac": frac if model_valid else issue_slots_frac,
+            "governing_note": ("frac (algorithmic bytes / kernel time / HBM peak)" if model_valid else
+                               "issue_slots_frac: frac > 1 means the timed kernel does not request the bytes the model counts (skip-to-box), so the HBM "
+                               "model is void for this workload; the kernel is bound by instruction issue"),
+            "lane_util": lane_util,
+            "lane_util_note": "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): the share of its 64 lanes the average vector instruction serves",
             "traffic": traffic, "traffic_note": pmc_note,
             "definition": "achieved = bytes the REFERENCE algorithm loads for these frames (4 S + 4 K + V + 25 H per ray + 4 B per pixel, "
                           "SURVEY.md 8(d), counted by the counting build that walks to the grid's face like the shader) / kernel time: a rate "
@@ -992,11 +1097,12 @@ def main(argv=None) -> None:
             "insts_per_launch": insts, "clock_hz": clock_hz,
         }
 
+    t_ph = phase("roofline_leg", t_ph)
     if rank == 0:
         par = (f"1 GPU, whole frame, {args.frames_in_flight} frame(s) in flight" if not sharded else
                f"image tiles 16x16 interleaved over {world} GPU(s), every frame gathered once to rank 0, "
-               + (f"native RCCL pipeline: {leg.batch if world > 1 else 1} frame(s) per launch and per collective (`value`; the one-collective-per-frame "
-                  f"leg is legs.batch1), {args.dist_frames} launches in flight, rank 0 owns {leg.root_share} % of an equal share of the tiles"
+               + (f"native RCCL pipeline, ONE collective per frame (`value` = legs.{primary_name}; the leg with {leg.batch if world > 1 else 1} frame(s) per launch and per "
+                  f"collective is `value_batched`), {args.dist_frames} launches in flight, rank 0 owns {leg.root_share} % of an equal share of the tiles"
                   if native else "torch.distributed gather per frame, frame f overlaps the kernel of f+1"))
         out = {
             "metric": metric_name(w),
@@ -1006,8 +1112,12 @@ def main(argv=None) -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "precondition_frames": precondition,
-            "precondition_note": f"untimed frames before the {args.warmup} warm-up steps (about {PRECONDITION_MS:.0f} ms of continuous GPU work: the clocks "
-                                 "ramp for tens of milliseconds, tools/short_run.py); the timed region is exactly `steps` steps",
+            "precondition_note": "untimed frames before the warm-up steps (--precondition-ms, default 0: the protocol is `warmup` untimed + `steps` timed steps)",
+            "value_device_events": (rays_of(per_view, args.steps) / (device_ms * 1e-3) / 1e6) if device_ms else None,
+            "value_device_events_note": "the same timed steps by the device's clock: hipEventElapsedTime from the earlier of the two streams' begin events to the "
+                                        "later of their end events (vrt_region_begin / _end, SURVEY.md 8(d)); `value` is the host's wall clock around them",
+            "value_sustained": sustained,
+            "phase_seconds": {k: round(v, 3) for k, v in phase_seconds.items()},
             "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_single_stream": single,
             "higher_is_better": True,
@@ -1028,11 +1138,16 @@ def main(argv=None) -> None:
                        "parallelism": par},
             "roofline": roofline,
         }
+        if roofline is not None:
+            out["present_pass"] = present
         if sharded:
             out["legs"] = legs_out
-            out["legs_note"] = ("batch1 = north_star's literal one RCCL gather per frame; the batched leg traces N frames per launch and gathers them "
-                                "with one collective (N frames of latency for 2-3x the frame rate at 8 ranks: a rank's 1/R of the tiles does not "
-                                "fill a GPU); `value` is the last leg's")
+            last = plan[-1][0]
+            out["value_batched"] = legs_out[last]["value"] if last != primary_name else None
+            out["legs_note"] = ("batch1 = north_star's literal one RCCL gather per frame = `value`; the batched leg traces N frames per launch and gathers them "
+                                "with one collective (N frames of latency for 2-3x the frame rate at 8 ranks in the one-GPU emulation: a rank's 1/R of the tiles "
+                                "does not fill a GPU) = `value_batched`")
+            out["wall_budget_s"] = args.wall_budget
             out["root_share_tuning"] = tune_reports
             out["native_probe"] = probe_report   # None: not run (one rank, --dist torch, --no-native-probe)
             out["secondary"] = secondary

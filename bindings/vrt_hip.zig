@@ -261,6 +261,8 @@ pub extern fn vrt_dist_profile(ctx: ?*Ctx, enable: u32) c_int;
 pub extern fn vrt_dist_stats(ctx: ?*Ctx, out: *[8]f64) c_int;
 pub extern fn vrt_dist_selftest(ctx: ?*Ctx) c_int;
 pub extern fn vrt_last_kernel_ms(ctx: ?*Ctx) f64;
+pub extern fn vrt_region_begin(ctx: ?*Ctx) c_int;
+pub extern fn vrt_region_end(ctx: ?*Ctx, ms: [*c]f64) c_int;
 pub extern fn vrt_get_counters(ctx: ?*Ctx, out: [*c]Counters) c_int;
 pub extern fn vrt_get_wave_counters(ctx: ?*Ctx, out: *[3]u64) c_int;
 pub extern fn vrt_trace_wave_timeline(ctx: ?*Ctx, camera: [*c]const CameraDevice, sun: [*c]const SunDevice, out: [*c]u64, capacity_pairs: u64, n_pairs: [*c]u64) c_int;

@@ -289,6 +289,11 @@ int vrt_dist_selftest(vrt_ctx *ctx);
 /* hipEvent time of the most recent vrt_dispatch / average per frame of the
  * most recent vrt_dispatch_repeat, in milliseconds; <0 if none completed. */
 double vrt_last_kernel_ms(vrt_ctx *ctx);
+/* A region of dispatches by the device's own clock (hipEventElapsedTime around the kernels): _begin records an event on
+ * each of the context's streams, _end another pair, waits for them and returns the time from the earlier begin to the later end in
+ * milliseconds — what the frames between the two calls took on the GPU, without the host's launch and notification latency. */
+int vrt_region_begin(vrt_ctx *ctx);
+int vrt_region_end(vrt_ctx *ctx, double *ms);
 
 /* Traversal counters of ONE frame of the last dispatch (enable_counters != 0; the counting build runs once per call):
  * rays = GridHit invocations, S = status-word loads (comp:323-326),

@@ -1,4 +1,4 @@
-"""bench.py's launch and rank plumbing on CPU: world size 2 over gloo with the stub renderer (`--stub`).
+"""bench.py's launch and rank plumbing on CPU: world sizes 2, 4 and 8 over gloo with the stub renderer (`--stub`).
 
 What this pins ("make the multi-GPU entry unbreakable"):
   * `python bench.py --gpus 2` WITHOUT rank environment re-executes itself under torch.distributed.run and
@@ -51,9 +51,14 @@ def test_gpus_2_without_rank_env_spawns_two_ranks():
     assert out["steps"] == 6 and out["warmup"] == 2
     assert out["value"] > 0 and out["ms_per_step"] > 0
     assert "re-executing" in r.stderr.decode()
-    # two timed legs in one invocation: north_star's literal one-gather-per-frame and the batched default; `value` is the batched leg's
+    # two timed legs in one invocation: north_star's literal one-gather-per-frame — `value` — and the batched one, `value_batched`
     assert set(out["legs"]) == {"batch1", "batch8"}
-    assert out["value"] == out["legs"]["batch8"]["value"] and out["ms_per_step"] == pytest.approx(out["legs"]["batch8"]["ms_per_step"])
+    assert out["value"] == out["legs"]["batch1"]["value"] and out["ms_per_step"] == pytest.approx(out["legs"]["batch1"]["ms_per_step"])
+    assert out["value_batched"] == out["legs"]["batch8"]["value"]
+    assert "ONE collective per frame" in out["config"]["parallelism"]
+    # per-phase wall clock of the run and the budget the secondary leg has to fit
+    assert {"startup", "count_rays", "native_probe", "contexts_and_root_share_tuning", "timed_legs", "secondary_leg"} <= set(out["phase_seconds"])
+    assert sum(out["phase_seconds"].values()) < out["wall_budget_s"] == 900.0
     assert out["legs"]["batch1"]["frames_per_collective"] == 1 and out["legs"]["batch8"]["frames_per_collective"] == 8
     # the root share comes from a warm-up auto-tune whose winner every rank agrees on (times are maxima over ranks); the stub's
     # frames are fastest at a share of 60 %
@@ -78,6 +83,49 @@ def test_native_failure_on_one_rank_moves_every_rank_to_the_torch_path():
     assert out["rccl_world"] is None
     assert "torch.distributed gather per frame" in out["config"]["parallelism"]
     assert set(out["legs"]) == {"torch"} and out["secondary"] is None
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [4, 8])
+def test_four_and_eight_ranks_over_gloo(world):
+    """the plumbing of the first 8-GPU contact at its real rank counts — both legs, the tuner's agreement across ranks, a
+    breakdown row per rank, the secondary leg, the wall-clock phases."""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = _run(["--gpus", str(world), "--steps", "6", "--warmup", "2", "--stub"], timeout=550)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = _one_json_line(r.stdout)
+    assert out["n_gpus"] == world and out["ranks_seen"] == list(range(world)) and out["rccl_world"] == world
+    assert out["dist_path"] == "native" and set(out["legs"]) == {"batch1", "batch8"}
+    assert out["value"] == out["legs"]["batch1"]["value"] and out["value_batched"] == out["legs"]["batch8"]["value"]
+    cands = {str(c) for c in bench.root_share_candidates(world)}
+    assert len(cands) == 3
+    for leg in ("batch1", "batch8"):
+        tune = out["root_share_tuning"][leg]
+        # (every rank timed every candidate, the times are maxima over ranks, so the winner is one number for the whole job)
+        assert tune["tuned"] and set(tune["candidates_ms_per_frame"]) == cands and str(tune["root_share"]) in cands
+        assert out["legs"][leg]["root_share_percent"] == tune["root_share"]
+        bd = out["legs"][leg]["breakdown"]
+        assert [row["rank"] for row in bd["per_rank"]] == list(range(world))
+    assert out["secondary"]["workload"] == "cfg3_4k_1024c_b8" and out["secondary"]["value"] > 0
+    assert sum(out["phase_seconds"].values()) < 900.0
+
+
+@pytest.mark.timeout(600)
+def test_native_failure_on_one_of_eight_ranks_moves_every_rank_to_the_torch_path():
+    r = _run(["--gpus", "8", "--steps", "4", "--warmup", "1", "--stub", "--stub-fail-native-on", "5"], timeout=550)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = _one_json_line(r.stdout)
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == list(range(8))
+    assert out["dist_path"] == "torch" and out["rccl_world"] is None and set(out["legs"]) == {"torch"} and out["secondary"] is None
+
+
+@pytest.mark.timeout(400)
+def test_secondary_leg_is_skipped_when_the_wall_budget_is_spent():
+    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--stub", "--wall-budget", "1"])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = _one_json_line(r.stdout)
+    assert set(out["legs"]) == {"batch1", "batch8"} and "wall budget" in out["secondary"]["skipped"]
 
 
 def test_world_size_contradicting_gpus_is_an_error():

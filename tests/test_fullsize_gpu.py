@@ -296,7 +296,12 @@ def test_path_kernel_memory_layouts_change_no_pixel():
     path = 1 << 23
     names = []
     base = _frames_with_flags(w, views, 0, kernel_names=names, kernel_variant=path)
-    # the spheres reach the grid's faces: the dilated-index walk without steps-left counters; with the flag, the one with them
+    # the spheres reach the grid's faces: the walk ends at the grid's face — round 4: a pool of rays per wave (vrt_pool_kernel);
+    # without it vrt_path_kernel's dilated-index walk without steps-left counters; with the second flag, the one with them
+    assert set(names) == {"vrt_pool_kernel<8, 5, 64, 2>"}, names
+    names = []
+    for v, a, b in zip(views, base, _frames_with_flags(w, views, L.TUNE_NO_PATH_POOL, kernel_names=names, kernel_variant=path)):
+        assert np.array_equal(a, b), ("a ray per lane", v)
     assert set(names) == {"vrt_path_kernel<8, 5, false, false, false, false, 2>"}, names
     names = []
     _frames_with_flags(w, views[:1], L.TUNE_NO_PATH_GRID_EXIT, kernel_names=names, kernel_variant=path)
@@ -304,6 +309,7 @@ def test_path_kernel_memory_layouts_change_no_pixel():
     for flags in (L.TUNE_NO_PATH_GRID_EXIT, L.TUNE_NO_PATH_GRID_EXIT | L.TUNE_NO_SKIP_TO_BOX | L.TUNE_NO_PATH_BRICK_LDS,
                   L.TUNE_NO_PATH_DILATED, L.TUNE_NO_PATH_DILATED | L.TUNE_NO_SKIP_TO_BOX | L.TUNE_NO_CELL_OCCUPANCY, L.TUNE_NO_SKIP_TO_BOX,
                   L.TUNE_NO_PATH_BRICK_LDS, L.TUNE_NO_PATH_HALFBLOCKS, L.TUNE_PATH_EAGER_START, L.TUNE_NO_CELL_OCCUPANCY, L.TUNE_NO_START_SHORTCUT,
+                  L.TUNE_NO_PATH_POOL | L.TUNE_NO_CELL_OCCUPANCY, L.TUNE_NO_PATH_POOL | L.TUNE_NO_SKIP_TO_BOX | L.TUNE_NO_START_SHORTCUT,
                   L.TUNE_NO_CELL_OCCUPANCY | L.TUNE_NO_START_SHORTCUT | L.TUNE_PATH_EAGER_START,
                   L.TUNE_NO_PATH_BRICK_LDS | L.TUNE_NO_PATH_HALFBLOCKS | L.TUNE_NO_SKIP_TO_BOX):
         for v, a, b in zip(views, base, _frames_with_flags(w, views, flags, kernel_variant=path)):

@@ -14,6 +14,6 @@ rt = W.make_renderer(w, grid, kernel_variant=variant, tuning_flags=flags, **({"l
 W.set_view(rt, view)
 for _ in range(frames):
     rt.draw()
-rt.wait()
+    rt.wait()   # (behind a finished frame the library knows the box of the occupied cells: the next frame takes the grid-exit kernel)
 print(rt.kernel_name(), rt.last_kernel_ms())
 rt.deinit()

@@ -32,6 +32,6 @@ for db in sorted(glob.glob("$OUT/p*/**/*.db", recursive=True)):
     q = f"""select s.kernel_name, i.name, sum(e.value), count(distinct d.id), avg(d.end - d.start) from {pmc[0]} e join {inf[0]} i on e.pmc_id=i.id
             join {kd[0]} d on e.event_id=d.event_id join {ks[0]} s on d.kernel_id=s.id group by s.kernel_name, i.name"""
     for name, ctr, val, n, dur in c.execute(q):
-        if "path_kernel" in name or "trace_kernel" in name: print(f"{ctr:40s} {val/n:.6g}  ({n} dispatches, {dur/1e6:.2f} ms)  {name[:60]}")
+        if "path_kernel" in name or "trace_kernel" in name or "pool_kernel" in name: print(f"{ctr:40s} {val/n:.6g}  ({n} dispatches, {dur/1e6:.2f} ms)  {name[:60]}")
 PY
 rm -rf $OUT/p[0-9]

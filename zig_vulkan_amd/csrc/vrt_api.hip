@@ -201,6 +201,7 @@ struct vrt_ctx {
     bool status_dirty = true;        // brick_status changed since the derived copy was built
     size_t lds_bytes = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_region[4] = {}; // vrt_region_begin / _end: {begin, end} on the primary stream, {begin, end} on the second
     hipEvent_t ev_post_start = nullptr, ev_post_stop = nullptr; // around the most recent present / denoise pass (vrt_last_denoise_ms)
     bool post_timed = false;
     bool in_flight = false;
@@ -314,6 +315,8 @@ void free_ctx(vrt_ctx *c) {
     }
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    for (hipEvent_t e : c->ev_region)
+        if (e) (void)hipEventDestroy(e);
     if (c->ev_post_start) (void)hipEventDestroy(c->ev_post_start);
     if (c->ev_post_stop) (void)hipEventDestroy(c->ev_post_stop);
     if (c->stream_b) {
@@ -795,8 +798,12 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (c->kernel_grid_exit == c->kernel) c->kernel_grid_exit = nullptr;
         if (c->product_grid_exit == c->product[0]) c->product_grid_exit = nullptr;
         // round 4: where that kernel would run on 8^3 bricks staged in LDS, a pool of rays per wave runs instead (vrt_pool_kernel.h)
+        int pool_mw = 0, pool_slots = 0, pool_stages = 0;
+#ifdef VRT_DEV_VARIANTS
+        if (const char *e = std::getenv("VRT_DEV_POOL_KERNEL")) (void)std::sscanf(e, "%d:%d:%d", &pool_mw, &pool_slots, &pool_stages); // "<waves per SIMD>:<LDS slots>:<staging areas>"
+#endif
         const vrt::KernelEntry *pool = (kind == 2 && cfg->brick_dimension == 8u && !(cfg->tuning_flags & (VRT_TUNE_NO_PATH_BRICK_LDS | VRT_TUNE_NO_PATH_POOL)))
-                                           ? vrt::find_pool_kernel((int)cfg->brick_dimension) : nullptr;
+                                           ? vrt::find_pool_kernel((int)cfg->brick_dimension, pool_mw, pool_slots, pool_stages) : nullptr;
         if (pool && c->kernel_grid_exit) c->kernel_grid_exit = pool->fn;
         if (pool && c->product_grid_exit) c->product_grid_exit = pool->fn;
     }
@@ -863,7 +870,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         const vrt::KernelEntry *e2 = c->product_grid_exit ? vrt::kernel_entry_of(c->product_grid_exit) : nullptr;
         if ((e1 && e1->path == 2) || (e2 && e2->path == 2)) {
             // (never read before it is written: a path's record is filled by the transition that gives the path its first pixel)
-            c->pool_stream_dwords = (size_t)(4 * cus) * 4u * vrt::kPoolPaths * vrt::kPoolPathDwords;
+            c->pool_stream_dwords = (size_t)(8 * cus) * 4u * vrt::kPoolPaths * vrt::kPoolPathDwords; // (room for any occupancy)
             VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_pool_paths), 2u * c->pool_stream_dwords * sizeof(uint32_t)));
         }
     }
@@ -887,11 +894,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.path_lds_bytes = c->path_lds_bytes;
     {
         p.pool_paths = c->d_pool_paths;
-        p.pool_groups = 4u * (uint32_t)cus; // four 256-thread workgroups per CU (LDS)
+        p.pool_cus = (uint32_t)cus;
         p.pool_walk_k = 16u;
-        p.pool_brick_thr = 56u;
-        p.pool_trans_thr = 56u;
-        p.pool_walk_min = 24u;
+        p.pool_brick_thr = 48u; // (tools/pool_sweep.py: a plateau from 48 to 56, walk_min 32 to 40, walk_k 16 to 20)
+        p.pool_trans_thr = 48u;
+        p.pool_walk_min = 32u;
         p.path_groups = 8u * (uint32_t)cus; // twice what 4 waves per SIMD hold: late groups find the counter exhausted and leave
         p.path_fin_batch = 32u;
         p.path_brick_lds = (cfg->brick_dimension == 8u && !(cfg->tuning_flags & VRT_TUNE_NO_PATH_BRICK_LDS)) ? 1u : 0u;
@@ -1351,6 +1358,37 @@ int vrt_denoise(vrt_ctx *ctx, const vrt_denoise_config *cfg, uint32_t out_w, uin
     VRT_HIP(ctx, hipEventRecord(ctx->ev_post_stop, s));
     ctx->post_timed = true;
     ctx->denoised_stream = s;
+    return VRT_OK;
+}
+
+int vrt_region_begin(vrt_ctx *ctx) {
+    if (!ctx) return VRT_E_INVALID_ARG;
+    DeviceGuard dg(ctx->device);
+    for (hipEvent_t &e : ctx->ev_region)
+        if (!e) VRT_HIP(ctx, hipEventCreate(&e));
+    VRT_HIP(ctx, hipEventRecord(ctx->ev_region[0], ctx->stream));
+    if (ctx->stream_b) VRT_HIP(ctx, hipEventRecord(ctx->ev_region[2], ctx->stream_b));
+    return VRT_OK;
+}
+
+int vrt_region_end(vrt_ctx *ctx, double *ms) {
+    if (!ctx || !ms) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "ms is NULL") : VRT_E_INVALID_ARG;
+    if (!ctx->ev_region[0]) return fail(ctx, VRT_E_STATE, "vrt_region_end without vrt_region_begin");
+    DeviceGuard dg(ctx->device);
+    VRT_HIP(ctx, hipEventRecord(ctx->ev_region[1], ctx->stream));
+    if (ctx->stream_b) VRT_HIP(ctx, hipEventRecord(ctx->ev_region[3], ctx->stream_b));
+    VRT_HIP(ctx, wait_event(ctx->ev_region[1]));
+    float a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+    VRT_HIP(ctx, hipEventElapsedTime(&a1, ctx->ev_region[0], ctx->ev_region[1]));
+    double begin = 0.0, end = a1; // (times relative to the primary stream's begin event)
+    if (ctx->stream_b) {
+        VRT_HIP(ctx, wait_event(ctx->ev_region[3]));
+        VRT_HIP(ctx, hipEventElapsedTime(&b0, ctx->ev_region[0], ctx->ev_region[2]));
+        VRT_HIP(ctx, hipEventElapsedTime(&b1, ctx->ev_region[0], ctx->ev_region[3]));
+        begin = std::min(0.0, (double)b0);
+        end = std::max((double)a1, (double)b1);
+    }
+    *ms = end - begin;
     return VRT_OK;
 }
 

@@ -10,7 +10,7 @@
     {(vrt::KernelFn)vrt::vrt_path_kernel<B, MW, FILTER, HALF, AHEAD, DIST, DIL>,                                                              \
      "vrt_path_kernel<" #B ", " #MW ", " #FILTER ", " #HALF ", " #AHEAD ", " #DIST ", " #DIL ">", 1, B, 0, 4, MW, 0, (FILTER ? 512 : 256), FILTER, HALF, AHEAD, \
      DIST, DIL}
-#define VRT_POOL_ENTRY(B, MW) {(vrt::KernelFn)vrt::vrt_pool_kernel<B, MW>, "vrt_pool_kernel<" #B ", " #MW ">", 2, B, 0, 4, MW, 0, 256, 0, 0, 0, 0, 2}
+#define VRT_POOL_ENTRY(B, MW, SLOTS, STAGES) {(vrt::KernelFn)vrt::vrt_pool_kernel<B, MW, SLOTS, STAGES>, "vrt_pool_kernel<" #B ", " #MW ", " #SLOTS ", " #STAGES ">", 2, B, 0, 4, MW, 0, 256, 0, 0, 0, 0, 2, SLOTS, STAGES}
 #define VRT_PATH_ENTRY_D(B, MW, FILTER, HALF, AHEAD, DIST) VRT_PATH_ENTRY_L(B, MW, FILTER, HALF, AHEAD, DIST, 0)
 #define VRT_PATH_ENTRY_S(B, MW, FILTER, HALF, AHEAD) VRT_PATH_ENTRY_D(B, MW, FILTER, HALF, AHEAD, false)
 #define VRT_PATH_ENTRY(B, MW, FILTER, HALF) VRT_PATH_ENTRY_S(B, MW, FILTER, HALF, false)

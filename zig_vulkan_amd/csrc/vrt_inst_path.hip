@@ -13,7 +13,13 @@ const KernelEntry kEntries[] = {
     VRT_PATH_ENTRY_L(4, 5, false, false, false, false, 1), VRT_PATH_ENTRY_L(8, 5, false, false, false, false, 1),
     VRT_PATH_ENTRY_L(4, 5, false, false, false, false, 2), VRT_PATH_ENTRY_L(8, 5, false, false, false, false, 2),
     // round 4: a pool of 128 rays per wave (vrt_pool_kernel.h): 8^3 bricks, the counter-free dilated-index walk, 4 waves per SIMD
-    VRT_POOL_ENTRY(8, 4),
+    // round 4: a pool of 128 rays per wave (vrt_pool_kernel.h): 8^3 bricks, the counter-free dilated-index walk
+    // (five waves per SIMD: the four waves of a workgroup share two staging areas for bricks; 2048^3 path trace, same box:
+    // vrt_path_kernel 129.6 ms, a staging area per wave at four waves per SIMD 117.5, this 112.4)
+    VRT_POOL_ENTRY(8, 5, 64, 2),
+#ifdef VRT_DEV_VARIANTS
+    VRT_POOL_ENTRY(8, 4, 64, 4), VRT_POOL_ENTRY(8, 5, 64, 1), VRT_POOL_ENTRY(8, 6, 56, 1), VRT_POOL_ENTRY(8, 5, 40, 4),
+#endif
 #ifdef VRT_DEV_VARIANTS
     // DIL 4 (round 3): the counter-free dilated-index walk with the DDA two cells ahead of the test (two requests in flight per lane;
     // whoever leaves the loop takes a step back, ~7 % of the trips are walked twice): 128.5 vs 129.8 ms from inside the 2048^3 field,

@@ -119,7 +119,7 @@ struct TraceParams {
     // vrt_pool_kernel (round 4: a pool of 128 rays per wave, vrt_pool_kernel.h): the paths' records in global memory, 16 dwords per
     // path by field, one block of 128 paths per wave of the launch; and the phase rule's four numbers
     uint32_t *pool_paths;
-    uint32_t pool_groups;                // workgroups to launch: what the GPU holds at four per CU (39 KiB of LDS each)
+    uint32_t pool_cus;                   // compute units: min_waves workgroups are launched for each
     uint32_t pool_walk_k;                // a call of the walk loop returns once this many of its lanes have parked or left
     uint32_t pool_brick_thr;             // a brick round runs once this many of the wave's 128 rays wait for one
     uint32_t pool_trans_thr;             // a round of transitions once this many wait for one

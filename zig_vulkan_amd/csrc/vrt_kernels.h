@@ -26,6 +26,7 @@ struct KernelEntry {
     KernelFn fn;
     const char *name;
     uint8_t path;      // 0: vrt_trace_kernel<B, COUNT, MODE, MIN_WAVES, SHADE, BLOCK>   1: vrt_path_kernel<B, MIN_WAVES, FILTER, HALF, AHEAD, DIST, DIL>
+                       // 2: vrt_pool_kernel<B, MIN_WAVES, SLOTS, STAGES> (persistent waves like 1: pixels from TraceParams::work_counter)
                        // 2: vrt_pool_kernel<B, MIN_WAVES> (persistent waves like 1: pixels from TraceParams::work_counter)
     uint8_t b;         // brick dimension
     uint8_t count;     // trace: counting build
@@ -39,6 +40,8 @@ struct KernelEntry {
     uint8_t dist;      // path: the walk loop on the L1 distance field of the occupied cells (TraceParams::cell_distance; development)
     uint8_t dil;       // path: the half-block walk loop on a dilated cell index (all three grid dimensions powers of two): 1 = the walk
                        // ends at the box of the occupied cells (steps-left counters), 2 = at the grid's face (no counters in the loop)
+    uint8_t pool_slots = 0;  // vrt_pool_kernel: ray records in LDS per wave (the wave owns 64 + pool_slots paths)
+    uint8_t pool_stages = 0; // vrt_pool_kernel: staging areas for bricks per workgroup (4: one per wave; fewer: shared)
 };
 struct KernelTable {
     const KernelEntry *entries;
@@ -51,15 +54,16 @@ KernelTable inst_path();
 
 const KernelEntry *find_trace_kernel(int b, bool count, int mode, int min_waves, int shade, int block = 256);
 const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead = false, bool dist = false, int dil = 0);
-const KernelEntry *find_pool_kernel(int b);
+const KernelEntry *find_pool_kernel(int b, int min_waves = 0, int slots = 0, int stages = 0); // (0: the first in the table = the library's choice)
 const KernelEntry *kernel_entry_of(KernelFn fn);
 int compiled_kernel_count();
 
-// vrt_pool_kernel (vrt_pool_kernel.h): per wave 64 ray records of 21 dwords in LDS beside 4 KiB of staged bricks, 256 B of slot
-// states and 256 B of scratch; 128 paths per wave, 16 dwords each in global memory (TraceParams::pool_paths)
+// vrt_pool_kernel (vrt_pool_kernel.h): per wave `slots` ray records of 21 dwords in LDS, a dword of state and one of scratch per slot;
+// per workgroup 16 lock words and `stages` staging areas of 4 KiB for bricks; 64 + slots paths per wave, 16 dwords each in global
+// memory (TraceParams::pool_paths, sized for 128 paths per wave)
 constexpr uint32_t kPoolRecDwords = 21u;
 constexpr uint32_t kPoolStageBytes = 4096u;
-constexpr uint32_t kPoolWaveLdsBytes = kPoolStageBytes + kPoolRecDwords * 256u + 256u + 256u; // 9 984
+constexpr uint32_t pool_group_lds_bytes(uint32_t slots, uint32_t stages) { return 64u + stages * kPoolStageBytes + 4u * (kPoolRecDwords + 2u) * 4u * slots; }
 constexpr uint32_t kPoolPaths = 128u;
 constexpr uint32_t kPoolPathDwords = 16u;
 

@@ -21,8 +21,11 @@
 // Per ray the sequence of arithmetic operations is ray_color's / main()'s exactly as in vrt_path_kernel (the same functions are
 // called); the samples of a pixel are traced one after the other by the path that owns the pixel and summed in order: frames are
 // bit-identical.  No cross-wave communication (no barrier, no atomics but the pixel counter): a wave's LDS is its own.
-// LDS per wave: 4 KiB staged bricks + 21 x 256 B records + 256 B slot states + 256 B scratch = 9 984 B; four 256-thread workgroups
-// per CU = 156 KiB of the CU's 160, four waves per SIMD (128 VGPRs).
+// LDS per wave: 21 x 256 B records + 256 B slot states + 256 B scratch = 5 888 B, and 4 KiB of staged bricks for a wave in a brick
+// round.  With a staging area per wave that is four 256-thread workgroups per CU (156 of the CU's 160 KiB), four waves per SIMD.
+// Measured, the kernel issues one instruction per ~11 cycles per wave whatever the wave count — a wave is one chain of dependent
+// instructions — so occupancy is worth what it is in a latency-bound kernel: the waves of a workgroup SHARE two staging areas
+// (STAGES; a wave locks one for the length of its brick round), five workgroups fit, five waves per SIMD.
 // Only the configuration the 2048^3 path trace runs: 8^3 bricks staged in LDS, the counter-free dilated-index walk (all three grid
 // dimensions powers of two, the walk ends at the grid's face: vrt_path_kernel<..., DIL 2>'s loop).  Everything else keeps
 // vrt_path_kernel.
@@ -43,17 +46,26 @@ VRT_DI uint32_t pool_mbcnt(unsigned long long m) { // set bits of m below this l
 VRT_DI uint32_t f2u(float v) { return __builtin_bit_cast(uint32_t, v); }
 VRT_DI float u2f(uint32_t v) { return __builtin_bit_cast(float, v); }
 
-template <int B, int MIN_WAVES>
+// SLOTS: ray records in LDS per wave (the wave owns 64 + SLOTS paths).  STAGES: 4 KiB staging areas for bricks per workgroup of four
+// waves — 4: one per wave; fewer: a wave takes one for the length of a brick round (try-lock in LDS; if none is free it serves another
+// queue), which is what lets five workgroups of 128-path waves fit a CU's LDS.
+template <int B, int MIN_WAVES, int SLOTS = 64, int STAGES = 4>
 __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TraceParams p) {
     static_assert(B == 8, "bricks of 8^3 voxels staged in LDS");
     extern __shared__ __attribute__((aligned(16))) uint32_t pool_lds[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t *const wl = pool_lds + wave * (kPoolWaveLdsBytes / 4u);
-    // this wave's staging area for bricks (LDS byte address; layout dictated by global_load_lds: vrt_trace_kernels.h)
-    const uint32_t wave_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)pool_lds + wave * kPoolWaveLdsBytes;
-    uint32_t *const rec = wl + kPoolStageBytes / 4u; // rec[64 k + j]: dword k of the ray in slot j
-    uint32_t *const sstate = rec + kPoolRecDwords * 64u; // state of the ray in slot j
-    uint32_t *const tmp = sstate + 64u;
+    // the workgroup's LDS: 16 lock words | STAGES staging areas of 4 KiB | per wave: records, slot states, scratch
+    constexpr uint32_t S = (uint32_t)SLOTS, kWaveDwords = (kPoolRecDwords + 2u) * S;
+    uint32_t *const locks = pool_lds;
+    // the staging areas for bricks (LDS byte address; layout inside one dictated by global_load_lds: vrt_trace_kernels.h)
+    const uint32_t stage0 = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)pool_lds + 64u;
+    uint32_t *const rec = pool_lds + 16u + (uint32_t)STAGES * (kPoolStageBytes / 4u) + wave * kWaveDwords; // rec[S k + j]: dword k of the ray in slot j
+    uint32_t *const sstate = rec + kPoolRecDwords * S; // state of the ray in slot j
+    uint32_t *const tmp = sstate + S;
+    if constexpr (STAGES < 4) {
+        if (threadIdx.x < 16u) locks[threadIdx.x] = 0u;
+        __syncthreads();
+    }
     uint32_t *const path = p.pool_paths + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave) * (size_t)(kPoolPaths * kPoolPathDwords);
 
     const PushConstants &pc = p.pcs[blockIdx.y];
@@ -102,9 +114,11 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
     uint32_t fl = lane;
     uint32_t code = 3u << 4; // GridParkRegs::code
     uint32_t st = kRayFetch;
-    sstate[lane] = kRayFetch;
+    if (lane < S) {
+        sstate[lane] = kRayFetch;
 #pragma unroll
-    for (uint32_t k = 0; k < kPoolRecDwords; k++) rec[64u * k + lane] = (k == 19u) ? 64u + lane : 0u;
+        for (uint32_t k = 0; k < kPoolRecDwords; k++) rec[S * k + lane] = (k == 19u) ? 64u + lane : 0u;
+    }
 
     auto sx_of = [](uint32_t f) { return (int)((f >> 8) & 3u) - 1; };
     auto sy_of = [](uint32_t f) { return (int)((f >> 10) & 3u) - 1; };
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
 
     // lanes whose ray is not of class X take the ray of a slot that is, as many as there are on either side
     auto exchange = [&](uint32_t X) {
-        const uint32_t sst = sstate[lane];
+        const uint32_t sst = lane < S ? sstate[lane] : (uint32_t)kRayExit;
         const unsigned long long offer = __builtin_amdgcn_ballot_w64(pool_class(sst) == X);
         const unsigned long long want = __builtin_amdgcn_ballot_w64(pool_class(st) != X);
         const uint32_t n = min((uint32_t)__builtin_popcountll(offer), (uint32_t)__builtin_popcountll(want));
@@ -124,8 +138,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
         if (((want >> lane) & 1ull) && r < n) {
             const uint32_t j = tmp[r];
             uint32_t *const s = rec + j;
-#define VRT_XCH_F(k, v) { const uint32_t t_ = s[64u * (k)]; s[64u * (k)] = f2u(v); v = u2f(t_); }
-#define VRT_XCH_U(k, v) { const uint32_t t_ = s[64u * (k)]; s[64u * (k)] = v; v = t_; }
+#define VRT_XCH_F(k, v) { const uint32_t t_ = s[S * (k)]; s[S * (k)] = f2u(v); v = u2f(t_); }
+#define VRT_XCH_U(k, v) { const uint32_t t_ = s[S * (k)]; s[S * (k)] = v; v = t_; }
             VRT_XCH_F(0, ro.x) VRT_XCH_F(1, ro.y) VRT_XCH_F(2, ro.z) VRT_XCH_F(3, rd.x) VRT_XCH_F(4, rd.y) VRT_XCH_F(5, rd.z)
             VRT_XCH_F(6, inv.x) VRT_XCH_F(7, inv.y) VRT_XCH_F(8, inv.z) VRT_XCH_F(9, sd.x) VRT_XCH_F(10, sd.y) VRT_XCH_F(11, sd.z)
             VRT_XCH_U(12, idx) VRT_XCH_U(13, cw) VRT_XCH_F(14, t_in) VRT_XCH_F(15, t_out) VRT_XCH_F(16, gtmin) VRT_XCH_F(17, gtmax)
@@ -158,7 +172,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
     // 2048^3 / 16 spp frame takes ~40 000 rounds)
     for (uint32_t round = 0u; round < (1u << 23); round++) {
         // how many of the wave's rays wait for what
-        const uint32_t sst = sstate[lane];
+        VRT_PROF_BEGIN(tpd);
+        const uint32_t sst = lane < S ? sstate[lane] : (uint32_t)kRayExit;
         const uint32_t n_walk = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kRayWalk)) +
                                 (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sst == kRayWalk));
         const uint32_t n_brick = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kRayParked)) +
@@ -173,10 +188,30 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
         else if (n_brick != 0u && n_brick >= n_trans) phase = 2u;
         else if (n_trans != 0u) phase = 0u;
         else phase = 1u;
+        [[maybe_unused]] int stage = (int)wave;
+        if constexpr (STAGES < 4) {
+            if (phase == 2u) {
+                // a staging area for the length of the round; all taken by other waves of the workgroup: serve another queue
+                stage = -1;
+                if (lane == 0u) {
+                    for (int i = 0; i < STAGES && stage < 0; i++)
+                        if (atomicCAS(&locks[i], 0u, 1u) == 0u) stage = i;
+                }
+                stage = __builtin_amdgcn_readfirstlane(stage);
+                if (stage < 0) phase = n_walk != 0u ? 1u : (n_trans != 0u ? 0u : 3u);
+            }
+        }
+        VRT_PROF_END(3, tpd);
+        if (phase == 3u) {
+            __builtin_amdgcn_s_sleep(16);
+            continue;
+        }
 
         if (phase == 0u) {
             [[maybe_unused]] const unsigned long long pf0 = VRT_PF_NOW();
+            VRT_PROF_BEGIN(tpz);
             exchange(0u);
+            VRT_PROF_END(7, tpz);
             VRT_PF_N(0, 1);
             VRT_PF_N(1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(st <= kRayHit)));
             if (st <= kRayHit) {
@@ -417,7 +452,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
         } else if (phase == 1u) {
             // every lane that has a ray to walk walks (comp:314-375), until pool_walk_k of them have parked or left
             [[maybe_unused]] const unsigned long long pf1 = VRT_PF_NOW();
+            VRT_PROF_BEGIN(tpx);
             exchange(1u);
+            VRT_PROF_END(0, tpx);
             const unsigned long long walking = __builtin_amdgcn_ballot_w64(st == kRayWalk);
             if (walking == 0ull) continue;
             const uint32_t n_walking = (uint32_t)__builtin_popcountll(walking);
@@ -435,7 +472,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
             const float t_in_keep = t_in; // (the loop's output register: lanes outside the call keep theirs)
             uint32_t word = cw, cell;
             unsigned long long gone = 0ull;
+            VRT_PROF_BEGIN(tpw);
             grid_walk_park_dilated_carry_gfx950(sd, inv, idx, cell, nm_x, nm_y, nm_z, word, hb_rsrc, g, flip, gone);
+            VRT_PROF_END(1, tpw);
             const bool was_walking = (walking >> lane) & 1ull;
             const bool parked = __builtin_amdgcn_inverse_ballot_w64(g.parked);
             const bool moving = __builtin_amdgcn_inverse_ballot_w64(g.alive);
@@ -461,7 +500,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
         } else {
             // the rays that stand in front of an occupied cell walk its brick (comp:378-471)
             [[maybe_unused]] const unsigned long long pf2 = VRT_PF_NOW();
+            const uint32_t wave_lds = stage0 + (uint32_t)stage * kPoolStageBytes;
+            VRT_PROF_BEGIN(tpy);
             exchange(2u);
+            VRT_PROF_END(6, tpy);
             VRT_PF_N(5, 1);
             VRT_PF_N(6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kRayParked)));
             if (st == kRayParked) {
@@ -501,6 +543,11 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                     cw = p.status_halfblocks[(idx ^ flip) >> 5]; // (an A-trip park left the lane's word in the other register set)
                     code = ((code >> 2) & 3u) << 4;              // the axis of its last step, for its first trip in the next call
                 }
+            }
+            if constexpr (STAGES < 4) {
+                // (every LDS read of the round has returned before the area is handed on)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0u) __hip_atomic_store(&locks[stage], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             VRT_PF_T(2, pf2);
         }

@@ -420,8 +420,10 @@ const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half
                (e.dist != 0) == dist && (int)e.dil == dil;
     });
 }
-const KernelEntry *find_pool_kernel(int b) {
-    return find_entry([&](const KernelEntry &e) { return e.path == 2 && e.b == b; });
+const KernelEntry *find_pool_kernel(int b, int min_waves, int slots, int stages) {
+    return find_entry([&](const KernelEntry &e) {
+        return e.path == 2 && e.b == b && (!min_waves || e.min_waves == min_waves) && (!slots || e.pool_slots == slots) && (!stages || e.pool_stages == stages);
+    });
 }
 const KernelEntry *kernel_entry_of(KernelFn fn) {
     return find_entry([&](const KernelEntry &e) { return e.fn == fn; });
@@ -562,9 +564,10 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
         if (!p.work_counter || !p.pool_paths || frames != 1u) return hipErrorInvalidValue;
         hipError_t e = hipMemsetAsync(p.work_counter, 0, kMaxBatchFrames * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
-        const uint32_t fit = (p.owned_tiles * 256u + 4u * kPoolPaths - 1u) / (4u * kPoolPaths);
-        const uint32_t groups = fit < p.pool_groups ? (fit ? fit : 1u) : p.pool_groups;
-        hipLaunchKernelGGL(fn, dim3(groups, 1), dim3(256), 4u * kPoolWaveLdsBytes, stream, p);
+        const uint32_t per_group = 4u * (64u + pe->pool_slots), fit = (p.owned_tiles * 256u + per_group - 1u) / per_group;
+        const uint32_t hold = p.pool_cus * pe->min_waves; // (min_waves 256-thread workgroups per CU)
+        const uint32_t groups = fit < hold ? (fit ? fit : 1u) : hold;
+        hipLaunchKernelGGL(fn, dim3(groups, 1), dim3(256), pool_group_lds_bytes(pe->pool_slots, pe->pool_stages), stream, p);
         return hipGetLastError();
     }
     if (is_path_kernel(fn)) {

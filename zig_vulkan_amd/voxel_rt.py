@@ -328,6 +328,15 @@ class VoxelRT:
     def wait(self) -> None:
         self._check(self._lib.vrt_wait(self._h))
 
+    def region_begin(self) -> None:
+        self._check(self._lib.vrt_region_begin(self._h))
+
+    def region_end(self) -> float:
+        """Milliseconds the dispatches since region_begin() took on the device (HIP events on both streams)."""
+        ms = C.c_double()
+        self._check(self._lib.vrt_region_end(self._h, C.byref(ms)))
+        return float(ms.value)
+
     def last_kernel_ms(self) -> float:
         return self._lib.vrt_last_kernel_ms(self._h)
 
