@@ -266,7 +266,7 @@ def test_bounce_frames_of_a_path_kernel_context_go_through_the_pipeline_on_the_l
         W.set_view(plain, v)
         plain.draw()
         ref[v] = plain.read_rgba8().copy()
-    assert plain.kernel_name() == "vrt_path_kernel<8, 5, false, false, false, false, 2>"
+    assert plain.kernel_name() == "vrt_pool_kernel<8, 5, 64, 2>"   # (round 4: a pool of rays per wave where the counter-free walk would run on 8^3 bricks)
     plain.deinit()
     world = 2
     uid = b"fake-rccl-path" + os.urandom(16) + bytes(128 - 30)

@@ -60,9 +60,9 @@ def test_cfg3_4k_1024c_four_rays_per_pixel():
 
 def test_cfg4_4k_2048c_sparse_path_trace():
     # the first frame is traced on the dilated cell index with steps-left counters and compared with the oracle; behind it the host
-    # knows that the spheres fill the grid, and the second frame — the counter-free twin's — must be the same bytes
+    # knows that the spheres fill the grid, and the second frame — vrt_pool_kernel's (round 4: a pool of 128 rays per wave) — must be the same bytes
     _sampled_parity("cfg4_4k_2048c_b8_sparse", "V1", 3000,
-                    kernels=("vrt_path_kernel<8, 5, false, false, false, false, 1>", "vrt_path_kernel<8, 5, false, false, false, false, 2>"))
+                    kernels=("vrt_path_kernel<8, 5, false, false, false, false, 1>", "vrt_pool_kernel<8, 5, 64, 2>"))
 
 
 def test_grid_edits_reach_the_next_dispatch():

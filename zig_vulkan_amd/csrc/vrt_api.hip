@@ -45,7 +45,8 @@ hipError_t launch_build_status_bytes(const TraceParams &p, hipStream_t stream);
 hipError_t launch_build_status_halfblocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_build_cell_distance(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_build_cell_bounds(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
-hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, hipStream_t stream);
+hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, uint64_t cell_lo, uint64_t cell_hi, uint64_t slot_lo,
+                                       uint64_t slot_hi, hipStream_t stream);
 hipError_t launch_check_start_is_slot(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, hipStream_t stream);
 hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
                           void *out_f32, hipStream_t stream);
@@ -195,7 +196,11 @@ struct vrt_ctx {
     uint32_t *d_status_halfblocks = nullptr; // derived: status bits by 4 x 4 x 2 cells per word (vrt_path_kernel on eligible grids)
     uint8_t *d_cell_occupancy = nullptr;     // derived: occupancy bits by cell (TraceParams::cell_occupancy; vrt_path_kernel, within a memory budget)
     uint32_t *d_start_is_slot = nullptr;     // derived: 1 = binding 6 holds slot * B^3 for every allocated brick (TraceParams::start_is_slot)
-    bool occupancy_dirty = true;             // bindings 3-5 changed since the by-cell copy was built
+    bool occupancy_dirty = true;             // bindings 3-5 changed since the by-cell copy was built ...
+    // ... in these ranges (the reference issues a single-brick delta every frame, VoxelRT.zig:107-172; the copy is then
+    // refreshed for the cells and brick slots it names, not gathered anew over the whole grid): cells whose status bit / brick index
+    // changed and brick slots whose occupancy bytes changed, both [lo, hi); lo >= hi: none
+    uint64_t occ_cell_lo = 0, occ_cell_hi = ~0ull, occ_slot_lo = 0, occ_slot_hi = 0;
     bool start_dirty = true;                 // binding 6 changed since it was checked
     vrt::TileOwnership own{};        // weighted tile ownership (period 0: tile t belongs to rank t % shard_count)
     bool status_dirty = true;        // brick_status changed since the derived copy was built
@@ -847,10 +852,18 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         // is a chain of dependent misses): at most 2 GiB, and — walked in global memory instead of LDS — a 32-bit bit index
         const uint64_t by_cell_bytes = cells * (bits / 8u);
         const bool lds_walk = cfg->brick_dimension == 8u && !(cfg->tuning_flags & VRT_TUNE_NO_PATH_BRICK_LDS);
+        // (an optional structure — within a quarter of the memory that is free now, and a failed allocation means "no
+        // by-cell copy", not a failed vrt_create: the kernels then reach a brick's bits through brick_index as the shader does)
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0;
         if (any_kernel([](const vrt::KernelEntry &e) { return e.path != 0; }) && !(cfg->tuning_flags & VRT_TUNE_NO_CELL_OCCUPANCY) &&
-            by_cell_bytes <= (2ull << 30) && (lds_walk || cells * bits <= (1ull << 32))) {
-            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_cell_occupancy), by_cell_bytes + 64u));
-            VRT_CREATE_HIP(hipMemsetAsync(c->d_cell_occupancy, 0, by_cell_bytes + 64u, c->stream));
+            by_cell_bytes <= (2ull << 30) && by_cell_bytes + 64u <= mem_free / 4u && (lds_walk || cells * bits <= (1ull << 32))) {
+            if (hipMalloc(reinterpret_cast<void **>(&c->d_cell_occupancy), by_cell_bytes + 64u) != hipSuccess) {
+                (void)hipGetLastError();
+                c->d_cell_occupancy = nullptr;
+            } else {
+                VRT_CREATE_HIP(hipMemsetAsync(c->d_cell_occupancy, 0, by_cell_bytes + 64u, c->stream));
+            }
         }
         if (!(cfg->tuning_flags & VRT_TUNE_NO_START_SHORTCUT)) {
             VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_start_is_slot), 64u));
@@ -994,10 +1007,22 @@ uint64_t vrt_buffer_size(const vrt_ctx *ctx, vrt_buffer_id id) {
 }
 
 // which derived structures a write to scene buffer `id` invalidates (rebuilt before the next frame, pre_dispatch)
-static void mark_dirty(vrt_ctx *ctx, vrt_buffer_id id) {
+static void mark_dirty(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, uint64_t nbytes) {
     if (id == VRT_BUF_BRICK_STATUS) ctx->status_dirty = true;
-    if (id == VRT_BUF_BRICK_STATUS || id == VRT_BUF_BRICK_INDEX || id == VRT_BUF_BRICK_OCCUPANCY) ctx->occupancy_dirty = true;
     if (id == VRT_BUF_BRICK_START_INDEX) ctx->start_dirty = true;
+    if (id != VRT_BUF_BRICK_STATUS && id != VRT_BUF_BRICK_INDEX && id != VRT_BUF_BRICK_OCCUPANCY) return;
+    auto widen = [](uint64_t &lo, uint64_t &hi, uint64_t a, uint64_t b) {
+        if (lo >= hi) lo = a, hi = b;
+        else lo = std::min(lo, a), hi = std::max(hi, b);
+    };
+    const uint64_t end = byte_offset + nbytes;
+    if (id == VRT_BUF_BRICK_STATUS) widen(ctx->occ_cell_lo, ctx->occ_cell_hi, byte_offset * 8u, end * 8u);
+    else if (id == VRT_BUF_BRICK_INDEX) widen(ctx->occ_cell_lo, ctx->occ_cell_hi, byte_offset / 4u, (end + 3u) / 4u);
+    else {
+        const uint64_t brick_bytes = (uint64_t)ctx->cfg.brick_dimension * ctx->cfg.brick_dimension * ctx->cfg.brick_dimension / 8u;
+        widen(ctx->occ_slot_lo, ctx->occ_slot_hi, byte_offset / brick_bytes, (end + brick_bytes - 1u) / brick_bytes);
+    }
+    ctx->occupancy_dirty = true;
 }
 
 static int check_range(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, const void *src, uint64_t nbytes) {
@@ -1017,7 +1042,7 @@ int vrt_upload(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, const void 
         // the kernel takes the UBO through its argument block; keep the host mirror current
         std::memcpy(reinterpret_cast<uint8_t *>(&ctx->params.grid) + byte_offset, src, (size_t)nbytes);
     }
-    mark_dirty(ctx, id);
+    mark_dirty(ctx, id, byte_offset, nbytes);
     return copy_h2d(ctx, static_cast<uint8_t *>(ctx->dbuf[id]) + byte_offset, src, nbytes);
 }
 
@@ -1030,7 +1055,7 @@ int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, cons
                                     ctx->stream));
         VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    mark_dirty(ctx, id);
+    mark_dirty(ctx, id, byte_offset, nbytes);
     const int rcb = begin_scene_write(ctx);
     if (rcb != VRT_OK) return rcb;
     VRT_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->dbuf[id]) + byte_offset, dev_src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1098,12 +1123,15 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
     if ((ctx->occupancy_dirty && ctx->d_cell_occupancy) || (ctx->start_dirty && ctx->d_start_is_slot)) {
         int rcw = begin_scene_write(ctx);
         if (rcw != VRT_OK) return rcw;
-        if (ctx->occupancy_dirty) VRT_HIP(ctx, vrt::launch_build_cell_occupancy(ctx->params, ctx->cfg.brick_dimension, ctx->cfg.brick_alloc, ctx->stream));
+        if (ctx->occupancy_dirty)
+            VRT_HIP(ctx, vrt::launch_build_cell_occupancy(ctx->params, ctx->cfg.brick_dimension, ctx->cfg.brick_alloc, ctx->occ_cell_lo, ctx->occ_cell_hi, ctx->occ_slot_lo,
+                                                          ctx->occ_slot_hi, ctx->stream));
         if (ctx->start_dirty) VRT_HIP(ctx, vrt::launch_check_start_is_slot(ctx->params, ctx->cfg.brick_dimension, ctx->cfg.brick_alloc, ctx->stream));
         rcw = end_scene_write(ctx);
         if (rcw != VRT_OK) return rcw;
     }
     ctx->occupancy_dirty = ctx->start_dirty = false;
+    ctx->occ_cell_lo = ctx->occ_cell_hi = ctx->occ_slot_lo = ctx->occ_slot_hi = 0;
     // max_bounce <= 1 ("only primary ray" + its shadow ray): the bounce loop runs at most once
     *fn = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? ctx->kernel_single1 : ctx->kernel_single) : ctx->kernel;
     if (ctx->bounds_pending && hipEventQuery(ctx->ev_bounds) == hipSuccess) {
@@ -1799,7 +1827,7 @@ int vrt_dist_broadcast(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, uin
         VRT_HIP(ctx, hipMemcpyAsync(reinterpret_cast<uint8_t *>(&ctx->params.grid) + byte_offset, range, nbytes, hipMemcpyDeviceToHost, ctx->stream));
         VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    mark_dirty(ctx, id);
+    mark_dirty(ctx, id, byte_offset, nbytes);
     return end_scene_write(ctx);
 }
 

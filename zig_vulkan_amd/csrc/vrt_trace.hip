@@ -118,15 +118,19 @@ __global__ __launch_bounds__(256) void vrt_build_status_bytes(const uint32_t *__
 
 // The occupancy bits of every occupied cell's brick, stored by cell (TraceParams::cell_occupancy): one thread per 8-byte word of
 // the copy; words8 = B^3 / 64 words per brick.  Cells whose status bit is clear are never read by the kernels and are left alone.
+// Refresh: the cells [scan_lo, scan_hi) are looked at; a cell's words are copied if it lies in [cell_lo, cell_hi) (its status bit or
+// brick index was written) or its brick's slot in [slot_lo, slot_hi) (that brick's occupancy bytes were written).
 __global__ __launch_bounds__(256) void vrt_build_cell_occupancy(const uint32_t *__restrict__ status, const uint32_t *__restrict__ brick_index,
-                                                                const uint2 *__restrict__ occupancy, uint2 *__restrict__ out, uint32_t cells,
-                                                                uint32_t words8, uint64_t brick_alloc) {
-    const uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+                                                                const uint2 *__restrict__ occupancy, uint2 *__restrict__ out, uint64_t scan_lo, uint64_t scan_hi,
+                                                                uint32_t words8, uint64_t brick_alloc, uint64_t cell_lo, uint64_t cell_hi, uint64_t slot_lo,
+                                                                uint64_t slot_hi) {
+    const uint64_t w = scan_lo * words8 + (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const uint64_t cell = w / words8;
-    if (cell >= cells) return;
+    if (cell >= scan_hi) return;
     if (!((status[cell >> 5] >> (cell & 31u)) & 1u)) return;
     const uint32_t slot = brick_index[cell];
     if (slot >= brick_alloc) return; // (malformed scene: the shader would read outside binding 5)
+    if (!((cell >= cell_lo && cell < cell_hi) || (slot >= slot_lo && slot < slot_hi))) return;
     out[w] = occupancy[(uint64_t)slot * words8 + (w % words8)];
 }
 
@@ -619,13 +623,21 @@ hipError_t launch_build_cell_distance(const TraceParams &p, uint32_t dim_x, uint
 #endif
 }
 
-hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, hipStream_t stream) {
+hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, uint64_t cell_lo, uint64_t cell_hi, uint64_t slot_lo,
+                                       uint64_t slot_hi, hipStream_t stream) {
     if (!p.cell_occupancy) return hipSuccess;
     const uint32_t words8 = brick_dimension * brick_dimension * brick_dimension / 64u;
-    const uint64_t words = (uint64_t)p.status_cells * words8;
+    const uint64_t cells = p.status_cells;
+    cell_hi = cell_hi < cells ? cell_hi : cells;
+    // written brick slots may belong to any cell: every cell is looked at (a read of its status bit and index), the named ones copied;
+    // written cells only: those cells
+    const bool any_slot = slot_lo < slot_hi;
+    const uint64_t scan_lo = any_slot ? 0u : (cell_lo < cell_hi ? cell_lo : 0u), scan_hi = any_slot ? cells : (cell_lo < cell_hi ? cell_hi : 0u);
+    if (scan_lo >= scan_hi) return hipSuccess;
+    const uint64_t words = (scan_hi - scan_lo) * words8;
     hipLaunchKernelGGL(vrt_build_cell_occupancy, dim3((uint32_t)((words + 255u) / 256u)), dim3(256), 0, stream, p.brick_status, p.brick_index,
-                       reinterpret_cast<const uint2 *>(p.brick_occupancy), reinterpret_cast<uint2 *>(const_cast<uint8_t *>(p.cell_occupancy)), p.status_cells,
-                       words8, brick_alloc);
+                       reinterpret_cast<const uint2 *>(p.brick_occupancy), reinterpret_cast<uint2 *>(const_cast<uint8_t *>(p.cell_occupancy)), scan_lo, scan_hi,
+                       words8, brick_alloc, cell_lo, cell_hi, slot_lo, slot_hi);
     return hipGetLastError();
 }
 
