@@ -49,36 +49,101 @@ VRT_DI uint32_t unorm8p(float c) {
     return (uint32_t)__builtin_rintf(c * 255.0f);
 }
 
+// Round 4: the pass took 0.40 ms per 1080p frame — longer than the headline's trace (0.13 ms along the reference's benchmark path) — at
+// ~500 instructions per tap: two integer `%` per texel coordinate (wrap), twelve IEEE divisions by 255 per tap, three generic pow()
+// per tap, and the spiral's per-sample arithmetic (rotation, sqrt, a pow) recomputed by every pixel although it depends on the sample
+// index alone.  Now: the per-sample constants (texel offset, cubed distance weight) are computed once per workgroup into LDS by the
+// SAME operations (bit-equal); coordinates wrap by one conditional add / subtract (a tap lies within a few texels of the image);
+// c / 255 is c * (1 / 255) (<= 1 ulp); pow(x, 8) is three squarings and pow(x, t) for integer t <= 64 a chain of squarings, v_exp /
+// v_log otherwise (<= 2e-6 relative).  The tolerance of the pass is 1e-4 per channel (tests/test_denoise.py, tests/test_ref_gl.py).
+constexpr int kDenoiseTable = 256; // per-sample constants held in LDS (more samples: computed in place)
+
+VRT_DI int wrap_near(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); } // i in [-n, 2n)
+VRT_DI f3 texel_rgb(const uchar4 *__restrict__ img, int W, int j, int i) {
+    const uchar4 p = img[(size_t)j * W + i];
+    const float k = 1.0f / 255.0f;
+    return mk3((float)p.x * k, (float)p.y * k, (float)p.z * k);
+}
+template <bool NEAR>
+VRT_DI f3 sample_bilinear_fast(const uchar4 *__restrict__ img, int W, int H, float u, float v) {
+    const float s = u * (float)W - 0.5f, t = v * (float)H - 0.5f;
+    const float fs = __builtin_floorf(s), ft = __builtin_floorf(t);
+    const float a = s - fs, b = t - ft;
+    const int i0 = NEAR ? wrap_near((int)fs, W) : wrap_repeat((int)fs, W), i1 = NEAR ? wrap_near((int)fs + 1, W) : wrap_repeat((int)fs + 1, W);
+    const int j0 = NEAR ? wrap_near((int)ft, H) : wrap_repeat((int)ft, H), j1 = NEAR ? wrap_near((int)ft + 1, H) : wrap_repeat((int)ft + 1, H);
+    const f3 p00 = texel_rgb(img, W, j0, i0), p10 = texel_rgb(img, W, j0, i1), p01 = texel_rgb(img, W, j1, i0), p11 = texel_rgb(img, W, j1, i1);
+    return mk3(mix1(mix1(p00.x, p10.x, a), mix1(p01.x, p11.x, a), b), mix1(mix1(p00.y, p10.y, a), mix1(p01.y, p11.y, a), b),
+               mix1(mix1(p00.z, p10.z, a), mix1(p01.z, p11.z, a), b));
+}
+// max(a, 0) ^ e: by squarings when e is a small whole number (wave-uniform), else exp2(e * log2(a))
+VRT_DI float pow_whole(float a, int e) {
+    a = gl_max(a, 0.0f);
+    float r = 1.0f, q = a;
+    for (int k = e; k > 0; k >>= 1) { // (uniform trip count)
+        if (k & 1) r *= q;
+        q *= q;
+    }
+    return r;
+}
+// normalize() and length() of a tap through the hardware's reciprocal square root / square root (<= 1 ulp; 0 -> inf -> NaN as in IEEE)
+VRT_DI f3 normalize_fast(f3 a) { return a * __builtin_amdgcn_rsqf(dot3(a, a)); }
+VRT_DI float length_fast(f3 a) { return __builtin_amdgcn_sqrtf(dot3(a, a)); }
+VRT_DI float pow_fast(float a, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(gl_max(a, 0.0f))); }
+
+// NEAR: every tap lies within one image width / height of the image (the launcher checks the spiral's radius): one conditional wrap
+template <bool NEAR>
 __global__ __launch_bounds__(256) void vrt_denoise_kernel(const uchar4 *__restrict__ img, int W, int H, DenoiseParams pc, int out_w, int out_h,
                                                           uint32_t *__restrict__ out_u8, float4 *__restrict__ out_f32) {
+    __shared__ float tab_x[kDenoiseTable], tab_y[kDenoiseTable], tab_w[kDenoiseTable];
+    const float cosg = -0.7373688f, sing = 0.6754904f; // cos/sin(GOLDEN_ANGLE), image.frag:25,29
+    const float sample_radius = __builtin_sqrtf((float)pc.samples);
+    const float sample_true_radius = 0.5f / (sample_radius * sample_radius);
+    const float spx = 1.0f / (float)W, spy = 1.0f / (float)H;
+    // sample k of the spiral (image.frag:45-55): its texel offset and its distance weight, cubed — the sample index is all they depend on
+    auto spiral = [&](int k, float &rx, float &ry, float &ox, float &oy, float &wgt) {
+        const float nx = rx * cosg + ry * sing, ny = rx * (-sing) + ry * cosg;
+        rx = nx;
+        ry = ny;
+        const float sq = __builtin_sqrtf((float)k);
+        const float px = ((pc.pixel_multiplier * rx) * sq) * 0.5f, py = ((pc.pixel_multiplier * ry) * sq) * 0.5f;
+        float influence = 1.0f - sample_true_radius * ppow(__builtin_fmaf(py, py, px * px), pc.distribution_bias);
+        influence *= influence * influence;
+        ox = px * spx, oy = py * spy, wgt = influence;
+    };
+    const int n = pc.samples + 1; // x = 0 .. samples inclusive (image.frag:45)
+    if (threadIdx.x == 0) {
+        float rx = 0.0f, ry = 1.0f;
+        for (int k = 0; k < n && k < kDenoiseTable; k++) spiral(k, rx, ry, tab_x[k], tab_y[k], tab_w[k]);
+    }
+    __syncthreads();
     // 16x16 output pixels per workgroup: neighbouring lanes fetch neighbouring texels
     const int ox = (int)(blockIdx.x * 16u + (threadIdx.x & 15u));
     const int oy = (int)(blockIdx.y * 16u + (threadIdx.x >> 4));
     if (ox >= out_w || oy >= out_h) return;
-    const float cosg = -0.7373688f, sing = 0.6754904f; // cos/sin(GOLDEN_ANGLE), image.frag:25,29
     const float u = ((float)ox + 0.5f) / (float)out_w, v = ((float)oy + 0.5f) / (float)out_h;
-    const float sample_radius = __builtin_sqrtf((float)pc.samples);
-    const float sample_true_radius = 0.5f / (sample_radius * sample_radius);
-    const float spx = 1.0f / (float)W, spy = 1.0f / (float)H;
-    const f3 center = sample_bilinear(img, W, H, u, v);
+    const f3 center = sample_bilinear_fast<NEAR>(img, W, H, u, v);
     const f3 center_norm = normalize3(center);
     const float center_sat = length3(center);
+    const int hue_whole = (pc.inverse_hue_tolerance >= 0.0f && pc.inverse_hue_tolerance <= 64.0f && pc.inverse_hue_tolerance == __builtin_floorf(pc.inverse_hue_tolerance))
+                              ? (int)pc.inverse_hue_tolerance : -1;
     f3 denoised = mk3(0, 0, 0);
     float influence_sum = 0.0f;
-    float rx = 0.0f, ry = 1.0f;
-    for (float x = 0.0f; x <= (float)pc.samples; x++) { // image.frag:45
-        const float nx = rx * cosg + ry * sing, ny = rx * (-sing) + ry * cosg;
-        rx = nx;
-        ry = ny;
-        const float sq = __builtin_sqrtf(x);
-        float px = ((pc.pixel_multiplier * rx) * sq) * 0.5f, py = ((pc.pixel_multiplier * ry) * sq) * 0.5f;
-        float influence = 1.0f - sample_true_radius * ppow(__builtin_fmaf(py, py, px * px), pc.distribution_bias);
-        px *= spx;
-        py *= spy;
-        const f3 c = sample_bilinear(img, W, H, u + px, v + py);
-        influence *= influence * influence;
-        influence *= ppow(0.5f + 0.5f * dot3(center_norm, normalize3(c)), pc.inverse_hue_tolerance) *
-                     ppow(1.0f - __builtin_fabsf(length3(c) - __builtin_fabsf(center_sat)), 8.0f);
+    float rx = 0.0f, ry = 1.0f; // (only walked beyond the table)
+    for (int k = 0; k < n; k++) {
+        float px, py, influence;
+        if (k < kDenoiseTable) px = tab_x[k], py = tab_y[k], influence = tab_w[k];
+        else {
+            if (k == kDenoiseTable) { // catch up with the spiral's rotation
+                rx = 0.0f, ry = 1.0f;
+                float a, b, c;
+                for (int q = 0; q < kDenoiseTable; q++) spiral(q, rx, ry, a, b, c);
+            }
+            spiral(k, rx, ry, px, py, influence);
+        }
+        const f3 c = sample_bilinear_fast<NEAR>(img, W, H, u + px, v + py);
+        const float hue = 0.5f + 0.5f * dot3(center_norm, normalize_fast(c));
+        const float sat = 1.0f - __builtin_fabsf(length_fast(c) - __builtin_fabsf(center_sat));
+        influence *= (hue_whole >= 0 ? pow_whole(hue, hue_whole) : pow_fast(hue, pc.inverse_hue_tolerance)) * pow_whole(sat, 8);
         influence_sum += influence;
         denoised = denoised + c * influence;
     }
@@ -92,8 +157,12 @@ hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias
                           void *out_f32, hipStream_t stream) {
     const dim3 grid((out_w + 15) / 16, (out_h + 15) / 16);
     const DenoiseParams pc{samples, bias, mult, tol};
-    hipLaunchKernelGGL(vrt_denoise_kernel, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8,
-                       (float4 *)out_f32);
+    // the farthest tap: |pixel_multiplier| * sqrt(samples) / 2 texels from the pixel's own (image.frag:49-50), + the bilinear footprint
+    const float reach = __builtin_fabsf(mult) * __builtin_sqrtf((float)samples) * 0.5f + 3.0f;
+    if (reach < (float)(W < H ? W : H))
+        hipLaunchKernelGGL(vrt_denoise_kernel<true>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
+    else
+        hipLaunchKernelGGL(vrt_denoise_kernel<false>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
     return hipGetLastError();
 }
 
