@@ -973,6 +973,19 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.tile_cost = c->d_tile_cost;
     p.tile_schedule = c->d_tile_schedule;
     p.wave_groups = (cfg->kernel_variant >> 20) & 0x1u;
+    {
+        // small frames (configs[0], 256 tiles = one wave per SIMD, lasts as long as its slowest wave's chain): when the
+        // frame's waves do not fill the SIMDs twice, every tile goes to two workgroups of 32-lane waves
+        int cus2 = 0;
+        if (hipDeviceGetAttribute(&cus2, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus2 <= 0) cus2 = 256;
+        const uint32_t waves = sh.owned_tiles * 4u, simds = 4u * (uint32_t)cus2;
+        const bool eligible = c->order_auto && c->tile_order == 3u && !p.wave_groups && sh.shard_count == 1u && !(cfg->tuning_flags & VRT_TUNE_NO_SMALL_FRAME_SPLIT) &&
+                              (vrt::resolve_variant(cfg->kernel_variant) & 0xFFu) != vrt::kVariantLinearLds512;
+        // (configs[0], same box, us per frame V0 / V1 / V2 / V1x: whole tiles 16.3 / 24.0 / 27.3 / 28.6, halves 15.7 / 21.8 / 23.8 / 25.8,
+        // quarters 16.7 / 21.5 / 24.1 / 23.4, eighths 16.4 / 23.3 / 25.4 / 24.1: halves; the rest of such a frame is its launch and the
+        // fixed part of a wave's chain — the status bits in LDS change nothing, tools/small_frame_ab.py)
+        p.split_all = (eligible && waves <= 2u * simds) ? 1u : 0u;
+    }
     p.brick_batch = (cfg->kernel_variant >> 24) & 0xFu ? ((cfg->kernel_variant >> 24) & 0xFu) * 4u : 8u; // tuning knob: units of 4 lanes
     p.path_brick_batch = (cfg->kernel_variant >> 24) & 0xFu ? ((cfg->kernel_variant >> 24) & 0xFu) * 4u : 32u; // vrt_path_kernel: waiting is cheap there
     p.block_threads = ((vrt::resolve_variant(c->cfg.kernel_variant) & 0xFFu) == vrt::kVariantLinearLds512) ? 512u : 256u;
@@ -1481,7 +1494,10 @@ int vrt_trace_wave_timeline(vrt_ctx *ctx, const vrt_camera_device *camera, const
     VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), bytes));
     VRT_HIP(ctx, hipMemsetAsync(d, 0, bytes, ctx->stream));
     ctx->params.wave_timeline = d;
+    const uint32_t split_all = ctx->params.split_all;
+    ctx->params.split_all = 0u; // (one row of the timeline per wave of a whole tile)
     const int rc = do_dispatch(ctx, camera, sun, 1, true);
+    ctx->params.split_all = split_all;
     ctx->params.wave_timeline = nullptr;
     if (rc != VRT_OK) {
         (void)hipFree(d);
@@ -1633,6 +1649,7 @@ int dist_flush(vrt_ctx *ctx) {
     pk.target_rgba32f = nullptr;
     pk.packed_tiles = 1u;
     pk.packed_rgb = 1u;
+    pk.split_all = 0u; // (the RGB shard store needs all 64 lanes of a wave)
     pk.batch_target_stride = (uint32_t)d->shard_bytes;
     if (sl.marked) dist_collect(d, sl, false); // (profile: the slot's previous launch, if it has finished; else that sample is dropped)
     const bool mark = d->profile;

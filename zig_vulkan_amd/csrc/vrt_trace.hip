@@ -590,6 +590,7 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
     // frame 0 start first
     if (p.block_threads == 512u) hipLaunchKernelGGL(fn, dim3((p.owned_tiles + 1u) / 2u, frames), dim3(512), lds_bytes, stream, p);
     else if (p.wave_groups) hipLaunchKernelGGL(fn, dim3(p.owned_tiles * 4u, frames), dim3(64), lds_bytes, stream, p);
+    else if (p.tile_order == 3u && p.split_all) hipLaunchKernelGGL(fn, dim3(p.owned_tiles << p.split_all, frames), dim3(256), lds_bytes, stream, p);
     else hipLaunchKernelGGL(fn, dim3(p.owned_tiles + (p.tile_order == 5u ? p.sched_extra : 0u), frames), dim3(256), lds_bytes, stream, p);
     return hipGetLastError();
 }

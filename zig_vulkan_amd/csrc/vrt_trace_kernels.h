@@ -2111,7 +2111,10 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     // hardware dispatcher hands 8x8 blocks to whichever SIMD frees a slot (dynamic load balance at
     // wave granularity); otherwise a 256-thread workgroup covers one 16x16 tile with four waves.
     // BLOCK 512: two 16x16 tiles per workgroup share one LDS copy of the status bitmap
-    const uint32_t unit = p.wave_groups ? (blockIdx.x >> 2) : (BLOCK == 512 ? blockIdx.x * 2u + (threadIdx.x >> 8) : blockIdx.x);
+    // p.split_all = s (small frames, reverse raster only): 2^s workgroups per tile, each renders 8 >> s rows of every 8x8 block on
+    // 64 >> s lanes per wave — a frame with fewer waves than the GPU has SIMDs lasts as long as its slowest wave, and a wave walks the
+    // bricks its lanes meet one after the other: fewer lanes, a shorter chain
+    const uint32_t unit = p.wave_groups ? (blockIdx.x >> 2) : (BLOCK == 512 ? blockIdx.x * 2u + (threadIdx.x >> 8) : (blockIdx.x >> p.split_all));
     const uint32_t wave = p.wave_groups ? (blockIdx.x & 3u) : ((threadIdx.x >> 6) & 3u);
     if (BLOCK == 512 && unit >= p.owned_tiles) return; // odd tile count: the last workgroup's second half is idle
     uint32_t owned;
@@ -2138,6 +2141,8 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         // reverse raster, consecutive tiles on consecutive XCDs: every XCD samples the whole image, and
         // the rows that usually hold the ground (long rays) start first so that sky tiles fill the tail
         owned = p.owned_tiles - 1u - unit;
+        split = p.split_all;
+        half = blockIdx.x & ((1u << p.split_all) - 1u);
     } else if (p.tile_order == 4u) {
         // strided permutation: consecutive launches sample the whole image (stride coprime to the count)
         owned = (uint32_t)(((unsigned long long)unit * p.tile_stride) % p.owned_tiles);
@@ -2155,7 +2160,8 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const uint32_t lane = threadIdx.x & 63u;
     const PushConstants &pc = p.pcs[blockIdx.y]; // frame blockIdx.y of this launch (kernarg segment, scalar loads)
     const uint32_t in_x = (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t in_y = (wave >> 1) * 8u + (split ? half * 4u + ((lane >> 3) & 3u) : (lane >> 3));
+    const uint32_t rows = 8u >> split; // rows of its 8x8 block this wave renders (split: 4 or 2), from row `half * rows`
+    const uint32_t in_y = (wave >> 1) * 8u + half * rows + ((lane >> 3) & (rows - 1u));
     const uint32_t px = tile_x * kTileW + in_x;
     const uint32_t py = tile_y * kTileH + in_y;
 
@@ -2167,7 +2173,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const unsigned long long t_begin = (p.tile_order == 5u) ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long wall_begin = p.wave_timeline ? wall_clock64() : 0ull;
     Cnt<COUNT> c;
-    const bool inside = (px < p.width) && (py < p.height) && (!split || lane < 32u); // comp:155-159
+    const bool inside = (px < p.width) && (py < p.height) && (lane < (64u >> split)); // comp:155-159
     uint32_t rgba = 0u; // this lane's pixel (0 outside the image), also needed after the branch by the RGB shard store
     if (inside) {
         f3 color = mk3(0, 0, 0);
