@@ -680,3 +680,26 @@ def test_bench_probe_child_runs_the_native_pipeline_on_real_rccl():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dist-probe", "--probe-uid", uids.hex(), "--probe-rank", "0",
                         "--probe-world", "1", "--probe-device", "0"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]   # (stdout: RCCL's version banner; the parent discards it)
+
+
+def test_small_frames_split_every_tile_and_keep_the_frame():
+    """configs[0] (256 tiles: one wave per SIMD) goes to two workgroups of 32-lane waves per tile (round 4); a frame whose pixels do not
+    fill its last tiles and several samples per pixel as well: the same bytes as one workgroup per tile, and the oracle's."""
+    from zig_vulkan_amd import _lib as L
+    for w in (W.WORKLOADS["cfg0_256x256_64c_b4"], W.Workload("small_odd", 203, 121, 64, 8, 3, 0, True, 5.0)):
+        grid = W.build_grid(w)
+        frames = {}
+        for flags in (0, L.TUNE_NO_SMALL_FRAME_SPLIT):
+            rt = W.make_renderer(w, grid, tuning_flags=flags, want_float_output=True)
+            for v in ("V0", "V2"):
+                W.set_view(rt, v)
+                rt.draw()
+                frames[(flags, v)] = (rt.read_rgba32f().copy(), rt.read_rgba8().copy())
+            if flags == 0:
+                pc = O.push_constants(rt.camera.blob(), rt.sun.blob())   # (view V2)
+            rt.deinit()
+        for v in ("V0", "V2"):
+            assert np.array_equal(frames[(0, v)][0].view(np.uint32), frames[(L.TUNE_NO_SMALL_FRAME_SPLIT, v)][0].view(np.uint32)), (w.name, v)
+            assert np.array_equal(frames[(0, v)][1], frames[(L.TUNE_NO_SMALL_FRAME_SPLIT, v)][1]), (w.name, v)
+        fo, uo, _ = O.render(oracle_scene_from_grid(grid), pc)
+        assert np.array_equal(frames[(0, "V2")][0].view(np.uint32), fo.view(np.uint32)) and np.array_equal(frames[(0, "V2")][1], uo), w.name
