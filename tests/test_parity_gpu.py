@@ -686,7 +686,11 @@ def test_small_frames_split_every_tile_and_keep_the_frame():
     """configs[0] (256 tiles: one wave per SIMD) goes to two workgroups of 32-lane waves per tile (round 4); a frame whose pixels do not
     fill its last tiles and several samples per pixel as well: the same bytes as one workgroup per tile, and the oracle's."""
     from zig_vulkan_amd import _lib as L
-    for w in (W.WORKLOADS["cfg0_256x256_64c_b4"], W.Workload("small_odd", 203, 121, 64, 8, 3, 0, True, 5.0)):
+    # (two samples per pixel in a half-tile workgroup: lanes 32-63 trace the second sample of the pixels of lanes 0-31 — bounces and
+    # soft sun, both brick sizes, and without bounces)
+    for w in (W.WORKLOADS["cfg0_256x256_64c_b4"], W.Workload("small_odd", 203, 121, 64, 8, 3, 0, True, 5.0),
+              W.Workload("small_dual_b4", 203, 121, 64, 4, 2, 2, True, 5.0), W.Workload("small_dual_b8", 190, 131, 128, 8, 2, 1, True, 5.0),
+              W.Workload("small_dual_nobounce", 120, 75, 64, 4, 2, 0, True, 0.0)):
         grid = W.build_grid(w)
         frames = {}
         for flags in (0, L.TUNE_NO_SMALL_FRAME_SPLIT):

@@ -8,9 +8,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from helpers import oracle_scene_from_grid, push_for, O
 
 view = sys.argv[1] if len(sys.argv) > 1 else "V1"
-w = W.WORKLOADS[W.HEADLINE]
+w = W.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 else W.HEADLINE]
 grid = W.build_grid(w)
-rt = W.make_renderer(w, grid)
+rt = W.make_renderer(w, grid, kernel_variant=0x30000, tuning_flags=16384)   # reverse raster, whole tiles: wave -> pixel block is the plain map
 W.set_view(rt, view)
 rt.draw(); rt.wait()
 t = rt.wave_timeline().astype(np.int64)

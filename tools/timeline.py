@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zig_vulkan_amd import workloads as W  # noqa: E402
 
 variant = int(sys.argv[1], 0) if len(sys.argv) > 1 else 0
-w = W.WORKLOADS[W.HEADLINE]
+w = W.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 else W.HEADLINE]
 grid = W.build_grid(w)
 rt = W.make_renderer(w, grid, kernel_variant=variant)
 for view in ["V0", "V1", "V2"]:

@@ -2159,9 +2159,15 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     // lane -> pixel: wave w of the tile covers the 8x8 quadrant (w&1, w>>1)
     const uint32_t lane = threadIdx.x & 63u;
     const PushConstants &pc = p.pcs[blockIdx.y]; // frame blockIdx.y of this launch (kernarg segment, scalar loads)
-    const uint32_t in_x = (wave & 1u) * 8u + (lane & 7u);
+    // A half-tile workgroup of a frame with TWO samples per pixel gives its idle lanes the second sample (round 4): lanes 0-31 trace
+    // sample 0 of the wave's 32 pixels, lanes 32-63 sample 1 of the same pixels, and lane l adds lane l + 32's colour to its own —
+    // (0 + s0) + s1, the sample loop's own sum (comp:173) — before the tone-map.  The slowest waves of a bounce frame (the frame lasts
+    // as long as they do: the reference app's run, tools/timeline.py) then have half the GridHits to go through one after the other.
+    const bool dual = SHADE != 2 && !COUNT && split == 1u && !p.packed_rgb && pc.cam.samples_per_pixel == 2; // (uniform over the workgroup)
+    const uint32_t plane = dual ? (lane & 31u) : lane;
+    const uint32_t in_x = (wave & 1u) * 8u + (plane & 7u);
     const uint32_t rows = 8u >> split; // rows of its 8x8 block this wave renders (split: 4 or 2), from row `half * rows`
-    const uint32_t in_y = (wave >> 1) * 8u + half * rows + ((lane >> 3) & (rows - 1u));
+    const uint32_t in_y = (wave >> 1) * 8u + half * rows + ((plane >> 3) & (rows - 1u));
     const uint32_t px = tile_x * kTileW + in_x;
     const uint32_t py = tile_y * kTileH + in_y;
 
@@ -2173,7 +2179,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const unsigned long long t_begin = (p.tile_order == 5u) ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long wall_begin = p.wave_timeline ? wall_clock64() : 0ull;
     Cnt<COUNT> c;
-    const bool inside = (px < p.width) && (py < p.height) && (lane < (64u >> split)); // comp:155-159
+    const bool inside = (px < p.width) && (py < p.height) && (dual || lane < (64u >> split)); // comp:155-159
     uint32_t rgba = 0u; // this lane's pixel (0 outside the image), also needed after the branch by the RGB shard store
     if (inside) {
         f3 color = mk3(0, 0, 0);
@@ -2191,7 +2197,8 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
             const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
             color = mk3(0, 0, 0) + ray_color_single<B, COUNT, MODE>(p, pc, lds_filter, create_ray(origin, ray_dir), c);
         } else {
-            for (int sample_i = 0; sample_i < spp; sample_i++) {
+            const int sample_begin = dual ? (int)(lane >> 5) : 0, sample_end = dual ? sample_begin + 1 : spp;
+            for (int sample_i = sample_begin; sample_i < sample_end; sample_i++) {
                 // Re-derive the camera vectors from their SGPRs in every trip: a VALU op takes a single scalar
                 // operand, so the compiler copies them to VGPRs — hoisted out of this loop, twelve copies would
                 // stay live across the whole traversal and cost a wave per SIMD.
@@ -2209,6 +2216,14 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
                 else color = color + ray_color<B, COUNT, MODE>(p, pc, lds_filter, create_ray(origin, ray_dir), c);
             }
         }
+        bool writer = true;
+        if constexpr (SHADE != 2 && !COUNT) {
+            if (dual) { // (both lanes of a pixel are inside the image or neither is: the source lane is active)
+                const f3 second = mk3(__shfl(color.x, (int)lane + 32, 64), __shfl(color.y, (int)lane + 32, 64), __shfl(color.z, (int)lane + 32, 64));
+                color = color + second;
+                writer = lane < 32u;
+            }
+        }
         const float fspp = (float)spp;
         color = mk3(__builtin_sqrtf(color.x / fspp), __builtin_sqrtf(color.y / fspp), __builtin_sqrtf(color.z / fspp));
 
@@ -2219,9 +2234,11 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
             o = (size_t)py * p.width + px; // row-major frame
         }
         rgba = unorm8(color.x) | (unorm8(color.y) << 8) | (unorm8(color.z) << 16) | (255u << 24);
-        if (!p.packed_rgb) reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] = rgba;
-        if (p.target_rgba32f) {
-            reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(color.x, color.y, color.z, 1.0f);
+        if (writer) {
+            if (!p.packed_rgb) reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] = rgba;
+            if (p.target_rgba32f) {
+                reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(color.x, color.y, color.z, 1.0f);
+            }
         }
     }
     if (p.packed_rgb) {
