@@ -58,6 +58,18 @@ __global__ __launch_bounds__(256) void k_walk(const uint32_t *status, uint32_t s
         grid_walk_park_gfx950(w, inv, index, cell, 1u, 64u * 64u, 64u, word, rsrc, g);
         t1 = __builtin_readcyclecounter();
         trips = (uint32_t)((steps - w.rx) + (steps - w.ry) + (steps - w.rz));
+    } else if constexpr (VARIANT == 4) {
+        // the park loop two trips ahead (grid_walk_ahead_gfx950): a ring of three cells per lane, two requests in flight
+        AheadRing ring{index, index + 1u, index + 2u, 0u, 0u, 0u, 0u, 2u, 0.0f, 0.0f, 0.0f};
+        AheadWalkRegs g;
+        g.alive = ~0ull;
+        g.batch = 64u;
+        g.min_alive = 0u;
+        t0 = __builtin_readcyclecounter();
+        grid_walk_ahead_gfx950(w, inv, ring, 1u, 64u * 64u, 64u, rsrc, g);
+        t1 = __builtin_readcyclecounter();
+        trips = (uint32_t)((steps - w.rx) + (steps - w.ry) + (steps - w.rz));
+        index = ring.q0 + ring.w0;
     } else {
         // dilated index of a 2^k-cell grid: x field bits 0-1 + 5.., z bits 2-3 + .., y bit 4 + ..; the walk ends when a field overflows
         const uint32_t lx = 10u, lz = 10u, ly = 10u; // 1024^3 cells: `steps` trips never reach a face from the middle
@@ -205,6 +217,7 @@ int main() {
     run<1>("grid_walk_bytes_gfx950 (byte per cell)", d_status, words, d_out, steps);
     run<2>("grid_walk_park_gfx950 (words, parking)", d_status, words, d_out, steps);
     run<3>("grid_walk_park_dilated_carry_gfx950 (pool)", d_status, words, d_out, steps);
+    run<4>("grid_walk_ahead_gfx950 (words, two ahead)", d_status, words, d_out, steps);
     run<100>("candidate: selects on the vector unit (bytes)", d_status, words, d_out, steps);
     return 0;
 }
