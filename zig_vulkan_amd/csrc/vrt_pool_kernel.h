@@ -29,7 +29,7 @@
 // Only the configuration the 2048^3 path trace runs: 8^3 bricks staged in LDS, the counter-free dilated-index walk (all three grid
 // dimensions powers of two, the walk ends at the grid's face: vrt_path_kernel<..., DIL 2>'s loop).  Everything else keeps
 // vrt_path_kernel.
-#include "vrt_trace_kernels.h"
+#include "vrt_path_kernel.h"
 
 namespace vrt {
 

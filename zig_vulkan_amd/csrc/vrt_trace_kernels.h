@@ -13,7 +13,9 @@
 //   * frames with bounces on scenes larger than the caches: persistent lanes (vrt_path_kernel), bricks staged in LDS,
 //     status bits read by 4 x 4 x 2-cell words;
 //   * workgroups are handed tiles in an order that follows their measured cost (vrt_schedule_kernel), round-robin over XCDs.
-// Variants that lost their A/B measurement are compiled only with -DVRT_DEV_VARIANTS (make dev).
+// Variants that lost their A/B measurement are compiled only with -DVRT_DEV_VARIANTS (make dev): their loops live in
+// vrt_trace_kernels_dev.h, included section by section at the places they were measured from.  The persistent-lane kernel of round 2
+// is vrt_path_kernel.h, round 4's pool of rays per wave vrt_pool_kernel.h.
 #include <hip/hip_runtime.h>
 #include "vrt_internal.h"
 #include "vrt_kernels.h"
@@ -272,14 +274,11 @@ struct GridWalkRegs {
     "s_mov_b64 exec, %[cz]\n\t"                                          \
     "s_waitcnt vmcnt(1)\n\t"
 #define VRT_WAIT_BUFFER "s_waitcnt vmcnt(0)\n\t"
-#define VRT_LOAD_LDS_A(IDX, IDXN, WORD, WORDN)                                       \
-    "s_mov_b64 %[cz], exec\n\t"                                          \
-    "v_lshrrev_b32_e32 %[t2], 3, %[" IDXN "]\n\t"                         \
-    "v_and_b32_e32 %[t2], %[rsrc], %[t2]\n\t"                             \
-    "ds_read_b32 %[" WORDN "], %[t2]\n\t"
-#define VRT_LOAD_LDS_B(IDX, IDXN, WORD, WORDN)                                       \
-    "s_mov_b64 exec, %[cz]\n\t"                                          \
-    "s_waitcnt lgkmcnt(1)\n\t"
+#ifdef VRT_DEV_VARIANTS
+#define VRT_DEV_SECTION 1
+#include "vrt_trace_kernels_dev.h"
+#undef VRT_DEV_SECTION
+#endif
 #define VRT_WAIT_LDS "s_waitcnt lgkmcnt(0)\n\t"
 
 // voxel level only (comp:469): the lane also leaves when the crossed distance, scaled to world units, is not
@@ -356,15 +355,15 @@ VRT_DI void grid_walk_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32
     asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_BUFFER, VRT_TEST_BIT, VRT_WAIT_BUFFER) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
 }
 
-// brick level with the status bitmap in LDS; `rsrc` is the byte-address mask (allocation size - 4)
+#ifdef VRT_DEV_VARIANTS
+#define VRT_DEV_SECTION 2
+#include "vrt_trace_kernels_dev.h"
+#undef VRT_DEV_SECTION
+#else
+// (the status bitmap in LDS, a development variant: declared for the discarded branches of grid_hit)
 VRT_DI void grid_walk_lds_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
-                                 uint32_t &word, uint32_t rsrc, GridWalkRegs &g) {
-    unsigned long long mxya, mxyb, ex, by, cz, save;
-    float t0, t1, t2;
-    uint32_t wordb;
-    asm volatile(VRT_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_LDS, VRT_TEST_BIT, VRT_WAIT_LDS) : VRT_WALK_OUTPUTS : VRT_WALK_INPUTS : "vcc", "scc");
-}
-
+                                 uint32_t &word, uint32_t rsrc, GridWalkRegs &g);
+#endif
 // brick level on the byte-per-cell copy of the status bits: `index` is the byte offset, `word` the byte of the current cell;
 // rsrc: a raw buffer (stride 0) over TraceParams::status_bytes, so that an out-of-grid index reads 0
 VRT_DI void grid_walk_bytes_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
@@ -411,6 +410,52 @@ struct GridParkRegs {
     uint32_t code;
     uint32_t batch;                  // in: the call returns once this many lanes are parked (or nobody is moving)
     uint32_t min_alive = 0;          // in: ... or, at a back edge, once fewer than this many lanes are still moving (0: never)
+};
+
+// state of the development walk loops a lane carries between calls (the loops themselves: vrt_trace_kernels_dev.h)
+// ---- the park loop pipelined TWO trips ahead (vrt_path_kernel<AHEAD>) ---------------------------------------------------------
+// The loops above keep ONE status word in flight per lane: the word of the next cell is requested a trip ahead, and on a scene
+// larger than the caches a wave then waits ~670 cycles per trip for it (tools/path_profile.py: 13 400 cycles per call of ~20 trips,
+// 27 vector instructions per trip, 5 waves per SIMD).  Here the DDA runs two cells ahead of the test: a lane carries a ring of three
+// cells (q0, q1, q2) with their words (w0, w1, w2) and the crossed distances of the steps INTO them (ts0, ts1, ts2); a trip rotates
+// the ring, takes the step out of q1 into the new q2, requests q2's word, waits until at most TWO requests are outstanding — i.e.
+// for the word of q0, asked for two trips ago — and tests q0.  Per lane the sequence of DDA operations is the shader's (comp:345-372),
+// run two steps early.  What that takes:
+//   * a lane whose q0 is occupied PARKS as it is: ring and DDA state stay, the caller walks the brick of q0 (entered through the axis
+//     in `hist` bits 4-5 at distance ts0; the counters of q0 = the current ones with the two later steps' decrements undone) and, if
+//     the brick holds nothing for the ray, the lane simply walks on: its next trip rotates q1 into place.  No roll-back, no re-request;
+//   * a step that leaves the box of the occupied cells puts the SENTINEL ~0 into q2, and so does every later step (q1 == ~0): the
+//     word index of ~0 lies outside the buffer, its word reads 0, its test fails, and when the sentinel reaches q0 the lane has tested
+//     every cell up to the box's face and leaves (`left`).  The cells a lane would "enter" beyond the face are thus never tested
+//     (at a face of the grid the next linear index would be a real cell of the next row);
+//   * `hist`: two bits per step, the axis of the step into q2 in bits 0-1, into q1 in bits 2-3, into q0 in bits 4-5 (3: q0 was entered
+//     without a step — the slab test — at the start of a ray).
+// Canonical state between calls, for every lane: [q0 tested, q1 next to be tested, q2 newest], the DDA state (side distances,
+// counters) that of q2, w1 / w2 arrived.  A new ray is primed in C++ with one step (path kernel, START).
+struct AheadWalkRegs {
+    unsigned long long alive;  // in: lanes to walk; out: lanes still moving when the call ended
+    unsigned long long parked; // out: lanes whose q0 is occupied
+    unsigned long long left;   // out: lanes that have tested every cell up to the face of the box
+    uint32_t batch;            // in: the call returns once this many lanes are parked (or nobody is moving)
+    uint32_t min_alive;        // in: ... or, at the back edge, once fewer than this many lanes are still moving
+};
+// The words travel in THREE registers used in turn (a register with a request in flight cannot be moved): trip k of the unrolled
+// body (k = 0, 1, 2) requests into W[k] and tests W[(k + 1) % 3].  A lane leaves the loop after some trip k — parked, or still
+// moving when the call ends — and `phase` records that k; the caller then puts word(q1) into w1 and word(q2) into w2
+// (AheadRing::settle), which is where trip 0 of the next call expects them.  The cells and distances are moved (computed values).
+struct AheadRing {
+    uint32_t q0, q1, q2, w0, w1, w2, hist, phase;
+    float ts0, ts1, ts2;
+    VRT_DI void settle() { // after a call: phase k -> word(q1) is in W[(k + 2) % 3], word(q2) in W[k]
+        const uint32_t a = phase == 0u ? w2 : (phase == 1u ? w0 : w1), b = phase == 0u ? w0 : (phase == 1u ? w1 : w2);
+        w1 = a;
+        w2 = b;
+        phase = 2u;
+    }
+};
+struct DistRegs {
+    unsigned long long pend; // in/out: lanes whose `word` is an answer for their current cell (the others know it to be empty)
+    int k;                   // per lane, in/out: trips the lane may take before it asks again
 };
 
 #define VRT_PARK(LABEL, PRE, IN_AXIS, OUT_MX, OUT_MY, SWAP, NEXT, EXIT)                                  \
@@ -670,250 +715,16 @@ VRT_DI void grid_walk_park_dilated_carry_gfx950(f3 &side_dist, const f3 &inv_dir
 #undef VRT_LOAD_DILATED_A
 #undef VRT_LOAD_DILATED_B
 #undef VRT_TEST_DILATED
-// ---- the counter-free dilated loop with the DDA TWO cells ahead of the test (vrt_path_kernel<..., DIL 4>, round 3) -----------------
-// The trip of the loops above lasts as long as the round trip of its one request plus the instructions between a word's arrival and
-// the next request: the word of the cell entered in trip k is tested in trip k + 1.  Here it is tested in trip k + 2 —
-// two requests in flight per lane — and the round trip leaves the chain.  Three register sets (x, y, z: cell, word, crossed
-// distance, crossed-axis masks, carry, keep mask) are used in turn, so nothing rotates inside the loop:
-//   trip k (sets K = k % 3, N = next, J = previous):  step c_k -> c_k+1 (idxN), request word(c_k+1) -> wN by the lanes that enter
-//   another half-block (the others, kpN, take it from wK one trip later: a register with a request in flight cannot be read),
-//   advance the side distance; wait until at most two requests are outstanding (word(c_k-1) has arrived); wK <- wJ for kpK;
-//   test c_k-1 in wJ; lanes whose step k - 1 left the grid (cyJ) have now had their last cell tested and leave.
-// Between calls, and for parked lanes, the state is the ONE-ahead loops' (the caller cannot tell the difference): whoever leaves
-// the loop after trip k — parked on c_k-1, or still moving when the call ends — takes step k back (the crossed axis' side distance
-// := the crossed distance of trip k, which IS its old value; the cell := c_k; the carry of that step is forgotten), and a call
-// starts with a trip that tests nothing.  One trip per lane per call and per brick entered is walked twice (about 7 % of the trips
-// of the 2048^3 path trace); per lane the sequence of DDA operations is unchanged.
-#define VRT_A2_HEAD(K, N)                                                                                   \
-    "v_min3_f32 %[ts" K "], %[sdx], %[sdy], %[sdz]\n\t"                                                     \
-    "v_cmp_eq_f32_e64 %[mt], %[sdz], %[ts" K "]\n\t"                                                        \
-    "v_cmp_eq_f32_e64 %[mY" K "], %[sdy], %[ts" K "]\n\t"                                                   \
-    "s_andn2_b64 %[mY" K "], %[mY" K "], %[mt]\n\t"                                                         \
-    "s_andn2_b64 %[mt], exec, %[mt]\n\t"                                                                    \
-    "s_andn2_b64 %[mX" K "], %[mt], %[mY" K "]\n\t"                                                         \
-    "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[mY" K "]\n\t"                                               \
-    "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[mX" K "]\n\t"                                                \
-    "v_or_b32_e32 %[t1], %[idx" K "], %[t0]\n\t"                                                            \
-    "v_add_co_u32_e64 %[t1], %[cy" K "], 1, %[t1]\n\t"                                                      \
-    "v_bfi_b32 %[idx" N "], %[t0], %[idx" K "], %[t1]\n\t"                                                  \
-    "v_xor_b32_e32 %[t2], %[idx" N "], %[idx" K "]\n\t"                                                     \
-    "v_cmp_lt_u32_e64 %[by], 31, %[t2]\n\t"                                                                 \
-    "s_cmp_eq_u64 %[by], 0\n\t"                                                                             \
-    "s_cselect_b64 %[by], exec, %[by]\n\t"                                                                  \
-    "s_and_saveexec_b64 %[cz], %[by]\n\t"                                                                   \
-    "v_xor_b32_e32 %[t2], %[idx" N "], %[flip]\n\t"                                                         \
-    "v_lshrrev_b32_e32 %[t2], 5, %[t2]\n\t"                                                                 \
-    "buffer_load_dword %[w" N "], %[t2], %[rsrc], 0 idxen\n\t"                                              \
-    "s_andn2_b64 %[kp" N "], %[cz], %[by]\n\t"                                                              \
-    "s_mov_b64 exec, %[mX" K "]\n\t"                                                                        \
-    "v_add_f32_e64 %[sdx], %[sdx], |%[ix]|\n\t"                                                             \
-    "s_mov_b64 exec, %[mY" K "]\n\t"                                                                        \
-    "v_add_f32_e64 %[sdy], %[sdy], |%[iy]|\n\t"                                                             \
-    "s_andn2_b64 exec, %[cz], %[mt]\n\t"                                                                    \
-    "v_add_f32_e64 %[sdz], %[sdz], |%[iz]|\n\t"
-#define VRT_A2_TAIL(K, J, PARK)                                                                             \
-    "s_and_b64 exec, %[cz], %[kp" K "]\n\t"                                                                 \
-    "s_waitcnt vmcnt(2)\n\t"                                                                                \
-    "v_mov_b32_e32 %[w" K "], %[w" J "]\n\t"                                                                \
-    "s_mov_b64 exec, %[cz]\n\t"                                                                             \
-    "v_xor_b32_e32 %[t1], %[idx" J "], %[flip]\n\t"                                                         \
-    "v_bfe_u32 %[t1], %[w" J "], %[t1], 1\n\t"                                                              \
-    "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"                                                                    \
-    "s_andn2_b64 exec, exec, %[cy" J "]\n\t"                                                                \
-    "s_cbranch_vccnz " PARK "\n\t"
-// take step K back for the lanes in MASK (a scalar pair; clobbers by, EXEC)
-#define VRT_A2_UNSTEP(K, MASK)                                                                              \
-    "s_and_b64 exec, " MASK ", %[mX" K "]\n\t"                                                              \
-    "v_mov_b32_e32 %[sdx], %[ts" K "]\n\t"                                                                  \
-    "s_and_b64 exec, " MASK ", %[mY" K "]\n\t"                                                              \
-    "v_mov_b32_e32 %[sdy], %[ts" K "]\n\t"                                                                  \
-    "s_or_b64 %[by], %[mX" K "], %[mY" K "]\n\t"                                                            \
-    "s_andn2_b64 exec, " MASK ", %[by]\n\t"                                                                 \
-    "v_mov_b32_e32 %[sdz], %[ts" K "]\n\t"
-// the lanes in vcc have their cell c_k-1 occupied: the one-ahead loops' parked state (see GridParkRegs), step k taken back
-#define VRT_A2_PARK(LABEL, K, J, INAXIS, TSIN, MOVIDX, NEXT, EXIT)                                          \
-    LABEL ":\n\t"                                                                                           \
-    "s_and_b64 %[by], %[cy" J "], vcc\n\t"                                                                  \
-    "s_or_b64 %[gone], %[gone], %[by]\n\t"                                                                  \
-    "s_mov_b64 %[ex], exec\n\t"                                                                             \
-    "s_mov_b64 exec, vcc\n\t"                                                                               \
-    INAXIS                                                                                                  \
-    "v_cndmask_b32_e64 %[t1], 2, 1, %[mY" J "]\n\t"                                                         \
-    "v_cndmask_b32_e64 %[t1], %[t1], 0, %[mX" J "]\n\t"                                                     \
-    "v_lshl_or_b32 %[code], %[t1], 2, %[t0]\n\t"                                                            \
-    "v_mov_b32_e32 %[cell], %[idx" J "]\n\t"                                                                \
-    MOVIDX                                                                                                  \
-    "v_mov_b32_e32 %[tin], " TSIN "\n\t"                                                                    \
-    "v_mov_b32_e32 %[tout], %[ts" J "]\n\t"                                                                 \
-    VRT_A2_UNSTEP(K, "vcc")                                                                                 \
-    "s_or_b64 %[parked], %[parked], vcc\n\t"                                                                \
-    "s_andn2_b64 exec, %[ex], vcc\n\t"                                                                      \
-    "s_bcnt1_i32_b64 %[n], %[parked]\n\t"                                                                   \
-    "s_cmp_ge_u32 %[n], %[batch]\n\t"                                                                       \
-    "s_cbranch_scc1 " EXIT "\n\t"                                                                           \
-    "s_cbranch_execnz " NEXT "\n\t"                                                                         \
-    "s_branch " EXIT "\n\t"
-#define VRT_A2_IN_CODE "v_bfe_u32 %[t0], %[code], 4, 2\n\t"
-#define VRT_A2_IN_SET(I) "v_cndmask_b32_e64 %[t0], 2, 1, %[mY" I "]\n\t" "v_cndmask_b32_e64 %[t0], %[t0], 0, %[mX" I "]\n\t"
-// the call ends after trip K with the lanes in EXEC still moving: step k back, their cell, its word and their last step where the caller looks for them
-#define VRT_A2_EXIT(LABEL, K, J, MOVIDX)                                                                    \
-    LABEL ":\n\t"                                                                                           \
-    "s_mov_b64 %[alive], exec\n\t"                                                                          \
-    "s_waitcnt vmcnt(0)\n\t"                                                                                \
-    VRT_A2_UNSTEP(K, "%[alive]")                                                                            \
-    "s_mov_b64 exec, %[alive]\n\t"                                                                          \
-    MOVIDX                                                                                                  \
-    "v_mov_b32_e32 %[tout], %[ts" J "]\n\t"                                                                 \
-    "s_mov_b64 %[mxb], %[mX" J "]\n\t"                                                                      \
-    "s_mov_b64 %[myb], %[mY" J "]\n\t"                                                                      \
-    "s_branch 99f\n\t"
-VRT_DI void grid_walk_park_dilated_ahead_gfx950(f3 &side_dist, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t nm_x, uint32_t nm_y, uint32_t nm_z,
-                                                uint32_t &word, u32x4 rsrc, GridParkRegs &g, uint32_t flip, unsigned long long &gone) {
-    unsigned long long mXx, mYx, mXy, mYy, mXz, mYz, cyx, cyy, cyz, kpx, kpy, kpz, mt, ex, by, cz, save;
-    float tsx, tsy, tsz, t0, t1, t2;
-    uint32_t idxy, idxz, wy, wz, n;
-    gone = 0ull;
-    asm volatile(
-        "s_mov_b64 %[save], exec\n\t"
-        "s_mov_b64 exec, %[alive]\n\t"
-        "s_mov_b64 %[parked], 0\n\t"
-        "s_mov_b64 %[kpx], 0\n\t"
-        /* trip 0: nothing to test yet */
-        VRT_A2_HEAD("x", "y")
-        "s_mov_b64 exec, %[cz]\n\t"
-        /* trip 1: tests c_0 (its word came with the call; it was entered by the lane's last step before the call: code, tout) */
-        VRT_A2_HEAD("y", "z")
-        VRT_A2_TAIL("y", "x", "10f")
-        "0:\n\t"
-        VRT_A2_HEAD("z", "x")
-        VRT_A2_TAIL("z", "y", "11f")
-        "21:\n\t"
-        VRT_A2_HEAD("x", "y")
-        VRT_A2_TAIL("x", "z", "12f")
-        "22:\n\t"
-        VRT_A2_HEAD("y", "z")
-        VRT_A2_TAIL("y", "x", "13f")
-        "23:\n\t"
-        "s_cbranch_execz 31f\n\t"
-        "s_bcnt1_i32_b64 %[n], exec\n\t"
-        "s_cmp_ge_u32 %[n], %[minalive]\n\t"
-        "s_cbranch_scc1 0b\n\t"
-        "s_branch 31f\n\t"
-        VRT_A2_PARK("10", "y", "x", VRT_A2_IN_CODE, "%[tout]", "v_mov_b32_e32 %[idxx], %[idxy]\n\t", "0b", "31f")
-        VRT_A2_PARK("11", "z", "y", VRT_A2_IN_SET("x"), "%[tsx]", "v_mov_b32_e32 %[idxx], %[idxz]\n\t", "21b", "32f")
-        VRT_A2_PARK("12", "x", "z", VRT_A2_IN_SET("y"), "%[tsy]", "", "22b", "30f")
-        VRT_A2_PARK("13", "y", "x", VRT_A2_IN_SET("z"), "%[tsz]", "v_mov_b32_e32 %[idxx], %[idxy]\n\t", "23b", "31f")
-        VRT_A2_EXIT("30", "x", "z", "")
-        VRT_A2_EXIT("31", "y", "x", "v_mov_b32_e32 %[idxx], %[idxy]\n\t" "v_mov_b32_e32 %[wx], %[wy]\n\t")
-        VRT_A2_EXIT("32", "z", "y", "v_mov_b32_e32 %[idxx], %[idxz]\n\t" "v_mov_b32_e32 %[wx], %[wz]\n\t")
-        "99:\n\t"
-        "s_mov_b64 exec, %[save]"
-        : [sdx] "+v"(side_dist.x), [sdy] "+v"(side_dist.y), [sdz] "+v"(side_dist.z), [idxx] "+v"(index), [idxy] "=&v"(idxy), [idxz] "=&v"(idxz),
-          [cell] "=&v"(cell), [wx] "+v"(word), [wy] "=&v"(wy), [wz] "=&v"(wz), [tsx] "=&v"(tsx), [tsy] "=&v"(tsy), [tsz] "=&v"(tsz), [tout] "+v"(g.t_out),
-          [tin] "=&v"(g.t_in), [code] "+v"(g.code), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y),
-          [alive] "+s"(g.alive), [mXx] "=&s"(mXx), [mYx] "=&s"(mYx), [mXy] "=&s"(mXy), [mYy] "=&s"(mYy), [mXz] "=&s"(mXz), [mYz] "=&s"(mYz), [cyx] "=&s"(cyx),
-          [cyy] "=&s"(cyy), [cyz] "=&s"(cyz), [kpx] "=&s"(kpx), [kpy] "=&s"(kpy), [kpz] "=&s"(kpz), [mt] "=&s"(mt), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz),
-          [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n), [gone] "+s"(gone)
-        : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(nm_x), [sty] "v"(nm_y), [stz] "v"(nm_z), [rsrc] "s"(rsrc), [batch] "s"(g.batch),
-          [minalive] "s"(g.min_alive), [flip] "v"(flip)
-        : "vcc", "scc");
-}
-#undef VRT_A2_HEAD
-#undef VRT_A2_TAIL
-#undef VRT_A2_UNSTEP
-#undef VRT_A2_PARK
-#undef VRT_A2_IN_CODE
-#undef VRT_A2_IN_SET
-#undef VRT_A2_EXIT
-// The counter-free dilated loop on 4 x 4 x 4-CELL words (vrt_path_kernel<..., DIL 3>): the 64-bit words of TraceParams::status_blocks,
-// index bits 0-5 = the cell's place in its block (x&3 | (z&3) << 2 | (y&3) << 4), the bits above = the block's number.  A lane asks
-// when its step enters another block: 0.265 times per trip in the 2048^3 sparse field against 0.333 for half-blocks
-// (tools/request_replay.py).  The word is a register pair; the test shifts the cell's bit into bit 63 (v_lshlrev_b64 by ~index, of
-// which the instruction reads the low six bits) and compares with 0.
-#define VRT_LOAD_DILATED64_A(IDX, IDXN, WORD, WORDN)                       \
-    "v_xor_b32_e32 %[t2], %[" IDXN "], %[" IDX "]\n\t"                     \
-    "v_cmp_lt_u32_e64 %[by], 63, %[t2]\n\t"                                \
-    "s_cmp_eq_u64 %[by], 0\n\t"                                            \
-    "s_cselect_b64 %[by], exec, %[by]\n\t"                                 \
-    "s_and_saveexec_b64 %[cz], %[by]\n\t"                                  \
-    "v_xor_b32_e32 %[t2], %[" IDXN "], %[flip]\n\t"                        \
-    "v_lshrrev_b32_e32 %[t2], 6, %[t2]\n\t"                                \
-    "buffer_load_dwordx2 %[" WORDN "], %[t2], %[rsrc], 0 idxen\n\t"
-#define VRT_LOAD_DILATED64_B(IDX, IDXN, WORD, WORDN)                       \
-    "s_andn2_b64 exec, %[cz], %[by]\n\t"                                   \
-    "s_waitcnt vmcnt(1)\n\t"                                               \
-    "v_mov_b64_e32 %[" WORDN "], %[" WORD "]\n\t"                          \
-    "s_mov_b64 exec, %[cz]\n\t"
-#define VRT_TEST_DILATED64(WORD, IDX)                                      \
-    "v_xnor_b32_e32 %[t1], %[" IDX "], %[flip]\n\t"                        \
-    "v_lshlrev_b64 %[tp], %[t1], %[" WORD "]\n\t"                          \
-    "v_cmp_gt_i64_e64 vcc, 0, %[tp]\n\t"
-VRT_DI void grid_walk_park_dilated64_gfx950(f3 &side_dist, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t nm_x, uint32_t nm_y, uint32_t nm_z,
-                                            unsigned long long &word, u32x4 rsrc, GridParkRegs &g, uint32_t flip, unsigned long long &gone) {
-    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save;
-    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
-    u32x2 wordb, tp, wa = __builtin_bit_cast(u32x2, word);
-    float t0, t1, t2;
-    uint32_t n;
-    const uint32_t stride_x = nm_x, stride_y = nm_y, stride_z = nm_z; // (the operand list's names)
-    gone = 0ull;
-    asm volatile(VRT_PARK_WALK_ASM_W(VRT_TRIP_E, VRT_STEP_DILATED_CARRY, VRT_EXIT_CARRY, "s_and_b64 %[by], %[ex], vcc\n\ts_or_b64 %[gone], %[gone], %[by]\n\t",
-                                     VRT_NO_LIMIT, VRT_LOAD_DILATED64, VRT_TEST_DILATED64, VRT_WAIT_BUFFER, "v_mov_b64_e32 %[worda], %[wordb]\n\t")
-                 : [sdx] "+v"(side_dist.x), [sdy] "+v"(side_dist.y), [sdz] "+v"(side_dist.z), [idxa] "+v"(index), [idxb] "=&v"(cell), [worda] "+v"(wa),
-                   [wordb] "=&v"(wordb), [tp] "=&v"(tp), [tsb] "+v"(g.t_out), [tsa] "=&v"(g.t_in), [code] "+v"(g.code), [t0] "=&v"(t0), [t1] "=&v"(t1),
-                   [t2] "=&v"(t2), [mxb] "+s"(g.out_x), [myb] "+s"(g.out_y), [alive] "+s"(g.alive), [mxa] "=&s"(mxa), [mya] "=&s"(mya), [mxya] "=&s"(mxya),
-                   [mxyb] "=&s"(mxyb), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz), [save] "=&s"(save), [parked] "=&s"(g.parked), [n] "=&s"(n), [gone] "+s"(gone)
-                 : VRT_PARK_WALK_INPUTS, [flip] "v"(flip)
-                 : "vcc", "scc");
-    word = __builtin_bit_cast(unsigned long long, wa);
-}
-#undef VRT_LOAD_DILATED64_A
-#undef VRT_LOAD_DILATED64_B
-#undef VRT_TEST_DILATED64
-// ---- the brick-level park loop on a DISTANCE FIELD (vrt_path_kernel<DIST>, round 3) ---------------------------------------------
-// A DDA trip moves one cell along one axis, so n trips reach exactly the cells within L1 (Manhattan) distance n of where they
-// started.  TraceParams::cell_distance holds, per cell, its L1 distance in cells to the nearest occupied cell (0 = occupied, capped
-// at 255; derived from binding 3 at every status upload).  A lane that has read d > 0 at cell P knows the next d - 1 cells of ANY walk
-// to be empty: it takes those trips without asking — same DDA operations, same order, fewer tests — and asks again for the cell
-// d trips behind P.  Per lane: `k` = trips it may still take before it has to ask (<= 0: ask in this trip), and the usual one-trip
-// pipeline: the byte of the cell entered is requested in the trip that enters it and tested in the next, after that trip's step
-// (a lane that asks keeps asking every trip until an answer > 1 arrives: the answer for P is only there when P + 1 has been asked).
-// Against the half-block words (27 vector instructions per trip, a request per lane every third trip) a trip is 17 vector
-// instructions and, in the 2048^3 sparse field, a lane asks about twice per d cells.  The index is the plain linear cell index =
-// the byte offset: any grid dimensions.  If no lane of the wave has to ask, all do (a trip always issues one request, so that
-// vmcnt(1) keeps its meaning); `nd<word>` = the lanes whose <word> register holds an answer.
-#define VRT_LOAD_DIST_A(IDX, IDXN, WORD, WORDN)                                    \
-    "v_cmp_gt_i32_e64 %[nd" WORDN "], 1, %[k]\n\t"                                 \
-    "v_add_u32_e32 %[k], -1, %[k]\n\t"                                             \
-    "s_cmp_eq_u64 %[nd" WORDN "], 0\n\t"                                           \
-    "s_cselect_b64 %[nd" WORDN "], exec, %[nd" WORDN "]\n\t"                       \
-    "s_and_saveexec_b64 %[cz], %[nd" WORDN "]\n\t"                                 \
-    "buffer_load_ubyte %[" WORDN "], %[" IDXN "], %[rsrc], 0 offen\n\t"
-#define VRT_LOAD_DIST_B(IDX, IDXN, WORD, WORDN)                                    \
-    "s_mov_b64 exec, %[cz]\n\t"                                                    \
-    "s_waitcnt vmcnt(1)\n\t"
-#define VRT_TEST_DIST(WORD, IDX)                                                   \
-    "v_cmp_eq_u32_e32 vcc, 0, %[" WORD "]\n\t"                                     \
-    "v_add_u32_e32 %[t1], -2, %[" WORD "]\n\t"                                     \
-    "s_and_b64 vcc, vcc, %[nd" WORD "]\n\t"         /* occupied: an answer, and it is 0 */ \
-    "v_cndmask_b32_e64 %[k], %[k], %[t1], %[nd" WORD "]\n\t"
-struct DistRegs {
-    unsigned long long pend; // in/out: lanes whose `word` is an answer for their current cell (the others know it to be empty)
-    int k;                   // per lane, in/out: trips the lane may take before it asks again
-};
-VRT_DI void grid_walk_park_dist_gfx950(Walk &w, const f3 &inv_dir, uint32_t &index, uint32_t &cell, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z,
-                                       uint32_t &word, u32x4 rsrc, GridParkRegs &g, DistRegs &d) {
-    unsigned long long mxa, mya, mxya, mxyb, ex, by, cz, save, ndwordb;
-    float t0, t1, t2;
-    uint32_t wordb, n;
-    asm volatile(VRT_PARK_WALK_ASM(VRT_NO_LIMIT, VRT_LOAD_DIST, VRT_TEST_DIST, VRT_WAIT_BUFFER, "s_mov_b64 %[ndworda], %[ndwordb]\n\t")
-                 : VRT_PARK_WALK_OPERANDS, [ndworda] "+s"(d.pend), [ndwordb] "=&s"(ndwordb), [k] "+v"(d.k)
-                 : VRT_PARK_WALK_INPUTS
-                 : "vcc", "scc");
-}
-#undef VRT_LOAD_DIST_A
-#undef VRT_LOAD_DIST_B
-#undef VRT_TEST_DIST
+#ifdef VRT_DEV_VARIANTS
+#define VRT_DEV_SECTION 3
+#include "vrt_trace_kernels_dev.h"
+#undef VRT_DEV_SECTION
+#endif
+#ifdef VRT_DEV_VARIANTS
+#define VRT_DEV_SECTION 4
+#include "vrt_trace_kernels_dev.h"
+#undef VRT_DEV_SECTION
+#endif
 // index of the half-block word that holds cell `index`
 VRT_DI uint32_t halfblock_word(const HalfBlockConsts &hb, uint32_t index) {
     return ((index >> 2) & hb.mx) | ((index >> 4) & hb.mzs) | ((index >> 5) & hb.mys);
@@ -925,143 +736,11 @@ VRT_DI uint32_t halfblock_word(const HalfBlockConsts &hb, uint32_t index) {
 #undef VRT_WORD_MOV32
 #undef VRT_PARK_WALK_OPERANDS
 #undef VRT_PARK_WALK_INPUTS
-// ---- the park loop pipelined TWO trips ahead (vrt_path_kernel<AHEAD>) ---------------------------------------------------------
-// The loops above keep ONE status word in flight per lane: the word of the next cell is requested a trip ahead, and on a scene
-// larger than the caches a wave then waits ~670 cycles per trip for it (tools/path_profile.py: 13 400 cycles per call of ~20 trips,
-// 27 vector instructions per trip, 5 waves per SIMD).  Here the DDA runs two cells ahead of the test: a lane carries a ring of three
-// cells (q0, q1, q2) with their words (w0, w1, w2) and the crossed distances of the steps INTO them (ts0, ts1, ts2); a trip rotates
-// the ring, takes the step out of q1 into the new q2, requests q2's word, waits until at most TWO requests are outstanding — i.e.
-// for the word of q0, asked for two trips ago — and tests q0.  Per lane the sequence of DDA operations is the shader's (comp:345-372),
-// run two steps early.  What that takes:
-//   * a lane whose q0 is occupied PARKS as it is: ring and DDA state stay, the caller walks the brick of q0 (entered through the axis
-//     in `hist` bits 4-5 at distance ts0; the counters of q0 = the current ones with the two later steps' decrements undone) and, if
-//     the brick holds nothing for the ray, the lane simply walks on: its next trip rotates q1 into place.  No roll-back, no re-request;
-//   * a step that leaves the box of the occupied cells puts the SENTINEL ~0 into q2, and so does every later step (q1 == ~0): the
-//     word index of ~0 lies outside the buffer, its word reads 0, its test fails, and when the sentinel reaches q0 the lane has tested
-//     every cell up to the box's face and leaves (`left`).  The cells a lane would "enter" beyond the face are thus never tested
-//     (at a face of the grid the next linear index would be a real cell of the next row);
-//   * `hist`: two bits per step, the axis of the step into q2 in bits 0-1, into q1 in bits 2-3, into q0 in bits 4-5 (3: q0 was entered
-//     without a step — the slab test — at the start of a ray).
-// Canonical state between calls, for every lane: [q0 tested, q1 next to be tested, q2 newest], the DDA state (side distances,
-// counters) that of q2, w1 / w2 arrived.  A new ray is primed in C++ with one step (path kernel, START).
-struct AheadWalkRegs {
-    unsigned long long alive;  // in: lanes to walk; out: lanes still moving when the call ended
-    unsigned long long parked; // out: lanes whose q0 is occupied
-    unsigned long long left;   // out: lanes that have tested every cell up to the face of the box
-    uint32_t batch;            // in: the call returns once this many lanes are parked (or nobody is moving)
-    uint32_t min_alive;        // in: ... or, at the back edge, once fewer than this many lanes are still moving
-};
-// The words travel in THREE registers used in turn (a register with a request in flight cannot be moved): trip k of the unrolled
-// body (k = 0, 1, 2) requests into W[k] and tests W[(k + 1) % 3].  A lane leaves the loop after some trip k — parked, or still
-// moving when the call ends — and `phase` records that k; the caller then puts word(q1) into w1 and word(q2) into w2
-// (AheadRing::settle), which is where trip 0 of the next call expects them.  The cells and distances are moved (computed values).
-struct AheadRing {
-    uint32_t q0, q1, q2, w0, w1, w2, hist, phase;
-    float ts0, ts1, ts2;
-    VRT_DI void settle() { // after a call: phase k -> word(q1) is in W[(k + 2) % 3], word(q2) in W[k]
-        const uint32_t a = phase == 0u ? w2 : (phase == 1u ? w0 : w1), b = phase == 0u ? w0 : (phase == 1u ? w1 : w2);
-        w1 = a;
-        w2 = b;
-        phase = 2u;
-    }
-};
-#define VRT_AHEAD_TRIP(WL, WT, K, NEXT)                                                        \
-        /* rotate the cells and the crossed distances */                                        \
-        "v_mov_b32_e32 %[q0], %[q1]\n\t"                                                        \
-        "v_mov_b32_e32 %[q1], %[q2]\n\t"                                                        \
-        "v_mov_b32_e32 %[ts0], %[ts1]\n\t"                                                      \
-        "v_mov_b32_e32 %[ts1], %[ts2]\n\t"                                                      \
-        /* the step out of q1 (comp:345-372), as in VRT_TRIP_T */                               \
-        "v_min3_f32 %[ts2], %[sdx], %[sdy], %[sdz]\n\t"                                         \
-        "v_cmp_eq_f32_e64 %[mxy], %[sdz], %[ts2]\n\t"                                           \
-        "v_cmp_eq_f32_e64 %[my], %[sdy], %[ts2]\n\t"                                            \
-        "s_andn2_b64 %[my], %[my], %[mxy]\n\t"                                                  \
-        "s_andn2_b64 %[mxy], exec, %[mxy]\n\t"                                                  \
-        "s_andn2_b64 %[mx], %[mxy], %[my]\n\t"                                                  \
-        "s_mov_b64 %[ex], exec\n\t"                                                             \
-        "s_mov_b64 exec, %[mx]\n\t"                                                             \
-        "v_add_f32_e64 %[sdx], %[sdx], |%[ix]|\n\t"                                             \
-        "s_mov_b64 exec, %[my]\n\t"                                                             \
-        "v_add_f32_e64 %[sdy], %[sdy], |%[iy]|\n\t"                                             \
-        "s_andn2_b64 exec, %[ex], %[mxy]\n\t"                                                   \
-        "v_add_f32_e64 %[sdz], %[sdz], |%[iz]|\n\t"                                             \
-        "s_mov_b64 exec, %[ex]\n\t"                                                             \
-        "v_cndmask_b32_e64 %[t1], 2, 1, %[my]\n\t"                                              \
-        "v_cndmask_b32_e64 %[t1], %[t1], 0, %[mx]\n\t"                                          \
-        "v_lshl_or_b32 %[hist], %[hist], 2, %[t1]\n\t"                                          \
-        "v_cndmask_b32_e64 %[t0], %[stz], %[sty], %[my]\n\t"                                    \
-        "v_cndmask_b32_e64 %[t0], %[t0], %[stx], %[mx]\n\t"                                     \
-        "v_add_u32_e32 %[t2], %[q1], %[t0]\n\t"                                                 \
-        "v_subbrev_co_u32_e64 %[rx], %[ex], 0, %[rx], %[mx]\n\t"                                \
-        "v_subbrev_co_u32_e64 %[ry], %[by], 0, %[ry], %[my]\n\t"                                \
-        "v_addc_co_u32_e64 %[rz], %[cz], -1, %[rz], %[mxy]\n\t"                                 \
-        "s_or_b64 %[ex], %[ex], %[by]\n\t"                                                      \
-        "s_orn2_b64 %[ex], %[ex], %[cz]\n\t"    /* z: carry-out 0 = borrow; the step left the box ... */ \
-        "v_cmp_eq_u32_e64 %[by], -1, %[q1]\n\t" /* ... or an earlier one did */                  \
-        "s_or_b64 %[ex], %[ex], %[by]\n\t"                                                      \
-        "v_cndmask_b32_e64 %[q2], %[t2], -1, %[ex]\n\t"                                         \
-        /* q2's word; the word of q0, asked for two trips ago, has arrived when at most two requests are outstanding */ \
-        "v_lshrrev_b32_e32 %[t0], 5, %[q2]\n\t"                                                 \
-        "buffer_load_dword %[" WL "], %[t0], %[rsrc], 0 idxen\n\t"                              \
-        "s_waitcnt vmcnt(2)\n\t"                                                                \
-        "v_bfe_u32 %[t1], %[" WT "], %[q0], 1\n\t"                                              \
-        "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"                                                    \
-        "v_cmp_eq_u32_e64 %[by], -1, %[q0]\n\t" /* the sentinel has arrived: every cell up to the face has been tested */ \
-        "s_or_b64 %[left], %[left], %[by]\n\t"                                                  \
-        "s_andn2_b64 exec, exec, %[by]\n\t"                                                     \
-        "s_cbranch_vccz " NEXT "f\n\t"                                                          \
-        "s_mov_b64 %[ex], exec\n\t"                                                             \
-        "s_mov_b64 exec, vcc\n\t"                                                               \
-        "v_mov_b32_e32 %[phase], " K "\n\t"                                                     \
-        "s_andn2_b64 exec, %[ex], vcc\n\t"                                                      \
-        "s_or_b64 %[parked], %[parked], vcc\n\t"                                                \
-        "s_bcnt1_i32_b64 %[n], %[parked]\n\t"                                                   \
-        "s_cmp_ge_u32 %[n], %[batch]\n\t"                                                       \
-        "s_cbranch_scc1 9" K "f\n\t"                                                            \
-        NEXT ":\n\t"
-VRT_DI void grid_walk_ahead_gfx950(Walk &w, const f3 &inv_dir, AheadRing &a, uint32_t stride_x, uint32_t stride_y, uint32_t stride_z, u32x4 rsrc,
-                                   AheadWalkRegs &g) {
-    unsigned long long mx, my, mxy, ex, by, cz, save;
-    float t0, t1, t2;
-    uint32_t n;
-    asm volatile(
-        "s_mov_b64 %[save], exec\n\t"
-        "s_mov_b64 exec, %[alive]\n\t"
-        "s_mov_b64 %[parked], 0\n\t"
-        "s_mov_b64 %[left], 0\n\t"
-        "0:\n\t"
-        VRT_AHEAD_TRIP("w0", "w1", "0", "20")
-        "s_cbranch_execz 90f\n\t"
-        VRT_AHEAD_TRIP("w1", "w2", "1", "21")
-        "s_cbranch_execz 91f\n\t"
-        VRT_AHEAD_TRIP("w2", "w0", "2", "22")
-        "s_cbranch_execz 92f\n\t"
-        "s_bcnt1_i32_b64 %[n], exec\n\t"
-        "s_cmp_ge_u32 %[n], %[minalive]\n\t"
-        "s_cbranch_scc1 0b\n\t"
-        "92:\n\t"
-        "v_mov_b32_e32 %[phase], 2\n\t"
-        "s_branch 99f\n\t"
-        "90:\n\t"
-        "v_mov_b32_e32 %[phase], 0\n\t"
-        "s_branch 99f\n\t"
-        "91:\n\t"
-        "v_mov_b32_e32 %[phase], 1\n\t"
-        "99:\n\t"
-        "s_mov_b64 %[alive], exec\n\t"
-        "s_mov_b64 exec, %[save]\n\t"
-        "s_waitcnt vmcnt(0)"
-        : [sdx] "+v"(w.side_dist.x), [sdy] "+v"(w.side_dist.y), [sdz] "+v"(w.side_dist.z), [rx] "+v"(w.rx), [ry] "+v"(w.ry), [rz] "+v"(w.rz),
-          [q0] "+v"(a.q0), [q1] "+v"(a.q1), [q2] "+v"(a.q2), [w0] "+v"(a.w0), [w1] "+v"(a.w1), [w2] "+v"(a.w2), [ts0] "+v"(a.ts0), [ts1] "+v"(a.ts1),
-          [ts2] "+v"(a.ts2), [hist] "+v"(a.hist), [phase] "+v"(a.phase), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [mx] "=&s"(mx), [my] "=&s"(my),
-          [mxy] "=&s"(mxy), [ex] "=&s"(ex), [by] "=&s"(by), [cz] "=&s"(cz), [save] "=&s"(save), [parked] "=&s"(g.parked), [left] "=&s"(g.left),
-          [alive] "+s"(g.alive), [n] "=&s"(n)
-        : [ix] "v"(inv_dir.x), [iy] "v"(inv_dir.y), [iz] "v"(inv_dir.z), [stx] "v"(stride_x), [sty] "v"(stride_y), [stz] "v"(stride_z), [rsrc] "s"(rsrc),
-          [batch] "s"(g.batch), [minalive] "s"(g.min_alive)
-        : "vcc", "scc", "memory");
-    a.settle();
-}
-#undef VRT_AHEAD_TRIP
+#ifdef VRT_DEV_VARIANTS
+#define VRT_DEV_SECTION 5
+#include "vrt_trace_kernels_dev.h"
+#undef VRT_DEV_SECTION
+#endif
 // ---- block filter (vrt_path_kernel<FILTER>) ---------------------------------------------------------------------------
 // The 1-bit-per-4x4x4-cells filter that vrt_build_status_blocks derives from binding 3 ("some cell of the block is occupied"),
 // staged in LDS once per workgroup.  The block index is formed from the linear cell index by bit fields, so the grid's x and z
@@ -1569,56 +1248,11 @@ VRT_DI bool skip_to_box(Walk &w, const RaySetup &s, int span_x, int span_y, int 
     return skipped;
 }
 
-// The lane stands in a 4x4x4 block of cells that holds no occupied cell (at cell (bx, by, bz) of it): jump behind the step
-// that leaves the block.  Each axis has its exit crossing (the e-th from now, e = cells to the block's face in the ray's
-// direction + 1, at the side distance after e-1 additions); the one that comes first in merge order (smallest distance; z
-// before y before x among equals, as the walk picks) is the step that leaves the block, and everything before it is consumed
-// exactly as skip_to_box does.  ~100 vector instructions and no memory access for what would be one to ten trips.
-VRT_DI void skip_empty_block(Walk &w, const RaySetup &s, uint32_t bx, uint32_t by, uint32_t bz, uint32_t &index, uint32_t stride_x, uint32_t stride_y,
-                             uint32_t stride_z, bool &more, int &in_axis, float &t_in) {
-    const int ex = s.sx > 0 ? 4 - (int)bx : (int)bx + 1, ey = s.sy > 0 ? 4 - (int)by : (int)by + 1, ez = s.sz > 0 ? 4 - (int)bz : (int)bz + 1;
-    auto exit_distance = [](float sd, float d, int e, int step) {
-        const float a1 = sd + d, a2 = a1 + d, a3 = a2 + d;
-        const float t = e == 1 ? sd : (e == 2 ? a1 : (e == 3 ? a2 : a3));
-        return step != 0 ? t : __builtin_inff(); // an axis the ray does not move along is never crossed
-    };
-    const float tx = exit_distance(w.side_dist.x, s.ray_delta().x, ex, s.sx);
-    const float ty = exit_distance(w.side_dist.y, s.ray_delta().y, ey, s.sy);
-    const float tz = exit_distance(w.side_dist.z, s.ray_delta().z, ez, s.sz);
-    const bool az = tz <= tx && tz <= ty, ay = !az && ty <= tx, ax = !az && !ay;
-    const float t = ax ? tx : (ay ? ty : tz);
-    const float t_strict = next_below(t); // c < t  <=>  c <= t_strict
-    // The other two axes: their elements that precede t in merge order (x loses every tie, z wins every tie, y wins against x
-    // only) — at most three each, their own exit crossing comes later.  Straight-line: no loop, no lane mask juggling.
-    const float never = -__builtin_inff();
-    auto consume = [](float &c, float d, float lim, int &n) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const bool before = c <= lim;
-            c = before ? c + d : c;
-            n += before ? 1 : 0;
-        }
-    };
-    float cx = w.side_dist.x, cy = w.side_dist.y, cz = w.side_dist.z;
-    int nx = 0, ny = 0, nz = 0;
-    consume(cx, s.ray_delta().x, ax ? never : t_strict, nx);
-    consume(cy, s.ray_delta().y, ay ? never : (ax ? t : t_strict), ny);
-    consume(cz, s.ray_delta().z, az ? never : t, nz);
-    w.side_dist.x = ax ? t + s.ray_delta().x : cx;
-    w.side_dist.y = ay ? t + s.ray_delta().y : cy;
-    w.side_dist.z = az ? t + s.ray_delta().z : cz;
-    nx = ax ? ex : nx;
-    ny = ay ? ey : ny;
-    nz = az ? ez : nz;
-    w.rx -= nx;
-    w.ry -= ny;
-    w.rz -= nz;
-    index += (uint32_t)nx * stride_x + (uint32_t)ny * stride_y + (uint32_t)nz * stride_z;
-    more = (w.rx | w.ry | w.rz) >= 0; // a counter below zero: the far face of the box of occupied cells was crossed on the way
-    in_axis = ax ? 0 : (ay ? 1 : 2);
-    t_in = t;
-}
-
+#ifdef VRT_DEV_VARIANTS
+#define VRT_DEV_SECTION 6
+#include "vrt_trace_kernels_dev.h"
+#undef VRT_DEV_SECTION
+#endif
 // comp:271-376.  t_min = 1e-5, t_max = +inf at every call site (comp:218,247).
 // BATCH (used for frames with bounces, whose secondary rays are incoherent): a lane that reaches an
 // occupied cell does not walk its brick at once but waits (__ballot) until p.brick_batch lanes are waiting or
@@ -2294,588 +1928,6 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
             atomicAdd(&p.counters->wave_voxel_iters, v[8]);
         }
     }
-}
-
-// ---- frames with bounces: persistent lanes -------------------------------------------------------------------------
-// vrt_trace_kernel<SHADE 0> runs the shader's loops in lockstep: the 64 lanes of a wave take sample s together, bounce k
-// together, and every GridHit lasts as long as the longest of its 64 walks.  On the path-trace configuration (incoherent
-// secondary rays through a sparse field, 16 samples, 3 bounces) that leaves about a fifth of the lanes of an instruction
-// busy (367 wave-instructions per ray against ~70 for 64 rays in step; profiles/r02a_cfg4*).  Here a lane is not tied to
-// its wave's progress: each lane carries its own (pixel, sample, bounce, ray) and moves through
-//     FETCH a pixel -> SAMPLE (camera ray) -> START a ray (slab test, walk set-up) -> WALK (the hand-written park loop,
-//     shared by primary, bounce and shadow rays of all lanes) -> DONE (shade: scatter, shadow ray, next bounce) -> END of
-//     the path (tone-map, accumulate the sample) -> STORE the pixel -> FETCH ...
-// A lane whose ray has left the grid is handed its next ray while its neighbours keep walking: the walk loop returns
-// when `path_fin_batch` lanes have finished (or `brick_batch` lanes wait at a brick, or nobody is moving), the transitions
-// run for the lanes that need them, and the loop is re-entered with every lane that has a ray.  Pixels come from one
-// counter per frame (p.work_counter), 64 consecutive pixels of an 8x8 block at a time while the wave is empty.
-// Per lane the sequence of arithmetic operations is exactly ray_color's / main()'s (comp:153-265): the samples of a pixel
-// are traced one after the other by the lane that owns the pixel and summed in order, so frames are bit-identical.
-enum : int { kLaneFetch = 0, kLaneSample, kLaneStart, kLaneWalk, kLaneDone, kLaneEnd, kLaneStore, kLaneExit };
-
-// FILTER: 512-thread workgroups (eight waves, two per SIMD, share one LDS copy of the block filter); two workgroups per CU:
-// 2 x (32 KiB filter + 8 x 4 KiB of staged bricks) = 128 of the CU's 160 KiB, four waves per SIMD.  (640-thread groups for five
-// waves per SIMD do not pair up: ten waves leave the SIMDs 3/3/2/2, and 96 registers do not admit a sixth wave.)
-// AHEAD (round 3): the walk loop pipelined two trips ahead (grid_walk_ahead_gfx950), on the shader's linear status words.
-// DIST (round 3): the walk loop on the L1 distance field of the occupied cells (grid_walk_park_dist_gfx950).
-// DIL (round 3): the half-block walk loop on a dilated cell index (all three dimensions powers of two): 1 = with the steps-left
-// counters (grid_walk_park_dilated_gfx950: the walk ends at the box of the occupied cells), 2 = without them
-// (grid_walk_park_dilated_carry_gfx950: the walk ends at the grid's face; chosen when the box is, or nearly is, the grid);
-// 3 = 2 on 4 x 4 x 4-cell words (development); 4 = 2 with the DDA two cells ahead of the test (grid_walk_park_dilated_ahead_gfx950).
-template <int B, int MIN_WAVES, bool FILTER, bool HALF = false, bool AHEAD = false, bool DIST = false, int DIL = 0>
-__global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN_WAVES) void vrt_path_kernel(const TraceParams p) {
-    static_assert(!AHEAD || (!HALF && !FILTER), "the two-trips-ahead loop reads the linear status words");
-    static_assert(!DIST || (!HALF && !FILTER && !AHEAD), "the distance-field loop has its own status structure");
-    static_assert(!DIL || (!HALF && !FILTER && !AHEAD && !DIST), "the dilated-index loop is a walk kind of its own (it reads the half-block words)");
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_block_filter[];
-    FilterConsts fc{};
-    if constexpr (FILTER) {
-        // stage the block filter (1 bit per 4x4x4 block of cells: "some cell occupied") once per workgroup; the kernel has no
-        // static LDS, so the dynamic region starts at LDS address 0, which the walk loop's ds_read relies on
-        const uint32_t nblocks = p.nbx * p.nby * p.nbz;
-        const uint32_t nwords = (nblocks + 31u) >> 5;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.status_blocks + (size_t)nblocks);
-        for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) lds_block_filter[i] = src[i];
-        __syncthreads();
-        const uint32_t lx = 31u - (uint32_t)__builtin_clz(p.grid.dim_x), lz = 31u - (uint32_t)__builtin_clz(p.grid.dim_z);
-        fc.wx = lx - 2u;
-        fc.shz = lx + 2u;
-        fc.mz = (p.grid.dim_z >> 2) - 1u;
-        fc.shy = lx + lz + 2u;
-        fc.shyb = lx + lz - 4u;
-    }
-    // brick staging area of this wave (8^3 bricks, p.path_brick_lds): 4 KiB behind the block filter, as an LDS byte address
-    [[maybe_unused]] const uint32_t wave_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds_block_filter +
-                                               (FILTER ? p.path_lds_bytes : 0u) + (threadIdx.x >> 6) * 4096u;
-    const PushConstants &pc = p.pcs[blockIdx.y];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total = p.owned_tiles * (uint32_t)(kTileW * kTileH);
-    uint32_t *const counter = p.work_counter + blockIdx.y;
-    const bool sun_enabled = pc.sun.enabled > 0;
-    const int spp = pc.cam.samples_per_pixel;
-    const int max_bounce = pc.cam.max_bounce;
-    const float t_max = __builtin_inff();
-
-    const f3 g_min = mk3(p.grid.min_point_base_t[0], p.grid.min_point_base_t[1], p.grid.min_point_base_t[2]);
-    const float g_scale = p.grid.max_point_scale[3];
-    const int dx = (int)p.grid.dim_x, dy = (int)p.grid.dim_y, dz = (int)p.grid.dim_z;
-    int lox = 0, loy = 0, loz = 0, hix = dx - 1, hiy = dy - 1, hiz = dz - 1;
-    if (p.cell_bounds) {
-        lox = -p.cell_bounds[0], loy = -p.cell_bounds[1], loz = -p.cell_bounds[2];
-        hix = p.cell_bounds[3], hiy = p.cell_bounds[4], hiz = p.cell_bounds[5];
-    }
-    const int zero_budget = dx + dy + dz + 8;
-    const unsigned long long status_addr = (unsigned long long)p.brick_status;
-    u32x4 rsrc;
-    rsrc.x = (uint32_t)status_addr;
-    rsrc.y = (uint32_t)(status_addr >> 32) | (4u << 16); // stride 4: one record per status word
-    rsrc.z = p.status_words;
-    rsrc.w = 0x00020000u;
-
-    // the walk loop on half-block words (p.status_halfblocks: derived, 4 x 4 x 2 cells per word; eligible grids only)
-    HalfBlockConsts hb;
-    u32x4 hb_rsrc;
-    constexpr bool halfblocks = HALF; // (a template parameter: two asm blocks with scalar outputs behind a run-time branch do not compile)
-    {
-        // (computed unconditionally and pinned to SGPRs: they are scalar operands of the hand-written loop)
-        auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-        const uint32_t lx = 31u - (uint32_t)__builtin_clz(p.grid.dim_x | 4u), lz = 31u - (uint32_t)__builtin_clz(p.grid.dim_z | 4u);
-        hb.nmask = uni(~(3u | (3u << lx) | (1u << (lx + lz))));
-        hb.mx = uni((1u << (lx - 2u)) - 1u);
-        hb.mzs = uni(((p.grid.dim_z >> 2) - 1u) << (lx - 2u));
-        hb.mys = uni(~((1u << (lx + lz - 4u)) - 1u));
-        hb.lx = uni(lx);
-        hb.lxz = uni(lx + lz);
-        const unsigned long long a = (unsigned long long)p.status_halfblocks;
-        hb_rsrc.x = uni((uint32_t)a);
-        hb_rsrc.y = uni((uint32_t)(a >> 32) | (4u << 16));
-        hb_rsrc.z = uni(p.status_words);
-        hb_rsrc.w = 0x00020000u;
-    }
-    // the walk loop on the distance field (p.cell_distance: derived, one byte per cell; a raw buffer, num_records = cells)
-    [[maybe_unused]] u32x4 dist_rsrc;
-    if constexpr (DIST) {
-        auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-        const unsigned long long a = (unsigned long long)p.cell_distance;
-        dist_rsrc.x = uni((uint32_t)a);
-        dist_rsrc.y = uni((uint32_t)(a >> 32));
-        dist_rsrc.z = uni(p.status_cells);
-        dist_rsrc.w = 0x00020000u;
-    }
-    // the status word of a cell, in the layout the walk loop reads (DIST: the cell's distance byte; such a lane's word is an answer
-    // for the cell it stands on and it has to ask in its next trip: fresh_word)
-    [[maybe_unused]] uint32_t flip = 0u; // DIL, per lane: the field masks of the axes the ray walks down (index ^ flip = the real dilated index)
-    auto status_word = [&](uint32_t index) {
-        if constexpr (DIST) return (uint32_t)p.cell_distance[index];
-        else if constexpr (DIL == 3) return 0u; // (64-bit words: status_word64)
-        else if constexpr (DIL) return p.status_halfblocks[(index ^ flip) >> 5];
-        else return halfblocks ? p.status_halfblocks[halfblock_word(hb, index)] : p.brick_status[index >> 5];
-    };
-    [[maybe_unused]] unsigned long long word64 = 0ull; // DIL 3: the lane's 4 x 4 x 4-cell word
-    auto status_word64 = [&](uint32_t index) { return reinterpret_cast<const unsigned long long *>(p.status_blocks)[(index ^ flip) >> 6]; };
-    [[maybe_unused]] u32x4 blk_rsrc;
-    if constexpr (DIL == 3) {
-        auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-        const unsigned long long a = (unsigned long long)p.status_blocks;
-        blk_rsrc.x = uni((uint32_t)a);
-        blk_rsrc.y = uni((uint32_t)(a >> 32) | (8u << 16)); // stride 8: one record per block word
-        blk_rsrc.z = uni(p.nbx * p.nby * p.nbz);
-        blk_rsrc.w = 0x00020000u;
-    }
-    [[maybe_unused]] DistRegs dr{0ull, 0};
-    [[maybe_unused]] bool fresh_word = false; // DIST: the lane's word was loaded outside the walk loop since the last call
-
-    // the by-cell copy of the occupancy bits and the start-index shortcut (derived structures, TraceParams), wave-uniform
-    const bool by_cell = p.cell_occupancy != nullptr;
-    const bool start_is_slot = p.start_is_slot != nullptr && __builtin_amdgcn_readfirstlane((int)*p.start_is_slot) != 0;
-
-    // ---- per-lane state ----
-    int st = kLaneFetch;
-    uint32_t work = 0u;          // pixel: index into this context's tiles, 256 per tile, 8x8 blocks inside
-    int sample_i = 0;
-    f3 acc = mk3(0, 0, 0);       // sum of the samples' colours (comp:173)
-    // the path (RayColor's locals, comp:203-216)
-    int loop_count = 0;
-    f3 color = mk3(0, 0, 0);
-    float cur_dir_y = 0.0f;      // current_ray.direction.y, for BackgroundColor when loop_count ends at 0
-    // the ray being walked: the path's current ray (kind 0) or the shadow ray of its last hit (kind 1)
-    Ray r = Ray{mk3(0, 0, 0), mk3(0, 0, 1), 1.0f, MAT_NONE};
-    int kind = 0;
-    bool found = false;
-    // kept while the shadow ray is walked: the scattered ray (its origin is the shadow ray's origin, hit.point), the
-    // albedo, and whether the material scattered (comp:221-239)
-    f3 sc_dir = mk3(0, 0, 1);
-    float sc_ir = 1.0f;
-    uint32_t sc_ignore = MAT_NONE;
-    f3 attenuation = mk3(0, 0, 0);
-    bool scattered_ok = false;
-    // the walk (grid_hit's locals)
-    RaySetup s;
-    s.inv_dir = mk3(1, 1, 1);
-    s.entry_code = 0;
-    s.sx = s.sy = s.sz = 0;
-    s.grid_t_min = s.grid_t_max = 0.0f;
-    Walk w;
-    w.side_dist = mk3(0, 0, 0);
-    w.rx = w.ry = w.rz = -1;
-    w.t_value = 0.0f;
-    int base_x = 0, base_y = 0, base_z = 0;
-    uint32_t grid_index = 0u, word = 0u;
-    uint32_t stride_x = 0u, stride_y = 0u, stride_z = 0u;
-    Hit hit;
-    hit.point = hit.normal = mk3(0, 0, 0);
-    hit.t = 0.0f;
-    hit.index = 0u;
-    int hit_axis = 0;
-    GridParkRegs g;
-    g.alive = 0ull;
-    g.out_x = g.out_y = 0ull;
-    g.t_out = g.t_in = 0.0f;
-    g.code = 3u << 4;
-    g.batch = p.path_brick_batch;
-    [[maybe_unused]] AheadRing ring{0u, ~0u, ~0u, 0u, 0u, 0u, 0u, 2u, 0.0f, 0.0f, 0.0f}; // (AHEAD: the lane's three cells in flight)
-    // FILTER: a walking lane is `ready` once its cell is known to lie in a block that holds occupied cells (it takes trips);
-    // otherwise its block is looked up, and jumped over if empty.  `stale`: the lane has jumped since `word` was loaded.
-    [[maybe_unused]] bool ready = false, stale = false;
-
-    bool work_left = true; // wave-uniform
-#ifdef VRT_DEV_PROFILE
-    if (threadIdx.x < 8) vrt_prof[threadIdx.x] = 0ull; // (the brick walk's own phase hooks; static LDS: not with FILTER)
-    __syncthreads();
-    // development-only (make EXTRA=-DVRT_DEV_PROFILE, tools/path_profile.py): cycles and lane counts per phase, per wave
-    unsigned long long pf_t[3] = {0ull, 0ull, 0ull};      // cycles in transitions / walk loop / bricks
-    unsigned long long pf_n[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; // rounds: transitions, waiting lanes; walk calls, alive lanes at entry,
-                                                                                    // alive lanes at exit; brick rounds, parked lanes; hits
-#define VRT_PF_T(k, t0) pf_t[k] += __builtin_readcyclecounter() - (t0)
-#define VRT_PF_N(k, v) pf_n[k] += (unsigned long long)(v)
-#define VRT_PF_NOW() __builtin_readcyclecounter()
-#else
-#define VRT_PF_T(k, t0)
-#define VRT_PF_N(k, v)
-#define VRT_PF_NOW() 0ull
-#endif
-    for (;;) {
-        // How many lanes wait for a transition?  Few: leave them waiting and keep the others walking (the divergent
-        // code below costs the whole wave its issue slots).
-        const unsigned long long walking0 = __builtin_amdgcn_ballot_w64(st == kLaneWalk);
-        const unsigned long long waiting = __builtin_amdgcn_ballot_w64(st != kLaneWalk && st != kLaneExit);
-        const uint32_t n_walking0 = (uint32_t)__builtin_popcountll(walking0), n_waiting = (uint32_t)__builtin_popcountll(waiting);
-        if (n_walking0 == 0u && n_waiting == 0u) break;
-        [[maybe_unused]] const unsigned long long pf0 = VRT_PF_NOW();
-        if (n_waiting != 0u && (n_walking0 == 0u || n_waiting >= min(p.path_fin_batch, max(1u, n_walking0 >> 1)))) {
-            VRT_PF_N(0, 1);
-            VRT_PF_N(1, n_waiting);
-            // (1) a ray has finished: comp:218-258 from the loop condition's GridHit onwards
-            if (st == kLaneDone) {
-                bool after_shadow = false;
-                if (kind == 0) {
-                    if (found) {
-                        // (brick_walk_gfx950 records a hit as distance + material + face: comp:433-436 from those)
-                        const float t_offset = (g_scale * (1.0f / (float)B)) * 0.05f;
-                        hit.normal = axis_normal(s, hit_axis);
-                        hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
-                        loop_count += 1;
-                        Ray scattered = r;
-                        bool result = false;
-                        const vrt_material *m = p.materials + hit.index;
-                        const uint32_t mtype = m->type;
-                        attenuation = mk3(m->albedo_r, m->albedo_g, m->albedo_b);
-                        const float mdata = m->type_data;
-                        switch (mtype) {
-                            case MAT_LAMBERTIAN: result = scatter_lambertian(hit, scattered); break;
-                            case MAT_METAL: result = scatter_metal(mdata, r, hit, scattered); break;
-                            case MAT_DIELECTRIC: result = scatter_dielectric(mdata, r, hit, scattered); break;
-                            default:
-                                loop_count -= 1;
-                                result = false;
-                                break;
-                        }
-                        scattered_ok = result;
-                        sc_dir = scattered.direction;
-                        sc_ir = scattered.internal_reflection;
-                        sc_ignore = scattered.ignore_type_material;
-                        cur_dir_y = r.direction.y;
-                        if (sun_enabled) {
-                            const f3 sun_position = mk3(pc.sun.position[0], pc.sun.position[1], pc.sun.position[2]);
-                            const f3 rv = rand_vec3_range(r.direction.x + r.direction.z, r.direction.y + r.direction.z, -pc.sun.radius, pc.sun.radius);
-                            const f3 shadow_ray_dir = (sun_position + rv) - hit.point;
-                            r = create_ray(hit.point, shadow_ray_dir); // CreateShadowRay, comp:186-190 (ignore type MAT_NONE)
-                            kind = 1;
-                            st = kLaneStart;
-                        } else {
-                            color = color + attenuation;
-                            // the scattered ray starts where the shadow ray would have: keep the origin in r
-                            r.origin = hit.point;
-                            after_shadow = true;
-                        }
-                    } else {
-                        cur_dir_y = r.direction.y;
-                        st = kLaneEnd; // the while condition failed (comp:218)
-                    }
-                } else {
-                    if (!found) color = color + attenuation * mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
-                    after_shadow = true;
-                }
-                if (after_shadow) {
-                    if (!scattered_ok) {
-                        st = kLaneEnd; // comp:253-255
-                    } else {
-                        r.direction = sc_dir; // current_ray = scattered (its origin, hit.point, is r.origin already)
-                        r.internal_reflection = sc_ir;
-                        r.ignore_type_material = sc_ignore;
-                        cur_dir_y = sc_dir.y;
-                        kind = 0;
-                        st = (loop_count < max_bounce) ? kLaneStart : kLaneEnd;
-                    }
-                }
-            }
-            // (2) the path is over: comp:260-264, then the sample loop's accumulation (comp:173)
-            if (st == kLaneEnd) {
-                if (loop_count == 0) {
-                    const f3 sun_color = mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
-                    const float t = 0.5f * (cur_dir_y + 1.0f);
-                    const f3 bg = fma3(splat3(1.0f - t), splat3(1.0f), mk3(0.5f, 0.7f, 1.0f) * t);
-                    color = color + bg * (sun_enabled ? sun_color : splat3(1.0f));
-                }
-                acc = acc + color / (color + splat3(1.0f));
-                sample_i += 1;
-                st = (sample_i < spp) ? kLaneSample : kLaneStore;
-            }
-            // (3) the pixel is finished: comp:176-177
-            if (st == kLaneStore) {
-                const uint32_t owned = p.owned_tiles - 1u - (work >> 8);
-                const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
-                const uint32_t j = work & 255u;
-                const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
-                const uint32_t px = (tile % p.tiles_x) * kTileW + in_x, py = (tile / p.tiles_x) * kTileH + in_y;
-                const float fspp = (float)spp;
-                const f3 c = mk3(__builtin_sqrtf(acc.x / fspp), __builtin_sqrtf(acc.y / fspp), __builtin_sqrtf(acc.z / fspp));
-                const size_t o = (p.shard_count > 1u || p.packed_tiles) ? (size_t)owned * (kTileW * kTileH) + in_y * kTileW + in_x : (size_t)py * p.width + px;
-                reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] =
-                    unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
-                if (p.target_rgba32f) reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(c.x, c.y, c.z, 1.0f);
-                st = kLaneFetch;
-            }
-            // (4) next pixel: one atomic per wave for all the lanes that ask
-            {
-                const unsigned long long asking = __builtin_amdgcn_ballot_w64(st == kLaneFetch);
-                if (asking != 0ull) {
-                    if (work_left) {
-                        const uint32_t n = (uint32_t)__builtin_popcountll(asking);
-                        uint32_t first = 0u;
-                        if (lane == (uint32_t)__builtin_ctzll(asking)) first = atomicAdd(counter, n);
-                        first = (uint32_t)__builtin_amdgcn_readlane((int)first, __builtin_ctzll(asking));
-                        if (st == kLaneFetch) {
-                            const uint32_t mine = first + (uint32_t)__builtin_popcountll(asking & ((1ull << lane) - 1ull));
-                            if (mine < total) {
-                                work = mine;
-                                sample_i = 0;
-                                acc = mk3(0, 0, 0);
-                                st = kLaneSample;
-                            } else {
-                                st = kLaneExit;
-                            }
-                        }
-                        work_left = first + n < total;
-                    } else if (st == kLaneFetch) {
-                        st = kLaneExit;
-                    }
-                }
-            }
-            // (5) next sample of the pixel: comp:162-171
-            if (st == kLaneSample) {
-                const uint32_t owned = p.owned_tiles - 1u - (work >> 8);
-                const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
-                const uint32_t j = work & 255u;
-                const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
-                const uint32_t px = (tile % p.tiles_x) * kTileW + in_x, py = (tile / p.tiles_x) * kTileH + in_y;
-                if (px >= p.width || py >= p.height) {
-                    st = kLaneFetch; // outside the image (comp:155-159): nothing to trace, nothing to store
-                } else {
-                    const float x = (float)px, y = (float)py;
-                    const f3 horizontal = mk3(pc.cam.horizontal[0], pc.cam.horizontal[1], pc.cam.horizontal[2]);
-                    const f3 vertical = mk3(pc.cam.vertical[0], pc.cam.vertical[1], pc.cam.vertical[2]);
-                    const f3 llc = mk3(pc.cam.lower_left_corner[0], pc.cam.lower_left_corner[1], pc.cam.lower_left_corner[2]);
-                    const f3 origin = mk3(pc.cam.origin[0], pc.cam.origin[1], pc.cam.origin[2]);
-                    const float flag = (sample_i > 0) ? 1.0f : 0.0f;
-                    const float noise_x = hash_12_jitter(x + (float)sample_i, y, flag);
-                    const float u = (x + noise_x) / (float)(pc.cam.image_width - 1u);
-                    const float noise_y = hash_12_jitter(x, y + (float)sample_i, flag);
-                    const float v = (y + noise_y) / (float)(pc.cam.image_height - 1u);
-                    const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
-                    r = create_ray(origin, ray_dir);
-                    kind = 0;
-                    loop_count = 0;
-                    color = mk3(0, 0, 0);
-                    cur_dir_y = r.direction.y;
-                    st = (loop_count < max_bounce) ? kLaneStart : kLaneEnd;
-                }
-            }
-            // (6) a new ray: comp:271-312 (GridHit up to its loop)
-            if (st == kLaneStart) {
-                found = false;
-                st = kLaneDone;
-                if (grid_slab(p, r, 0.00001f, t_max, s)) {
-                    const float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
-                    const f3 fposition = p.scale_pow2 ? (ray_at(r, global_t_value) - g_min) * p.inv_grid_scale : (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
-                    w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta());
-                    const int px = f2i_clamp(__builtin_floorf(fposition.x));
-                    const int py = f2i_clamp(__builtin_floorf(fposition.y));
-                    const int pz = f2i_clamp(__builtin_floorf(fposition.z));
-                    w.rx = steps_left_box(s.sx, px, lox, hix, zero_budget);
-                    w.ry = steps_left_box(s.sy, py, loy, hiy, zero_budget);
-                    w.rz = steps_left_box(s.sz, pz, loz, hiz, zero_budget);
-                    base_x = walk_base_box(s.sx, px, lox, hix), base_y = walk_base_box(s.sy, py, loy, hiy), base_z = walk_base_box(s.sz, pz, loz, hiz);
-                    w.t_value = 0;
-                    grid_index = (uint32_t)px + (uint32_t)dx * ((uint32_t)pz + (uint32_t)dz * (uint32_t)py);
-                    stride_x = (uint32_t)s.sx, stride_y = (uint32_t)s.sy * (uint32_t)dx * (uint32_t)dz, stride_z = (uint32_t)s.sz * (uint32_t)dx;
-                    bool more = (global_t_value <= t_max) && (unsigned)px < (unsigned)dx && (unsigned)py < (unsigned)dy && (unsigned)pz < (unsigned)dz &&
-                                (w.rx | w.ry | w.rz) >= 0;
-                    int in_axis = 3; // the first cell of the walk was entered through the slab test, not by a step ...
-                    float skip_t = 0.0f;
-                    // ... unless the ray enters the grid in front of the occupied-cell box and jumps to its near face
-                    if (p.cell_bounds && p.skip_to_box)
-                        skip_to_box(w, s, (int)((uint32_t)hix - (uint32_t)lox), (int)((uint32_t)hiy - (uint32_t)loy), (int)((uint32_t)hiz - (uint32_t)loz), grid_index,
-                                    stride_x, stride_y, stride_z, more, in_axis, skip_t);
-                    if constexpr (DIL) {
-                        if (more) {
-                            // the walk's index in dilated form, from the cell the lane stands on (= base - step * steps left, after the
-                            // jump to the box as well); axes walked down are stored mirrored; stride_* become the loop's per-axis
-                            // "everything but this axis' field" masks (all ones: the axis is never stepped along)
-                            const uint32_t lx = hb.lx, lz = hb.lxz - hb.lx;
-                            const uint32_t ly = 31u - (uint32_t)__builtin_clz(p.grid.dim_y);
-                            const uint32_t cx = (uint32_t)(base_x - __mul24(s.sx, w.rx)), cy = (uint32_t)(base_y - __mul24(s.sy, w.ry)),
-                                           cz = (uint32_t)(base_z - __mul24(s.sz, w.rz));
-                            const uint32_t mx = s.sx < 0 ? ((uint32_t)dx - 1u - cx) : cx, my = s.sy < 0 ? ((uint32_t)dy - 1u - cy) : cy,
-                                           mz = s.sz < 0 ? ((uint32_t)dz - 1u - cz) : cz;
-                            // (DIL 3: 4 x 4 x 4-cell words: two y bits among the low six, and everything above one bit higher)
-                            constexpr uint32_t yb = DIL == 3 ? 2u : 1u, lo = 4u + yb;
-                            const uint32_t fx = 3u | (((1u << (lx - 2u)) - 1u) << lo), fz = (3u << 2) | (((1u << (lz - 2u)) - 1u) << (lx + lo - 2u)),
-                                           fy = (((1u << yb) - 1u) << 4) | (((1u << (ly - yb)) - 1u) << (lx + lz + lo - 4u));
-                            grid_index = (mx & 3u) | ((mz & 3u) << 2) | ((my & ((1u << yb) - 1u)) << 4) | ((mx >> 2) << lo) | ((mz >> 2) << (lx + lo - 2u)) |
-                                         ((my >> yb) << (lx + lz + lo - 4u));
-                            flip = (s.sx < 0 ? fx : 0u) | (s.sy < 0 ? fy : 0u) | (s.sz < 0 ? fz : 0u);
-                            stride_x = s.sx != 0 ? ~fx : ~0u, stride_y = s.sy != 0 ? ~fy : ~0u, stride_z = s.sz != 0 ? ~fz : ~0u;
-                        }
-                    }
-                    if (more) {
-                        if constexpr (FILTER) {
-                            ready = false;
-                            stale = true; // (the word is requested when the lane is about to take trips)
-                        } else if constexpr (AHEAD) {
-                            // prime the ring: q1 = the ray's first cell, q2 = the cell behind one step (comp:345-372), both words asked for
-                            ring.q1 = grid_index;
-                            ring.w1 = p.brick_status[grid_index >> 5];
-                            ring.ts1 = skip_t;
-                            int ax = 0;
-                            dda_step<true>(w, s.ray_delta(), g_scale, ax, grid_index, stride_x, stride_y, stride_z);
-                            ring.ts2 = w.t_value;
-                            ring.hist = ((uint32_t)in_axis << 2) | (uint32_t)ax;
-                            ring.q2 = (min3i(w.rx, w.ry, w.rz) < 0) ? ~0u : grid_index; // (the step left the box: the sentinel)
-                            ring.w2 = (ring.q2 != ~0u) ? p.brick_status[ring.q2 >> 5] : 0u;
-                        } else {
-                            if constexpr (DIL == 3) word64 = status_word64(grid_index);
-                            else word = status_word(grid_index);
-                            fresh_word = true;
-                        }
-                        g.t_out = skip_t;
-                        g.code = (uint32_t)in_axis << 4;
-                        st = kLaneWalk;
-                    }
-                }
-            }
-        }
-        VRT_PF_T(0, pf0);
-        // (7) every lane that has a ray walks (comp:314-375), until enough of them are done for the next round of transitions
-        unsigned long long walking = __builtin_amdgcn_ballot_w64(st == kLaneWalk);
-        if (walking == 0ull) continue;
-        [[maybe_unused]] const unsigned long long pf1 = VRT_PF_NOW();
-        if constexpr (FILTER) {
-            // (7a) lanes whose block is not known to hold occupied cells: look the block up (LDS); empty -> jump behind the step
-            // that leaves it (no memory access), and again, until enough lanes are ready for trips or the round's budget is spent
-            for (uint32_t it = 0; it < p.path_skip_rounds; it++) {
-                const bool seeking = (st == kLaneWalk) && !ready;
-                if (__builtin_amdgcn_ballot_w64(seeking) == 0ull) break;
-                if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kLaneWalk && ready)) >= p.path_ready_batch) break;
-                if (seeking) {
-                    const uint32_t bi = ((grid_index >> 2) & ((1u << fc.wx) - 1u)) | (((grid_index >> fc.shz) & fc.mz) << fc.wx) | ((grid_index >> fc.shy) << fc.shyb);
-                    if ((lds_block_filter[bi >> 5] >> (bi & 31u)) & 1u) {
-                        ready = true;
-                    } else {
-                        bool more = true;
-                        int in_axis = 0;
-                        float t_in = 0.0f;
-                        skip_empty_block(w, s, grid_index & 3u, (grid_index >> (fc.shy - 2u)) & 3u, (grid_index >> (fc.wx + 2u)) & 3u, grid_index, stride_x, stride_y,
-                                         stride_z, more, in_axis, t_in);
-                        g.t_out = t_in;
-                        g.code = (uint32_t)in_axis << 4;
-                        stale = true;
-                        if (!more) {
-                            found = false; // left the box of the occupied cells
-                            st = kLaneDone;
-                        }
-                    }
-                }
-            }
-            walking = __builtin_amdgcn_ballot_w64(st == kLaneWalk && ready);
-            if (walking == 0ull) continue;
-            if (st == kLaneWalk && ready && stale) {
-                word = status_word(grid_index);
-                stale = false;
-            }
-        }
-        const uint32_t n_walking = (uint32_t)__builtin_popcountll(walking);
-        const uint32_t fin = min(p.path_fin_batch, max(1u, n_walking >> 1));
-        g.alive = walking;
-        // (FILTER: five trips per call, the way through a block of four cells; then the blocks are looked up again)
-        g.min_alive = FILTER ? 65u : (n_walking >= fin ? n_walking - fin + 1u : 1u);
-        uint32_t cell; // the occupied cell each parked lane stood on before its last step
-        [[maybe_unused]] unsigned long long gone = 0ull; // DIL 2, 3: the parked lanes whose step out of that cell left the grid
-        if constexpr (AHEAD) {
-            AheadWalkRegs ga;
-            ga.alive = g.alive;
-            ga.batch = g.batch;
-            ga.min_alive = g.min_alive;
-            grid_walk_ahead_gfx950(w, s.inv_dir, ring, stride_x, stride_y, stride_z, rsrc, ga);
-            g.alive = ga.alive;
-            g.parked = ga.parked;
-            cell = ring.q0;
-        } else if constexpr (DIL == 4) {
-            grid_walk_park_dilated_ahead_gfx950(w.side_dist, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, flip, gone);
-        } else if constexpr (DIL == 3) {
-            grid_walk_park_dilated64_gfx950(w.side_dist, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word64, blk_rsrc, g, flip, gone);
-        } else if constexpr (DIL == 2) {
-            grid_walk_park_dilated_carry_gfx950(w.side_dist, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, flip, gone);
-        } else if constexpr (DIL == 1) {
-            grid_walk_park_dilated_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, flip);
-        } else if constexpr (DIST) {
-            const unsigned long long fresh = __builtin_amdgcn_ballot_w64(fresh_word);
-            dr.pend |= fresh;
-            if (fresh_word) dr.k = 0;
-            fresh_word = false;
-            grid_walk_park_dist_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, dist_rsrc, g, dr);
-        } else if constexpr (halfblocks) grid_walk_park_halfblocks_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, hb_rsrc, g, hb);
-        else grid_walk_park_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
-        VRT_PF_T(1, pf1);
-        VRT_PF_N(2, 1);
-        VRT_PF_N(3, n_walking);
-        VRT_PF_N(4, __builtin_popcountll(g.alive));
-        [[maybe_unused]] const unsigned long long pf2 = VRT_PF_NOW();
-        const bool was_walking = (walking >> lane) & 1ull;
-        const bool parked = __builtin_amdgcn_inverse_ballot_w64(g.parked);
-        const bool moving = __builtin_amdgcn_inverse_ballot_w64(g.alive);
-        if (was_walking && !parked && !moving) {
-            found = false; // left the box of the occupied cells
-            st = kLaneDone;
-        }
-        if constexpr (FILTER) {
-            if (was_walking) ready = false; // it has moved: its block is looked up again
-        }
-        if (g.parked != 0ull) {
-            VRT_PF_N(5, 1);
-            VRT_PF_N(6, __builtin_popcountll(g.parked));
-            if (parked) {
-                // AHEAD: the lane's DDA state is two steps beyond the occupied cell q0: undo both decrements; q0 was entered through
-                // the axis in hist bits 4-5 at distance ts0.  Otherwise the lane has taken one step out of the cell.
-                int a = AHEAD ? (int)((ring.hist >> 4) & 3u) : (int)(g.code & 3u);
-                const uint32_t out = AHEAD ? ((ring.hist >> 2) & 3u) : ((g.code >> 2) & 3u), out2 = AHEAD ? (ring.hist & 3u) : 3u;
-                const float t_into = AHEAD ? ring.ts0 : g.t_in;
-                const int rx = w.rx + (out == 0u ? 1 : 0) + (out2 == 0u ? 1 : 0), ry = w.ry + (out == 1u ? 1 : 0) + (out2 == 1u ? 1 : 0),
-                          rz = w.rz + (out == 2u ? 1 : 0) + (out2 == 2u ? 1 : 0);
-                int cx = base_x - __mul24(s.sx, rx), cy = base_y - __mul24(s.sy, ry), cz = base_z - __mul24(s.sz, rz); // cell position
-                if constexpr (DIL >= 2) { // (no counters: the position is the loop's own index, un-mirrored and un-dilated)
-                    constexpr uint32_t yb = DIL == 3 ? 2u : 1u, lo = 4u + yb;
-                    const uint32_t real = cell ^ flip, lx = hb.lx, lz = hb.lxz - hb.lx;
-                    cx = (int)((real & 3u) | ((real >> (lo - 2u)) & (((1u << (lx - 2u)) - 1u) << 2)));
-                    cz = (int)(((real >> 2) & 3u) | ((real >> (lx + lo - 4u)) & (((1u << (lz - 2u)) - 1u) << 2)));
-                    cy = (int)(((real >> 4) & ((1u << yb) - 1u)) | ((real >> (lx + lz + lo - 4u)) << yb));
-                }
-                if constexpr (DIL) cell = (uint32_t)cx + (uint32_t)dx * ((uint32_t)cz + (uint32_t)dz * (uint32_t)cy); // (the loop's index is dilated)
-                const uint32_t occ_slot = by_cell ? cell : p.brick_index[cell]; // comp:337 (by_cell: only on a solid voxel)
-                if constexpr (B == 8) {
-                    if (p.path_brick_lds) stage_brick_lds(p, occ_slot, by_cell, wave_lds); // (first: the arithmetic below runs while the brick arrives)
-                }
-                const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min);  // comp:331
-                const float global_t_value = t_into * g_scale + s.grid_t_min + 0.01f * g_scale;          // comp:347 (deferred) + comp:332
-                hit.t = global_t_value;
-                bool hit_voxel;
-                if constexpr (B == 8) {
-                    hit_voxel = p.path_brick_lds ? brick_walk_park_gfx950<B, true, true>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis, wave_lds)
-                                                 : brick_walk_park_gfx950<B>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis);
-                } else {
-                    hit_voxel = brick_walk_park_gfx950<B>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis);
-                }
-                if (hit_voxel) {
-                    found = true;
-                    st = kLaneDone;
-                } else if (!(global_t_value <= t_max) || (DIL >= 2 ? __builtin_amdgcn_inverse_ballot_w64(gone) : (!AHEAD && min3i(w.rx, w.ry, w.rz) < 0))) {
-                    found = false; // t became NaN (comp:316), or the step out of this cell left the box
-                    st = kLaneDone;
-                } else if constexpr (!AHEAD) {
-                    if constexpr (DIL == 3) word64 = status_word64(grid_index);
-                    else word = status_word(grid_index); // (an A-trip park left the lane's word in the other register set)
-                    fresh_word = true;
-                }   // (AHEAD: the lane walks on as it is; a step that left the box has put the sentinel into its ring)
-            }
-        }
-        // every lane of the call: the axis of its last step, for its first trip in the next call
-        if (!AHEAD && was_walking)
-            g.code = parked ? ((g.code >> 2) & 3u) << 4
-                            : (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
-        VRT_PF_T(2, pf2);
-    }
-#ifdef VRT_DEV_PROFILE
-    if (p.wave_timeline && lane == 0u) {
-        for (int k = 0; k < 3; k++) atomicAdd(&p.wave_timeline[k], pf_t[k]);
-        for (int k = 0; k < 8; k++) atomicAdd(&p.wave_timeline[3 + k], pf_n[k]);
-        atomicAdd(&p.wave_timeline[11], 1ull);
-    }
-    __syncthreads();
-    if (p.wave_timeline && threadIdx.x < 8) atomicAdd(&p.wave_timeline[12 + threadIdx.x], vrt_prof[threadIdx.x]);
-#endif
-#undef VRT_PF_T
-#undef VRT_PF_N
-#undef VRT_PF_NOW
 }
 
 } // namespace vrt
