@@ -138,7 +138,7 @@ pub const SunDevice = extern struct { // Sun.Device, Sun.zig:13-18 (32 bytes)
 
 pub const Config = extern struct {
     struct_size: u32 = @sizeOf(Config),
-    abi_version: u32 = 1,
+    abi_version: u32 = 2, // VRT_ABI_VERSION
     width: u32,
     height: u32,
     brick_dimension: u32 = 4, // State.brick_dimension

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 1u
+#define VRT_ABI_VERSION 2u /* 2 (round 4): + vrt_region_begin / _end, vrt_last_denoise_ms, tuning flags 13-14; the product build refuses development kernel_variants */
 
 /* ---- status codes (replace Zig error unions, e.g. StagingRamp.zig:320-325) */
 enum {
@@ -323,9 +323,15 @@ const char *vrt_last_error(const vrt_ctx *ctx); /* ctx may be NULL: create error
 uint32_t vrt_abi_version(void);
 /* The traversal kernel that rendered the most recent frame (before the first frame: the one a frame without bounces and with
  * one sample per pixel would take), as its template-id — the kernel name rocprofv3 reports minus the `void vrt::` prefix and
- * the argument list, e.g. "vrt_trace_kernel<8, false, 7, 7, 2, 256>" (B, COUNT, MODE, MIN_WAVES, SHADE, BLOCK) or
- * "vrt_path_kernel<8, 5, false, true>" (B, MIN_WAVES, FILTER, HALF).  On a counting context: the product kernel, not the
- * counting build that ran before it. */
+ * the argument list: "vrt_trace_kernel<8, false, 7, 7, 2, 256>" (B, COUNT, MODE, MIN_WAVES, SHADE, BLOCK),
+ * "vrt_path_kernel<8, 5, false, false, false, false, 1>" (B, MIN_WAVES, FILTER, HALF, AHEAD, DIST, DIL) or
+ * "vrt_pool_kernel<8, 5, 64, 2>" (B, MIN_WAVES, SLOTS, STAGES).  On a counting context: the product kernel, not the counting build that
+ * ran before it.  The name is that of the LAST frame and may change between frames of one context: a context whose bounce frames
+ * the persistent kernels trace starts on vrt_path_kernel<..., DIL 1> and moves to vrt_pool_kernel (8^3 bricks) or <..., DIL 2> once the
+ * host copy of the occupied cells' box has arrived and says that the box is the grid; frames of other sample / bounce counts take
+ * other kernels.  The product build (make) holds the kernels the library chooses itself — kernel_variant modes 0, 5 and 9 with the
+ * occupancy and order fields — and answers every other kernel_variant with VRT_E_INVALID_ARG; the development build (make dev) holds
+ * them all (ABI version 2 records that change). */
 const char *vrt_kernel_name(const vrt_ctx *ctx);
 /* number of traversal kernels compiled into this build of the library (tests/test_kernel_resources.py) */
 int vrt_compiled_kernel_count(void);

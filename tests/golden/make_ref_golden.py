@@ -56,9 +56,23 @@ CASES = {
 }
 
 
+def check_implementation(info: str, directory: str) -> None:
+    """The product's arithmetic contract is this ONE implementation's lowering of the shader: every fixture records the
+    GL implementation that rendered it, and regenerating them under another one (another Mesa / LLVM build lowers fma, dot or sin
+    differently) must be a decision, not an accident."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(directory, "*.npz"))):
+        prov = str(np.load(f)["provenance"])
+        if info not in prov and "--accept-implementation-change" not in sys.argv:
+            raise SystemExit(f"{os.path.basename(f)} was rendered by another GL implementation than the one here:\n  fixture: ...{prov[-110:]}\n  here:    {info}\n"
+                             "the frames would move with the implementation's lowering of the shader (vrt_math.h, DESIGN.md 3); re-run with "
+                             "--accept-implementation-change to regenerate every fixture under this one")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     info = GlRef().info()
+    check_implementation(info, OUT)
     refs = {}
     for name, (w, view, mats) in CASES.items():
         grid = W.build_grid(w)
@@ -97,6 +111,7 @@ def main_present():
     from oracle.ref_gl import ReferencePresent
     rp = ReferencePresent()
     info = GlRef().info()
+    check_implementation(info, OUT)
     for name, (src, (ow, oh), kw) in PRESENT_CASES.items():
         img = np.load(os.path.join(OUT, src + ".npz"))["rgba8"]
         f = rp.render(img, ow, oh, **kw)
@@ -148,6 +163,7 @@ def main_full():
     from tests.golden.make_golden import scene_digest
     os.makedirs(FULL_OUT, exist_ok=True)
     info = GlRef().info()
+    check_implementation(info, FULL_OUT)
     grids, refs = {}, {}
     for name, (w, view, radius, size) in full_cases().items():
         grid = grids.setdefault(w.name, W.build_grid(w))

@@ -50,6 +50,20 @@ def _flipped(f, ref_rgb):
     return d, int((d > TOL).sum())
 
 
+def test_every_reference_fixture_names_the_one_implementation_that_rendered_it():
+    """the product's arithmetic is pinned to ONE GL implementation's lowering of the shader; the fixtures say which, all of
+    them the same, and tests/golden/make_ref_golden.py refuses to regenerate them under another without being told to."""
+    import glob
+    import re
+    names = set()
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref*", "*.npz"))):
+        prov = str(np.load(f)["provenance"])
+        m = re.search(r"Mesa [0-9][^|]*\| llvmpipe \(LLVM [0-9.]+, \d+ bits\)", prov)
+        assert m, (f, prov)
+        names.add(m.group(0))
+    assert len(names) == 1, names
+
+
 def test_fixtures_present():
     assert len(FIXTURES) >= 11
     for p in FIXTURES:
