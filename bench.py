@@ -903,10 +903,11 @@ def main(argv=None) -> None:
     sustained = None
     if not sharded and not stub:
         lg = plan[0][1]
-        lg.run(int(min(4000, PRECONDITION_MS / frame_ms_est)))
+        pre_sustained = int(min(4000, PRECONDITION_MS / frame_ms_est))
+        lg.run(pre_sustained)
         lg.run(args.warmup)
         dts = lg.timed(args.steps)
-        sustained = {"value": rays_of(per_view, args.steps) / dts / 1e6, "ms_per_step": dts / args.steps * 1e3,
+        sustained = {"value": rays_of(per_view, args.steps) / dts / 1e6, "ms_per_step": dts / args.steps * 1e3, "precondition_frames": pre_sustained,
                      "value_device_events": (rays_of(per_view, args.steps) / (lg.device_ms * 1e-3) / 1e6) if lg.device_ms else None,
                      "note": f"the same {args.steps} steps timed again behind {PRECONDITION_MS:.0f} ms of untimed frames + the warm-up: the rate of a renderer that runs "
                              "continuously (the clocks ramp for tens of milliseconds); `value` is the cold protocol's"}

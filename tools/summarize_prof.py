@@ -34,30 +34,34 @@ if os.path.exists(log):
         if not line or not line.get("roofline"):
             break
         db = sqlite3.connect(f)
-        d = [r[0] / 1e3 for r in db.execute("select duration from kernels where name like '%vrt_trace_kernel<%, false,%' or name like '%vrt_path_kernel<%' order by start")]
+        d = [r[0] / 1e3 for r in db.execute("select duration from kernels where name like '%vrt_trace_kernel<%, false,%' or name like '%vrt_path_kernel<%' or name like '%vrt_pool_kernel<%' order by start")]
         steps, warmup = line["steps"], line["warmup"]
         pre = line.get("precondition_frames", 0)
         views = line["config"]["views"] + line["config"].get("views_reported_only", [])
         settle = line["roofline"]["settle_frames"]
         reps = line["roofline"].get("timed_frames_per_view") or max(8, steps // len(line["config"]["views"]))
         timed = min(reps, 512)
-        # bench.py's launch sequence of the PRODUCT kernel: 2 counting contexts x views x 1 frame | 2 probe frames, pre-conditioning,
-        # warm-up, timed region | (single-stream leg) warm-up, timed region | per view: settle, `reps` back to back, min(reps, 512) timed
-        head = 2 * len(views) + 2 + pre + 2 * (warmup + steps)
-        want = head + len(views) * (settle + reps + timed)
+        # bench.py's launch sequence of the PRODUCT kernel (round 4): 2 counting contexts x views x 1 frame | 2 probe frames, pre-conditioning
+        # (0 by default), warm-up, timed region | `value_sustained`: ~150 ms of frames, warm-up, timed region | (single-stream leg) warm-up,
+        # timed region | per view: settle, `reps` back to back, min(reps, 512) timed | present pass: 64 frames
+        sus = (line.get("value_sustained") or {}).get("precondition_frames")
+        sus_n = (sus + warmup + steps) if sus is not None else 0
+        tail = 64 if line.get("present_pass") and "error" not in line["present_pass"] else 0
+        head = 2 * len(views) + 2 + pre + (warmup + steps) + sus_n + (warmup + steps)
+        want = head + len(views) * (settle + reps + timed) + tail
         print(f"\n## {len(d)} launches of the traversal kernel by bench.py phase (us)")
         if len(d) != want:
             print(f"   (expected {want} launches from the bench line; phase breakdown skipped)")
             continue
         a = 2 * len(views) + 2 + pre
         main = d[a + warmup:a + warmup + steps]
-        single = d[a + warmup + steps + warmup:a + 2 * (warmup + steps)]
+        single = d[a + warmup + steps + sus_n + warmup:a + sus_n + 2 * (warmup + steps)]
         two = "1 frame(s) in flight" not in line["config"]["parallelism"]
         print(f"   timed region ({steps} launches): avg {sum(main) / steps:.2f}"
               + ("  (two frames in flight: two kernels share the GPU, a kernel's duration is not a frame's cost)" if two else ""))
         print(f"   single-stream timed region ({steps} launches): avg {sum(single) / steps:.2f}   "
               f"(bench line ms_per_step_single_stream, wall clock incl. launch gaps: {line['ms_per_step_single_stream'] * 1e3:.2f})")
-        leg = d[head:]
+        leg = d[head:len(d) - tail]
         per = settle + reps + timed
         tot = []
         for v, name in enumerate(views):
