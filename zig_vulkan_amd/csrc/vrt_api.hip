@@ -44,7 +44,6 @@ hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint
 hipError_t launch_build_status_bytes(const TraceParams &p, hipStream_t stream);
 hipError_t launch_build_status_halfblocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_build_cell_distance(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
-hipError_t launch_build_status_halfblocks_tiled(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_build_cell_bounds(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, uint64_t cell_lo, uint64_t cell_hi, uint64_t slot_lo,
                                        uint64_t slot_hi, hipStream_t stream);
@@ -195,7 +194,6 @@ struct vrt_ctx {
     uint8_t *d_status_bytes = nullptr; // derived: one byte per grid cell (TraceParams::status_bytes)
     uint8_t *d_cell_distance = nullptr;      // derived: L1 distance of every cell to the nearest occupied cell (vrt_path_kernel<DIST>)
     uint32_t *d_status_halfblocks = nullptr; // derived: status bits by 4 x 4 x 2 cells per word (vrt_path_kernel on eligible grids)
-    uint32_t *d_status_halfblocks_tiled = nullptr; // ... the same words in tiled order (vrt_pool_kernel)
     uint8_t *d_cell_occupancy = nullptr;     // derived: occupancy bits by cell (TraceParams::cell_occupancy; vrt_path_kernel, within a memory budget)
     uint32_t *d_start_is_slot = nullptr;     // derived: 1 = binding 6 holds slot * B^3 for every allocated brick (TraceParams::start_is_slot)
     bool occupancy_dirty = true;             // bindings 3-5 changed since the by-cell copy was built ...
@@ -280,7 +278,6 @@ void free_ctx(vrt_ctx *c) {
     if (c->own_t8 && c->target8) (void)hipFree(c->target8);
     if (c->own_t32 && c->target32f) (void)hipFree(c->target32f);
     if (c->d_counters) (void)hipFree(c->d_counters);
-    if (c->d_status_halfblocks_tiled) (void)hipFree(c->d_status_halfblocks_tiled);
     if (c->d_work_counter) (void)hipFree(c->d_work_counter);
     if (c->d_pool_paths) (void)hipFree(c->d_pool_paths);
     if (c->d_status_blocks) (void)hipFree(c->d_status_blocks);
@@ -887,9 +884,6 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if ((e1 && e1->path == 2) || (e2 && e2->path == 2)) {
             // (never read before it is written: a path's record is filled by the transition that gives the path its first pixel)
             c->pool_stream_dwords = (size_t)(8 * cus) * 4u * vrt::kPoolPaths * vrt::kPoolPathDwords; // (room for any occupancy)
-            const size_t bytes_hb = (size_t)(cells / 32u) * 4u + 64u;
-            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_status_halfblocks_tiled), bytes_hb));
-            VRT_CREATE_HIP(hipMemsetAsync(c->d_status_halfblocks_tiled, 0, bytes_hb, c->stream));
             VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_pool_paths), 2u * c->pool_stream_dwords * sizeof(uint32_t)));
         }
     }
@@ -961,7 +955,6 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.cell_bounds = c->d_cell_bounds;
     p.status_bytes = c->d_status_bytes;
     p.status_halfblocks = c->d_status_halfblocks;
-    p.status_halfblocks_tiled = c->d_status_halfblocks_tiled;
     p.cell_distance = c->d_cell_distance;
     p.cell_occupancy = c->d_cell_occupancy;
     p.start_is_slot = c->d_start_is_slot;
@@ -1135,7 +1128,6 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
         }
         VRT_HIP(ctx, vrt::launch_build_status_bytes(ctx->params, ctx->stream));
         VRT_HIP(ctx, vrt::launch_build_status_halfblocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
-        VRT_HIP(ctx, vrt::launch_build_status_halfblocks_tiled(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
         VRT_HIP(ctx, vrt::launch_build_cell_distance(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
         rcw = end_scene_write(ctx);
         if (rcw != VRT_OK) return rcw;

@@ -118,11 +118,6 @@ struct TraceParams {
     uint32_t path_eager_start;           // ... and its brick_start_index entry is requested together with the brick (one dependent miss less per hit)
     // vrt_pool_kernel (round 4: a pool of 128 rays per wave, vrt_pool_kernel.h): the paths' records in global memory, 16 dwords per
     // path by field, one block of 128 paths per wave of the launch; and the phase rule's four numbers
-    // derived from binding 3 for vrt_pool_kernel (nullptr: not built): the half-block words of status_halfblocks in TILED order — word
-    // index = (x>>2 & 3) | (z>>2 & 3) << 2 | (y>>1 & 1) << 4 | the higher bits of x, z, y above — so that a 128-byte line holds the 32
-    // half-blocks of a 16 x 16 x 4-cell box instead of a 128 x 4 x 2-cell pencil along x: a ray in a general direction changes lines
-    // half as often (round 4)
-    const uint32_t *status_halfblocks_tiled;
     uint32_t *pool_paths;
     uint32_t pool_cus;                   // compute units: min_waves workgroups are launched for each
     uint32_t pool_walk_k;                // a call of the walk loop returns once this many of its lanes have parked or left

@@ -88,23 +88,11 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
     // the dilated cell index (vrt_trace_kernels.h, grid_walk_park_dilated_gfx950): the three axes' bit fields
     const uint32_t lx = uni(31u - (uint32_t)__builtin_clz(p.grid.dim_x)), lz = uni(31u - (uint32_t)__builtin_clz(p.grid.dim_z)),
                    ly = uni(31u - (uint32_t)__builtin_clz(p.grid.dim_y));
-    // ... in TILED order (TraceParams::status_halfblocks_tiled): above the five bits of the cell's place in its half-block come the
-    // half-block's place in its 128-byte line (x >> 2 & 3, z >> 2 & 3, y >> 1 & 1 — a 16 x 16 x 4-cell box per line), then the rest of x, z, y
-    const uint32_t wxb = uni(min(2u, lx - 2u)), wzb = uni(min(2u, lz - 2u)), wyb = uni(min(1u, ly - 1u));
-    const uint32_t wxc = uni(lx - 2u - wxb), wzc = uni(lz - 2u - wzb), wyc = uni(ly - 1u - wyb);
-    const uint32_t sxb = 5u, szb = uni(5u + wxb), syb = uni(5u + wxb + wzb), sxc = uni(5u + wxb + wzb + wyb), szc = uni(sxc + wxc), syc = uni(szc + wzc);
-    const uint32_t fx = uni(3u | (((1u << wxb) - 1u) << sxb) | (((1u << wxc) - 1u) << sxc)),
-                   fz = uni((3u << 2) | (((1u << wzb) - 1u) << szb) | (((1u << wzc) - 1u) << szc)),
-                   fy = uni((1u << 4) | (((1u << wyb) - 1u) << syb) | (((1u << wyc) - 1u) << syc));
-    // a cell's (mirrored) coordinates -> the index, and back
-    auto dilate = [&](uint32_t mx, uint32_t my, uint32_t mz) {
-        const uint32_t bx = mx >> 2, bz = mz >> 2, by = my >> 1;
-        return (mx & 3u) | ((mz & 3u) << 2) | ((my & 1u) << 4) | ((bx & ((1u << wxb) - 1u)) << sxb) | ((bz & ((1u << wzb) - 1u)) << szb) |
-               ((by & ((1u << wyb) - 1u)) << syb) | ((bx >> wxb) << sxc) | ((bz >> wzb) << szc) | ((by >> wyb) << syc);
-    };
+    const uint32_t fx = uni(3u | (((1u << (lx - 2u)) - 1u) << 5)), fz = uni((3u << 2) | (((1u << (lz - 2u)) - 1u) << (lx + 3u))),
+                   fy = uni((1u << 4) | (((1u << (ly - 1u)) - 1u) << (lx + lz + 1u)));
     u32x4 hb_rsrc;
     {
-        const unsigned long long a = (unsigned long long)p.status_halfblocks_tiled;
+        const unsigned long long a = (unsigned long long)p.status_halfblocks;
         hb_rsrc.x = uni((uint32_t)a);
         hb_rsrc.y = uni((uint32_t)(a >> 32) | (4u << 16));
         hb_rsrc.z = uni(p.status_words);
@@ -433,9 +421,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                                            cz = (uint32_t)(base_z - __mul24(s.sz, w.rz));
                             const uint32_t mx = s.sx < 0 ? ((uint32_t)dx - 1u - cx) : cx, my = s.sy < 0 ? ((uint32_t)dy - 1u - cy) : cy,
                                            mz = s.sz < 0 ? ((uint32_t)dz - 1u - cz) : cz;
-                            idx = dilate(mx, my, mz);
+                            idx = (mx & 3u) | ((mz & 3u) << 2) | ((my & 1u) << 4) | ((mx >> 2) << 5) | ((mz >> 2) << (lx + 3u)) | ((my >> 1) << (lx + lz + 1u));
                             const uint32_t flip = (s.sx < 0 ? fx : 0u) | (s.sy < 0 ? fy : 0u) | (s.sz < 0 ? fz : 0u);
-                            cw = p.status_halfblocks_tiled[(idx ^ flip) >> 5];
+                            cw = p.status_halfblocks[(idx ^ flip) >> 5];
                             sd = w.side_dist;
                             t_out = skip_t;
                             t_in = 0.0f;
@@ -523,9 +511,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 const uint32_t flip = (sx < 0 ? fx : 0u) | (sy < 0 ? fy : 0u) | (sz < 0 ? fz : 0u);
                 // the cell's position from the walk's index, un-mirrored and un-dilated
                 const uint32_t real = cw ^ flip;
-                const int cx = (int)((real & 3u) | (((real >> sxb) & ((1u << wxb) - 1u)) << 2) | (((real >> sxc) & ((1u << wxc) - 1u)) << (2u + wxb)));
-                const int cz = (int)(((real >> 2) & 3u) | (((real >> szb) & ((1u << wzb) - 1u)) << 2) | (((real >> szc) & ((1u << wzc) - 1u)) << (2u + wzb)));
-                const int cy = (int)(((real >> 4) & 1u) | (((real >> syb) & ((1u << wyb) - 1u)) << 1) | ((real >> syc) << (1u + wyb)));
+                const int cx = (int)((real & 3u) | ((real >> 3) & (((1u << (lx - 2u)) - 1u) << 2)));
+                const int cz = (int)(((real >> 2) & 3u) | ((real >> (lx + 1u)) & (((1u << (lz - 2u)) - 1u) << 2)));
+                const int cy = (int)(((real >> 4) & 1u) | ((real >> (lx + lz + 1u)) << 1));
                 const uint32_t cell = (uint32_t)cx + (uint32_t)dx * ((uint32_t)cz + (uint32_t)dz * (uint32_t)cy);
                 const uint32_t occ_slot = by_cell ? cell : p.brick_index[cell]; // comp:337 (by_cell: only on a solid voxel)
                 stage_brick_lds(p, occ_slot, by_cell, wave_lds); // (first: the arithmetic below runs while the brick arrives)
@@ -552,7 +540,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                     st = kRayMiss; // t became NaN (comp:316), or the step out of this cell left the grid
                 } else {
                     st = kRayWalk;
-                    cw = p.status_halfblocks_tiled[(idx ^ flip) >> 5]; // (an A-trip park left the lane's word in the other register set)
+                    cw = p.status_halfblocks[(idx ^ flip) >> 5]; // (an A-trip park left the lane's word in the other register set)
                     code = ((code >> 2) & 3u) << 4;              // the axis of its last step, for its first trip in the next call
                 }
             }

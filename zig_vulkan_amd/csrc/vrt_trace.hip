@@ -58,34 +58,6 @@ __global__ __launch_bounds__(256) void vrt_build_status_halfblocks(const uint32_
     out[wi] = word;
 }
 
-// The same words in TILED order (TraceParams::status_halfblocks_tiled, vrt_pool_kernel; all three dimensions powers of two): word index
-// = xb | zb << wxb | yb << (wxb + wzb) | xc << (wxb + wzb + wyb) | zc << (.. + wxc) | yc << (.. + wxc + wzc), where x >> 2 = xb | xc << wxb
-// with wxb = min(2, log2(dim_x) - 2) bits (z alike), y >> 1 = yb | yc << wyb with wyb = min(1, log2(dim_y) - 1).  One thread per word.
-__global__ __launch_bounds__(256) void vrt_build_status_halfblocks_tiled(const uint32_t *__restrict__ status, uint32_t *__restrict__ out, uint32_t lx,
-                                                                         uint32_t ly, uint32_t lz) {
-    const uint32_t wxb = min(2u, lx - 2u), wzb = min(2u, lz - 2u), wyb = min(1u, ly - 1u);
-    const uint32_t wxc = lx - 2u - wxb, wzc = lz - 2u - wzb;
-    const uint32_t words = 1u << (lx + lz + ly - 5u);
-    const uint32_t wi = blockIdx.x * 256u + threadIdx.x;
-    if (wi >= words) return;
-    uint32_t r = wi;
-    auto take = [&](uint32_t bits) {
-        const uint32_t v = r & ((1u << bits) - 1u);
-        r >>= bits;
-        return v;
-    };
-    const uint32_t xb = take(wxb), zb = take(wzb), yb = take(wyb), xc = take(wxc), zc = take(wzc), yc = r;
-    const uint32_t bx = xb | (xc << wxb), bz = zb | (zc << wzb), by = yb | (yc << wyb);
-    const uint32_t dim_x = 1u << lx, dim_z = 1u << lz;
-    uint32_t word = 0u;
-    for (uint32_t k = 0; k < 32u; k++) {
-        const uint32_t x = bx * 4u + (k & 3u), z = bz * 4u + ((k >> 2) & 3u), y = by * 2u + (k >> 4);
-        const uint32_t gi = x + dim_x * (z + dim_z * y);
-        word |= ((status[gi >> 5] >> (gi & 31u)) & 1u) << k;
-    }
-    out[wi] = word;
-}
-
 // The L1 distance field of the occupied cells (TraceParams::cell_distance; grid_walk_park_dist_gfx950): one byte per cell, 0 where
 // the status bit is set, else min(255, Manhattan distance in cells to the nearest set bit).  The L1 distance transform separates:
 // seed 0 / 255, then along each axis in turn a forward and a backward sweep d = min(d, neighbour + 1) — exact after x, z, y (the
@@ -634,15 +606,6 @@ hipError_t launch_build_status_halfblocks(const TraceParams &p, uint32_t dim_x, 
     const uint32_t words = (dim_x >> 2) * (dim_z >> 2) * (dim_y >> 1);
     hipLaunchKernelGGL(vrt_build_status_halfblocks, dim3((words + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
                        const_cast<uint32_t *>(p.status_halfblocks), dim_x, dim_y, dim_z);
-    return hipGetLastError();
-}
-
-hipError_t launch_build_status_halfblocks_tiled(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
-    if (!p.status_halfblocks_tiled) return hipSuccess;
-    const uint32_t lx = 31u - (uint32_t)__builtin_clz(dim_x), ly = 31u - (uint32_t)__builtin_clz(dim_y), lz = 31u - (uint32_t)__builtin_clz(dim_z);
-    const uint32_t words = 1u << (lx + lz + ly - 5u);
-    hipLaunchKernelGGL(vrt_build_status_halfblocks_tiled, dim3((words + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
-                       const_cast<uint32_t *>(p.status_halfblocks_tiled), lx, ly, lz);
     return hipGetLastError();
 }
 
