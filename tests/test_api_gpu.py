@@ -192,3 +192,27 @@ def test_kernel_name_is_the_symbol_that_ran():
         rt.deinit()
     assert L.lib.vrt_compiled_kernel_count() == 27   # 26 + vrt_pool_kernel (round 4)
     assert re.fullmatch(r"vrt_(trace|path)_kernel<[^>]+>", "vrt_trace_kernel<8, false, 7, 7, 2, 256>")
+
+
+def test_region_and_present_timing_by_device_events():
+    """Round 4 (ABI version 2): vrt_region_begin / _end bracket dispatches with HIP events on both of the context's streams (SURVEY.md 8(d));
+    vrt_last_denoise_ms times the present pass.  The region covers at least the frames' own kernel times; calls out of order are errors."""
+    w = W.Workload("t", 320, 200, 64, 8, 1, 0, True, 5.0)
+    grid = W.build_grid(w)
+    for fif in (1, 2):
+        rt = W.make_renderer(w, grid, frames_in_flight=fif)
+        with pytest.raises(VrtError):
+            rt.region_end()                      # no region begun
+        W.set_view(rt, "V1")
+        rt.draw(frames=4)
+        rt.wait()
+        one = rt.last_kernel_ms()
+        rt.region_begin()
+        for _ in range(6):
+            rt.draw()
+        ms = rt.region_end()
+        assert ms > 0.0 and ms >= 0.5 * 6 * one / fif and ms < 1000.0, (fif, ms, one)
+        assert rt.last_denoise_ms() < 0.0        # no present pass issued yet
+        rt.present(400, 260)
+        assert 0.0 < rt.last_denoise_ms() < 100.0
+        rt.deinit()
