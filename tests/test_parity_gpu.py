@@ -707,3 +707,51 @@ def test_small_frames_split_every_tile_and_keep_the_frame():
             assert np.array_equal(frames[(0, v)][1], frames[(L.TUNE_NO_SMALL_FRAME_SPLIT, v)][1]), (w.name, v)
         fo, uo, _ = O.render(oracle_scene_from_grid(grid), pc)
         assert np.array_equal(frames[(0, "V2")][0].view(np.uint32), fo.view(np.uint32)) and np.array_equal(frames[(0, "V2")][1], uo), w.name
+
+
+def test_pool_kernel_shards_two_frames_in_flight_and_frames_smaller_than_a_wave():
+    """vrt_pool_kernel (round 4: a pool of 128 rays per wave; taken where the counter-free dilated-index walk would run on 8^3 bricks — a
+    scene whose occupied cells reach the grid's faces, once the host knows the box): a shard (rank 1 of 3) holds the lockstep kernel's
+    packed tiles; two frames in flight (two streams, a pixel counter and a block of path records each) equal the single-stream frames;
+    a frame of fewer pixels than ONE wave's 128 paths, odd frame sizes, one sample and sixteen: all the oracle's / the lockstep kernel's."""
+    w = W.Workload("t", 208, 112, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000)
+    grid = W.build_grid(w)
+
+    def frames(views, **kw):
+        rt = W.make_renderer(w, grid, **kw)
+        W.set_view(rt, views[0])
+        rt.draw()
+        rt.wait()      # (the box of the occupied cells has reached the host)
+        out = []
+        for v in views:
+            W.set_view(rt, v)
+            rt.draw()
+            out.append(rt.read_rgba8().copy())
+        name = rt.kernel_name()
+        rt.deinit()
+        return out, name
+
+    a, name = frames(["V2"], shard_rank=1, shard_count=3, kernel_variant=PATH)
+    assert name.startswith("vrt_pool_kernel<8,"), name
+    b, name_b = frames(["V2"], shard_rank=1, shard_count=3, kernel_variant=1 << 21)
+    assert name_b.startswith("vrt_trace_kernel<8,")
+    assert np.array_equal(a[0], b[0]) and a[0].any()
+    views = ["V0", "V2", "V1x", "V2", "V0"]
+    one, n1 = frames(views, kernel_variant=PATH)
+    two, n2 = frames(views, kernel_variant=PATH, frames_in_flight=2)
+    assert n1.startswith("vrt_pool_kernel<8,") and n2.startswith("vrt_pool_kernel<8,")
+    for v, x, y in zip(views, one, two):
+        assert np.array_equal(x, y), v
+    for (width, height, spp, bounce) in ((9, 7, 1, 3), (37, 3, 16, 2), (130, 95, 3, 1)):
+        ws = W.Workload("s", width, height, 256, 8, spp, bounce, True, 5.0, "sparse", 0.08, 30000)
+        rt = W.make_renderer(ws, grid, kernel_variant=PATH, want_float_output=True)
+        W.set_view(rt, "V0")
+        rt.draw()
+        rt.wait()
+        rt.draw()
+        f, u = rt.read_rgba32f(), rt.read_rgba8()
+        assert rt.kernel_name().startswith("vrt_pool_kernel<8,")
+        pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+        rt.deinit()
+        fo, uo, _ = O.render(oracle_scene_from_grid(grid), pc)
+        assert np.array_equal(f.view(np.uint32), fo.view(np.uint32)) and np.array_equal(u, uo), (width, height, spp, bounce)
