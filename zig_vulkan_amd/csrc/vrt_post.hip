@@ -90,8 +90,24 @@ VRT_DI f3 normalize_fast(f3 a) { return a * __builtin_amdgcn_rsqf(dot3(a, a)); }
 VRT_DI float length_fast(f3 a) { return __builtin_amdgcn_sqrtf(dot3(a, a)); }
 VRT_DI float pow_fast(float a, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(gl_max(a, 0.0f))); }
 
+// The taps of a workgroup's 16 x 16 output pixels fall into a small box of the traced image (25 x 25 texels at the reference's defaults,
+// 1 : 1): with TILED the workgroup converts that box to floats ONCE into LDS (32 x 32 texels, 16 KiB; coordinates wrapped there) and a
+// tap is four ds_read_b128 — no global loads, no unpacking, no wrapping per tap (round 4: 163 -> ~120 us per 1080p frame).  The launcher
+// takes it when every workgroup's box fits.
+constexpr int kDenoiseTile = 32;
+VRT_DI f3 sample_bilinear_tile(const float4 *tile, int x0, int y0, int W, int H, float u, float v) {
+    const float s = u * (float)W - 0.5f, t = v * (float)H - 0.5f;
+    const float fs = __builtin_floorf(s), ft = __builtin_floorf(t);
+    const float a = s - fs, b = t - ft;
+    const int i0 = (int)fs - x0, j0 = (int)ft - y0; // (inside [0, kDenoiseTile - 2] by the launcher's bound on the box)
+    const float4 p00 = tile[j0 * kDenoiseTile + i0], p10 = tile[j0 * kDenoiseTile + i0 + 1], p01 = tile[(j0 + 1) * kDenoiseTile + i0],
+                 p11 = tile[(j0 + 1) * kDenoiseTile + i0 + 1];
+    return mk3(mix1(mix1(p00.x, p10.x, a), mix1(p01.x, p11.x, a), b), mix1(mix1(p00.y, p10.y, a), mix1(p01.y, p11.y, a), b),
+               mix1(mix1(p00.z, p10.z, a), mix1(p01.z, p11.z, a), b));
+}
+
 // NEAR: every tap lies within one image width / height of the image (the launcher checks the spiral's radius): one conditional wrap
-template <bool NEAR>
+template <bool NEAR, bool TILED = false>
 __global__ __launch_bounds__(256) void vrt_denoise_kernel(const uchar4 *__restrict__ img, int W, int H, DenoiseParams pc, int out_w, int out_h,
                                                           uint32_t *__restrict__ out_u8, float4 *__restrict__ out_f32) {
     __shared__ float tab_x[kDenoiseTable], tab_y[kDenoiseTable], tab_w[kDenoiseTable];
@@ -115,13 +131,30 @@ __global__ __launch_bounds__(256) void vrt_denoise_kernel(const uchar4 *__restri
         float rx = 0.0f, ry = 1.0f;
         for (int k = 0; k < n && k < kDenoiseTable; k++) spiral(k, rx, ry, tab_x[k], tab_y[k], tab_w[k]);
     }
+    // the box of traced texels this workgroup's taps can touch: from the first pixel's tap furthest left / up to the last pixel's furthest
+    // right / down (s = u W - 0.5 grows with the pixel; `reach` texels of spiral; a texel of slack either side for the roundings)
+    __shared__ float4 tile[TILED ? kDenoiseTile * kDenoiseTile : 1];
+    [[maybe_unused]] int x0 = 0, y0 = 0;
+    if constexpr (TILED) {
+        const float reach = __builtin_fabsf(pc.pixel_multiplier) * sample_radius * 0.5f;
+        x0 = (int)__builtin_floorf(((float)(blockIdx.x * 16u) + 0.5f) / (float)out_w * (float)W - 0.5f - reach) - 1;
+        y0 = (int)__builtin_floorf(((float)(blockIdx.y * 16u) + 0.5f) / (float)out_h * (float)H - 0.5f - reach) - 1;
+        for (int i = (int)threadIdx.x; i < kDenoiseTile * kDenoiseTile; i += 256) {
+            const f3 c = texel_rgb(img, W, wrap_repeat(y0 + i / kDenoiseTile, H), wrap_repeat(x0 + i % kDenoiseTile, W));
+            tile[i] = make_float4(c.x, c.y, c.z, 0.0f);
+        }
+    }
     __syncthreads();
     // 16x16 output pixels per workgroup: neighbouring lanes fetch neighbouring texels
     const int ox = (int)(blockIdx.x * 16u + (threadIdx.x & 15u));
     const int oy = (int)(blockIdx.y * 16u + (threadIdx.x >> 4));
     if (ox >= out_w || oy >= out_h) return;
     const float u = ((float)ox + 0.5f) / (float)out_w, v = ((float)oy + 0.5f) / (float)out_h;
-    const f3 center = sample_bilinear_fast<NEAR>(img, W, H, u, v);
+    auto tap = [&](float tu, float tv) {
+        if constexpr (TILED) return sample_bilinear_tile(tile, x0, y0, W, H, tu, tv);
+        else return sample_bilinear_fast<NEAR>(img, W, H, tu, tv);
+    };
+    const f3 center = tap(u, v);
     const f3 center_norm = normalize3(center);
     const float center_sat = length3(center);
     const int hue_whole = (pc.inverse_hue_tolerance >= 0.0f && pc.inverse_hue_tolerance <= 64.0f && pc.inverse_hue_tolerance == __builtin_floorf(pc.inverse_hue_tolerance))
@@ -140,7 +173,7 @@ __global__ __launch_bounds__(256) void vrt_denoise_kernel(const uchar4 *__restri
             }
             spiral(k, rx, ry, px, py, influence);
         }
-        const f3 c = sample_bilinear_fast<NEAR>(img, W, H, u + px, v + py);
+        const f3 c = tap(u + px, v + py);
         const float hue = 0.5f + 0.5f * dot3(center_norm, normalize_fast(c));
         const float sat = 1.0f - __builtin_fabsf(length_fast(c) - __builtin_fabsf(center_sat));
         influence *= (hue_whole >= 0 ? pow_whole(hue, hue_whole) : pow_fast(hue, pc.inverse_hue_tolerance)) * pow_whole(sat, 8);
@@ -159,7 +192,11 @@ hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias
     const DenoiseParams pc{samples, bias, mult, tol};
     // the farthest tap: |pixel_multiplier| * sqrt(samples) / 2 texels from the pixel's own (image.frag:49-50), + the bilinear footprint
     const float reach = __builtin_fabsf(mult) * __builtin_sqrtf((float)samples) * 0.5f + 3.0f;
-    if (reach < (float)(W < H ? W : H))
+    // the box of a workgroup: 15 output pixels' worth of texels + the spiral both ways + the bilinear footprint and slack (kernel: x0 .. x0 + 31)
+    const float span_x = 15.0f * (float)W / (float)out_w + 2.0f * (reach - 3.0f) + 5.0f, span_y = 15.0f * (float)H / (float)out_h + 2.0f * (reach - 3.0f) + 5.0f;
+    if (span_x <= (float)kDenoiseTile && span_y <= (float)kDenoiseTile && samples < kDenoiseTable)
+        hipLaunchKernelGGL((vrt_denoise_kernel<true, true>), grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
+    else if (reach < (float)(W < H ? W : H))
         hipLaunchKernelGGL(vrt_denoise_kernel<true>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
     else
         hipLaunchKernelGGL(vrt_denoise_kernel<false>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
