@@ -216,3 +216,31 @@ def test_region_and_present_timing_by_device_events():
         rt.present(400, 260)
         assert 0.0 < rt.last_denoise_ms() < 100.0
         rt.deinit()
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_carries_the_round_4_fields():
+    """`python bench.py` at N = 1 (short form, no CPU baseline, no counter passes): ONE JSON line whose `value` is the cold protocol's,
+    with the device-event and sustained values beside it, the roofline's validity flag, the present pass and the wall-clock phases."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--pmc", "off"],
+                       cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=550)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 12 and out["warmup"] == 3 and out["precondition_frames"] == 0
+    assert out["value"] > 1000.0 and out["value_device_events"] > 1000.0                      # (>= 1 Grays/s, north_star's floor)
+    assert 0.5 < out["value_device_events"] / out["value"] < 2.0
+    assert out["value_sustained"]["value"] > 1000.0 and out["value_sustained"]["precondition_frames"] > 0
+    rf = out["roofline"]
+    assert rf["bound"] in ("hbm", "issue") and rf["frac_model_valid"] == (rf["frac"] <= 1.0) and rf["kernel"].startswith("vrt_trace_kernel<8,")
+    assert rf["lane_util"] is None and rf["traffic"] is None                                  # --pmc off
+    pp = out["present_pass"]
+    assert pp["kernel"] == "vrt_denoise_kernel" and 10.0 < pp["us_median"] < 5000.0 and pp["algorithmic_bytes"] == (22 * 16 + 4) * 1920 * 1080
+    assert {"startup", "count_rays", "timed_legs", "roofline_leg"} <= set(out["phase_seconds"])
+    assert "cpu_baseline" not in out
