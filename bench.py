@@ -527,6 +527,7 @@ class Leg:
         import ctypes as C
         self.env, self.W, self.w, self.sharded, self.batch, self.root_share = env, W, w, sharded, batch, root_share
         self.native, self.fg, self.rt, self.dist_info, self.rccl_world = False, None, None, None, None
+        self.launches_in_flight = None
         self.frame_no = 0
         args, stub, rank, world = env.args, env.stub, env.rank, env.world
         if sharded and want_native:
@@ -553,7 +554,10 @@ class Leg:
                 if not stub:
                     self.rt = W.make_renderer(w, grid, device_id=env.local_rank, shard_rank=rank, shard_count=world, kernel_variant=args.variant,
                                               shard_root_weight=(root_share if (2 <= world <= 8 and root_share < 100) else 0))
-                self.rt.dist_init(uid, rank, world, args.dist_frames, frames_per_launch=(batch if world > 1 else 1))
+                # (one frame per launch: a rank's 1/R of the tiles is a small kernel, and the more of them are in flight the better they
+                # overlap — rank 1 of 8 over the RCCL stand-in: 39.3 us per frame with 4 launches in flight, 29.9 with 8, tools/dist_host_probe.py)
+                self.launches_in_flight = args.dist_frames if (batch > 1 or world == 1) else max(args.dist_frames, 8)
+                self.rt.dist_init(uid, rank, world, self.launches_in_flight, frames_per_launch=(batch if world > 1 else 1))
                 if world == 1:
                     self.rt.dist_selftest()
                 self.dist_info = self.rt.dist_info()
@@ -897,7 +901,8 @@ def main(argv=None) -> None:
         if name == primary_name:
             device_ms = getattr(leg, "device_ms", None)
         legs_out[name] = {"value": rays_of(per_view, args.steps) / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt / args.steps * 1e3,
-                          "frames_per_collective": leg.batch, "root_share_percent": leg.root_share if leg.native else None,
+                          "frames_per_collective": leg.batch, "launches_in_flight": leg.launches_in_flight,
+                          "root_share_percent": leg.root_share if leg.native else None,
                           "dist_path": ("native" if leg.native else "torch") if sharded else None,
                           "breakdown": leg.breakdown(2 * args.dist_frames)}
     sustained = None
@@ -1103,7 +1108,7 @@ def main(argv=None) -> None:
         par = (f"1 GPU, whole frame, {args.frames_in_flight} frame(s) in flight" if not sharded else
                f"image tiles 16x16 interleaved over {world} GPU(s), every frame gathered once to rank 0, "
                + (f"native RCCL pipeline, ONE collective per frame (`value` = legs.{primary_name}; the leg with {leg.batch if world > 1 else 1} frame(s) per launch and per "
-                  f"collective is `value_batched`), {args.dist_frames} launches in flight, rank 0 owns {leg.root_share} % of an equal share of the tiles"
+                  f"collective is `value_batched`), launches in flight: legs.*.launches_in_flight, rank 0 owns {leg.root_share} % of an equal share of the tiles"
                   if native else "torch.distributed gather per frame, frame f overlaps the kernel of f+1"))
         out = {
             "metric": metric_name(w),

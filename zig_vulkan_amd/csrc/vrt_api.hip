@@ -206,6 +206,8 @@ struct vrt_ctx {
     bool status_dirty = true;        // brick_status changed since the derived copy was built
     size_t lds_bytes = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool split_ok = false;   // small frames may go to half-tile workgroups (vrt_create's conditions other than the number of waves)
+    uint32_t simds = 1024u;
     hipEvent_t ev_region[4] = {}; // vrt_region_begin / _end: {begin, end} on the primary stream, {begin, end} on the second
     hipEvent_t ev_post_start = nullptr, ev_post_stop = nullptr; // around the most recent present / denoise pass (vrt_last_denoise_ms)
     bool post_timed = false;
@@ -979,8 +981,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         int cus2 = 0;
         if (hipDeviceGetAttribute(&cus2, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus2 <= 0) cus2 = 256;
         const uint32_t waves = sh.owned_tiles * 4u, simds = 4u * (uint32_t)cus2;
-        const bool eligible = c->order_auto && c->tile_order == 3u && !p.wave_groups && sh.shard_count == 1u && !(cfg->tuning_flags & VRT_TUNE_NO_SMALL_FRAME_SPLIT) &&
+        // (a shard of a multi-GPU frame is a small frame as well: a rank of eight owns 1 020 tiles of the headline's 8 160)
+        const bool eligible = c->order_auto && c->tile_order == 3u && !p.wave_groups && !(cfg->tuning_flags & VRT_TUNE_NO_SMALL_FRAME_SPLIT) &&
                               (vrt::resolve_variant(cfg->kernel_variant) & 0xFFu) != vrt::kVariantLinearLds512;
+        c->split_ok = eligible;
+        c->simds = simds;
         // (configs[0], same box, us per frame V0 / V1 / V2 / V1x: whole tiles 16.3 / 24.0 / 27.3 / 28.6, halves 15.7 / 21.8 / 23.8 / 25.8,
         // quarters 16.7 / 21.5 / 24.1 / 23.4, eighths 16.4 / 23.3 / 25.4 / 24.1: halves; the rest of such a frame is its launch and the
         // fixed part of a wave's chain — the status bits in LDS change nothing, tools/small_frame_ab.py)
@@ -1649,7 +1654,8 @@ int dist_flush(vrt_ctx *ctx) {
     pk.target_rgba32f = nullptr;
     pk.packed_tiles = 1u;
     pk.packed_rgb = 1u;
-    pk.split_all = 0u; // (the RGB shard store needs all 64 lanes of a wave)
+    // (a launch of n frames of this rank's tiles: half-tile workgroups while its waves do not fill the SIMDs twice)
+    pk.split_all = (ctx->split_ok && pk.tile_order == 3u && (uint64_t)ctx->shard.owned_tiles * 4u * n <= 2ull * ctx->simds) ? 1u : 0u;
     pk.batch_target_stride = (uint32_t)d->shard_bytes;
     if (sl.marked) dist_collect(d, sl, false); // (profile: the slot's previous launch, if it has finished; else that sample is dropped)
     const bool mark = d->profile;
