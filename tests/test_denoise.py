@@ -76,3 +76,30 @@ def test_hip_denoise_with_shadows_nan_pattern():
     ok = ~np.isnan(fo)
     assert np.abs(f[ok] - fo[ok]).max() <= 1e-4
     assert np.abs(u.astype(int) - uo.astype(int)).max() <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frame, out_size, kw", [
+    ((320, 200), (320, 200), dict(samples=20)),                                   # the workgroup's box of texels fits LDS: the staged path
+    ((320, 200), (200, 130), dict(samples=60, pixel_multiplier=6.0)),             # a spiral of 23 texels: taps from global memory, one conditional wrap
+    ((320, 200), (640, 400), dict(samples=7, inverse_hue_tolerance=12.5, distribution_bias=0.9)),   # up-scaling; a non-integer hue exponent
+    ((24, 16), (96, 64), dict(samples=40, pixel_multiplier=9.0)),                 # the spiral reaches across the whole image: general wrap
+    ((320, 200), (320, 200), dict(samples=300)),                                  # more samples than the per-sample table holds
+])
+def test_hip_denoise_paths_match_oracle(frame, out_size, kw):
+    """vrt_denoise_kernel's three ways to a texel (round 4: a box staged in LDS / global with one conditional wrap / global with the
+    general wrap) and its per-sample table, each against the oracle within the pass's tolerance."""
+    w = W.Workload("t", frame[0], frame[1], 64, 4, 2, 2, False, 0.0)
+    grid = W.build_grid(w)
+    rt = W.make_renderer(w, grid)
+    W.set_view(rt, "V2")
+    rt.draw()
+    traced = rt.read_rgba8()
+    u, f = rt.denoise(out_size[0], out_size[1], want_float=True, **kw)
+    rt.deinit()
+    fo, uo = O.denoise(traced, out_size[0], out_size[1], **kw)
+    nan_o, nan_k = np.isnan(fo[..., :3]).any(axis=-1), np.isnan(f[..., :3]).any(axis=-1)
+    assert np.array_equal(nan_o, nan_k)
+    ok = ~nan_o
+    assert ok.any() and np.abs(f[ok] - fo[ok]).max() <= 1e-4
+    assert np.abs(u.astype(int) - uo.astype(int))[ok].max() <= 1
