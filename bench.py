@@ -1070,6 +1070,7 @@ def main(argv=None) -> None:
                                "issue_slots_frac: frac > 1 means the timed kernel does not request the bytes the model counts (skip-to-box), so the HBM "
                                "model is void for this workload; the kernel is bound by instruction issue"),
             "lane_util": lane_util,
+            "lane_util_counters": ({k: pmc[k] for k in ("SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU")} if lane_util is not None else None),
             "lane_util_note": "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): the share of its 64 lanes the average vector instruction serves",
             "traffic": traffic, "traffic_note": pmc_note,
             "definition": "achieved = bytes the REFERENCE algorithm loads for these frames (4 S + 4 K + V + 25 H per ray + 4 B per pixel, "
@@ -1120,6 +1121,7 @@ def main(argv=None) -> None:
             "precondition_frames": precondition,
             "precondition_note": "untimed frames before the warm-up steps (--precondition-ms, default 0: the protocol is `warmup` untimed + `steps` timed steps)",
             "value_device_events": (rays_of(per_view, args.steps) / (device_ms * 1e-3) / 1e6) if device_ms else None,
+            "device_ms_timed_region": device_ms, "rays_timed_region": rays_of(per_view, args.steps),
             "value_device_events_note": "the same timed steps by the device's clock: hipEventElapsedTime from the earlier of the two streams' begin events to the "
                                         "later of their end events (vrt_region_begin / _end, SURVEY.md 8(d)); `value` is the host's wall clock around them",
             "value_sustained": sustained,
