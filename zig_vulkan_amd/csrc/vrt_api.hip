@@ -938,6 +938,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.width = cfg->width;
     p.height = cfg->height;
     p.tiles_x = sh.tiles_x;
+    p.pool_tiles_x_magic = sh.tiles_x > 1u ? (uint32_t)((1ull << 32) / sh.tiles_x) + 1u : 0u;
     p.tiles_y = sh.tiles_y;
     p.shard_rank = sh.shard_rank;
     p.shard_count = sh.shard_count;
@@ -1082,10 +1083,15 @@ int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, cons
 
 // Common front part of a frame: argument checks, push constants, derived-structure refresh.  Leaves the
 // kernel to launch in *fn.  Runs on the primary stream.
-// vrt_pool_kernel packs a path's sample index into 16 bits and its bounce count into 4; frames beyond that keep vrt_path_kernel
-static bool grid_exit_fits(vrt::KernelFn fn, const vrt_camera_device *camera) {
+// vrt_pool_kernel packs a path's sample index into 16 bits and its bounce count into 4, and divides a tile's number by the tiles
+// per row with one multiplication (exact while tiles * tiles_x < 2^32); frames beyond that keep vrt_path_kernel
+static bool grid_exit_fits(vrt::KernelFn fn, const vrt_camera_device *camera, bool tiles_fit) {
     const vrt::KernelEntry *e = vrt::kernel_entry_of(fn);
-    return !(e && e->path == 2) || (camera->samples_per_pixel <= 65535 && camera->max_bounce <= 15);
+    return !(e && e->path == 2) || (camera->samples_per_pixel <= 65535 && camera->max_bounce <= 15 && tiles_fit);
+}
+
+static bool pool_tiles_fit(const vrt_ctx *ctx) {
+    return (unsigned long long)ctx->shard.tiles_x * ctx->shard.tiles_y * ctx->shard.tiles_x < (1ull << 32);
 }
 
 static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, vrt::KernelFn *fn) {
@@ -1161,7 +1167,7 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
         ctx->box_is_grid = all;
         ctx->bounds_pending = false;
     }
-    if (camera->max_bounce > 1 && ctx->box_is_grid && !ctx->d_counters && ctx->kernel_grid_exit && grid_exit_fits(ctx->kernel_grid_exit, camera))
+    if (camera->max_bounce > 1 && ctx->box_is_grid && !ctx->d_counters && ctx->kernel_grid_exit && grid_exit_fits(ctx->kernel_grid_exit, camera, pool_tiles_fit(ctx)))
         *fn = ctx->kernel_grid_exit;
     return VRT_OK;
 }
@@ -1182,7 +1188,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     if (ctx->d_counters) {
         product_fn = ctx->product[(camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? 2 : 1) : 0];
         if (!product_fn) return fail(ctx, VRT_E_STATE, "no product kernel for this configuration");
-        if (camera->max_bounce > 1 && ctx->box_is_grid && ctx->product_grid_exit && grid_exit_fits(ctx->product_grid_exit, camera)) product_fn = ctx->product_grid_exit;
+        if (camera->max_bounce > 1 && ctx->box_is_grid && ctx->product_grid_exit && grid_exit_fits(ctx->product_grid_exit, camera, pool_tiles_fit(ctx))) product_fn = ctx->product_grid_exit;
     }
     note_kernel(ctx, product_fn ? product_fn : fn);
     // (the persistent-lane kernel takes its pixels from a counter: it neither reads the tile schedule nor reports tile costs)

@@ -53,7 +53,8 @@ template <int B, int MIN_WAVES, int SLOTS = 64, int STAGES = 4>
 __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TraceParams p) {
     static_assert(B == 8, "bricks of 8^3 voxels staged in LDS");
     extern __shared__ __attribute__((aligned(16))) uint32_t pool_lds[];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // (the wave's number through readfirstlane: its LDS and its block of path records are then scalar addresses, not per-lane registers)
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // the workgroup's LDS: 16 lock words | STAGES staging areas of 4 KiB | per wave: records, slot states, scratch
     constexpr uint32_t S = (uint32_t)SLOTS, kWaveDwords = (kPoolRecDwords + 2u) * S;
     uint32_t *const locks = pool_lds;
@@ -120,6 +121,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
         for (uint32_t k = 0; k < kPoolRecDwords; k++) rec[S * k + lane] = (k == 19u) ? 64u + lane : 0u;
     }
 
+    // tile / tiles_x by the host's reciprocal (TraceParams::pool_tiles_x_magic): the compiler's own would be a per-lane register kept
+    // for the length of the kernel
+    auto tile_row = [&](uint32_t tile) { return p.pool_tiles_x_magic ? __umulhi(tile, p.pool_tiles_x_magic) : tile; };
     auto sx_of = [](uint32_t f) { return (int)((f >> 8) & 3u) - 1; };
     auto sy_of = [](uint32_t f) { return (int)((f >> 10) & 3u) - 1; };
     auto sz_of = [](uint32_t f) { return (int)((f >> 12) & 3u) - 1; };
@@ -324,7 +328,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                     const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
                     const uint32_t j = work & 255u;
                     const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
-                    const uint32_t px = (tile % p.tiles_x) * kTileW + in_x, py = (tile / p.tiles_x) * kTileH + in_y;
+                    const uint32_t tile_y = tile_row(tile), tile_x = tile - tile_y * p.tiles_x;
+                    const uint32_t px = tile_x * kTileW + in_x, py = tile_y * kTileH + in_y;
                     const float fspp = (float)spp;
                     const f3 c = mk3(__builtin_sqrtf(acc.x / fspp), __builtin_sqrtf(acc.y / fspp), __builtin_sqrtf(acc.z / fspp));
                     const size_t o = (p.shard_count > 1u || p.packed_tiles) ? (size_t)owned * (kTileW * kTileH) + in_y * kTileW + in_x : (size_t)py * p.width + px;
@@ -365,7 +370,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                     const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
                     const uint32_t j = work & 255u;
                     const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
-                    const uint32_t px = (tile % p.tiles_x) * kTileW + in_x, py = (tile / p.tiles_x) * kTileH + in_y;
+                    const uint32_t tile_y = tile_row(tile), tile_x = tile - tile_y * p.tiles_x;
+                    const uint32_t px = tile_x * kTileW + in_x, py = tile_y * kTileH + in_y;
                     if (px >= p.width || py >= p.height) {
                         ls = kLaneFetch; // outside the image (comp:155-159): nothing to trace, nothing to store; asks again next round
                     } else {
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 if (ls == kLaneStart) {
                     nst = kRayMiss;
                     if (grid_slab(p, r, 0.00001f, t_max, s)) {
-                        const float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
+                        const float global_t_value = s.grid_t_min + 0.0001f * opaque_uniform(g_scale); // comp:287 (opaque: the product is not kept in a register)
                         const f3 fposition = p.scale_pow2 ? (ray_at(r, global_t_value) - g_min) * p.inv_grid_scale : (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
                         Walk w;
                         w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta());
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 s.sx = sx, s.sy = sy, s.sz = sz;
                 s.grid_t_min = gtmin, s.grid_t_max = gtmax;
                 const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min); // comp:331
-                const float global_t_value = t_in * g_scale + gtmin + 0.01f * g_scale;                    // comp:347 (deferred) + comp:332
+                const float global_t_value = t_in * g_scale + gtmin + 0.01f * opaque_uniform(g_scale);   // comp:347 (deferred) + comp:332
                 Hit hit;
                 hit.t = global_t_value;
                 hit.index = 0u;

@@ -1074,7 +1074,13 @@ VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const Ray
     rsrc.w = 0x00020000u;
     const uint32_t *occ_words = reinterpret_cast<const uint32_t *>(occupancy);
     typedef __attribute__((address_space(3))) const uint32_t lds_u32;
-    [[maybe_unused]] const uint32_t lane_base = wave_lds + ((threadIdx.x & 63u) << 4);
+    // (the lane's number is formed here, by an instruction the optimiser may not move: hoisted out of the caller's loop it is one more
+    // per-lane register that lives as long as the kernel)
+    [[maybe_unused]] uint32_t lane_base;
+    if constexpr (LDS) {
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_base));
+        lane_base = wave_lds + (lane_base << 4);
+    }
     uint32_t word;
     [[maybe_unused]] uint32_t eager_start = 0u;
     VRT_PROF_BEGIN(tp5);
