@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised parity fuzz (usage: fuzz_parity.py [cases] [seed] [big|pow2]; pow2: grids and frames that take vrt_path_kernel's block-skipping walk): random small grids (odd dimensions, both brick sizes, any
+"""Randomised parity fuzz (usage: fuzz_parity.py [cases] [seed] [big|pow2|pool]; pow2: grids and frames that take vrt_path_kernel's block-skipping walk;
+pool: the pow2 draw narrowed to what vrt_pool_kernel takes — 8^3 bricks, three power-of-two dimensions, voxels in two opposite corners so
+that the occupied cells' box is the grid, two or three bounces): random small grids (odd dimensions, both brick sizes, any
 scale, sparse allocation), random materials incl. glass / metal / unknown types, random cameras inside and outside the
 box, samples 1-3, bounces 0-2, sun on/off with and without jitter — product kernel against the oracle, whole frames,
 float target bit for bit.  The committed tests pin chosen cases; this looks for the ones nobody chose.  A mismatching case is
@@ -11,7 +13,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from zig_vulkan_amd import BrickGrid, Config, CameraConfig, SunConfig, VoxelRT, default_materials
 from helpers import O, oracle_scene_from_grid
 
-def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: bool = False, library=None) -> int:
+def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: bool = False, library=None, pool: bool = False) -> int:
     """Returns the number of mismatching cases.  library: path of the development build (make dev) — the variants that lost their
     A/B measurement then take part in the draw; without it only the kernels of the product build are drawn."""
     dev = library is not None
@@ -20,6 +22,7 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: b
                     else [0, 0, 9, 5, 0x10070000, 0x10070000, PATH, PATH | (3 << 24), PATH | (5 << 8), PATH | (2 << 24)])
     pow2_variants = [PATH | (1 << 22), PATH | (1 << 22) | (5 << 8), PATH] if dev else [PATH, PATH | (5 << 8), PATH | (2 << 24)]
     rng = np.random.default_rng(seed)
+    pow2 = pow2 or pool
     bad = 0
     used = {}
     for case in range(cases):
@@ -27,6 +30,8 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: b
         dims = [int(rng.integers(1, 25 if big else 9)) for _ in range(3)]
         if pow2:  # grids the path kernel's block filter accepts: x, z powers of two >= 4, y a multiple of 4
             dims = [int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 12, 16, 20])), int(rng.choice([4, 8, 16, 32]))]
+        if pool:
+            b, dims = 8, [int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 16])), int(rng.choice([4, 8, 16, 32]))]
         scale = float(rng.choice([0.5, 1.0, 2.0, 0.3, 1.7, 4.0]))
         min_point = [float(-0.5 * d * scale + rng.normal() * 0.3) for d in dims]
         cells = dims[0] * dims[1] * dims[2]
@@ -37,12 +42,15 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: b
             k = int(rng.integers(1, 6))
             centres = np.stack([rng.integers(0, b * d, k) for d in dims], axis=-1)
             xyz = np.clip(centres[rng.integers(0, k, n)] + rng.integers(-2 * b, 2 * b + 1, (n, 3)), 0, np.array(dims) * b - 1)
-        if rng.random() < 0.5:  # the occupied cells fill only a sub-box of the grid: rays enter the grid in front of it (skip_to_box)
+        if not pool and rng.random() < 0.5:  # the occupied cells fill only a sub-box of the grid: rays enter the grid in front of it (skip_to_box)
             lo = [int(rng.integers(0, d)) for d in dims]
             hi = [int(rng.integers(l, d)) for l, d in zip(lo, dims)]
             xyz = np.stack([b * l + rng.integers(0, b * (h - l + 1), n) for l, h in zip(lo, hi)], axis=-1)
         if rng.random() < 0.5:  # clumps: whole columns
             xyz[:, 1] = rng.integers(0, b * dims[1], n) // 2 * 2
+        if pool:  # the box of the occupied cells is the grid
+            xyz = np.concatenate([xyz, np.array([[0, 0, 0], [b * d - 1 for d in dims]])])
+            n += 2
         grid.insert_many(xyz, rng.integers(0, 14, n))
         mats = default_materials(256)
         mats[8] = (2, 0.9, 0.95, 1.0, 1.52)
@@ -54,13 +62,13 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: b
         w, h = int(rng.integers(1, 400 if big else 90)), int(rng.integers(1, 260 if big else 70))
         spp, bounce = int(rng.integers(1, 4)), int(rng.integers(0, 3))
         if pow2:
-            bounce = int(rng.integers(1, 4))
+            bounce = int(rng.integers(2 if pool else 1, 4))
         sun_on, radius = bool(rng.random() < 0.7), float(rng.choice([0.0, 5.0, 40.0]))
         rt = VoxelRT(grid, Config(internal_resolution_width=w, internal_resolution_height=h, camera=CameraConfig(samples_per_pixel=spp, max_bounce=bounce),
                                   sun=SunConfig(enabled=sun_on, radius=radius), want_float_output=True,
                                   library=library,
-                                  kernel_variant=int(rng.choice(big_variants)) if big
-                                  else int(rng.choice(pow2_variants) if pow2 else rng.choice([0, 0, PATH]))))
+                                  kernel_variant=PATH if pool else (int(rng.choice(big_variants)) if big
+                                  else int(rng.choice(pow2_variants) if pow2 else rng.choice([0, 0, PATH])))))
         rt.push_materials(mats)
         size = np.array(dims) * scale
         centre = np.array(min_point) + 0.5 * size
@@ -102,7 +110,7 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: b
             print(f"case {case}: MISMATCH  {name} b={b} dims={dims} scale={scale} {w}x{h} spp={spp} bounce={bounce} sun={sun_on}/{radius}  {np.count_nonzero(f != fo)} floats differ, "
                   f"{len(du)} RGBA8 bytes differ, first {[(i.tolist(), int(u[tuple(i)]), int(uo[tuple(i)])) for i in du[:4]]}")
         elif verbose and case % 10 == 0:
-            print(f"case {case}: ok  b={b} dims={dims} scale={scale} {w}x{h} spp={spp} bounce={bounce} sun={sun_on}/{radius} rays={co['rays']} hits={co['hits']}")
+            print(f"case {case}: ok  b={b} dims={dims} scale={scale} {w}x{h} spp={spp} bounce={bounce} sun={sun_on}/{radius} rays={co['rays']} hits={co['hits']} {name.split('<')[0]}")
     if verbose:
         print(f"{cases} cases, {bad} mismatching; kernels: " + ", ".join(f"{k} x{v}" for k, v in sorted(used.items())))
     return bad
@@ -110,4 +118,5 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: b
 
 if __name__ == "__main__":
     sys.exit(1 if fuzz(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 7,
-                       len(sys.argv) > 3 and sys.argv[3] in ("big", "pow2"), pow2=len(sys.argv) > 3 and sys.argv[3] == "pow2") else 0)
+                       len(sys.argv) > 3 and sys.argv[3] in ("big", "pow2", "pool"), pow2=len(sys.argv) > 3 and sys.argv[3] == "pow2",
+                       pool=len(sys.argv) > 3 and sys.argv[3] == "pool") else 0)
