@@ -156,6 +156,43 @@ def test_amortised_tile_schedule_keeps_every_frame_identical(frames_in_flight):
     rt.deinit()
 
 
+def test_tile_schedule_of_two_sample_frames_splits_freely_and_follows_the_sample_count():
+    """Round 4: under the cost schedule, frames of two samples per pixel may split EVERY tile whose slowest wave is above a lower bar
+    (the halves trace the second sample on their idle lanes), frames of any other sample count keep round 3's rule (an eighth of the
+    tiles, a higher bar).  The rule follows the camera of each dispatch: a change re-sorts at once into a list laid out for either.
+    One context, the sample count going 2 -> 1 -> 3 -> 2 with re-sorts every 8 frames in between: every frame read equals the frame of
+    a context that launches its tiles in plain reverse raster (no schedule, no splits)."""
+    w = W.Workload("t", 400, 300, 128, 4, 2, 2, True, 5.0)
+    grid = W.build_grid(w)
+    ref = {}
+    for spp in (1, 2, 3):
+        rt = W.make_renderer(w, grid, kernel_variant=0x30000)
+        rt.camera.d_camera.samples_per_pixel = spp
+        for v in ("V0", "V2"):
+            W.set_view(rt, v)
+            rt.draw()
+            ref[(spp, v)] = rt.read_rgba8().copy()
+        rt.deinit()
+    assert not np.array_equal(ref[(1, "V2")], ref[(2, "V2")]) and not np.array_equal(ref[(3, "V2")], ref[(2, "V2")])
+    rt = W.make_renderer(w, grid, kernel_variant=0x30070000)
+    for spp in (2, 1, 3, 2, 2):
+        rt.camera.d_camera.samples_per_pixel = spp
+        for i in range(20):   # two re-sorts on measured costs without a read in between
+            W.set_view(rt, ("V0", "V2")[(i // 3) % 2])
+            rt.draw()
+        for v in ("V2", "V0", "V2"):
+            W.set_view(rt, v)
+            rt.draw()
+            assert np.array_equal(rt.read_rgba8(), ref[(spp, v)]), (spp, v)
+    # ... and the first frame after a change of the sample count (sorted on the costs of the other rule's frames)
+    for spp, v in ((1, "V0"), (2, "V2"), (3, "V0"), (2, "V0"), (1, "V2")):
+        rt.camera.d_camera.samples_per_pixel = spp
+        W.set_view(rt, v)
+        rt.draw()
+        assert np.array_equal(rt.read_rgba8(), ref[(spp, v)]), (spp, v)
+    rt.deinit()
+
+
 @pytest.mark.parametrize("variant", [0, 0x50000, 0x70000, 0x100000])
 def test_two_frames_in_flight_give_the_same_frames_and_respect_uploads(variant):
     """frames_in_flight = 2: frames alternate between two streams/targets; every frame still equals

@@ -36,7 +36,7 @@ uint32_t resolve_variant(uint32_t variant);
 size_t trace_lds_bytes(const TraceParams &p, uint32_t variant);
 hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream, uint32_t frames = 1);
 bool is_path_kernel(KernelFn fn);
-hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra, uint32_t wave_slots,
+hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra_max, uint32_t extra, uint32_t wave_slots,
                            hipStream_t stream);
 hipError_t launch_assemble_rgb(const void *gathered, void *frame, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t shard_count,
                                uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream, uint32_t frames, uint32_t frame_src_stride_bytes);
@@ -176,6 +176,10 @@ struct vrt_ctx {
     uint32_t bounce_variant = 0; // kernel_variant with the occupancy choice of the bounce kernel filled in
     uint32_t single_variant = 0; // kernel_variant with the library's choice of mode for frames without bounces filled in
     uint32_t tile_order = 0, sched_extra = 0, sched_stride = 0, wave_slots = 0;
+    // the cost schedule's two rules (index 1: frames whose split tiles trace their second sample on the idle lanes — two samples per
+    // pixel — where a split costs nothing but the second workgroup's fixed part): how many tiles an order may split, and the wave
+    // slots the "time the frame needs anyway" is computed for; sched_mode: the rule the current order was sorted under
+    uint32_t sched_cap[2] = {0, 0}, sched_slots[2] = {0, 0}, sched_mode = 0;
     uint64_t sched_seq = 0, b_seen_sched = 0;
     hipEvent_t ev_sched = nullptr, ev_b_sched = nullptr;
     bool b_sched_recorded = false;
@@ -675,7 +679,16 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (order == 0u) order = (n > 6u * (uint32_t)cus && n <= 64u * (uint32_t)cus) ? 7u : 3u;
         c->tile_order = order;
         const bool plain_tiles = !((cfg->kernel_variant >> 20) & 0x1u) && (vrt::resolve_variant(cfg->kernel_variant) & 0xFFu) != vrt::kVariantLinearLds512;
-        c->sched_extra = (order == 7u && plain_tiles) ? std::min(1024u, n / 8u) : 0u;
+        // spare entries: one per tile (the list's layout); a sort may use min(1024, n / 8) of them — or all, with a lower bar, for
+        // frames of two samples per pixel (measured on the reference app's run, same box, V0 / V1 / V2: 0.336 / 0.340 / 0.364 ms with
+        // n / 8 and a bar of 1.25 x the frame's wave-cycles over 24 slots per CU; 0.294 / 0.306 / 0.330 with every tile eligible
+        // and 40 slots per CU — 28 / 32 / 36 / 44: 0.329 / 0.306 / 0.293 / 0.295 on V0; every tile split 0.339 / 0.345 / 0.370; a cap
+        // below what the bar asks for makes the order flip between sorts: n / 4 0.395 / 0.367 / 0.396)
+        c->sched_extra = (order == 7u && plain_tiles) ? n : 0u;
+        c->sched_cap[0] = std::min(std::min(1024u, n / 8u), c->sched_extra);
+        c->sched_cap[1] = c->sched_extra;
+        c->sched_slots[0] = c->wave_slots;
+        c->sched_slots[1] = 40u * (uint32_t)cus;
         VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_tile_cost), n * 32u)); // [half][tile][wave]
         const uint32_t ns = 8u * ((n + c->sched_extra + 7u) / 8u); // an order buffer is stored XCD-major: 8 rows of ceil((n + extra) / 8)
         c->sched_stride = ns;
@@ -694,7 +707,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         VRT_CREATE_HIP(e);
         // first launch of the schedule kernel now (code-object load, about 2 ms, stays out of the frames): with no cost
         // measured yet it copies the initial order into the second buffer
-        if (n > 1u) VRT_CREATE_HIP(vrt::launch_schedule(c->d_tile_cost, c->d_tile_schedule + 2u * (size_t)ns, c->d_tile_schedule, c->d_tile_schedule + ns, n, c->sched_extra, c->wave_slots, c->stream));
+        if (n > 1u) VRT_CREATE_HIP(vrt::launch_schedule(c->d_tile_cost, c->d_tile_schedule + 2u * (size_t)ns, c->d_tile_schedule, c->d_tile_schedule + ns, n, c->sched_extra, c->sched_cap[0], c->sched_slots[0], c->stream));
     }
     for (int i = 0; i < kStagingSlots; i++) {
         VRT_CREATE_HIP(hipHostMalloc(&c->staging[i], kStagingSlotBytes, hipHostMallocDefault));
@@ -966,6 +979,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     // instead, see do_dispatch and DESIGN.md §4)
     p.tile_order = c->tile_order;
     p.sched_extra = c->sched_extra;
+    p.sched_units = c->sched_cap[0];
     if (p.tile_order == 7u) {
         // the cost-feedback schedule, re-sorted every 32 frames instead of every frame: the kernel sees order 5
         p.tile_order = 5u;
@@ -1239,7 +1253,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     const uint32_t ns = ctx->sched_stride; // stride of a schedule buffer
     if (ctx->params.tile_order == 5u && nt > 1u && !ctx->sched_period && scheduled) {
         // re-sort the tile list by last frame's measured cost (inside the timed region: it is per-frame work)
-        VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule + 2u * (size_t)ns, ctx->d_tile_schedule, ctx->d_tile_schedule, nt, 0u, ctx->wave_slots, ctx->stream));
+        VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule + 2u * (size_t)ns, ctx->d_tile_schedule, ctx->d_tile_schedule, nt, ctx->sched_extra, 0u, ctx->wave_slots, ctx->stream));
     }
     if (ctx->order_auto && ctx->stream_b && frames == 1 && !primary_only) {
         // the even frames of two frames in flight: the other stream fills this frame's tail, and reverse raster keeps
@@ -1265,6 +1279,15 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         if (ctx->target32f) VRT_HIP(ctx, hipMemsetAsync(ctx->target32f, 0xCD, ctx->target_pixels * 16u, ctx->stream));
         fn = product_fn;
     }
+    if (ctx->sched_period && scheduled) {
+        // which of the schedule's two rules this frame's kernel is served by (vrt_trace_kernel's `dual`): a change re-sorts now
+        const uint32_t mode = (camera->samples_per_pixel == 2 && !ctx->params.packed_rgb) ? 1u : 0u;
+        if (mode != ctx->sched_mode) {
+            ctx->sched_mode = mode;
+            ctx->params.sched_units = ctx->sched_cap[mode];
+            ctx->sched_since = ctx->sched_period;
+        }
+    }
     for (uint32_t f = 0; f < frames; f++) {
         if (marks) VRT_HIP(ctx, hipEventRecord(marks[f], ctx->stream)); // per-frame timing (vrt_dispatch_timed)
         if (ctx->sched_period && nt > 1u && ctx->sched_since >= ctx->sched_period && scheduled) {
@@ -1275,7 +1298,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
             // then the order lags behind frames that are queued ahead (vrt_dispatch_repeat) by a whole call.
             if (ctx->b_sched_recorded) VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_b_sched, 0)); // (signalled a period ago)
             uint32_t *cur = ctx->d_tile_schedule + (size_t)ctx->sched_cur * ns, *alt = ctx->d_tile_schedule + (size_t)(ctx->sched_cur ^ 1u) * ns;
-            VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule + 2u * (size_t)ns, cur, alt, nt, ctx->sched_extra, ctx->wave_slots, ctx->stream));
+            VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule + 2u * (size_t)ns, cur, alt, nt, ctx->sched_extra, ctx->sched_cap[ctx->sched_mode], ctx->sched_slots[ctx->sched_mode], ctx->stream));
             VRT_HIP(ctx, hipEventRecord(ctx->ev_sched, ctx->stream));
             ctx->sched_cur ^= 1u;
             ctx->params.tile_schedule = alt;
@@ -1490,7 +1513,7 @@ int vrt_trace_wave_timeline(vrt_ctx *ctx, const vrt_camera_device *camera, const
     if (!ctx || !out || !n_pairs) return VRT_E_INVALID_ARG;
     // (the cost-ordered launch has spare workgroups for the halves of split tiles: their waves are listed too; a workgroup that
     // stayed idle leaves zeros)
-    const uint64_t waves = ((uint64_t)ctx->shard.owned_tiles + (ctx->params.tile_order == 5u ? ctx->sched_extra : 0u)) * 4u;
+    const uint64_t waves = ((uint64_t)ctx->shard.owned_tiles + (ctx->params.tile_order == 5u ? ctx->params.sched_units : 0u)) * 4u;
     if (capacity_pairs < waves) return fail(ctx, VRT_E_OUT_OF_RANGE, "timeline buffer too small");
     DeviceGuard dg(ctx->device);
     const size_t bytes = std::max<size_t>(waves * 16u, 32u * sizeof(unsigned long long)); // (the profile build of vrt_path_kernel writes 20 words)

@@ -100,7 +100,8 @@ struct TraceParams {
     unsigned long long *wave_timeline;   // optional (measurement): [begin,end] wall-clock ticks per wave, 2 u64 each
     const uint32_t *tile_schedule;
     uint32_t tile_stride;                // tile_order 4: multiplier coprime to owned_tiles
-    uint32_t sched_extra;                // tile_order 5: spare schedule entries (= extra workgroups) for the second halves of split tiles
+    uint32_t sched_extra;                // tile_order 5: spare schedule entries for the second halves of split tiles (the list's layout)
+    uint32_t sched_units;                // ... and how many of them the current order may use (= extra workgroups launched)
     uint32_t packed_tiles;               // 1: write the packed tile-major shard layout even when shard_count == 1
     uint32_t packed_rgb;                 // 1 (with packed_tiles): 3 bytes per pixel in the shard (alpha is the constant 255): a quarter
                                          // less to gather over xGMI; the un-swizzle on rank 0 puts the alpha back

@@ -180,15 +180,17 @@ __global__ __launch_bounds__(256) void vrt_build_cell_bounds(const uint32_t *__r
 // not be a permutation.  The order affects timing only, never pixels.
 constexpr uint32_t kScheduleBuckets = 8u;
 __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ snap,
-                                                            const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra,
-                                                            uint32_t wave_slots) {
+                                                            const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra_max,
+                                                            uint32_t extra, uint32_t wave_slots) {
     __shared__ uint32_t s_max, s_nsplit, s_longest;
     __shared__ unsigned long long s_total;
     __shared__ uint32_t wave_total[kScheduleBuckets + 1u][16];
     __shared__ uint32_t class_total[kScheduleBuckets + 1u];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     uint32_t *state = snap + n;
-    const uint32_t row = (n + extra + 7u) >> 3; // order[] is stored XCD-major: entry k at (k % 8) * row + k / 8
+    // order[] is stored XCD-major: entry k at (k % 8) * row + k / 8.  extra_max: the spare entries the buffer holds (its layout);
+    // extra <= extra_max: how many tiles this sort may split (the frames launch n + extra workgroups)
+    const uint32_t row = (n + extra_max + 7u) >> 3;
     if (tid == 0) {
         s_max = 0u;
         s_nsplit = 0u;
@@ -591,13 +593,14 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
     if (p.block_threads == 512u) hipLaunchKernelGGL(fn, dim3((p.owned_tiles + 1u) / 2u, frames), dim3(512), lds_bytes, stream, p);
     else if (p.wave_groups) hipLaunchKernelGGL(fn, dim3(p.owned_tiles * 4u, frames), dim3(64), lds_bytes, stream, p);
     else if (p.tile_order == 3u && p.split_all) hipLaunchKernelGGL(fn, dim3(p.owned_tiles << p.split_all, frames), dim3(256), lds_bytes, stream, p);
-    else hipLaunchKernelGGL(fn, dim3(p.owned_tiles + (p.tile_order == 5u ? p.sched_extra : 0u), frames), dim3(256), lds_bytes, stream, p);
+    else hipLaunchKernelGGL(fn, dim3(p.owned_tiles + (p.tile_order == 5u ? p.sched_units : 0u), frames), dim3(256), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
-hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra,
-                           uint32_t wave_slots, hipStream_t stream) {
-    hipLaunchKernelGGL(vrt_schedule_kernel, dim3(1), dim3(1024), 0, stream, cost, snap, prev_order, order, n, extra, wave_slots);
+hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra_max,
+                           uint32_t extra, uint32_t wave_slots, hipStream_t stream) {
+    hipLaunchKernelGGL(vrt_schedule_kernel, dim3(1), dim3(1024), 0, stream, cost, snap, prev_order, order, n, extra_max, extra < extra_max ? extra : extra_max,
+                       wave_slots);
     return hipGetLastError();
 }
 
