@@ -156,13 +156,16 @@ def test_amortised_tile_schedule_keeps_every_frame_identical(frames_in_flight):
     rt.deinit()
 
 
-def test_tile_schedule_of_two_sample_frames_splits_freely_and_follows_the_sample_count():
+@pytest.mark.parametrize("width, height, variant, frames_in_flight, warm", [(400, 300, 0x30070000, 1, 20), (400, 300, 0x30070000, 2, 20), (1024, 576, 0, 2, 70)])
+def test_tile_schedule_of_two_sample_frames_splits_freely_and_follows_the_sample_count(width, height, variant, frames_in_flight, warm):
     """Round 4: under the cost schedule, frames of two samples per pixel may split EVERY tile whose slowest wave is above a lower bar
     (the halves trace the second sample on their idle lanes), frames of any other sample count keep round 3's rule (an eighth of the
     tiles, a higher bar).  The rule follows the camera of each dispatch: a change re-sorts at once into a list laid out for either.
     One context, the sample count going 2 -> 1 -> 3 -> 2 with re-sorts every 8 frames in between: every frame read equals the frame of
-    a context that launches its tiles in plain reverse raster (no schedule, no splits)."""
-    w = W.Workload("t", 400, 300, 128, 4, 2, 2, True, 5.0)
+    a context that launches its tiles in plain reverse raster (no schedule, no splits).  Also with two frames in flight, and with the
+    library's own choice of order at the app's frame size (1024 x 576: the cost schedule; with two frames in flight reverse raster —
+    except for frames of two samples, which keep the schedule on both streams)."""
+    w = W.Workload("t", width, height, 128, 4, 2, 2, True, 5.0)
     grid = W.build_grid(w)
     ref = {}
     for spp in (1, 2, 3):
@@ -174,10 +177,10 @@ def test_tile_schedule_of_two_sample_frames_splits_freely_and_follows_the_sample
             ref[(spp, v)] = rt.read_rgba8().copy()
         rt.deinit()
     assert not np.array_equal(ref[(1, "V2")], ref[(2, "V2")]) and not np.array_equal(ref[(3, "V2")], ref[(2, "V2")])
-    rt = W.make_renderer(w, grid, kernel_variant=0x30070000)
+    rt = W.make_renderer(w, grid, kernel_variant=variant, frames_in_flight=frames_in_flight)
     for spp in (2, 1, 3, 2, 2):
         rt.camera.d_camera.samples_per_pixel = spp
-        for i in range(20):   # two re-sorts on measured costs without a read in between
+        for i in range(warm):   # two re-sorts on measured costs without a read in between
             W.set_view(rt, ("V0", "V2")[(i // 3) % 2])
             rt.draw()
         for v in ("V2", "V0", "V2"):

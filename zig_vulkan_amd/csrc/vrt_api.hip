@@ -1211,7 +1211,12 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     // (tile_order 5 re-sorts the tile schedule in place before every frame on the primary stream: a frame running on
     // the second stream would read it while it is being rewritten, so that order runs one frame at a time.  The
     // amortised form, tile_order 7, sorts into the other of two buffers and may use both streams.)
-    const bool slot_b = ctx->stream_b && frames == 1 && !primary_only && (ctx->frame_seq & 1u) && (ctx->params.tile_order != 5u || ctx->sched_period);
+    // which of the cost schedule's two rules serves this frame (vrt_trace_kernel's `dual`: two samples per pixel, whole RGBA pixels); a
+    // change re-sorts at once, on the primary stream
+    const uint32_t sched_mode = (ctx->sched_period && scheduled && camera->samples_per_pixel == 2 && !ctx->params.packed_rgb) ? 1u : 0u;
+    const bool sched_changes = ctx->sched_period && scheduled && sched_mode != ctx->sched_mode;
+    const bool slot_b = ctx->stream_b && frames == 1 && !primary_only && (ctx->frame_seq & 1u) && (ctx->params.tile_order != 5u || ctx->sched_period) &&
+                        !sched_changes;
     if (slot_b) {
         // second frame slot: its own stream and target; ordered after every scene write so far
         if (ctx->b_seen_upload != ctx->upload_seq) {
@@ -1223,7 +1228,10 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
             VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->ev_sched, 0));
         }
         vrt::TraceParams pb = ctx->params;
-        if (ctx->order_auto) pb.tile_order = 3u;
+        // (frames of two samples per pixel keep the cost schedule on both streams: their split tiles trace the second sample on the idle
+        // lanes, which is worth more than reverse raster's neighbourhood — the app's run, two frames in flight, V0 / V1 / V2: 0.205 /
+        // 0.214 / 0.237 ms per frame against 0.267 / 0.262 / 0.286, tools/fif_order_ab.py)
+        if (ctx->order_auto && sched_mode == 0u) pb.tile_order = 3u;
         pb.target_rgba8 = ctx->target8_b;
         pb.target_rgba32f = ctx->target32f_b;
         pb.work_counter = ctx->d_work_counter + vrt::kMaxBatchFrames; // its frames run beside the primary stream's
@@ -1255,7 +1263,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         // re-sort the tile list by last frame's measured cost (inside the timed region: it is per-frame work)
         VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule + 2u * (size_t)ns, ctx->d_tile_schedule, ctx->d_tile_schedule, nt, ctx->sched_extra, 0u, ctx->wave_slots, ctx->stream));
     }
-    if (ctx->order_auto && ctx->stream_b && frames == 1 && !primary_only) {
+    if (ctx->order_auto && ctx->stream_b && frames == 1 && !primary_only && sched_mode == 0u && !sched_changes) {
         // the even frames of two frames in flight: the other stream fills this frame's tail, and reverse raster keeps
         // neighbouring tiles together (measured 4 % faster than the cost order in that mode)
         vrt::TraceParams pa = ctx->params;
@@ -1279,14 +1287,10 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         if (ctx->target32f) VRT_HIP(ctx, hipMemsetAsync(ctx->target32f, 0xCD, ctx->target_pixels * 16u, ctx->stream));
         fn = product_fn;
     }
-    if (ctx->sched_period && scheduled) {
-        // which of the schedule's two rules this frame's kernel is served by (vrt_trace_kernel's `dual`): a change re-sorts now
-        const uint32_t mode = (camera->samples_per_pixel == 2 && !ctx->params.packed_rgb) ? 1u : 0u;
-        if (mode != ctx->sched_mode) {
-            ctx->sched_mode = mode;
-            ctx->params.sched_units = ctx->sched_cap[mode];
-            ctx->sched_since = ctx->sched_period;
-        }
+    if (sched_changes) {
+        ctx->sched_mode = sched_mode;
+        ctx->params.sched_units = ctx->sched_cap[sched_mode];
+        ctx->sched_since = ctx->sched_period;
     }
     for (uint32_t f = 0; f < frames; f++) {
         if (marks) VRT_HIP(ctx, hipEventRecord(marks[f], ctx->stream)); // per-frame timing (vrt_dispatch_timed)
