@@ -62,6 +62,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
     const uint32_t stage0 = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)pool_lds + 64u;
     uint32_t *const rec = pool_lds + 16u + (uint32_t)STAGES * (kPoolStageBytes / 4u) + wave * kWaveDwords; // rec[S k + j]: dword k of the ray in slot j
     uint32_t *const sstate = rec + kPoolRecDwords * S; // state of the ray in slot j
+    // (LDS byte addresses for the exchange's instructions; scalar: the wave's number is)
+    const uint32_t rec_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)rec);
+    const uint32_t tmp_lds = rec_lds + (kPoolRecDwords + 1u) * S * 4u;
     uint32_t *const tmp = sstate + S;
     if constexpr (STAGES < 4) {
         if (threadIdx.x < 16u) locks[threadIdx.x] = 0u;
@@ -134,25 +137,38 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
         const unsigned long long offer = __builtin_amdgcn_ballot_w64(pool_class(sst) == X);
         const unsigned long long want = __builtin_amdgcn_ballot_w64(pool_class(st) != X);
         const uint32_t n = min((uint32_t)__builtin_popcountll(offer), (uint32_t)__builtin_popcountll(want));
-        if (n == 0u) return;
         const uint32_t q = pool_mbcnt(offer), r = pool_mbcnt(want);
         if (((offer >> lane) & 1ull) && q < n) tmp[q] = lane;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (((want >> lane) & 1ull) && r < n) {
-            const uint32_t j = tmp[r];
-            uint32_t *const s = rec + j;
-#define VRT_XCH_F(k, v) { const uint32_t t_ = s[S * (k)]; s[S * (k)] = f2u(v); v = u2f(t_); }
-#define VRT_XCH_U(k, v) { const uint32_t t_ = s[S * (k)]; s[S * (k)] = v; v = t_; }
-            VRT_XCH_F(0, ro.x) VRT_XCH_F(1, ro.y) VRT_XCH_F(2, ro.z) VRT_XCH_F(3, rd.x) VRT_XCH_F(4, rd.y) VRT_XCH_F(5, rd.z)
-            VRT_XCH_F(6, inv.x) VRT_XCH_F(7, inv.y) VRT_XCH_F(8, inv.z) VRT_XCH_F(9, sd.x) VRT_XCH_F(10, sd.y) VRT_XCH_F(11, sd.z)
-            VRT_XCH_U(12, idx) VRT_XCH_U(13, cw) VRT_XCH_F(14, t_in) VRT_XCH_F(15, t_out) VRT_XCH_F(16, gtmin) VRT_XCH_F(17, gtmax)
-            VRT_XCH_F(18, ir) VRT_XCH_U(19, fl) VRT_XCH_U(20, code)
-#undef VRT_XCH_F
-#undef VRT_XCH_U
-            const uint32_t mine = st;
-            st = sstate[j];
-            sstate[j] = mine;
+        {
+            // the lane's 21 dwords and its state against the slot's, field by field: ds_wrxchg writes the register and returns what was
+            // there into the same register — one LDS instruction per field, nothing copied.  The taking lanes are selected by EXEC inside
+            // the block: to the compiler this is straight-line code on the ray's registers (as a branch it copies all 22 of them to
+            // another set of registers before every exchange: the loaded values are the branch's, the old ones the other path's)
+            const unsigned long long take = __builtin_amdgcn_ballot_w64(((want >> lane) & 1ull) && r < n);
+            const uint32_t slot_of = tmp_lds + (r << 2);
+            unsigned long long saved;
+            uint32_t at;
+#define VRT_X(k) "ds_wrxchg_rtn_b32 %[f" #k "], %[at], %[f" #k "] offset:%[o" #k "]\n\t"
+            asm volatile("s_and_saveexec_b64 %[saved], %[take]\n\t"
+                         "ds_read_b32 %[at], %[slot]\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "v_lshl_add_u32 %[at], %[at], 2, %[rec]\n\t"
+                         VRT_X(0) VRT_X(1) VRT_X(2) VRT_X(3) VRT_X(4) VRT_X(5) VRT_X(6) VRT_X(7) VRT_X(8) VRT_X(9) VRT_X(10) VRT_X(11) VRT_X(12) VRT_X(13)
+                         VRT_X(14) VRT_X(15) VRT_X(16) VRT_X(17) VRT_X(18) VRT_X(19) VRT_X(20) VRT_X(21)
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "s_mov_b64 exec, %[saved]"
+                         : [f0] "+v"(ro.x), [f1] "+v"(ro.y), [f2] "+v"(ro.z), [f3] "+v"(rd.x), [f4] "+v"(rd.y), [f5] "+v"(rd.z), [f6] "+v"(inv.x),
+                           [f7] "+v"(inv.y), [f8] "+v"(inv.z), [f9] "+v"(sd.x), [f10] "+v"(sd.y), [f11] "+v"(sd.z), [f12] "+v"(idx), [f13] "+v"(cw),
+                           [f14] "+v"(t_in), [f15] "+v"(t_out), [f16] "+v"(gtmin), [f17] "+v"(gtmax), [f18] "+v"(ir), [f19] "+v"(fl),
+                           [f20] "+v"(code), [f21] "+v"(st), [at] "=&v"(at), [saved] "=&s"(saved)
+                         : [take] "s"(take), [slot] "v"(slot_of), [rec] "s"(rec_lds), [o0] "n"(0), [o1] "n"(4 * S), [o2] "n"(8 * S), [o3] "n"(12 * S),
+                           [o4] "n"(16 * S), [o5] "n"(20 * S), [o6] "n"(24 * S), [o7] "n"(28 * S), [o8] "n"(32 * S), [o9] "n"(36 * S), [o10] "n"(40 * S),
+                           [o11] "n"(44 * S), [o12] "n"(48 * S), [o13] "n"(52 * S), [o14] "n"(56 * S), [o15] "n"(60 * S), [o16] "n"(64 * S),
+                           [o17] "n"(68 * S), [o18] "n"(72 * S), [o19] "n"(76 * S), [o20] "n"(80 * S), [o21] "n"(84 * S)
+                         : "memory", "scc");
+#undef VRT_X
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -206,11 +222,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
             }
         }
         VRT_PROF_END(3, tpd);
-        if (phase == 3u) {
-            __builtin_amdgcn_s_sleep(16);
-            continue;
-        }
-
+        // (three separate `if`s on the wave-uniform phase, no `else`, no `continue`: an if / else-if chain is linearised by the compiler's
+        // CFG structuriser with a join per arm, and every join copies the 22 values of the ray from one set of registers to another)
+        if (phase == 3u) __builtin_amdgcn_s_sleep(16);
         if (phase == 0u) {
             [[maybe_unused]] const unsigned long long pf0 = VRT_PF_NOW();
             VRT_PROF_BEGIN(tpz);
@@ -455,14 +469,15 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 pr[13 * 128] = f2u(attenuation.x), pr[14 * 128] = f2u(attenuation.y), pr[15 * 128] = f2u(attenuation.z);
             }
             VRT_PF_T(0, pf0);
-        } else if (phase == 1u) {
+        }
+        if (phase == 1u) {
             // every lane that has a ray to walk walks (comp:314-375), until pool_walk_k of them have parked or left
             [[maybe_unused]] const unsigned long long pf1 = VRT_PF_NOW();
             VRT_PROF_BEGIN(tpx);
             exchange(1u);
             VRT_PROF_END(0, tpx);
             const unsigned long long walking = __builtin_amdgcn_ballot_w64(st == kRayWalk);
-            if (walking == 0ull) continue;
+            if (walking != 0ull) {
             const uint32_t n_walking = (uint32_t)__builtin_popcountll(walking);
             const int sx = sx_of(fl), sy = sy_of(fl), sz = sz_of(fl);
             const uint32_t flip = (sx < 0 ? fx : 0u) | (sy < 0 ? fy : 0u) | (sz < 0 ? fz : 0u);
@@ -488,22 +503,19 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
             VRT_PF_N(2, 1);
             VRT_PF_N(3, n_walking);
             VRT_PF_N(4, __builtin_popcountll(g.alive));
+            // (selects, not branches: the asm ran under the walking lanes' EXEC, so its in/out operands — side distances, index, t_out —
+            // are the other lanes' own values still; a branch here is one more join that copies the ray)
             t_in = was_walking ? g.t_in : t_in_keep;
-            if (was_walking) {
-                t_out = g.t_out;
-                if (parked) {
-                    st = kRayParked;
-                    cw = cell;
-                    code = g.code; // bits 0-1 the axis INTO the occupied cell, 2-3 the axis out of it
-                    fl = (fl & ~(1u << 20)) | (__builtin_amdgcn_inverse_ballot_w64(gone) ? (1u << 20) : 0u);
-                } else if (moving) {
-                    cw = word;
-                    code = (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
-                } else {
-                    st = kRayMiss; // left the grid
-                }
+            t_out = g.t_out;
+            const bool park = was_walking && parked, move = was_walking && !parked && moving, left = was_walking && !parked && !moving;
+            const uint32_t axis_code = (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
+            st = park ? (uint32_t)kRayParked : (left ? (uint32_t)kRayMiss : st); // (left: the ray has left the grid)
+            cw = park ? cell : (move ? word : cw);
+            code = park ? g.code : (move ? axis_code : code); // parked: bits 0-1 the axis INTO the occupied cell, 2-3 the axis out of it
+            fl = park ? ((fl & ~(1u << 20)) | (__builtin_amdgcn_inverse_ballot_w64(gone) ? (1u << 20) : 0u)) : fl;
             }
-        } else {
+        }
+        if (phase == 2u) {
             // the rays that stand in front of an occupied cell walk its brick (comp:378-471)
             [[maybe_unused]] const unsigned long long pf2 = VRT_PF_NOW();
             const uint32_t wave_lds = stage0 + (uint32_t)stage * kPoolStageBytes;
