@@ -471,7 +471,11 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
             VRT_PF_T(0, pf0);
         }
         if (phase == 1u) {
-            // every lane that has a ray to walk walks (comp:314-375), until pool_walk_k of them have parked or left
+            // every lane that has a ray to walk walks (comp:314-375), until pool_walk_k of them have parked or left — and again while the
+            // phase rule keeps saying so (two calls in three follow a call): an inner loop, whose rays stay in ONE set of registers from
+            // call to call (at the outer loop's back edge the compiler copies all 22 values of the ray to another set and back)
+            bool again; // wave-uniform
+            do {
             [[maybe_unused]] const unsigned long long pf1 = VRT_PF_NOW();
             VRT_PROF_BEGIN(tpx);
             exchange(1u);
@@ -514,6 +518,18 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
             code = park ? g.code : (move ? axis_code : code); // parked: bits 0-1 the axis INTO the occupied cell, 2-3 the axis out of it
             fl = park ? ((fl & ~(1u << 20)) | (__builtin_amdgcn_inverse_ballot_w64(gone) ? (1u << 20) : 0u)) : fl;
             }
+            // the phase rule's first three lines on fresh counts: neither of the other queues is full, and enough rays are left to walk
+            {
+                const uint32_t sst2 = lane < S ? sstate[lane] : (uint32_t)kRayExit;
+                const uint32_t w2 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kRayWalk)) +
+                                    (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sst2 == kRayWalk));
+                const uint32_t b2 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kRayParked)) +
+                                    (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sst2 == kRayParked));
+                const uint32_t t2 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st <= kRayHit)) +
+                                    (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sst2 <= kRayHit));
+                again = b2 < brick_thr && t2 < trans_thr && w2 >= walk_min && ++round < (1u << 23);
+            }
+            } while (again);
         }
         if (phase == 2u) {
             // the rays that stand in front of an occupied cell walk its brick (comp:378-471)
