@@ -198,6 +198,7 @@ struct vrt_ctx {
     uint8_t *d_status_bytes = nullptr; // derived: one byte per grid cell (TraceParams::status_bytes)
     uint8_t *d_cell_distance = nullptr;      // derived: L1 distance of every cell to the nearest occupied cell (vrt_path_kernel<DIST>)
     uint32_t *d_status_halfblocks = nullptr; // derived: status bits by 4 x 4 x 2 cells per word (vrt_path_kernel on eligible grids)
+    bool cell_occupancy_lockstep = false;    // ... read by the lockstep bounce kernel too (scenes that stay in the caches)
     uint8_t *d_cell_occupancy = nullptr;     // derived: occupancy bits by cell (TraceParams::cell_occupancy; vrt_path_kernel, within a memory budget)
     uint32_t *d_start_is_slot = nullptr;     // derived: 1 = binding 6 holds slot * B^3 for every allocated brick (TraceParams::start_is_slot)
     bool occupancy_dirty = true;             // bindings 3-5 changed since the by-cell copy was built ...
@@ -871,13 +872,19 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         // by-cell copy", not a failed vrt_create: the kernels then reach a brick's bits through brick_index as the shader does)
         size_t mem_free = 0, mem_total = 0;
         if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0;
-        if (any_kernel([](const vrt::KernelEntry &e) { return e.path != 0; }) && !(cfg->tuning_flags & VRT_TUNE_NO_CELL_OCCUPANCY) &&
+        // (round 4: also for the lockstep bounce kernel on scenes that stay in the caches — up to 64 MiB of it —, whose brick entries then
+        // request the bits without waiting for brick_index[cell]: brick_walk_gfx950<..., BY_CELL>)
+        const bool persistent = any_kernel([](const vrt::KernelEntry &e) { return e.path != 0; });
+        const bool lockstep_bounce = any_kernel([](const vrt::KernelEntry &e) { return e.path == 0 && e.shade == 0 && !e.count; }) &&
+                                     by_cell_bytes <= (64ull << 20) && cells * bits <= (1ull << 32);
+        if ((persistent || lockstep_bounce) && !(cfg->tuning_flags & VRT_TUNE_NO_CELL_OCCUPANCY) &&
             by_cell_bytes <= (2ull << 30) && by_cell_bytes + 64u <= mem_free / 4u && (lds_walk || cells * bits <= (1ull << 32))) {
             if (hipMalloc(reinterpret_cast<void **>(&c->d_cell_occupancy), by_cell_bytes + 64u) != hipSuccess) {
                 (void)hipGetLastError();
                 c->d_cell_occupancy = nullptr;
             } else {
                 VRT_CREATE_HIP(hipMemsetAsync(c->d_cell_occupancy, 0, by_cell_bytes + 64u, c->stream));
+                c->cell_occupancy_lockstep = lockstep_bounce;
             }
         }
         if (!(cfg->tuning_flags & VRT_TUNE_NO_START_SHORTCUT)) {
@@ -973,6 +980,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.status_halfblocks = c->d_status_halfblocks;
     p.cell_distance = c->d_cell_distance;
     p.cell_occupancy = c->d_cell_occupancy;
+    p.cell_occupancy_lockstep = (c->d_cell_occupancy && c->cell_occupancy_lockstep) ? 1u : 0u;
     p.start_is_slot = c->d_start_is_slot;
     p.status_cells = (uint32_t)cells;
     // (order_auto: frames that alternate between the two streams of a frames_in_flight = 2 context take reverse raster (3)
@@ -1005,6 +1013,9 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         // quarters 16.7 / 21.5 / 24.1 / 23.4, eighths 16.4 / 23.3 / 25.4 / 24.1: halves; the rest of such a frame is its launch and the
         // fixed part of a wave's chain — the status bits in LDS change nothing, tools/small_frame_ab.py)
         p.split_all = (eligible && waves <= 2u * simds) ? 1u : 0u;
+#ifdef VRT_EXP_SPLIT_ALL
+        if (c->tile_order == 3u) p.split_all = VRT_EXP_SPLIT_ALL;
+#endif
     }
     p.brick_batch = (cfg->kernel_variant >> 24) & 0xFu ? ((cfg->kernel_variant >> 24) & 0xFu) * 4u : 8u; // tuning knob: units of 4 lanes
     p.path_brick_batch = (cfg->kernel_variant >> 24) & 0xFu ? ((cfg->kernel_variant >> 24) & 0xFu) * 4u : 32u; // vrt_path_kernel: waiting is cheap there

@@ -85,6 +85,7 @@ struct TraceParams {
     // cell (cell * B^3 / 8 bytes) — a brick entry then needs no brick_index look-up before it can ask for the brick's bits
     // (comp:337 -> comp:415 is one dependent miss less; the index is fetched only when a solid voxel was found)
     const uint8_t *cell_occupancy;
+    uint32_t cell_occupancy_lockstep; // 1: the lockstep bounce kernel reads it too (round 4: the scene stays in the caches, cells * B^3 < 2^32)
     // derived from binding 6: *start_is_slot == 1 when every allocated brick's start index is slot * B^3 — the pattern the
     // reference's allocator produces (MaterialAllocator.zig:39 hands out B^3 entries per brick in slot order) — so that comp:422's
     // look-up is replaced by a multiplication; nullptr or 0: look it up

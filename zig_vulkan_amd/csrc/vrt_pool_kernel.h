@@ -498,7 +498,11 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
             uint32_t word = cw, cell;
             unsigned long long gone = 0ull;
             VRT_PROF_BEGIN(tpw);
+#ifdef VRT_POOL_AHEAD
+            grid_walk_park_dilated_ahead_gfx950(sd, inv, idx, cell, nm_x, nm_y, nm_z, word, hb_rsrc, g, flip, gone);
+#else
             grid_walk_park_dilated_carry_gfx950(sd, inv, idx, cell, nm_x, nm_y, nm_z, word, hb_rsrc, g, flip, gone);
+#endif
             VRT_PROF_END(1, tpw);
             const bool was_walking = (walking >> lane) & 1ull;
             const bool parked = __builtin_amdgcn_inverse_ballot_w64(g.parked);

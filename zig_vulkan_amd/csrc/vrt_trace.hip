@@ -178,14 +178,20 @@ __global__ __launch_bounds__(256) void vrt_build_cell_bounds(const uint32_t *__r
 // One workgroup.  cost[] ([half][tile][wave], overwritten by every frame) is condensed into snap[] first: frames
 // on another stream may still be writing cost[], and every pass below must see the same values or order[] would
 // not be a permutation.  The order affects timing only, never pixels.
+// Round 4: the halves of split tiles are no longer ONE class in reverse-raster order but kSplitBuckets classes by the tile's slowest
+// wave, slowest first — on the reference app's own run nearly every tile that holds terrain is split (3 000 half-tile workgroups for
+// 1 024 workgroup slots), and with them unordered the second generation of workgroups held waves as long as the first's longest:
+// they started at 100 us and ended at 300 (tools/timeline_tail.py).
 constexpr uint32_t kScheduleBuckets = 8u;
+constexpr uint32_t kSplitBuckets = 8u;
+constexpr uint32_t kAllBuckets = kScheduleBuckets + kSplitBuckets;
 __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ snap,
                                                             const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra_max,
                                                             uint32_t extra, uint32_t wave_slots) {
     __shared__ uint32_t s_max, s_nsplit, s_longest;
     __shared__ unsigned long long s_total;
-    __shared__ uint32_t wave_total[kScheduleBuckets + 1u][16];
-    __shared__ uint32_t class_total[kScheduleBuckets + 1u];
+    __shared__ uint32_t wave_total[kAllBuckets][16];
+    __shared__ uint32_t class_total[kAllBuckets];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     uint32_t *state = snap + n;
     // order[] is stored XCD-major: entry k at (k % 8) * row + k / 8.  extra_max: the spare entries the buffer holds (its layout);
@@ -251,30 +257,35 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__re
     for (uint32_t i = tid; i < n; i += 1024u) {
         uint32_t want = (reorder && extra && (unsigned long long)(state[i] >> 1) > threshold) ? 1u : 0u;
         if (want && atomicAdd(&s_nsplit, 1u) >= extra) want = 0u; // no spare entry left
-        state[i] = want;
+        state[i] = (state[i] & ~1u) | want; // (bits 1-31: the tile's slowest wave, for the class of a split tile below)
     }
     __syncthreads();
     const uint32_t nsplit = min(s_nsplit, extra);
     const float scale = reorder ? (float)kScheduleBuckets / (float)mx : 0.0f; // (0: one class, i.e. reverse raster)
+    const float split_scale = (float)kSplitBuckets / (float)max(1u, s_longest);
+    auto class_of = [&](uint32_t tile, uint32_t st) {
+        return (st & 1u) ? kScheduleBuckets + min(kSplitBuckets - 1u, (uint32_t)((float)(st >> 1) * split_scale))
+                         : min(kScheduleBuckets - 1u, (uint32_t)((float)snap[tile] * scale));
+    };
     // thread t owns positions [lo, hi) of the default order (position j = tile n-1-j)
     const uint32_t chunk = (n + 1023u) / 1024u;
     const uint32_t lo = min(n, tid * chunk), hi = min(n, lo + chunk);
-    uint32_t cnt[kScheduleBuckets + 1u]; // class kScheduleBuckets: the halves of split tiles
+    uint32_t cnt[kAllBuckets]; // classes kScheduleBuckets ...: the halves of split tiles
 #pragma unroll
-    for (uint32_t b = 0; b <= kScheduleBuckets; b++) cnt[b] = 0u;
+    for (uint32_t b = 0; b < kAllBuckets; b++) cnt[b] = 0u;
 #pragma unroll 4
     for (uint32_t j = lo; j < hi; j++) {
         const uint32_t tile = n - 1u - j;
-        const uint32_t sp = state[tile];
-        const uint32_t b = sp ? kScheduleBuckets : min(kScheduleBuckets - 1u, (uint32_t)((float)snap[tile] * scale));
+        const uint32_t st = state[tile], sp = st & 1u;
+        const uint32_t b = class_of(tile, st);
 #pragma unroll
-        for (uint32_t k = 0; k <= kScheduleBuckets; k++) cnt[k] += (k == b) ? (1u + sp) : 0u;
+        for (uint32_t k = 0; k < kAllBuckets; k++) cnt[k] += (k == b) ? (1u + sp) : 0u;
     }
     // exclusive scan of every class over the threads, heaviest class first: inside the wave by shuffles, over the 16 waves
     // by one thread per class
-    uint32_t pos[kScheduleBuckets + 1u];
+    uint32_t pos[kAllBuckets];
 #pragma unroll
-    for (uint32_t b = 0; b <= kScheduleBuckets; b++) {
+    for (uint32_t b = 0; b < kAllBuckets; b++) {
         uint32_t incl = cnt[b];
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__re
         if (lane == 63u) wave_total[b][wv] = incl;
     }
     __syncthreads();
-    if (tid <= kScheduleBuckets) {
+    if (tid < kAllBuckets) {
         uint32_t acc = 0u;
         for (uint32_t k = 0; k < 16u; k++) {
             const uint32_t t = wave_total[tid][k];
@@ -297,18 +308,18 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__re
     {
         uint32_t base = 0u;
 #pragma unroll
-        for (int b = (int)kScheduleBuckets; b >= 0; b--) {
+        for (int b = (int)kAllBuckets - 1; b >= 0; b--) {
             pos[b] += base + wave_total[b][wv];
             base += class_total[b];
         }
     }
     for (uint32_t j = lo; j < hi; j++) {
         const uint32_t tile = n - 1u - j;
-        const uint32_t sp = state[tile];
-        const uint32_t b = sp ? kScheduleBuckets : min(kScheduleBuckets - 1u, (uint32_t)((float)snap[tile] * scale));
+        const uint32_t st = state[tile], sp = st & 1u;
+        const uint32_t b = class_of(tile, st);
         uint32_t at = 0u;
 #pragma unroll
-        for (uint32_t k = 0; k <= kScheduleBuckets; k++) {
+        for (uint32_t k = 0; k < kAllBuckets; k++) {
             if (k == b) {
                 at = pos[k];
                 pos[k] += 1u + sp;

@@ -715,7 +715,7 @@ VRT_DI void grid_walk_park_dilated_carry_gfx950(f3 &side_dist, const f3 &inv_dir
 #undef VRT_LOAD_DILATED_A
 #undef VRT_LOAD_DILATED_B
 #undef VRT_TEST_DILATED
-#ifdef VRT_DEV_VARIANTS
+#if defined(VRT_DEV_VARIANTS) || defined(VRT_POOL_AHEAD)
 #define VRT_DEV_SECTION 3
 #include "vrt_trace_kernels_dev.h"
 #undef VRT_DEV_SECTION
@@ -941,9 +941,13 @@ VRT_DI bool brick_walk(const TraceParams &p, const Ray &r, const RaySetup &s, fl
 // The loop returns when some lane has left a solid voxel behind; the material test (comp:422-427) and the hit
 // record are done here, and lanes whose voxel is to be ignored walk on.  `axis_in`: the face through which the
 // brick was entered (the brick-level walk's crossed axis), used when the very first voxel is the hit.
-template <int B, bool EAGER = true>
+// BY_CELL (round 4, frames with bounces on scenes that stay in the caches): the brick's bits are read from the by-cell copy
+// (TraceParams::cell_occupancy, `cell` = the grid cell) when the context holds one, so that the request for them does not wait for
+// brick_index[cell] (comp:337) — which then only the material look-up of a solid voxel needs.  Such frames last as long as their slowest
+// wave, and that wave's time is its chain of brick entries: one dependent round trip less per entry.
+template <int B, bool EAGER = true, bool BY_CELL = false>
 VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t brick_index, f3 brick_min, Hit &hit,
-                              int axis_in, int &hit_axis) {
+                              int axis_in, int &hit_axis, uint32_t cell = 0u) {
     const float brick_voxel_scale = 1.0f / (float)B; // spec const 5, Pipeline.zig:313
     const float voxel_scale = g_scale * brick_voxel_scale;
     const f3 fposition = p.scale_pow2 ? (ray_at(r, hit.t) - brick_min) * p.inv_voxel_scale : (ray_at(r, hit.t) - brick_min) / splat3(voxel_scale);
@@ -959,18 +963,20 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
     w.t_value = 0;
     const float local_t_max = s.grid_t_max - hit.t;
     // global bit index of the voxel in brick_occupancy: brick * B^3 + voxel index (comp:412-415)
-    const uint32_t base = brick_index * (uint32_t)(B * B * B);
+    const bool by_cell = BY_CELL && p.cell_occupancy_lockstep != 0u; // (wave-uniform; vrt_create keeps cells * B^3 below 2^32 for this copy)
+    const uint32_t base = (by_cell ? cell : brick_index) * (uint32_t)(B * B * B);
     uint32_t bit_index = base + ((uint32_t)px + (uint32_t)B * ((uint32_t)pz + (uint32_t)B * (uint32_t)py));
     const uint32_t stride_x = (uint32_t)s.sx, stride_y = (uint32_t)(s.sy * (B * B)), stride_z = (uint32_t)(s.sz * B);
     const bool more = more_init(px, py, pz, B) && (0.0f <= local_t_max); // comp:409 with t_value = 0
 
-    const unsigned long long occ_addr = (unsigned long long)p.brick_occupancy;
+    const uint8_t *const occupancy = by_cell ? p.cell_occupancy : p.brick_occupancy;
+    const unsigned long long occ_addr = (unsigned long long)occupancy;
     u32x4 rsrc;
     rsrc.x = (uint32_t)occ_addr;
     rsrc.y = (uint32_t)(occ_addr >> 32) | (4u << 16);
-    rsrc.z = p.occupancy_words;
+    rsrc.z = by_cell ? p.status_cells * (uint32_t)(B * B * B / 32) : p.occupancy_words;
     rsrc.w = 0x00020000u;
-    uint32_t word = reinterpret_cast<const uint32_t *>(p.brick_occupancy)[more ? (bit_index >> 5) : 0u];
+    uint32_t word = reinterpret_cast<const uint32_t *>(occupancy)[more ? (bit_index >> 5) : 0u];
     // comp:422.  EAGER: requested before the walk, so that a solid voxel's material test starts one dependent load later
     // (scenes that stay in the caches).  Otherwise requested at the first solid voxel: on a scene larger than the caches
     // every request is a 128-byte line from HBM, and four of five brick walks of the path-trace configuration end without
@@ -1403,7 +1409,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         VRT_COUNT_WAVE(wave_brick_walks);
         bool found;
         if constexpr ((MODE == kStatusLinearAlways || MODE == kStatusLinearLds || MODE == kStatusBytes) && !COUNT) {
-            found = brick_walk_gfx950<B>(p, r, s, g_scale, brick_index, brick_min, hit, brick_axis, hit_axis);
+            found = brick_walk_gfx950<B, true, BATCH>(p, r, s, g_scale, brick_index, brick_min, hit, brick_axis, hit_axis, cell);
         } else {
             found = brick_walk<B, COUNT, MODE == kStatusLinear || MODE == kStatusLinearLds || MODE == kStatusLinearAhead>(
                 p, r, s, g_scale, brick_index, brick_min, hit, brick_axis, c);
@@ -1438,12 +1444,16 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
         g.t_out = skip_t;
         g.code = (uint32_t)axis << 4; // 3: the first cell of the walk was entered through the slab test, not by a step
         g.batch = p.brick_batch;
+        VRT_PROF_END(3, tp3);
         while (g.alive != 0ull) {
             uint32_t cell; // the occupied cell each parked lane stood on before its last step
+            VRT_PROF_BEGIN(tp0);
             grid_walk_park_gfx950(w, s.inv_dir, grid_index, cell, stride_x, stride_y, stride_z, word, rsrc, g);
+            VRT_PROF_END(0, tp0);
             if (g.parked == 0ull) break; // every lane has left the grid
             const bool parked = __builtin_amdgcn_inverse_ballot_w64(g.parked);
             bool resume = false;
+            VRT_PROF_BEGIN(tp1);
             if (parked) {
                 int a = (int)(g.code & 3u);
                 const uint32_t out = (g.code >> 2) & 3u;
@@ -1451,6 +1461,7 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
                 enter_brick_at(w.rx + (out == 0u ? 1 : 0), w.ry + (out == 1u ? 1 : 0), w.rz + (out == 2u ? 1 : 0), g.t_in, cell, a);
                 resume = (stop == 0) && min3i(w.rx, w.ry, w.rz) >= 0;
             }
+            VRT_PROF_END(1, tp1);
             // every lane: the axis of its last step, for its first trip in the next call
             g.code = parked ? ((g.code >> 2) & 3u) << 4
                             : (__builtin_amdgcn_inverse_ballot_w64(g.out_x) ? 0u : (__builtin_amdgcn_inverse_ballot_w64(g.out_y) ? 1u : 2u)) << 4;
@@ -1803,8 +1814,10 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     // sample 0 of the wave's 32 pixels, lanes 32-63 sample 1 of the same pixels, and lane l adds lane l + 32's colour to its own —
     // (0 + s0) + s1, the sample loop's own sum (comp:173) — before the tone-map.  The slowest waves of a bounce frame (the frame lasts
     // as long as they do: the reference app's run, tools/timeline.py) then have half the GridHits to go through one after the other.
-    const bool dual = SHADE != 2 && !COUNT && split == 1u && !p.packed_rgb && pc.cam.samples_per_pixel == 2; // (uniform over the workgroup)
-    const uint32_t plane = dual ? (lane & 31u) : lane;
+    // (a quarter- or eighth-tile workgroup: 16 or 8 pixels per wave, twice as many lanes at work)
+    const bool dual = SHADE != 2 && !COUNT && split != 0u && !p.packed_rgb && pc.cam.samples_per_pixel == 2; // (uniform over the workgroup)
+    const uint32_t pixels = 64u >> split; // pixels of its 8x8 block this wave renders
+    const uint32_t plane = dual ? (lane & (pixels - 1u)) : lane;
     const uint32_t in_x = (wave & 1u) * 8u + (plane & 7u);
     const uint32_t rows = 8u >> split; // rows of its 8x8 block this wave renders (split: 4 or 2), from row `half * rows`
     const uint32_t in_y = (wave >> 1) * 8u + half * rows + ((plane >> 3) & (rows - 1u));
@@ -1819,7 +1832,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const unsigned long long t_begin = (p.tile_order == 5u) ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long wall_begin = p.wave_timeline ? wall_clock64() : 0ull;
     Cnt<COUNT> c;
-    const bool inside = (px < p.width) && (py < p.height) && (dual || lane < (64u >> split)); // comp:155-159
+    const bool inside = (px < p.width) && (py < p.height) && lane < (dual ? 2u * pixels : pixels); // comp:155-159
     uint32_t rgba = 0u; // this lane's pixel (0 outside the image), also needed after the branch by the RGB shard store
     if (inside) {
         f3 color = mk3(0, 0, 0);
@@ -1837,7 +1850,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
             const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
             color = mk3(0, 0, 0) + ray_color_single<B, COUNT, MODE>(p, pc, lds_filter, create_ray(origin, ray_dir), c);
         } else {
-            const int sample_begin = dual ? (int)(lane >> 5) : 0, sample_end = dual ? sample_begin + 1 : spp;
+            const int sample_begin = dual ? (int)(lane >= pixels ? 1u : 0u) : 0, sample_end = dual ? sample_begin + 1 : spp;
             for (int sample_i = sample_begin; sample_i < sample_end; sample_i++) {
                 // Re-derive the camera vectors from their SGPRs in every trip: a VALU op takes a single scalar
                 // operand, so the compiler copies them to VGPRs — hoisted out of this loop, twelve copies would
@@ -1859,9 +1872,10 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         bool writer = true;
         if constexpr (SHADE != 2 && !COUNT) {
             if (dual) { // (both lanes of a pixel are inside the image or neither is: the source lane is active)
-                const f3 second = mk3(__shfl(color.x, (int)lane + 32, 64), __shfl(color.y, (int)lane + 32, 64), __shfl(color.z, (int)lane + 32, 64));
+                const int from = (int)((lane + pixels) & 63u);
+                const f3 second = mk3(__shfl(color.x, from, 64), __shfl(color.y, from, 64), __shfl(color.z, from, 64));
                 color = color + second;
-                writer = lane < 32u;
+                writer = lane < pixels;
             }
         }
         const float fspp = (float)spp;

@@ -402,8 +402,8 @@ class VoxelRT:
 
     def wave_timeline(self, raw: bool = False) -> np.ndarray:
         """One frame with per-wave [begin, end] wall-clock ticks (100 MHz); shape (waves, 2).  The cost-ordered launch has up to
-        1024 spare workgroups (second halves of split tiles); the rows of those that stayed idle are dropped unless raw."""
-        n = (self.shard_info().owned_tiles + 1024) * 4
+        one spare workgroup per tile (second halves of split tiles); the rows of those that stayed idle are dropped unless raw."""
+        n = (2 * self.shard_info().owned_tiles + 1024) * 4
         out = np.zeros((n, 2), dtype=np.uint64)
         got = C.c_uint64()
         self._check(self._lib.vrt_trace_wave_timeline(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data), out.ctypes.data, n,
