@@ -262,10 +262,12 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__re
     __syncthreads();
     const uint32_t nsplit = min(s_nsplit, extra);
     const float scale = reorder ? (float)kScheduleBuckets / (float)mx : 0.0f; // (0: one class, i.e. reverse raster)
-    const float split_scale = (float)kSplitBuckets / (float)max(1u, s_longest);
+    // ONE scale for all workgroups when tiles are split: the expected time of the workgroup's slowest wave — the tile's slowest wave,
+    // over 1.28 for a half (what splitting gains) — so that a whole tile with a long wave is not launched behind every half
+    const float split_scale = (float)kAllBuckets / (float)max(1u, s_longest);
     auto class_of = [&](uint32_t tile, uint32_t st) {
-        return (st & 1u) ? kScheduleBuckets + min(kSplitBuckets - 1u, (uint32_t)((float)(st >> 1) * split_scale))
-                         : min(kScheduleBuckets - 1u, (uint32_t)((float)snap[tile] * scale));
+        if (nsplit != 0u) return min(kAllBuckets - 1u, (uint32_t)((float)(st >> 1) * ((st & 1u) ? 0.78125f : 1.0f) * split_scale));
+        return min(kScheduleBuckets - 1u, (uint32_t)((float)snap[tile] * scale));
     };
     // thread t owns positions [lo, hi) of the default order (position j = tile n-1-j)
     const uint32_t chunk = (n + 1023u) / 1024u;
