@@ -689,7 +689,9 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         c->sched_cap[0] = std::min(std::min(1024u, n / 8u), c->sched_extra);
         c->sched_cap[1] = c->sched_extra;
         c->sched_slots[0] = c->wave_slots;
-        c->sched_slots[1] = 40u * (uint32_t)cus;
+        // (with the halves in cost classes of their own — vrt_schedule_kernel, round 4 — a lower bar pays: 28 / 40 / 52 / 64 / 96 slots
+        // per CU 0.300 / 0.260 / 0.259 / 0.259 / 0.259 ms on V0, 0.323 / 0.285 / 0.262 / 0.255 / 0.257 on V1, 0.350 / 0.312 / 0.286 / 0.284 / 0.282 on V2)
+        c->sched_slots[1] = 64u * (uint32_t)cus;
         VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_tile_cost), n * 32u)); // [half][tile][wave]
         const uint32_t ns = 8u * ((n + c->sched_extra + 7u) / 8u); // an order buffer is stored XCD-major: 8 rows of ceil((n + extra) / 8)
         c->sched_stride = ns;
