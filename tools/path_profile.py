@@ -15,7 +15,8 @@ rc = W.make_renderer(w, grid, kernel_variant=variant, enable_counters=True)
 W.set_view(rt, view); W.set_view(rc, view)
 rt.draw(); rt.wait()   # (behind a finished frame the library knows the box of the occupied cells)
 rt.draw(); rt.wait()
-raw = rt.wave_timeline(raw=True).reshape(-1).astype(float)
+rt_raw_int = rt.wave_timeline(raw=True).reshape(-1)
+raw = rt_raw_int.astype(float)
 kernel = rt.kernel_name()
 pr = raw[:12]
 bw = raw[12:20]
@@ -32,6 +33,13 @@ print(f"  walk loop: {n_calls/1e6:.2f} M calls, {n_alive_in/n_calls:.1f} lanes a
       f"lane-trips {c['grid_steps']/1e6:.0f} M -> {c['grid_steps']/n_calls:.1f} lane-trips per call")
 print(f"  bricks: {n_brick/1e6:.2f} M rounds, {n_parked/n_brick:.1f} parked lanes per round, {t_brick/n_brick:.0f} cycles per round")
 rt.deinit(); rc.deinit()
+if "pool" in kernel and len(raw) > 23 and raw[22]:
+    rawi = rt_raw_int
+    inv = lambda v: (~int(v)) & 0xFFFFFFFFFFFFFFFF
+    begin, first_dry, last_dry, end = inv(rawi[20]), inv(rawi[21]), int(rawi[23]), int(rawi[22])
+    span = (end - begin) / 100.0
+    print(f"  drain: kernel {span / 1e3:.2f} ms by the wall clock; the first wave finds the pixel counter exhausted at {100 * (first_dry - begin) / (end - begin):.1f} % of it, "
+          f"the last at {100 * (last_dry - begin) / (end - begin):.1f} %; the last wave ends {(end - first_dry) / 100.0 / 1e3:.2f} ms after the counter ran out")
 if "pool" in kernel:
     print(f"  vrt_pool_kernel (wave-cycles, share of all): phase rule {100*bw[3]/tot:.1f} %, exchange before a walk call {100*bw[0]/tot:.1f} % ({bw[0]/n_calls:.0f} cycles per call), "
           f"the walk loop itself {100*bw[1]/tot:.1f} % ({bw[1]/n_calls:.0f} cycles per call), exchange before a brick round {100*bw[6]/tot:.1f} % ({bw[6]/n_brick:.0f} per round), "

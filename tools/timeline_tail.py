@@ -28,8 +28,11 @@ for view in views:
     print(f"{view}: span {span:.1f} us, {len(t)} waves, sum of durations {dur.sum() / 1e3:.1f} wave-ms")
     print("   last to finish   (start -> end, us): " + "  ".join(f"{start[i]:.0f}->{end[i]:.0f}" for i in last))
     print("   longest          (start -> end, us): " + "  ".join(f"{start[i]:.0f}->{end[i]:.0f}" for i in longest))
-    for lo, hi in ((0, 1), (1, 20), (20, 60), (60, 120), (120, 180), (180, 1e9)):
-        m = (start >= lo) & (start < hi)
+    edges = [0.0, 1.0] + [span * k / 8 for k in range(1, 9)]
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        m = (start >= lo) & (start < hi + (1e-9 if hi == span else 0))
         if m.any():
-            print(f"   started in [{lo}, {hi}) us: {m.sum():6d} waves, duration mean {dur[m].mean():6.1f} p90 {np.percentile(dur[m], 90):6.1f} max {dur[m].max():6.1f}, last end {end[m].max():6.1f}")
+            print(f"   started in [{lo:6.1f}, {hi:6.1f}) us: {m.sum():6d} waves, duration mean {dur[m].mean():6.1f} p90 {np.percentile(dur[m], 90):6.1f} max {dur[m].max():6.1f}, last end {end[m].max():6.1f}")
+    res = [np.clip(np.minimum(end, b) - np.maximum(start, a), 0, None).sum() / (b - a) for a, b in zip(np.linspace(0, span, 11)[:-1], np.linspace(0, span, 11)[1:])]
+    print("   resident waves per tenth of the span: " + " ".join(f"{x:.0f}" for x in res))
 rt.deinit()

@@ -230,6 +230,8 @@ struct vrt_ctx {
     uint32_t *d_work_counter = nullptr;    // vrt_path_kernel's pixel counters: [2 streams][kMaxBatchFrames]
     uint32_t *d_pool_paths = nullptr;      // vrt_pool_kernel's path records: [2 streams][pool_groups * 4 waves][16 dwords][128 paths]
     size_t pool_stream_dwords = 0;
+    float4 *d_pool_samples = nullptr;      // vrt_pool_kernel -> vrt_pool_resolve_kernel: [2 streams][owned pixels][samples] terms of the sample sum, sized by the frames asked for
+    size_t pool_samples_stream_elems = 0;
     uint32_t path_lds_bytes = 0;           // LDS block filter of vrt_path_kernel (0: grid not eligible)
     vrt::KernelFn kernel_single = nullptr; // specialisation for max_bounce <= 1
     vrt::KernelFn kernel_single1 = nullptr; // ... and samples_per_pixel == 1
@@ -287,6 +289,7 @@ void free_ctx(vrt_ctx *c) {
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_work_counter) (void)hipFree(c->d_work_counter);
     if (c->d_pool_paths) (void)hipFree(c->d_pool_paths);
+    if (c->d_pool_samples) (void)hipFree(c->d_pool_samples);
     if (c->d_status_blocks) (void)hipFree(c->d_status_blocks);
     if (c->d_cell_bounds) (void)hipFree(c->d_cell_bounds);
     if (c->h_cell_bounds) (void)hipHostFree(c->h_cell_bounds);
@@ -1112,9 +1115,35 @@ int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, cons
 // kernel to launch in *fn.  Runs on the primary stream.
 // vrt_pool_kernel packs a path's sample index into 16 bits and its bounce count into 4, and divides a tile's number by the tiles
 // per row with one multiplication (exact while tiles * tiles_x < 2^32); frames beyond that keep vrt_path_kernel
-static bool grid_exit_fits(vrt::KernelFn fn, const vrt_camera_device *camera, bool tiles_fit) {
+// ... and takes SAMPLES from its counter (32 bits), whose terms of the sample sum it leaves in a buffer of 16 bytes per sample and stream
+// for vrt_pool_resolve_kernel: 2 x 2 GiB for a 4K frame of 16 samples.  The buffer grows with the frames asked for (both streams idle
+// first); where it cannot be had — more than half of the free memory, or a failed allocation — the frame keeps vrt_path_kernel.
+static bool pool_samples_ready(vrt_ctx *ctx, const vrt_camera_device *camera) {
+    const uint64_t units = (uint64_t)ctx->shard.owned_tiles * 256u * (uint64_t)std::max(1, camera->samples_per_pixel);
+    if (units >= (1ull << 32)) return false;
+    if (ctx->pool_samples_stream_elems >= units) return true;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+    if (ctx->stream_b && hipStreamSynchronize(ctx->stream_b) != hipSuccess) return false;
+    if (ctx->d_pool_samples) (void)hipFree(ctx->d_pool_samples);
+    ctx->d_pool_samples = nullptr;
+    ctx->pool_samples_stream_elems = 0;
+    ctx->params.pool_samples = nullptr;
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return false;
+    const size_t bytes = 2u * (size_t)units * sizeof(float4);
+    if (bytes > mem_free / 2u) return false;
+    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_pool_samples), bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->d_pool_samples = nullptr;
+        return false;
+    }
+    ctx->pool_samples_stream_elems = (size_t)units;
+    ctx->params.pool_samples = ctx->d_pool_samples;
+    return true;
+}
+static bool grid_exit_fits(vrt_ctx *ctx, vrt::KernelFn fn, const vrt_camera_device *camera, bool tiles_fit) {
     const vrt::KernelEntry *e = vrt::kernel_entry_of(fn);
-    return !(e && e->path == 2) || (camera->samples_per_pixel <= 65535 && camera->max_bounce <= 15 && tiles_fit);
+    return !(e && e->path == 2) || (camera->max_bounce <= 15 && tiles_fit && pool_samples_ready(ctx, camera));
 }
 
 static bool pool_tiles_fit(const vrt_ctx *ctx) {
@@ -1194,7 +1223,7 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
         ctx->box_is_grid = all;
         ctx->bounds_pending = false;
     }
-    if (camera->max_bounce > 1 && ctx->box_is_grid && !ctx->d_counters && ctx->kernel_grid_exit && grid_exit_fits(ctx->kernel_grid_exit, camera, pool_tiles_fit(ctx)))
+    if (camera->max_bounce > 1 && ctx->box_is_grid && !ctx->d_counters && ctx->kernel_grid_exit && grid_exit_fits(ctx, ctx->kernel_grid_exit, camera, pool_tiles_fit(ctx)))
         *fn = ctx->kernel_grid_exit;
     return VRT_OK;
 }
@@ -1215,7 +1244,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     if (ctx->d_counters) {
         product_fn = ctx->product[(camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? 2 : 1) : 0];
         if (!product_fn) return fail(ctx, VRT_E_STATE, "no product kernel for this configuration");
-        if (camera->max_bounce > 1 && ctx->box_is_grid && ctx->product_grid_exit && grid_exit_fits(ctx->product_grid_exit, camera, pool_tiles_fit(ctx))) product_fn = ctx->product_grid_exit;
+        if (camera->max_bounce > 1 && ctx->box_is_grid && ctx->product_grid_exit && grid_exit_fits(ctx, ctx->product_grid_exit, camera, pool_tiles_fit(ctx))) product_fn = ctx->product_grid_exit;
     }
     note_kernel(ctx, product_fn ? product_fn : fn);
     // (the persistent-lane kernel takes its pixels from a counter: it neither reads the tile schedule nor reports tile costs)
@@ -1249,6 +1278,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         pb.target_rgba32f = ctx->target32f_b;
         pb.work_counter = ctx->d_work_counter + vrt::kMaxBatchFrames; // its frames run beside the primary stream's
         if (pb.pool_paths) pb.pool_paths += ctx->pool_stream_dwords;
+        if (pb.pool_samples) pb.pool_samples += ctx->pool_samples_stream_elems;
         VRT_HIP(ctx, vrt::launch_trace(fn, pb, ctx->lds_bytes, ctx->stream_b));
         if (product_fn) VRT_HIP(ctx, vrt::launch_trace(product_fn, pb, ctx->lds_bytes, ctx->stream_b));
         VRT_HIP(ctx, hipEventRecord(ctx->ev_b_done, ctx->stream_b));

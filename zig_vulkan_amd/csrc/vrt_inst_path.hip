@@ -47,5 +47,9 @@ const KernelEntry kEntries[] = {
 #endif
 };
 } // namespace
+hipError_t launch_pool_resolve(const TraceParams &p, hipStream_t stream) {
+    hipLaunchKernelGGL(vrt_pool_resolve_kernel, dim3(p.owned_tiles, 1), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
 KernelTable inst_path() { return KernelTable{kEntries, (int)(sizeof kEntries / sizeof kEntries[0])}; }
 } // namespace vrt

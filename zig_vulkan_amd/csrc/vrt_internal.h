@@ -122,6 +122,7 @@ struct TraceParams {
     // path by field, one block of 128 paths per wave of the launch; and the phase rule's four numbers
     uint32_t *pool_paths;
     uint32_t pool_cus;                   // compute units: min_waves workgroups are launched for each
+    float4 *pool_samples;                // vrt_pool_kernel -> vrt_pool_resolve_kernel: the terms of the sample loop's sum, [owned pixel][sample]
     uint32_t pool_walk_k;                // a call of the walk loop returns once this many of its lanes have parked or left
     uint32_t pool_brick_thr;             // a brick round runs once this many of the wave's 128 rays wait for one
     uint32_t pool_trans_thr;             // a round of transitions once this many wait for one

@@ -56,6 +56,8 @@ const KernelEntry *find_trace_kernel(int b, bool count, int mode, int min_waves,
 const KernelEntry *find_path_kernel(int b, int min_waves, bool filter, bool half, bool ahead = false, bool dist = false, int dil = 0);
 const KernelEntry *find_pool_kernel(int b, int min_waves = 0, int slots = 0, int stages = 0); // (0: the first in the table = the library's choice)
 const KernelEntry *kernel_entry_of(KernelFn fn);
+// vrt_pool_resolve_kernel (vrt_pool_kernel.h) over the pixels of the owned tiles, behind a vrt_pool_kernel on the same stream
+hipError_t launch_pool_resolve(const TraceParams &p, hipStream_t stream);
 int compiled_kernel_count();
 
 // vrt_pool_kernel (vrt_pool_kernel.h): per wave `slots` ray records of 21 dwords in LDS, a dword of state and one of scratch per slot;

@@ -19,8 +19,13 @@
 // the transitions only and lies in global memory (16 dwords per path, by field, wave-private: TraceParams::pool_paths), loaded and
 // stored once per transition.
 // Per ray the sequence of arithmetic operations is ray_color's / main()'s exactly as in vrt_path_kernel (the same functions are
-// called); the samples of a pixel are traced one after the other by the path that owns the pixel and summed in order: frames are
-// bit-identical.  No cross-wave communication (no barrier, no atomics but the pixel counter): a wave's LDS is its own.
+// called).  The unit of work a path takes from the counter is ONE SAMPLE of a pixel (unit = pixel * spp + sample): its term of the sample
+// loop's sum, color / (color + 1) (comp:173), goes to TraceParams::pool_samples[unit], and vrt_pool_resolve_kernel adds a pixel's terms
+// in the sample loop's order, tone-maps and stores (comp:173-177): frames are bit-identical.  (A path that owned a whole PIXEL — 16
+// samples one after the other — left the frame a drain of 11 % of its time: when the counter ran out every path still had half a pixel
+// to go, and the pools emptied for 12.6 ms of a 113 ms frame, tools/path_profile.py.  With samples as units the drain is one sample long,
+// and the 16 rays of a pixel start side by side in one wave.)
+// No cross-wave communication (no barrier, no atomics but the unit counter): a wave's LDS is its own.
 // LDS per wave: 21 x 256 B records + 256 B slot states + 256 B scratch = 5 888 B, and 4 KiB of staged bricks for a wave in a brick
 // round.  With a staging area per wave that is four 256-thread workgroups per CU (156 of the CU's 160 KiB), four waves per SIMD.
 // Measured, the kernel issues one instruction per ~11 cycles per wave whatever the wave count — a wave is one chain of dependent
@@ -66,17 +71,15 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
     const uint32_t rec_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)rec);
     const uint32_t tmp_lds = rec_lds + (kPoolRecDwords + 1u) * S * 4u;
     uint32_t *const tmp = sstate + S;
-    if constexpr (STAGES < 4) {
-        if (threadIdx.x < 16u) locks[threadIdx.x] = 0u;
-        __syncthreads();
-    }
+    if (threadIdx.x < 16u) locks[threadIdx.x] = 0u; // (staging locks free; every wave's chunk empty, the counter not yet run out)
+    __syncthreads();
     uint32_t *const path = p.pool_paths + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave) * (size_t)(kPoolPaths * kPoolPathDwords);
 
     const PushConstants &pc = p.pcs[blockIdx.y];
-    const uint32_t total = p.owned_tiles * (uint32_t)(kTileW * kTileH);
+    const uint32_t uspp = (uint32_t)max(1, pc.cam.samples_per_pixel);
+    const uint32_t total = p.owned_tiles * (uint32_t)(kTileW * kTileH) * uspp; // units: samples (vrt_api.hip keeps this below 2^32)
     uint32_t *const counter = p.work_counter + blockIdx.y;
     const bool sun_enabled = pc.sun.enabled > 0;
-    const int spp = pc.cam.samples_per_pixel;
     const int max_bounce = pc.cam.max_bounce;
     const float t_max = __builtin_inff();
     const f3 g_min = mk3(p.grid.min_point_base_t[0], p.grid.min_point_base_t[1], p.grid.min_point_base_t[2]);
@@ -174,12 +177,17 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
         __builtin_amdgcn_wave_barrier();
     };
 
-    bool work_left = true; // wave-uniform
+    // the wave's chunk of units: [next, end) and "the counter has run out", in three of the workgroup's spare lock words — the lanes
+    // that make a round of transitions are not the lanes that made the last one, so the state cannot live in their registers
+    constexpr uint32_t kPoolChunk = 256u;
+    uint32_t *const chunk = locks + 4u + wave * 3u;
 #ifdef VRT_DEV_PROFILE
     if (threadIdx.x < 8) vrt_prof[threadIdx.x] = 0ull;
     __syncthreads();
     unsigned long long pf_t[3] = {0ull, 0ull, 0ull};
     unsigned long long pf_n[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    const unsigned long long pf_begin = wall_clock64();
+    unsigned long long pf_dry = 0ull; // when this wave first found the pixel counter exhausted
 #define VRT_PF_T(k, t0) pf_t[k] += __builtin_readcyclecounter() - (t0)
 #define VRT_PF_N(k, v) pf_n[k] += (unsigned long long)(v)
 #define VRT_PF_NOW() __builtin_readcyclecounter()
@@ -237,15 +245,13 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 uint32_t *const pr = path + ps;
                 // the path: pixel, sample index, the sample sum (comp:173), RayColor's locals (comp:203-216) and what it keeps while the
                 // shadow ray is walked (comp:221-239)
-                uint32_t work = pr[0];
+                uint32_t work = pr[0]; // the path's unit: pixel * spp + sample
                 uint32_t pf = pr[128];
-                f3 acc = mk3(u2f(pr[2 * 128]), u2f(pr[3 * 128]), u2f(pr[4 * 128]));
                 f3 color = mk3(u2f(pr[5 * 128]), u2f(pr[6 * 128]), u2f(pr[7 * 128]));
                 float cur_dir_y = u2f(pr[8 * 128]);
                 f3 sc_dir = mk3(u2f(pr[9 * 128]), u2f(pr[10 * 128]), u2f(pr[11 * 128]));
                 float sc_ir = u2f(pr[12 * 128]);
                 f3 attenuation = mk3(u2f(pr[13 * 128]), u2f(pr[14 * 128]), u2f(pr[15 * 128]));
-                int sample_i = (int)(pf & 0xFFFFu);
                 int loop_count = (int)((pf >> 16) & 15u);
                 int kind = (int)((pf >> 20) & 1u);
                 bool scattered_ok = ((pf >> 21) & 1u) != 0u;
@@ -332,57 +338,58 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                         const f3 bg = fma3(splat3(1.0f - t), splat3(1.0f), mk3(0.5f, 0.7f, 1.0f) * t);
                         color = color + bg * (sun_enabled ? sun_color : splat3(1.0f));
                     }
-                    acc = acc + color / (color + splat3(1.0f));
-                    sample_i += 1;
-                    ls = (sample_i < spp) ? kLaneSample : kLaneStore;
-                }
-                // (3) the pixel is finished: comp:176-177
-                if (ls == kLaneStore) {
-                    const uint32_t owned = p.owned_tiles - 1u - (work >> 8);
-                    const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
-                    const uint32_t j = work & 255u;
-                    const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
-                    const uint32_t tile_y = tile_row(tile), tile_x = tile - tile_y * p.tiles_x;
-                    const uint32_t px = tile_x * kTileW + in_x, py = tile_y * kTileH + in_y;
-                    const float fspp = (float)spp;
-                    const f3 c = mk3(__builtin_sqrtf(acc.x / fspp), __builtin_sqrtf(acc.y / fspp), __builtin_sqrtf(acc.z / fspp));
-                    const size_t o = (p.shard_count > 1u || p.packed_tiles) ? (size_t)owned * (kTileW * kTileH) + in_y * kTileW + in_x : (size_t)py * p.width + px;
-                    reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] =
-                        unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
-                    if (p.target_rgba32f) reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(c.x, c.y, c.z, 1.0f);
+                    // (3) the sample's term of the sum; the pixel is finished by vrt_pool_resolve_kernel (comp:173-177)
+                    const f3 term = color / (color + splat3(1.0f));
+                    p.pool_samples[work] = make_float4(term.x, term.y, term.z, 0.0f);
                     ls = kLaneFetch;
                 }
-                // (4) next pixel: one atomic per wave for all the lanes that ask
+                // (4) next unit, from the wave's chunk of kPoolChunk consecutive units; one atomic per chunk (one per round of
+                // transitions, 90 M a second on one address, made every transition wait for the counter: the frame from outside the
+                // field 34 -> 46 ms).  A lane that asks where the chunk ends and the next has not come yet asks again next round.
                 {
                     const unsigned long long asking = __builtin_amdgcn_ballot_w64(ls == kLaneFetch);
                     if (asking != 0ull) {
+                        uint32_t chunk_next = chunk[0], chunk_end = chunk[1];
+                        bool more_chunks = chunk[2] == 0u;
+                        bool work_left = more_chunks || chunk_next < chunk_end;
                         if (work_left) {
-                            const uint32_t n = (uint32_t)__builtin_popcountll(asking);
-                            uint32_t first = 0u;
-                            if (lane == (uint32_t)__builtin_ctzll(asking)) first = atomicAdd(counter, n);
-                            first = (uint32_t)__builtin_amdgcn_readlane((int)first, __builtin_ctzll(asking));
-                            if (ls == kLaneFetch) {
-                                const uint32_t mine = first + pool_mbcnt(asking);
-                                if (mine < total) {
-                                    work = mine;
-                                    sample_i = 0;
-                                    acc = mk3(0, 0, 0);
-                                    ls = kLaneSample;
-                                } else {
-                                    ls = kLaneExit;
-                                }
+                            const uint32_t n = (uint32_t)__builtin_popcountll(asking), rank = pool_mbcnt(asking);
+                            const uint32_t take = min(chunk_end - chunk_next, n);
+                            if (ls == kLaneFetch && rank < take) {
+                                work = chunk_next + rank;
+                                ls = kLaneSample;
                             }
-                            work_left = first + n < total;
-                        } else if (ls == kLaneFetch) {
-                            ls = kLaneExit;
+                            chunk_next += take;
+                            if (take < n && more_chunks) {
+                                uint32_t first = 0u;
+                                if (lane == (uint32_t)__builtin_ctzll(asking)) first = atomicAdd(counter, kPoolChunk);
+                                first = (uint32_t)__builtin_amdgcn_readlane((int)first, __builtin_ctzll(asking));
+                                more_chunks = first < total;
+                                chunk_next = more_chunks ? first : 0u;
+                                chunk_end = more_chunks ? min(first + kPoolChunk, total) : 0u;
+                                const uint32_t take2 = min(chunk_end - chunk_next, n - take);
+                                if (ls == kLaneFetch && rank >= take && rank - take < take2) {
+                                    work = chunk_next + (rank - take);
+                                    ls = kLaneSample;
+                                }
+                                chunk_next += take2;
+                            }
+                            work_left = more_chunks || chunk_next < chunk_end;
+                            if (lane == (uint32_t)__builtin_ctzll(asking)) chunk[0] = chunk_next, chunk[1] = chunk_end, chunk[2] = more_chunks ? 0u : 1u;
+#ifdef VRT_DEV_PROFILE
+                            if (!work_left && pf_dry == 0ull) pf_dry = wall_clock64();
+#endif
                         }
+                        if (!work_left && ls == kLaneFetch) ls = kLaneExit;
                     }
                 }
-                // (5) next sample of the pixel: comp:162-171
+                // (5) the unit's sample of its pixel: comp:162-171
                 if (ls == kLaneSample) {
-                    const uint32_t owned = p.owned_tiles - 1u - (work >> 8);
+                    const uint32_t pixel = work / uspp;
+                    const int sample_i = (int)(work - pixel * uspp);
+                    const uint32_t owned = p.owned_tiles - 1u - (pixel >> 8);
                     const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
-                    const uint32_t j = work & 255u;
+                    const uint32_t j = pixel & 255u;
                     const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
                     const uint32_t tile_y = tile_row(tile), tile_x = tile - tile_y * p.tiles_x;
                     const uint32_t px = tile_x * kTileW + in_x, py = tile_y * kTileH + in_y;
@@ -460,8 +467,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 }
                 st = nst;
                 pr[0] = work;
-                pr[128] = ((uint32_t)sample_i & 0xFFFFu) | (((uint32_t)loop_count & 15u) << 16) | ((uint32_t)kind << 20) | ((scattered_ok ? 1u : 0u) << 21) | ((sc_ignore & 3u) << 22);
-                pr[2 * 128] = f2u(acc.x), pr[3 * 128] = f2u(acc.y), pr[4 * 128] = f2u(acc.z);
+                pr[128] = (((uint32_t)loop_count & 15u) << 16) | ((uint32_t)kind << 20) | ((scattered_ok ? 1u : 0u) << 21) | ((sc_ignore & 3u) << 22);
                 pr[5 * 128] = f2u(color.x), pr[6 * 128] = f2u(color.y), pr[7 * 128] = f2u(color.z);
                 pr[8 * 128] = f2u(cur_dir_y);
                 pr[9 * 128] = f2u(sc_dir.x), pr[10 * 128] = f2u(sc_dir.y), pr[11 * 128] = f2u(sc_dir.z);
@@ -595,6 +601,11 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
         for (int k = 0; k < 3; k++) atomicAdd(&p.wave_timeline[k], pf_t[k]);
         for (int k = 0; k < 8; k++) atomicAdd(&p.wave_timeline[3 + k], pf_n[k]);
         atomicAdd(&p.wave_timeline[11], 1ull);
+        // the frame's drain: first wave to find the counter exhausted, last wave to end (100 MHz ticks, stored complemented where a minimum is wanted)
+        atomicMax(&p.wave_timeline[20], ~pf_begin);
+        if (pf_dry) atomicMax(&p.wave_timeline[21], ~pf_dry);
+        if (pf_dry) atomicMax(&p.wave_timeline[23], pf_dry);
+        atomicMax(&p.wave_timeline[22], wall_clock64());
     }
     __syncthreads();
     if (p.wave_timeline && threadIdx.x < 8) atomicAdd(&p.wave_timeline[12 + threadIdx.x], vrt_prof[threadIdx.x]);
@@ -602,6 +613,34 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
 #undef VRT_PF_T
 #undef VRT_PF_N
 #undef VRT_PF_NOW
+}
+
+// comp:173-177 for the frames vrt_pool_kernel traced: one thread per pixel of the owned tiles adds the pixel's terms
+// (TraceParams::pool_samples) in the sample loop's order, tone-maps and stores.  HBM-bound: 16 B per sample read, 4 (+ 16) B per pixel
+// written; 2 GiB for a 4K frame of 16 samples, 0.5 ms.
+__global__ __launch_bounds__(256) void vrt_pool_resolve_kernel(const TraceParams p) {
+    const PushConstants &pc = p.pcs[blockIdx.y];
+    const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
+    if (pixel >= p.owned_tiles * (uint32_t)(kTileW * kTileH)) return;
+    const uint32_t spp = (uint32_t)max(1, pc.cam.samples_per_pixel);
+    const uint32_t owned = p.owned_tiles - 1u - (pixel >> 8);
+    const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
+    const uint32_t j = pixel & 255u;
+    const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
+    const uint32_t tile_y = tile / p.tiles_x, tile_x = tile - tile_y * p.tiles_x;
+    const uint32_t px = tile_x * kTileW + in_x, py = tile_y * kTileH + in_y;
+    if (px >= p.width || py >= p.height) return; // comp:155-159
+    const float4 *s = p.pool_samples + (size_t)pixel * spp;
+    f3 acc = mk3(0, 0, 0);
+    for (uint32_t k = 0; k < spp; k++) {
+        const float4 t = s[k];
+        acc = acc + mk3(t.x, t.y, t.z);
+    }
+    const float fspp = (float)pc.cam.samples_per_pixel;
+    const f3 c = mk3(__builtin_sqrtf(acc.x / fspp), __builtin_sqrtf(acc.y / fspp), __builtin_sqrtf(acc.z / fspp));
+    const size_t o = (p.shard_count > 1u || p.packed_tiles) ? (size_t)owned * (kTileW * kTileH) + in_y * kTileW + in_x : (size_t)py * p.width + px;
+    reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
+    if (p.target_rgba32f) reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(c.x, c.y, c.z, 1.0f);
 }
 
 } // namespace vrt

@@ -580,14 +580,17 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
     if (p.owned_tiles == 0 || frames == 0) return hipSuccess;
     if (const KernelEntry *pe = kernel_entry_of(fn); pe && pe->path == 2) {
         // a pool of rays per wave (vrt_pool_kernel.h): as many workgroups as the GPU holds, or as the frame has pixels for
-        if (!p.work_counter || !p.pool_paths || frames != 1u) return hipErrorInvalidValue;
+        if (!p.work_counter || !p.pool_paths || !p.pool_samples || frames != 1u) return hipErrorInvalidValue;
         hipError_t e = hipMemsetAsync(p.work_counter, 0, kMaxBatchFrames * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
-        const uint32_t per_group = 4u * (64u + pe->pool_slots), fit = (p.owned_tiles * 256u + per_group - 1u) / per_group;
+        // (units of work: samples; a frame with fewer of them than the GPU holds paths launches fewer workgroups)
+        const uint64_t units = (uint64_t)p.owned_tiles * 256u * (uint64_t)(p.pcs[0].cam.samples_per_pixel > 0 ? p.pcs[0].cam.samples_per_pixel : 1);
+        const uint32_t per_group = 4u * (64u + pe->pool_slots), fit = (uint32_t)std::min<uint64_t>((units + per_group - 1u) / per_group, 1u << 30);
         const uint32_t hold = p.pool_cus * pe->min_waves; // (min_waves 256-thread workgroups per CU)
         const uint32_t groups = fit < hold ? (fit ? fit : 1u) : hold;
         hipLaunchKernelGGL(fn, dim3(groups, 1), dim3(256), pool_group_lds_bytes(pe->pool_slots, pe->pool_stages), stream, p);
-        return hipGetLastError();
+        e = hipGetLastError();
+        return e != hipSuccess ? e : launch_pool_resolve(p, stream);
     }
     if (is_path_kernel(fn)) {
         // persistent lanes: as many workgroups as the GPU holds a few times over; they take pixels from p.work_counter
