@@ -179,7 +179,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
 
     // the wave's chunk of units: [next, end) and "the counter has run out", in three of the workgroup's spare lock words — the lanes
     // that make a round of transitions are not the lanes that made the last one, so the state cannot live in their registers
-    constexpr uint32_t kPoolChunk = 256u;
+#ifndef VRT_POOL_CHUNK
+#define VRT_POOL_CHUNK 512u /* 64 / 128 / 256 / 512 / 1024: 2048^3 path trace 92.7 / 92.3 / 92.3 / 92.3 / 93.6 ms, from outside the field 33.6 / 26.8 / 24.5 / 23.6 / 24.3 */
+#endif
+    constexpr uint32_t kPoolChunk = VRT_POOL_CHUNK;
     uint32_t *const chunk = locks + 4u + wave * 3u;
 #ifdef VRT_DEV_PROFILE
     if (threadIdx.x < 8) vrt_prof[threadIdx.x] = 0ull;
