@@ -795,3 +795,33 @@ def test_pool_kernel_shards_two_frames_in_flight_and_frames_smaller_than_a_wave(
         rt.deinit()
         fo, uo, _ = O.render(oracle_scene_from_grid(grid), pc)
         assert np.array_equal(f.view(np.uint32), fo.view(np.uint32)) and np.array_equal(u, uo), (width, height, spp, bounce)
+
+
+def test_pool_kernel_sample_buffer_follows_the_sample_count():
+    """vrt_pool_kernel takes SAMPLES from its counter and leaves their terms of the sample sum to vrt_pool_resolve_kernel in a buffer
+    sized by the frames asked for: one context, two frames in flight, the sample count going 2 -> 16 -> 3 -> 1 -> 5 between frames (the
+    buffer grows behind both streams); every frame equals vrt_path_kernel's, which sums a pixel's samples in its own lane."""
+    w = W.Workload("t", 208, 112, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000)
+    grid = W.build_grid(w)
+    seq = [("V0", 2), ("V2", 16), ("V2", 16), ("V1x", 3), ("V0", 1), ("V2", 5), ("V0", 5)]
+
+    def frames(**kw):
+        rt = W.make_renderer(w, grid, kernel_variant=PATH, **kw)
+        W.set_view(rt, "V0")
+        rt.draw()
+        rt.wait()      # (the box of the occupied cells has reached the host)
+        out, names = [], set()
+        for v, spp in seq:
+            W.set_view(rt, v)
+            rt.camera.d_camera.samples_per_pixel = spp
+            rt.draw()
+            out.append(rt.read_rgba8().copy())
+            names.add(rt.kernel_name().split("<")[0])
+        rt.deinit()
+        return out, names
+
+    pool, n_pool = frames(frames_in_flight=2)
+    path, n_path = frames(tuning_flags=L.TUNE_NO_PATH_POOL)
+    assert n_pool == {"vrt_pool_kernel"} and n_path == {"vrt_path_kernel"}, (n_pool, n_path)
+    for (v, spp), a, b in zip(seq, pool, path):
+        assert np.array_equal(a, b) and a.any(), (v, spp)

@@ -23,7 +23,7 @@ bw = raw[12:20]
 ms = rt.last_kernel_ms()
 rc.draw(); c = rc.counters()
 t_trans, t_walk, t_brick = pr[0:3]
-n_tr, n_wait, n_calls, n_alive_in, n_alive_out, n_brick, n_parked, _, waves = pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10], pr[11]
+n_tr, n_wait, n_calls, n_alive_in, n_alive_out, n_brick, n_parked, n_nostage, waves = pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10], pr[11]
 tot = t_trans + t_walk + t_brick
 print(f"{w.name} {view} variant {variant:#x} {kernel}: {ms:.2f} ms, {int(waves)} waves, rays {c['rays']/1e6:.1f}M, grid steps/ray {c['grid_steps']/c['rays']:.1f}, bricks/ray {c['bricks_entered']/c['rays']:.2f}, "
       f"voxel steps/ray {c['voxel_steps']/c['rays']:.1f}")
@@ -41,6 +41,7 @@ if "pool" in kernel and len(raw) > 23 and raw[22]:
     print(f"  drain: kernel {span / 1e3:.2f} ms by the wall clock; the first wave finds the pixel counter exhausted at {100 * (first_dry - begin) / (end - begin):.1f} % of it, "
           f"the last at {100 * (last_dry - begin) / (end - begin):.1f} %; the last wave ends {(end - first_dry) / 100.0 / 1e3:.2f} ms after the counter ran out")
 if "pool" in kernel:
+    print(f"  brick rounds that found both staging areas of the workgroup taken (the wave served another queue): {n_nostage/1e6:.2f} M against {n_brick/1e6:.2f} M rounds run")
     print(f"  vrt_pool_kernel (wave-cycles, share of all): phase rule {100*bw[3]/tot:.1f} %, exchange before a walk call {100*bw[0]/tot:.1f} % ({bw[0]/n_calls:.0f} cycles per call), "
           f"the walk loop itself {100*bw[1]/tot:.1f} % ({bw[1]/n_calls:.0f} cycles per call), exchange before a brick round {100*bw[6]/tot:.1f} % ({bw[6]/n_brick:.0f} per round), "
           f"before a transition round {100*bw[7]/tot:.1f} % ({bw[7]/n_tr:.0f} per round)")

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                         if (atomicCAS(&locks[i], 0u, 1u) == 0u) stage = i;
                 }
                 stage = __builtin_amdgcn_readfirstlane(stage);
+                VRT_PF_N(7, stage < 0 ? 1 : 0);
                 if (stage < 0) phase = n_walk != 0u ? 1u : (n_trans != 0u ? 0u : 3u);
             }
         }
