@@ -1120,7 +1120,7 @@ int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, cons
 // first); where it cannot be had — more than half of the free memory, or a failed allocation — the frame keeps vrt_path_kernel.
 static bool pool_samples_ready(vrt_ctx *ctx, const vrt_camera_device *camera) {
     const uint64_t units = (uint64_t)ctx->shard.owned_tiles * 256u * (uint64_t)std::max(1, camera->samples_per_pixel);
-    if (units >= (1ull << 32)) return false;
+    if (units >= (1ull << 32) - (1ull << 26)) return false; // (the counter keeps counting, a chunk per wave, after it has run out)
     if (ctx->pool_samples_stream_elems >= units) return true;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
     if (ctx->stream_b && hipStreamSynchronize(ctx->stream_b) != hipSuccess) return false;

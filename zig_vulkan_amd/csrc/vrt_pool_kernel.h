@@ -343,8 +343,11 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                         color = color + bg * (sun_enabled ? sun_color : splat3(1.0f));
                     }
                     // (3) the sample's term of the sum; the pixel is finished by vrt_pool_resolve_kernel (comp:173-177)
+                    // (stored by groups of 64 pixels, sample-major inside a group: the resolve pass then reads whole lines — by unit it
+                    // read 64 lines per instruction for 64 pixels, 1.9 ms per 4K frame of 16 samples instead of 0.5)
                     const f3 term = color / (color + splat3(1.0f));
-                    p.pool_samples[work] = make_float4(term.x, term.y, term.z, 0.0f);
+                    const uint32_t tpx = work / uspp, tk = work - tpx * uspp;
+                    p.pool_samples[((size_t)(tpx >> 6) * uspp + tk) * 64u + (tpx & 63u)] = make_float4(term.x, term.y, term.z, 0.0f);
                     ls = kLaneFetch;
                 }
                 // (4) next unit, from the wave's chunk of kPoolChunk consecutive units; one atomic per chunk (one per round of
@@ -634,10 +637,10 @@ __global__ __launch_bounds__(256) void vrt_pool_resolve_kernel(const TraceParams
     const uint32_t tile_y = tile / p.tiles_x, tile_x = tile - tile_y * p.tiles_x;
     const uint32_t px = tile_x * kTileW + in_x, py = tile_y * kTileH + in_y;
     if (px >= p.width || py >= p.height) return; // comp:155-159
-    const float4 *s = p.pool_samples + (size_t)pixel * spp;
+    const float4 *s = p.pool_samples + (size_t)(pixel >> 6) * spp * 64u + (pixel & 63u); // (groups of 64 pixels, sample-major inside)
     f3 acc = mk3(0, 0, 0);
     for (uint32_t k = 0; k < spp; k++) {
-        const float4 t = s[k];
+        const float4 t = s[(size_t)k * 64u];
         acc = acc + mk3(t.x, t.y, t.z);
     }
     const float fspp = (float)pc.cam.samples_per_pixel;
