@@ -825,3 +825,30 @@ def test_pool_kernel_sample_buffer_follows_the_sample_count():
     assert n_pool == {"vrt_pool_kernel"} and n_path == {"vrt_path_kernel"}, (n_pool, n_path)
     for (v, spp), a, b in zip(seq, pool, path):
         assert np.array_equal(a, b) and a.any(), (v, spp)
+
+
+def test_bounce_frames_as_one_wave_workgroups_keep_the_frame():
+    """The lockstep bounce kernel is launched as one-wave workgroups (round 4: a tile's four waves end at different times, and a 256-thread
+    workgroup waits for four free slots of one CU): the reference app's shape at a size whose tiles the cost schedule splits, two and three
+    samples per pixel, an odd frame, two frames in flight — the same bytes as with a 256-thread workgroup per tile
+    (VRT_TUNE_NO_BOUNCE_WAVE_GROUPS), and the oracle's on the last view."""
+    from zig_vulkan_amd import _lib as L
+    for w, fif in ((W.Workload("app_like", 509, 283, 256, 4, 2, 2, True, 5.0), 1), (W.Workload("app_like_3spp", 320, 200, 128, 8, 3, 2, True, 5.0), 2)):
+        grid = W.build_grid(w)
+        frames = {}
+        for flags in (0, L.TUNE_NO_BOUNCE_WAVE_GROUPS):
+            rt = W.make_renderer(w, grid, tuning_flags=flags, want_float_output=True, frames_in_flight=fif, kernel_variant=1 << 21)   # (lockstep)
+            for v in ("V0", "V2", "V1"):
+                W.set_view(rt, v)
+                for _ in range(40):   # (past a sort of the cost schedule: split tiles, half-tile waves, the second sample on the idle lanes)
+                    rt.draw()
+                frames[(flags, v)] = (rt.read_rgba32f().copy(), rt.read_rgba8().copy())
+            assert rt.kernel_name().startswith("vrt_trace_kernel<"), rt.kernel_name()
+            if flags == 0:
+                pc = O.push_constants(rt.camera.blob(), rt.sun.blob())   # (view V1)
+            rt.deinit()
+        for v in ("V0", "V2", "V1"):
+            assert np.array_equal(frames[(0, v)][0].view(np.uint32), frames[(L.TUNE_NO_BOUNCE_WAVE_GROUPS, v)][0].view(np.uint32)), (w.name, v)
+            assert np.array_equal(frames[(0, v)][1], frames[(L.TUNE_NO_BOUNCE_WAVE_GROUPS, v)][1]), (w.name, v)
+        fo, uo, _ = O.render(oracle_scene_from_grid(grid), pc)
+        assert np.array_equal(frames[(0, "V1")][0].view(np.uint32), fo.view(np.uint32)) and np.array_equal(frames[(0, "V1")][1], uo), w.name

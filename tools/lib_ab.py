@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-box, same-process A/B of two builds of libvrt_hip on one workload: two contexts over the same grid, alternating frames,
 HIP-event kernel time (min and all), frames compared bit for bit.
-usage: lib_ab.py <libA.so> <libB.so> [workload] [view ...]        env: AB_REPS (3), AB_FLAGS_A / AB_FLAGS_B (tuning flags)"""
+usage: lib_ab.py <libA.so> <libB.so> [workload] [view ...]        env: AB_REPS (3), AB_FLAGS_A / AB_FLAGS_B (tuning flags), AB_VARIANT_A / AB_VARIANT_B (kernel_variant)"""
 import hashlib
 import os
 import sys
@@ -14,8 +14,8 @@ name = sys.argv[3] if len(sys.argv) > 3 else "cfg4_4k_2048c_b8_sparse"
 views = sys.argv[4:] or ["V0"]
 w = W.WORKLOADS[name]
 grid = W.build_grid(w)
-a = W.make_renderer(w, grid, library=la, tuning_flags=int(os.environ.get("AB_FLAGS_A", "0"), 0))
-b = W.make_renderer(w, grid, library=lb, tuning_flags=int(os.environ.get("AB_FLAGS_B", "0"), 0))
+a = W.make_renderer(w, grid, library=la, tuning_flags=int(os.environ.get("AB_FLAGS_A", "0"), 0), kernel_variant=int(os.environ.get("AB_VARIANT_A", "0"), 0))
+b = W.make_renderer(w, grid, library=lb, tuning_flags=int(os.environ.get("AB_FLAGS_B", "0"), 0), kernel_variant=int(os.environ.get("AB_VARIANT_B", "0"), 0))
 reps = int(os.environ.get("AB_REPS", "3"))
 for v in views:
     for rt in (a, b):

@@ -682,7 +682,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         c->order_auto = (order == 0u);
         if (order == 0u) order = (n > 6u * (uint32_t)cus && n <= 64u * (uint32_t)cus) ? 7u : 3u;
         c->tile_order = order;
-        const bool plain_tiles = !((cfg->kernel_variant >> 20) & 0x1u) && (vrt::resolve_variant(cfg->kernel_variant) & 0xFFu) != vrt::kVariantLinearLds512;
+        const bool plain_tiles = (vrt::resolve_variant(cfg->kernel_variant) & 0xFFu) != vrt::kVariantLinearLds512;
         // spare entries: one per tile (the list's layout); a sort may use min(1024, n / 8) of them — or all, with a lower bar, for
         // frames of two samples per pixel (measured on the reference app's run, same box, V0 / V1 / V2: 0.336 / 0.340 / 0.364 ms with
         // n / 8 and a bar of 1.25 x the frame's wave-cycles over 24 slots per CU; 0.294 / 0.306 / 0.330 with every tile eligible
@@ -1003,6 +1003,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.tile_cost = c->d_tile_cost;
     p.tile_schedule = c->d_tile_schedule;
     p.wave_groups = (cfg->kernel_variant >> 20) & 0x1u;
+    p.wave_groups_bounce = (cfg->tuning_flags & VRT_TUNE_NO_BOUNCE_WAVE_GROUPS) ? 0u : 1u;
     {
         // small frames (configs[0], 256 tiles = one wave per SIMD, lasts as long as its slowest wave's chain): when the
         // frame's waves do not fill the SIMDs twice, every tile goes to two workgroups of 32-lane waves
@@ -1119,7 +1120,8 @@ int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, cons
 // for vrt_pool_resolve_kernel: 2 x 2 GiB for a 4K frame of 16 samples.  The buffer grows with the frames asked for (both streams idle
 // first); where it cannot be had — more than half of the free memory, or a failed allocation — the frame keeps vrt_path_kernel.
 static bool pool_samples_ready(vrt_ctx *ctx, const vrt_camera_device *camera) {
-    const uint64_t units = (uint64_t)ctx->shard.owned_tiles * 256u * (uint64_t)std::max(1, camera->samples_per_pixel);
+    if (camera->samples_per_pixel < 1) return false; // (a frame of no samples is not a frame of units)
+    const uint64_t units = (uint64_t)ctx->shard.owned_tiles * 256u * (uint64_t)camera->samples_per_pixel;
     if (units >= (1ull << 32) - (1ull << 26)) return false; // (the counter keeps counting, a chunk per wave, after it has run out)
     if (ctx->pool_samples_stream_elems >= units) return true;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;

@@ -128,6 +128,7 @@ struct TraceParams {
     uint32_t pool_trans_thr;             // a round of transitions once this many wait for one
     uint32_t pool_walk_min;              // below this many rays to walk the fuller of the two other queues is served first
     uint32_t pool_tiles_x_magic;         // 2^32 / tiles_x + 1 (0: tiles_x == 1): tile / tiles_x as one multiplication (exact while tiles * tiles_x < 2^32)
+    uint32_t wave_groups_bounce;         // 1: the lockstep bounce kernel is launched as one-wave workgroups (launch_trace; round 4)
     uint32_t split_all;                  // vrt_trace_kernel, tile_order 3: log2 of the workgroups per tile (0: one; small frames: 1 or 2)
     uint32_t count_box;                  // counting build only: 1 = walk to the occupied-cell box like the product kernel (issued loads)
     uint32_t skip_to_box;                // 1: rays that enter the grid in front of the occupied-cell box jump to its near face (skip_to_box())

@@ -604,10 +604,21 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
         hipLaunchKernelGGL(fn, dim3(groups, frames), dim3(threads), (filter ? p.path_lds_bytes : 0u) + (p.path_brick_lds ? (threads >> 6) * 4096u : 0u), stream, p);
         return hipGetLastError();
     }
+    // The lockstep bounce kernel holds four waves per SIMD, sixteen per CU, and the four waves of a tile end at different times: a
+    // 256-thread workgroup waits until four slots of one CU are free — a fifth of the slots stood empty through the body of the reference
+    // app's frames (tools/timeline_tail.py).  As one-wave workgroups every wave that ends is replaced at once: the app's run V0 / V1 / V2 /
+    // all-ground -2 / -5.5 / -5 / -9.5 %, same box.  (The one-sample kernels at seven waves per SIMD: -4 ... +1 %, not taken.)
+    if (const KernelEntry *te = kernel_entry_of(fn); te && te->path == 0 && te->shade == 0 && !te->count && p.wave_groups_bounce && !p.wave_groups &&
+                                                       p.block_threads != 512u && !p.split_all && !p.packed_rgb) {
+        TraceParams q = p;
+        q.wave_groups = 1u;
+        hipLaunchKernelGGL(fn, dim3((q.owned_tiles + (q.tile_order == 5u ? q.sched_units : 0u)) * 4u, frames), dim3(64), lds_bytes, stream, q);
+        return hipGetLastError();
+    }
     // grid.y = the frames of this launch (p.pcs[0 .. frames-1]); workgroups are dispatched x-fastest, so the tiles of
     // frame 0 start first
     if (p.block_threads == 512u) hipLaunchKernelGGL(fn, dim3((p.owned_tiles + 1u) / 2u, frames), dim3(512), lds_bytes, stream, p);
-    else if (p.wave_groups) hipLaunchKernelGGL(fn, dim3(p.owned_tiles * 4u, frames), dim3(64), lds_bytes, stream, p);
+    else if (p.wave_groups) hipLaunchKernelGGL(fn, dim3((p.owned_tiles + (p.tile_order == 5u ? p.sched_units : 0u)) * 4u, frames), dim3(64), lds_bytes, stream, p);
     else if (p.tile_order == 3u && p.split_all) hipLaunchKernelGGL(fn, dim3(p.owned_tiles << p.split_all, frames), dim3(256), lds_bytes, stream, p);
     else hipLaunchKernelGGL(fn, dim3(p.owned_tiles + (p.tile_order == 5u ? p.sched_units : 0u), frames), dim3(256), lds_bytes, stream, p);
     return hipGetLastError();
