@@ -198,6 +198,10 @@ pub const TUNE_NO_PATH_DILATED: u32 = 1 << 9;
 pub const TUNE_NO_PATH_GRID_EXIT: u32 = 1 << 10;
 pub const TUNE_PATH_BLOCKS64: u32 = 1 << 11;
 pub const TUNE_PATH_TWO_AHEAD: u32 = 1 << 12;
+pub const TUNE_NO_PATH_POOL: u32 = 1 << 13;
+pub const TUNE_NO_SMALL_FRAME_SPLIT: u32 = 1 << 14;
+pub const TUNE_NO_BOUNCE_WAVE_GROUPS: u32 = 1 << 15;
+pub const TUNE_NO_SAMPLE_UNITS: u32 = 1 << 16;
 
 pub const GridConfig = extern struct { // Grid.zig:13-20
     brick_alloc: u64 = 0,

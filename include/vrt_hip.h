@@ -161,7 +161,8 @@ typedef struct vrt_config {
 #define VRT_TUNE_NO_PATH_POOL         (1u << 13) /* frames with bounces on scenes larger than the caches: vrt_path_kernel (a ray per lane) instead of vrt_pool_kernel (a pool of 128 rays per wave; round 4) */
 #define VRT_TUNE_NO_SMALL_FRAME_SPLIT (1u << 14) /* frames with fewer waves than twice the SIMDs: one 256-thread workgroup per 16x16 tile as for large frames (instead of two with 32-lane waves) */
 #define VRT_TUNE_NO_BOUNCE_WAVE_GROUPS (1u << 15) /* the lockstep bounce kernel as 256-thread workgroups (a tile each) instead of one-wave workgroups */
-#define VRT_TUNE_ALL                0xFFFFu
+#define VRT_TUNE_NO_SAMPLE_UNITS     (1u << 16) /* frames with bounces on scenes larger than the caches: a path takes whole pixels from the counter and sums their samples itself (vrt_path_kernel; vrt_pool_kernel is not chosen), instead of single samples whose terms vrt_pool_resolve_kernel adds */
+#define VRT_TUNE_ALL                0x1FFFFu
 
 typedef struct vrt_ctx vrt_ctx;
 

@@ -821,10 +821,11 @@ def test_pool_kernel_sample_buffer_follows_the_sample_count():
         return out, names
 
     pool, n_pool = frames(frames_in_flight=2)
-    path, n_path = frames(tuning_flags=L.TUNE_NO_PATH_POOL)
-    assert n_pool == {"vrt_pool_kernel"} and n_path == {"vrt_path_kernel"}, (n_pool, n_path)
-    for (v, spp), a, b in zip(seq, pool, path):
-        assert np.array_equal(a, b) and a.any(), (v, spp)
+    path, n_path = frames(tuning_flags=L.TUNE_NO_PATH_POOL, frames_in_flight=2)     # (vrt_path_kernel, samples as units as well)
+    pixels, n_pixels = frames(tuning_flags=L.TUNE_NO_SAMPLE_UNITS)                  # (vrt_path_kernel, a pixel per lane: the sum in its lane)
+    assert n_pool == {"vrt_pool_kernel"} and n_path == {"vrt_path_kernel"} and n_pixels == {"vrt_path_kernel"}, (n_pool, n_path, n_pixels)
+    for (v, spp), a, b, c in zip(seq, pool, path, pixels):
+        assert np.array_equal(a, c) and np.array_equal(b, c) and a.any(), (v, spp)
 
 
 def test_bounce_frames_as_one_wave_workgroups_keep_the_frame():

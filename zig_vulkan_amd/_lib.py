@@ -38,6 +38,7 @@ TUNE_NO_SKIP_TO_BOX, TUNE_NO_PATH_BRICK_LDS, TUNE_NO_PATH_HALFBLOCKS, TUNE_PATH_
 TUNE_NO_CELL_OCCUPANCY, TUNE_NO_START_SHORTCUT, TUNE_PATH_AHEAD, TUNE_PATH_DISTANCE, TUNE_NO_PATH_DILATED, TUNE_NO_PATH_GRID_EXIT, TUNE_PATH_BLOCKS64, TUNE_PATH_TWO_AHEAD = 32, 64, 128, 256, 512, 1024, 2048, 4096
 TUNE_NO_SMALL_FRAME_SPLIT = 16384
 TUNE_NO_BOUNCE_WAVE_GROUPS = 32768
+TUNE_NO_SAMPLE_UNITS = 65536
 TUNE_NO_PATH_POOL = 8192  # frames with bounces on scenes larger than the caches: vrt_path_kernel (a ray per lane) instead of vrt_pool_kernel
 
 # vrt_buffer_id — shader bindings 1..7

@@ -1120,10 +1120,15 @@ int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, cons
 // for vrt_pool_resolve_kernel: 2 x 2 GiB for a 4K frame of 16 samples.  The buffer grows with the frames asked for (both streams idle
 // first); where it cannot be had — more than half of the free memory, or a failed allocation — the frame keeps vrt_path_kernel.
 static bool pool_samples_ready(vrt_ctx *ctx, const vrt_camera_device *camera) {
+    ctx->params.pool_samples = nullptr; // (until this frame's buffer is known to be there)
+    if (ctx->cfg.tuning_flags & VRT_TUNE_NO_SAMPLE_UNITS) return false;
     if (camera->samples_per_pixel < 1) return false; // (a frame of no samples is not a frame of units)
     const uint64_t units = (uint64_t)ctx->shard.owned_tiles * 256u * (uint64_t)camera->samples_per_pixel;
     if (units >= (1ull << 32) - (1ull << 26)) return false; // (the counter keeps counting, a chunk per wave, after it has run out)
-    if (ctx->pool_samples_stream_elems >= units) return true;
+    if (ctx->pool_samples_stream_elems >= units) {
+        ctx->params.pool_samples = ctx->d_pool_samples;
+        return true;
+    }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
     if (ctx->stream_b && hipStreamSynchronize(ctx->stream_b) != hipSuccess) return false;
     if (ctx->d_pool_samples) (void)hipFree(ctx->d_pool_samples);
@@ -1248,6 +1253,8 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         if (!product_fn) return fail(ctx, VRT_E_STATE, "no product kernel for this configuration");
         if (camera->max_bounce > 1 && ctx->box_is_grid && ctx->product_grid_exit && grid_exit_fits(ctx, ctx->product_grid_exit, camera, pool_tiles_fit(ctx))) product_fn = ctx->product_grid_exit;
     }
+    // (vrt_path_kernel takes samples as units of work where the sample buffer can be had, whole pixels otherwise)
+    if (const vrt::KernelEntry *pe = vrt::kernel_entry_of(product_fn ? product_fn : fn); pe && pe->path == 1) (void)pool_samples_ready(ctx, camera);
     note_kernel(ctx, product_fn ? product_fn : fn);
     // (the persistent-lane kernel takes its pixels from a counter: it neither reads the tile schedule nor reports tile costs)
     const bool scheduled = !vrt::is_path_kernel(product_fn ? product_fn : fn);

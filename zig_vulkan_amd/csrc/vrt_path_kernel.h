@@ -72,10 +72,19 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                                                (FILTER ? p.path_lds_bytes : 0u) + (threadIdx.x >> 6) * 4096u;
     const PushConstants &pc = p.pcs[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total = p.owned_tiles * (uint32_t)(kTileW * kTileH);
-    uint32_t *const counter = p.work_counter + blockIdx.y;
     const bool sun_enabled = pc.sun.enabled > 0;
     const int spp = pc.cam.samples_per_pixel;
+    // Round 4, as vrt_pool_kernel (vrt_pool_kernel.h): where the context holds a sample buffer (TraceParams::pool_samples; the launcher
+    // passes it for launches of one frame) the unit of work is one SAMPLE of a pixel — its term of comp:173's sum goes to the buffer and
+    // vrt_pool_resolve_kernel finishes the pixel —, so that the frame does not end in a drain of half-finished pixels; and the units come
+    // from the counter a chunk per wave at a time either way.
+    const bool by_sample = p.pool_samples != nullptr; // (wave-uniform)
+    const uint32_t uspp = by_sample ? (uint32_t)max(1, spp) : 1u;
+    const uint32_t total = p.owned_tiles * (uint32_t)(kTileW * kTileH) * uspp;
+    uint32_t *const counter = p.work_counter + blockIdx.y;
+    constexpr uint32_t kPathChunk = 256u;
+    uint32_t chunk_next = 0u, chunk_end = 0u; // the wave's chunk of units (wave-uniform: every lane goes through the fetch below)
+    bool more_chunks = true;
     const int max_bounce = pc.cam.max_bounce;
     const float t_max = __builtin_inff();
 
@@ -300,9 +309,16 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                     const f3 bg = fma3(splat3(1.0f - t), splat3(1.0f), mk3(0.5f, 0.7f, 1.0f) * t);
                     color = color + bg * (sun_enabled ? sun_color : splat3(1.0f));
                 }
-                acc = acc + color / (color + splat3(1.0f));
-                sample_i += 1;
-                st = (sample_i < spp) ? kLaneSample : kLaneStore;
+                if (by_sample) {
+                    // (the buffer's layout: groups of 64 pixels, sample-major inside a group — vrt_pool_resolve_kernel reads whole lines)
+                    const f3 term = color / (color + splat3(1.0f));
+                    p.pool_samples[((size_t)(work >> 6) * uspp + (uint32_t)sample_i) * 64u + (work & 63u)] = make_float4(term.x, term.y, term.z, 0.0f);
+                    st = kLaneFetch;
+                } else {
+                    acc = acc + color / (color + splat3(1.0f));
+                    sample_i += 1;
+                    st = (sample_i < spp) ? kLaneSample : kLaneStore;
+                }
             }
             // (3) the pixel is finished: comp:176-177
             if (st == kLaneStore) {
@@ -319,30 +335,37 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                 if (p.target_rgba32f) reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(c.x, c.y, c.z, 1.0f);
                 st = kLaneFetch;
             }
-            // (4) next pixel: one atomic per wave for all the lanes that ask
+            // (4) next unit (a pixel, or one sample of a pixel), from the wave's chunk of kPathChunk consecutive units: one atomic per chunk
             {
                 const unsigned long long asking = __builtin_amdgcn_ballot_w64(st == kLaneFetch);
                 if (asking != 0ull) {
                     if (work_left) {
-                        const uint32_t n = (uint32_t)__builtin_popcountll(asking);
-                        uint32_t first = 0u;
-                        if (lane == (uint32_t)__builtin_ctzll(asking)) first = atomicAdd(counter, n);
-                        first = (uint32_t)__builtin_amdgcn_readlane((int)first, __builtin_ctzll(asking));
-                        if (st == kLaneFetch) {
-                            const uint32_t mine = first + (uint32_t)__builtin_popcountll(asking & ((1ull << lane) - 1ull));
-                            if (mine < total) {
-                                work = mine;
-                                sample_i = 0;
-                                acc = mk3(0, 0, 0);
-                                st = kLaneSample;
-                            } else {
-                                st = kLaneExit;
-                            }
+                        const uint32_t n = (uint32_t)__builtin_popcountll(asking), rank = (uint32_t)__builtin_popcountll(asking & ((1ull << lane) - 1ull));
+                        uint32_t unit = 0u;
+                        bool got = false;
+                        const uint32_t take = min(chunk_end - chunk_next, n);
+                        if (st == kLaneFetch && rank < take) unit = chunk_next + rank, got = true;
+                        chunk_next += take;
+                        if (take < n && more_chunks) {
+                            uint32_t first = 0u;
+                            if (lane == (uint32_t)__builtin_ctzll(asking)) first = atomicAdd(counter, kPathChunk);
+                            first = (uint32_t)__builtin_amdgcn_readlane((int)first, __builtin_ctzll(asking));
+                            more_chunks = first < total;
+                            chunk_next = more_chunks ? first : 0u;
+                            chunk_end = more_chunks ? min(first + kPathChunk, total) : 0u;
+                            const uint32_t take2 = min(chunk_end - chunk_next, n - take);
+                            if (st == kLaneFetch && rank >= take && rank - take < take2) unit = chunk_next + (rank - take), got = true;
+                            chunk_next += take2;
                         }
-                        work_left = first + n < total;
-                    } else if (st == kLaneFetch) {
-                        st = kLaneExit;
+                        if (got) {
+                            work = unit / uspp;
+                            sample_i = (int)(unit - work * uspp);
+                            acc = mk3(0, 0, 0);
+                            st = kLaneSample;
+                        }
+                        work_left = more_chunks || chunk_next < chunk_end;
                     }
+                    if (!work_left && st == kLaneFetch) st = kLaneExit;
                 }
             }
             // (5) next sample of the pixel: comp:162-171

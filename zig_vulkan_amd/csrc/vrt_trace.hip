@@ -601,8 +601,12 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
         const uint32_t threads = filter ? (uint32_t)kPathFilterThreads : 256u;
         const uint32_t want = filter ? (p.path_groups * 256u + threads - 1u) / threads : p.path_groups;
         const uint32_t groups = p.owned_tiles < want ? p.owned_tiles : want;
-        hipLaunchKernelGGL(fn, dim3(groups, frames), dim3(threads), (filter ? p.path_lds_bytes : 0u) + (p.path_brick_lds ? (threads >> 6) * 4096u : 0u), stream, p);
-        return hipGetLastError();
+        // (samples as units of work — vrt_pool_resolve_kernel behind the kernel — for launches of one frame whose context holds the buffer)
+        TraceParams q = p;
+        if (frames != 1u) q.pool_samples = nullptr;
+        hipLaunchKernelGGL(fn, dim3(groups, frames), dim3(threads), (filter ? p.path_lds_bytes : 0u) + (p.path_brick_lds ? (threads >> 6) * 4096u : 0u), stream, q);
+        e = hipGetLastError();
+        return (e != hipSuccess || !q.pool_samples) ? e : launch_pool_resolve(q, stream);
     }
     // The lockstep bounce kernel holds four waves per SIMD, sixteen per CU, and the four waves of a tile end at different times: a
     // 256-thread workgroup waits until four slots of one CU are free — a fifth of the slots stood empty through the body of the reference
