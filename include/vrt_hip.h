@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 2u /* 2 (round 4): + vrt_region_begin / _end, vrt_last_denoise_ms, tuning flags 13-14; the product build refuses development kernel_variants */
+#define VRT_ABI_VERSION 2u /* 2 (round 4): + vrt_region_begin / _end, vrt_last_denoise_ms, tuning flags 13-16; the product build refuses development kernel_variants */
 
 /* ---- status codes (replace Zig error unions, e.g. StagingRamp.zig:320-325) */
 enum {

@@ -935,7 +935,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     {
         p.pool_paths = c->d_pool_paths;
         p.pool_cus = (uint32_t)cus;
-        p.pool_walk_k = 16u;
+        p.pool_walk_k = 12u;
         p.pool_brick_thr = 48u; // (tools/pool_sweep.py: a plateau from 48 to 56, walk_min 32 to 40, walk_k 16 to 20)
         p.pool_trans_thr = 48u;
         p.pool_walk_min = 32u;
