@@ -17,4 +17,9 @@ timeout 600 python tools/slow_waves.py V0 $APP 2>&1 | grep -v amdgpu > $OUT/r04_
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/r04_bench_driver_protocol_steps20.json 2> $OUT/driver.err
 tools/r04_flythrough.sh > $OUT/fly.log 2>&1
 python tools/small_frame_ab.py cfg0_256x256_64c_b4 2>&1 | grep -v amdgpu > $OUT/r04_small_frame_ab.txt
+python tools/timeline_tail.py $APP V0,V1,V2,VG 2>&1 | grep -v amdgpu > $OUT/r04_timeline_tail_refapp.txt
+{ python tools/timeline_tail.py cfg2_1080p_512c_b8; python tools/timeline_tail.py cfg0_256x256_64c_b4; } 2>&1 | grep -v amdgpu > $OUT/r04_timeline_tail_headline.txt
+python tools/timeline_order.py cfg2_1080p_512c_b8 2>&1 | grep -v amdgpu > $OUT/r04_timeline_order_headline.txt
+python tools/timeline_order.py $APP VG,V1 2>&1 | grep -v amdgpu > $OUT/r04_timeline_order_refapp.txt
+python tools/sky_frame.py 2>&1 | grep -v amdgpu > $OUT/r04_sky_frame.txt
 ls -la $OUT
