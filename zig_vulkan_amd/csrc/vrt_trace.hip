@@ -253,9 +253,12 @@ __global__ __launch_bounds__(1024) void vrt_schedule_kernel(const uint32_t *__re
     const unsigned long long par = s_total / (wave_slots ? wave_slots : 1u);
     const bool reorder = (unsigned long long)s_longest * 5ull > par * 3ull;
     const unsigned long long threshold = par + (par >> 2);
+    const uint32_t top_bar = (uint32_t)(0.85f * (float)s_longest); // (0.7: the headline's V1 +3 %; none: V1 / V2 +2 %)
 #pragma unroll 4
     for (uint32_t i = tid; i < n; i += 1024u) {
-        uint32_t want = (reorder && extra && (unsigned long long)(state[i] >> 1) > threshold) ? 1u : 0u;
+        // (... and the frame's very longest waves whatever the bar says: a frame whose slowest wave is all of it — the headline's V1 / V2 —
+        // ends with that wave)
+        uint32_t want = (reorder && extra && ((unsigned long long)(state[i] >> 1) > threshold || (state[i] >> 1) > top_bar)) ? 1u : 0u;
         if (want && atomicAdd(&s_nsplit, 1u) >= extra) want = 0u; // no spare entry left
         state[i] = (state[i] & ~1u) | want; // (bits 1-31: the tile's slowest wave, for the class of a split tile below)
     }
