@@ -202,6 +202,7 @@ pub const TUNE_NO_PATH_POOL: u32 = 1 << 13;
 pub const TUNE_NO_SMALL_FRAME_SPLIT: u32 = 1 << 14;
 pub const TUNE_NO_BOUNCE_WAVE_GROUPS: u32 = 1 << 15;
 pub const TUNE_NO_SAMPLE_UNITS: u32 = 1 << 16;
+pub const TUNE_NO_DEFERRED_MATERIAL: u32 = 1 << 17;
 
 pub const GridConfig = extern struct { // Grid.zig:13-20
     brick_alloc: u64 = 0,

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 2u /* 2 (round 4): + vrt_region_begin / _end, vrt_last_denoise_ms, tuning flags 13-16; the product build refuses development kernel_variants */
+#define VRT_ABI_VERSION 2u /* 2 (round 4): + vrt_region_begin / _end, vrt_last_denoise_ms, tuning flags 13-17; the product build refuses development kernel_variants */
 
 /* ---- status codes (replace Zig error unions, e.g. StagingRamp.zig:320-325) */
 enum {
@@ -162,7 +162,8 @@ typedef struct vrt_config {
 #define VRT_TUNE_NO_SMALL_FRAME_SPLIT (1u << 14) /* frames with fewer waves than twice the SIMDs: one 256-thread workgroup per 16x16 tile as for large frames (instead of two with 32-lane waves) */
 #define VRT_TUNE_NO_BOUNCE_WAVE_GROUPS (1u << 15) /* the lockstep bounce kernel as 256-thread workgroups (a tile each) instead of one-wave workgroups */
 #define VRT_TUNE_NO_SAMPLE_UNITS     (1u << 16) /* frames with bounces on scenes larger than the caches: a path takes whole pixels from the counter and sums their samples itself (vrt_path_kernel; vrt_pool_kernel is not chosen), instead of single samples whose terms vrt_pool_resolve_kernel adds */
-#define VRT_TUNE_ALL                0x1FFFFu
+#define VRT_TUNE_NO_DEFERRED_MATERIAL (1u << 17) /* vrt_pool_kernel: look a solid voxel's material up in the brick round (comp:422-427 where the shader has them), not in the round of transitions that shades the hit */
+#define VRT_TUNE_ALL                0x3FFFFu
 
 typedef struct vrt_ctx vrt_ctx;
 

@@ -853,3 +853,46 @@ def test_bounce_frames_as_one_wave_workgroups_keep_the_frame():
             assert np.array_equal(frames[(0, v)][1], frames[(L.TUNE_NO_BOUNCE_WAVE_GROUPS, v)][1]), (w.name, v)
         fo, uo, _ = O.render(oracle_scene_from_grid(grid), pc)
         assert np.array_equal(frames[(0, "V1")][0].view(np.uint32), fo.view(np.uint32)) and np.array_equal(frames[(0, "V1")][1], uo), w.name
+
+
+def test_pool_kernel_defers_the_hit_material_only_where_no_record_can_be_ignored():
+    """vrt_pool_kernel leaves comp:337 / :422-427's look-ups of a hit to the round of transitions that shades it while no material record
+    has the type MAT_NONE (TraceParams::materials_plain): the same bytes as with the look-ups in the brick round
+    (VRT_TUNE_NO_DEFERRED_MATERIAL).  A table with a MAT_NONE record whose type_data is 1 — which camera and shadow rays DO ignore
+    (comp:427) — uploaded between two frames of one context turns the deferral off: that frame is the oracle's, and differs."""
+    from zig_vulkan_amd import _lib as L
+    from zig_vulkan_amd import default_materials
+    w = W.Workload("t", 208, 112, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000)
+    grid = W.build_grid(w)
+    mats = default_materials(256)
+    mats[3] = (3, 0.3, 0.9, 0.3, 1.0)     # MAT_NONE, type_data == the rays' refraction index: ignored by comp:427
+
+    def frames(**kw):
+        rt = W.make_renderer(w, grid, kernel_variant=PATH, want_float_output=True, **kw)
+        W.set_view(rt, "V0")
+        rt.draw()
+        rt.wait()      # (the box of the occupied cells has reached the host)
+        out = []
+        for v in ("V0", "V2"):
+            W.set_view(rt, v)
+            rt.draw()
+            out.append((rt.read_rgba32f().copy(), rt.read_rgba8().copy()))
+        rt.push_materials(mats)
+        rt.draw()
+        out.append((rt.read_rgba32f().copy(), rt.read_rgba8().copy()))
+        assert rt.kernel_name().startswith("vrt_pool_kernel<8,"), rt.kernel_name()
+        pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+        rt.deinit()
+        return out, pc
+
+    a, pc = frames()
+    b, _ = frames(tuning_flags=L.TUNE_NO_DEFERRED_MATERIAL)
+    for (fa, ua), (fb, ub) in zip(a, b):
+        assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)) and np.array_equal(ua, ub) and ua.any()
+    scene = oracle_scene_from_grid(grid)
+    fo, uo, _ = O.render(scene, pc)                      # (the default table)
+    assert np.array_equal(a[1][0].view(np.uint32), fo.view(np.uint32)) and np.array_equal(a[1][1], uo)
+    scene2 = oracle_scene_from_grid(grid, materials=mats)
+    fo2, uo2, _ = O.render(scene2, pc)
+    assert np.array_equal(a[2][0].view(np.uint32), fo2.view(np.uint32)) and np.array_equal(a[2][1], uo2)
+    assert not np.array_equal(uo, uo2)

@@ -48,6 +48,7 @@ hipError_t launch_build_cell_bounds(const TraceParams &p, uint32_t dim_x, uint32
 hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, uint64_t cell_lo, uint64_t cell_hi, uint64_t slot_lo,
                                        uint64_t slot_hi, hipStream_t stream);
 hipError_t launch_check_start_is_slot(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, hipStream_t stream);
+hipError_t launch_check_materials_plain(const TraceParams &p, uint32_t count, hipStream_t stream);
 hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
                           void *out_f32, hipStream_t stream);
 hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per_pixel, uint32_t width, uint32_t height, uint32_t tiles_x,
@@ -206,6 +207,8 @@ struct vrt_ctx {
     // refreshed for the cells and brick slots it names, not gathered anew over the whole grid): cells whose status bit / brick index
     // changed and brick slots whose occupancy bytes changed, both [lo, hi); lo >= hi: none
     uint64_t occ_cell_lo = 0, occ_cell_hi = ~0ull, occ_slot_lo = 0, occ_slot_hi = 0;
+    uint32_t *d_materials_plain = nullptr;   // derived: 1 = no material record has the type MAT_NONE (TraceParams::materials_plain)
+    bool materials_dirty = true;             // binding 0 changed since it was checked
     bool start_dirty = true;                 // binding 6 changed since it was checked
     vrt::TileOwnership own{};        // weighted tile ownership (period 0: tile t belongs to rank t % shard_count)
     bool status_dirty = true;        // brick_status changed since the derived copy was built
@@ -299,6 +302,7 @@ void free_ctx(vrt_ctx *c) {
     if (c->d_cell_distance) (void)hipFree(c->d_cell_distance);
     if (c->d_cell_occupancy) (void)hipFree(c->d_cell_occupancy);
     if (c->d_start_is_slot) (void)hipFree(c->d_start_is_slot);
+    if (c->d_materials_plain) (void)hipFree(c->d_materials_plain);
     if (c->dist) {
         Dist *d = c->dist;
         for (uint32_t i = 0; i < d->nslots; i++) {
@@ -892,6 +896,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
                 c->cell_occupancy_lockstep = lockstep_bounce;
             }
         }
+        if (!(cfg->tuning_flags & VRT_TUNE_NO_DEFERRED_MATERIAL)) {
+            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_materials_plain), 64u));
+            VRT_CREATE_HIP(hipMemsetAsync(c->d_materials_plain, 0, 64u, c->stream));
+        }
         if (!(cfg->tuning_flags & VRT_TUNE_NO_START_SHORTCUT)) {
             VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_start_is_slot), 64u));
             VRT_CREATE_HIP(hipMemsetAsync(c->d_start_is_slot, 0, 64u, c->stream));
@@ -987,6 +995,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.cell_occupancy = c->d_cell_occupancy;
     p.cell_occupancy_lockstep = (c->d_cell_occupancy && c->cell_occupancy_lockstep) ? 1u : 0u;
     p.start_is_slot = c->d_start_is_slot;
+    p.materials_plain = c->d_materials_plain;
     p.status_cells = (uint32_t)cells;
     // (order_auto: frames that alternate between the two streams of a frames_in_flight = 2 context take reverse raster (3)
     // instead, see do_dispatch and DESIGN.md §4)
@@ -1060,6 +1069,7 @@ uint64_t vrt_buffer_size(const vrt_ctx *ctx, vrt_buffer_id id) {
 static void mark_dirty(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, uint64_t nbytes) {
     if (id == VRT_BUF_BRICK_STATUS) ctx->status_dirty = true;
     if (id == VRT_BUF_BRICK_START_INDEX) ctx->start_dirty = true;
+    if (id == VRT_BUF_MATERIALS) ctx->materials_dirty = true;
     if (id != VRT_BUF_BRICK_STATUS && id != VRT_BUF_BRICK_INDEX && id != VRT_BUF_BRICK_OCCUPANCY) return;
     auto widen = [](uint64_t &lo, uint64_t &hi, uint64_t a, uint64_t b) {
         if (lo >= hi) lo = a, hi = b;
@@ -1207,17 +1217,18 @@ static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt
         if (rcw != VRT_OK) return rcw;
         ctx->status_dirty = false;
     }
-    if ((ctx->occupancy_dirty && ctx->d_cell_occupancy) || (ctx->start_dirty && ctx->d_start_is_slot)) {
+    if ((ctx->occupancy_dirty && ctx->d_cell_occupancy) || (ctx->start_dirty && ctx->d_start_is_slot) || (ctx->materials_dirty && ctx->d_materials_plain)) {
         int rcw = begin_scene_write(ctx);
         if (rcw != VRT_OK) return rcw;
         if (ctx->occupancy_dirty)
             VRT_HIP(ctx, vrt::launch_build_cell_occupancy(ctx->params, ctx->cfg.brick_dimension, ctx->cfg.brick_alloc, ctx->occ_cell_lo, ctx->occ_cell_hi, ctx->occ_slot_lo,
                                                           ctx->occ_slot_hi, ctx->stream));
         if (ctx->start_dirty) VRT_HIP(ctx, vrt::launch_check_start_is_slot(ctx->params, ctx->cfg.brick_dimension, ctx->cfg.brick_alloc, ctx->stream));
+        if (ctx->materials_dirty) VRT_HIP(ctx, vrt::launch_check_materials_plain(ctx->params, std::max<uint32_t>(256u, (uint32_t)(ctx->dsize[VRT_BUF_MATERIALS] / sizeof(vrt_material))), ctx->stream));
         rcw = end_scene_write(ctx);
         if (rcw != VRT_OK) return rcw;
     }
-    ctx->occupancy_dirty = ctx->start_dirty = false;
+    ctx->occupancy_dirty = ctx->start_dirty = ctx->materials_dirty = false;
     ctx->occ_cell_lo = ctx->occ_cell_hi = ctx->occ_slot_lo = ctx->occ_slot_hi = 0;
     // max_bounce <= 1 ("only primary ray" + its shadow ray): the bounce loop runs at most once
     *fn = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? ctx->kernel_single1 : ctx->kernel_single) : ctx->kernel;

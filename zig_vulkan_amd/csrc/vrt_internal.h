@@ -90,6 +90,12 @@ struct TraceParams {
     // reference's allocator produces (MaterialAllocator.zig:39 hands out B^3 entries per brick in slot order) — so that comp:422's
     // look-up is replaced by a multiplication; nullptr or 0: look it up
     const uint32_t *start_is_slot;
+    // derived from binding 0 (round 4): *materials_plain == 1 when no material record has the type MAT_NONE (3).  comp:427 skips a solid
+    // voxel whose material's type is the ray's ignore type (and whose type_data is the ray's refraction index); camera rays, shadow rays
+    // and rays scattered by anything but a dielectric ignore MAT_NONE, which then no record can match — vrt_pool_kernel decides the test
+    // without the record and leaves the hit's look-ups (brick_index -> material_index -> material: three dependent misses on a scene
+    // larger than the caches) to the round of transitions that shades it; nullptr or 0: always look the record up in the brick round
+    const uint32_t *materials_plain;
     // derived, device-built copy of brick_status: one 64-bit word per 4x4x4 block of grid cells,
     // block index bx + nbx*(bz + nbz*by), bit (x&3) + 4*(z&3) + 16*(y&3)  (x, z, y order as comp:318)
     const uint2 *status_blocks;

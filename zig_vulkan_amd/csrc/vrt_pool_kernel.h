@@ -277,6 +277,19 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                             Hit hit;
                             hit.t = t_in;
                             hit.index = f2u(t_out);
+                            if (hit.index & kDeferredHit) {
+                                // the brick round left comp:337 / :422 / :425 to this round: the parked cell (still in cw) -> its brick ->
+                                // the brick's first material entry -> the voxel's material
+                                const uint32_t flipped = (sx_of(fl) < 0 ? fx : 0u) | (sy_of(fl) < 0 ? fy : 0u) | (sz_of(fl) < 0 ? fz : 0u);
+                                const uint32_t real = cw ^ flipped;
+                                const uint32_t hx = (real & 3u) | ((real >> 3) & (((1u << (lx - 2u)) - 1u) << 2));
+                                const uint32_t hz = ((real >> 2) & 3u) | ((real >> (lx + 1u)) & (((1u << (lz - 2u)) - 1u) << 2));
+                                const uint32_t hy = ((real >> 4) & 1u) | ((real >> (lx + lz + 1u)) << 1);
+                                const uint32_t hcell = hx + (uint32_t)dx * (hz + (uint32_t)dz * hy);
+                                const uint32_t hbrick = p.brick_index[hcell];
+                                const uint32_t hstart = start_is_slot ? hbrick * (uint32_t)(B * B * B) : (p.brick_start_index[hbrick] & 0x7FFFFFFFu);
+                                hit.index = p.material_index[hstart + (hit.index & ~kDeferredHit)];
+                            }
                             const float t_offset = (g_scale * (1.0f / (float)B)) * 0.05f;
                             hit.normal = axis_normal(s, (int)((fl >> 21) & 3u));
                             hit.point = ray_at(r, hit.t) + hit.normal * t_offset;
@@ -581,7 +594,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 hit.index = 0u;
                 int hit_axis = 0;
                 const int a = (int)(code & 3u);
-                const bool hit_voxel = brick_walk_park_gfx950<B, true, true>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis, wave_lds);
+                const bool hit_voxel = brick_walk_park_gfx950<B, true, true, true>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis, wave_lds);
                 if (hit_voxel) {
                     st = kRayHit;
                     t_in = hit.t;

@@ -144,6 +144,12 @@ __global__ __launch_bounds__(256) void vrt_check_start_is_slot(const uint32_t *_
     if (v != 0xFFFFFFFFu && (uint64_t)(v & 0x7FFFFFFFu) != i * bits) *flag = 0u;
 }
 
+// *flag = 1 iff no material record has the type MAT_NONE (TraceParams::materials_plain).  Set to 1 before the launch; violators clear it.
+__global__ __launch_bounds__(256) void vrt_check_materials_plain(const vrt_material *__restrict__ materials, uint32_t *__restrict__ flag, uint32_t count) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < count && materials[i].type == 3u /* MAT_NONE */) *flag = 0u;
+}
+
 // Bounding box of the occupied grid cells (TraceParams::cell_bounds), from the status bits of binding 3: one thread per
 // status word, six atomic maxima over {-x, -y, -z, x, y, z}; bounds[] starts as 0x80808080 (hipMemsetAsync 0x80).
 __global__ __launch_bounds__(256) void vrt_build_cell_bounds(const uint32_t *__restrict__ status, int *__restrict__ bounds, uint32_t words,
@@ -688,6 +694,15 @@ hipError_t launch_check_start_is_slot(const TraceParams &p, uint32_t brick_dimen
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(vrt_check_start_is_slot, dim3((uint32_t)((brick_alloc + 255u) / 256u)), dim3(256), 0, stream, p.brick_start_index, flag, brick_alloc,
                        brick_dimension * brick_dimension * brick_dimension);
+    return hipGetLastError();
+}
+
+hipError_t launch_check_materials_plain(const TraceParams &p, uint32_t count, hipStream_t stream) {
+    if (!p.materials_plain) return hipSuccess;
+    uint32_t *flag = const_cast<uint32_t *>(p.materials_plain);
+    const hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flag), 1, 1, stream);
+    if (e != hipSuccess) return e;
+    if (count) hipLaunchKernelGGL(vrt_check_materials_plain, dim3((count + 255u) / 256u), dim3(256), 0, stream, p.materials, flag, count);
     return hipGetLastError();
 }
 

@@ -1047,7 +1047,11 @@ VRT_DI void stage_brick_lds(const TraceParams &p, uint32_t occ_slot, bool by_cel
     for (int c = 0; c < 4; c++)
         __builtin_amdgcn_global_load_lds((glb_void *)(src + 4 * c), (lds_void *)((__attribute__((address_space(3))) char *)dst + 1024 * c), 16, 0, 0);
 }
-template <int B, bool LDS = false, bool PRESTAGED = false>
+// DEFER (vrt_pool_kernel, round 4): a lane whose ray ignores no material type any record has (TraceParams::materials_plain, the ray's
+// ignore type MAT_NONE) needs none of comp:422-427's three dependent look-ups here — its hit is recorded as the voxel's index in its
+// brick with kDeferredHit set in hit.index, and the round of transitions that shades the hit looks the material up (pool_hit_material).
+constexpr uint32_t kDeferredHit = 0x80000000u;
+template <int B, bool LDS = false, bool PRESTAGED = false, bool DEFER = false>
 VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const RaySetup &s, float g_scale, uint32_t occ_slot, uint32_t cell, bool by_cell,
                                    bool start_is_slot, f3 brick_min, Hit &hit, int axis_in, int &hit_axis, uint32_t wave_lds = 0u) {
     static_assert(!LDS || B == 8, "the LDS layout is written for 64-byte bricks");
@@ -1110,6 +1114,8 @@ VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const Ray
     g.batch = 64u;
     g.min_alive = 0u;
     bool found = false;
+    [[maybe_unused]] const bool deferred = DEFER && p.materials_plain != nullptr && __builtin_amdgcn_readfirstlane((int)*p.materials_plain) != 0 &&
+                                           r.ignore_type_material == MAT_NONE; // (per lane)
     while (g.alive != 0ull) {
         uint32_t solid_bit; // parked lanes: bit index of the solid voxel they left behind
         VRT_PROF_BEGIN(tp2);
@@ -1120,7 +1126,14 @@ VRT_DI bool brick_walk_park_gfx950(const TraceParams &p, const Ray &r, const Ray
         const bool parked = __builtin_amdgcn_inverse_ballot_w64(g.parked);
         bool resume = false;
         VRT_PROF_BEGIN(tp4);
-        if (parked) {
+        if (parked && deferred) {
+            const uint32_t in = g.code & 3u;
+            hit.index = (solid_bit - base) | kDeferredHit;
+            const float t_offset = voxel_scale * 0.05f;
+            hit.t += g.t_in * voxel_scale - t_offset; // t_value of the step into this voxel (comp:442), 0 for the first
+            hit_axis = (in == 3u) ? axis_in : (int)in;
+            found = true;
+        } else if (parked) {
             const uint32_t voxel_index = solid_bit - base;
             const uint32_t brick_index = by_cell ? p.brick_index[cell] : occ_slot; // comp:337, by the lanes that need it
             const uint32_t brick_material_index = start_is_slot ? brick_index * (uint32_t)(B * B * B)
