@@ -79,6 +79,9 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
     // vrt_pool_resolve_kernel finishes the pixel —, so that the frame does not end in a drain of half-finished pixels; and the units come
     // from the counter a chunk per wave at a time either way.
     const bool by_sample = p.pool_samples != nullptr; // (wave-uniform)
+    // (a hit's material looked up by the transition that shades it — brick_walk_park_gfx950<..., DEFER> —, not in the development walks
+    // whose `word` is not a plain register of the lane)
+    constexpr bool kDefer = !AHEAD && DIL != 3;
     const uint32_t uspp = by_sample ? (uint32_t)max(1, spp) : 1u;
     const uint32_t total = p.owned_tiles * (uint32_t)(kTileW * kTileH) * uspp;
     uint32_t *const counter = p.work_counter + blockIdx.y;
@@ -249,6 +252,13 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                         loop_count += 1;
                         Ray scattered = r;
                         bool result = false;
+                        if (hit.index & kDeferredHit) {
+                            // (round 4, as vrt_pool_kernel: the brick round left comp:337 / :422 / :425 of this hit to this round — the cell is
+                            // in `word`, which the finished walk no longer needs)
+                            const uint32_t hbrick = p.brick_index[word];
+                            const uint32_t hstart = start_is_slot ? hbrick * (uint32_t)(B * B * B) : (p.brick_start_index[hbrick] & 0x7FFFFFFFu);
+                            hit.index = p.material_index[hstart + (hit.index & ~kDeferredHit)];
+                        }
                         const vrt_material *m = p.materials + hit.index;
                         const uint32_t mtype = m->type;
                         attenuation = mk3(m->albedo_r, m->albedo_g, m->albedo_b);
@@ -586,14 +596,17 @@ __global__ __launch_bounds__(FILTER ? kPathFilterThreads : 256, FILTER ? 4 : MIN
                 hit.t = global_t_value;
                 bool hit_voxel;
                 if constexpr (B == 8) {
-                    hit_voxel = p.path_brick_lds ? brick_walk_park_gfx950<B, true, true>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis, wave_lds)
-                                                 : brick_walk_park_gfx950<B>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis);
+                    hit_voxel = p.path_brick_lds ? brick_walk_park_gfx950<B, true, true, kDefer>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis, wave_lds)
+                                                 : brick_walk_park_gfx950<B, false, false, kDefer>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis);
                 } else {
-                    hit_voxel = brick_walk_park_gfx950<B>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis);
+                    hit_voxel = brick_walk_park_gfx950<B, false, false, kDefer>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis);
                 }
                 if (hit_voxel) {
                     found = true;
                     st = kLaneDone;
+                    if constexpr (kDefer) {
+                        if (hit.index & kDeferredHit) word = cell; // (the hit's material is looked up by the transition: where it lies)
+                    }
                 } else if (!(global_t_value <= t_max) || (DIL >= 2 ? __builtin_amdgcn_inverse_ballot_w64(gone) : (!AHEAD && min3i(w.rx, w.ry, w.rz) < 0))) {
                     found = false; // t became NaN (comp:316), or the step out of this cell left the box
                     st = kLaneDone;
