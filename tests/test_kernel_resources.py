@@ -37,10 +37,11 @@ def _kernels():
 
 
 def test_the_product_binary_holds_only_shipped_kernels():
-    """at most 40 kernels in the product code objects (round 2 shipped 175, most of them losers of an A/B);
-    the variants that lost live in the development build (make dev)."""
+    """about 40 kernels in the product code objects (round 2 shipped 175, most of them losers of an A/B);
+    the variants that lost live in the development build (make dev).  Round 4: 27 traversal kernels + 16 small ones (builders of
+    the derived structures, schedule, un-swizzle, the two present kernels, vrt_pool_resolve_kernel, vrt_check_materials_plain)."""
     ks = _kernels()
-    assert len(ks) <= 42, sorted(ks)
+    assert len(ks) <= 43, sorted(ks)
     traversal = [n for n in ks if "vrt_trace_kernel" in n or "vrt_path_kernel" in n or "vrt_pool_kernel" in n]
     assert len(traversal) == 27, sorted(traversal)
 
