@@ -834,7 +834,8 @@ def test_bounce_frames_as_one_wave_workgroups_keep_the_frame():
     samples per pixel, an odd frame, two frames in flight — the same bytes as with a 256-thread workgroup per tile
     (VRT_TUNE_NO_BOUNCE_WAVE_GROUPS), and the oracle's on the last view."""
     from zig_vulkan_amd import _lib as L
-    for w, fif in ((W.Workload("app_like", 509, 283, 256, 4, 2, 2, True, 5.0), 1), (W.Workload("app_like_3spp", 320, 200, 128, 8, 3, 2, True, 5.0), 2), (W.Workload("two_spp_one_bounce", 640, 360, 256, 8, 2, 1, True, 5.0), 1)):
+    for w, fif in ((W.Workload("app_like", 509, 283, 256, 4, 2, 2, True, 5.0), 1), (W.Workload("app_like_3spp", 320, 200, 128, 8, 3, 2, True, 5.0), 2), (W.Workload("two_spp_one_bounce", 640, 360, 256, 8, 2, 1, True, 5.0), 1),
+                   (W.Workload("one_sample_two_in_flight", 640, 360, 256, 8, 1, 1, True, 5.0), 2)):   # (reverse raster on both streams: one-wave workgroups too)
         grid = W.build_grid(w)
         frames = {}
         for flags in (0, L.TUNE_NO_BOUNCE_WAVE_GROUPS):

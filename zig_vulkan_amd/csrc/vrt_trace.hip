@@ -621,9 +621,10 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
     // 256-thread workgroup waits until four slots of one CU are free — a fifth of the slots stood empty through the body of the reference
     // app's frames (tools/timeline_tail.py).  As one-wave workgroups every wave that ends is replaced at once: the app's run V0 / V1 / V2 /
     // all-ground -2 / -5.5 / -5 / -9.5 %, same box, two frames in flight -9 %.  The several-samples kernel at six waves per SIMD (4K / 1024^3, two
-    // samples): -2 % alone and with two frames in flight.  (The one-sample kernels at seven waves per SIMD: 256^3 -1 ... -6 %, but the
-    // headline +-0 with two frames in flight and its view V2 +11 % alone — not taken; tools/fif_waves_ab.py.)
-    if (const KernelEntry *te = kernel_entry_of(fn); te && te->path == 0 && te->shade <= 1 && !te->count && p.wave_groups_bounce && !p.wave_groups &&
+    // samples): -2 % alone and with two frames in flight.  The one-sample kernels at seven waves per SIMD take it in reverse raster only
+    // (two frames in flight, frames of more tiles than the schedule takes): headline -0.7 / -1.8 / -0.8 %, 256^3 -0.3 / -4.4 / -6.2 %
+    // with two frames in flight; under the cost schedule, one frame at a time, the headline's V2 lost 11 % (tools/fif_waves_ab.py).
+    if (const KernelEntry *te = kernel_entry_of(fn); te && te->path == 0 && (te->shade <= 1 || p.tile_order == 3u) && !te->count && p.wave_groups_bounce && !p.wave_groups &&
                                                        p.block_threads != 512u && !p.split_all && !p.packed_rgb) {
         TraceParams q = p;
         q.wave_groups = 1u;
