@@ -138,7 +138,7 @@ pub const SunDevice = extern struct { // Sun.Device, Sun.zig:13-18 (32 bytes)
 
 pub const Config = extern struct {
     struct_size: u32 = @sizeOf(Config),
-    abi_version: u32 = 2, // VRT_ABI_VERSION
+    abi_version: u32 = 3, // VRT_ABI_VERSION
     width: u32,
     height: u32,
     brick_dimension: u32 = 4, // State.brick_dimension
@@ -244,6 +244,7 @@ pub extern fn vrt_buffer_size(ctx: ?*const Ctx, id: BufferId) u64;
 pub extern fn vrt_upload_device(ctx: ?*Ctx, id: BufferId, byte_offset: u64, dev_src: ?*const anyopaque, nbytes: u64) c_int;
 pub extern fn vrt_dispatch(ctx: ?*Ctx, camera: [*c]const CameraDevice, sun: [*c]const SunDevice) c_int;
 pub extern fn vrt_wait(ctx: ?*Ctx) c_int;
+pub extern fn vrt_reserve_samples(ctx: ?*Ctx, max_samples_per_pixel: u32) c_int;
 pub extern fn vrt_dispatch_repeat(ctx: ?*Ctx, camera: [*c]const CameraDevice, sun: [*c]const SunDevice, frames: u32) c_int;
 pub extern fn vrt_dispatch_timed(ctx: ?*Ctx, camera: [*c]const CameraDevice, sun: [*c]const SunDevice, frames: u32, ms_per_frame: [*c]f32) c_int;
 pub extern fn vrt_read_rgba8(ctx: ?*Ctx, dst: ?*anyopaque, nbytes: u64) c_int;
@@ -258,6 +259,7 @@ pub extern fn vrt_dist_unique_id(rccl_path: ?[*:0]const u8, out_id128: ?*anyopaq
 pub extern fn vrt_dist_init(ctx: ?*Ctx, rccl_path: ?[*:0]const u8, id128: ?*const anyopaque, rank: c_int, world: c_int, frames_in_flight: u32) c_int;
 pub extern fn vrt_dist_init_batched(ctx: ?*Ctx, rccl_path: ?[*:0]const u8, id128: ?*const anyopaque, rank: c_int, world: c_int, frames_in_flight: u32, frames_per_launch: u32) c_int;
 pub extern fn vrt_dist_frame(ctx: ?*Ctx, camera: [*c]const CameraDevice, sun: [*c]const SunDevice) c_int;
+pub extern fn vrt_dist_frames(ctx: ?*Ctx, cameras: [*c]const CameraDevice, suns: [*c]const SunDevice, n: u32, sun_stride: u32) c_int;
 pub extern fn vrt_dist_wait(ctx: ?*Ctx) c_int;
 pub extern fn vrt_dist_read_frame(ctx: ?*Ctx, dst: ?*anyopaque, nbytes: u64) c_int;
 pub extern fn vrt_dist_broadcast(ctx: ?*Ctx, id: BufferId, byte_offset: u64, nbytes: u64, root: c_int) c_int;

@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 2u /* 2 (round 4): + vrt_region_begin / _end, vrt_last_denoise_ms, tuning flags 13-17; the product build refuses development kernel_variants */
+#define VRT_ABI_VERSION 3u /* 3 (round 5): + vrt_dist_frames, vrt_reserve_samples; vrt_trace_wave_timeline's capacity rule.  2 (round 4): + vrt_region_begin / _end,
+                             vrt_last_denoise_ms, tuning flags 13-17; the product build refuses development kernel_variants */
 
 /* ---- status codes (replace Zig error unions, e.g. StagingRamp.zig:320-325) */
 enum {
@@ -197,6 +198,16 @@ int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, cons
 int vrt_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun);
 int vrt_wait(vrt_ctx *ctx);
 
+/* Frames with bounces on scenes larger than the caches are traced by persistent kernels whose unit of work is one SAMPLE of a pixel;
+ * the samples' terms go through a buffer of 16 bytes per sample — owned pixels x samples_per_pixel, one buffer per stream of frames
+ * (two with frames_in_flight = 2, one per launch in flight of the multi-GPU pipeline; 2 GiB for a 4K frame of 16 samples).  By default
+ * that buffer is made by the first frame that needs it and grows when a later frame has more samples per pixel: such a vrt_dispatch
+ * allocates, and — when it replaces a smaller buffer — waits for the frames in flight on that stream.  vrt_reserve_samples makes the
+ * buffers now, for frames of up to max_samples_per_pixel, so that no dispatch does.  VRT_OK also where the context has no such kernel
+ * (nothing to reserve); VRT_E_OOM where a buffer cannot be had (more than half of the free memory): the context stays usable, frames
+ * keep a kernel that does without, as they do when a growth at dispatch time fails (the buffer it has is kept). */
+int vrt_reserve_samples(vrt_ctx *ctx, uint32_t max_samples_per_pixel);
+
 /* Same launch repeated `frames` times back-to-back on the ctx stream without
  * host round trips (benchmarking; every frame is a full render). */
 int vrt_dispatch_repeat(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames);
@@ -264,6 +275,11 @@ int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int ra
 int vrt_dist_init_batched(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight,
                           uint32_t frames_per_launch);
 int vrt_dist_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun);
+/* n consecutive vrt_dist_frame calls in one: frame i takes cameras[i] and suns[i * sun_stride] (sun_stride 0: every frame the same
+ * sun).  A host that knows its next frames — a scripted fly-through (Benchmark.zig:141-172), a benchmark — submits them without a
+ * round trip through its own language per frame; what the call costs per frame is the library's own submission (kernel launch, grouped
+ * send / recv, event records).  Stops at the first error.  A collective call like vrt_dist_frame: every rank, same n. */
+int vrt_dist_frames(vrt_ctx *ctx, const vrt_camera_device *cameras, const vrt_sun_device *suns, uint32_t n, uint32_t sun_stride);
 int vrt_dist_wait(vrt_ctx *ctx);
 /* rank 0: the most recently submitted frame, row-major RGBA8 (waits for it).  With frames_per_launch > 1 the queue must
  * be empty (full batch just launched, or after vrt_dist_wait): a launch carries a collective, every rank launches together. */
@@ -313,8 +329,9 @@ int vrt_get_counters(vrt_ctx *ctx, vrt_counters *out);
 int vrt_get_wave_counters(vrt_ctx *ctx, uint64_t out[3]);
 
 /* Measurement aid: render one frame with per-wave begin/end timestamps (100 MHz wall clock) and copy
- * them to `out` as pairs, `capacity_pairs` >= waves launched (4 per owned tile).  Returns the number of
- * pairs written through *n_pairs.  Not part of the reference's interface. */
+ * them to `out` as pairs.  `capacity_pairs` >= 4 x (owned tiles + the cost schedule's spare entries, at most one per owned
+ * tile: the second halves of split tiles) — the most waves any launch of this context can hold.  Returns the number of
+ * pairs of THIS launch through *n_pairs.  Not part of the reference's interface. */
 int vrt_trace_wave_timeline(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint64_t *out,
                             uint64_t capacity_pairs, uint64_t *n_pairs);
 
@@ -328,13 +345,13 @@ uint32_t vrt_abi_version(void);
  * one sample per pixel would take), as its template-id — the kernel name rocprofv3 reports minus the `void vrt::` prefix and
  * the argument list: "vrt_trace_kernel<8, false, 7, 7, 2, 256>" (B, COUNT, MODE, MIN_WAVES, SHADE, BLOCK),
  * "vrt_path_kernel<8, 5, false, false, false, false, 1>" (B, MIN_WAVES, FILTER, HALF, AHEAD, DIST, DIL) or
- * "vrt_pool_kernel<8, 5, 64, 2>" (B, MIN_WAVES, SLOTS, STAGES).  On a counting context: the product kernel, not the counting build that
+ * "vrt_pool_kernel<8, 5, 64, 2>" (B, MIN_WAVES, SLOTS, STAGES).  Inside the multi-GPU pipeline: the kernel of the frame queued last.  On a counting context: the product kernel, not the counting build that
  * ran before it.  The name is that of the LAST frame and may change between frames of one context: a context whose bounce frames
  * the persistent kernels trace starts on vrt_path_kernel<..., DIL 1> and moves to vrt_pool_kernel (8^3 bricks) or <..., DIL 2> once the
  * host copy of the occupied cells' box has arrived and says that the box is the grid; frames of other sample / bounce counts take
  * other kernels.  The product build (make) holds the kernels the library chooses itself — kernel_variant modes 0, 5 and 9 with the
  * occupancy and order fields — and answers every other kernel_variant with VRT_E_INVALID_ARG; the development build (make dev) holds
- * them all (ABI version 2 records that change). */
+ * them all (ABI version 2 recorded that change). */
 const char *vrt_kernel_name(const vrt_ctx *ctx);
 /* number of traversal kernels compiled into this build of the library (tests/test_kernel_resources.py) */
 int vrt_compiled_kernel_count(void);

@@ -246,18 +246,15 @@ def test_pipeline_stage_profile(world, frames_per_launch):
         assert (st["unswizzle_ms_per_launch"] > 0) == (r == 0)
 
 
-def test_bounce_frames_of_a_path_kernel_context_go_through_the_pipeline_on_the_lockstep_kernel():
-    """A context whose bounce frames vrt_path_kernel traces (forced here; chosen by the library on scenes larger than the caches),
-    on a scene whose occupied cells reach the grid's faces: once the host knows the box, plain dispatches take the counter-free
-    dilated-index twin — and the multi-rank pipeline must still substitute the lockstep kernel for either (its RGB shard store
-    needs the fixed lane -> pixel map).  Frames with bounces, two ranks, assembled frame == the single-context frame."""
-    if not os.path.exists(FAKE):
-        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
-    path = 1 << 23
+def _bounce_scene():
+    """A cfg4-shaped scene at test size: 8^3 bricks, power-of-two grid, sparse spheres that reach the grid's faces, 2 spp, 2 bounces,
+    soft sun — the shape on which the library picks vrt_pool_kernel once the host knows the box of the occupied cells."""
     w = W.Workload("t", 330, 210, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000)
-    grid = W.build_grid(w)
-    views = ["V0", "V1x", "V0", "V2", "V1x"]
-    plain = W.make_renderer(w, grid, kernel_variant=path)
+    return w, W.build_grid(w)
+
+
+def _single_context_frames(w, grid, views, variant):
+    plain = W.make_renderer(w, grid, kernel_variant=variant)
     W.set_view(plain, "V0")
     plain.draw()
     plain.wait()          # (the box of the occupied cells has reached the host)
@@ -266,11 +263,81 @@ def test_bounce_frames_of_a_path_kernel_context_go_through_the_pipeline_on_the_l
         W.set_view(plain, v)
         plain.draw()
         ref[v] = plain.read_rgba8().copy()
-    assert plain.kernel_name() == "vrt_pool_kernel<8, 5, 64, 2>"   # (round 4: a pool of rays per wave where the counter-free walk would run on 8^3 bricks)
+    name = plain.kernel_name()
     plain.deinit()
+    return ref, name
+
+
+@pytest.mark.parametrize("world,frames_in_flight,frames_per_launch,root_weight,reserve",
+                         [(2, 2, 1, 0, False), (4, 3, 1, 77, True), (8, 2, 1, 30, False), (8, 8, 1, 0, True), (2, 2, 3, 0, False), (4, 2, 8, 46, True), (8, 3, 2, 18, False)])
+def test_bounce_frames_go_through_the_pipeline_on_the_persistent_kernels(world, frames_in_flight, frames_per_launch, root_weight, reserve):
+    """BASELINE configs[4] is an 8-GPU path trace, and until round 4 the pipeline sent bounce frames to the lockstep
+    kernel.  Now every launch slot has its own unit counters, path records and sample buffer, and vrt_pool_resolve_kernel writes the
+    packed RGB shard: inside the pipeline the frames are traced by vrt_path_kernel<..., DIL 1> until the host knows the box of the
+    occupied cells and by vrt_pool_kernel from then on — the kernels a single context uses — and every assembled frame equals the
+    single-context frame.  Ranks are threads over tests/fake_rccl; with and without vrt_reserve_samples; batches (the persistent
+    kernels then take their frames one per launch into the batch's buffer, ONE collective per batch)."""
+    if not os.path.exists(FAKE):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
+    path = 1 << 23
+    w, grid = _bounce_scene()
+    views = ["V0", "V1x", "V0", "V2", "V1x", "V2", "V0", "V1x"]
+    ref, single_name = _single_context_frames(w, grid, views, path)
+    assert single_name == "vrt_pool_kernel<8, 5, 64, 2>"
+    uid = b"fake-rccl-pool" + bytes([world, frames_in_flight, frames_per_launch]) + os.urandom(16) + bytes(128 - 33)
+    ranks = [W.make_renderer(w, grid, kernel_variant=path, shard_rank=r, shard_count=world, shard_root_weight=root_weight) for r in range(world)]
+    for r, rt in enumerate(ranks):
+        rt.dist_init(uid, r, world, frames_in_flight=frames_in_flight, rccl_path=FAKE, frames_per_launch=frames_per_launch)
+        if reserve:
+            rt.reserve_samples(w.spp)
+    got, errors, names = [], [], {r: [] for r in range(world)}
+    reads = [i for i in range(len(views)) if (i + 1) % frames_per_launch == 0]   # only where the queue has just been launched
+
+    def drive(r):
+        try:
+            rt = ranks[r]
+            for i, v in enumerate(views):
+                W.set_view(rt, v)
+                rt.dist_frame()
+                names[r].append(rt.kernel_name())
+                if i in reads:
+                    rt.dist_wait()        # (lets the box of the occupied cells reach the host between frames, as a renderer's frames do)
+                    if r == 0:
+                        got.append((v, rt.dist_read_frame().copy()))
+            rt.dist_wait()
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=180)
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    assert not errors, errors
+    for rt in ranks:
+        rt.deinit()
+    assert len(got) == len(reads)
+    for v, frame in got:
+        assert np.array_equal(frame, ref[v]), f"assembled frame of view {v} differs from the single-context frame"
+    for r in range(world):
+        assert all(n.startswith(("vrt_path_kernel<8, 5,", "vrt_pool_kernel<8, 5,")) for n in names[r]), names[r]
+        assert names[r][-1] == "vrt_pool_kernel<8, 5, 64, 2>", names[r]
+
+
+def test_bounce_frames_without_a_sample_buffer_keep_the_lockstep_kernel_in_the_pipeline():
+    """VRT_TUNE_NO_SAMPLE_UNITS: vrt_path_kernel would store whole RGBA pixels from whichever lane finished them — not a shard the
+    gather can carry — so the pipeline substitutes the lockstep kernel, as it did for every bounce frame until round 4."""
+    if not os.path.exists(FAKE):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
+    from zig_vulkan_amd import _lib as L
+    path = 1 << 23
+    w, grid = _bounce_scene()
+    views = ["V0", "V1x", "V2"]
+    ref, _ = _single_context_frames(w, grid, views, path)
     world = 2
-    uid = b"fake-rccl-path" + os.urandom(16) + bytes(128 - 30)
-    ranks = [W.make_renderer(w, grid, kernel_variant=path, shard_rank=r, shard_count=world) for r in range(world)]
+    uid = b"fake-rccl-lock" + os.urandom(16) + bytes(128 - 30)
+    ranks = [W.make_renderer(w, grid, kernel_variant=path, shard_rank=r, shard_count=world, tuning_flags=L.TUNE_NO_SAMPLE_UNITS) for r in range(world)]
     for r, rt in enumerate(ranks):
         rt.dist_init(uid, r, world, frames_in_flight=2, rccl_path=FAKE, frames_per_launch=1)
     got, errors = [], []
@@ -300,3 +367,51 @@ def test_bounce_frames_of_a_path_kernel_context_go_through_the_pipeline_on_the_l
     for v, frame, name in got:
         assert name.startswith("vrt_trace_kernel<8, false,"), name
         assert np.array_equal(frame, ref[v]), f"assembled frame of view {v} differs from the single-context frame"
+
+
+@pytest.mark.parametrize("world,frames_per_launch,bounce", [(2, 1, False), (4, 8, False), (8, 1, False), (2, 1, True)])
+def test_frames_submitted_by_one_call(world, frames_per_launch, bounce):
+    """vrt_dist_frames (a C-side multi-frame submit for the pipeline): n cameras, one call across the ABI; the frames
+    are those of n vrt_dist_frame calls."""
+    if not os.path.exists(FAKE):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
+    if bounce:
+        w, grid = _bounce_scene()
+        variant = 1 << 23
+    else:
+        w, grid, variant = W.Workload("t", 332, 210, 64, 4, 1, 0, True, 0.0), None, 0
+        grid = W.build_grid(w)
+    views = ["V0", "V1", "V2", "V1", "V2", "V0", "V0", "V2", "V1", "V1", "V0", "V2", "V0", "V1", "V2", "V2"]
+    plain = W.make_renderer(w, grid, kernel_variant=variant)
+    W.set_view(plain, views[-1])
+    plain.draw()
+    ref = plain.read_rgba8().copy()
+    plain.deinit()
+    uid = b"fake-rccl-many" + bytes([world, frames_per_launch]) + os.urandom(16) + bytes(128 - 32)
+    ranks = [W.make_renderer(w, grid, kernel_variant=variant, shard_rank=r, shard_count=world) for r in range(world)]
+    cams = []
+    for v in views:
+        W.set_view(ranks[0], v)
+        cams.append(bytes(ranks[0].camera.d_camera))
+    for r, rt in enumerate(ranks):
+        rt.dist_init(uid, r, world, frames_in_flight=4, rccl_path=FAKE, frames_per_launch=frames_per_launch)
+    errors = []
+
+    def drive(r):
+        try:
+            ranks[r].dist_frames(cams[:5])
+            ranks[r].dist_frames(cams[5:])
+            ranks[r].dist_wait()
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads) and not errors, errors
+    got = ranks[0].dist_read_frame()
+    for rt in ranks:
+        rt.deinit()
+    assert np.array_equal(got, ref)

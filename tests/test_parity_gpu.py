@@ -897,3 +897,94 @@ def test_pool_kernel_defers_the_hit_material_only_where_no_record_can_be_ignored
     fo2, uo2, _ = O.render(scene2, pc)
     assert np.array_equal(a[2][0].view(np.uint32), fo2.view(np.uint32)) and np.array_equal(a[2][1], uo2)
     assert not np.array_equal(uo, uo2)
+
+
+def test_frames_the_pool_kernel_cannot_take_keep_the_counter_free_path_kernel():
+    """vrt_pool_kernel packs the bounce count into 4 bits; a frame of more than 15 bounces used to fall back to
+    vrt_path_kernel<..., DIL 1> (steps-left counters in the walk loop) although the box of the occupied cells is the grid — now the DIL-2
+    twin is kept beside the pool kernel and takes such frames.  Same bytes as the lockstep kernel's frame."""
+    w = W.Workload("t", 208, 112, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000)
+    grid = W.build_grid(w)
+    out = {}
+    for variant in (PATH, 1 << 21):
+        rt = W.make_renderer(w, grid, kernel_variant=variant)
+        W.set_view(rt, "V0")
+        rt.draw()
+        rt.wait()      # (the box of the occupied cells has reached the host)
+        W.set_view(rt, "V2")
+        rt.draw()
+        first = rt.kernel_name()
+        rt.camera.d_camera.max_bounce = 17
+        rt.draw()
+        out[variant] = (rt.read_rgba8().copy(), first, rt.kernel_name())
+        rt.deinit()
+    assert out[PATH][1] == "vrt_pool_kernel<8, 5, 64, 2>" and out[PATH][2] == "vrt_path_kernel<8, 5, false, false, false, false, 2>", out[PATH][1:]
+    assert out[1 << 21][2].startswith("vrt_trace_kernel<8,")
+    assert np.array_equal(out[PATH][0], out[1 << 21][0]) and out[PATH][0].any()
+
+
+def test_sample_buffers_reserved_up_front_and_kept_when_growth_fails():
+    """ADVICE r04: vrt_reserve_samples sizes the persistent kernels' sample buffers once (no allocation, no drain inside a dispatch);
+    a request no memory can serve — 65 535 samples per pixel of a 4K frame — is VRT_E_OOM / VRT_E_OUT_OF_RANGE and leaves the context
+    as it was: the next frames are still vrt_pool_kernel's and still right.  Contexts without persistent kernels have nothing to reserve."""
+    from zig_vulkan_amd import _lib as L
+    w = W.Workload("t", 208, 112, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000)
+    grid = W.build_grid(w)
+    ref = W.make_renderer(w, grid, kernel_variant=1 << 21)
+    W.set_view(ref, "V2")
+    ref.camera.d_camera.samples_per_pixel = 7
+    ref.draw()
+    want = ref.read_rgba8().copy()
+    ref.reserve_samples(64)          # (the lockstep kernel: nothing to reserve, VRT_OK)
+    ref.deinit()
+    for fif in (1, 2):
+        rt = W.make_renderer(w, grid, kernel_variant=PATH, frames_in_flight=fif)
+        rt.reserve_samples(7)
+        W.set_view(rt, "V0")
+        rt.draw()
+        rt.wait()
+        W.set_view(rt, "V2")
+        rt.camera.d_camera.samples_per_pixel = 7
+        for _ in range(3):
+            rt.draw()
+        assert rt.kernel_name() == "vrt_pool_kernel<8, 5, 64, 2>" and np.array_equal(rt.read_rgba8(), want)
+        with pytest.raises(L.VrtError):
+            rt.reserve_samples(70000)
+        big = W.make_renderer(W.Workload("big", 3840, 2160, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000), grid, kernel_variant=PATH)
+        with pytest.raises(L.VrtError) as e:
+            big.reserve_samples(65535)      # 8.3 M pixels x 65 535 samples: beyond the 32-bit unit counter
+        assert e.value.code in (L.VRT_E_OOM, L.VRT_E_OUT_OF_RANGE)
+        big.deinit()
+        rt.draw()
+        rt.draw()
+        assert rt.kernel_name() == "vrt_pool_kernel<8, 5, 64, 2>" and np.array_equal(rt.read_rgba8(), want)
+        rt.deinit()
+
+
+def test_wave_timeline_across_a_change_of_the_schedule_rule():
+    """vrt_trace_wave_timeline sized its device buffer by the spare workgroups of the CURRENT schedule rule and
+    then dispatched a frame that may change the rule (two samples per pixel: every tile may be split) — the launch then wrote rows past
+    the buffer.  The buffer now holds a row for every wave any rule can launch, and the row count is that of the launch: timelines of
+    1-, 2-, 1-sample frames in turn, each followed by a plain frame that must still be the fresh context's."""
+    w = W.Workload("t", 1024, 576, 256, 4, 1, 2, True, 5.0)
+    grid = W.build_grid(w)
+    fresh = {}
+    for spp in (1, 2):
+        rt = W.make_renderer(w, grid, kernel_variant=1 << 21)
+        W.set_view(rt, "V1")
+        rt.camera.d_camera.samples_per_pixel = spp
+        rt.draw()
+        fresh[spp] = rt.read_rgba8().copy()
+        rt.deinit()
+    rt = W.make_renderer(w, grid, kernel_variant=1 << 21)
+    tiles = rt.shard_info().owned_tiles
+    W.set_view(rt, "V1")
+    for spp in (1, 2, 1, 2, 2, 1):
+        rt.camera.d_camera.samples_per_pixel = spp
+        rt.draw(frames=40)           # (past a sort of the cost schedule under this rule)
+        rows = rt.wave_timeline(raw=True)
+        assert tiles * 4 <= len(rows) <= tiles * 8, (spp, len(rows), tiles)
+        assert (rows[:, 1] >= rows[:, 0]).all()
+        rt.draw()
+        assert np.array_equal(rt.read_rgba8(), fresh[spp]), spp
+    rt.deinit()

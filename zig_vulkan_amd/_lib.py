@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (VRT_HIP_LIB: development builds of the same library, e.g. the phase-profile build of tools/frame_phases.py)
 LIB_PATH = os.environ.get("VRT_HIP_LIB") or os.path.join(_HERE, "libvrt_hip.so")
 
-VRT_ABI_VERSION = 2
+VRT_ABI_VERSION = 3
 
 VRT_OK = 0
 VRT_E_INVALID_ARG = -1
@@ -176,6 +176,8 @@ SIGNATURES = {
     "vrt_dist_init": (C.c_int, [_ctx, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32]),
     "vrt_dist_init_batched": (C.c_int, [_ctx, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32]),
     "vrt_dist_frame": (C.c_int, [_ctx, _P(CameraDevice), _P(SunDevice)]),
+    "vrt_dist_frames": (C.c_int, [_ctx, _P(CameraDevice), _P(SunDevice), C.c_uint32, C.c_uint32]),
+    "vrt_reserve_samples": (C.c_int, [_ctx, C.c_uint32]),
     "vrt_dist_wait": (C.c_int, [_ctx]),
     "vrt_dist_read_frame": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
     "vrt_dist_selftest": (C.c_int, [_ctx]),

@@ -1,251 +1,29 @@
-// vrt_api.hip — implementation of the C ABI in include/vrt_hip.h: context
-// (device buffers, stream, events), stream-ordered uploads through a pinned
-// staging ring, dispatch of the traversal kernel, read-back, timing.
+// vrt_api.hip — the context behind the C ABI of include/vrt_hip.h: creation (device buffers, streams, events, kernel
+// selection), destruction, the seven stream-ordered uploads through a pinned staging ring, read-back, counters.
+// The frame itself is vrt_frame.hip, the multi-GPU pipeline vrt_dist.hip, the present pass vrt_post.hip.
 //
-// Replaces src/modules/voxel_rt/ComputePipeline.zig (init / dispatch / deinit)
-// and the Pipeline.transfer* family (Pipeline.zig:560-652) with its StagingRamp
-// (render/StagingRamp.zig) for this one path.  There is no CPU fallback: without
-// a HIP device vrt_create fails with VRT_E_NO_DEVICE.
+// Replaces src/modules/voxel_rt/ComputePipeline.zig (init / deinit) and the Pipeline.transfer* family
+// (Pipeline.zig:560-652) with its StagingRamp (render/StagingRamp.zig) for this one path.  There is no CPU fallback:
+// without a HIP device vrt_create fails with VRT_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
-#include <dlfcn.h>
-#include <rccl/rccl.h> // types and prototypes only: the library is reached through dlopen, not linked
 #include <algorithm>
-#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
-#include <vector>
 #include <thread>
 #include "host_brick_grid.hpp"
-#include "vrt_internal.h"
-#include "vrt_kernels.h"
+#include "vrt_ctx.h"
 
-namespace vrt {
-KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t variant, int shade);
-KernelFn path_kernel_halfblock_twin(KernelFn fn);
-KernelFn path_kernel_ahead_twin(KernelFn fn);
-KernelFn path_kernel_dist_twin(KernelFn fn);
-KernelFn path_kernel_dilated_twin(KernelFn fn, int kind);
-int path_kernel_dilated_kind(KernelFn fn);
-bool is_path_halfblock_kernel(KernelFn fn);
-const char *kernel_name_of(KernelFn fn);
-uint32_t resolve_variant(uint32_t variant);
-size_t trace_lds_bytes(const TraceParams &p, uint32_t variant);
-hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hipStream_t stream, uint32_t frames = 1);
-bool is_path_kernel(KernelFn fn);
-hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra_max, uint32_t extra, uint32_t wave_slots,
-                           hipStream_t stream);
-hipError_t launch_assemble_rgb(const void *gathered, void *frame, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t shard_count,
-                               uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream, uint32_t frames, uint32_t frame_src_stride_bytes);
-hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
-hipError_t launch_build_status_bytes(const TraceParams &p, hipStream_t stream);
-hipError_t launch_build_status_halfblocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
-hipError_t launch_build_cell_distance(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
-hipError_t launch_build_cell_bounds(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
-hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, uint64_t cell_lo, uint64_t cell_hi, uint64_t slot_lo,
-                                       uint64_t slot_hi, hipStream_t stream);
-hipError_t launch_check_start_is_slot(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, hipStream_t stream);
-hipError_t launch_check_materials_plain(const TraceParams &p, uint32_t count, hipStream_t stream);
-hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
-                          void *out_f32, hipStream_t stream);
-hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per_pixel, uint32_t width, uint32_t height, uint32_t tiles_x,
-                           uint32_t shard_count, uint32_t tiles_per_rank, const TileOwnership &own, hipStream_t stream, uint32_t frames = 1,
-                           uint32_t frame_src_stride_pixels = 0);
-} // namespace vrt
+using namespace vrt_impl;
 
 namespace {
 thread_local std::string g_create_error;
-
-constexpr size_t kStagingSlotBytes = 32u << 20; // pinned staging slot
-constexpr int kStagingSlots = 2;
 } // namespace
 
-// RCCL entry points resolved with dlsym from the library the host process already uses.
-struct RcclApi {
-    void *lib = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclSend) Send = nullptr;
-    decltype(&ncclRecv) Recv = nullptr;
-    decltype(&ncclBroadcast) Broadcast = nullptr; // optional: replica updates fall back to send / recv from the root
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    decltype(&ncclCommCount) CommCount = nullptr;       // optional (vrt_dist_info)
-    decltype(&ncclCommUserRank) CommUserRank = nullptr; // optional
-    bool load(const char *path, std::string &err) {
-        lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) {
-            err = std::string("dlopen(") + (path ? path : "NULL") + "): " + dlerror();
-            return false;
-        }
-#define VRT_RCCL_SYM(field, name)                                   \
-        field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); \
-        if (!field) {                                                \
-            err = std::string("dlsym ") + name + " failed";         \
-            return false;                                            \
-        }
-        VRT_RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
-        VRT_RCCL_SYM(CommInitRank, "ncclCommInitRank")
-        VRT_RCCL_SYM(CommDestroy, "ncclCommDestroy")
-        VRT_RCCL_SYM(GroupStart, "ncclGroupStart")
-        VRT_RCCL_SYM(GroupEnd, "ncclGroupEnd")
-        VRT_RCCL_SYM(Send, "ncclSend")
-        VRT_RCCL_SYM(Recv, "ncclRecv")
-        VRT_RCCL_SYM(GetErrorString, "ncclGetErrorString")
-#undef VRT_RCCL_SYM
-        Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(lib, "ncclBroadcast"));
-        CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
-        CommUserRank = reinterpret_cast<decltype(CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
-        return true;
-    }
-};
-
-constexpr uint32_t kMaxDistSlots = 8;
-
-// One launch in flight of the multi-GPU pipeline: its stream carries kernel -> gather -> un-swizzle for a batch of up to
-// `batch` consecutive frames (see Dist).
-struct DistSlot {
-    hipStream_t stream = nullptr;
-    uint8_t *shard = nullptr;    // this rank's packed tiles, frame-major: batch x shard_bytes (on rank 0: region 0 of `gathered`)
-    uint8_t *gathered = nullptr; // rank 0: world x batch x shard_bytes, rank-major then frame-major
-    uint8_t *frame = nullptr;    // rank 0: batch row-major RGBA8 frames
-    hipEvent_t done = nullptr;
-    uint64_t seen_upload = 0;
-    uint32_t frames = 0;         // frames of the batch this slot holds
-    bool used = false;
-    // vrt_dist_profile: events around the three stages of the slot's most recent launch (kernel | collective | un-swizzle)
-    hipEvent_t mark[4] = {};
-    bool marked = false;         // the most recent launch recorded its marks and they have not been read yet
-};
-
-struct Dist {
-    RcclApi api;
-    ncclComm_t comm = nullptr;
-    int rank = 0, world = 1;
-    uint32_t nslots = 0;
-    DistSlot slots[kMaxDistSlots];
-    uint64_t frame_no = 0;       // batches launched so far (slot = frame_no % nslots)
-    int last_slot = -1;
-    size_t shard_bytes = 0;
-    // Frames are traced `batch` to a launch (grid.y): a rank owns 1/world of the tiles, too few waves to fill the GPU
-    // and no shorter than the frame's longest wave, so single-frame launches leave most of the machine idle
-    // (tools/shard_streams.py: 19-31 us per 1/8 frame with eight single-frame launches in flight, against 8-18 us for
-    // an eighth of a whole-frame launch).  vrt_dist_frame queues; a full queue, vrt_dist_wait, vrt_dist_read_frame or a
-    // scene upload launches what is queued.
-    uint32_t batch = 1;
-    bool failed = false;         // a collective failed: peers are out of step, every later vrt_dist_* call fails
-    uint32_t npend = 0;
-    vrt::PushConstants pend[vrt::kMaxBatchFrames];
-    vrt::KernelFn pend_fn = nullptr;
-    // vrt_dist_profile / vrt_dist_stats: per-launch stage times, summed over the launches sampled
-    bool profile = false;
-    uint64_t prof_launches = 0, prof_frames = 0;
-    double prof_ms[3] = {0.0, 0.0, 0.0}; // kernel, collective, un-swizzle
-};
-
-struct vrt_ctx {
-    vrt_config cfg{};
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    // second frame slot (frames_in_flight == 2): own stream + own target images
-    uint32_t frames_in_flight = 1;
-    hipStream_t stream_b = nullptr;
-    uint8_t *target8_b = nullptr;
-    float *target32f_b = nullptr;
-    hipEvent_t ev_b_done = nullptr, ev_upload = nullptr;
-    bool b_pending = false;          // stream_b has frames the primary stream has not been ordered after
-    uint64_t upload_seq = 0, b_seen_upload = 0;
-    uint32_t frame_seq = 0;
-    int last_slot = 0;
-    void *dbuf[VRT_BUF_COUNT] = {};
-    uint64_t dsize[VRT_BUF_COUNT] = {};
-    uint8_t *target8 = nullptr;
-    float *target32f = nullptr;
-    bool own_t8 = false, own_t32 = false;
-    uint64_t target_pixels = 0; // pixels in the (possibly sharded, padded) target
-    vrt::DeviceCounters *d_counters = nullptr;
-    uint32_t *d_tile_cost = nullptr, *d_tile_schedule = nullptr; // cost-feedback tile schedule (two order buffers + snapshot)
-    // amortised cost-feedback schedule (tile_order 7): re-sorted every sched_period frames into the other buffer
-    uint32_t sched_period = 0, sched_since = 0, sched_cur = 0;
-    bool order_auto = false; // kernel_variant left the tile order to the library
-    uint32_t bounce_variant = 0; // kernel_variant with the occupancy choice of the bounce kernel filled in
-    uint32_t single_variant = 0; // kernel_variant with the library's choice of mode for frames without bounces filled in
-    uint32_t tile_order = 0, sched_extra = 0, sched_stride = 0, wave_slots = 0;
-    // the cost schedule's two rules (index 1: frames whose split tiles trace their second sample on the idle lanes — two samples per
-    // pixel — where a split costs nothing but the second workgroup's fixed part): how many tiles an order may split, and the wave
-    // slots the "time the frame needs anyway" is computed for; sched_mode: the rule the current order was sorted under
-    uint32_t sched_cap[2] = {0, 0}, sched_slots[2] = {0, 0}, sched_mode = 0;
-    uint64_t sched_seq = 0, b_seen_sched = 0;
-    hipEvent_t ev_sched = nullptr, ev_b_sched = nullptr;
-    bool b_sched_recorded = false;
-    void *d_denoised8 = nullptr, *d_denoised32f = nullptr;       // output of the present/denoise pass
-    struct Dist *dist = nullptr;                                 // multi-GPU frame pipeline (vrt_dist_*)
-    uint32_t denoised_w = 0, denoised_h = 0;
-    hipStream_t denoised_stream = nullptr;
-    void *d_status_blocks = nullptr; // derived: 4x4x4 block words + block filter (vrt_trace.hip)
-    int *d_cell_bounds = nullptr;    // derived: bounding box of the occupied cells (TraceParams::cell_bounds)
-    // The host's copy of that box (read back behind every rebuild, never waited for): when it is, or nearly is, the grid, bounce
-    // frames of a context whose kernel is the dilated-index path kernel are traced by its twin without steps-left counters.
-    int *h_cell_bounds = nullptr;
-    hipEvent_t ev_bounds = nullptr;
-    bool bounds_pending = false, box_is_grid = false;
-    vrt::KernelFn kernel_grid_exit = nullptr, product_grid_exit = nullptr;
-    uint8_t *d_status_bytes = nullptr; // derived: one byte per grid cell (TraceParams::status_bytes)
-    uint8_t *d_cell_distance = nullptr;      // derived: L1 distance of every cell to the nearest occupied cell (vrt_path_kernel<DIST>)
-    uint32_t *d_status_halfblocks = nullptr; // derived: status bits by 4 x 4 x 2 cells per word (vrt_path_kernel on eligible grids)
-    bool cell_occupancy_lockstep = false;    // ... read by the lockstep bounce kernel too (scenes that stay in the caches)
-    uint8_t *d_cell_occupancy = nullptr;     // derived: occupancy bits by cell (TraceParams::cell_occupancy; vrt_path_kernel, within a memory budget)
-    uint32_t *d_start_is_slot = nullptr;     // derived: 1 = binding 6 holds slot * B^3 for every allocated brick (TraceParams::start_is_slot)
-    bool occupancy_dirty = true;             // bindings 3-5 changed since the by-cell copy was built ...
-    // ... in these ranges (the reference issues a single-brick delta every frame, VoxelRT.zig:107-172; the copy is then
-    // refreshed for the cells and brick slots it names, not gathered anew over the whole grid): cells whose status bit / brick index
-    // changed and brick slots whose occupancy bytes changed, both [lo, hi); lo >= hi: none
-    uint64_t occ_cell_lo = 0, occ_cell_hi = ~0ull, occ_slot_lo = 0, occ_slot_hi = 0;
-    uint32_t *d_materials_plain = nullptr;   // derived: 1 = no material record has the type MAT_NONE (TraceParams::materials_plain)
-    bool materials_dirty = true;             // binding 0 changed since it was checked
-    bool start_dirty = true;                 // binding 6 changed since it was checked
-    vrt::TileOwnership own{};        // weighted tile ownership (period 0: tile t belongs to rank t % shard_count)
-    bool status_dirty = true;        // brick_status changed since the derived copy was built
-    size_t lds_bytes = 0;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool split_ok = false;   // small frames may go to half-tile workgroups (vrt_create's conditions other than the number of waves)
-    uint32_t simds = 1024u;
-    hipEvent_t ev_region[4] = {}; // vrt_region_begin / _end: {begin, end} on the primary stream, {begin, end} on the second
-    hipEvent_t ev_post_start = nullptr, ev_post_stop = nullptr; // around the most recent present / denoise pass (vrt_last_denoise_ms)
-    bool post_timed = false;
-    bool in_flight = false;
-    bool timing_valid = false;
-    uint32_t timed_frames = 0;
-    double last_ms = -1.0;
-    void *staging[kStagingSlots] = {};
-    hipEvent_t staging_ev[kStagingSlots] = {};
-    bool staging_busy[kStagingSlots] = {};
-    int staging_next = 0;
-    vrt::TraceParams params{};
-    vrt::KernelFn kernel = nullptr;        // frames with bounces: persistent lanes (vrt_path_kernel) unless kernel_variant bit 21
-    vrt::KernelFn kernel_lockstep = nullptr; // ... the lockstep bounce loop (always used by the multi-GPU pipeline: RGB shards)
-    uint32_t *d_work_counter = nullptr;    // vrt_path_kernel's pixel counters: [2 streams][kMaxBatchFrames]
-    uint32_t *d_pool_paths = nullptr;      // vrt_pool_kernel's path records: [2 streams][pool_groups * 4 waves][16 dwords][128 paths]
-    size_t pool_stream_dwords = 0;
-    float4 *d_pool_samples = nullptr;      // vrt_pool_kernel -> vrt_pool_resolve_kernel: [2 streams][owned pixels][samples] terms of the sample sum, sized by the frames asked for
-    size_t pool_samples_stream_elems = 0;
-    uint32_t path_lds_bytes = 0;           // LDS block filter of vrt_path_kernel (0: grid not eligible)
-    vrt::KernelFn kernel_single = nullptr; // specialisation for max_bounce <= 1
-    vrt::KernelFn kernel_single1 = nullptr; // ... and samples_per_pixel == 1
-    vrt::KernelFn product[3] = {};         // counting contexts: the product kernel that renders the frame read back, by shade (0 bounces, 1, 2)
-    vrt::KernelFn last_fn = nullptr;       // the kernel of the most recent frame (vrt_kernel_name)
-    vrt_shard_info shard{};
-    std::string err;
-    std::string kernel_name, name_note;
-};
-
-namespace {
+namespace vrt_impl {
 
 int fail(vrt_ctx *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg;
@@ -253,143 +31,17 @@ int fail(vrt_ctx *ctx, int code, const std::string &msg) {
     return code;
 }
 
-// remember which kernel rendered the most recent frame (vrt_kernel_name reports what ran, not what was asked for)
-void note_kernel(vrt_ctx *c, vrt::KernelFn fn) {
-    if (fn == c->last_fn) return;
-    c->last_fn = fn;
-    c->kernel_name = std::string(vrt::kernel_name_of(fn)) + c->name_note;
-}
-
-int hip_fail(vrt_ctx *ctx, hipError_t e, const char *what) {
-    return fail(ctx, e == hipErrorOutOfMemory ? VRT_E_OOM : VRT_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
-}
-
-#define VRT_HIP(ctx, call)                                  \
-    do {                                                    \
-        hipError_t e_ = (call);                             \
-        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
-    } while (0)
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
 void free_ctx(vrt_ctx *c) {
     if (!c) return;
     DeviceGuard dg(c->device); // the caller's current device is restored on return
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (int i = 0; i < VRT_BUF_COUNT; i++)
-        if (c->dbuf[i]) (void)hipFree(c->dbuf[i]);
-    if (c->own_t8 && c->target8) (void)hipFree(c->target8);
-    if (c->own_t32 && c->target32f) (void)hipFree(c->target32f);
-    if (c->d_counters) (void)hipFree(c->d_counters);
-    if (c->d_work_counter) (void)hipFree(c->d_work_counter);
-    if (c->d_pool_paths) (void)hipFree(c->d_pool_paths);
-    if (c->d_pool_samples) (void)hipFree(c->d_pool_samples);
-    if (c->d_status_blocks) (void)hipFree(c->d_status_blocks);
-    if (c->d_cell_bounds) (void)hipFree(c->d_cell_bounds);
-    if (c->h_cell_bounds) (void)hipHostFree(c->h_cell_bounds);
-    if (c->ev_bounds) (void)hipEventDestroy(c->ev_bounds);
-    if (c->d_status_bytes) (void)hipFree(c->d_status_bytes);
-    if (c->d_status_halfblocks) (void)hipFree(c->d_status_halfblocks);
-    if (c->d_cell_distance) (void)hipFree(c->d_cell_distance);
-    if (c->d_cell_occupancy) (void)hipFree(c->d_cell_occupancy);
-    if (c->d_start_is_slot) (void)hipFree(c->d_start_is_slot);
-    if (c->d_materials_plain) (void)hipFree(c->d_materials_plain);
-    if (c->dist) {
-        Dist *d = c->dist;
-        for (uint32_t i = 0; i < d->nslots; i++) {
-            DistSlot &sl = d->slots[i];
-            if (sl.stream) {
-                (void)hipStreamSynchronize(sl.stream);
-                (void)hipStreamDestroy(sl.stream);
-            }
-            if (sl.gathered) (void)hipFree(sl.gathered);
-            else if (sl.shard) (void)hipFree(sl.shard);
-            if (sl.frame) (void)hipFree(sl.frame);
-            if (sl.done) (void)hipEventDestroy(sl.done);
-            for (hipEvent_t e : sl.mark)
-                if (e) (void)hipEventDestroy(e);
-        }
-        if (d->comm && d->api.CommDestroy) (void)d->api.CommDestroy(d->comm);
-        delete d;
-        c->dist = nullptr;
-    }
-    if (c->d_denoised8) (void)hipFree(c->d_denoised8);
-    if (c->d_denoised32f) (void)hipFree(c->d_denoised32f);
-    if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
-    if (c->d_tile_schedule) (void)hipFree(c->d_tile_schedule);
-    if (c->ev_sched) (void)hipEventDestroy(c->ev_sched);
-    if (c->ev_b_sched) (void)hipEventDestroy(c->ev_b_sched);
-    for (int i = 0; i < kStagingSlots; i++) {
-        if (c->staging[i]) (void)hipHostFree(c->staging[i]);
-        if (c->staging_ev[i]) (void)hipEventDestroy(c->staging_ev[i]);
-    }
-    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
-    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
-    for (hipEvent_t e : c->ev_region)
-        if (e) (void)hipEventDestroy(e);
-    if (c->ev_post_start) (void)hipEventDestroy(c->ev_post_start);
-    if (c->ev_post_stop) (void)hipEventDestroy(c->ev_post_stop);
-    if (c->stream_b) {
-        (void)hipStreamSynchronize(c->stream_b);
-        (void)hipStreamDestroy(c->stream_b);
-    }
-    if (c->target8_b) (void)hipFree(c->target8_b);
-    if (c->target32f_b) (void)hipFree(c->target32f_b);
-    if (c->ev_b_done) (void)hipEventDestroy(c->ev_b_done);
-    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    dist_destroy(c);      // (its streams are drained and its communicator closed before the memory they use goes)
+    c->res.release_all(); // every allocation, event and stream the context made, in reverse order
     delete c;
 }
 
-// Waiting for a stream / an event: poll for up to a few milliseconds before handing the thread to the runtime's blocking wait.
-// The blocking wait sleeps on an interrupt and wakes up tens of microseconds after the GPU has finished — as long as a whole
-// frame of the headline workload (tools/short_trace.py: a 20-frame region took 1.45 ms on the GPU and 1.59 ms on the host's clock).
-template <typename Query>
-hipError_t poll_then(Query query) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        for (int i = 0; i < 64; i++) {
-            const hipError_t e = query();
-            if (e != hipErrorNotReady) return e;
-        }
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipErrorNotReady; // long frame: sleep instead
-    }
-}
-hipError_t wait_stream(hipStream_t s) {
-    const hipError_t e = poll_then([&] { return hipStreamQuery(s); });
-    return e == hipErrorNotReady ? hipStreamSynchronize(s) : e;
-}
-hipError_t wait_event(hipEvent_t ev) {
-    const hipError_t e = poll_then([&] { return hipEventQuery(ev); });
-    return e == hipErrorNotReady ? hipEventSynchronize(ev) : e;
-}
-
-// wait for the frame in flight (the fence wait of ComputePipeline.zig:423-434)
-int finish_frame(vrt_ctx *c) {
-    if (!c->in_flight) return VRT_OK;
-    VRT_HIP(c, wait_event(c->ev_stop));
-    float ms = 0.0f;
-    VRT_HIP(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
-    c->last_ms = (double)ms / (double)(c->timed_frames ? c->timed_frames : 1u);
-    c->timing_valid = true;
-    c->in_flight = false;
-    return VRT_OK;
-}
-
-// Scene writes happen on the primary stream.  With two frames in flight they must not overtake a frame
-// that is still reading the scene on stream_b, and later frames on stream_b must see them.
-int dist_flush(vrt_ctx *ctx);
 int begin_scene_write(vrt_ctx *c) {
-    if (c->dist && c->dist->npend) { // frames queued before this write must see the scene as it was
+    if (dist_has_pending(c)) { // frames queued before this write must see the scene as it was
         const int rcf = dist_flush(c);
         if (rcf != VRT_OK) return rcf;
     }
@@ -397,11 +49,7 @@ int begin_scene_write(vrt_ctx *c) {
         VRT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_b_done, 0));
         c->b_pending = false;
     }
-    if (c->dist) {
-        for (uint32_t i = 0; i < c->dist->nslots; i++)
-            if (c->dist->slots[i].used) VRT_HIP(c, hipStreamWaitEvent(c->stream, c->dist->slots[i].done, 0));
-    }
-    return VRT_OK;
+    return dist_order_primary_after_slots(c);
 }
 int end_scene_write(vrt_ctx *c) {
     if (c->stream_b || c->dist) {
@@ -411,6 +59,38 @@ int end_scene_write(vrt_ctx *c) {
     return VRT_OK;
 }
 
+// which derived structures a write to scene buffer `id` invalidates (rebuilt before the next frame, pre_dispatch)
+void mark_dirty(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, uint64_t nbytes) {
+    if (id == VRT_BUF_BRICK_STATUS) ctx->status_dirty = true;
+    if (id == VRT_BUF_BRICK_START_INDEX) ctx->start_dirty = true;
+    if (id == VRT_BUF_MATERIALS) ctx->materials_dirty = true;
+    if (id != VRT_BUF_BRICK_STATUS && id != VRT_BUF_BRICK_INDEX && id != VRT_BUF_BRICK_OCCUPANCY) return;
+    auto widen = [](uint64_t &lo, uint64_t &hi, uint64_t a, uint64_t b) {
+        if (lo >= hi) lo = a, hi = b;
+        else lo = std::min(lo, a), hi = std::max(hi, b);
+    };
+    const uint64_t end = byte_offset + nbytes;
+    if (id == VRT_BUF_BRICK_STATUS) widen(ctx->occ_cell_lo, ctx->occ_cell_hi, byte_offset * 8u, end * 8u);
+    else if (id == VRT_BUF_BRICK_INDEX) widen(ctx->occ_cell_lo, ctx->occ_cell_hi, byte_offset / 4u, (end + 3u) / 4u);
+    else {
+        const uint64_t brick_bytes = (uint64_t)ctx->cfg.brick_dimension * ctx->cfg.brick_dimension * ctx->cfg.brick_dimension / 8u;
+        widen(ctx->occ_slot_lo, ctx->occ_slot_hi, byte_offset / brick_bytes, (end + brick_bytes - 1u) / brick_bytes);
+    }
+    ctx->occupancy_dirty = true;
+}
+
+// the unit counters and (contexts that select vrt_pool_kernel) the path records of one stream of persistent-kernel frames
+int lane_init(vrt_ctx *c, vrt::PersistentLane &lane) {
+    if (lane.work_counter) return VRT_OK;
+    VRT_HIP(c, c->res.device(&lane.work_counter, vrt::kMaxBatchFrames * sizeof(uint32_t)));
+    VRT_HIP(c, hipMemsetAsync(lane.work_counter, 0, vrt::kMaxBatchFrames * sizeof(uint32_t), c->stream));
+    // (never read before it is written: a path's record is filled by the transition that gives the path its first pixel)
+    if (c->pool_stream_dwords) VRT_HIP(c, c->res.device(&lane.pool_paths, c->pool_stream_dwords * sizeof(uint32_t)));
+    return VRT_OK;
+}
+} // namespace vrt_impl
+
+namespace {
 // Host copy into the pinned slot.  One core moves ~20 GB/s, a third of the PCIe Gen5 x16 link the DMA
 // that follows can use, so large pieces are split over a few short-lived threads.
 void staging_copy(void *dst, const uint8_t *src, size_t n) {
@@ -556,13 +236,12 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (cfg->stream) {
         c->stream = static_cast<hipStream_t>(cfg->stream);
     } else {
-        VRT_CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
+        VRT_CREATE_HIP(c->res.stream(&c->stream));
     }
-    VRT_CREATE_HIP(hipEventCreate(&c->ev_start));
-    VRT_CREATE_HIP(hipEventCreate(&c->ev_stop));
-    VRT_CREATE_HIP(hipEventCreate(&c->ev_post_start));
-    VRT_CREATE_HIP(hipEventCreate(&c->ev_post_stop));
+    VRT_CREATE_HIP(c->res.event(&c->ev_start));
+    VRT_CREATE_HIP(c->res.event(&c->ev_stop));
+    VRT_CREATE_HIP(c->res.event(&c->ev_post_start));
+    VRT_CREATE_HIP(c->res.event(&c->ev_post_stop));
 
     // buffer sizes as Pipeline.zig:273-283 derives them from the State slices
     c->dsize[VRT_BUF_GRID_STATE] = sizeof(vrt_grid_state);
@@ -578,7 +257,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         // a voxel whose id is beyond the uploaded table reads a zero record instead of foreign memory.
         uint64_t alloc = c->dsize[i] + 16u;
         if (i == VRT_BUF_MATERIALS) alloc = std::max<uint64_t>(alloc, 256u * sizeof(vrt_material) + 16u);
-        VRT_CREATE_HIP(hipMalloc(&c->dbuf[i], alloc));
+        VRT_CREATE_HIP(c->res.device(&c->dbuf[i], alloc));
         VRT_CREATE_HIP(hipMemsetAsync(c->dbuf[i], 0, alloc, c->stream));
     }
 
@@ -638,26 +317,24 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (cfg->external_target_rgba8) {
         c->target8 = static_cast<uint8_t *>(cfg->external_target_rgba8);
     } else {
-        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->target8), c->target_pixels * 4u));
-        c->own_t8 = true;
+        VRT_CREATE_HIP(c->res.device(&c->target8, c->target_pixels * 4u));
         VRT_CREATE_HIP(hipMemsetAsync(c->target8, 0, c->target_pixels * 4u, c->stream));
     }
     if (cfg->external_target_rgba32f) {
         c->target32f = static_cast<float *>(cfg->external_target_rgba32f);
     } else if (cfg->want_float_output) {
-        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->target32f), c->target_pixels * 16u));
-        c->own_t32 = true;
+        VRT_CREATE_HIP(c->res.device(&c->target32f, c->target_pixels * 16u));
         VRT_CREATE_HIP(hipMemsetAsync(c->target32f, 0, c->target_pixels * 16u, c->stream));
     }
     if (cfg->frames_in_flight == 2 && !cfg->stream && !cfg->external_target_rgba8 && !cfg->external_target_rgba32f && !cfg->enable_counters) {
         c->frames_in_flight = 2;
-        VRT_CREATE_HIP(hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
-        VRT_CREATE_HIP(hipEventCreateWithFlags(&c->ev_b_done, hipEventDisableTiming));
-        VRT_CREATE_HIP(hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
-        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->target8_b), c->target_pixels * 4u));
+        VRT_CREATE_HIP(c->res.stream(&c->stream_b));
+        VRT_CREATE_HIP(c->res.event(&c->ev_b_done, hipEventDisableTiming));
+        VRT_CREATE_HIP(c->res.event(&c->ev_upload, hipEventDisableTiming));
+        VRT_CREATE_HIP(c->res.device(&c->target8_b, c->target_pixels * 4u));
         VRT_CREATE_HIP(hipMemsetAsync(c->target8_b, 0, c->target_pixels * 4u, c->stream));
         if (c->target32f) {
-            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->target32f_b), c->target_pixels * 16u));
+            VRT_CREATE_HIP(c->res.device(&c->target32f_b, c->target_pixels * 16u));
             VRT_CREATE_HIP(hipMemsetAsync(c->target32f_b, 0, c->target_pixels * 16u, c->stream));
         }
     } else if (cfg->frames_in_flight > 2) {
@@ -665,11 +342,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         return fail(nullptr, VRT_E_INVALID_ARG, "frames_in_flight must be 0, 1 or 2");
     }
     if (cfg->enable_counters) {
-        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_counters), sizeof(vrt::DeviceCounters)));
+        VRT_CREATE_HIP(c->res.device(&c->d_counters, sizeof(vrt::DeviceCounters)));
         VRT_CREATE_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(vrt::DeviceCounters), c->stream));
     }
     const uint32_t nbx = (cfg->dim_x + 3u) / 4u, nby = (cfg->dim_y + 3u) / 4u, nbz = (cfg->dim_z + 3u) / 4u;
-    VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_cell_bounds), 6 * sizeof(int)));
+    VRT_CREATE_HIP(c->res.device(&c->d_cell_bounds, 6 * sizeof(int)));
     VRT_CREATE_HIP(hipMemsetAsync(c->d_cell_bounds, 0x80, 6 * sizeof(int), c->stream)); // no cell occupied yet
     // (the other derived copies of the status bits — byte per cell, half-block words, 4^3 block words — are allocated further
     // down, each only when a kernel this context selects reads it)
@@ -699,10 +376,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         // (with the halves in cost classes of their own — vrt_schedule_kernel, round 4 — a lower bar pays: 28 / 40 / 52 / 64 / 96 slots
         // per CU 0.300 / 0.260 / 0.259 / 0.259 / 0.259 ms on V0, 0.323 / 0.285 / 0.262 / 0.255 / 0.257 on V1, 0.350 / 0.312 / 0.286 / 0.284 / 0.282 on V2)
         c->sched_slots[1] = 64u * (uint32_t)cus;
-        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_tile_cost), n * 32u)); // [half][tile][wave]
+        VRT_CREATE_HIP(c->res.device(&c->d_tile_cost, n * 32u)); // [half][tile][wave]
         const uint32_t ns = 8u * ((n + c->sched_extra + 7u) / 8u); // an order buffer is stored XCD-major: 8 rows of ceil((n + extra) / 8)
         c->sched_stride = ns;
-        VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_tile_schedule), (2u * (size_t)ns + 2u * (size_t)n) * 4u)); // order A, order B, snapshot + split state
+        VRT_CREATE_HIP(c->res.device(&c->d_tile_schedule, (2u * (size_t)ns + 2u * (size_t)n) * 4u)); // order A, order B, snapshot + split state
         VRT_CREATE_HIP(hipMemsetAsync(c->d_tile_cost, 0, n * 32u, c->stream));
         VRT_CREATE_HIP(hipMemsetAsync(c->d_tile_schedule + 2u * (size_t)ns, 0, 2u * (size_t)n * 4u, c->stream));
         uint32_t *init = static_cast<uint32_t *>(std::malloc((size_t)ns * 4u));
@@ -720,8 +397,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (n > 1u) VRT_CREATE_HIP(vrt::launch_schedule(c->d_tile_cost, c->d_tile_schedule + 2u * (size_t)ns, c->d_tile_schedule, c->d_tile_schedule + ns, n, c->sched_extra, c->sched_cap[0], c->sched_slots[0], c->stream));
     }
     for (int i = 0; i < kStagingSlots; i++) {
-        VRT_CREATE_HIP(hipHostMalloc(&c->staging[i], kStagingSlotBytes, hipHostMallocDefault));
-        VRT_CREATE_HIP(hipEventCreateWithFlags(&c->staging_ev[i], hipEventDisableTiming));
+        VRT_CREATE_HIP(c->res.pinned(&c->staging[i], kStagingSlotBytes));
+        VRT_CREATE_HIP(c->res.event(&c->staging_ev[i], hipEventDisableTiming));
     }
 
     // the bounce kernel comes in a 4- and an 8-waves-per-SIMD build (vrt_trace.hip, select_trace_kernel): the second one for
@@ -834,8 +511,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
 #endif
         const vrt::KernelEntry *pool = (kind == 2 && cfg->brick_dimension == 8u && !(cfg->tuning_flags & (VRT_TUNE_NO_PATH_BRICK_LDS | VRT_TUNE_NO_PATH_POOL)))
                                            ? vrt::find_pool_kernel((int)cfg->brick_dimension, pool_mw, pool_slots, pool_stages) : nullptr;
-        if (pool && c->kernel_grid_exit) c->kernel_grid_exit = pool->fn;
-        if (pool && c->product_grid_exit) c->product_grid_exit = pool->fn;
+        // (the DIL-2 twin stays beside a pool kernel: frames the pool kernel cannot take — more than 15 bounces, no sample buffer — keep it
+        // instead of falling back to the DIL-1 kernel with its steps-left counters)
+        if (pool && c->kernel_grid_exit) c->kernel_grid_exit_path = c->kernel_grid_exit, c->kernel_grid_exit = pool->fn;
+        if (pool && c->product_grid_exit) c->product_grid_exit_path = c->product_grid_exit, c->product_grid_exit = pool->fn;
     }
     c->single_variant = single_variant;
     {
@@ -851,8 +530,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         }
         // derived copies of the status bits, each only if a kernel of this context reads it
         auto any_kernel = [&](auto pred) {
-            const vrt::KernelFn fns[9] = {c->kernel, c->kernel_lockstep, c->kernel_single, c->kernel_single1, c->product[0], c->product[1], c->product[2],
-                                          c->kernel_grid_exit, c->product_grid_exit};
+            const vrt::KernelFn fns[11] = {c->kernel, c->kernel_lockstep, c->kernel_single, c->kernel_single1, c->product[0], c->product[1], c->product[2],
+                                           c->kernel_grid_exit, c->product_grid_exit, c->kernel_grid_exit_path, c->product_grid_exit_path};
             for (vrt::KernelFn fn : fns) {
                 const vrt::KernelEntry *e = fn ? vrt::kernel_entry_of(fn) : nullptr;
                 if (e && pred(*e)) return true;
@@ -861,16 +540,16 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         };
         if (any_kernel([](const vrt::KernelEntry &e) { return !e.path && e.mode == vrt::kStatusBytes; })) {
             const size_t status_bytes_size = (size_t)((cells + 31u) / 32u) * 32u + 64u; // 32 bytes per status word
-            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_status_bytes), status_bytes_size));
+            VRT_CREATE_HIP(c->res.device(&c->d_status_bytes, status_bytes_size));
             VRT_CREATE_HIP(hipMemsetAsync(c->d_status_bytes, 0, status_bytes_size, c->stream));
         }
         if (any_kernel([](const vrt::KernelEntry &e) { return e.path && (e.half || e.dil); })) {
             const size_t bytes_hb = (size_t)(cells / 32u) * 4u + 64u;
-            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_status_halfblocks), bytes_hb));
+            VRT_CREATE_HIP(c->res.device(&c->d_status_halfblocks, bytes_hb));
             VRT_CREATE_HIP(hipMemsetAsync(c->d_status_halfblocks, 0, bytes_hb, c->stream));
         }
         if (any_kernel([](const vrt::KernelEntry &e) { return e.path && e.dist; })) {
-            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_cell_distance), (size_t)cells + 64u));
+            VRT_CREATE_HIP(c->res.device(&c->d_cell_distance, (size_t)cells + 64u));
             VRT_CREATE_HIP(hipMemsetAsync(c->d_cell_distance, 0xFF, (size_t)cells + 64u, c->stream));
         }
         // the by-cell copy of the occupancy bits, for the persistent-lane kernel (scenes larger than the caches, where a brick entry
@@ -888,7 +567,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
                                      by_cell_bytes <= (64ull << 20) && cells * bits <= (1ull << 32);
         if ((persistent || lockstep_bounce) && !(cfg->tuning_flags & VRT_TUNE_NO_CELL_OCCUPANCY) &&
             by_cell_bytes <= (2ull << 30) && by_cell_bytes + 64u <= mem_free / 4u && (lds_walk || cells * bits <= (1ull << 32))) {
-            if (hipMalloc(reinterpret_cast<void **>(&c->d_cell_occupancy), by_cell_bytes + 64u) != hipSuccess) {
+            if (c->res.device(&c->d_cell_occupancy, by_cell_bytes + 64u) != hipSuccess) {
                 (void)hipGetLastError();
                 c->d_cell_occupancy = nullptr;
             } else {
@@ -897,17 +576,17 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
             }
         }
         if (!(cfg->tuning_flags & VRT_TUNE_NO_DEFERRED_MATERIAL)) {
-            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_materials_plain), 64u));
+            VRT_CREATE_HIP(c->res.device(&c->d_materials_plain, 64u));
             VRT_CREATE_HIP(hipMemsetAsync(c->d_materials_plain, 0, 64u, c->stream));
         }
         if (!(cfg->tuning_flags & VRT_TUNE_NO_START_SHORTCUT)) {
-            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_start_is_slot), 64u));
+            VRT_CREATE_HIP(c->res.device(&c->d_start_is_slot, 64u));
             VRT_CREATE_HIP(hipMemsetAsync(c->d_start_is_slot, 0, 64u, c->stream));
         }
         if (any_kernel([](const vrt::KernelEntry &e) { return (e.path && (e.filter || e.dil == 3)) || (!e.path && (e.mode == vrt::kStatusBlocked || e.mode == vrt::kStatusBlockedLds)); })) {
             const size_t nblocks = (size_t)nbx * nby * nbz;
             const size_t status_blocks_bytes = nblocks * 8u + ((nblocks + 31u) / 32u) * 4u + 16u;
-            VRT_CREATE_HIP(hipMalloc(&c->d_status_blocks, status_blocks_bytes));
+            VRT_CREATE_HIP(c->res.device(&c->d_status_blocks, status_blocks_bytes));
             VRT_CREATE_HIP(hipMemsetAsync(c->d_status_blocks, 0, status_blocks_bytes, c->stream));
         }
     }
@@ -916,14 +595,17 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     {
         const vrt::KernelEntry *e1 = c->kernel_grid_exit ? vrt::kernel_entry_of(c->kernel_grid_exit) : nullptr;
         const vrt::KernelEntry *e2 = c->product_grid_exit ? vrt::kernel_entry_of(c->product_grid_exit) : nullptr;
-        if ((e1 && e1->path == 2) || (e2 && e2->path == 2)) {
-            // (never read before it is written: a path's record is filled by the transition that gives the path its first pixel)
-            c->pool_stream_dwords = (size_t)(8 * cus) * 4u * vrt::kPoolPaths * vrt::kPoolPathDwords; // (room for any occupancy)
-            VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_pool_paths), 2u * c->pool_stream_dwords * sizeof(uint32_t)));
+        // (vrt_pool_kernel's path records, per stream of frames: room for eight workgroups per CU, any occupancy)
+        if ((e1 && e1->path == 2) || (e2 && e2->path == 2)) c->pool_stream_dwords = (size_t)(8 * cus) * 4u * vrt::kPoolPaths * vrt::kPoolPathDwords;
+    }
+    for (int l = 0; l < (c->stream_b ? 2 : 1); l++) {
+        const int rcl = lane_init(c, c->lane[l]);
+        if (rcl != VRT_OK) {
+            const std::string why = c->err;
+            free_ctx(c);
+            return fail(nullptr, rcl, why);
         }
     }
-    VRT_CREATE_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_work_counter), 2u * vrt::kMaxBatchFrames * sizeof(uint32_t)));
-    VRT_CREATE_HIP(hipMemsetAsync(c->d_work_counter, 0, 2u * vrt::kMaxBatchFrames * sizeof(uint32_t), c->stream));
 
     vrt::TraceParams &p = c->params;
     std::memset(&p, 0, sizeof p);
@@ -938,10 +620,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.counters = c->d_counters;
     p.count_box = (cfg->enable_counters == 2u) ? 1u : 0u;
     p.skip_to_box = (cfg->tuning_flags & VRT_TUNE_NO_SKIP_TO_BOX) ? 0u : 1u;
-    p.work_counter = c->d_work_counter;
+    p.work_counter = c->lane[0].work_counter;
     p.path_lds_bytes = c->path_lds_bytes;
     {
-        p.pool_paths = c->d_pool_paths;
+        p.pool_paths = c->lane[0].pool_paths;
         p.pool_cus = (uint32_t)cus;
         p.pool_walk_k = 12u;
         p.pool_brick_thr = 48u; // (tools/pool_sweep.py: a plateau from 48 to 56, walk_min 32 to 40, walk_k 16 to 20)
@@ -1006,8 +688,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         // the cost-feedback schedule, re-sorted every 32 frames instead of every frame: the kernel sees order 5
         p.tile_order = 5u;
         c->sched_period = (cfg->kernel_variant >> 28) ? (1u << (cfg->kernel_variant >> 28)) : 32u; // tuning knob: log2 of the period
-        VRT_CREATE_HIP(hipEventCreateWithFlags(&c->ev_sched, hipEventDisableTiming));
-        VRT_CREATE_HIP(hipEventCreateWithFlags(&c->ev_b_sched, hipEventDisableTiming));
+        VRT_CREATE_HIP(c->res.event(&c->ev_sched, hipEventDisableTiming));
+        VRT_CREATE_HIP(c->res.event(&c->ev_b_sched, hipEventDisableTiming));
     }
     p.tile_cost = c->d_tile_cost;
     p.tile_schedule = c->d_tile_schedule;
@@ -1065,26 +747,6 @@ uint64_t vrt_buffer_size(const vrt_ctx *ctx, vrt_buffer_id id) {
     return ctx->dsize[id];
 }
 
-// which derived structures a write to scene buffer `id` invalidates (rebuilt before the next frame, pre_dispatch)
-static void mark_dirty(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, uint64_t nbytes) {
-    if (id == VRT_BUF_BRICK_STATUS) ctx->status_dirty = true;
-    if (id == VRT_BUF_BRICK_START_INDEX) ctx->start_dirty = true;
-    if (id == VRT_BUF_MATERIALS) ctx->materials_dirty = true;
-    if (id != VRT_BUF_BRICK_STATUS && id != VRT_BUF_BRICK_INDEX && id != VRT_BUF_BRICK_OCCUPANCY) return;
-    auto widen = [](uint64_t &lo, uint64_t &hi, uint64_t a, uint64_t b) {
-        if (lo >= hi) lo = a, hi = b;
-        else lo = std::min(lo, a), hi = std::max(hi, b);
-    };
-    const uint64_t end = byte_offset + nbytes;
-    if (id == VRT_BUF_BRICK_STATUS) widen(ctx->occ_cell_lo, ctx->occ_cell_hi, byte_offset * 8u, end * 8u);
-    else if (id == VRT_BUF_BRICK_INDEX) widen(ctx->occ_cell_lo, ctx->occ_cell_hi, byte_offset / 4u, (end + 3u) / 4u);
-    else {
-        const uint64_t brick_bytes = (uint64_t)ctx->cfg.brick_dimension * ctx->cfg.brick_dimension * ctx->cfg.brick_dimension / 8u;
-        widen(ctx->occ_slot_lo, ctx->occ_slot_hi, byte_offset / brick_bytes, (end + brick_bytes - 1u) / brick_bytes);
-    }
-    ctx->occupancy_dirty = true;
-}
-
 static int check_range(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, const void *src, uint64_t nbytes) {
     if (!ctx) return VRT_E_INVALID_ARG;
     if ((int)id < 0 || id >= VRT_BUF_COUNT) return fail(ctx, VRT_E_INVALID_ARG, "bad buffer id");
@@ -1122,312 +784,6 @@ int vrt_upload_device(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, cons
     return end_scene_write(ctx);
 }
 
-// Common front part of a frame: argument checks, push constants, derived-structure refresh.  Leaves the
-// kernel to launch in *fn.  Runs on the primary stream.
-// vrt_pool_kernel packs a path's sample index into 16 bits and its bounce count into 4, and divides a tile's number by the tiles
-// per row with one multiplication (exact while tiles * tiles_x < 2^32); frames beyond that keep vrt_path_kernel
-// ... and takes SAMPLES from its counter (32 bits), whose terms of the sample sum it leaves in a buffer of 16 bytes per sample and stream
-// for vrt_pool_resolve_kernel: 2 x 2 GiB for a 4K frame of 16 samples.  The buffer grows with the frames asked for (both streams idle
-// first); where it cannot be had — more than half of the free memory, or a failed allocation — the frame keeps vrt_path_kernel.
-static bool pool_samples_ready(vrt_ctx *ctx, const vrt_camera_device *camera) {
-    ctx->params.pool_samples = nullptr; // (until this frame's buffer is known to be there)
-    if (ctx->cfg.tuning_flags & VRT_TUNE_NO_SAMPLE_UNITS) return false;
-    if (camera->samples_per_pixel < 1) return false; // (a frame of no samples is not a frame of units)
-    const uint64_t units = (uint64_t)ctx->shard.owned_tiles * 256u * (uint64_t)camera->samples_per_pixel;
-    if (units >= (1ull << 32) - (1ull << 26)) return false; // (the counter keeps counting, a chunk per wave, after it has run out)
-    if (ctx->pool_samples_stream_elems >= units) {
-        ctx->params.pool_samples = ctx->d_pool_samples;
-        return true;
-    }
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
-    if (ctx->stream_b && hipStreamSynchronize(ctx->stream_b) != hipSuccess) return false;
-    if (ctx->d_pool_samples) (void)hipFree(ctx->d_pool_samples);
-    ctx->d_pool_samples = nullptr;
-    ctx->pool_samples_stream_elems = 0;
-    ctx->params.pool_samples = nullptr;
-    size_t mem_free = 0, mem_total = 0;
-    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return false;
-    const size_t bytes = 2u * (size_t)units * sizeof(float4);
-    if (bytes > mem_free / 2u) return false;
-    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_pool_samples), bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        ctx->d_pool_samples = nullptr;
-        return false;
-    }
-    ctx->pool_samples_stream_elems = (size_t)units;
-    ctx->params.pool_samples = ctx->d_pool_samples;
-    return true;
-}
-static bool grid_exit_fits(vrt_ctx *ctx, vrt::KernelFn fn, const vrt_camera_device *camera, bool tiles_fit) {
-    const vrt::KernelEntry *e = vrt::kernel_entry_of(fn);
-    return !(e && e->path == 2) || (camera->max_bounce <= 15 && tiles_fit && pool_samples_ready(ctx, camera));
-}
-
-static bool pool_tiles_fit(const vrt_ctx *ctx) {
-    return (unsigned long long)ctx->shard.tiles_x * ctx->shard.tiles_y * ctx->shard.tiles_x < (1ull << 32);
-}
-
-static int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, vrt::KernelFn *fn) {
-    if (!ctx || !camera || !sun) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL camera/sun") : VRT_E_INVALID_ARG;
-    if (camera->image_width != ctx->cfg.width || camera->image_height != ctx->cfg.height)
-        return fail(ctx, VRT_E_INVALID_ARG, "camera image size differs from the target image");
-    // The reference blocks here on the previous frame's fence because it re-records its one
-    // command buffer (ComputePipeline.zig:423-436).  Launches are stream-ordered and carry their
-    // arguments by value, so frames may queue; vrt_wait / vrt_read_* are the synchronisation points.
-    ctx->in_flight = false;
-    ctx->params.pcs[0].cam = *camera;
-    ctx->params.pcs[0].sun = *sun;
-    const vrt_grid_state &g = ctx->params.grid;
-    {
-        auto pow2_with_normal_reciprocal = [](float v) {
-            uint32_t b;
-            std::memcpy(&b, &v, 4);
-            const uint32_t e = (b >> 23) & 0xFFu;
-            return (b & 0x7FFFFFu) == 0u && e >= 2u && e <= 252u;
-        };
-        const float gs = g.max_point_scale[3];
-        const float vs = gs * (1.0f / (float)ctx->cfg.brick_dimension); // as the kernel forms it (Pipeline.zig:313)
-        const bool ok = pow2_with_normal_reciprocal(gs) && pow2_with_normal_reciprocal(vs);
-        ctx->params.scale_pow2 = ok ? 1u : 0u;
-        ctx->params.inv_grid_scale = ok ? 1.0f / gs : 0.0f;
-        ctx->params.inv_voxel_scale = ok ? 1.0f / vs : 0.0f;
-    }
-    if (g.dim_x != 0 && (g.dim_x != ctx->cfg.dim_x || g.dim_y != ctx->cfg.dim_y || g.dim_z != ctx->cfg.dim_z))
-        return fail(ctx, VRT_E_INVALID_ARG, "uploaded grid state has other brick dimensions than the context was created with");
-    if (ctx->d_counters) VRT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(vrt::DeviceCounters), ctx->stream));
-    if (ctx->status_dirty) {
-        // refresh the derived block words / filter from the uploaded status bits (stream-ordered after the uploads)
-        int rcw = begin_scene_write(ctx);
-        if (rcw != VRT_OK) return rcw;
-        VRT_HIP(ctx, vrt::launch_build_status_blocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
-        VRT_HIP(ctx, vrt::launch_build_cell_bounds(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
-        if (ctx->kernel_grid_exit || ctx->product_grid_exit) {
-            if (!ctx->h_cell_bounds) VRT_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_cell_bounds), 6 * sizeof(int), hipHostMallocDefault));
-            if (!ctx->ev_bounds) VRT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_bounds, hipEventDisableTiming));
-            if (ctx->bounds_pending) VRT_HIP(ctx, hipEventSynchronize(ctx->ev_bounds)); // (the copy before this one still owns the buffer)
-            VRT_HIP(ctx, hipMemcpyAsync(ctx->h_cell_bounds, ctx->d_cell_bounds, 6 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            VRT_HIP(ctx, hipEventRecord(ctx->ev_bounds, ctx->stream));
-            ctx->bounds_pending = true;
-            ctx->box_is_grid = false; // until the new box is known
-        }
-        VRT_HIP(ctx, vrt::launch_build_status_bytes(ctx->params, ctx->stream));
-        VRT_HIP(ctx, vrt::launch_build_status_halfblocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
-        VRT_HIP(ctx, vrt::launch_build_cell_distance(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
-        rcw = end_scene_write(ctx);
-        if (rcw != VRT_OK) return rcw;
-        ctx->status_dirty = false;
-    }
-    if ((ctx->occupancy_dirty && ctx->d_cell_occupancy) || (ctx->start_dirty && ctx->d_start_is_slot) || (ctx->materials_dirty && ctx->d_materials_plain)) {
-        int rcw = begin_scene_write(ctx);
-        if (rcw != VRT_OK) return rcw;
-        if (ctx->occupancy_dirty)
-            VRT_HIP(ctx, vrt::launch_build_cell_occupancy(ctx->params, ctx->cfg.brick_dimension, ctx->cfg.brick_alloc, ctx->occ_cell_lo, ctx->occ_cell_hi, ctx->occ_slot_lo,
-                                                          ctx->occ_slot_hi, ctx->stream));
-        if (ctx->start_dirty) VRT_HIP(ctx, vrt::launch_check_start_is_slot(ctx->params, ctx->cfg.brick_dimension, ctx->cfg.brick_alloc, ctx->stream));
-        if (ctx->materials_dirty) VRT_HIP(ctx, vrt::launch_check_materials_plain(ctx->params, std::max<uint32_t>(256u, (uint32_t)(ctx->dsize[VRT_BUF_MATERIALS] / sizeof(vrt_material))), ctx->stream));
-        rcw = end_scene_write(ctx);
-        if (rcw != VRT_OK) return rcw;
-    }
-    ctx->occupancy_dirty = ctx->start_dirty = ctx->materials_dirty = false;
-    ctx->occ_cell_lo = ctx->occ_cell_hi = ctx->occ_slot_lo = ctx->occ_slot_hi = 0;
-    // max_bounce <= 1 ("only primary ray" + its shadow ray): the bounce loop runs at most once
-    *fn = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? ctx->kernel_single1 : ctx->kernel_single) : ctx->kernel;
-    if (ctx->bounds_pending && hipEventQuery(ctx->ev_bounds) == hipSuccess) {
-        // the box of the occupied cells {-min, max} per axis: "the grid, or nearly" = at most an eighth of the axis free on either side
-        const int *b = ctx->h_cell_bounds;
-        const int dim[3] = {(int)ctx->cfg.dim_x, (int)ctx->cfg.dim_y, (int)ctx->cfg.dim_z};
-        bool all = b[0] != (int)0x80808080;
-        for (int a = 0; a < 3 && all; a++) all = (-b[a]) * 8 <= dim[a] && (dim[a] - 1 - b[3 + a]) * 8 <= dim[a];
-        ctx->box_is_grid = all;
-        ctx->bounds_pending = false;
-    }
-    if (camera->max_bounce > 1 && ctx->box_is_grid && !ctx->d_counters && ctx->kernel_grid_exit && grid_exit_fits(ctx, ctx->kernel_grid_exit, camera, pool_tiles_fit(ctx)))
-        *fn = ctx->kernel_grid_exit;
-    return VRT_OK;
-}
-
-static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames, bool primary_only = false,
-                       hipEvent_t *marks = nullptr) {
-    if (frames == 0) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "zero frames") : VRT_E_INVALID_ARG;
-    if (ctx && ctx->dist) return fail(ctx, VRT_E_STATE, "this context runs the multi-GPU pipeline: use vrt_dist_frame");
-    DeviceGuard dg(ctx ? ctx->device : 0);
-    vrt::KernelFn fn = nullptr;
-    const int rcp = pre_dispatch(ctx, camera, sun, &fn);
-    if (rcp != VRT_OK) return rcp;
-
-    // With counters enabled the counting build of the kernel (compiler-generated loops, per-lane counters) runs
-    // first and fills the counters; the frame that is read back is then rendered by the product kernel itself,
-    // so that every parity check made on a counting context checks the shipped code path.
-    vrt::KernelFn product_fn = nullptr;
-    if (ctx->d_counters) {
-        product_fn = ctx->product[(camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? 2 : 1) : 0];
-        if (!product_fn) return fail(ctx, VRT_E_STATE, "no product kernel for this configuration");
-        if (camera->max_bounce > 1 && ctx->box_is_grid && ctx->product_grid_exit && grid_exit_fits(ctx, ctx->product_grid_exit, camera, pool_tiles_fit(ctx))) product_fn = ctx->product_grid_exit;
-    }
-    // (vrt_path_kernel takes samples as units of work where the sample buffer can be had, whole pixels otherwise)
-    if (const vrt::KernelEntry *pe = vrt::kernel_entry_of(product_fn ? product_fn : fn); pe && pe->path == 1) (void)pool_samples_ready(ctx, camera);
-    note_kernel(ctx, product_fn ? product_fn : fn);
-    // (the persistent-lane kernel takes its pixels from a counter: it neither reads the tile schedule nor reports tile costs)
-    const bool scheduled = !vrt::is_path_kernel(product_fn ? product_fn : fn);
-
-    // (tile_order 5 re-sorts the tile schedule in place before every frame on the primary stream: a frame running on
-    // the second stream would read it while it is being rewritten, so that order runs one frame at a time.  The
-    // amortised form, tile_order 7, sorts into the other of two buffers and may use both streams.)
-    // which of the cost schedule's two rules serves this frame (vrt_trace_kernel's `dual`: two samples per pixel, whole RGBA pixels); a
-    // change re-sorts at once, on the primary stream
-    const uint32_t sched_mode = (ctx->sched_period && scheduled && camera->samples_per_pixel == 2 && !ctx->params.packed_rgb) ? 1u : 0u;
-    const bool sched_changes = ctx->sched_period && scheduled && sched_mode != ctx->sched_mode;
-    const bool slot_b = ctx->stream_b && frames == 1 && !primary_only && (ctx->frame_seq & 1u) && (ctx->params.tile_order != 5u || ctx->sched_period) &&
-                        !sched_changes;
-    if (slot_b) {
-        // second frame slot: its own stream and target; ordered after every scene write so far
-        if (ctx->b_seen_upload != ctx->upload_seq) {
-            VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->ev_upload, 0));
-            ctx->b_seen_upload = ctx->upload_seq;
-        }
-        if (ctx->b_seen_sched != ctx->sched_seq) {
-            // the schedule buffer this frame reads was sorted on the primary stream
-            VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->ev_sched, 0));
-        }
-        vrt::TraceParams pb = ctx->params;
-        // (frames of two samples per pixel keep the cost schedule on both streams: their split tiles trace the second sample on the idle
-        // lanes, which is worth more than reverse raster's neighbourhood — the app's run, two frames in flight, V0 / V1 / V2: 0.205 /
-        // 0.214 / 0.237 ms per frame against 0.267 / 0.262 / 0.286, tools/fif_order_ab.py)
-        if (ctx->order_auto && sched_mode == 0u) pb.tile_order = 3u;
-        pb.target_rgba8 = ctx->target8_b;
-        pb.target_rgba32f = ctx->target32f_b;
-        pb.work_counter = ctx->d_work_counter + vrt::kMaxBatchFrames; // its frames run beside the primary stream's
-        if (pb.pool_paths) pb.pool_paths += ctx->pool_stream_dwords;
-        if (pb.pool_samples) pb.pool_samples += ctx->pool_samples_stream_elems;
-        VRT_HIP(ctx, vrt::launch_trace(fn, pb, ctx->lds_bytes, ctx->stream_b));
-        if (product_fn) VRT_HIP(ctx, vrt::launch_trace(product_fn, pb, ctx->lds_bytes, ctx->stream_b));
-        VRT_HIP(ctx, hipEventRecord(ctx->ev_b_done, ctx->stream_b));
-        if (ctx->b_seen_sched != ctx->sched_seq) {
-            // everything this stream read from the OTHER schedule buffer is finished once this event is
-            VRT_HIP(ctx, hipEventRecord(ctx->ev_b_sched, ctx->stream_b));
-            ctx->b_sched_recorded = true;
-            ctx->b_seen_sched = ctx->sched_seq;
-        }
-        ctx->sched_since++;
-        ctx->b_pending = true;
-        ctx->frame_seq++;
-        ctx->last_slot = 1;
-        return VRT_OK;
-    }
-    if (ctx->stream_b && (frames > 1 || primary_only) && ctx->b_pending) {
-        // timed back-to-back launches: do not let a frame on the other stream run underneath them
-        VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_b_done, 0));
-        ctx->b_pending = false;
-    }
-    VRT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-    const uint32_t nt = ctx->shard.owned_tiles;
-    const uint32_t ns = ctx->sched_stride; // stride of a schedule buffer
-    if (ctx->params.tile_order == 5u && nt > 1u && !ctx->sched_period && scheduled) {
-        // re-sort the tile list by last frame's measured cost (inside the timed region: it is per-frame work)
-        VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule + 2u * (size_t)ns, ctx->d_tile_schedule, ctx->d_tile_schedule, nt, ctx->sched_extra, 0u, ctx->wave_slots, ctx->stream));
-    }
-    if (ctx->order_auto && ctx->stream_b && frames == 1 && !primary_only && sched_mode == 0u && !sched_changes) {
-        // the even frames of two frames in flight: the other stream fills this frame's tail, and reverse raster keeps
-        // neighbouring tiles together (measured 4 % faster than the cost order in that mode)
-        vrt::TraceParams pa = ctx->params;
-        pa.tile_order = 3u;
-        VRT_HIP(ctx, vrt::launch_trace(fn, pa, ctx->lds_bytes, ctx->stream));
-        if (product_fn) VRT_HIP(ctx, vrt::launch_trace(product_fn, pa, ctx->lds_bytes, ctx->stream));
-        VRT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
-        ctx->timed_frames = 1;
-        ctx->in_flight = true;
-        ctx->frame_seq++;
-        ctx->last_slot = 0;
-        return VRT_OK;
-    }
-    if (product_fn) {
-        // Counting context: the counting build runs ONCE per call (the counters are those of one frame however many
-        // frames were asked for), then both targets are overwritten with 0xCD, then the product kernel renders the
-        // frame(s): a pixel the product kernel fails to write reads back as 0xCDCDCDCD / -4.3e8, not as the counting
-        // build's (correct) colour.
-        VRT_HIP(ctx, vrt::launch_trace(fn, ctx->params, ctx->lds_bytes, ctx->stream));
-        VRT_HIP(ctx, hipMemsetAsync(ctx->target8, 0xCD, ctx->target_pixels * 4u, ctx->stream));
-        if (ctx->target32f) VRT_HIP(ctx, hipMemsetAsync(ctx->target32f, 0xCD, ctx->target_pixels * 16u, ctx->stream));
-        fn = product_fn;
-    }
-    if (sched_changes) {
-        ctx->sched_mode = sched_mode;
-        ctx->params.sched_units = ctx->sched_cap[sched_mode];
-        ctx->sched_since = ctx->sched_period;
-    }
-    for (uint32_t f = 0; f < frames; f++) {
-        if (marks) VRT_HIP(ctx, hipEventRecord(marks[f], ctx->stream)); // per-frame timing (vrt_dispatch_timed)
-        if (ctx->sched_period && nt > 1u && ctx->sched_since >= ctx->sched_period && scheduled) {
-            // Amortised re-sort, in the frames' own stream (inside the timed region as well): the measured costs (running mean)
-            // order the tiles into the buffer no frame reads; frames launched from here on read that one.  A sort costs about
-            // 35 us of the stream's time (the kernel plus the two kernel boundaries).  Measured alternatives: on a second
-            // stream with event waits 80 us per sort; on a second stream with the host polling for its completion nothing, but
-            // then the order lags behind frames that are queued ahead (vrt_dispatch_repeat) by a whole call.
-            if (ctx->b_sched_recorded) VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_b_sched, 0)); // (signalled a period ago)
-            uint32_t *cur = ctx->d_tile_schedule + (size_t)ctx->sched_cur * ns, *alt = ctx->d_tile_schedule + (size_t)(ctx->sched_cur ^ 1u) * ns;
-            VRT_HIP(ctx, vrt::launch_schedule(ctx->d_tile_cost, ctx->d_tile_schedule + 2u * (size_t)ns, cur, alt, nt, ctx->sched_extra, ctx->sched_cap[ctx->sched_mode], ctx->sched_slots[ctx->sched_mode], ctx->stream));
-            VRT_HIP(ctx, hipEventRecord(ctx->ev_sched, ctx->stream));
-            ctx->sched_cur ^= 1u;
-            ctx->params.tile_schedule = alt;
-            ctx->sched_seq++;
-            ctx->sched_since = 0;
-        }
-        VRT_HIP(ctx, vrt::launch_trace(fn, ctx->params, ctx->lds_bytes, ctx->stream));
-        ctx->sched_since++;
-    }
-    if (marks) VRT_HIP(ctx, hipEventRecord(marks[frames], ctx->stream));
-    VRT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
-    ctx->timed_frames = frames;
-    ctx->in_flight = true;
-    ctx->frame_seq++;
-    ctx->last_slot = 0;
-    return VRT_OK;
-}
-
-int vrt_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun) { return do_dispatch(ctx, camera, sun, 1); }
-
-int vrt_dispatch_repeat(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames) {
-    return do_dispatch(ctx, camera, sun, frames);
-}
-
-int vrt_dispatch_timed(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint32_t frames, float *ms_per_frame) {
-    if (!ctx || !ms_per_frame) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "ms_per_frame is NULL") : VRT_E_INVALID_ARG;
-    if (frames == 0 || frames > 4096u) return fail(ctx, VRT_E_INVALID_ARG, "vrt_dispatch_timed: 1..4096 frames");
-    DeviceGuard dg(ctx->device);
-    std::vector<hipEvent_t> marks(frames + 1u, nullptr);
-    int rc = VRT_OK;
-    for (uint32_t i = 0; i <= frames && rc == VRT_OK; i++)
-        if (hipEventCreate(&marks[i]) != hipSuccess) rc = fail(ctx, VRT_E_HIP, "hipEventCreate failed");
-    // frames > 1 or primary_only keeps every frame on the primary stream, one after another
-    if (rc == VRT_OK) rc = do_dispatch(ctx, camera, sun, frames, true, marks.data());
-    if (rc == VRT_OK && hipEventSynchronize(marks[frames]) != hipSuccess) rc = fail(ctx, VRT_E_HIP, "hipEventSynchronize failed");
-    for (uint32_t f = 0; f < frames && rc == VRT_OK; f++)
-        if (hipEventElapsedTime(&ms_per_frame[f], marks[f], marks[f + 1u]) != hipSuccess) rc = fail(ctx, VRT_E_HIP, "hipEventElapsedTime failed");
-    for (hipEvent_t e : marks)
-        if (e) (void)hipEventDestroy(e);
-    return rc;
-}
-
-int vrt_wait(vrt_ctx *ctx) {
-    if (!ctx) return VRT_E_INVALID_ARG;
-    DeviceGuard dg(ctx->device);
-    const int rc = finish_frame(ctx);
-    if (rc != VRT_OK) return rc;
-    VRT_HIP(ctx, wait_stream(ctx->stream));
-    if (ctx->stream_b) {
-        VRT_HIP(ctx, wait_stream(ctx->stream_b));
-        ctx->b_pending = false;
-    }
-    return VRT_OK;
-}
-
-double vrt_last_kernel_ms(vrt_ctx *ctx) {
-    if (!ctx) return -1.0;
-    DeviceGuard dg(ctx->device);
-    if (finish_frame(ctx) != VRT_OK) return -1.0;
-    return ctx->timing_valid ? ctx->last_ms : -1.0;
-}
-
 static int read_back(vrt_ctx *ctx, void *dst, uint64_t nbytes, const void *src, uint64_t avail) {
     if (!ctx || !dst) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "dst is NULL") : VRT_E_INVALID_ARG;
     if (!src) return fail(ctx, VRT_E_STATE, "target not allocated (want_float_output = 0?)");
@@ -1453,16 +809,10 @@ int vrt_set_target(vrt_ctx *ctx, void *rgba8, void *rgba32f) {
     if (!rgba8) return fail(ctx, VRT_E_INVALID_ARG, "rgba8 target is NULL");
     if (ctx->stream_b) return fail(ctx, VRT_E_STATE, "vrt_set_target needs frames_in_flight = 1");
     DeviceGuard dg(ctx->device);
-    if (ctx->own_t8 && ctx->target8) {
-        VRT_HIP(ctx, hipStreamSynchronize(ctx->stream)); // frames in flight still write the owned image
-        (void)hipFree(ctx->target8);
-        ctx->own_t8 = false;
-    }
-    if (ctx->own_t32 && ctx->target32f) {
-        VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->target32f);
-        ctx->own_t32 = false;
-    }
+    // (frames in flight still write the images the context made for itself; a caller's earlier images are left alone)
+    VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->res.drop(ctx->target8);
+    ctx->res.drop(ctx->target32f);
     ctx->target8 = static_cast<uint8_t *>(rgba8);
     ctx->target32f = static_cast<float *>(rgba32f);
     ctx->params.target_rgba8 = ctx->target8;
@@ -1472,93 +822,6 @@ int vrt_set_target(vrt_ctx *ctx, void *rgba8, void *rgba32f) {
 void *vrt_device_target_rgba8(vrt_ctx *ctx) { return ctx ? (ctx->last_slot == 1 ? ctx->target8_b : ctx->target8) : nullptr; }
 void *vrt_device_target_rgba32f(vrt_ctx *ctx) { return ctx ? (ctx->last_slot == 1 ? ctx->target32f_b : ctx->target32f) : nullptr; }
 uint64_t vrt_target_bytes_rgba8(const vrt_ctx *ctx) { return ctx ? ctx->target_pixels * 4u : 0; }
-
-int vrt_denoise(vrt_ctx *ctx, const vrt_denoise_config *cfg, uint32_t out_w, uint32_t out_h, uint32_t want_float) {
-    if (!ctx || out_w == 0 || out_h == 0) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "zero output size") : VRT_E_INVALID_ARG;
-    if (ctx->shard.shard_count > 1u) return fail(ctx, VRT_E_STATE, "vrt_denoise needs the whole frame (unsharded context)");
-    vrt_denoise_config c{20, 0.6f, 1.5f, 20.0f}; // GraphicsPipeline.Config, GraphicsPipeline.zig:34-39
-    if (cfg) c = *cfg;
-    if (c.samples < 0 || c.samples > 4096) return fail(ctx, VRT_E_INVALID_ARG, "samples out of range");
-    DeviceGuard dg(ctx->device);
-    // runs on the stream that rendered the most recent frame, so it is ordered after that frame
-    const hipStream_t s = (ctx->last_slot == 1) ? ctx->stream_b : ctx->stream;
-    if (ctx->denoised_w != out_w || ctx->denoised_h != out_h || (want_float && !ctx->d_denoised32f)) {
-        VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->stream_b) VRT_HIP(ctx, hipStreamSynchronize(ctx->stream_b));
-        if (ctx->d_denoised8) (void)hipFree(ctx->d_denoised8);
-        if (ctx->d_denoised32f) (void)hipFree(ctx->d_denoised32f);
-        ctx->d_denoised8 = ctx->d_denoised32f = nullptr;
-        VRT_HIP(ctx, hipMalloc(&ctx->d_denoised8, (size_t)out_w * out_h * 4u));
-        if (want_float) VRT_HIP(ctx, hipMalloc(&ctx->d_denoised32f, (size_t)out_w * out_h * 16u));
-        ctx->denoised_w = out_w;
-        ctx->denoised_h = out_h;
-    }
-    const void *img = (ctx->last_slot == 1) ? ctx->target8_b : ctx->target8;
-    VRT_HIP(ctx, hipEventRecord(ctx->ev_post_start, s));
-    VRT_HIP(ctx, vrt::launch_denoise(img, (int)ctx->cfg.width, (int)ctx->cfg.height, c.samples, c.distribution_bias, c.pixel_multiplier,
-                                     c.inverse_hue_tolerance, (int)out_w, (int)out_h, ctx->d_denoised8, want_float ? ctx->d_denoised32f : nullptr, s));
-    VRT_HIP(ctx, hipEventRecord(ctx->ev_post_stop, s));
-    ctx->post_timed = true;
-    ctx->denoised_stream = s;
-    return VRT_OK;
-}
-
-int vrt_region_begin(vrt_ctx *ctx) {
-    if (!ctx) return VRT_E_INVALID_ARG;
-    DeviceGuard dg(ctx->device);
-    for (hipEvent_t &e : ctx->ev_region)
-        if (!e) VRT_HIP(ctx, hipEventCreate(&e));
-    VRT_HIP(ctx, hipEventRecord(ctx->ev_region[0], ctx->stream));
-    if (ctx->stream_b) VRT_HIP(ctx, hipEventRecord(ctx->ev_region[2], ctx->stream_b));
-    return VRT_OK;
-}
-
-int vrt_region_end(vrt_ctx *ctx, double *ms) {
-    if (!ctx || !ms) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "ms is NULL") : VRT_E_INVALID_ARG;
-    if (!ctx->ev_region[0]) return fail(ctx, VRT_E_STATE, "vrt_region_end without vrt_region_begin");
-    DeviceGuard dg(ctx->device);
-    VRT_HIP(ctx, hipEventRecord(ctx->ev_region[1], ctx->stream));
-    if (ctx->stream_b) VRT_HIP(ctx, hipEventRecord(ctx->ev_region[3], ctx->stream_b));
-    VRT_HIP(ctx, wait_event(ctx->ev_region[1]));
-    float a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
-    VRT_HIP(ctx, hipEventElapsedTime(&a1, ctx->ev_region[0], ctx->ev_region[1]));
-    double begin = 0.0, end = a1; // (times relative to the primary stream's begin event)
-    if (ctx->stream_b) {
-        VRT_HIP(ctx, wait_event(ctx->ev_region[3]));
-        VRT_HIP(ctx, hipEventElapsedTime(&b0, ctx->ev_region[0], ctx->ev_region[2]));
-        VRT_HIP(ctx, hipEventElapsedTime(&b1, ctx->ev_region[0], ctx->ev_region[3]));
-        begin = std::min(0.0, (double)b0);
-        end = std::max((double)a1, (double)b1);
-    }
-    *ms = end - begin;
-    return VRT_OK;
-}
-
-double vrt_last_denoise_ms(vrt_ctx *ctx) {
-    if (!ctx || !ctx->post_timed) return -1.0;
-    DeviceGuard dg(ctx->device);
-    if (wait_event(ctx->ev_post_stop) != hipSuccess) return -1.0;
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, ctx->ev_post_start, ctx->ev_post_stop) != hipSuccess) return -1.0;
-    return (double)ms;
-}
-
-static int read_denoised(vrt_ctx *ctx, void *dst, uint64_t nbytes, const void *src, uint64_t avail) {
-    if (!ctx || !dst) return VRT_E_INVALID_ARG;
-    if (!src) return fail(ctx, VRT_E_STATE, "no denoised image (call vrt_denoise first; want_float for the float image)");
-    if (nbytes > avail) return fail(ctx, VRT_E_OUT_OF_RANGE, "read exceeds the denoised image");
-    DeviceGuard dg(ctx->device);
-    VRT_HIP(ctx, hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx->denoised_stream));
-    VRT_HIP(ctx, hipStreamSynchronize(ctx->denoised_stream));
-    return VRT_OK;
-}
-int vrt_read_denoised_rgba8(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
-    return read_denoised(ctx, dst, nbytes, ctx ? ctx->d_denoised8 : nullptr, ctx ? (uint64_t)ctx->denoised_w * ctx->denoised_h * 4u : 0);
-}
-int vrt_read_denoised_rgba32f(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
-    return read_denoised(ctx, dst, nbytes, ctx ? ctx->d_denoised32f : nullptr, ctx ? (uint64_t)ctx->denoised_w * ctx->denoised_h * 16u : 0);
-}
-void *vrt_device_denoised_rgba8(vrt_ctx *ctx) { return ctx ? ctx->d_denoised8 : nullptr; }
 
 int vrt_get_shard_info(const vrt_ctx *ctx, vrt_shard_info *out) {
     if (!ctx || !out) return VRT_E_INVALID_ARG;
@@ -1573,381 +836,6 @@ int vrt_assemble_frame(vrt_ctx *ctx, const void *gathered, void *dst_frame, uint
     VRT_HIP(ctx, vrt::launch_assemble(gathered, dst_frame, bytes_per_pixel, ctx->cfg.width, ctx->cfg.height, ctx->shard.tiles_x,
                                       ctx->shard.shard_count, ctx->shard.tiles_per_rank, ctx->own, ctx->stream));
     return VRT_OK;
-}
-
-int vrt_trace_wave_timeline(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, uint64_t *out, uint64_t capacity_pairs,
-                            uint64_t *n_pairs) {
-    if (!ctx || !out || !n_pairs) return VRT_E_INVALID_ARG;
-    // (the cost-ordered launch has spare workgroups for the halves of split tiles: their waves are listed too; a workgroup that
-    // stayed idle leaves zeros)
-    const uint64_t waves = ((uint64_t)ctx->shard.owned_tiles + (ctx->params.tile_order == 5u ? ctx->params.sched_units : 0u)) * 4u;
-    if (capacity_pairs < waves) return fail(ctx, VRT_E_OUT_OF_RANGE, "timeline buffer too small");
-    DeviceGuard dg(ctx->device);
-    const size_t bytes = std::max<size_t>(waves * 16u, 32u * sizeof(unsigned long long)); // (the profile build of vrt_path_kernel writes 20 words)
-#ifndef VRT_DEV_PROFILE
-    {
-        // the persistent-lane kernel has no wave -> tile map to report: refuse instead of returning zeros
-        const vrt::KernelFn would = (camera && camera->max_bounce > 1) ? (ctx->d_counters ? ctx->product[0] : ctx->kernel) : nullptr;
-        if (would && vrt::is_path_kernel(would)) return fail(ctx, VRT_E_STATE, "vrt_trace_wave_timeline: frames with bounces run vrt_path_kernel on this context (no per-tile waves)");
-    }
-#endif
-    unsigned long long *d = nullptr;
-    VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), bytes));
-    VRT_HIP(ctx, hipMemsetAsync(d, 0, bytes, ctx->stream));
-    ctx->params.wave_timeline = d;
-    const uint32_t split_all = ctx->params.split_all;
-    ctx->params.split_all = 0u; // (one row of the timeline per wave of a whole tile)
-    const int rc = do_dispatch(ctx, camera, sun, 1, true);
-    ctx->params.split_all = split_all;
-    ctx->params.wave_timeline = nullptr;
-    if (rc != VRT_OK) {
-        (void)hipFree(d);
-        return rc;
-    }
-    VRT_HIP(ctx, hipMemcpyAsync(out, d, waves * 16u, hipMemcpyDeviceToHost, ctx->stream));
-    VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d);
-    *n_pairs = waves;
-    return VRT_OK;
-}
-
-// ---- multi-GPU frame pipeline ------------------------------------------------------------------------
-#define VRT_NCCL(ctx, d, call)                                                                               \
-    do {                                                                                                     \
-        const ncclResult_t r_ = (call);                                                                      \
-        if (r_ != ncclSuccess) return fail(ctx, VRT_E_RCCL, std::string(#call) + ": " + (d)->api.GetErrorString(r_)); \
-    } while (0)
-
-int vrt_dist_unique_id(const char *rccl_path, void *out_id128) {
-    if (!rccl_path || !out_id128) return VRT_E_INVALID_ARG;
-    RcclApi api;
-    std::string err;
-    if (!api.load(rccl_path, err)) return fail(nullptr, VRT_E_RCCL, err);
-    ncclUniqueId id;
-    const ncclResult_t r = api.GetUniqueId(&id);
-    if (r != ncclSuccess) return fail(nullptr, VRT_E_RCCL, std::string("ncclGetUniqueId: ") + api.GetErrorString(r));
-    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
-    std::memcpy(out_id128, &id, sizeof id);
-    return VRT_OK;
-}
-
-int vrt_dist_init_batched(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight,
-                          uint32_t frames_per_launch) {
-    if (!ctx || !rccl_path || !id128) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL argument") : VRT_E_INVALID_ARG;
-    if (ctx->dist) return fail(ctx, VRT_E_STATE, "vrt_dist_init called twice");
-    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, VRT_E_INVALID_ARG, "bad rank / world");
-    if ((uint32_t)world != ctx->shard.shard_count || (uint32_t)rank != ctx->shard.shard_rank)
-        return fail(ctx, VRT_E_INVALID_ARG, "context was not created with shard_rank / shard_count = rank / world");
-    if (ctx->stream_b || ctx->cfg.stream || ctx->cfg.external_target_rgba8 || ctx->d_counters)
-        return fail(ctx, VRT_E_STATE, "the multi-GPU pipeline owns its streams and targets (no frames_in_flight=2, caller stream/target or counters)");
-    if (frames_in_flight == 0) frames_in_flight = 4;
-    if (frames_in_flight > kMaxDistSlots) return fail(ctx, VRT_E_INVALID_ARG, "at most 8 launches in flight");
-    if (frames_per_launch == 0) frames_per_launch = 1;
-    if (frames_per_launch > (uint32_t)vrt::kMaxBatchFrames) return fail(ctx, VRT_E_INVALID_ARG, "at most 8 frames per launch");
-    DeviceGuard dg(ctx->device);
-    Dist *d = new (std::nothrow) Dist();
-    if (!d) return fail(ctx, VRT_E_OOM, "host allocation failed");
-    std::string err;
-    if (!d->api.load(rccl_path, err)) {
-        delete d;
-        return fail(ctx, VRT_E_RCCL, err);
-    }
-    if (ctx->cfg.tuning_flags & VRT_TUNE_DIST_NO_BROADCAST) d->api.Broadcast = nullptr; // the send / recv form of vrt_dist_broadcast
-    d->rank = rank;
-    d->world = world;
-    d->nslots = frames_in_flight;
-    d->batch = frames_per_launch;
-    // shards travel as RGB (the alpha of the RGBA8 target is the constant 255): a quarter less for rank 0's links to take in
-    d->shard_bytes = (size_t)ctx->shard.tiles_per_rank * vrt::kTileW * vrt::kTileH * 3u;
-    ctx->dist = d; // from here free_ctx cleans up
-    ncclUniqueId id;
-    std::memcpy(&id, id128, sizeof id);
-    VRT_NCCL(ctx, d, d->api.CommInitRank(&d->comm, world, id, rank));
-    const size_t region = d->shard_bytes * d->batch; // one rank's shards of a batch, frame-major
-    for (uint32_t i = 0; i < d->nslots; i++) {
-        DistSlot &sl = d->slots[i];
-        VRT_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-        VRT_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-        if (rank == 0) {
-            VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&sl.gathered), region * (size_t)world));
-            VRT_HIP(ctx, hipMemsetAsync(sl.gathered, 0, region * (size_t)world, ctx->stream));
-            sl.shard = sl.gathered; // rank 0's own tiles are region 0 of the gathered buffer: no copy
-            VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&sl.frame), (size_t)ctx->cfg.width * ctx->cfg.height * 4u * d->batch));
-        } else {
-            VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&sl.shard), region));
-            VRT_HIP(ctx, hipMemsetAsync(sl.shard, 0, region, ctx->stream));
-        }
-    }
-    if (!ctx->ev_upload) VRT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
-    // everything enqueued on the primary stream so far (scene uploads, clears) precedes the first frame of every slot
-    VRT_HIP(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
-    ctx->upload_seq++;
-    return VRT_OK;
-}
-
-int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight) {
-    return vrt_dist_init_batched(ctx, rccl_path, id128, rank, world, frames_in_flight, 1);
-}
-
-int vrt_dist_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun) {
-    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
-    Dist *d = ctx->dist;
-    DeviceGuard dg(ctx->device);
-    vrt::KernelFn fn = nullptr;
-    const int rcp = pre_dispatch(ctx, camera, sun, &fn); // (a scene write it may have to do launches the queued frames first)
-    if (rcp != VRT_OK) return rcp;
-    // the pipeline's launches overlap on several streams and write RGB shards with a row-of-eight-lanes shuffle: both
-    // need the lockstep kernel (vrt_path_kernel has one pixel counter per stream and no fixed lane -> pixel map)
-    if (fn == ctx->kernel || (ctx->kernel_grid_exit && fn == ctx->kernel_grid_exit)) fn = ctx->kernel_lockstep;
-    if (d->npend > 0 && d->pend_fn != fn) { // another kernel specialisation (bounces / samples changed): not in the same launch
-        const int rcf = dist_flush(ctx);
-        if (rcf != VRT_OK) return rcf;
-    }
-    note_kernel(ctx, fn);
-    d->pend[d->npend].cam = *camera;
-    d->pend[d->npend].sun = *sun;
-    d->pend_fn = fn;
-    d->npend++;
-    return d->npend >= d->batch ? dist_flush(ctx) : VRT_OK;
-}
-
-} // extern "C"
-
-namespace {
-// vrt_dist_profile: add the stage times of the slot's most recent launch to the sums (wait: the launch is known to have
-// finished; otherwise only if it has)
-void dist_collect(Dist *d, DistSlot &sl, bool finished) {
-    if (!sl.marked) return;
-    sl.marked = false;
-    if (!finished && hipEventQuery(sl.mark[3]) != hipSuccess) return;
-    float ms[3] = {0.0f, 0.0f, 0.0f};
-    for (int k = 0; k < 3; k++)
-        if (hipEventElapsedTime(&ms[k], sl.mark[k], sl.mark[k + 1]) != hipSuccess) return;
-    for (int k = 0; k < 3; k++) d->prof_ms[k] += (double)ms[k];
-    d->prof_launches++;
-    d->prof_frames += sl.frames;
-}
-
-// Launch the queued frames: one kernel over (tiles of this rank) x (frames), ONE collective, one un-swizzle per frame.
-int dist_flush(vrt_ctx *ctx) {
-    Dist *d = ctx->dist;
-    if (d->failed) return fail(ctx, VRT_E_RCCL, "an earlier collective of this context failed: its ranks are out of step, destroy it");
-    const uint32_t n = d->npend;
-    if (n == 0) return VRT_OK;
-    d->npend = 0; // (also on failure: the frames are dropped, not retried)
-    const int k = (int)(d->frame_no % d->nslots);
-    DistSlot &sl = d->slots[k];
-    if (sl.seen_upload != ctx->upload_seq) { // scene writes happen on the primary stream
-        VRT_HIP(ctx, hipStreamWaitEvent(sl.stream, ctx->ev_upload, 0));
-        sl.seen_upload = ctx->upload_seq;
-    }
-    // 1. this rank's tiles of the n frames, packed tile-major, frame after frame, straight into the buffer RCCL sends
-    //    (rank 0: into region 0 of `gathered`)
-    vrt::TraceParams pk = ctx->params;
-    if (ctx->order_auto) pk.tile_order = 3u; // (no cost feedback across the slots of the pipeline yet)
-    for (uint32_t f = 0; f < n; f++) pk.pcs[f] = d->pend[f];
-    pk.target_rgba8 = sl.shard;
-    pk.target_rgba32f = nullptr;
-    pk.packed_tiles = 1u;
-    pk.packed_rgb = 1u;
-    // (a launch of n frames of this rank's tiles: half-tile workgroups while its waves do not fill the SIMDs twice)
-    pk.split_all = (ctx->split_ok && pk.tile_order == 3u && (uint64_t)ctx->shard.owned_tiles * 4u * n <= 2ull * ctx->simds) ? 1u : 0u;
-    pk.batch_target_stride = (uint32_t)d->shard_bytes;
-    if (sl.marked) dist_collect(d, sl, false); // (profile: the slot's previous launch, if it has finished; else that sample is dropped)
-    const bool mark = d->profile;
-    if (mark) {
-        for (hipEvent_t &e : sl.mark)
-            if (!e) VRT_HIP(ctx, hipEventCreate(&e));
-        VRT_HIP(ctx, hipEventRecord(sl.mark[0], sl.stream));
-    }
-    VRT_HIP(ctx, vrt::launch_trace(d->pend_fn, pk, ctx->lds_bytes, sl.stream, n));
-    if (mark) VRT_HIP(ctx, hipEventRecord(sl.mark[1], sl.stream));
-    // 2. the one collective of the batch: every rank's shards -> rank 0 (grouped point-to-point = gather)
-    const size_t region = d->shard_bytes * d->batch;
-    if (d->world > 1) {
-        VRT_NCCL(ctx, d, d->api.GroupStart());
-        // a failing Send / Recv must not leave the group open on this rank: close it, then report, and the context
-        // stays failed (every later vrt_dist_* call returns VRT_E_RCCL) because its peers are now out of step
-        ncclResult_t first_bad = ncclSuccess;
-        if (d->rank == 0) {
-            for (int r = 1; r < d->world && first_bad == ncclSuccess; r++)
-                first_bad = d->api.Recv(sl.gathered + (size_t)r * region, d->shard_bytes * n, ncclUint8, r, d->comm, sl.stream);
-        } else {
-            first_bad = d->api.Send(sl.shard, d->shard_bytes * n, ncclUint8, 0, d->comm, sl.stream);
-        }
-        const ncclResult_t end = d->api.GroupEnd();
-        if (first_bad != ncclSuccess || end != ncclSuccess) {
-            d->failed = true;
-            return fail(ctx, VRT_E_RCCL, std::string("RCCL gather failed: ") + d->api.GetErrorString(first_bad != ncclSuccess ? first_bad : end));
-        }
-    }
-    if (mark) VRT_HIP(ctx, hipEventRecord(sl.mark[2], sl.stream));
-    // 3. rank 0: tile-major shards -> row-major frames
-    if (d->rank == 0) {
-        // (one launch for the n frames of the batch: grid.z)
-        VRT_HIP(ctx, vrt::launch_assemble_rgb(sl.gathered, sl.frame, ctx->cfg.width, ctx->cfg.height, ctx->shard.tiles_x, (uint32_t)d->world,
-                                              ctx->shard.tiles_per_rank * d->batch, ctx->own, sl.stream, n, (uint32_t)d->shard_bytes));
-    }
-    if (mark) VRT_HIP(ctx, hipEventRecord(sl.mark[3], sl.stream));
-    sl.marked = mark;
-    VRT_HIP(ctx, hipEventRecord(sl.done, sl.stream));
-    sl.used = true;
-    sl.frames = n;
-    d->last_slot = k;
-    d->frame_no++;
-    return VRT_OK;
-}
-} // namespace
-
-extern "C" {
-
-int vrt_dist_wait(vrt_ctx *ctx) {
-    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
-    DeviceGuard dg(ctx->device);
-    const int rcf = dist_flush(ctx);
-    if (rcf != VRT_OK) return rcf;
-    for (uint32_t i = 0; i < ctx->dist->nslots; i++) VRT_HIP(ctx, wait_stream(ctx->dist->slots[i].stream));
-    VRT_HIP(ctx, wait_stream(ctx->stream));
-    for (uint32_t i = 0; i < ctx->dist->nslots; i++) dist_collect(ctx->dist, ctx->dist->slots[i], true);
-    return VRT_OK;
-}
-
-int vrt_dist_profile(vrt_ctx *ctx, uint32_t enable) {
-    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
-    Dist *d = ctx->dist;
-    d->profile = enable != 0u;
-    d->prof_launches = d->prof_frames = 0;
-    d->prof_ms[0] = d->prof_ms[1] = d->prof_ms[2] = 0.0;
-    return VRT_OK;
-}
-
-int vrt_dist_stats(vrt_ctx *ctx, double out[8]) {
-    if (!ctx || !ctx->dist || !out) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called / out NULL") : VRT_E_INVALID_ARG;
-    const Dist *d = ctx->dist;
-    const double n = d->prof_launches ? (double)d->prof_launches : 1.0;
-    out[0] = (double)d->prof_launches;
-    out[1] = (double)d->prof_frames;
-    out[2] = d->prof_ms[0] / n;
-    out[3] = d->prof_ms[1] / n;
-    out[4] = d->rank == 0 ? d->prof_ms[2] / n : 0.0; // (only rank 0 un-swizzles; elsewhere the interval holds two event records)
-    out[5] = (double)ctx->shard.owned_tiles;
-    out[6] = (double)d->shard_bytes;
-    out[7] = (double)d->batch;
-    return VRT_OK;
-}
-
-int vrt_dist_info(vrt_ctx *ctx, int32_t out[4]) {
-    if (!ctx || !ctx->dist || !out) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called / out NULL") : VRT_E_INVALID_ARG;
-    Dist *d = ctx->dist;
-    int rank = d->rank, world = d->world;
-    // what the communicator itself says, not what vrt_dist_init was told
-    if (d->comm && d->api.CommCount && d->api.CommUserRank) {
-        VRT_NCCL(ctx, d, d->api.CommCount(d->comm, &world));
-        VRT_NCCL(ctx, d, d->api.CommUserRank(d->comm, &rank));
-    }
-    out[0] = rank;
-    out[1] = world;
-    out[2] = (int32_t)d->batch;
-    out[3] = (int32_t)d->nslots;
-    return VRT_OK;
-}
-
-int vrt_dist_read_frame(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
-    if (!ctx || !ctx->dist || !dst) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called / dst NULL") : VRT_E_INVALID_ARG;
-    Dist *d = ctx->dist;
-    if (d->rank != 0) return fail(ctx, VRT_E_STATE, "only rank 0 holds the assembled frame");
-    if (nbytes > (uint64_t)ctx->cfg.width * ctx->cfg.height * 4u) return fail(ctx, VRT_E_OUT_OF_RANGE, "read exceeds the frame");
-    DeviceGuard dg(ctx->device);
-    // A launch carries a collective, so every rank must launch the same frames together: rank 0 cannot launch a partial
-    // queue on its own.  Queues empty themselves when full and in vrt_dist_wait, which every rank calls.
-    if (d->npend) return fail(ctx, VRT_E_STATE, "frames are still queued for the next launch: call vrt_dist_wait on every rank first");
-    if (d->last_slot < 0) return fail(ctx, VRT_E_STATE, "no frame submitted yet");
-    DistSlot &sl = d->slots[d->last_slot];
-    const size_t frame_bytes = (size_t)ctx->cfg.width * ctx->cfg.height * 4u;
-    VRT_HIP(ctx, hipMemcpyAsync(dst, sl.frame + (size_t)(sl.frames - 1u) * frame_bytes, nbytes, hipMemcpyDeviceToHost, sl.stream));
-    VRT_HIP(ctx, hipStreamSynchronize(sl.stream));
-    return VRT_OK;
-}
-
-int vrt_dist_selftest(vrt_ctx *ctx) {
-    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
-    Dist *d = ctx->dist;
-    DeviceGuard dg(ctx->device);
-    const size_t n = d->shard_bytes;
-    uint8_t *a = nullptr, *b = nullptr;
-    VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a), n));
-    VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&b), n));
-    std::string host(n, '\0'), back(n, '\0');
-    for (size_t i = 0; i < n; i++) host[i] = (char)((i * 131u + 7u) & 0xFFu);
-    hipStream_t s = d->slots[0].stream;
-    int rc = VRT_OK;
-    do {
-        if (hipMemcpyAsync(a, host.data(), n, hipMemcpyHostToDevice, s) != hipSuccess || hipMemsetAsync(b, 0, n, s) != hipSuccess) {
-            rc = fail(ctx, VRT_E_HIP, "selftest copy failed");
-            break;
-        }
-        ncclResult_t r = d->api.GroupStart();
-        if (r == ncclSuccess) r = d->api.Send(a, n, ncclUint8, d->rank, d->comm, s);
-        if (r == ncclSuccess) r = d->api.Recv(b, n, ncclUint8, d->rank, d->comm, s);
-        const ncclResult_t r2 = d->api.GroupEnd();
-        if (r == ncclSuccess) r = r2;
-        if (r != ncclSuccess) {
-            rc = fail(ctx, VRT_E_RCCL, std::string("self send/recv: ") + d->api.GetErrorString(r));
-            break;
-        }
-        if (hipMemcpyAsync(&back[0], b, n, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-            rc = fail(ctx, VRT_E_HIP, "selftest read-back failed");
-            break;
-        }
-        if (back != host) rc = fail(ctx, VRT_E_RCCL, "self send/recv returned different bytes");
-    } while (0);
-    (void)hipFree(a);
-    (void)hipFree(b);
-    return rc;
-}
-
-// Replica update (delta upload "+ replica broadcast"): one collective per dirty range.
-int vrt_dist_broadcast(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, uint64_t nbytes, int root) {
-    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
-    Dist *d = ctx->dist;
-    if (d->failed) return fail(ctx, VRT_E_RCCL, "an earlier collective failed: the ranks are out of step, destroy the context");
-    if ((int)id < 0 || id >= VRT_BUF_COUNT) return fail(ctx, VRT_E_INVALID_ARG, "bad buffer id");
-    if (root < 0 || root >= d->world) return fail(ctx, VRT_E_INVALID_ARG, "root is not a rank of the communicator");
-    if (byte_offset > ctx->dsize[id] || nbytes > ctx->dsize[id] - byte_offset)
-        return fail(ctx, VRT_E_OUT_OF_RANGE, "range exceeds device buffer (DestOutOfDeviceMemory)");
-    if (nbytes == 0) return VRT_OK;
-    DeviceGuard dg(ctx->device);
-    // a scene write: frames queued or in flight see the scene as it was, later ones as it becomes
-    const int rcb = begin_scene_write(ctx);
-    if (rcb != VRT_OK) return rcb;
-    uint8_t *range = static_cast<uint8_t *>(ctx->dbuf[id]) + byte_offset;
-    ncclResult_t r = ncclSuccess;
-    {
-        if (d->api.Broadcast) { // (also with a single rank: the call is then RCCL's own no-op, and the binding is exercised)
-            r = d->api.Broadcast(range, range, (size_t)nbytes, ncclUint8, root, d->comm, ctx->stream);
-        } else {
-            r = d->api.GroupStart();
-            if (d->rank == root) {
-                for (int peer = 0; peer < d->world && r == ncclSuccess; peer++)
-                    if (peer != root) r = d->api.Send(range, (size_t)nbytes, ncclUint8, peer, d->comm, ctx->stream);
-            } else if (r == ncclSuccess) {
-                r = d->api.Recv(range, (size_t)nbytes, ncclUint8, root, d->comm, ctx->stream);
-            }
-            const ncclResult_t r2 = d->api.GroupEnd(); // (always: an open group would swallow every later call)
-            if (r == ncclSuccess) r = r2;
-        }
-    }
-    if (r != ncclSuccess) {
-        d->failed = true;
-        return fail(ctx, VRT_E_RCCL, std::string("replica broadcast: ") + d->api.GetErrorString(r));
-    }
-    if (id == VRT_BUF_GRID_STATE && d->rank != root) {
-        // the kernel takes the UBO through its argument block: bring the host mirror up to date
-        VRT_HIP(ctx, hipMemcpyAsync(reinterpret_cast<uint8_t *>(&ctx->params.grid) + byte_offset, range, nbytes, hipMemcpyDeviceToHost, ctx->stream));
-        VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    mark_dirty(ctx, id, byte_offset, nbytes);
-    return end_scene_write(ctx);
 }
 
 int vrt_get_counters(vrt_ctx *ctx, vrt_counters *out) {

@@ -1,0 +1,520 @@
+// vrt_dist.hip — the multi-GPU frame pipeline behind vrt_dist_* (include/vrt_hip.h): one process per GPU, the frame sharded by
+// interleaved 16x16 tiles, ONE gather per launch (grouped ncclSend / ncclRecv over xGMI) to rank 0, which un-swizzles.
+// RCCL is reached through dlopen of the library the host process already uses; libvrt_hip.so does not link it.
+// The reference is single-GPU: this is north_star's image-tile sharding.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and prototypes only: the library is reached through dlopen, not linked
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include "vrt_ctx.h"
+
+using namespace vrt_impl;
+
+// RCCL entry points resolved with dlsym from the library the host process already uses.
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr; // optional: replica updates fall back to send / recv from the root
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;       // optional (vrt_dist_info)
+    decltype(&ncclCommUserRank) CommUserRank = nullptr; // optional
+    bool load(const char *path, std::string &err) {
+        lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) {
+            err = std::string("dlopen(") + (path ? path : "NULL") + "): " + dlerror();
+            return false;
+        }
+#define VRT_RCCL_SYM(field, name)                                   \
+        field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); \
+        if (!field) {                                                \
+            err = std::string("dlsym ") + name + " failed";         \
+            return false;                                            \
+        }
+        VRT_RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+        VRT_RCCL_SYM(CommInitRank, "ncclCommInitRank")
+        VRT_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+        VRT_RCCL_SYM(GroupStart, "ncclGroupStart")
+        VRT_RCCL_SYM(GroupEnd, "ncclGroupEnd")
+        VRT_RCCL_SYM(Send, "ncclSend")
+        VRT_RCCL_SYM(Recv, "ncclRecv")
+        VRT_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef VRT_RCCL_SYM
+        Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(lib, "ncclBroadcast"));
+        CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
+        CommUserRank = reinterpret_cast<decltype(CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
+        return true;
+    }
+};
+
+constexpr uint32_t kMaxDistSlots = 8;
+
+// One launch in flight of the multi-GPU pipeline: its stream carries kernel -> gather -> un-swizzle for a batch of up to
+// `batch` consecutive frames (see Dist).
+struct DistSlot {
+    hipStream_t stream = nullptr;
+    uint8_t *shard = nullptr;    // this rank's packed tiles, frame-major: batch x shard_bytes (on rank 0: region 0 of `gathered`)
+    uint8_t *gathered = nullptr; // rank 0: world x batch x shard_bytes, rank-major then frame-major
+    uint8_t *frame = nullptr;    // rank 0: batch row-major RGBA8 frames
+    hipEvent_t done = nullptr;
+    vrt::PersistentLane lane;    // frames of the persistent kernels on this slot's stream: unit counters, path records, sample buffer
+    uint64_t seen_upload = 0;
+    uint32_t frames = 0;         // frames of the batch this slot holds
+    bool used = false;
+    // vrt_dist_profile: events around the three stages of the slot's most recent launch (kernel | collective | un-swizzle)
+    hipEvent_t mark[4] = {};
+    bool marked = false;         // the most recent launch recorded its marks and they have not been read yet
+};
+
+struct Dist {
+    RcclApi api;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    uint32_t nslots = 0;
+    DistSlot slots[kMaxDistSlots];
+    uint64_t frame_no = 0;       // batches launched so far (slot = frame_no % nslots)
+    int last_slot = -1;
+    size_t shard_bytes = 0;
+    // Frames are traced `batch` to a launch (grid.y): a rank owns 1/world of the tiles, too few waves to fill the GPU
+    // and no shorter than the frame's longest wave, so single-frame launches leave most of the machine idle
+    // (tools/shard_streams.py: 19-31 us per 1/8 frame with eight single-frame launches in flight, against 8-18 us for
+    // an eighth of a whole-frame launch).  vrt_dist_frame queues; a full queue, vrt_dist_wait, vrt_dist_read_frame or a
+    // scene upload launches what is queued.
+    uint32_t batch = 1;
+    bool failed = false;         // a collective failed: peers are out of step, every later vrt_dist_* call fails
+    uint32_t npend = 0;
+    vrt::PushConstants pend[vrt::kMaxBatchFrames];
+    vrt::KernelFn pend_fn = nullptr;
+    bool pend_samples = false;   // ... a persistent kernel that takes samples as its units (vrt_pool_resolve_kernel writes the shard)
+    // vrt_dist_profile / vrt_dist_stats: per-launch stage times, summed over the launches sampled
+    bool profile = false;
+    uint64_t prof_launches = 0, prof_frames = 0;
+    double prof_ms[3] = {0.0, 0.0, 0.0}; // kernel, collective, un-swizzle
+};
+
+// ---- multi-GPU frame pipeline ------------------------------------------------------------------------
+#define VRT_NCCL(ctx, d, call)                                                                               \
+    do {                                                                                                     \
+        const ncclResult_t r_ = (call);                                                                      \
+        if (r_ != ncclSuccess) return fail(ctx, VRT_E_RCCL, std::string(#call) + ": " + (d)->api.GetErrorString(r_)); \
+    } while (0)
+
+extern "C" {
+
+int vrt_dist_unique_id(const char *rccl_path, void *out_id128) {
+    if (!rccl_path || !out_id128) return VRT_E_INVALID_ARG;
+    RcclApi api;
+    std::string err;
+    if (!api.load(rccl_path, err)) return fail(nullptr, VRT_E_RCCL, err);
+    ncclUniqueId id;
+    const ncclResult_t r = api.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, VRT_E_RCCL, std::string("ncclGetUniqueId: ") + api.GetErrorString(r));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(out_id128, &id, sizeof id);
+    return VRT_OK;
+}
+
+int vrt_dist_init_batched(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight,
+                          uint32_t frames_per_launch) {
+    if (!ctx || !rccl_path || !id128) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL argument") : VRT_E_INVALID_ARG;
+    if (ctx->dist) return fail(ctx, VRT_E_STATE, "vrt_dist_init called twice");
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, VRT_E_INVALID_ARG, "bad rank / world");
+    if ((uint32_t)world != ctx->shard.shard_count || (uint32_t)rank != ctx->shard.shard_rank)
+        return fail(ctx, VRT_E_INVALID_ARG, "context was not created with shard_rank / shard_count = rank / world");
+    if (ctx->stream_b || ctx->cfg.stream || ctx->cfg.external_target_rgba8 || ctx->d_counters)
+        return fail(ctx, VRT_E_STATE, "the multi-GPU pipeline owns its streams and targets (no frames_in_flight=2, caller stream/target or counters)");
+    if (frames_in_flight == 0) frames_in_flight = 4;
+    if (frames_in_flight > kMaxDistSlots) return fail(ctx, VRT_E_INVALID_ARG, "at most 8 launches in flight");
+    if (frames_per_launch == 0) frames_per_launch = 1;
+    if (frames_per_launch > (uint32_t)vrt::kMaxBatchFrames) return fail(ctx, VRT_E_INVALID_ARG, "at most 8 frames per launch");
+    DeviceGuard dg(ctx->device);
+    Dist *d = new (std::nothrow) Dist();
+    if (!d) return fail(ctx, VRT_E_OOM, "host allocation failed");
+    std::string err;
+    if (!d->api.load(rccl_path, err)) {
+        delete d;
+        return fail(ctx, VRT_E_RCCL, err);
+    }
+    if (ctx->cfg.tuning_flags & VRT_TUNE_DIST_NO_BROADCAST) d->api.Broadcast = nullptr; // the send / recv form of vrt_dist_broadcast
+    d->rank = rank;
+    d->world = world;
+    d->nslots = frames_in_flight;
+    d->batch = frames_per_launch;
+    // shards travel as RGB (the alpha of the RGBA8 target is the constant 255): a quarter less for rank 0's links to take in
+    d->shard_bytes = (size_t)ctx->shard.tiles_per_rank * vrt::kTileW * vrt::kTileH * 3u;
+    ctx->dist = d; // from here free_ctx cleans up
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    VRT_NCCL(ctx, d, d->api.CommInitRank(&d->comm, world, id, rank));
+    const size_t region = d->shard_bytes * d->batch; // one rank's shards of a batch, frame-major
+    for (uint32_t i = 0; i < d->nslots; i++) {
+        DistSlot &sl = d->slots[i];
+        VRT_HIP(ctx, ctx->res.stream(&sl.stream));
+        VRT_HIP(ctx, ctx->res.event(&sl.done, hipEventDisableTiming));
+        // (a context whose bounce frames the persistent kernels trace: each launch slot runs its frames beside the others')
+        if (vrt::is_path_kernel(ctx->kernel)) {
+            const int rcl = lane_init(ctx, sl.lane);
+            if (rcl != VRT_OK) return rcl;
+        }
+        if (rank == 0) {
+            VRT_HIP(ctx, ctx->res.device(&sl.gathered, region * (size_t)world));
+            VRT_HIP(ctx, hipMemsetAsync(sl.gathered, 0, region * (size_t)world, ctx->stream));
+            sl.shard = sl.gathered; // rank 0's own tiles are region 0 of the gathered buffer: no copy
+            VRT_HIP(ctx, ctx->res.device(&sl.frame, (size_t)ctx->cfg.width * ctx->cfg.height * 4u * d->batch));
+        } else {
+            VRT_HIP(ctx, ctx->res.device(&sl.shard, region));
+            VRT_HIP(ctx, hipMemsetAsync(sl.shard, 0, region, ctx->stream));
+        }
+    }
+    if (!ctx->ev_upload) VRT_HIP(ctx, ctx->res.event(&ctx->ev_upload, hipEventDisableTiming));
+    // everything enqueued on the primary stream so far (scene uploads, clears) precedes the first frame of every slot
+    VRT_HIP(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
+    ctx->upload_seq++;
+    return VRT_OK;
+}
+
+int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight) {
+    return vrt_dist_init_batched(ctx, rccl_path, id128, rank, world, frames_in_flight, 1);
+}
+
+// one frame into the pipeline's queue (vrt_dist_frame, vrt_dist_frames)
+static int dist_queue_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun) {
+    Dist *d = ctx->dist;
+    // (a refresh of the derived structures is a scene write and launches what is queued: do that now, so that the launch slot — and with
+    // it the lane — this frame's batch will use is known before the kernel is chosen)
+    if (d->npend && (ctx->status_dirty || ctx->occupancy_dirty || ctx->start_dirty || ctx->materials_dirty)) {
+        const int rcf = dist_flush(ctx);
+        if (rcf != VRT_OK) return rcf;
+    }
+    DistSlot &sl = d->slots[d->frame_no % d->nslots];
+    vrt::KernelFn fn = nullptr, product_fn = nullptr;
+    bool with_samples = false;
+    const int rcp = pre_dispatch(ctx, camera, sun, sl.lane.work_counter ? &sl.lane : nullptr, sl.stream, &fn, &product_fn, &with_samples);
+    if (rcp != VRT_OK) return rcp;
+    // Frames with bounces on scenes larger than the caches (round 5): the persistent kernels trace them inside the pipeline too, each
+    // launch slot with its own unit counters, path records and sample buffer; the shard is written by vrt_pool_resolve_kernel, whose
+    // fixed thread -> pixel map packs RGB like the lockstep kernel's.  Without the sample buffer (not to be had, VRT_TUNE_NO_SAMPLE_UNITS)
+    // vrt_path_kernel would store whole RGBA pixels from wherever a pixel ended: such frames keep the lockstep kernel.
+    if (vrt::is_path_kernel(fn) && !with_samples) fn = ctx->kernel_lockstep;
+    if (!vrt::is_path_kernel(fn)) with_samples = false;
+    if (d->npend > 0 && (d->pend_fn != fn || d->pend_samples != with_samples)) { // another kernel (bounces / samples changed): not in the same launch
+        const int rcf = dist_flush(ctx);
+        if (rcf != VRT_OK) return rcf;
+    }
+    note_kernel(ctx, fn);
+    d->pend[d->npend].cam = *camera;
+    d->pend[d->npend].sun = *sun;
+    d->pend_fn = fn;
+    d->pend_samples = with_samples;
+    d->npend++;
+    return d->npend >= d->batch ? dist_flush(ctx) : VRT_OK;
+}
+
+int vrt_dist_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun) {
+    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
+    DeviceGuard dg(ctx->device);
+    return dist_queue_frame(ctx, camera, sun);
+}
+
+int vrt_dist_frames(vrt_ctx *ctx, const vrt_camera_device *cameras, const vrt_sun_device *suns, uint32_t n, uint32_t sun_stride) {
+    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
+    if (n && (!cameras || !suns)) return fail(ctx, VRT_E_INVALID_ARG, "NULL cameras / suns");
+    DeviceGuard dg(ctx->device); // (one device switch, one call across the ABI for the n frames)
+    for (uint32_t i = 0; i < n; i++) {
+        const int rc = dist_queue_frame(ctx, &cameras[i], &suns[sun_stride ? (size_t)i * sun_stride : 0u]);
+        if (rc != VRT_OK) return rc;
+    }
+    return VRT_OK;
+}
+
+} // extern "C"
+
+namespace {
+// vrt_dist_profile: add the stage times of the slot's most recent launch to the sums (wait: the launch is known to have
+// finished; otherwise only if it has)
+void dist_collect(Dist *d, DistSlot &sl, bool finished) {
+    if (!sl.marked) return;
+    sl.marked = false;
+    if (!finished && hipEventQuery(sl.mark[3]) != hipSuccess) return;
+    float ms[3] = {0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < 3; k++)
+        if (hipEventElapsedTime(&ms[k], sl.mark[k], sl.mark[k + 1]) != hipSuccess) return;
+    for (int k = 0; k < 3; k++) d->prof_ms[k] += (double)ms[k];
+    d->prof_launches++;
+    d->prof_frames += sl.frames;
+}
+
+} // namespace
+
+namespace vrt_impl {
+// Launch the queued frames: one kernel over (tiles of this rank) x (frames), ONE collective, one un-swizzle per frame.
+int dist_flush(vrt_ctx *ctx) {
+    Dist *d = ctx->dist;
+    if (d->failed) return fail(ctx, VRT_E_RCCL, "an earlier collective of this context failed: its ranks are out of step, destroy it");
+    const uint32_t n = d->npend;
+    if (n == 0) return VRT_OK;
+    d->npend = 0; // (also on failure: the frames are dropped, not retried)
+    const int k = (int)(d->frame_no % d->nslots);
+    DistSlot &sl = d->slots[k];
+    if (sl.seen_upload != ctx->upload_seq) { // scene writes happen on the primary stream
+        VRT_HIP(ctx, hipStreamWaitEvent(sl.stream, ctx->ev_upload, 0));
+        sl.seen_upload = ctx->upload_seq;
+    }
+    // 1. this rank's tiles of the n frames, packed tile-major, frame after frame, straight into the buffer RCCL sends
+    //    (rank 0: into region 0 of `gathered`)
+    vrt::TraceParams pk = ctx->params;
+    if (ctx->order_auto) pk.tile_order = 3u; // (no cost feedback across the slots of the pipeline yet)
+    for (uint32_t f = 0; f < n; f++) pk.pcs[f] = d->pend[f];
+    pk.target_rgba8 = sl.shard;
+    pk.target_rgba32f = nullptr;
+    pk.packed_tiles = 1u;
+    pk.packed_rgb = 1u;
+    // (a launch of n frames of this rank's tiles: half-tile workgroups while its waves do not fill the SIMDs twice)
+    pk.split_all = (ctx->split_ok && pk.tile_order == 3u && (uint64_t)ctx->shard.owned_tiles * 4u * n <= 2ull * ctx->simds) ? 1u : 0u;
+    pk.batch_target_stride = (uint32_t)d->shard_bytes;
+    if (sl.marked) dist_collect(d, sl, false); // (profile: the slot's previous launch, if it has finished; else that sample is dropped)
+    const bool mark = d->profile;
+    if (mark) {
+        for (hipEvent_t &e : sl.mark)
+            if (!e) VRT_HIP(ctx, ctx->res.event(&e));
+        VRT_HIP(ctx, hipEventRecord(sl.mark[0], sl.stream));
+    }
+    if (vrt::is_path_kernel(d->pend_fn)) {
+        // the persistent kernels take ONE frame per launch (a frame of theirs fills the GPU by itself: the batch exists for the
+        // one-sample frames whose shards do not), each into its place of the batch's buffer; all on this slot's lane
+        pk.batch_target_stride = 0u;
+        for (uint32_t f = 0; f < n; f++) {
+            pk.pcs[0] = d->pend[f];
+            pk.target_rgba8 = sl.shard + (size_t)f * d->shard_bytes;
+            lane_into_params(sl.lane, d->pend_samples, pk);
+            VRT_HIP(ctx, vrt::launch_trace(d->pend_fn, pk, ctx->lds_bytes, sl.stream, 1));
+        }
+    } else {
+        VRT_HIP(ctx, vrt::launch_trace(d->pend_fn, pk, ctx->lds_bytes, sl.stream, n));
+    }
+    if (mark) VRT_HIP(ctx, hipEventRecord(sl.mark[1], sl.stream));
+    // 2. the one collective of the batch: every rank's shards -> rank 0 (grouped point-to-point = gather)
+    const size_t region = d->shard_bytes * d->batch;
+    if (d->world > 1) {
+        VRT_NCCL(ctx, d, d->api.GroupStart());
+        // a failing Send / Recv must not leave the group open on this rank: close it, then report, and the context
+        // stays failed (every later vrt_dist_* call returns VRT_E_RCCL) because its peers are now out of step
+        ncclResult_t first_bad = ncclSuccess;
+        if (d->rank == 0) {
+            for (int r = 1; r < d->world && first_bad == ncclSuccess; r++)
+                first_bad = d->api.Recv(sl.gathered + (size_t)r * region, d->shard_bytes * n, ncclUint8, r, d->comm, sl.stream);
+        } else {
+            first_bad = d->api.Send(sl.shard, d->shard_bytes * n, ncclUint8, 0, d->comm, sl.stream);
+        }
+        const ncclResult_t end = d->api.GroupEnd();
+        if (first_bad != ncclSuccess || end != ncclSuccess) {
+            d->failed = true;
+            return fail(ctx, VRT_E_RCCL, std::string("RCCL gather failed: ") + d->api.GetErrorString(first_bad != ncclSuccess ? first_bad : end));
+        }
+    }
+    if (mark) VRT_HIP(ctx, hipEventRecord(sl.mark[2], sl.stream));
+    // 3. rank 0: tile-major shards -> row-major frames
+    if (d->rank == 0) {
+        // (one launch for the n frames of the batch: grid.z)
+        VRT_HIP(ctx, vrt::launch_assemble_rgb(sl.gathered, sl.frame, ctx->cfg.width, ctx->cfg.height, ctx->shard.tiles_x, (uint32_t)d->world,
+                                              ctx->shard.tiles_per_rank * d->batch, ctx->own, sl.stream, n, (uint32_t)d->shard_bytes));
+    }
+    if (mark) VRT_HIP(ctx, hipEventRecord(sl.mark[3], sl.stream));
+    sl.marked = mark;
+    VRT_HIP(ctx, hipEventRecord(sl.done, sl.stream));
+    sl.used = true;
+    sl.frames = n;
+    d->last_slot = k;
+    d->frame_no++;
+    return VRT_OK;
+}
+
+bool dist_has_pending(const vrt_ctx *ctx) { return ctx->dist && ctx->dist->npend != 0; }
+
+int dist_order_primary_after_slots(vrt_ctx *ctx) {
+    if (!ctx->dist) return VRT_OK;
+    for (uint32_t i = 0; i < ctx->dist->nslots; i++)
+        if (ctx->dist->slots[i].used) VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->dist->slots[i].done, 0));
+    return VRT_OK;
+}
+
+bool dist_reserve_samples(vrt_ctx *ctx, uint64_t units) {
+    bool ok = true;
+    for (uint32_t i = 0; i < ctx->dist->nslots; i++) {
+        DistSlot &sl = ctx->dist->slots[i];
+        ok = sl.lane.work_counter && lane_samples_ready(ctx, sl.lane, units, sl.stream) && ok;
+    }
+    return ok;
+}
+
+void dist_destroy(vrt_ctx *ctx) {
+    Dist *d = ctx->dist;
+    if (!d) return;
+    for (uint32_t i = 0; i < d->nslots; i++)
+        if (d->slots[i].stream) (void)hipStreamSynchronize(d->slots[i].stream);
+    if (d->comm && d->api.CommDestroy) (void)d->api.CommDestroy(d->comm);
+    delete d;
+    ctx->dist = nullptr;
+}
+} // namespace vrt_impl
+
+extern "C" {
+
+int vrt_dist_wait(vrt_ctx *ctx) {
+    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
+    DeviceGuard dg(ctx->device);
+    const int rcf = dist_flush(ctx);
+    if (rcf != VRT_OK) return rcf;
+    for (uint32_t i = 0; i < ctx->dist->nslots; i++) VRT_HIP(ctx, wait_stream(ctx->dist->slots[i].stream));
+    VRT_HIP(ctx, wait_stream(ctx->stream));
+    for (uint32_t i = 0; i < ctx->dist->nslots; i++) dist_collect(ctx->dist, ctx->dist->slots[i], true);
+    return VRT_OK;
+}
+
+int vrt_dist_profile(vrt_ctx *ctx, uint32_t enable) {
+    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
+    Dist *d = ctx->dist;
+    d->profile = enable != 0u;
+    d->prof_launches = d->prof_frames = 0;
+    d->prof_ms[0] = d->prof_ms[1] = d->prof_ms[2] = 0.0;
+    return VRT_OK;
+}
+
+int vrt_dist_stats(vrt_ctx *ctx, double out[8]) {
+    if (!ctx || !ctx->dist || !out) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called / out NULL") : VRT_E_INVALID_ARG;
+    const Dist *d = ctx->dist;
+    const double n = d->prof_launches ? (double)d->prof_launches : 1.0;
+    out[0] = (double)d->prof_launches;
+    out[1] = (double)d->prof_frames;
+    out[2] = d->prof_ms[0] / n;
+    out[3] = d->prof_ms[1] / n;
+    out[4] = d->rank == 0 ? d->prof_ms[2] / n : 0.0; // (only rank 0 un-swizzles; elsewhere the interval holds two event records)
+    out[5] = (double)ctx->shard.owned_tiles;
+    out[6] = (double)d->shard_bytes;
+    out[7] = (double)d->batch;
+    return VRT_OK;
+}
+
+int vrt_dist_info(vrt_ctx *ctx, int32_t out[4]) {
+    if (!ctx || !ctx->dist || !out) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called / out NULL") : VRT_E_INVALID_ARG;
+    Dist *d = ctx->dist;
+    int rank = d->rank, world = d->world;
+    // what the communicator itself says, not what vrt_dist_init was told
+    if (d->comm && d->api.CommCount && d->api.CommUserRank) {
+        VRT_NCCL(ctx, d, d->api.CommCount(d->comm, &world));
+        VRT_NCCL(ctx, d, d->api.CommUserRank(d->comm, &rank));
+    }
+    out[0] = rank;
+    out[1] = world;
+    out[2] = (int32_t)d->batch;
+    out[3] = (int32_t)d->nslots;
+    return VRT_OK;
+}
+
+int vrt_dist_read_frame(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
+    if (!ctx || !ctx->dist || !dst) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called / dst NULL") : VRT_E_INVALID_ARG;
+    Dist *d = ctx->dist;
+    if (d->rank != 0) return fail(ctx, VRT_E_STATE, "only rank 0 holds the assembled frame");
+    if (nbytes > (uint64_t)ctx->cfg.width * ctx->cfg.height * 4u) return fail(ctx, VRT_E_OUT_OF_RANGE, "read exceeds the frame");
+    DeviceGuard dg(ctx->device);
+    // A launch carries a collective, so every rank must launch the same frames together: rank 0 cannot launch a partial
+    // queue on its own.  Queues empty themselves when full and in vrt_dist_wait, which every rank calls.
+    if (d->npend) return fail(ctx, VRT_E_STATE, "frames are still queued for the next launch: call vrt_dist_wait on every rank first");
+    if (d->last_slot < 0) return fail(ctx, VRT_E_STATE, "no frame submitted yet");
+    DistSlot &sl = d->slots[d->last_slot];
+    const size_t frame_bytes = (size_t)ctx->cfg.width * ctx->cfg.height * 4u;
+    VRT_HIP(ctx, hipMemcpyAsync(dst, sl.frame + (size_t)(sl.frames - 1u) * frame_bytes, nbytes, hipMemcpyDeviceToHost, sl.stream));
+    VRT_HIP(ctx, hipStreamSynchronize(sl.stream));
+    return VRT_OK;
+}
+
+int vrt_dist_selftest(vrt_ctx *ctx) {
+    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
+    Dist *d = ctx->dist;
+    DeviceGuard dg(ctx->device);
+    const size_t n = d->shard_bytes;
+    uint8_t *a = nullptr, *b = nullptr;
+    VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&a), n));
+    VRT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&b), n));
+    std::string host(n, '\0'), back(n, '\0');
+    for (size_t i = 0; i < n; i++) host[i] = (char)((i * 131u + 7u) & 0xFFu);
+    hipStream_t s = d->slots[0].stream;
+    int rc = VRT_OK;
+    do {
+        if (hipMemcpyAsync(a, host.data(), n, hipMemcpyHostToDevice, s) != hipSuccess || hipMemsetAsync(b, 0, n, s) != hipSuccess) {
+            rc = fail(ctx, VRT_E_HIP, "selftest copy failed");
+            break;
+        }
+        ncclResult_t r = d->api.GroupStart();
+        if (r == ncclSuccess) r = d->api.Send(a, n, ncclUint8, d->rank, d->comm, s);
+        if (r == ncclSuccess) r = d->api.Recv(b, n, ncclUint8, d->rank, d->comm, s);
+        const ncclResult_t r2 = d->api.GroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) {
+            rc = fail(ctx, VRT_E_RCCL, std::string("self send/recv: ") + d->api.GetErrorString(r));
+            break;
+        }
+        if (hipMemcpyAsync(&back[0], b, n, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(ctx, VRT_E_HIP, "selftest read-back failed");
+            break;
+        }
+        if (back != host) rc = fail(ctx, VRT_E_RCCL, "self send/recv returned different bytes");
+    } while (0);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return rc;
+}
+
+// Replica update (delta upload "+ replica broadcast"): one collective per dirty range.
+int vrt_dist_broadcast(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, uint64_t nbytes, int root) {
+    if (!ctx || !ctx->dist) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called") : VRT_E_INVALID_ARG;
+    Dist *d = ctx->dist;
+    if (d->failed) return fail(ctx, VRT_E_RCCL, "an earlier collective failed: the ranks are out of step, destroy the context");
+    if ((int)id < 0 || id >= VRT_BUF_COUNT) return fail(ctx, VRT_E_INVALID_ARG, "bad buffer id");
+    if (root < 0 || root >= d->world) return fail(ctx, VRT_E_INVALID_ARG, "root is not a rank of the communicator");
+    if (byte_offset > ctx->dsize[id] || nbytes > ctx->dsize[id] - byte_offset)
+        return fail(ctx, VRT_E_OUT_OF_RANGE, "range exceeds device buffer (DestOutOfDeviceMemory)");
+    if (nbytes == 0) return VRT_OK;
+    DeviceGuard dg(ctx->device);
+    // a scene write: frames queued or in flight see the scene as it was, later ones as it becomes
+    const int rcb = begin_scene_write(ctx);
+    if (rcb != VRT_OK) return rcb;
+    uint8_t *range = static_cast<uint8_t *>(ctx->dbuf[id]) + byte_offset;
+    ncclResult_t r = ncclSuccess;
+    {
+        if (d->api.Broadcast) { // (also with a single rank: the call is then RCCL's own no-op, and the binding is exercised)
+            r = d->api.Broadcast(range, range, (size_t)nbytes, ncclUint8, root, d->comm, ctx->stream);
+        } else {
+            r = d->api.GroupStart();
+            if (d->rank == root) {
+                for (int peer = 0; peer < d->world && r == ncclSuccess; peer++)
+                    if (peer != root) r = d->api.Send(range, (size_t)nbytes, ncclUint8, peer, d->comm, ctx->stream);
+            } else if (r == ncclSuccess) {
+                r = d->api.Recv(range, (size_t)nbytes, ncclUint8, root, d->comm, ctx->stream);
+            }
+            const ncclResult_t r2 = d->api.GroupEnd(); // (always: an open group would swallow every later call)
+            if (r == ncclSuccess) r = r2;
+        }
+    }
+    if (r != ncclSuccess) {
+        d->failed = true;
+        return fail(ctx, VRT_E_RCCL, std::string("replica broadcast: ") + d->api.GetErrorString(r));
+    }
+    if (id == VRT_BUF_GRID_STATE && d->rank != root) {
+        // the kernel takes the UBO through its argument block: bring the host mirror up to date
+        VRT_HIP(ctx, hipMemcpyAsync(reinterpret_cast<uint8_t *>(&ctx->params.grid) + byte_offset, range, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+        VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    mark_dirty(ctx, id, byte_offset, nbytes);
+    return end_scene_write(ctx);
+}
+
+} // extern "C"

@@ -637,11 +637,13 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
 
 // comp:173-177 for the frames vrt_pool_kernel traced: one thread per pixel of the owned tiles adds the pixel's terms
 // (TraceParams::pool_samples) in the sample loop's order, tone-maps and stores.  HBM-bound: 16 B per sample read, 4 (+ 16) B per pixel
-// written; 2 GiB for a 4K frame of 16 samples, 0.5 ms.
+// written; 2 GiB for a 4K frame of 16 samples, 0.5 ms.  A workgroup is one tile and its threads map to the tile's pixels as the lanes of
+// vrt_trace_kernel's four waves do, so the RGB shard of the multi-GPU pipeline (TraceParams::packed_rgb, round 5) is packed by the same
+// row-of-eight-lanes exchange.
 __global__ __launch_bounds__(256) void vrt_pool_resolve_kernel(const TraceParams p) {
     const PushConstants &pc = p.pcs[blockIdx.y];
     const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
-    if (pixel >= p.owned_tiles * (uint32_t)(kTileW * kTileH)) return;
+    if (pixel >= p.owned_tiles * (uint32_t)(kTileW * kTileH)) return; // (uniform over the workgroup)
     const uint32_t spp = (uint32_t)max(1, pc.cam.samples_per_pixel);
     const uint32_t owned = p.owned_tiles - 1u - (pixel >> 8);
     const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
@@ -649,18 +651,33 @@ __global__ __launch_bounds__(256) void vrt_pool_resolve_kernel(const TraceParams
     const uint32_t in_x = ((j >> 6) & 1u) * 8u + (j & 7u), in_y = (j >> 7) * 8u + ((j >> 3) & 7u);
     const uint32_t tile_y = tile / p.tiles_x, tile_x = tile - tile_y * p.tiles_x;
     const uint32_t px = tile_x * kTileW + in_x, py = tile_y * kTileH + in_y;
-    if (px >= p.width || py >= p.height) return; // comp:155-159
-    const float4 *s = p.pool_samples + (size_t)(pixel >> 6) * spp * 64u + (pixel & 63u); // (groups of 64 pixels, sample-major inside)
-    f3 acc = mk3(0, 0, 0);
-    for (uint32_t k = 0; k < spp; k++) {
-        const float4 t = s[(size_t)k * 64u];
-        acc = acc + mk3(t.x, t.y, t.z);
+    uint32_t rgba = 0u; // (0 outside the image: the shard's padding, as vrt_trace_kernel leaves it)
+    if (px < p.width && py < p.height) { // comp:155-159
+        const float4 *s = p.pool_samples + (size_t)(pixel >> 6) * spp * 64u + (pixel & 63u); // (groups of 64 pixels, sample-major inside)
+        f3 acc = mk3(0, 0, 0);
+        for (uint32_t k = 0; k < spp; k++) {
+            const float4 t = s[(size_t)k * 64u];
+            acc = acc + mk3(t.x, t.y, t.z);
+        }
+        const float fspp = (float)pc.cam.samples_per_pixel;
+        const f3 c = mk3(__builtin_sqrtf(acc.x / fspp), __builtin_sqrtf(acc.y / fspp), __builtin_sqrtf(acc.z / fspp));
+        const size_t o = (p.shard_count > 1u || p.packed_tiles) ? (size_t)owned * (kTileW * kTileH) + in_y * kTileW + in_x : (size_t)py * p.width + px;
+        rgba = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
+        if (!p.packed_rgb) reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] = rgba;
+        if (p.target_rgba32f) reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(c.x, c.y, c.z, 1.0f);
     }
-    const float fspp = (float)pc.cam.samples_per_pixel;
-    const f3 c = mk3(__builtin_sqrtf(acc.x / fspp), __builtin_sqrtf(acc.y / fspp), __builtin_sqrtf(acc.z / fspp));
-    const size_t o = (p.shard_count > 1u || p.packed_tiles) ? (size_t)owned * (kTileW * kTileH) + in_y * kTileW + in_x : (size_t)py * p.width + px;
-    reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[o] = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
-    if (p.target_rgba32f) reinterpret_cast<float4 *>(p.target_rgba32f)[o] = make_float4(c.x, c.y, c.z, 1.0f);
+    if (p.packed_rgb) {
+        // 16x16 tiles of 3-byte pixels, 768 bytes per tile: the eight threads of a row of this wave's 8x8 block hold 24 consecutive
+        // bytes = 6 dwords; thread k < 6 of the row assembles dword k from the two pixels it spans (vrt_trace_kernel's store)
+        const uint32_t lane = threadIdx.x & 63u, k = lane & 7u;
+        const uint32_t first = k + (k >= 3u ? 1u : 0u); // = 4k / 3 for k < 6
+        const int src = (int)((lane & ~7u) + first);
+        const uint32_t lo = (uint32_t)__shfl((int)rgba, src, 64), hi = (uint32_t)__shfl((int)rgba, src + 1, 64);
+        const uint32_t m = k % 3u;
+        const uint32_t dword = (m == 0u) ? ((lo & 0xFFFFFFu) | (hi << 24)) : ((m == 1u) ? (((lo >> 8) & 0xFFFFu) | (hi << 16)) : (((lo >> 16) & 0xFFu) | (hi << 8)));
+        if (k < 6u)
+            reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[(size_t)owned * 192u + in_y * 12u + (in_x >> 3) * 6u + k] = dword;
+    }
 }
 
 } // namespace vrt

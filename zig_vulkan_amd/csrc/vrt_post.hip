@@ -10,7 +10,7 @@
 // Arithmetic lowering is stated in the oracle's restatement header; pow() is ocml's here, so the
 // parity test uses the 1e-4 tolerance instead of bit equality.
 #include <hip/hip_runtime.h>
-#include "vrt_internal.h"
+#include "vrt_ctx.h"
 #include "vrt_math.h"
 
 namespace vrt {
@@ -204,3 +204,65 @@ hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias
 }
 
 } // namespace vrt
+
+// ---- the C ABI of the pass (include/vrt_hip.h: vrt_denoise, vrt_read_denoised_*, vrt_last_denoise_ms) ----
+using namespace vrt_impl;
+
+extern "C" {
+
+int vrt_denoise(vrt_ctx *ctx, const vrt_denoise_config *cfg, uint32_t out_w, uint32_t out_h, uint32_t want_float) {
+    if (!ctx || out_w == 0 || out_h == 0) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "zero output size") : VRT_E_INVALID_ARG;
+    if (ctx->shard.shard_count > 1u) return fail(ctx, VRT_E_STATE, "vrt_denoise needs the whole frame (unsharded context)");
+    vrt_denoise_config c{20, 0.6f, 1.5f, 20.0f}; // GraphicsPipeline.Config, GraphicsPipeline.zig:34-39
+    if (cfg) c = *cfg;
+    if (c.samples < 0 || c.samples > 4096) return fail(ctx, VRT_E_INVALID_ARG, "samples out of range");
+    DeviceGuard dg(ctx->device);
+    // runs on the stream that rendered the most recent frame, so it is ordered after that frame
+    const hipStream_t s = (ctx->last_slot == 1) ? ctx->stream_b : ctx->stream;
+    if (ctx->denoised_w != out_w || ctx->denoised_h != out_h || (want_float && !ctx->d_denoised32f)) {
+        VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->stream_b) VRT_HIP(ctx, hipStreamSynchronize(ctx->stream_b));
+        ctx->res.drop(ctx->d_denoised8);
+        ctx->res.drop(ctx->d_denoised32f);
+        VRT_HIP(ctx, ctx->res.device(&ctx->d_denoised8, (size_t)out_w * out_h * 4u));
+        if (want_float) VRT_HIP(ctx, ctx->res.device(&ctx->d_denoised32f, (size_t)out_w * out_h * 16u));
+        ctx->denoised_w = out_w;
+        ctx->denoised_h = out_h;
+    }
+    const void *img = (ctx->last_slot == 1) ? ctx->target8_b : ctx->target8;
+    VRT_HIP(ctx, hipEventRecord(ctx->ev_post_start, s));
+    VRT_HIP(ctx, vrt::launch_denoise(img, (int)ctx->cfg.width, (int)ctx->cfg.height, c.samples, c.distribution_bias, c.pixel_multiplier,
+                                     c.inverse_hue_tolerance, (int)out_w, (int)out_h, ctx->d_denoised8, want_float ? ctx->d_denoised32f : nullptr, s));
+    VRT_HIP(ctx, hipEventRecord(ctx->ev_post_stop, s));
+    ctx->post_timed = true;
+    ctx->denoised_stream = s;
+    return VRT_OK;
+}
+
+double vrt_last_denoise_ms(vrt_ctx *ctx) {
+    if (!ctx || !ctx->post_timed) return -1.0;
+    DeviceGuard dg(ctx->device);
+    if (wait_event(ctx->ev_post_stop) != hipSuccess) return -1.0;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev_post_start, ctx->ev_post_stop) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+static int read_denoised(vrt_ctx *ctx, void *dst, uint64_t nbytes, const void *src, uint64_t avail) {
+    if (!ctx || !dst) return VRT_E_INVALID_ARG;
+    if (!src) return fail(ctx, VRT_E_STATE, "no denoised image (call vrt_denoise first; want_float for the float image)");
+    if (nbytes > avail) return fail(ctx, VRT_E_OUT_OF_RANGE, "read exceeds the denoised image");
+    DeviceGuard dg(ctx->device);
+    VRT_HIP(ctx, hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx->denoised_stream));
+    VRT_HIP(ctx, hipStreamSynchronize(ctx->denoised_stream));
+    return VRT_OK;
+}
+int vrt_read_denoised_rgba8(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
+    return read_denoised(ctx, dst, nbytes, ctx ? ctx->d_denoised8 : nullptr, ctx ? (uint64_t)ctx->denoised_w * ctx->denoised_h * 4u : 0);
+}
+int vrt_read_denoised_rgba32f(vrt_ctx *ctx, void *dst, uint64_t nbytes) {
+    return read_denoised(ctx, dst, nbytes, ctx ? ctx->d_denoised32f : nullptr, ctx ? (uint64_t)ctx->denoised_w * ctx->denoised_h * 16u : 0);
+}
+void *vrt_device_denoised_rgba8(vrt_ctx *ctx) { return ctx ? ctx->d_denoised8 : nullptr; }
+
+} // extern "C"

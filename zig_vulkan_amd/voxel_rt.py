@@ -436,6 +436,20 @@ class VoxelRT:
     def dist_frame(self) -> None:
         self._check(self._lib.vrt_dist_frame(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data)))
 
+    def dist_frames(self, cameras, sun=None) -> None:
+        """vrt_dist_frames: the frames of `cameras` (96-byte Camera.Device blobs, or a ctypes array of CameraDevice) submitted by ONE
+        call across the ABI, all with this renderer's sun."""
+        if not isinstance(cameras, C.Array):
+            arr = (L.CameraDevice * len(cameras))()
+            for i, blob in enumerate(cameras):
+                C.memmove(C.byref(arr[i]), bytes(blob), 96)
+            cameras = arr
+        self._check(self._lib.vrt_dist_frames(self._h, cameras, C.byref(sun if sun is not None else self.sun.device_data), len(cameras), 0))
+
+    def reserve_samples(self, max_samples_per_pixel: int) -> None:
+        """vrt_reserve_samples: the persistent kernels' sample buffers made now instead of by the first dispatch that needs them."""
+        self._check(self._lib.vrt_reserve_samples(self._h, int(max_samples_per_pixel)))
+
     def dist_wait(self) -> None:
         self._check(self._lib.vrt_dist_wait(self._h))
 
