@@ -390,6 +390,12 @@ class _StubRT:
     def dist_frame(self):
         self.draw()
 
+    def dist_frames(self, cameras, sun=None):
+        self.draw(frames=len(cameras))
+
+    def reserve_samples(self, *a):
+        pass
+
     def dist_info(self):
         return {"rank": int(os.environ.get("RANK", "0")), "world": int(os.environ.get("WORLD_SIZE", "1")), "frames_per_launch": self.batch,
                 "launches_in_flight": 1}
@@ -597,10 +603,42 @@ class Leg:
                 W.set_view(self.rt, v)
                 self.cams[v] = bytes(self.rt.camera.d_camera)
         self._C = C
+        self._cam_arrays = {}
 
     def set_cam(self, v: str) -> None:
         if not self.env.stub:
             self._C.memmove(self._C.byref(self.rt.camera.d_camera), self.cams[v], 96)
+
+    def cam_array(self, v: str, count: int):
+        """`count` copies of view v's Camera.Device: the argument of one vrt_dist_frames call."""
+        key = (v, count)
+        if key not in self._cam_arrays:
+            if self.env.stub:
+                self._cam_arrays[key] = [None] * count
+            else:
+                from zig_vulkan_amd import _lib as VL
+                arr = (VL.CameraDevice * count)()
+                for i in range(count):
+                    self._C.memmove(self._C.byref(arr[i]), self.cams[v], 96)
+                self._cam_arrays[key] = arr
+        return self._cam_arrays[key]
+
+    def steps(self, n: int) -> None:
+        """Frames 0 .. n-1 of a run of n.  The native pipeline takes the consecutive frames of one view by ONE call across the ABI
+        (vrt_dist_frames, --dist-submit call: what a compiled host's frame loop costs — submitted frame by frame from Python the host
+        took 14.6 us of a 30 us frame, tools/dist_host_probe.py); everything else steps frame by frame."""
+        if self.sharded and self.native and self.env.args.dist_submit == "call":
+            i = 0
+            while i < n:
+                v, j = view_of(i, n), i
+                while j < n and view_of(j, n) == v:
+                    j += 1
+                self.set_cam(v)
+                self.rt.dist_frames(self.cam_array(v, j - i))
+                i = j
+            return
+        for i in range(n):
+            self.step(i, n)
 
     def step(self, i: int, n: int) -> None:
         self.set_cam(view_of(i, n))
@@ -627,8 +665,7 @@ class Leg:
 
     def run(self, n: int) -> None:
         """n untimed frames."""
-        for i in range(n):
-            self.step(i, n)
+        self.steps(n)
         self.drain()
 
     def timed(self, n: int) -> float:
@@ -640,8 +677,7 @@ class Leg:
         t0 = time.perf_counter()
         if events:
             self.rt.region_begin()   # (HIP events around the same steps, on both streams: `value_device_events`)
-        for i in range(n):
-            self.step(i, n)
+        self.steps(n)
         self.drain()  # the last frame's gather + un-swizzle belong to the timed region
         if not self.native:
             self.rt.wait()
@@ -696,13 +732,13 @@ class Leg:
             self.rt = None
 
 
-def tuned_leg(env: Env, W, w, grid, batch: int, want_native: bool):
+def tuned_leg(env: Env, W, w, grid, batch: int, want_native: bool, fixed_share: int = -1):
     """The multi-GPU leg with rank 0's tile share chosen by a warm-up auto-tune: each candidate share gets its own context and
     communicator, 8 untimed + 32 timed frames (maximum over ranks, so every rank sees the same numbers and picks the same
     winner); the winner's context is kept, the others are destroyed.  --root-share N (>= 0) skips the tune."""
     args, world = env.args, env.world
-    if args.root_share >= 0 or not (2 <= world <= 8) or not want_native:
-        share = args.root_share if args.root_share >= 0 else 100
+    if args.root_share >= 0 or fixed_share >= 0 or not (2 <= world <= 8) or not want_native:
+        share = args.root_share if args.root_share >= 0 else (fixed_share if fixed_share >= 0 else 100)
         return Leg(env, W, w, grid, sharded=True, want_native=want_native, batch=batch, root_share=share), {"tuned": False, "root_share": share}
     legs, ms = {}, {}
     for share in root_share_candidates(world):
@@ -750,6 +786,9 @@ def main(argv=None) -> None:
     ap.add_argument("--dist-batch", type=int, default=8,
                     help="frames traced by one launch and carried by one collective in the batched leg when world > 1 (every frame is gathered "
                          "once); the north_star-literal leg, one collective per frame, is always timed as well")
+    ap.add_argument("--dist-submit", choices=["call", "frame"], default="call",
+                    help="native multi-GPU pipeline: call = the consecutive frames of a view submitted by one vrt_dist_frames call (a compiled host's "
+                         "frame loop); frame = one vrt_dist_frame call per frame from Python")
     ap.add_argument("--root-share", type=int, default=-1,
                     help="native multi-GPU pipeline: rank 0's share of the tiles in percent of an equal share; -1: chosen per leg by a warm-up "
                          "auto-tune over three candidates around 100 - 70 (world - 2) / 6")
@@ -928,46 +967,85 @@ def main(argv=None) -> None:
         print("[bench] headline legs: " + json.dumps({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "legs": legs_out,
                                                       "root_share_tuning": tune_reports}), file=sys.stderr, flush=True)
 
-    # ---- N > 1: the same pipeline on BASELINE.json's sharded configuration (configs[3]: 3840x2160, 1024^3, 4 rays per pixel) ----
-    secondary = None
-    # (the secondary leg builds a 1024^3 grid per rank — ~13 s — tunes three root shares and times up to `steps` 4K frames: budgeted as
-    # what the headline's contexts + tuning + legs took, twice over, + 60 s; if that does not fit the wall budget it is skipped, and says so)
-    spent = time.perf_counter() - t_run0
-    secondary_estimate = 2.0 * (phase_seconds.get("contexts_and_root_share_tuning", 0.0) + phase_seconds.get("timed_legs", 0.0)) + 60.0
-    secondary_fits = bool(env.all_min_int(int(spent + secondary_estimate <= args.wall_budget)))
-    if sharded and world > 1 and native and not args.no_secondary and (args.workload or W.HEADLINE) == W.HEADLINE and not secondary_fits:
-        secondary = {"skipped": f"wall budget: {spent:.0f} s spent + ~{secondary_estimate:.0f} s estimated > {args.wall_budget:.0f} s"}
-    elif sharded and world > 1 and native and not args.no_secondary and (args.workload or W.HEADLINE) == W.HEADLINE:
-        try:
-            w2 = W.WORKLOADS["cfg3_4k_1024c_b8"]
-            grid2 = None if stub else W.build_grid(w2)
-            # (rank 0 counts alone: a failure there must reach every rank, or the others would wait in the broadcast for ever)
-            pv2, err2 = None, None
-            if stub:
-                pv2 = stub_counts()
-            elif rank == 0:
-                try:
-                    pv2 = count_rays(W, w2, grid2, VIEW_ORDER, args.variant, local_rank)
-                except Exception as e:  # noqa: BLE001
-                    err2 = f"{type(e).__name__}: {e}"
-            pv2, err2 = env.bcast((pv2, err2))
-            if err2:
-                raise RuntimeError(f"counting the rays of {w2.name} failed on rank 0: {err2}")
-            leg2, rep2 = tuned_leg(env, W, w2, grid2, args.dist_batch, True)
+    # ---- N > 1: the same pipeline on BASELINE.json's sharded configurations: configs[3] (3840x2160, 1024^3, 4 rays per pixel: the one
+    # BASELINE names for 2 -> 4 -> 8 GPUs) and configs[4] (3840x2160, 2048^3 sparse, 16 spp path trace, "8 MI355X") ----
+    def secondary_leg(name, batches, tune, budget_note):
+        """One BASELINE configuration through the native pipeline: per entry of `batches` a timed leg (1 = north_star's literal one RCCL
+        gather per frame, whose rate is the leg's `value`; n = n frames per launch and per collective).  The root share is tuned on
+        the first leg only (three candidates) and kept for the others; tune=False: an equal share (frames of milliseconds, beside
+        which rank 0's receives and un-swizzle are nothing)."""
+        w2 = W.WORKLOADS[name]
+        t0 = time.perf_counter()
+        grid2 = None if stub else W.build_grid(w2)
+        # (rank 0 counts alone: a failure there must reach every rank, or the others would wait in the broadcast for ever)
+        pv2, err2 = None, None
+        if stub:
+            pv2 = stub_counts()
+        elif rank == 0:
+            try:
+                pv2 = count_rays(W, w2, grid2, VIEW_ORDER, args.variant, local_rank)
+            except Exception as e:  # noqa: BLE001
+                err2 = f"{type(e).__name__}: {e}"
+        pv2, err2 = env.bcast((pv2, err2))
+        if err2:
+            raise RuntimeError(f"counting the rays of {w2.name} failed on rank 0: {err2}")
+        out2 = {"workload": w2.name, "metric": metric_name(w2), "unit": "Mrays/s", "legs": {}, "budget": budget_note}
+        share = -1 if tune else 100
+        for b in batches:
+            leg2, rep2 = tuned_leg(env, W, w2, grid2, b, True, fixed_share=share)
+            if not leg2.native:
+                leg2.close()
+                raise RuntimeError("the native pipeline was not available on every rank")
+            share = leg2.root_share
+            if not stub and w2.max_bounce > 0:
+                leg2.rt.reserve_samples(w2.spp)      # (the persistent kernels' sample buffers: made now, not inside the first frames)
             est2 = leg2.estimate_frame_ms()
             steps2 = int(min(args.steps, max(6, 2000.0 / est2)))
             leg2.run(min(args.warmup, steps2))
             dt2 = leg2.timed(steps2)
-            secondary = {"workload": w2.name, "metric": metric_name(w2), "value": rays_of(pv2, steps2) / dt2 / 1e6, "unit": "Mrays/s", "steps": steps2,
-                         "ms_per_step": dt2 / steps2 * 1e3, "frames_per_collective": leg2.batch, "root_share": rep2,
-                         "breakdown": leg2.breakdown(2 * args.dist_frames)}
+            out2["legs"][f"batch{leg2.batch}"] = {"value": rays_of(pv2, steps2) / dt2 / 1e6, "unit": "Mrays/s", "steps": steps2, "ms_per_step": dt2 / steps2 * 1e3,
+                                                 "frames_per_collective": leg2.batch, "launches_in_flight": leg2.launches_in_flight, "root_share": rep2,
+                                                 "kernel": None if stub else leg2.rt.kernel_name(), "breakdown": leg2.breakdown(2 * args.dist_frames)}
             leg2.close()
-            del grid2
-        except Exception as e:  # noqa: BLE001 - the secondary leg must never take the headline line down
-            print(f"[bench rank {rank}] secondary leg failed: {type(e).__name__}: {e}", file=sys.stderr)
-            secondary = {"error": f"{type(e).__name__}: {e}"}
+        first = f"batch{batches[0]}"
+        out2.update({"value": out2["legs"][first]["value"], "ms_per_step": out2["legs"][first]["ms_per_step"], "steps": out2["legs"][first]["steps"],
+                     "frames_per_collective": batches[0], "value_batched": out2["legs"][f"batch{batches[-1]}"]["value"] if len(batches) > 1 else None,
+                     "seconds": round(time.perf_counter() - t0, 1)})
+        del grid2
+        return out2
 
-    t_ph = phase("secondary_leg", t_ph)
+    secondary, secondary_cfg4 = None, None
+    run_secondary = sharded and world > 1 and native and not args.no_secondary and (args.workload or W.HEADLINE) == W.HEADLINE
+    # (budgets, decided by every rank alike through an all-reduce.  configs[3]: a 1024^3 grid built per rank — ~13 s —, three root-share
+    # candidates and two legs of up to `steps` 4K frames: estimated at twice what the headline's contexts + tuning + legs took + 60 s.
+    # configs[4]: a 2048^3 sparse grid per rank, rank 0's ray count (~5 s of counting-build frames), one leg at an equal share, frames of
+    # ~90 ms / N: 90 s.  A leg that would take the run past --wall-budget is skipped, and says so.)
+    for key, name, batches, tune, estimate in (
+            ("secondary", "cfg3_4k_1024c_b8", [1] + ([args.dist_batch] if args.dist_batch > 1 else []), True,
+             2.0 * (phase_seconds.get("contexts_and_root_share_tuning", 0.0) + phase_seconds.get("timed_legs", 0.0)) + 60.0),
+            ("secondary_cfg4", "cfg4_4k_2048c_b8_sparse", [1], False, 90.0)):
+        if not run_secondary:
+            break
+        spent = time.perf_counter() - t_run0
+        fits = bool(env.all_min_int(int(spent + estimate <= args.wall_budget)))
+        note = f"{spent:.0f} s spent + ~{estimate:.0f} s estimated against --wall-budget {args.wall_budget:.0f} s"
+        if not fits:
+            result = {"skipped": "wall budget: " + note}
+        else:
+            try:
+                result = secondary_leg(name, batches, tune, note)
+            except Exception as e:  # noqa: BLE001 - a secondary leg must never take the headline line down
+                print(f"[bench rank {rank}] {key} leg failed: {type(e).__name__}: {e}", file=sys.stderr)
+                result = {"error": f"{type(e).__name__}: {e}"}
+        if key == "secondary":
+            secondary = result
+        else:
+            secondary_cfg4 = result
+        if rank == 0:
+            print(f"[bench] {key}: " + json.dumps(result), file=sys.stderr, flush=True)
+        t_ph = phase(key + "_leg", t_ph)
+
+    t_ph = phase("secondary_leg", t_ph) if "secondary_leg" not in phase_seconds else t_ph
     # ---- N = 1: the same steps strictly one frame after another, and the dominant kernel by HIP events ----
     roofline = None
     single = None
@@ -1158,7 +1236,8 @@ def main(argv=None) -> None:
             out["wall_budget_s"] = args.wall_budget
             out["root_share_tuning"] = tune_reports
             out["native_probe"] = probe_report   # None: not run (one rank, --dist torch, --no-native-probe)
-            out["secondary"] = secondary
+            out["secondary"] = secondary            # configs[3]: legs.batch1 (= its `value`) and legs.batch<N>
+            out["secondary_cfg4"] = secondary_cfg4  # configs[4]: the path trace, one gather per frame
         if world == 1 and not sharded and not args.no_cpu_baseline and not stub:
             # frames of this library for the parity certificate: the product build, and its fused-arithmetic twin where built
             hip_frames = {}

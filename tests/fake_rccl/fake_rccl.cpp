@@ -33,6 +33,7 @@ struct Posted {
     void *staging;
     size_t bytes;
     hipEvent_t ready;
+    bool owned; // staging is this stand-in's buffer (false: zero-copy mode, the sender's own)
 };
 struct Staging {
     void *ptr;
@@ -49,6 +50,9 @@ std::mutex g_mu;
 std::condition_variable g_cv;
 std::map<std::string, World *> g_worlds;
 uint64_t g_next_id = 1;
+// measurement aid (tools/dist_emulate.py): no staging copy, the receiver copies straight out of the send buffer — only sound when the
+// sender never rewrites that buffer, as the feeder thread of that tool.  FAKE_RCCL_ZERO_COPY sets the initial state.
+bool g_zero_copy = std::getenv("FAKE_RCCL_ZERO_COPY") != nullptr;
 }
 
 struct ncclComm {
@@ -95,7 +99,7 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
         }
         for (auto &q : w->sends)
             for (Posted &s : q.second) {
-                (void)hipFree(s.staging);
+                if (s.owned) (void)hipFree(s.staging); // (a zero-copy send that was never received: the buffer is the sender's)
                 (void)hipEventDestroy(s.ready);
             }
         g_worlds.erase(comm->key);
@@ -116,6 +120,11 @@ ncclResult_t ncclCommUserRank(const ncclComm_t comm, int *rank) {
     return ncclSuccess;
 }
 
+void fake_rccl_set_zero_copy(int on) { // (between communicators only)
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_zero_copy = on != 0;
+}
+
 ncclResult_t ncclGroupStart() { return ncclSuccess; } // operations are carried out as they are posted
 ncclResult_t ncclGroupEnd() { return ncclSuccess; }
 
@@ -123,12 +132,10 @@ ncclResult_t ncclGroupEnd() { return ncclSuccess; }
 // real RCCL's ncclSend / ncclRecv if PyTorch's librccl is already in the process)
 static ncclResult_t send_impl(const void *sendbuff, size_t count, int peer, ncclComm_t comm, hipStream_t stream) {
     if (!comm || peer < 0 || peer >= comm->world->nranks) return ncclInvalidArgument;
-    Posted s{nullptr, count, nullptr};
-    static const bool zero_copy = std::getenv("FAKE_RCCL_ZERO_COPY") != nullptr;
-    if (zero_copy) {
-        // measurement aid (tools/root_rank.py): no staging copy, the receiver copies straight out of the send buffer — only
-        // sound when the sender never rewrites that buffer, as the feeder thread of that tool
+    Posted s{nullptr, count, nullptr, true};
+    if (g_zero_copy) {
         s.staging = const_cast<void *>(sendbuff);
+        s.owned = false;
         if (hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(s.ready, stream) != hipSuccess)
             return ncclUnhandledCudaError;
         {
@@ -175,8 +182,7 @@ static ncclResult_t recv_impl(void *recvbuff, size_t count, int peer, ncclComm_t
     if (hipStreamWaitEvent(stream, s.ready, 0) != hipSuccess) return ncclUnhandledCudaError;
     if (hipMemcpyAsync(recvbuff, s.staging, count, hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
     (void)hipEventDestroy(s.ready); // (destruction is deferred by the runtime until the wait has been carried out)
-    static const bool zero_copy = std::getenv("FAKE_RCCL_ZERO_COPY") != nullptr;
-    if (zero_copy) return ncclSuccess; // (the buffer is the sender's)
+    if (!s.owned) return ncclSuccess; // (the buffer is the sender's)
     Staging g{s.staging, s.bytes, nullptr};
     if (hipEventCreateWithFlags(&g.idle, hipEventDisableTiming) != hipSuccess || hipEventRecord(g.idle, stream) != hipSuccess) return ncclUnhandledCudaError;
     {

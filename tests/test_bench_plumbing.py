@@ -57,7 +57,7 @@ def test_gpus_2_without_rank_env_spawns_two_ranks():
     assert out["value_batched"] == out["legs"]["batch8"]["value"]
     assert "ONE collective per frame" in out["config"]["parallelism"]
     # per-phase wall clock of the run and the budget the secondary leg has to fit
-    assert {"startup", "count_rays", "native_probe", "contexts_and_root_share_tuning", "timed_legs", "secondary_leg"} <= set(out["phase_seconds"])
+    assert {"startup", "count_rays", "native_probe", "contexts_and_root_share_tuning", "timed_legs", "secondary_leg", "secondary_cfg4_leg"} <= set(out["phase_seconds"])
     assert sum(out["phase_seconds"].values()) < out["wall_budget_s"] == 900.0
     assert out["legs"]["batch1"]["frames_per_collective"] == 1 and out["legs"]["batch8"]["frames_per_collective"] == 8
     # the root share comes from a warm-up auto-tune whose winner every rank agrees on (times are maxima over ranks); the stub's
@@ -68,9 +68,23 @@ def test_gpus_2_without_rank_env_spawns_two_ranks():
         assert out["legs"][leg]["root_share_percent"] == 60
         bd = out["legs"][leg]["breakdown"]
         assert [row["rank"] for row in bd["per_rank"]] == [0, 1] and bd["max_over_ranks"]["kernel_us_per_frame"] > 0
-    # and the same pipeline on BASELINE's sharded configuration as a secondary leg
-    assert out["secondary"]["workload"] == "cfg3_4k_1024c_b8" and out["secondary"]["value"] > 0
-    assert out["secondary"]["root_share"]["root_share"] == 60
+    # and the same pipeline on BASELINE's sharded configurations as secondary legs: configs[3] with the literal
+    # one-gather-per-frame leg — its `value` — beside the batched one, the root share tuned once; configs[4], the path trace, literal, equal share
+    _check_secondary(out)
+    assert out["secondary"]["legs"]["batch1"]["root_share"]["root_share"] == 60
+
+
+def _check_secondary(out):
+    sec = out["secondary"]
+    assert sec["workload"] == "cfg3_4k_1024c_b8" and set(sec["legs"]) == {"batch1", "batch8"}
+    assert sec["value"] == sec["legs"]["batch1"]["value"] > 0 and sec["value_batched"] == sec["legs"]["batch8"]["value"] > 0
+    assert sec["frames_per_collective"] == 1 and sec["legs"]["batch8"]["frames_per_collective"] == 8
+    assert sec["legs"]["batch1"]["root_share"]["tuned"] and not sec["legs"]["batch8"]["root_share"]["tuned"]
+    assert sec["legs"]["batch8"]["root_share"]["root_share"] == sec["legs"]["batch1"]["root_share"]["root_share"]
+    assert [row["rank"] for row in sec["legs"]["batch1"]["breakdown"]["per_rank"]] == list(range(out["n_gpus"]))
+    c4 = out["secondary_cfg4"]
+    assert c4["workload"] == "cfg4_4k_2048c_b8_sparse" and set(c4["legs"]) == {"batch1"} and c4["value"] == c4["legs"]["batch1"]["value"] > 0
+    assert c4["legs"]["batch1"]["root_share"] == {"tuned": False, "root_share": 100} and c4["value_batched"] is None
 
 
 @pytest.mark.timeout(400)
@@ -82,7 +96,7 @@ def test_native_failure_on_one_rank_moves_every_rank_to_the_torch_path():
     assert out["dist_path"] == "torch"     # rank 0's native set-up worked, rank 1's did not: both fall back
     assert out["rccl_world"] is None
     assert "torch.distributed gather per frame" in out["config"]["parallelism"]
-    assert set(out["legs"]) == {"torch"} and out["secondary"] is None
+    assert set(out["legs"]) == {"torch"} and out["secondary"] is None and out["secondary_cfg4"] is None
 
 
 @pytest.mark.timeout(600)
@@ -107,8 +121,9 @@ def test_four_and_eight_ranks_over_gloo(world):
         assert out["legs"][leg]["root_share_percent"] == tune["root_share"]
         bd = out["legs"][leg]["breakdown"]
         assert [row["rank"] for row in bd["per_rank"]] == list(range(world))
-    assert out["secondary"]["workload"] == "cfg3_4k_1024c_b8" and out["secondary"]["value"] > 0
-    assert sum(out["phase_seconds"].values()) < 900.0
+    _check_secondary(out)
+    # (first contact with an 8-GPU node is one shot: the whole run, both secondary legs included, inside the wall budget)
+    assert sum(out["phase_seconds"].values()) < 900.0 and {"secondary_leg", "secondary_cfg4_leg"} <= set(out["phase_seconds"])
 
 
 @pytest.mark.timeout(600)
@@ -125,7 +140,7 @@ def test_secondary_leg_is_skipped_when_the_wall_budget_is_spent():
     r = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--stub", "--wall-budget", "1"])
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     out = _one_json_line(r.stdout)
-    assert set(out["legs"]) == {"batch1", "batch8"} and "wall budget" in out["secondary"]["skipped"]
+    assert set(out["legs"]) == {"batch1", "batch8"} and "wall budget" in out["secondary"]["skipped"] and "wall budget" in out["secondary_cfg4"]["skipped"]
 
 
 def test_world_size_contradicting_gpus_is_an_error():
