@@ -147,6 +147,9 @@ def full_cases():
     for v in ("V0", "V1", "V2"):
         cases[f"cfg2_r0_{v}"] = (head, v, 0.0, None)      # hard sun: no pixel depends on sin()
         cases[f"cfg2_r5_{v}"] = (head, v, 5.0, None)      # the reference's default sun radius (Sun.zig:9): sin-hash RNG in every shadow ray
+    # BASELINE.json configs[1] (round 5, VERDICT r04 #3: it fits GL's 128 MiB block limit): 1920x1080, 256^3, 4^3 bricks, primary rays only
+    for v in ("V0", "V1", "V2"):
+        cases[f"cfg1_{v}"] = (W.WORKLOADS["cfg1_1080p_256c_b4"], v, 0.0, None)
     ra = refapp_workload()
     cases["refapp_V0"] = (ra, "V0", 5.0, None)            # at its full 1024x576
     cases["refapp_256x144_V0"] = (ra, "V0", 5.0, (256, 144))
@@ -159,13 +162,16 @@ def crop_origins(w, h):
     return [(min(int(h * fy) // 8 * 8, h - CROP), min(int(w * fx) // 8 * 8, w - CROP)) for fy, fx in ((0.15, 0.2), (0.35, 0.7), (0.5, 0.45), (0.55, 0.1), (0.65, 0.8), (0.75, 0.3), (0.85, 0.6), (0.93, 0.05))]
 
 
-def main_full():
+def main_full(only=()):
+    """only: name prefixes (e.g. cfg1) — the other fixtures are left as they are."""
     from tests.golden.make_golden import scene_digest
     os.makedirs(FULL_OUT, exist_ok=True)
     info = GlRef().info()
     check_implementation(info, FULL_OUT)
     grids, refs = {}, {}
     for name, (w, view, radius, size) in full_cases().items():
+        if only and not name.startswith(tuple(only)):
+            continue
         grid = grids.setdefault(w.name, W.build_grid(w))
         scene = oracle_scene_from_grid(grid)
         width, height = size or (w.width, w.height)
@@ -188,7 +194,7 @@ def main_full():
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "full":
-        main_full()
+        main_full(sys.argv[2:])
     else:
         main()
         main_present()

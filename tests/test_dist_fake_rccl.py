@@ -415,3 +415,61 @@ def test_frames_submitted_by_one_call(world, frames_per_launch, bounce):
     for rt in ranks:
         rt.deinit()
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("order", [("one", "bounce", "two", "one"), ("two", "one", "one", "bounce"), ("bounce", "bounce", "one", "two")])
+def test_a_batch_may_hold_frames_of_several_kernels(order):
+    """A launch carries a collective, so WHEN a queue is launched must never depend on anything a rank learns for itself (the box of the
+    occupied cells arrives at another moment on every rank) — and it must not depend on the kernels of the queued frames either: frames of
+    one sample, of two samples and with bounces (three kernels; the bounce frames by the persistent kernels, one launch each) share
+    batches of four, launched run by run, gathered by ONE collective.  The last frame of the sequence is checked for each order."""
+    if not os.path.exists(FAKE):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
+    w, grid = _bounce_scene()
+    kinds = {"one": (1, 0), "two": (2, 0), "bounce": (2, 2)}     # (samples per pixel, Camera.Config.max_bounce: the device value is + 1)
+    world = 3
+
+    def set_kind(rt, kind):
+        spp, bounce = kinds[kind]
+        rt.camera.d_camera.samples_per_pixel = spp
+        rt.camera.d_camera.max_bounce = bounce + 1
+
+    plain = W.make_renderer(w, grid, kernel_variant=1 << 23)
+    W.set_view(plain, "V2")
+    set_kind(plain, order[-1])
+    plain.draw()
+    plain.wait()
+    plain.draw()
+    ref = plain.read_rgba8().copy()
+    plain.deinit()
+    uid = b"fake-rccl-mix" + os.urandom(16) + bytes(128 - 29)
+    ranks = [W.make_renderer(w, grid, kernel_variant=1 << 23, shard_rank=r, shard_count=world) for r in range(world)]
+    for r, rt in enumerate(ranks):
+        W.set_view(rt, "V2")
+        rt.dist_init(uid, r, world, frames_in_flight=2, rccl_path=FAKE, frames_per_launch=4)
+    errors, names = [], []
+
+    def drive(r):
+        try:
+            rt = ranks[r]
+            for _ in range(3):           # (three batches: by the second the box of the occupied cells is known, each rank in its own time)
+                for kind in order:
+                    set_kind(rt, kind)
+                    rt.dist_frame()
+                    if r == 0:
+                        names.append(rt.kernel_name().split("<")[0])
+            rt.dist_wait()
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads) and not errors, errors
+    got = ranks[0].dist_read_frame()
+    for rt in ranks:
+        rt.deinit()
+    assert np.array_equal(got, ref)
+    assert {"vrt_trace_kernel"} < set(names) <= {"vrt_trace_kernel", "vrt_path_kernel", "vrt_pool_kernel"}, names

@@ -41,7 +41,7 @@ def test_the_product_binary_holds_only_shipped_kernels():
     the variants that lost live in the development build (make dev).  Round 4: 27 traversal kernels + 16 small ones (builders of
     the derived structures, schedule, un-swizzle, the two present kernels, vrt_pool_resolve_kernel, vrt_check_materials_plain)."""
     ks = _kernels()
-    assert len(ks) <= 43, sorted(ks)
+    assert len(ks) <= 45, sorted(ks)
     traversal = [n for n in ks if "vrt_trace_kernel" in n or "vrt_path_kernel" in n or "vrt_pool_kernel" in n]
     assert len(traversal) == 27, sorted(traversal)
 

@@ -988,3 +988,56 @@ def test_wave_timeline_across_a_change_of_the_schedule_rule():
         rt.draw()
         assert np.array_equal(rt.read_rgba8(), fresh[spp]), spp
     rt.deinit()
+
+
+def test_pool_kernel_takes_the_material_of_one_material_bricks_from_a_byte_per_cell():
+    """Round 5 (a third of the 2048^3 path trace's fabric traffic was a hit's two dependent look-ups, brick_index then one
+    byte of the 2 GiB material_index): a derived byte per cell names the material ALL solid voxels of the cell's brick share, 0xFF where
+    they do not (TraceParams::cell_material).  A scene with both kinds — spheres of one material each, plus 6 000 stray voxels of random
+    materials that make the bricks they fall into mixed: frames with and without the structure (VRT_TUNE_NO_CELL_MATERIAL) and the
+    oracle's are the same bytes.  Then the host re-inserts 500 solid voxels with ANOTHER material — only material_index entries change,
+    uniform bricks become mixed — and the delta upload must refresh exactly those bytes: the next frame is the oracle's of the edited grid."""
+    w = W.Workload("t", 208, 112, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000)
+    rng = np.random.default_rng(11)
+    stray = rng.integers(0, 256, (6000, 3))
+    stray_m = rng.integers(1, 8, 6000)
+
+    def build():
+        g = W.build_grid(w)
+        g.insert_many(stray, stray_m)
+        return g
+
+    def frames(grid, flags, edit=None):
+        rt = W.make_renderer(w, grid, kernel_variant=PATH, want_float_output=True, tuning_flags=flags)
+        W.set_view(rt, "V0")
+        rt.draw()
+        rt.wait()      # (the box of the occupied cells has reached the host)
+        out = []
+        for v in ("V0", "V2"):
+            W.set_view(rt, v)
+            rt.draw()
+            out.append((rt.read_rgba32f().copy(), rt.read_rgba8().copy()))
+        if edit is not None:
+            edit(grid)
+            rt.update_grid_delta()
+            rt.draw()
+            out.append((rt.read_rgba32f().copy(), rt.read_rgba8().copy()))
+        assert rt.kernel_name() == "vrt_pool_kernel<8, 5, 64, 2>", rt.kernel_name()
+        pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
+        rt.deinit()
+        return out, pc
+
+    # solid voxels of the spheres, re-inserted with another material (insert() flips y: use voxels this scene is known to hold — the strays)
+    def edit(g):
+        g.insert_many(stray[:500], (stray_m[:500] % 7) + 1)
+
+    grid = build()
+    a, pc = frames(grid, 0, edit)
+    b, _ = frames(build(), L.TUNE_NO_CELL_MATERIAL, edit)
+    for (fa, ua), (fb, ub) in zip(a, b):
+        assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)) and np.array_equal(ua, ub) and ua.any()
+    fo, uo, _ = O.render(oracle_scene_from_grid(grid), pc)        # (the edited grid, view V2)
+    assert np.array_equal(a[2][0].view(np.uint32), fo.view(np.uint32)) and np.array_equal(a[2][1], uo)
+    fo1, uo1, _ = O.render(oracle_scene_from_grid(build()), pc)   # (before the edit)
+    assert np.array_equal(a[1][0].view(np.uint32), fo1.view(np.uint32)) and np.array_equal(a[1][1], uo1)
+    assert not np.array_equal(uo, uo1), "the edit changed no pixel: the test does not test the refresh"

@@ -141,6 +141,7 @@ def test_full_size_fixtures_exist():
     names = set(FULL_IDS)
     assert {f"cfg2_r{r}_{v}" for r in (0, 5) for v in ("V0", "V1", "V2")} <= names
     assert {"refapp_V0", "refapp_256x144_V0", "refapp_256x144_V2"} <= names
+    assert {f"cfg1_{v}" for v in ("V0", "V1", "V2")} <= names      # (round 5: BASELINE configs[1], whole frames by the reference shader)
     for p in FULL:
         assert "brick_raytracer.comp" in str(np.load(p)["provenance"])
 

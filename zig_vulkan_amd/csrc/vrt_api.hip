@@ -64,19 +64,30 @@ void mark_dirty(vrt_ctx *ctx, vrt_buffer_id id, uint64_t byte_offset, uint64_t n
     if (id == VRT_BUF_BRICK_STATUS) ctx->status_dirty = true;
     if (id == VRT_BUF_BRICK_START_INDEX) ctx->start_dirty = true;
     if (id == VRT_BUF_MATERIALS) ctx->materials_dirty = true;
-    if (id != VRT_BUF_BRICK_STATUS && id != VRT_BUF_BRICK_INDEX && id != VRT_BUF_BRICK_OCCUPANCY) return;
+    if (id == VRT_BUF_GRID_STATE || id == VRT_BUF_MATERIALS) return;
     auto widen = [](uint64_t &lo, uint64_t &hi, uint64_t a, uint64_t b) {
         if (lo >= hi) lo = a, hi = b;
         else lo = std::min(lo, a), hi = std::max(hi, b);
     };
     const uint64_t end = byte_offset + nbytes;
-    if (id == VRT_BUF_BRICK_STATUS) widen(ctx->occ_cell_lo, ctx->occ_cell_hi, byte_offset * 8u, end * 8u);
-    else if (id == VRT_BUF_BRICK_INDEX) widen(ctx->occ_cell_lo, ctx->occ_cell_hi, byte_offset / 4u, (end + 3u) / 4u);
-    else {
-        const uint64_t brick_bytes = (uint64_t)ctx->cfg.brick_dimension * ctx->cfg.brick_dimension * ctx->cfg.brick_dimension / 8u;
+    const uint64_t brick_bytes = (uint64_t)ctx->cfg.brick_dimension * ctx->cfg.brick_dimension * ctx->cfg.brick_dimension / 8u;
+    // (both by-cell structures follow the cells and the occupancy slots; the material byte also the start indices and the entries of binding 7)
+    if (id == VRT_BUF_BRICK_STATUS) {
+        widen(ctx->occ_cell_lo, ctx->occ_cell_hi, byte_offset * 8u, end * 8u);
+        widen(ctx->cm_cell_lo, ctx->cm_cell_hi, byte_offset * 8u, end * 8u);
+    } else if (id == VRT_BUF_BRICK_INDEX) {
+        widen(ctx->occ_cell_lo, ctx->occ_cell_hi, byte_offset / 4u, (end + 3u) / 4u);
+        widen(ctx->cm_cell_lo, ctx->cm_cell_hi, byte_offset / 4u, (end + 3u) / 4u);
+    } else if (id == VRT_BUF_BRICK_OCCUPANCY) {
         widen(ctx->occ_slot_lo, ctx->occ_slot_hi, byte_offset / brick_bytes, (end + brick_bytes - 1u) / brick_bytes);
+        widen(ctx->cm_slot_lo, ctx->cm_slot_hi, byte_offset / brick_bytes, (end + brick_bytes - 1u) / brick_bytes);
+    } else if (id == VRT_BUF_BRICK_START_INDEX) {
+        widen(ctx->cm_slot_lo, ctx->cm_slot_hi, byte_offset / 4u, (end + 3u) / 4u);
+    } else {
+        widen(ctx->cm_mat_lo, ctx->cm_mat_hi, byte_offset, end);
     }
-    ctx->occupancy_dirty = true;
+    if (id == VRT_BUF_BRICK_STATUS || id == VRT_BUF_BRICK_INDEX || id == VRT_BUF_BRICK_OCCUPANCY) ctx->occupancy_dirty = true;
+    ctx->cell_material_dirty = true;
 }
 
 // the unit counters and (contexts that select vrt_pool_kernel) the path records of one stream of persistent-kernel frames
@@ -575,6 +586,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
                 c->cell_occupancy_lockstep = lockstep_bounce;
             }
         }
+        // (round 5) the material a cell's brick is made of, for the hits vrt_pool_kernel shades in its rounds of transitions
+        if (!(cfg->tuning_flags & (VRT_TUNE_NO_CELL_MATERIAL | VRT_TUNE_NO_DEFERRED_MATERIAL)) && any_kernel([](const vrt::KernelEntry &e) { return e.path == 2; })) {
+            VRT_CREATE_HIP(c->res.device(&c->d_cell_material, (size_t)cells + 64u));
+            VRT_CREATE_HIP(hipMemsetAsync(c->d_cell_material, 0xFF, (size_t)cells + 64u, c->stream));
+        }
         if (!(cfg->tuning_flags & VRT_TUNE_NO_DEFERRED_MATERIAL)) {
             VRT_CREATE_HIP(c->res.device(&c->d_materials_plain, 64u));
             VRT_CREATE_HIP(hipMemsetAsync(c->d_materials_plain, 0, 64u, c->stream));
@@ -678,6 +694,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     p.cell_occupancy_lockstep = (c->d_cell_occupancy && c->cell_occupancy_lockstep) ? 1u : 0u;
     p.start_is_slot = c->d_start_is_slot;
     p.materials_plain = c->d_materials_plain;
+    p.cell_material = c->d_cell_material;
     p.status_cells = (uint32_t)cells;
     // (order_auto: frames that alternate between the two streams of a frames_in_flight = 2 context take reverse raster (3)
     // instead, see do_dispatch and DESIGN.md §4)

@@ -38,6 +38,8 @@ hipError_t launch_build_cell_distance(const TraceParams &p, uint32_t dim_x, uint
 hipError_t launch_build_cell_bounds(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, uint64_t cell_lo, uint64_t cell_hi, uint64_t slot_lo,
                                        uint64_t slot_hi, hipStream_t stream);
+hipError_t launch_build_cell_material(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, uint64_t cell_lo, uint64_t cell_hi, uint64_t slot_lo,
+                                      uint64_t slot_hi, uint64_t mat_lo, uint64_t mat_hi, hipStream_t stream);
 hipError_t launch_check_start_is_slot(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, hipStream_t stream);
 hipError_t launch_check_materials_plain(const TraceParams &p, uint32_t count, hipStream_t stream);
 hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
@@ -190,6 +192,12 @@ struct vrt_ctx {
     // refreshed for the cells and brick slots it names, not gathered anew over the whole grid): cells whose status bit / brick index
     // changed and brick slots whose occupancy bytes changed, both [lo, hi); lo >= hi: none
     uint64_t occ_cell_lo = 0, occ_cell_hi = ~0ull, occ_slot_lo = 0, occ_slot_hi = 0;
+    // derived (round 5): the material every solid voxel of a cell's brick shares, a byte per cell (TraceParams::cell_material; contexts that
+    // select vrt_pool_kernel).  Refreshed like the by-cell occupancy, for what was written: cells [occ_cell_lo, hi) (status / index),
+    // slots [cm_slot_lo, hi) (occupancy / start index), material entries [cm_mat_lo, hi) (bytes of binding 7); lo >= hi: none
+    uint8_t *d_cell_material = nullptr;
+    bool cell_material_dirty = true;
+    uint64_t cm_cell_lo = 0, cm_cell_hi = ~0ull, cm_slot_lo = 0, cm_slot_hi = 0, cm_mat_lo = 0, cm_mat_hi = 0;
     uint32_t *d_materials_plain = nullptr;   // derived: 1 = no material record has the type MAT_NONE (TraceParams::materials_plain)
     bool materials_dirty = true;             // binding 0 changed since it was checked
     bool start_dirty = true;                 // binding 6 changed since it was checked

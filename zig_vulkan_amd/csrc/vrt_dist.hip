@@ -92,8 +92,11 @@ struct Dist {
     bool failed = false;         // a collective failed: peers are out of step, every later vrt_dist_* call fails
     uint32_t npend = 0;
     vrt::PushConstants pend[vrt::kMaxBatchFrames];
-    vrt::KernelFn pend_fn = nullptr;
-    bool pend_samples = false;   // ... a persistent kernel that takes samples as its units (vrt_pool_resolve_kernel writes the shard)
+    // the kernel of each queued frame.  A queue may hold frames of several kernels (another specialisation for another sample or bounce
+    // count; the box of the occupied cells arriving on THIS rank between two frames): the launch goes through them run by run, and the
+    // queue is launched only when full or by a call every rank makes — what a rank learns for itself never moves a collective
+    vrt::KernelFn pend_fn[vrt::kMaxBatchFrames] = {};
+    bool pend_samples[vrt::kMaxBatchFrames] = {}; // ... a persistent kernel that takes samples as its units (vrt_pool_resolve_kernel writes the shard)
     // vrt_dist_profile / vrt_dist_stats: per-launch stage times, summed over the launches sampled
     bool profile = false;
     uint64_t prof_launches = 0, prof_frames = 0;
@@ -190,10 +193,11 @@ static int dist_queue_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const
     Dist *d = ctx->dist;
     // (a refresh of the derived structures is a scene write and launches what is queued: do that now, so that the launch slot — and with
     // it the lane — this frame's batch will use is known before the kernel is chosen)
-    if (d->npend && (ctx->status_dirty || ctx->occupancy_dirty || ctx->start_dirty || ctx->materials_dirty)) {
+    if (d->npend && (ctx->status_dirty || ctx->occupancy_dirty || ctx->start_dirty || ctx->materials_dirty || ctx->cell_material_dirty)) {
         const int rcf = dist_flush(ctx);
         if (rcf != VRT_OK) return rcf;
     }
+    // (the frames of a queue are launched together on one slot's stream: its lane serves this frame whatever is queued before it)
     DistSlot &sl = d->slots[d->frame_no % d->nslots];
     vrt::KernelFn fn = nullptr, product_fn = nullptr;
     bool with_samples = false;
@@ -205,15 +209,11 @@ static int dist_queue_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const
     // vrt_path_kernel would store whole RGBA pixels from wherever a pixel ended: such frames keep the lockstep kernel.
     if (vrt::is_path_kernel(fn) && !with_samples) fn = ctx->kernel_lockstep;
     if (!vrt::is_path_kernel(fn)) with_samples = false;
-    if (d->npend > 0 && (d->pend_fn != fn || d->pend_samples != with_samples)) { // another kernel (bounces / samples changed): not in the same launch
-        const int rcf = dist_flush(ctx);
-        if (rcf != VRT_OK) return rcf;
-    }
     note_kernel(ctx, fn);
     d->pend[d->npend].cam = *camera;
     d->pend[d->npend].sun = *sun;
-    d->pend_fn = fn;
-    d->pend_samples = with_samples;
+    d->pend_fn[d->npend] = fn;
+    d->pend_samples[d->npend] = with_samples;
     d->npend++;
     return d->npend >= d->batch ? dist_flush(ctx) : VRT_OK;
 }
@@ -272,13 +272,10 @@ int dist_flush(vrt_ctx *ctx) {
     //    (rank 0: into region 0 of `gathered`)
     vrt::TraceParams pk = ctx->params;
     if (ctx->order_auto) pk.tile_order = 3u; // (no cost feedback across the slots of the pipeline yet)
-    for (uint32_t f = 0; f < n; f++) pk.pcs[f] = d->pend[f];
     pk.target_rgba8 = sl.shard;
     pk.target_rgba32f = nullptr;
     pk.packed_tiles = 1u;
     pk.packed_rgb = 1u;
-    // (a launch of n frames of this rank's tiles: half-tile workgroups while its waves do not fill the SIMDs twice)
-    pk.split_all = (ctx->split_ok && pk.tile_order == 3u && (uint64_t)ctx->shard.owned_tiles * 4u * n <= 2ull * ctx->simds) ? 1u : 0u;
     pk.batch_target_stride = (uint32_t)d->shard_bytes;
     if (sl.marked) dist_collect(d, sl, false); // (profile: the slot's previous launch, if it has finished; else that sample is dropped)
     const bool mark = d->profile;
@@ -287,18 +284,30 @@ int dist_flush(vrt_ctx *ctx) {
             if (!e) VRT_HIP(ctx, ctx->res.event(&e));
         VRT_HIP(ctx, hipEventRecord(sl.mark[0], sl.stream));
     }
-    if (vrt::is_path_kernel(d->pend_fn)) {
-        // the persistent kernels take ONE frame per launch (a frame of theirs fills the GPU by itself: the batch exists for the
-        // one-sample frames whose shards do not), each into its place of the batch's buffer; all on this slot's lane
-        pk.batch_target_stride = 0u;
-        for (uint32_t f = 0; f < n; f++) {
-            pk.pcs[0] = d->pend[f];
-            pk.target_rgba8 = sl.shard + (size_t)f * d->shard_bytes;
-            lane_into_params(sl.lane, d->pend_samples, pk);
-            VRT_HIP(ctx, vrt::launch_trace(d->pend_fn, pk, ctx->lds_bytes, sl.stream, 1));
+    for (uint32_t f = 0; f < n;) {
+        const vrt::KernelFn fn = d->pend_fn[f];
+        if (vrt::is_path_kernel(fn)) {
+            // the persistent kernels take ONE frame per launch (a frame of theirs fills the GPU by itself: the batch exists for the
+            // one-sample frames whose shards do not), each into its place of the batch's buffer; all on this slot's lane
+            vrt::TraceParams pf = pk;
+            pf.batch_target_stride = 0u;
+            pf.pcs[0] = d->pend[f];
+            pf.target_rgba8 = sl.shard + (size_t)f * d->shard_bytes;
+            lane_into_params(sl.lane, d->pend_samples[f], pf);
+            VRT_HIP(ctx, vrt::launch_trace(fn, pf, ctx->lds_bytes, sl.stream, 1));
+            f++;
+            continue;
         }
-    } else {
-        VRT_HIP(ctx, vrt::launch_trace(d->pend_fn, pk, ctx->lds_bytes, sl.stream, n));
+        // a run of frames of one tile kernel: one launch, grid.y = its frames
+        uint32_t g = f + 1u;
+        while (g < n && d->pend_fn[g] == fn) g++;
+        vrt::TraceParams pf = pk;
+        for (uint32_t j = f; j < g; j++) pf.pcs[j - f] = d->pend[j];
+        pf.target_rgba8 = sl.shard + (size_t)f * d->shard_bytes;
+        // (a launch of g - f frames of this rank's tiles: half-tile workgroups while its waves do not fill the SIMDs twice)
+        pf.split_all = (ctx->split_ok && pf.tile_order == 3u && (uint64_t)ctx->shard.owned_tiles * 4u * (g - f) <= 2ull * ctx->simds) ? 1u : 0u;
+        VRT_HIP(ctx, vrt::launch_trace(fn, pf, ctx->lds_bytes, sl.stream, g - f));
+        f = g;
     }
     if (mark) VRT_HIP(ctx, hipEventRecord(sl.mark[1], sl.stream));
     // 2. the one collective of the batch: every rank's shards -> rank 0 (grouped point-to-point = gather)

@@ -155,6 +155,16 @@ int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_de
     }
     ctx->occupancy_dirty = ctx->start_dirty = ctx->materials_dirty = false;
     ctx->occ_cell_lo = ctx->occ_cell_hi = ctx->occ_slot_lo = ctx->occ_slot_hi = 0;
+    if (ctx->cell_material_dirty && ctx->d_cell_material) {
+        int rcw = begin_scene_write(ctx);
+        if (rcw != VRT_OK) return rcw;
+        VRT_HIP(ctx, vrt::launch_build_cell_material(ctx->params, ctx->cfg.brick_dimension, ctx->cfg.brick_alloc, ctx->cm_cell_lo, ctx->cm_cell_hi, ctx->cm_slot_lo, ctx->cm_slot_hi,
+                                                     ctx->cm_mat_lo, ctx->cm_mat_hi, ctx->stream));
+        rcw = end_scene_write(ctx);
+        if (rcw != VRT_OK) return rcw;
+    }
+    ctx->cell_material_dirty = false;
+    ctx->cm_cell_lo = ctx->cm_cell_hi = ctx->cm_slot_lo = ctx->cm_slot_hi = ctx->cm_mat_lo = ctx->cm_mat_hi = 0;
     // max_bounce <= 1 ("only primary ray" + its shadow ray): the bounce loop runs at most once
     *fn = (camera->max_bounce <= 1) ? (camera->samples_per_pixel == 1 ? ctx->kernel_single1 : ctx->kernel_single) : ctx->kernel;
     if (ctx->bounds_pending && hipEventQuery(ctx->ev_bounds) == hipSuccess) {

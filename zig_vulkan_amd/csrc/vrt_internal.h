@@ -96,6 +96,12 @@ struct TraceParams {
     // without the record and leaves the hit's look-ups (brick_index -> material_index -> material: three dependent misses on a scene
     // larger than the caches) to the round of transitions that shades it; nullptr or 0: always look the record up in the brick round
     const uint32_t *materials_plain;
+    // derived from bindings 3-7 (round 5; vrt_pool_kernel; nullptr: not built): one byte per grid cell — the material id that ALL solid
+    // voxels of the cell's brick share, or 0xFF: look it up.  comp:337 -> :422 -> :425 is a chain of three dependent misses on a scene
+    // larger than the caches (brick_index 4 B of a 128-byte line, then one byte of material_index — 2 GiB on the 2048^3 scene — per hit:
+    // a third of the path trace's fabric traffic); where a brick is of one material — every brick of a sphere, most bricks of a
+    // terrain's height band — the hit needs this one byte instead, from an array 128 times smaller than material_index.
+    const uint8_t *cell_material;
     // derived, device-built copy of brick_status: one 64-bit word per 4x4x4 block of grid cells,
     // block index bx + nbx*(bz + nbz*by), bit (x&3) + 4*(z&3) + 16*(y&3)  (x, z, y order as comp:318)
     const uint2 *status_blocks;

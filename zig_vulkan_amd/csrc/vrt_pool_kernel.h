@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
         hb_rsrc.z = uni(p.status_words);
         hb_rsrc.w = 0x00020000u;
     }
-    const bool by_cell = p.cell_occupancy != nullptr;
+    const bool by_cell = p.cell_occupancy != nullptr, has_cell_material = p.cell_material != nullptr;
     const bool start_is_slot = p.start_is_slot != nullptr && __builtin_amdgcn_readfirstlane((int)*p.start_is_slot) != 0;
     const uint32_t walk_k = max(1u, p.pool_walk_k), brick_thr = p.pool_brick_thr, trans_thr = p.pool_trans_thr, walk_min = p.pool_walk_min;
 
@@ -286,9 +286,16 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                                 const uint32_t hz = ((real >> 2) & 3u) | ((real >> (lx + 1u)) & (((1u << (lz - 2u)) - 1u) << 2));
                                 const uint32_t hy = ((real >> 4) & 1u) | ((real >> (lx + lz + 1u)) << 1);
                                 const uint32_t hcell = hx + (uint32_t)dx * (hz + (uint32_t)dz * hy);
-                                const uint32_t hbrick = p.brick_index[hcell];
-                                const uint32_t hstart = start_is_slot ? hbrick * (uint32_t)(B * B * B) : (p.brick_start_index[hbrick] & 0x7FFFFFFFu);
-                                hit.index = p.material_index[hstart + (hit.index & ~kDeferredHit)];
+                                // (round 5) a brick of ONE material — every solid voxel's entry of binding 7 the same — has that id in a byte
+                                // per cell: one look-up in an array of `cells` bytes instead of two dependent ones in brick_index and the
+                                // 128 times larger material_index (TraceParams::cell_material; 0xFF: look it up)
+                                uint32_t hmat = has_cell_material ? (uint32_t)p.cell_material[hcell] : 0xFFu;
+                                if (hmat == 0xFFu) {
+                                    const uint32_t hbrick = p.brick_index[hcell];
+                                    const uint32_t hstart = start_is_slot ? hbrick * (uint32_t)(B * B * B) : (p.brick_start_index[hbrick] & 0x7FFFFFFFu);
+                                    hmat = p.material_index[hstart + (hit.index & ~kDeferredHit)];
+                                }
+                                hit.index = hmat;
                             }
                             const float t_offset = (g_scale * (1.0f / (float)B)) * 0.05f;
                             hit.normal = axis_normal(s, (int)((fl >> 21) & 3u));

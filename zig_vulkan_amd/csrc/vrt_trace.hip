@@ -134,6 +134,61 @@ __global__ __launch_bounds__(256) void vrt_build_cell_occupancy(const uint32_t *
     out[w] = occupancy[(uint64_t)slot * words8 + (w % words8)];
 }
 
+
+// TraceParams::cell_material: a wave looks at 64 consecutive cells; for every occupied one whose inputs were written — the cell itself
+// (status bit / brick index in [cell_lo, cell_hi)), its brick's slot (occupancy bytes / start index in [slot_lo, slot_hi)) or its
+// brick's material entries (bytes [mat_lo, mat_hi) of binding 7) — the lanes share the brick's voxels (B^3 / 64 each), find the first
+// solid voxel's material and whether every other solid voxel has it too.  0xFF: mixed, no solid voxel, a malformed brick, or the id 255.
+template <int B>
+__global__ __launch_bounds__(256) void vrt_build_cell_material(const uint32_t *__restrict__ status, const uint32_t *__restrict__ brick_index,
+                                                               const uint8_t *__restrict__ occupancy, const uint32_t *__restrict__ start_index,
+                                                               const uint8_t *__restrict__ material_index, uint8_t *__restrict__ out, uint32_t cells,
+                                                               uint32_t status_words, uint64_t brick_alloc, uint64_t material_bytes, uint64_t cell_lo,
+                                                               uint64_t cell_hi, uint64_t slot_lo, uint64_t slot_hi, uint64_t mat_lo, uint64_t mat_hi) {
+    constexpr uint32_t kBits = B * B * B, kPerLane = kBits / 64u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t base = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;
+    if (base >= cells) return;
+    const uint32_t w0 = (uint32_t)(base >> 5);
+    unsigned long long bits = status[w0] | (w0 + 1u < status_words ? (unsigned long long)status[w0 + 1u] << 32 : 0ull);
+    while (bits) { // (uniform over the wave)
+        const uint32_t b = (uint32_t)__builtin_ctzll(bits);
+        bits &= bits - 1ull;
+        const uint64_t cell = base + b;
+        if (cell >= cells) break;
+        const uint32_t slot = brick_index[cell];
+        if (slot >= brick_alloc) continue; // (malformed scene: the shader would read outside bindings 5 / 6)
+        const uint64_t start = start_index[slot] & 0x7FFFFFFFu; // comp:422
+        const bool written = (cell >= cell_lo && cell < cell_hi) || (slot >= slot_lo && slot < slot_hi) || (start < mat_hi && start + kBits > mat_lo);
+        if (!written) continue;
+        uint32_t first = 0xFFu;
+        bool solid = false, same = true;
+        if (start + kBits <= material_bytes) {
+            if constexpr (kPerLane == 8u) {
+                const uint32_t occ = occupancy[(uint64_t)slot * (kBits / 8u) + lane]; // voxels 8 lane .. 8 lane + 7 (Grid.zig:180-182)
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) {
+                    if (!((occ >> k) & 1u)) continue;
+                    const uint32_t id = material_index[start + 8u * lane + k]; // comp:425
+                    if (!solid) first = id, solid = true;
+                    else same = same && id == first;
+                }
+            } else {
+                solid = ((occupancy[(uint64_t)slot * (kBits / 8u) + (lane >> 3)] >> (lane & 7u)) & 1u) != 0u;
+                if (solid) first = material_index[start + lane];
+            }
+        }
+        const unsigned long long any = __builtin_amdgcn_ballot_w64(solid);
+        uint32_t id = 0xFFu;
+        if (any != 0ull) {
+            const uint32_t leader = (uint32_t)__builtin_ctzll(any);
+            const uint32_t m = (uint32_t)__shfl((int)first, (int)leader, 64);
+            if (__builtin_amdgcn_ballot_w64(solid && (!same || first != m)) == 0ull) id = m;
+        }
+        if (lane == 0u) out[cell] = (uint8_t)id;
+    }
+}
+
 // *flag = 1 iff every brick's start index (binding 6) is either unset (0xFFFFFFFF) or slot * bits in its low 31 bits
 // (TraceParams::start_is_slot).  The flag is set to 1 before the launch; violators clear it.
 __global__ __launch_bounds__(256) void vrt_check_start_is_slot(const uint32_t *__restrict__ start, uint32_t *__restrict__ flag, uint64_t brick_alloc,
@@ -685,6 +740,23 @@ hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dime
     hipLaunchKernelGGL(vrt_build_cell_occupancy, dim3((uint32_t)((words + 255u) / 256u)), dim3(256), 0, stream, p.brick_status, p.brick_index,
                        reinterpret_cast<const uint2 *>(p.brick_occupancy), reinterpret_cast<uint2 *>(const_cast<uint8_t *>(p.cell_occupancy)), scan_lo, scan_hi,
                        words8, brick_alloc, cell_lo, cell_hi, slot_lo, slot_hi);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_cell_material(const TraceParams &p, uint32_t brick_dimension, uint64_t brick_alloc, uint64_t cell_lo, uint64_t cell_hi, uint64_t slot_lo,
+                                      uint64_t slot_hi, uint64_t mat_lo, uint64_t mat_hi, hipStream_t stream) {
+    if (!p.cell_material) return hipSuccess;
+    const uint32_t cells = p.status_cells;
+    if (cells == 0u || (cell_lo >= cell_hi && slot_lo >= slot_hi && mat_lo >= mat_hi)) return hipSuccess;
+    const uint64_t bits = (uint64_t)brick_dimension * brick_dimension * brick_dimension;
+    const dim3 grid((cells + 255u) / 256u);
+    uint8_t *out = const_cast<uint8_t *>(p.cell_material);
+    if (brick_dimension == 8u)
+        hipLaunchKernelGGL(vrt_build_cell_material<8>, grid, dim3(256), 0, stream, p.brick_status, p.brick_index, p.brick_occupancy, p.brick_start_index, p.material_index, out,
+                           cells, p.status_words, brick_alloc, brick_alloc * bits, cell_lo, cell_hi, slot_lo, slot_hi, mat_lo, mat_hi);
+    else
+        hipLaunchKernelGGL(vrt_build_cell_material<4>, grid, dim3(256), 0, stream, p.brick_status, p.brick_index, p.brick_occupancy, p.brick_start_index, p.material_index, out,
+                           cells, p.status_words, brick_alloc, brick_alloc * bits, cell_lo, cell_hi, slot_lo, slot_hi, mat_lo, mat_hi);
     return hipGetLastError();
 }
 
