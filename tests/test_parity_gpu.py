@@ -1017,12 +1017,18 @@ def test_pool_kernel_takes_the_material_of_one_material_bricks_from_a_byte_per_c
             W.set_view(rt, v)
             rt.draw()
             out.append((rt.read_rgba32f().copy(), rt.read_rgba8().copy()))
+        assert rt.kernel_name() == "vrt_pool_kernel<8, 5, 64, 2>", rt.kernel_name()
         if edit is not None:
             edit(grid)
             rt.update_grid_delta()
+            # (insert() rewrites the cell's status word as well: the box of the occupied cells is unknown until its copy has come back, and
+            # the first frame behind the edit is vrt_path_kernel<..., DIL 1>'s; the one behind that vrt_pool_kernel's again — both checked)
+            rt.draw()
+            first = (rt.read_rgba32f().copy(), rt.read_rgba8().copy())
             rt.draw()
             out.append((rt.read_rgba32f().copy(), rt.read_rgba8().copy()))
-        assert rt.kernel_name() == "vrt_pool_kernel<8, 5, 64, 2>", rt.kernel_name()
+            assert rt.kernel_name() == "vrt_pool_kernel<8, 5, 64, 2>", rt.kernel_name()
+            assert np.array_equal(first[0].view(np.uint32), out[-1][0].view(np.uint32)) and np.array_equal(first[1], out[-1][1])
         pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
         rt.deinit()
         return out, pc

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
     float t_out = 0.0f; // crossed distance of the ray's last step; kRayHit: hit.index (bits)
     float gtmin = 0.0f, gtmax = 0.0f, ir = 1.0f;
     // flags: bits 0-6 the path (slot of `path`), 8-9 / 10-11 / 12-13 ray step x / y / z + 1, 14-17 slab-entry code, 18-19 ignored
-    // material type, 20 the step out of the parked cell left the grid, 21-22 kRayHit: the face of the voxel hit
+    // material type, 20 the step out of the parked cell left the grid, 21-22 kRayHit: the face of the voxel hit, 23 the ray is a shadow ray
+    // (RayColor's `kind`, kept with the ray: the transition that finds it finished knows which fields of the path it needs before loading any)
     uint32_t fl = lane;
     uint32_t code = 3u << 4; // GridParkRegs::code
     uint32_t st = kRayFetch;
@@ -248,14 +249,34 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 const uint32_t ps = fl & 127u;
                 uint32_t *const pr = path + ps;
                 // the path: pixel, sample index, the sample sum (comp:173), RayColor's locals (comp:203-216) and what it keeps while the
-                // shadow ray is walked (comp:221-239)
-                uint32_t work = pr[0]; // the path's unit: pixel * spp + sample
-                uint32_t pf = pr[128];
-                f3 color = mk3(u2f(pr[5 * 128]), u2f(pr[6 * 128]), u2f(pr[7 * 128]));
-                float cur_dir_y = u2f(pr[8 * 128]);
-                f3 sc_dir = mk3(u2f(pr[9 * 128]), u2f(pr[10 * 128]), u2f(pr[11 * 128]));
-                float sc_ir = u2f(pr[12 * 128]);
-                f3 attenuation = mk3(u2f(pr[13 * 128]), u2f(pr[14 * 128]), u2f(pr[15 * 128]));
+                // shadow ray is walked (comp:221-239).
+                // Round 5: only the fields this transition reads are loaded, only those it changes are stored.  The records of a wave are 6.6 KB,
+                // those of the 640 waves of an XCD 4.3 MB beside a 4 MiB L2 that the bricks stream through: a record was written back to the
+                // fabric and fetched again between two transitions of its path — 61 GB written and as much read per 4K frame of 16 samples, half
+                // of the kernel's fabric traffic (profiles/r05_cfg4_pool_counters.txt).  What a transition needs follows from what kind of ray
+                // has just finished, which is kept WITH THE RAY (bit 23 of its flags) so that no load waits for another:
+                //   a camera / scattered ray that hit, sun on: shades and starts the shadow ray — reads the flags word, writes it and the
+                //     eight words the shadow ray's end needs (attenuation, the scattered ray, the hit ray's direction.y);
+                //   a shadow ray: reads those eight, the colour and the unit — writes the flags and, if the sun reached the hit, the colour;
+                //   a ray that missed: the path is over — reads the colour and the unit; the unit is written when a new one is taken.
+                const bool fresh = st == kRayFetch;                       // (no path yet: every field it will use is set before it is read)
+                const bool was_shadow = !fresh && ((fl >> 23) & 1u) != 0u;
+                const bool shades_only = !fresh && !was_shadow && st == kRayHit && sun_enabled;
+                uint32_t work = 0u, pf = 0u;
+                f3 color = mk3(0, 0, 0), sc_dir = mk3(0, 0, 1), attenuation = mk3(0, 0, 0);
+                float cur_dir_y = 0.0f, sc_ir = 1.0f;
+                if (!fresh) pf = pr[128];
+                if (!fresh && !shades_only) {
+                    work = pr[0]; // the path's unit: pixel * spp + sample
+                    color = mk3(u2f(pr[5 * 128]), u2f(pr[6 * 128]), u2f(pr[7 * 128]));
+                }
+                if (was_shadow) {
+                    cur_dir_y = u2f(pr[8 * 128]);
+                    sc_dir = mk3(u2f(pr[9 * 128]), u2f(pr[10 * 128]), u2f(pr[11 * 128]));
+                    sc_ir = u2f(pr[12 * 128]);
+                    attenuation = mk3(u2f(pr[13 * 128]), u2f(pr[14 * 128]), u2f(pr[15 * 128]));
+                }
+                bool color_changed = false, work_changed = false;
                 int loop_count = (int)((pf >> 16) & 15u);
                 int kind = (int)((pf >> 20) & 1u);
                 bool scattered_ok = ((pf >> 21) & 1u) != 0u;
@@ -330,6 +351,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                                 ls = kLaneStart;
                             } else {
                                 color = color + attenuation;
+                                color_changed = true;
                                 r.origin = hit.point; // the scattered ray starts where the shadow ray would have
                                 after_shadow = true;
                             }
@@ -338,7 +360,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                             ls = kLaneEnd; // the while condition failed (comp:218)
                         }
                     } else {
-                        if (!found) color = color + attenuation * mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
+                        if (!found) {
+                            color = color + attenuation * mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
+                            color_changed = true;
+                        }
                         after_shadow = true;
                     }
                     if (after_shadow) {
@@ -438,6 +463,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                         kind = 0;
                         loop_count = 0;
                         color = mk3(0, 0, 0);
+                        color_changed = work_changed = true;
                         cur_dir_y = r.direction.y;
                         ls = (loop_count < max_bounce) ? kLaneStart : kLaneEnd;
                     }
@@ -492,14 +518,17 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                     fl = ps | ((uint32_t)(s.sx + 1) << 8) | ((uint32_t)(s.sy + 1) << 10) | ((uint32_t)(s.sz + 1) << 12) | (((uint32_t)s.entry_code & 15u) << 14) |
                          ((r.ignore_type_material & 3u) << 18);
                 }
+                fl = (fl & ~(1u << 23)) | ((uint32_t)kind << 23); // (what kind of ray the next transition of this path will find finished)
                 st = nst;
-                pr[0] = work;
                 pr[128] = (((uint32_t)loop_count & 15u) << 16) | ((uint32_t)kind << 20) | ((scattered_ok ? 1u : 0u) << 21) | ((sc_ignore & 3u) << 22);
-                pr[5 * 128] = f2u(color.x), pr[6 * 128] = f2u(color.y), pr[7 * 128] = f2u(color.z);
-                pr[8 * 128] = f2u(cur_dir_y);
-                pr[9 * 128] = f2u(sc_dir.x), pr[10 * 128] = f2u(sc_dir.y), pr[11 * 128] = f2u(sc_dir.z);
-                pr[12 * 128] = f2u(sc_ir);
-                pr[13 * 128] = f2u(attenuation.x), pr[14 * 128] = f2u(attenuation.y), pr[15 * 128] = f2u(attenuation.z);
+                if (work_changed) pr[0] = work;
+                if (color_changed) pr[5 * 128] = f2u(color.x), pr[6 * 128] = f2u(color.y), pr[7 * 128] = f2u(color.z);
+                if (shades_only) { // (what the end of the shadow ray started above will read)
+                    pr[8 * 128] = f2u(cur_dir_y);
+                    pr[9 * 128] = f2u(sc_dir.x), pr[10 * 128] = f2u(sc_dir.y), pr[11 * 128] = f2u(sc_dir.z);
+                    pr[12 * 128] = f2u(sc_ir);
+                    pr[13 * 128] = f2u(attenuation.x), pr[14 * 128] = f2u(attenuation.y), pr[15 * 128] = f2u(attenuation.z);
+                }
             }
             VRT_PF_T(0, pf0);
         }

@@ -1038,6 +1038,9 @@ VRT_DI bool brick_walk_gfx950(const TraceParams &p, const Ray &r, const RaySetup
 // the lanes that have found a solid voxel.  start_is_slot: comp:422's look-up is slot * B^3 for every brick (TraceParams).
 // The request for a lane's brick (LDS walk): four 16-byte chunks into the wave's staging area.  vrt_path_kernel issues it as soon as
 // it knows the cell (PRESTAGED) — the position arithmetic of the brick entry then runs while the 64 bytes are on their way.
+#ifndef VRT_BRICK_LOAD_AUX
+#define VRT_BRICK_LOAD_AUX 0 // cache-policy bits of the staging loads (experiment, DESIGN.md appendix: 2 = nt)
+#endif
 VRT_DI void stage_brick_lds(const TraceParams &p, uint32_t occ_slot, bool by_cell, uint32_t wave_lds) {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(by_cell ? p.cell_occupancy : p.brick_occupancy) + (size_t)occ_slot * 16u;
     typedef __attribute__((address_space(3))) void lds_void;
@@ -1045,7 +1048,7 @@ VRT_DI void stage_brick_lds(const TraceParams &p, uint32_t occ_slot, bool by_cel
     lds_void *dst = reinterpret_cast<lds_void *>((size_t)__builtin_amdgcn_readfirstlane(wave_lds));
 #pragma unroll
     for (int c = 0; c < 4; c++)
-        __builtin_amdgcn_global_load_lds((glb_void *)(src + 4 * c), (lds_void *)((__attribute__((address_space(3))) char *)dst + 1024 * c), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void *)(src + 4 * c), (lds_void *)((__attribute__((address_space(3))) char *)dst + 1024 * c), 16, 0, VRT_BRICK_LOAD_AUX);
 }
 // DEFER (vrt_pool_kernel, round 4): a lane whose ray ignores no material type any record has (TraceParams::materials_plain, the ray's
 // ignore type MAT_NONE) needs none of comp:422-427's three dependent look-ups here — its hit is recorded as the voxel's index in its
