@@ -165,7 +165,8 @@ typedef struct vrt_config {
 #define VRT_TUNE_NO_SAMPLE_UNITS     (1u << 16) /* frames with bounces on scenes larger than the caches: a path takes whole pixels from the counter and sums their samples itself (vrt_path_kernel; vrt_pool_kernel is not chosen), instead of single samples whose terms vrt_pool_resolve_kernel adds */
 #define VRT_TUNE_NO_DEFERRED_MATERIAL (1u << 17) /* vrt_pool_kernel: look a solid voxel's material up in the brick round (comp:422-427 where the shader has them), not in the round of transitions that shades the hit */
 #define VRT_TUNE_NO_CELL_MATERIAL     (1u << 18) /* vrt_pool_kernel: always reach a hit's material through brick_index and material_index (comp:337, :422-425), also where all solid voxels of the brick share one material (round 5: a byte per cell says which) */
-#define VRT_TUNE_ALL                0x7FFFFu
+#define VRT_TUNE_GRID_EXIT_ANY_BOX    (1u << 19) /* bounce frames of the persistent kernels: the counter-free walk to the grid's face (vrt_pool_kernel, vrt_path_kernel<..., DIL 2>) whatever the box of the occupied cells — by default only where that box is, or nearly is, the grid (a ray that leaves a smaller box walks the empty cells beyond it) */
+#define VRT_TUNE_ALL                0xFFFFFu
 
 typedef struct vrt_ctx vrt_ctx;
 

@@ -39,11 +39,12 @@ def _kernels():
 def test_the_product_binary_holds_only_shipped_kernels():
     """about 40 kernels in the product code objects (round 2 shipped 175, most of them losers of an A/B);
     the variants that lost live in the development build (make dev).  Round 4: 27 traversal kernels + 16 small ones (builders of
-    the derived structures, schedule, un-swizzle, the two present kernels, vrt_pool_resolve_kernel, vrt_check_materials_plain)."""
+    the derived structures, schedule, un-swizzle, the two present kernels, vrt_pool_resolve_kernel, vrt_check_materials_plain).  Round 5:
+    + vrt_pool_kernel for 4^3 bricks and the two builders of the byte-per-cell material (vrt_build_cell_material<4>, <8>)."""
     ks = _kernels()
-    assert len(ks) <= 45, sorted(ks)
+    assert len(ks) <= 46, sorted(ks)
     traversal = [n for n in ks if "vrt_trace_kernel" in n or "vrt_path_kernel" in n or "vrt_pool_kernel" in n]
-    assert len(traversal) == 27, sorted(traversal)
+    assert len(traversal) == 28, sorted(traversal)
 
 
 def test_no_traversal_kernel_owns_static_lds():
@@ -87,10 +88,10 @@ def test_pool_kernel_holds_5_waves():
     instruction in its code (the descriptor may reserve a few bytes — the compiler's emergency slot for saving a register while EXEC is
     rewritten — that no instruction touches)."""
     ks = {n: k for n, k in _kernels().items() if "vrt_pool_kernel" in n}
-    assert len(ks) == 1
+    assert len(ks) == 2      # (8^3 bricks staged in LDS; round 5: 4^3 bricks)
     for name, k in ks.items():
         assert k["vgpr"] <= 96 and k["scratch"] <= 32, (name, k)
-    assert _scratch_instructions("vrt_pool_kernel") == 0
+    assert _scratch_instructions("vrt_pool_kernelILi8E") == 0 and _scratch_instructions("vrt_pool_kernelILi4E") == 0
 
 
 def test_path_kernel_holds_5_waves():

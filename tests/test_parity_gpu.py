@@ -1047,3 +1047,34 @@ def test_pool_kernel_takes_the_material_of_one_material_bricks_from_a_byte_per_c
     fo1, uo1, _ = O.render(oracle_scene_from_grid(build()), pc)   # (before the edit)
     assert np.array_equal(a[1][0].view(np.uint32), fo1.view(np.uint32)) and np.array_equal(a[1][1], uo1)
     assert not np.array_equal(uo, uo1), "the edit changed no pixel: the test does not test the refresh"
+
+
+def test_pool_kernel_on_bricks_of_4_and_on_a_box_smaller_than_the_grid():
+    """Round 5: vrt_pool_kernel for the reference's own brick size (4^3: a brick is two words, read as its walk goes —
+    no staging in LDS) and, with VRT_TUNE_GRID_EXIT_ANY_BOX, on scenes whose occupied cells do NOT reach the grid's faces (a terrain: rays
+    that leave its box walk the empty cells up to the grid's face).  The reference app's shape — 128 x 64 x 128 bricks of 4^3, 2 samples,
+    2 bounces, soft sun — at test size, and a sparse field of 4^3 bricks: frames equal the lockstep kernel's and the oracle's."""
+    cases = [(W.Workload("app_like", 320, 180, 512, 4, 2, 2, True, 5.0, dims=(128, 64, 128)), L.TUNE_GRID_EXIT_ANY_BOX, ("V0", "V2", "V1")),
+             (W.Workload("sparse_b4", 208, 112, 128, 4, 3, 2, True, 5.0, "sparse", 0.08, 30000), L.TUNE_GRID_EXIT_ANY_BOX, ("V0", "V1x")),
+             (W.Workload("terrain_b8", 256, 144, 256, 8, 2, 2, True, 5.0), L.TUNE_GRID_EXIT_ANY_BOX, ("V1", "V0"))]
+    for w, flags, views in cases:
+        grid = W.build_grid(w)
+        out = {}
+        for variant, fl in ((PATH, flags), (1 << 21, 0)):
+            rt = W.make_renderer(w, grid, kernel_variant=variant, tuning_flags=fl, want_float_output=True)
+            W.set_view(rt, views[0])
+            rt.draw()
+            rt.wait()      # (the box of the occupied cells has reached the host)
+            frames = []
+            for v in views:
+                W.set_view(rt, v)
+                rt.draw()
+                frames.append((rt.read_rgba32f().copy(), rt.read_rgba8().copy()))
+            out[variant] = (frames, rt.kernel_name(), O.push_constants(rt.camera.blob(), rt.sun.blob()))
+            rt.deinit()
+        assert out[PATH][1] == f"vrt_pool_kernel<{w.brick_dimension}, 5, 64, {2 if w.brick_dimension == 8 else 0}>", (w.name, out[PATH][1])
+        assert out[1 << 21][1].startswith("vrt_trace_kernel<"), out[1 << 21][1]
+        for v, (fa, ua), (fb, ub) in zip(views, out[PATH][0], out[1 << 21][0]):
+            assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)) and np.array_equal(ua, ub) and ua.any(), (w.name, v)
+        fo, uo, _ = O.render(oracle_scene_from_grid(grid), out[PATH][2])
+        assert np.array_equal(out[PATH][0][-1][0].view(np.uint32), fo.view(np.uint32)) and np.array_equal(out[PATH][0][-1][1], uo), w.name

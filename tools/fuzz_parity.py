@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity fuzz (usage: fuzz_parity.py [cases] [seed] [big|pow2|pool]; pow2: grids and frames that take vrt_path_kernel's block-skipping walk;
-pool: the pow2 draw narrowed to what vrt_pool_kernel takes — 8^3 bricks, three power-of-two dimensions, voxels in two opposite corners so
-that the occupied cells' box is the grid, two or three bounces): random small grids (odd dimensions, both brick sizes, any
+pool: the pow2 draw narrowed to what vrt_pool_kernel takes — both brick sizes (round 5), three power-of-two dimensions, two or three
+bounces; voxels in two opposite corners so that the occupied cells' box is the grid, or (three cases in ten) any box with
+VRT_TUNE_GRID_EXIT_ANY_BOX; half of the cases with ONE material per brick (the byte-per-cell material, TraceParams::cell_material)): random small grids (odd dimensions, both brick sizes, any
 scale, sparse allocation), random materials incl. glass / metal / unknown types, random cameras inside and outside the
 box, samples 1-3, bounces 0-2, sun on/off with and without jitter — product kernel against the oracle, whole frames,
 float target bit for bit.  The committed tests pin chosen cases; this looks for the ones nobody chose.  A mismatching case is
@@ -30,8 +31,10 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: b
         dims = [int(rng.integers(1, 25 if big else 9)) for _ in range(3)]
         if pow2:  # grids the path kernel's block filter accepts: x, z powers of two >= 4, y a multiple of 4
             dims = [int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 12, 16, 20])), int(rng.choice([4, 8, 16, 32]))]
+        any_box = False
         if pool:
-            b, dims = 8, [int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 16])), int(rng.choice([4, 8, 16, 32]))]
+            dims = [int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 16])), int(rng.choice([4, 8, 16, 32]))]
+            any_box = bool(rng.random() < 0.3)
         scale = float(rng.choice([0.5, 1.0, 2.0, 0.3, 1.7, 4.0]))
         min_point = [float(-0.5 * d * scale + rng.normal() * 0.3) for d in dims]
         cells = dims[0] * dims[1] * dims[2]
@@ -42,20 +45,28 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: b
             k = int(rng.integers(1, 6))
             centres = np.stack([rng.integers(0, b * d, k) for d in dims], axis=-1)
             xyz = np.clip(centres[rng.integers(0, k, n)] + rng.integers(-2 * b, 2 * b + 1, (n, 3)), 0, np.array(dims) * b - 1)
-        if not pool and rng.random() < 0.5:  # the occupied cells fill only a sub-box of the grid: rays enter the grid in front of it (skip_to_box)
+        if (not pool or any_box) and rng.random() < 0.5:  # the occupied cells fill only a sub-box of the grid: rays enter the grid in front of it (skip_to_box)
             lo = [int(rng.integers(0, d)) for d in dims]
             hi = [int(rng.integers(l, d)) for l, d in zip(lo, dims)]
             xyz = np.stack([b * l + rng.integers(0, b * (h - l + 1), n) for l, h in zip(lo, hi)], axis=-1)
         if rng.random() < 0.5:  # clumps: whole columns
             xyz[:, 1] = rng.integers(0, b * dims[1], n) // 2 * 2
-        if pool:  # the box of the occupied cells is the grid
+        if pool and not any_box:  # the box of the occupied cells is the grid
             xyz = np.concatenate([xyz, np.array([[0, 0, 0], [b * d - 1 for d in dims]])])
             n += 2
-        grid.insert_many(xyz, rng.integers(0, 14, n))
+        voxel_mats = rng.integers(0, 14, n)
+        if pool and rng.random() < 0.5:  # one material per brick (insert() flips y brick-wise: bricks stay bricks)
+            c = xyz // b
+            voxel_mats = (c[:, 0] * 7 + c[:, 1] * 13 + c[:, 2] * 31 + int(rng.integers(0, 14))) % 14
+        grid.insert_many(xyz, voxel_mats)
         mats = default_materials(256)
         mats[8] = (2, 0.9, 0.95, 1.0, 1.52)
         mats[9] = (7, 0.9, 0.2, 0.9, 1.0)
         mats[10] = (3, 0.3, 0.9, 0.3, 1.0)
+        if pool and rng.random() < 0.6:
+            # (no record of the type MAT_NONE: vrt_pool_kernel then leaves a hit's material to the round of transitions that shades it,
+            # TraceParams::materials_plain — with the record above in the table every case took the other path)
+            mats[10] = (0, 0.3, 0.9, 0.3, 0.0)
         mats[11] = (1, 0.8, 0.8, 0.8, 0.05)
         mats[12] = (2, 0.9, 0.9, 1.0, 1.0)
         mats[13] = (1, 0.7, 0.6, 0.5, 0.6)
@@ -66,7 +77,7 @@ def fuzz(cases: int, seed: int, big: bool = False, verbose: bool = True, pow2: b
         sun_on, radius = bool(rng.random() < 0.7), float(rng.choice([0.0, 5.0, 40.0]))
         rt = VoxelRT(grid, Config(internal_resolution_width=w, internal_resolution_height=h, camera=CameraConfig(samples_per_pixel=spp, max_bounce=bounce),
                                   sun=SunConfig(enabled=sun_on, radius=radius), want_float_output=True,
-                                  library=library,
+                                  library=library, tuning_flags=(1 << 19) if any_box else 0,
                                   kernel_variant=PATH if pool else (int(rng.choice(big_variants)) if big
                                   else int(rng.choice(pow2_variants) if pow2 else rng.choice([0, 0, PATH])))))
         rt.push_materials(mats)

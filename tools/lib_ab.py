@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Same-box, same-process A/B of two builds of libvrt_hip on one workload: two contexts over the same grid, alternating frames,
 HIP-event kernel time (min and all), frames compared bit for bit.
-usage: lib_ab.py <libA.so> <libB.so> [workload] [view ...]        env: AB_REPS (3), AB_FLAGS_A / AB_FLAGS_B (tuning flags), AB_VARIANT_A / AB_VARIANT_B (kernel_variant)"""
+usage: lib_ab.py <libA.so> <libB.so> [workload] [view ...]        env: AB_REPS (3), AB_FLAGS_A / AB_FLAGS_B (tuning flags), AB_VARIANT_A / AB_VARIANT_B (kernel_variant),
+AB_WIDTH / AB_HEIGHT / AB_SPP (another frame size / sample count than the workload's)"""
 import hashlib
 import os
 import sys
@@ -14,9 +15,12 @@ name = sys.argv[3] if len(sys.argv) > 3 else "cfg4_4k_2048c_b8_sparse"
 views = sys.argv[4:] or ["V0"]
 w = W.WORKLOADS[name]
 grid = W.build_grid(w)
-a = W.make_renderer(w, grid, library=la, tuning_flags=int(os.environ.get("AB_FLAGS_A", "0"), 0), kernel_variant=int(os.environ.get("AB_VARIANT_A", "0"), 0))
-b = W.make_renderer(w, grid, library=lb, tuning_flags=int(os.environ.get("AB_FLAGS_B", "0"), 0), kernel_variant=int(os.environ.get("AB_VARIANT_B", "0"), 0))
+size = {k: int(os.environ[e]) for k, e in (("width", "AB_WIDTH"), ("height", "AB_HEIGHT")) if e in os.environ}
+a = W.make_renderer(w, grid, library=la, **size, tuning_flags=int(os.environ.get("AB_FLAGS_A", "0"), 0), kernel_variant=int(os.environ.get("AB_VARIANT_A", "0"), 0))
+b = W.make_renderer(w, grid, library=lb, **size, tuning_flags=int(os.environ.get("AB_FLAGS_B", "0"), 0), kernel_variant=int(os.environ.get("AB_VARIANT_B", "0"), 0))
 reps = int(os.environ.get("AB_REPS", "3"))
+if "AB_SPP" in os.environ:
+    a.camera.d_camera.samples_per_pixel = b.camera.d_camera.samples_per_pixel = int(os.environ["AB_SPP"])
 for v in views:
     for rt in (a, b):
         W.set_view(rt, v)

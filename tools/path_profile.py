@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase profile of vrt_path_kernel (frames with bounces).  Needs the library built with the development profile:
     make -C zig_vulkan_amd/csrc -B EXTRA=-DVRT_DEV_PROFILE
-usage: path_profile.py <workload> <view> [variant]"""
+usage: VRT_HIP_LIB=zig_vulkan_amd/libvrt_hip_prof.so path_profile.py <workload> <view> [variant] [tuning_flags]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zig_vulkan_amd import workloads as W
@@ -9,8 +9,9 @@ from zig_vulkan_amd import workloads as W
 w = W.WORKLOADS[sys.argv[1]]
 view = sys.argv[2]
 variant = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0
+flags = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0
 grid = W.build_grid(w)
-rt = W.make_renderer(w, grid, kernel_variant=variant)
+rt = W.make_renderer(w, grid, kernel_variant=variant, tuning_flags=flags)
 rc = W.make_renderer(w, grid, kernel_variant=variant, enable_counters=True)
 W.set_view(rt, view); W.set_view(rc, view)
 rt.draw(); rt.wait()   # (behind a finished frame the library knows the box of the occupied cells)

@@ -520,8 +520,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
 #ifdef VRT_DEV_VARIANTS
         if (const char *e = std::getenv("VRT_DEV_POOL_KERNEL")) (void)std::sscanf(e, "%d:%d:%d", &pool_mw, &pool_slots, &pool_stages); // "<waves per SIMD>:<LDS slots>:<staging areas>"
 #endif
-        const vrt::KernelEntry *pool = (kind == 2 && cfg->brick_dimension == 8u && !(cfg->tuning_flags & (VRT_TUNE_NO_PATH_BRICK_LDS | VRT_TUNE_NO_PATH_POOL)))
-                                           ? vrt::find_pool_kernel((int)cfg->brick_dimension, pool_mw, pool_slots, pool_stages) : nullptr;
+        // (8^3 bricks: staged in LDS, so not with VRT_TUNE_NO_PATH_BRICK_LDS; round 5: 4^3 bricks too, read from global memory as they are walked)
+        const bool pool_ok = kind == 2 && !(cfg->tuning_flags & VRT_TUNE_NO_PATH_POOL) &&
+                             (cfg->brick_dimension == 4u || !(cfg->tuning_flags & VRT_TUNE_NO_PATH_BRICK_LDS));
+        const vrt::KernelEntry *pool = pool_ok ? vrt::find_pool_kernel((int)cfg->brick_dimension, pool_mw, pool_slots, pool_stages) : nullptr;
         // (the DIL-2 twin stays beside a pool kernel: frames the pool kernel cannot take — more than 15 bounces, no sample buffer — keep it
         // instead of falling back to the DIL-1 kernel with its steps-left counters)
         if (pool && c->kernel_grid_exit) c->kernel_grid_exit_path = c->kernel_grid_exit, c->kernel_grid_exit = pool->fn;

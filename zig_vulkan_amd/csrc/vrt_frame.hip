@@ -172,7 +172,8 @@ int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_de
         const int *b = ctx->h_cell_bounds;
         const int dim[3] = {(int)ctx->cfg.dim_x, (int)ctx->cfg.dim_y, (int)ctx->cfg.dim_z};
         bool all = b[0] != (int)0x80808080;
-        for (int a = 0; a < 3 && all; a++) all = (-b[a]) * 8 <= dim[a] && (dim[a] - 1 - b[3 + a]) * 8 <= dim[a];
+        // (VRT_TUNE_GRID_EXIT_ANY_BOX, round 5's experiment: whatever the box — rays that leave it walk on to the grid's face)
+        for (int a = 0; a < 3 && all && !(ctx->cfg.tuning_flags & VRT_TUNE_GRID_EXIT_ANY_BOX); a++) all = (-b[a]) * 8 <= dim[a] && (dim[a] - 1 - b[3 + a]) * 8 <= dim[a];
         ctx->box_is_grid = all;
         ctx->bounds_pending = false;
     }

@@ -17,6 +17,8 @@ const KernelEntry kEntries[] = {
     // (five waves per SIMD: the four waves of a workgroup share two staging areas for bricks; 2048^3 path trace, same box:
     // vrt_path_kernel 129.6 ms, a staging area per wave at four waves per SIMD 117.5, this 112.4)
     VRT_POOL_ENTRY(8, 5, 64, 2),
+    // round 5: the same for 4^3 bricks (the reference's own brick size), whose two words are read as the voxel-level walk goes: no staging
+    VRT_POOL_ENTRY(4, 5, 64, 0),
 #ifdef VRT_DEV_VARIANTS
     VRT_POOL_ENTRY(8, 4, 64, 4), VRT_POOL_ENTRY(8, 5, 64, 1), VRT_POOL_ENTRY(8, 6, 56, 1), VRT_POOL_ENTRY(8, 5, 40, 4),
 #endif

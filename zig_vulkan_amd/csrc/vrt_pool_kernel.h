@@ -56,7 +56,9 @@ VRT_DI float u2f(uint32_t v) { return __builtin_bit_cast(float, v); }
 // queue), which is what lets five workgroups of 128-path waves fit a CU's LDS.
 template <int B, int MIN_WAVES, int SLOTS = 64, int STAGES = 4>
 __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TraceParams p) {
-    static_assert(B == 8, "bricks of 8^3 voxels staged in LDS");
+    // B = 8: a brick (64 bytes) is staged in LDS for its voxel-level walk (STAGES areas per workgroup).  B = 4 (round 5: the reference's own
+    // brick size, State.zig:5): a brick is two words, its walk asks for them as it goes — no staging area, no lock (STAGES = 0)
+    static_assert((B == 8 && STAGES >= 1) || (B == 4 && STAGES == 0), "8^3 bricks are staged in LDS, 4^3 bricks are not");
     extern __shared__ __attribute__((aligned(16))) uint32_t pool_lds[];
     // (the wave's number through readfirstlane: its LDS and its block of path records are then scalar addresses, not per-lane registers)
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -183,7 +185,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
 #ifndef VRT_POOL_CHUNK
 #define VRT_POOL_CHUNK 512u /* 64 / 128 / 256 / 512 / 1024: 2048^3 path trace 92.7 / 92.3 / 92.3 / 92.3 / 93.6 ms, from outside the field 33.6 / 26.8 / 24.5 / 23.6 / 24.3 */
 #endif
-    constexpr uint32_t kPoolChunk = VRT_POOL_CHUNK;
+    // (round 5: a frame of fewer units than the launch's waves take in chunks of 512 — the reference app's 1024 x 576 x 2 samples: 1.18 M
+    // units for 5 120 waves — left more than half of the waves without work and the others four generations of their pools to go through
+    // one after the other, the counter exhausted at 1.3 % of the kernel: the chunk shrinks until every wave gets sixteen, 64 at least)
+    const uint32_t kPoolChunk = uni(max(64u, min((uint32_t)VRT_POOL_CHUNK, total / (gridDim.x * 64u))));
     uint32_t *const chunk = locks + 4u + wave * 3u;
 #ifdef VRT_DEV_PROFILE
     if (threadIdx.x < 8) vrt_prof[threadIdx.x] = 0ull;
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
         else if (n_trans != 0u) phase = 0u;
         else phase = 1u;
         [[maybe_unused]] int stage = (int)wave;
-        if constexpr (STAGES < 4) {
+        if constexpr (STAGES > 0 && STAGES < 4) {
             if (phase == 2u) {
                 // a staging area for the length of the round; all taken by other waves of the workgroup: serve another queue
                 stage = -1;
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 const int cy = (int)(((real >> 4) & 1u) | ((real >> (lx + lz + 1u)) << 1));
                 const uint32_t cell = (uint32_t)cx + (uint32_t)dx * ((uint32_t)cz + (uint32_t)dz * (uint32_t)cy);
                 const uint32_t occ_slot = by_cell ? cell : p.brick_index[cell]; // comp:337 (by_cell: only on a solid voxel)
-                stage_brick_lds(p, occ_slot, by_cell, wave_lds); // (first: the arithmetic below runs while the brick arrives)
+                if constexpr (B == 8) stage_brick_lds(p, occ_slot, by_cell, wave_lds); // (first: the arithmetic below runs while the brick arrives)
                 Ray r = Ray{ro, rd, ir, (fl >> 18) & 3u};
                 RaySetup s;
                 s.inv_dir = inv;
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 hit.index = 0u;
                 int hit_axis = 0;
                 const int a = (int)(code & 3u);
-                const bool hit_voxel = brick_walk_park_gfx950<B, true, true, true>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis, wave_lds);
+                const bool hit_voxel = brick_walk_park_gfx950<B, B == 8, B == 8, true>(p, r, s, g_scale, occ_slot, cell, by_cell, start_is_slot, brick_min, hit, a, hit_axis, wave_lds);
                 if (hit_voxel) {
                     st = kRayHit;
                     t_in = hit.t;
@@ -644,7 +649,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                     code = ((code >> 2) & 3u) << 4;              // the axis of its last step, for its first trip in the next call
                 }
             }
-            if constexpr (STAGES < 4) {
+            if constexpr (STAGES > 0 && STAGES < 4) {
                 // (every LDS read of the round has returned before the area is handed on)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0u) __hip_atomic_store(&locks[stage], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

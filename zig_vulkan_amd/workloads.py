@@ -49,6 +49,10 @@ WORKLOADS: Dict[str, Workload] = {
     # the reference app's own default run, grid shape included (src/main.zig:77-81: 128 x 64 x 128 bricks of 4^3, min point
     # (-32, -16, -32), scale 0.5; :23,122-135: 1024x576, 2 samples, max_bounce 2, sun on): the workload a user of the reference sees
     "refapp_1024x576_128x64x128_b4": Workload("refapp_1024x576_128x64x128_b4", 1024, 576, 512, 4, 2, 2, True, 5.0, dims=(128, 64, 128)),
+    # not a BASELINE config (round 5): a path trace on 4^3 bricks — the reference's own brick size — at a size the persistent kernels
+    # are chosen for themselves... only where bindings 3-5 exceed the caches, which 4^3 bricks reach at 2048^3; used with kernel_variant
+    # bit 23 by the A/B of vrt_pool_kernel<4, ...> against vrt_path_kernel<4, ...> (tools/lib_ab.py)
+    "sparse_4k_1024c_b4": Workload("sparse_4k_1024c_b4", 3840, 2160, 1024, 4, 4, 2, True, 5.0, "sparse", 0.08, 2_000_000),
 }
 
 HEADLINE = "cfg2_1080p_512c_b8"
