@@ -277,31 +277,34 @@ PROBE_FRAMES = ["V0", "V1", "V2", "V1", "V2", "V0", "V0", "V2", "V1", "V1", "V0"
 
 
 def dist_probe_child(args) -> None:
-    """`bench.py --dist-probe`: one rank of a short run of the native RCCL pipeline (a 332 x 210 frame, batches of 1 and of 8 frames
-    per collective, each on its own communicator), in a process of its own.  Rank 0 compares the assembled frame with the frame one
-    context renders alone.  Exit code 0 = this rank got through.  No torch import; nothing on stdout."""
+    """`bench.py --dist-probe`: one rank of a short run of the native RCCL pipeline, in a process of its own: a 332 x 210 frame with
+    batches of 1 and of 8 frames per collective, then (round 5) a small path trace whose bounce frames the persistent kernels trace
+    inside the pipeline — each on its own communicator.  Rank 0 compares every assembled frame with the frame one context renders
+    alone.  Exit code 0 = this rank got through.  No torch import; nothing on stdout."""
     import numpy as np
     from zig_vulkan_amd import workloads as W
     uids = bytes.fromhex(args.probe_uid)
     rank, world, device = args.probe_rank, args.probe_world, args.probe_device
-    w = W.Workload("probe", 332, 210, 64, 4, 1, 0, True, 0.0)
-    grid = W.build_grid(w)
-    ref = None
-    if rank == 0:
-        plain = W.make_renderer(w, grid, device_id=device)
-        W.set_view(plain, PROBE_FRAMES[-1])
-        plain.draw()
-        ref = plain.read_rgba8().copy()
-        plain.deinit()
-    for i, batch in enumerate((1, 8)):
-        rt = W.make_renderer(w, grid, device_id=device, shard_rank=rank, shard_count=world)
+    cases = [(W.Workload("probe", 332, 210, 64, 4, 1, 0, True, 0.0), 0, 1), (W.Workload("probe", 332, 210, 64, 4, 1, 0, True, 0.0), 0, 8),
+             (W.Workload("probe_bounce", 330, 210, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000), 1 << 23, 1)]
+    grids = {}
+    for i, (w, variant, batch) in enumerate(cases):
+        grid = grids.setdefault(w.name, W.build_grid(w))
+        ref = None
+        if rank == 0:
+            plain = W.make_renderer(w, grid, device_id=device, kernel_variant=variant)
+            W.set_view(plain, PROBE_FRAMES[-1])
+            plain.draw()
+            ref = plain.read_rgba8().copy()
+            plain.deinit()
+        rt = W.make_renderer(w, grid, device_id=device, shard_rank=rank, shard_count=world, kernel_variant=variant)
         rt.dist_init(uids[128 * i:128 * (i + 1)], rank, world, 4, frames_per_launch=batch)
         for v in PROBE_FRAMES:
             W.set_view(rt, v)
             rt.dist_frame()
         rt.dist_wait()
         if rank == 0 and not np.array_equal(rt.dist_read_frame(), ref):
-            print(f"[bench probe] batch {batch}: the assembled frame differs from the single-context frame", file=sys.stderr)
+            print(f"[bench probe] case {i} ({w.name}, batch {batch}): the assembled frame differs from the single-context frame", file=sys.stderr)
             sys.exit(3)
         rt.deinit()
     sys.exit(0)
@@ -315,7 +318,7 @@ def native_probe(env, timeout: float):
     if env.rank == 0:
         try:
             from zig_vulkan_amd import VoxelRT
-            uids = VoxelRT.dist_unique_id() + VoxelRT.dist_unique_id()
+            uids = VoxelRT.dist_unique_id() + VoxelRT.dist_unique_id() + VoxelRT.dist_unique_id()
         except Exception as e:  # noqa: BLE001 - the other ranks wait in the broadcast below: it must happen either way
             print(f"[bench rank 0] no RCCL unique id for the probe: {type(e).__name__}: {e}", file=sys.stderr)
     uids = env.bcast(uids)
@@ -432,7 +435,7 @@ def percentiles(ms):
 
 def default_root_share(world: int) -> int:
     """Rank 0's share of the tiles in percent of an equal share, before tuning: 100 at 2 ranks ... 30 at 8 (the root also takes
-    in every other rank's shards and un-swizzles every frame; one-GPU emulation of both sides, tools/root_share_sweep.sh)."""
+    in every other rank's shards and un-swizzles every frame; one-GPU emulation of both sides, tools/experiments/root_share_sweep.sh)."""
     return max(30, 100 - (70 * max(0, world - 2) + 3) // 6)
 
 
@@ -561,7 +564,7 @@ class Leg:
                     self.rt = W.make_renderer(w, grid, device_id=env.local_rank, shard_rank=rank, shard_count=world, kernel_variant=args.variant,
                                               shard_root_weight=(root_share if (2 <= world <= 8 and root_share < 100) else 0))
                 # (one frame per launch: a rank's 1/R of the tiles is a small kernel, and the more of them are in flight the better they
-                # overlap — rank 1 of 8 over the RCCL stand-in: 39.3 us per frame with 4 launches in flight, 29.9 with 8, tools/dist_host_probe.py)
+                # overlap — rank 1 of 8 over the RCCL stand-in: 39.3 us per frame with 4 launches in flight, 29.9 with 8, tools/experiments/dist_host_probe.py)
                 self.launches_in_flight = args.dist_frames if (batch > 1 or world == 1) else max(args.dist_frames, 8)
                 self.rt.dist_init(uid, rank, world, self.launches_in_flight, frames_per_launch=(batch if world > 1 else 1))
                 if world == 1:
@@ -626,7 +629,7 @@ class Leg:
     def steps(self, n: int) -> None:
         """Frames 0 .. n-1 of a run of n.  The native pipeline takes the consecutive frames of one view by ONE call across the ABI
         (vrt_dist_frames, --dist-submit call: what a compiled host's frame loop costs — submitted frame by frame from Python the host
-        took 14.6 us of a 30 us frame, tools/dist_host_probe.py); everything else steps frame by frame."""
+        took 14.6 us of a 30 us frame, tools/experiments/dist_host_probe.py); everything else steps frame by frame."""
         if self.sharded and self.native and self.env.args.dist_submit == "call":
             i = 0
             while i < n:
@@ -925,7 +928,7 @@ def main(argv=None) -> None:
 
     # `value` is the protocol's: W untimed warm-up steps, then exactly K timed steps (round 3 ran ~150 ms of untimed frames
     # first; --precondition-ms brings that back for A/B, default 0).  The GPU reaches its sustained clocks only after tens of milliseconds
-    # of continuous work (tools/short_run.py: 20 frames timed cold 0.083 ms per frame, right after 40 ms of frames 0.077, 600 frames
+    # of continuous work (tools/experiments/short_run.py: 20 frames timed cold 0.083 ms per frame, right after 40 ms of frames 0.077, 600 frames
     # 0.071), which a renderer — it runs continuously — has behind it: `value_sustained` (N = 1) times the same K steps again behind
     # PRECONDITION_MS of frames, and says so.
     precondition = 0 if stub else int(min(4000, args.precondition_ms / frame_ms_est))

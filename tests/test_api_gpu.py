@@ -190,7 +190,7 @@ def test_kernel_name_is_the_symbol_that_ran():
         rt.wait()
         assert rt.kernel_name() == name
         rt.deinit()
-    assert L.lib.vrt_compiled_kernel_count() == 27   # 26 + vrt_pool_kernel (round 4)
+    assert L.lib.vrt_compiled_kernel_count() == 28   # 26 + vrt_pool_kernel<8, ...> (round 4) + vrt_pool_kernel<4, ...> (round 5)
     assert re.fullmatch(r"vrt_(trace|path)_kernel<[^>]+>", "vrt_trace_kernel<8, false, 7, 7, 2, 256>")
 
 

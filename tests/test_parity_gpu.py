@@ -710,13 +710,14 @@ def test_start_index_shortcut_only_when_the_pattern_holds(variant, bounces):
 
 def test_bench_probe_child_runs_the_native_pipeline_on_real_rccl():
     """bench.py --dist-probe, the child process by which the N > 1 bench tries the native RCCL pipeline before it trusts it: here
-    with one rank (RCCL refuses two ranks on one device) — communicators from two unique ids, one and eight frames per collective,
-    the assembled frame compared with a single context's."""
+    with one rank (RCCL refuses two ranks on one device) — communicators from three unique ids: one and eight frames per collective,
+    and (round 5) a small path trace whose bounce frames the persistent kernels trace inside the pipeline; every assembled frame
+    compared with a single context's."""
     import subprocess
     import sys
     from zig_vulkan_amd import VoxelRT
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    uids = VoxelRT.dist_unique_id() + VoxelRT.dist_unique_id()
+    uids = VoxelRT.dist_unique_id() + VoxelRT.dist_unique_id() + VoxelRT.dist_unique_id()
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dist-probe", "--probe-uid", uids.hex(), "--probe-rank", "0",
                         "--probe-world", "1", "--probe-device", "0"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]   # (stdout: RCCL's version banner; the parent discards it)

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (VRT_HIP_LIB: development builds of the same library, e.g. the phase-profile build of tools/frame_phases.py)
+# (VRT_HIP_LIB: development builds of the same library, e.g. the phase-profile build of tools/experiments/frame_phases.py)
 LIB_PATH = os.environ.get("VRT_HIP_LIB") or os.path.join(_HERE, "libvrt_hip.so")
 
 VRT_ABI_VERSION = 3

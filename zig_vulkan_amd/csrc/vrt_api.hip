@@ -644,7 +644,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         p.pool_paths = c->lane[0].pool_paths;
         p.pool_cus = (uint32_t)cus;
         p.pool_walk_k = 12u;
-        p.pool_brick_thr = 48u; // (tools/pool_sweep.py: a plateau from 48 to 56, walk_min 32 to 40, walk_k 16 to 20)
+        p.pool_brick_thr = 48u; // (tools/experiments/pool_sweep.py: a plateau from 48 to 56, walk_min 32 to 40, walk_k 16 to 20)
         p.pool_trans_thr = 48u;
         p.pool_walk_min = 32u;
         p.path_groups = 8u * (uint32_t)cus; // twice what 4 waves per SIMD hold: late groups find the counter exhausted and leave
@@ -727,7 +727,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         c->simds = simds;
         // (configs[0], same box, us per frame V0 / V1 / V2 / V1x: whole tiles 16.3 / 24.0 / 27.3 / 28.6, halves 15.7 / 21.8 / 23.8 / 25.8,
         // quarters 16.7 / 21.5 / 24.1 / 23.4, eighths 16.4 / 23.3 / 25.4 / 24.1: halves; the rest of such a frame is its launch and the
-        // fixed part of a wave's chain — the status bits in LDS change nothing, tools/small_frame_ab.py)
+        // fixed part of a wave's chain — the status bits in LDS change nothing, tools/experiments/small_frame_ab.py)
         p.split_all = (eligible && waves <= 2u * simds) ? 1u : 0u;
 #ifdef VRT_EXP_SPLIT_ALL
         if (c->tile_order == 3u) p.split_all = VRT_EXP_SPLIT_ALL;

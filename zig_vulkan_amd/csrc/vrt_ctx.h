@@ -258,7 +258,7 @@ struct DeviceGuard { // everything inside runs on `dev`; the caller's current de
 
 // Waiting for a stream / an event: poll for up to a few milliseconds before handing the thread to the runtime's blocking wait.
 // The blocking wait sleeps on an interrupt and wakes up tens of microseconds after the GPU has finished — as long as a whole
-// frame of the headline workload (tools/short_trace.py: a 20-frame region took 1.45 ms on the GPU and 1.59 ms on the host's clock).
+// frame of the headline workload (tools/experiments/short_trace.py: a 20-frame region took 1.45 ms on the GPU and 1.59 ms on the host's clock).
 template <typename Query> hipError_t poll_then(Query query) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {

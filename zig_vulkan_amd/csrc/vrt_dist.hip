@@ -85,7 +85,7 @@ struct Dist {
     size_t shard_bytes = 0;
     // Frames are traced `batch` to a launch (grid.y): a rank owns 1/world of the tiles, too few waves to fill the GPU
     // and no shorter than the frame's longest wave, so single-frame launches leave most of the machine idle
-    // (tools/shard_streams.py: 19-31 us per 1/8 frame with eight single-frame launches in flight, against 8-18 us for
+    // (tools/experiments/shard_streams.py: 19-31 us per 1/8 frame with eight single-frame launches in flight, against 8-18 us for
     // an eighth of a whole-frame launch).  vrt_dist_frame queues; a full queue, vrt_dist_wait, vrt_dist_read_frame or a
     // scene upload launches what is queued.
     uint32_t batch = 1;

@@ -239,7 +239,7 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         vrt::TraceParams pb = ctx->params;
         // (frames of two samples per pixel keep the cost schedule on both streams: their split tiles trace the second sample on the idle
         // lanes, which is worth more than reverse raster's neighbourhood — the app's run, two frames in flight, V0 / V1 / V2: 0.205 /
-        // 0.214 / 0.237 ms per frame against 0.267 / 0.262 / 0.286, tools/fif_order_ab.py)
+        // 0.214 / 0.237 ms per frame against 0.267 / 0.262 / 0.286, tools/experiments/fif_order_ab.py)
         if (ctx->order_auto && sched_mode == 0u) pb.tile_order = 3u;
         pb.target_rgba8 = ctx->target8_b;
         pb.target_rgba32f = ctx->target32f_b;

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void vrt_build_cell_bounds(const uint32_t *__r
 // Round 4: the halves of split tiles are no longer ONE class in reverse-raster order but kSplitBuckets classes by the tile's slowest
 // wave, slowest first — on the reference app's own run nearly every tile that holds terrain is split (3 000 half-tile workgroups for
 // 1 024 workgroup slots), and with them unordered the second generation of workgroups held waves as long as the first's longest:
-// they started at 100 us and ended at 300 (tools/timeline_tail.py).
+// they started at 100 us and ended at 300 (tools/experiments/timeline_tail.py).
 constexpr uint32_t kScheduleBuckets = 8u;
 constexpr uint32_t kSplitBuckets = 8u;
 constexpr uint32_t kAllBuckets = kScheduleBuckets + kSplitBuckets;
@@ -674,11 +674,11 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
     }
     // The lockstep bounce kernel holds four waves per SIMD, sixteen per CU, and the four waves of a tile end at different times: a
     // 256-thread workgroup waits until four slots of one CU are free — a fifth of the slots stood empty through the body of the reference
-    // app's frames (tools/timeline_tail.py).  As one-wave workgroups every wave that ends is replaced at once: the app's run V0 / V1 / V2 /
+    // app's frames (tools/experiments/timeline_tail.py).  As one-wave workgroups every wave that ends is replaced at once: the app's run V0 / V1 / V2 /
     // all-ground -2 / -5.5 / -5 / -9.5 %, same box, two frames in flight -9 %.  The several-samples kernel at six waves per SIMD (4K / 1024^3, two
     // samples): -2 % alone and with two frames in flight.  The one-sample kernels at seven waves per SIMD take it in reverse raster only
     // (two frames in flight, frames of more tiles than the schedule takes): headline -0.7 / -1.8 / -0.8 %, 256^3 -0.3 / -4.4 / -6.2 %
-    // with two frames in flight; under the cost schedule, one frame at a time, the headline's V2 lost 11 % (tools/fif_waves_ab.py).
+    // with two frames in flight; under the cost schedule, one frame at a time, the headline's V2 lost 11 % (tools/experiments/fif_waves_ab.py).
     if (const KernelEntry *te = kernel_entry_of(fn); te && te->path == 0 && (te->shade <= 1 || p.tile_order == 3u) && !te->count && p.wave_groups_bounce && !p.wave_groups &&
                                                        p.block_threads != 512u && !p.split_all && !p.packed_rgb) {
         TraceParams q = p;

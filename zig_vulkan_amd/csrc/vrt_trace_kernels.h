@@ -62,7 +62,7 @@ VRT_DI f3 ray_at(const Ray &r, float t) { return fma3(splat3(t), r.direction, r.
 // comp:267
 VRT_DI float safe_inverse(float x) { return (x == 0.0f) ? 1e12f : (1.0f / x); }
 
-// Development-only phase profile (make EXTRA=-DVRT_DEV_PROFILE; tools/one_tile.py --profile): core-clock
+// Development-only phase profile (make EXTRA=-DVRT_DEV_PROFILE; tools/experiments/one_tile.py --profile): core-clock
 // cycles per phase, summed over the waves of a workgroup in LDS and written to the wave-timeline buffer.
 #ifdef VRT_DEV_PROFILE
 __shared__ unsigned long long vrt_prof[8];
@@ -587,7 +587,7 @@ VRT_DI uint32_t brick_lds_address(uint32_t lane_base, uint32_t bit_index) {
     return lane_base + ((w >> 2) << 10) + ((w & 3u) << 2);
 }
 // ---- the brick-level park loop on HALF-BLOCK words (vrt_path_kernel on scenes larger than the caches) ---------------------
-// Measured on the 2048^3 path trace (tools/pmc_cfg4.sh): 64.5 G L1 accesses per frame, 0.58 per cycle per CU — a wave-wide
+// Measured on the 2048^3 path trace (tools/experiments/pmc_cfg4.sh): 64.5 G L1 accesses per frame, 0.58 per cycle per CU — a wave-wide
 // request of incoherent lanes is one tag look-up per lane, and the L1 handles about one per cycle; 77 % of them are the status
 // words of the walk loop, one per lane per trip, although the average L1 miss costs only ~190 cycles.  So the walk is bound by the
 // NUMBER of requests.  Here the status bits are read from a derived copy ordered by 4 x 4 x 2 cells (x, z, y) per 32-bit word
@@ -1829,7 +1829,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     // A half-tile workgroup of a frame with TWO samples per pixel gives its idle lanes the second sample (round 4): lanes 0-31 trace
     // sample 0 of the wave's 32 pixels, lanes 32-63 sample 1 of the same pixels, and lane l adds lane l + 32's colour to its own —
     // (0 + s0) + s1, the sample loop's own sum (comp:173) — before the tone-map.  The slowest waves of a bounce frame (the frame lasts
-    // as long as they do: the reference app's run, tools/timeline.py) then have half the GridHits to go through one after the other.
+    // as long as they do: the reference app's run, tools/experiments/timeline.py) then have half the GridHits to go through one after the other.
     // (a quarter- or eighth-tile workgroup: 16 or 8 pixels per wave, twice as many lanes at work)
     const bool dual = SHADE != 2 && !COUNT && split != 0u && !p.packed_rgb && pc.cam.samples_per_pixel == 2; // (uniform over the workgroup)
     const uint32_t pixels = 64u >> split; // pixels of its 8x8 block this wave renders

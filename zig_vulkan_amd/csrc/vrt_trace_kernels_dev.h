@@ -184,7 +184,7 @@ VRT_DI void grid_walk_park_dilated_ahead_gfx950(f3 &side_dist, const f3 &inv_dir
 // The counter-free dilated loop on 4 x 4 x 4-CELL words (vrt_path_kernel<..., DIL 3>): the 64-bit words of TraceParams::status_blocks,
 // index bits 0-5 = the cell's place in its block (x&3 | (z&3) << 2 | (y&3) << 4), the bits above = the block's number.  A lane asks
 // when its step enters another block: 0.265 times per trip in the 2048^3 sparse field against 0.333 for half-blocks
-// (tools/request_replay.py).  The word is a register pair; the test shifts the cell's bit into bit 63 (v_lshlrev_b64 by ~index, of
+// (tools/experiments/request_replay.py).  The word is a register pair; the test shifts the cell's bit into bit 63 (v_lshlrev_b64 by ~index, of
 // which the instruction reads the low six bits) and compares with 0.
 #define VRT_LOAD_DILATED64_A(IDX, IDXN, WORD, WORDN)                       \
     "v_xor_b32_e32 %[t2], %[" IDXN "], %[" IDX "]\n\t"                     \
