@@ -564,8 +564,9 @@ class Leg:
                     self.rt = W.make_renderer(w, grid, device_id=env.local_rank, shard_rank=rank, shard_count=world, kernel_variant=args.variant,
                                               shard_root_weight=(root_share if (2 <= world <= 8 and root_share < 100) else 0))
                 # (one frame per launch: a rank's 1/R of the tiles is a small kernel, and the more of them are in flight the better they
-                # overlap — rank 1 of 8 over the RCCL stand-in: 39.3 us per frame with 4 launches in flight, 29.9 with 8, tools/experiments/dist_host_probe.py)
-                self.launches_in_flight = args.dist_frames if (batch > 1 or world == 1) else max(args.dist_frames, 8)
+                # overlap — rank 1 of 8 over the RCCL stand-in: 40.6 us per frame with 4 launches in flight, 30.9 with 8, 26.0 with 16 on the runtime's default 4
+                # hardware queues; 21.2 / 22.8 / 16.2 on 24 queues, tools/experiments/literal_leg_probe.py)
+                self.launches_in_flight = args.dist_frames if (batch > 1 or world == 1) else max(args.dist_frames, min(16, args.literal_launches))
                 self.rt.dist_init(uid, rank, world, self.launches_in_flight, frames_per_launch=(batch if world > 1 else 1))
                 if world == 1:
                     self.rt.dist_selftest()
@@ -786,6 +787,8 @@ def main(argv=None) -> None:
     ap.add_argument("--dist", choices=["native", "torch"], default="native",
                     help="N>1 frame gather: native = RCCL send/recv inside libvrt_hip.so (pipelined); torch = torch.distributed.gather (fallback)")
     ap.add_argument("--dist-frames", type=int, default=4, help="launches in flight per rank of the native multi-GPU pipeline")
+    ap.add_argument("--hw-queues", type=int, default=0, help="N > 1: GPU_MAX_HW_QUEUES of the HIP runtime (0: leave it; the environment wins)")
+    ap.add_argument("--literal-launches", type=int, default=8, help="launches in flight per rank of the one-gather-per-frame leg (at most 16)")
     ap.add_argument("--dist-batch", type=int, default=8,
                     help="frames traced by one launch and carried by one collective in the batched leg when world > 1 (every frame is gathered "
                          "once); the north_star-literal leg, one collective per frame, is always timed as well")
@@ -809,6 +812,15 @@ def main(argv=None) -> None:
     ap.add_argument("--stub-fail-native-on", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
 
+    # N > 1: a rank's launch of its 1/N of the tiles lasts about as long as a whole frame's (its longest wave), so the literal leg's frame
+    # rate is the number of launches the GPU runs side by side — and the HIP runtime maps streams onto 4 hardware queues unless told
+    # otherwise, BEFORE it initialises (tools/experiments/literal_leg_probe.py: rank 1 of 8, one frame per launch, 30.9 us per frame with 8
+    # launches on 4 queues, 16.2 with 16 on 24).  A knob of the runtime, set by the host process; libvrt_hip.so reads no environment.
+    # On the one-GPU emulation of BOTH sides (tools/dist_emulate.py) 16 launches on 24 queues made rank 0 — which posts N-1 receives and
+    # an un-swizzle per frame — three times slower (51 -> 200 us per frame at 8 ranks), so neither is the default: --hw-queues /
+    # --literal-launches are there for the first run on a real node.
+    if (args.gpus > 1 or args.dist_probe) and args.hw_queues > 0:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.hw_queues))
     if args.pmc_child:
         pmc_child(args)
         return

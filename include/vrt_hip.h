@@ -255,8 +255,12 @@ int vrt_assemble_frame(vrt_ctx *ctx, const void *gathered, void *dst_frame, uint
  * The reference is single-GPU; this is the north-star's image-tile sharding.  A context created with
  * shard_rank / shard_count = this process's rank / world size renders its interleaved 16x16 tiles and
  * ONE gather per launch (grouped ncclSend / ncclRecv) brings the packed shards (RGB: the alpha of the target is the
- * constant 255) to rank 0, which un-swizzles them into row-major RGBA8 frames.  Up to 8 launches are in flight, each on
- * its own stream (kernel -> gather -> un-swizzle), so one launch's collective overlaps the next launches' kernels.
+ * constant 255) to rank 0, which un-swizzles them into row-major RGBA8 frames.  Up to 16 launches are in flight, each on
+ * its own stream (kernel -> gather -> un-swizzle), so one launch's collective overlaps the next launches' kernels.  (A launch of a
+ * rank's 1/N of the tiles lasts as long as its longest wave — about as long as the whole frame's — so a rank's frame RATE is the number of
+ * launches the GPU runs side by side: the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default; a host that
+ * wants more than 4 launches to overlap sets that variable of the RUNTIME before it initialises HIP — the library itself reads none.
+ * Rank 1 of 8 on the headline workload, one frame per launch: 30.9 us per frame with 8 launches on 4 queues, 16.2 with 16 on 24.)
  * RCCL is reached through dlopen(rccl_path) — pass the library the process already uses (PyTorch's
  * bundled librccl.so) so that there is one RCCL in the address space; libvrt_hip.so does not link it.
  * Rank 0 makes the 128-byte id with vrt_dist_unique_id and the host distributes it to every rank.

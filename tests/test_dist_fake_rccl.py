@@ -17,7 +17,7 @@ FAKE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "li
 
 
 @pytest.mark.parametrize("world,frames_in_flight,frames_per_launch,root_weight",
-                         [(2, 2, 1, 0), (3, 4, 1, 0), (8, 8, 1, 0), (8, 1, 1, 0), (2, 2, 3, 0), (8, 3, 8, 0), (5, 2, 4, 0), (8, 1, 2, 0),
+                         [(2, 2, 1, 0), (3, 4, 1, 0), (8, 8, 1, 0), (8, 16, 1, 30), (4, 12, 2, 0), (8, 1, 1, 0), (2, 2, 3, 0), (8, 3, 8, 0), (5, 2, 4, 0), (8, 1, 2, 0),
                           (8, 3, 8, 65), (2, 2, 1, 30), (5, 2, 3, 85), (8, 2, 4, 1),
                           # bench.py's root-share candidates (root_share_candidates: the emulated default, 0.6 x, 1.5 x) at 8 / 4 / 2 ranks,
                           # one collective per frame and eight frames per collective

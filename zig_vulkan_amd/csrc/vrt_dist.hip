@@ -55,7 +55,7 @@ struct RcclApi {
     }
 };
 
-constexpr uint32_t kMaxDistSlots = 8;
+constexpr uint32_t kMaxDistSlots = 16;
 
 // One launch in flight of the multi-GPU pipeline: its stream carries kernel -> gather -> un-swizzle for a batch of up to
 // `batch` consecutive frames (see Dist).
@@ -135,7 +135,7 @@ int vrt_dist_init_batched(vrt_ctx *ctx, const char *rccl_path, const void *id128
     if (ctx->stream_b || ctx->cfg.stream || ctx->cfg.external_target_rgba8 || ctx->d_counters)
         return fail(ctx, VRT_E_STATE, "the multi-GPU pipeline owns its streams and targets (no frames_in_flight=2, caller stream/target or counters)");
     if (frames_in_flight == 0) frames_in_flight = 4;
-    if (frames_in_flight > kMaxDistSlots) return fail(ctx, VRT_E_INVALID_ARG, "at most 8 launches in flight");
+    if (frames_in_flight > kMaxDistSlots) return fail(ctx, VRT_E_INVALID_ARG, "at most 16 launches in flight");
     if (frames_per_launch == 0) frames_per_launch = 1;
     if (frames_per_launch > (uint32_t)vrt::kMaxBatchFrames) return fail(ctx, VRT_E_INVALID_ARG, "at most 8 frames per launch");
     DeviceGuard dg(ctx->device);
