@@ -277,6 +277,7 @@ pub extern fn vrt_device_info(device: c_int, out: *[4]i64) c_int;
 pub extern fn vrt_last_error(ctx: ?*const Ctx) [*:0]const u8;
 pub extern fn vrt_abi_version() u32;
 pub extern fn vrt_kernel_name(ctx: ?*const Ctx) [*:0]const u8;
+pub extern fn vrt_bounce_autotune_info(ctx: ?*Ctx, out: *[4]f64) c_int;
 pub extern fn vrt_compiled_kernel_count() c_int;
 pub extern fn vrt_grid_create(dim_x: u32, dim_y: u32, dim_z: u32, cfg: [*c]const GridConfig, out: *?*Grid) c_int;
 pub extern fn vrt_grid_destroy(g: ?*Grid) void;

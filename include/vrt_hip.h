@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 3u /* 3 (round 5): + vrt_dist_frames, vrt_reserve_samples; vrt_trace_wave_timeline's capacity rule.  2 (round 4): + vrt_region_begin / _end,
+#define VRT_ABI_VERSION 3u /* 3 (round 5): + vrt_dist_frames, vrt_reserve_samples, vrt_bounce_autotune_info; vrt_trace_wave_timeline's capacity rule.  2 (round 4): + vrt_region_begin / _end,
                              vrt_last_denoise_ms, tuning flags 13-17; the product build refuses development kernel_variants */
 
 /* ---- status codes (replace Zig error unions, e.g. StagingRamp.zig:320-325) */
@@ -166,7 +166,8 @@ typedef struct vrt_config {
 #define VRT_TUNE_NO_DEFERRED_MATERIAL (1u << 17) /* vrt_pool_kernel: look a solid voxel's material up in the brick round (comp:422-427 where the shader has them), not in the round of transitions that shades the hit */
 #define VRT_TUNE_NO_CELL_MATERIAL     (1u << 18) /* vrt_pool_kernel: always reach a hit's material through brick_index and material_index (comp:337, :422-425), also where all solid voxels of the brick share one material (round 5: a byte per cell says which) */
 #define VRT_TUNE_GRID_EXIT_ANY_BOX    (1u << 19) /* bounce frames of the persistent kernels: the counter-free walk to the grid's face (vrt_pool_kernel, vrt_path_kernel<..., DIL 2>) whatever the box of the occupied cells — by default only where that box is, or nearly is, the grid (a ray that leaves a smaller box walks the empty cells beyond it) */
-#define VRT_TUNE_ALL                0xFFFFFu
+#define VRT_TUNE_NO_BOUNCE_AUTOTUNE   (1u << 20) /* bounce frames of scenes that stay in the caches: always the lockstep kernel; by default the library times it against vrt_pool_kernel where both apply (four trial frames) and keeps the faster (round 5) */
+#define VRT_TUNE_ALL                0x1FFFFFu
 
 typedef struct vrt_ctx vrt_ctx;
 
@@ -359,6 +360,15 @@ uint32_t vrt_abi_version(void);
  * occupancy and order fields — and answers every other kernel_variant with VRT_E_INVALID_ARG; the development build (make dev) holds
  * them all (ABI version 2 recorded that change). */
 const char *vrt_kernel_name(const vrt_ctx *ctx);
+/* The bounce kernel's auto-tune (round 5).  Bounce frames of a scene that stays in the caches are the lockstep kernel's by the library's
+ * size rule; where vrt_pool_kernel can trace them too (three power-of-two grid dimensions, occupied cells reaching the grid's faces, a
+ * sample buffer to be had) the library times both — four single-frame vrt_dispatch calls run alone on the primary stream, lockstep /
+ * pool / lockstep / pool — and keeps the faster (the pool kernel only if it wins by 15 %): a terrain keeps the lockstep kernel, a sparse
+ * field gets the pool kernel (1.6-2.2 x, profiles/r05_pool_generalised_ab.txt).  Same bytes either way; a status upload starts it again;
+ * VRT_TUNE_NO_BOUNCE_AUTOTUNE turns it off; contexts of the multi-GPU pipeline, counting contexts and contexts whose kernel_variant names
+ * the bounce kernel do not tune.  out = {state: 0 not applicable, 1 trials to come or in flight, 2 decided: lockstep, 3 decided: pool;
+ * trial frames launched; lockstep ms; pool ms (the minima of the two trials each, 0 until decided)}. */
+int vrt_bounce_autotune_info(vrt_ctx *ctx, double out[4]);
 /* number of traversal kernels compiled into this build of the library (tests/test_kernel_resources.py) */
 int vrt_compiled_kernel_count(void);
 

@@ -1079,3 +1079,61 @@ def test_pool_kernel_on_bricks_of_4_and_on_a_box_smaller_than_the_grid():
             assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)) and np.array_equal(ua, ub) and ua.any(), (w.name, v)
         fo, uo, _ = O.render(oracle_scene_from_grid(grid), out[PATH][2])
         assert np.array_equal(out[PATH][0][-1][0].view(np.uint32), fo.view(np.uint32)) and np.array_equal(out[PATH][0][-1][1], uo), w.name
+
+
+def test_bounce_kernel_is_chosen_by_timing_where_both_kernels_apply():
+    """Round 5: the size rule gives bounce frames of scenes that stay in the caches to the lockstep kernel — right for a terrain, wrong
+    by 1.6-2.2 x for a sparse field (profiles/r05_pool_generalised_ab.txt).  Where vrt_pool_kernel applies as well the library times
+    four single-frame dispatches (lockstep / pool / lockstep / pool) and keeps the faster.  A sparse field of 4^3 bricks whose spheres
+    reach the grid's faces: the trial frames and every frame behind them are the lockstep kernel's bytes, and the verdict is `pool`;
+    VRT_TUNE_NO_BOUNCE_AUTOTUNE and kernel_variant bit 21 keep the lockstep kernel without trials; the reference app's shape (a terrain:
+    its box is not the grid) and an odd-sized grid never start any."""
+    # (a 1024^3 field of 4^3 bricks at the reference app's frame size: lockstep 1.8 ms, pool 1.1 at 2 spp — the same spheres in a 512^3 grid
+    # are closer together, their rays shorter, and there the lockstep kernel wins the trials: 0.58 against 0.74 ms)
+    w = W.Workload("sparse_auto", 1024, 576, 1024, 4, 4, 2, True, 5.0, "sparse", 0.08, 2_000_000)
+    grid = W.build_grid(w)
+    ref = W.make_renderer(w, grid, kernel_variant=1 << 21)
+    assert ref.bounce_autotune_info()["state"] == "not applicable"
+    want = {}
+    for v in ("V0", "V2"):
+        W.set_view(ref, v)
+        ref.draw()
+        want[v] = ref.read_rgba8().copy()
+    ref.deinit()
+    for fif in (1, 2):
+        rt = W.make_renderer(w, grid, frames_in_flight=fif)
+        names = []
+        for i in range(14):
+            v = ("V0", "V2")[(i // 3) % 2]
+            W.set_view(rt, v)
+            rt.draw()
+            assert np.array_equal(rt.read_rgba8(), want[v]), (fif, i, rt.kernel_name())
+            names.append(rt.kernel_name().split("<")[0])
+        info = rt.bounce_autotune_info()
+        assert info["state"] == "pool" and info["trials_launched"] == 4 and 0 < info["pool_ms"] < info["lockstep_ms"], info
+        assert names[-1] == "vrt_pool_kernel" and names[0] == "vrt_trace_kernel", names
+        rt.push_materials(default_materials_for_test())     # (not a status upload: the verdict stands)
+        rt.draw()
+        assert rt.bounce_autotune_info()["state"] == "pool"
+        rt.deinit()
+    off = W.make_renderer(w, grid, tuning_flags=L.TUNE_NO_BOUNCE_AUTOTUNE)
+    W.set_view(off, "V0")
+    for _ in range(8):
+        off.draw()
+    assert off.bounce_autotune_info()["state"] == "not applicable" and off.kernel_name().startswith("vrt_trace_kernel<") and np.array_equal(off.read_rgba8(), want["V0"])
+    off.deinit()
+    for wl in (W.Workload("app_like", 320, 180, 512, 4, 2, 2, True, 5.0, dims=(128, 64, 128)), W.Workload("odd", 200, 120, 96, 8, 2, 2, True, 5.0)):
+        g = W.build_grid(wl)
+        rt = W.make_renderer(wl, g)
+        W.set_view(rt, "V1")
+        for _ in range(8):
+            rt.draw()
+        rt.wait()
+        info = rt.bounce_autotune_info()
+        assert info["trials_launched"] == 0 and rt.kernel_name().startswith("vrt_trace_kernel<"), (wl.name, info)
+        rt.deinit()
+
+
+def default_materials_for_test():
+    from zig_vulkan_amd import default_materials
+    return default_materials(256)

@@ -42,6 +42,7 @@ TUNE_NO_SAMPLE_UNITS = 65536
 TUNE_NO_DEFERRED_MATERIAL = 131072
 TUNE_NO_CELL_MATERIAL = 262144
 TUNE_GRID_EXIT_ANY_BOX = 524288
+TUNE_NO_BOUNCE_AUTOTUNE = 1048576
 TUNE_NO_PATH_POOL = 8192  # frames with bounces on scenes larger than the caches: vrt_path_kernel (a ray per lane) instead of vrt_pool_kernel
 
 # vrt_buffer_id — shader bindings 1..7
@@ -180,6 +181,7 @@ SIGNATURES = {
     "vrt_dist_frame": (C.c_int, [_ctx, _P(CameraDevice), _P(SunDevice)]),
     "vrt_dist_frames": (C.c_int, [_ctx, _P(CameraDevice), _P(SunDevice), C.c_uint32, C.c_uint32]),
     "vrt_reserve_samples": (C.c_int, [_ctx, C.c_uint32]),
+    "vrt_bounce_autotune_info": (C.c_int, [_ctx, _P(C.c_double)]),
     "vrt_dist_wait": (C.c_int, [_ctx]),
     "vrt_dist_read_frame": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
     "vrt_dist_selftest": (C.c_int, [_ctx]),

@@ -441,7 +441,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         }
     }
     uint32_t lockstep_variant = c->bounce_variant | vrt::kVariantLockstepBounce; // (before the path kernel's occupancy is filled in below)
-    bool want_halfblocks = false, want_distance = false, want_dilated = false;
+    bool want_halfblocks = false, want_distance = false, want_dilated = false, auto_candidate = false;
     {
         auto pow2 = [](uint32_t v) { return v >= 4u && (v & (v - 1u)) == 0u; };
         // Development build only (kernel_variant bit 22): the block-skipping walk of vrt_path_kernel<FILTER> — lanes in empty
@@ -482,6 +482,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
             // powers of two
             want_dilated = want_halfblocks && pow2(cfg->dim_y) && !(cfg->tuning_flags & VRT_TUNE_NO_PATH_DILATED);
         } else {
+            // (the lockstep kernel by the size rule, not by the caller's word: a candidate for the auto-tune below where the pool kernel's
+            // walk applies — three power-of-two dimensions)
+            auto_candidate = !(cfg->kernel_variant & vrt::kVariantLockstepBounce) && mwv == 0u && pow2(cfg->dim_x) && pow2(cfg->dim_y) && pow2(cfg->dim_z) &&
+                             !cfg->enable_counters && !block_skip;
             c->bounce_variant |= vrt::kVariantLockstepBounce;
         }
     }
@@ -529,6 +533,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (pool && c->kernel_grid_exit) c->kernel_grid_exit_path = c->kernel_grid_exit, c->kernel_grid_exit = pool->fn;
         if (pool && c->product_grid_exit) c->product_grid_exit_path = c->product_grid_exit, c->product_grid_exit = pool->fn;
     }
+    if (auto_candidate && !(cfg->tuning_flags & (VRT_TUNE_NO_BOUNCE_AUTOTUNE | VRT_TUNE_NO_PATH_POOL | VRT_TUNE_NO_PATH_GRID_EXIT | VRT_TUNE_NO_PATH_DILATED |
+                                                  VRT_TUNE_NO_PATH_HALFBLOCKS | VRT_TUNE_NO_SAMPLE_UNITS)) &&
+        (cfg->brick_dimension == 4u || !(cfg->tuning_flags & VRT_TUNE_NO_PATH_BRICK_LDS))) {
+        if (const vrt::KernelEntry *pool = vrt::find_pool_kernel((int)cfg->brick_dimension)) c->bounce_auto = pool->fn;
+    }
     c->single_variant = single_variant;
     {
         const bool cnt = cfg->enable_counters != 0;
@@ -543,8 +552,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         }
         // derived copies of the status bits, each only if a kernel of this context reads it
         auto any_kernel = [&](auto pred) {
-            const vrt::KernelFn fns[11] = {c->kernel, c->kernel_lockstep, c->kernel_single, c->kernel_single1, c->product[0], c->product[1], c->product[2],
-                                           c->kernel_grid_exit, c->product_grid_exit, c->kernel_grid_exit_path, c->product_grid_exit_path};
+            const vrt::KernelFn fns[12] = {c->kernel, c->kernel_lockstep, c->kernel_single, c->kernel_single1, c->product[0], c->product[1], c->product[2],
+                                           c->kernel_grid_exit, c->product_grid_exit, c->kernel_grid_exit_path, c->product_grid_exit_path, c->bounce_auto};
             for (vrt::KernelFn fn : fns) {
                 const vrt::KernelEntry *e = fn ? vrt::kernel_entry_of(fn) : nullptr;
                 if (e && pred(*e)) return true;
@@ -614,7 +623,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         const vrt::KernelEntry *e1 = c->kernel_grid_exit ? vrt::kernel_entry_of(c->kernel_grid_exit) : nullptr;
         const vrt::KernelEntry *e2 = c->product_grid_exit ? vrt::kernel_entry_of(c->product_grid_exit) : nullptr;
         // (vrt_pool_kernel's path records, per stream of frames: room for eight workgroups per CU, any occupancy)
-        if ((e1 && e1->path == 2) || (e2 && e2->path == 2)) c->pool_stream_dwords = (size_t)(8 * cus) * 4u * vrt::kPoolPaths * vrt::kPoolPathDwords;
+        if ((e1 && e1->path == 2) || (e2 && e2->path == 2) || c->bounce_auto) c->pool_stream_dwords = (size_t)(8 * cus) * 4u * vrt::kPoolPaths * vrt::kPoolPathDwords;
     }
     for (int l = 0; l < (c->stream_b ? 2 : 1); l++) {
         const int rcl = lane_init(c, c->lane[l]);

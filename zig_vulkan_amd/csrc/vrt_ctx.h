@@ -221,6 +221,16 @@ struct vrt_ctx {
     vrt::TraceParams params{};
     vrt::KernelFn kernel = nullptr;        // frames with bounces: persistent lanes (vrt_path_kernel) unless kernel_variant bit 21
     vrt::KernelFn kernel_lockstep = nullptr; // ... the lockstep bounce loop (the multi-GPU pipeline's fallback where a launch slot has no sample buffer)
+    // Round 5, bounce frames of scenes that stay in the caches: the size rule gives them to the lockstep kernel, and for a terrain that is
+    // right (coherent rays: 1.5-1.8 x faster than vrt_pool_kernel on the reference app's run) — for a sparse field it is wrong by 1.6-2.2 x
+    // (profiles/r05_pool_generalised_ab.txt).  Where both kernels can trace the frame (bounce_auto: the pool kernel of this configuration)
+    // the library TIMES them — four frames on the primary stream, lockstep / pool / lockstep / pool, HIP events around each — and keeps
+    // the faster (pool only if it wins by 15 %); a status upload starts the trials again.  Frames are the same bytes either way.
+    vrt::KernelFn bounce_auto = nullptr;
+    uint32_t auto_next = 0;                // trial frames launched so far (0 .. 4)
+    bool auto_decided = false, auto_use_pool = false;
+    hipEvent_t auto_ev[4][2] = {};
+    float auto_ms[2] = {0.0f, 0.0f};       // what the trials measured: lockstep, pool (vrt_bounce_autotune_ms)
     vrt::PersistentLane lane[2];           // what the persistent kernels need per stream: [0] the primary stream, [1] stream_b
     size_t pool_stream_dwords = 0;         // size of one lane's pool_paths (0: this context selects no vrt_pool_kernel)
     uint32_t path_lds_bytes = 0;           // LDS block filter of vrt_path_kernel (0: grid not eligible)
@@ -297,8 +307,9 @@ int finish_frame(vrt_ctx *c);                   // wait for the frame in flight 
 // stream.  `lane` (may be nullptr) belongs to the stream `lane_stream` the frame will run on: a persistent kernel that needs or can use
 // a sample buffer finds it there (grown if it has to be: lane_samples_ready); where it cannot be had the frame keeps a kernel that
 // does without.  *with_samples: the frame's kernel is a persistent one and takes samples as its units of work from the lane's buffer.
+// trial: >= 0 when this frame is trial `trial` of the bounce kernel's auto-tune (even: lockstep, odd: pool); -1 otherwise.
 int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, vrt::PersistentLane *lane, hipStream_t lane_stream, vrt::KernelFn *fn,
-                 vrt::KernelFn *product_fn, bool *with_samples);
+                 vrt::KernelFn *product_fn, bool *with_samples, int trial = -1);
 bool lane_samples_ready(vrt_ctx *ctx, vrt::PersistentLane &lane, uint64_t units, hipStream_t lane_stream);
 uint64_t sample_units(const vrt_ctx *ctx, int samples_per_pixel); // units of a frame of this context (0: not a frame of units)
 void lane_into_params(const vrt::PersistentLane &lane, bool with_samples, vrt::TraceParams &p);

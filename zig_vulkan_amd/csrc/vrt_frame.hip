@@ -92,7 +92,7 @@ static vrt::KernelFn grid_exit_choice(vrt_ctx *ctx, vrt::KernelFn exit_fn, vrt::
 // for a counting context in *product_fn too: the product kernel that renders the frame read back.  Runs on the primary stream.
 // with_samples: the kernel of the frame (a persistent one) takes samples as its units of work from `lane`'s buffer.
 int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun, vrt::PersistentLane *lane, hipStream_t lane_stream, vrt::KernelFn *fn,
-                 vrt::KernelFn *product_fn, bool *with_samples) {
+                 vrt::KernelFn *product_fn, bool *with_samples, int trial) {
     if (!ctx || !camera || !sun) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL camera/sun") : VRT_E_INVALID_ARG;
     if (camera->image_width != ctx->cfg.width || camera->image_height != ctx->cfg.height)
         return fail(ctx, VRT_E_INVALID_ARG, "camera image size differs from the target image");
@@ -126,7 +126,7 @@ int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_de
         if (rcw != VRT_OK) return rcw;
         VRT_HIP(ctx, vrt::launch_build_status_blocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
         VRT_HIP(ctx, vrt::launch_build_cell_bounds(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
-        if (ctx->kernel_grid_exit || ctx->product_grid_exit) {
+        if (ctx->kernel_grid_exit || ctx->product_grid_exit || ctx->bounce_auto) {
             if (!ctx->h_cell_bounds) VRT_HIP(ctx, ctx->res.pinned(&ctx->h_cell_bounds, 6 * sizeof(int)));
             if (!ctx->ev_bounds) VRT_HIP(ctx, ctx->res.event(&ctx->ev_bounds, hipEventDisableTiming));
             if (ctx->bounds_pending) VRT_HIP(ctx, hipEventSynchronize(ctx->ev_bounds)); // (the copy before this one still owns the buffer)
@@ -134,6 +134,8 @@ int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_de
             VRT_HIP(ctx, hipEventRecord(ctx->ev_bounds, ctx->stream));
             ctx->bounds_pending = true;
             ctx->box_is_grid = false; // until the new box is known
+            ctx->auto_next = 0;       // (another scene: the bounce kernel's auto-tune starts again)
+            ctx->auto_decided = ctx->auto_use_pool = false;
         }
         VRT_HIP(ctx, vrt::launch_build_status_bytes(ctx->params, ctx->stream));
         VRT_HIP(ctx, vrt::launch_build_status_halfblocks(ctx->params, ctx->cfg.dim_x, ctx->cfg.dim_y, ctx->cfg.dim_z, ctx->stream));
@@ -179,6 +181,12 @@ int pre_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_de
     }
     if (camera->max_bounce > 1 && ctx->box_is_grid && !ctx->d_counters && ctx->kernel_grid_exit)
         *fn = grid_exit_choice(ctx, ctx->kernel_grid_exit, ctx->kernel_grid_exit_path, *fn, camera, lane, lane_stream);
+    // the auto-tuned bounce kernel (bounce_auto): the pool kernel on its trial frames and once the trials have said so
+    if (camera->max_bounce > 1 && ctx->box_is_grid && ctx->bounce_auto && !ctx->dist && ((trial >= 0 && (trial & 1)) || (trial < 0 && ctx->auto_decided && ctx->auto_use_pool))) {
+        const vrt::KernelFn pool = grid_exit_choice(ctx, ctx->bounce_auto, nullptr, nullptr, camera, lane, lane_stream);
+        if (pool) *fn = pool;
+        else if (trial >= 0) ctx->auto_decided = true, ctx->auto_use_pool = false; // (this context's frames do not fit the pool kernel: no contest)
+    }
     // With counters enabled the counting build of the kernel (compiler-generated loops, per-lane counters) runs
     // first and fills the counters; the frame that is read back is then rendered by the product kernel itself,
     // so that every parity check made on a counting context checks the shipped code path.
@@ -207,12 +215,31 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     DeviceGuard dg(ctx ? ctx->device : 0);
     // (the stream a frame of the persistent kernels would run on — they never wait for a re-sort of the tile schedule — and with it
     // the lane whose buffers the frame uses)
+    // the bounce kernel's auto-tune (vrt_ctx::bounce_auto): read the trials' events once all four have been launched; is this frame a trial?
+    int trial = -1;
+    if (ctx && ctx->bounce_auto && !ctx->auto_decided) {
+        if (ctx->auto_next == 4u) {
+            bool done = true;
+            for (int k = 0; k < 4 && done; k++) done = hipEventQuery(ctx->auto_ev[k][1]) == hipSuccess;
+            if (done) {
+                float ms[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 4 && done; k++) done = hipEventElapsedTime(&ms[k], ctx->auto_ev[k][0], ctx->auto_ev[k][1]) == hipSuccess;
+                ctx->auto_ms[0] = std::min(ms[0], ms[2]), ctx->auto_ms[1] = std::min(ms[1], ms[3]);
+                ctx->auto_use_pool = done && ctx->auto_ms[1] < 0.85f * ctx->auto_ms[0];
+                ctx->auto_decided = true;
+            }
+        } else if (frames == 1 && !marks && camera && camera->max_bounce > 1 && ctx->box_is_grid && !ctx->status_dirty && !ctx->params.wave_timeline) {
+            trial = (int)ctx->auto_next;
+            primary_only = true; // (a trial runs alone on the primary stream: its time is the kernel's, not the overlap's)
+        }
+    }
     const bool b_turn = ctx && ctx->stream_b && frames == 1 && !primary_only && (ctx->frame_seq & 1u) && (ctx->params.tile_order != 5u || ctx->sched_period);
     vrt::PersistentLane *lane = ctx ? &ctx->lane[b_turn ? 1 : 0] : nullptr;
     vrt::KernelFn fn = nullptr, product_fn = nullptr;
     bool with_samples = false;
-    const int rcp = pre_dispatch(ctx, camera, sun, lane, ctx ? (b_turn ? ctx->stream_b : ctx->stream) : nullptr, &fn, &product_fn, &with_samples);
+    const int rcp = pre_dispatch(ctx, camera, sun, lane, ctx ? (b_turn ? ctx->stream_b : ctx->stream) : nullptr, &fn, &product_fn, &with_samples, trial);
     if (rcp != VRT_OK) return rcp;
+    if (trial >= 0 && ctx->auto_decided) trial = -1; // (the pool kernel cannot take this context's frames: decided without a contest)
     lane_into_params(ctx->lane[0], with_samples && !b_turn, ctx->params);
     note_kernel(ctx, product_fn ? product_fn : fn);
     // (the persistent-lane kernel takes its pixels from a counter: it neither reads the tile schedule nor reports tile costs)
@@ -308,6 +335,11 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         ctx->params.sched_units = ctx->sched_cap[sched_mode];
         ctx->sched_since = ctx->sched_period;
     }
+    if (trial >= 0) {
+        for (int e = 0; e < 2; e++)
+            if (!ctx->auto_ev[trial][e]) VRT_HIP(ctx, ctx->res.event(&ctx->auto_ev[trial][e]));
+        VRT_HIP(ctx, hipEventRecord(ctx->auto_ev[trial][0], ctx->stream));
+    }
     for (uint32_t f = 0; f < frames; f++) {
         if (marks) VRT_HIP(ctx, hipEventRecord(marks[f], ctx->stream)); // per-frame timing (vrt_dispatch_timed)
         if (ctx->sched_period && nt > 1u && ctx->sched_since >= ctx->sched_period && scheduled) {
@@ -329,11 +361,24 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         ctx->sched_since++;
     }
     if (marks) VRT_HIP(ctx, hipEventRecord(marks[frames], ctx->stream));
+    if (trial >= 0) {
+        VRT_HIP(ctx, hipEventRecord(ctx->auto_ev[trial][1], ctx->stream));
+        ctx->auto_next = (uint32_t)trial + 1u;
+    }
     VRT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->timed_frames = frames;
     ctx->in_flight = true;
     ctx->frame_seq++;
     ctx->last_slot = 0;
+    return VRT_OK;
+}
+
+int vrt_bounce_autotune_info(vrt_ctx *ctx, double out[4]) {
+    if (!ctx || !out) return VRT_E_INVALID_ARG;
+    out[0] = !ctx->bounce_auto || ctx->dist ? 0.0 : (!ctx->auto_decided ? 1.0 : (ctx->auto_use_pool ? 3.0 : 2.0));
+    out[1] = (double)ctx->auto_next;
+    out[2] = (double)ctx->auto_ms[0];
+    out[3] = (double)ctx->auto_ms[1];
     return VRT_OK;
 }
 

@@ -450,6 +450,12 @@ class VoxelRT:
         """vrt_reserve_samples: the persistent kernels' sample buffers made now instead of by the first dispatch that needs them."""
         self._check(self._lib.vrt_reserve_samples(self._h, int(max_samples_per_pixel)))
 
+    def bounce_autotune_info(self) -> dict:
+        """vrt_bounce_autotune_info: what the library's timing of the lockstep kernel against vrt_pool_kernel has said so far."""
+        out = (C.c_double * 4)()
+        self._check(self._lib.vrt_bounce_autotune_info(self._h, out))
+        return {"state": ("not applicable", "trials", "lockstep", "pool")[int(out[0])], "trials_launched": int(out[1]), "lockstep_ms": out[2], "pool_ms": out[3]}
+
     def dist_wait(self) -> None:
         self._check(self._lib.vrt_dist_wait(self._h))
 
