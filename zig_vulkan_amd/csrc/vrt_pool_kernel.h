@@ -261,8 +261,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 // of the kernel's fabric traffic (profiles/r05_cfg4_pool_counters.txt).  What a transition needs follows from what kind of ray
                 // has just finished, which is kept WITH THE RAY (bit 23 of its flags) so that no load waits for another:
                 //   a camera / scattered ray that hit, sun on: shades and starts the shadow ray — reads the flags word, writes it and the
-                //     eight words the shadow ray's end needs (attenuation, the scattered ray, the hit ray's direction.y);
-                //   a shadow ray: reads those eight, the colour and the unit — writes the flags and, if the sun reached the hit, the colour;
+                //     the scattered ray's direction (its refraction index and the hit ray's direction.y only where they will be
+                //     read; the attenuation is the hit material's albedo: its id rides in the flags word);
+                //   a shadow ray: reads those, the colour and the unit — writes the flags and, if the sun reached the hit, the colour;
                 //   a ray that missed: the path is over — reads the colour and the unit; the unit is written when a new one is taken.
                 const bool fresh = st == kRayFetch;                       // (no path yet: every field it will use is set before it is read)
                 const bool was_shadow = !fresh && ((fl >> 23) & 1u) != 0u;
@@ -276,16 +277,19 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                     color = mk3(u2f(pr[5 * 128]), u2f(pr[6 * 128]), u2f(pr[7 * 128]));
                 }
                 if (was_shadow) {
-                    cur_dir_y = u2f(pr[8 * 128]);
                     sc_dir = mk3(u2f(pr[9 * 128]), u2f(pr[10 * 128]), u2f(pr[11 * 128]));
-                    sc_ir = u2f(pr[12 * 128]);
-                    attenuation = mk3(u2f(pr[13 * 128]), u2f(pr[14 * 128]), u2f(pr[15 * 128]));
+                    // (two words that hardly ever matter, behind the flags word: the hit ray's direction.y is read again only by a path that
+                    // ends with loop_count 0 — its first hit was a material of unknown type, comp:235-237 —, the scattered ray's refraction
+                    // index only where it is not 1: inside glass)
+                    if (((pf >> 16) & 15u) == 0u) cur_dir_y = u2f(pr[8 * 128]);
+                    if (pf & 1u) sc_ir = u2f(pr[12 * 128]);
                 }
                 bool color_changed = false, work_changed = false;
                 int loop_count = (int)((pf >> 16) & 15u);
                 int kind = (int)((pf >> 20) & 1u);
                 bool scattered_ok = ((pf >> 21) & 1u) != 0u;
                 uint32_t sc_ignore = (pf >> 22) & 3u;
+                uint32_t hit_mat = pf >> 24; // the material of the hit the shadow ray left from: its albedo is the attenuation (comp:223-226), read again from the table
 
                 Ray r = Ray{ro, rd, ir, (fl >> 18) & 3u};
                 RaySetup s;
@@ -332,6 +336,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                             const vrt_material *m = p.materials + hit.index;
                             const uint32_t mtype = m->type;
                             attenuation = mk3(m->albedo_r, m->albedo_g, m->albedo_b);
+                            hit_mat = hit.index & 0xFFu;
                             const float mdata = m->type_data;
                             switch (mtype) {
                                 case MAT_LAMBERTIAN: result = scatter_lambertian(hit, scattered); break;
@@ -366,6 +371,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                         }
                     } else {
                         if (!found) {
+                            const vrt_material *hm = p.materials + hit_mat; // (5 KiB table: resident; three words of the record less to carry)
+                            attenuation = mk3(hm->albedo_r, hm->albedo_g, hm->albedo_b);
                             color = color + attenuation * mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
                             color_changed = true;
                         }
@@ -525,14 +532,15 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 }
                 fl = (fl & ~(1u << 23)) | ((uint32_t)kind << 23); // (what kind of ray the next transition of this path will find finished)
                 st = nst;
-                pr[128] = (((uint32_t)loop_count & 15u) << 16) | ((uint32_t)kind << 20) | ((scattered_ok ? 1u : 0u) << 21) | ((sc_ignore & 3u) << 22);
+                const bool ir_kept = shades_only && f2u(sc_ir) != 0x3F800000u; // (bit 0 of the flags word: the record holds a refraction index other than 1.0f)
+                pr[128] = (((uint32_t)loop_count & 15u) << 16) | ((uint32_t)kind << 20) | ((scattered_ok ? 1u : 0u) << 21) | ((sc_ignore & 3u) << 22) | (hit_mat << 24) |
+                          (ir_kept ? 1u : 0u);
                 if (work_changed) pr[0] = work;
                 if (color_changed) pr[5 * 128] = f2u(color.x), pr[6 * 128] = f2u(color.y), pr[7 * 128] = f2u(color.z);
                 if (shades_only) { // (what the end of the shadow ray started above will read)
-                    pr[8 * 128] = f2u(cur_dir_y);
                     pr[9 * 128] = f2u(sc_dir.x), pr[10 * 128] = f2u(sc_dir.y), pr[11 * 128] = f2u(sc_dir.z);
-                    pr[12 * 128] = f2u(sc_ir);
-                    pr[13 * 128] = f2u(attenuation.x), pr[14 * 128] = f2u(attenuation.y), pr[15 * 128] = f2u(attenuation.z);
+                    if (loop_count == 0) pr[8 * 128] = f2u(cur_dir_y);
+                    if (ir_kept) pr[12 * 128] = f2u(sc_ir);
                 }
             }
             VRT_PF_T(0, pf0);
