@@ -386,7 +386,7 @@ int vrt_reserve_samples(vrt_ctx *ctx, uint32_t max_samples_per_pixel) {
     if (!ctx) return VRT_E_INVALID_ARG;
     if (max_samples_per_pixel == 0u || max_samples_per_pixel > 65535u) return fail(ctx, VRT_E_INVALID_ARG, "max_samples_per_pixel: 1..65535");
     // (only contexts whose bounce frames a persistent kernel may trace have anything to reserve)
-    const vrt::KernelFn fns[5] = {ctx->kernel, ctx->kernel_grid_exit, ctx->kernel_grid_exit_path, ctx->product[0], ctx->product_grid_exit};
+    const vrt::KernelFn fns[6] = {ctx->kernel, ctx->kernel_grid_exit, ctx->kernel_grid_exit_path, ctx->product[0], ctx->product_grid_exit, ctx->bounce_auto};
     bool persistent = false;
     for (vrt::KernelFn fn : fns) persistent = persistent || (fn && vrt::is_path_kernel(fn));
     const uint64_t units = sample_units(ctx, (int)max_samples_per_pixel);
