@@ -21,7 +21,7 @@ for kern in kernels:
         if kern:
             os.environ["VRT_DEV_POOL_KERNEL"] = kern
         os.environ.update(VRT_DEV_POOL_WALK_K=str(k), VRT_DEV_POOL_BRICK_THR=str(b), VRT_DEV_POOL_TRANS_THR=str(t), VRT_DEV_POOL_WALK_MIN=str(wm))
-        rt = W.make_renderer(w, grid, library=lib)
+        rt = W.make_renderer(w, grid, library=lib, kernel_variant=int(os.environ.get("SWEEP_VARIANT", "0"), 0))
         W.set_view(rt, view)
         rt.draw(); rt.wait()
         rt.draw(); rt.wait()

@@ -30,7 +30,8 @@
 // round.  With a staging area per wave that is four 256-thread workgroups per CU (156 of the CU's 160 KiB), four waves per SIMD.
 // Measured, the kernel issues one instruction per ~11 cycles per wave whatever the wave count — a wave is one chain of dependent
 // instructions — so occupancy is worth what it is in a latency-bound kernel: the waves of a workgroup SHARE two staging areas
-// (STAGES; a wave locks one for the length of its brick round), five workgroups fit, five waves per SIMD.
+// (STAGES; a wave locks one for the length of its brick round), five workgroups fit, five waves per SIMD — and, round 5, six with 48
+// records per wave (the kernel has come down to 80 VGPRs): SLOTS 48, 112 paths per wave.
 // Only the configuration the 2048^3 path trace runs: 8^3 bricks staged in LDS, the counter-free dilated-index walk (all three grid
 // dimensions powers of two, the walk ends at the grid's face: vrt_path_kernel<..., DIL 2>'s loop).  Everything else keeps
 // vrt_path_kernel.
@@ -53,7 +54,7 @@ VRT_DI float u2f(uint32_t v) { return __builtin_bit_cast(float, v); }
 
 // SLOTS: ray records in LDS per wave (the wave owns 64 + SLOTS paths).  STAGES: 4 KiB staging areas for bricks per workgroup of four
 // waves — 4: one per wave; fewer: a wave takes one for the length of a brick round (try-lock in LDS; if none is free it serves another
-// queue), which is what lets five workgroups of 128-path waves fit a CU's LDS.
+// queue), which is what lets five workgroups of 128-path waves — or six of 112-path waves — fit a CU's LDS.
 template <int B, int MIN_WAVES, int SLOTS = 64, int STAGES = 4>
 __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TraceParams p) {
     // B = 8: a brick (64 bytes) is staged in LDS for its voxel-level walk (STAGES areas per workgroup).  B = 4 (round 5: the reference's own
