@@ -14,15 +14,18 @@ const KernelEntry kEntries[] = {
     VRT_PATH_ENTRY_L(4, 5, false, false, false, false, 2), VRT_PATH_ENTRY_L(8, 5, false, false, false, false, 2),
     // round 4: a pool of rays per wave (vrt_pool_kernel.h): the counter-free dilated-index walk; the four waves of a workgroup share two
     // staging areas for 8^3 bricks (2048^3 path trace, same box: vrt_path_kernel 129.6 ms, a staging area per wave at four waves per SIMD
-    // 117.5, two shared at five 112.4).  Round 5: SIX waves per SIMD — the kernel needs 80 VGPRs without a spill by now — with 48 ray
-    // records in LDS per wave (112 paths; 25 920 B per workgroup, six per CU): 84.8 -> 82.9 ms (56 records and one area: 106; 40 and
-    // three: 93; 44 and two: 85.0 — the pool's size is worth more than the areas, profiles/r05_pool_sweep.txt); 4^3 bricks (no staging):
-    // 64 records at six waves, 13.2 -> 12.0 ms on a 4K / 1024^3 sparse path trace
-    VRT_POOL_ENTRY(8, 6, 48, 2),
+    // 117.5, two shared at five 112.4).  Round 5: SIX waves per SIMD — the kernel needs 80 VGPRs without a spill by now — with as many
+    // ray records in LDS per wave as six workgroups per CU leave room for (LDS is granted by the KiB: 26 624 B each): 48 records of 23
+    // dwords 84.8 -> 82.9 ms (56 records and one area: 106; 40 and three: 93; 44 and two: 85.0 — the pool's size is worth more than the
+    // areas: 3.4 % per eight records at five waves per SIMD), then 54 records of 21 dwords (the exchange pairs lanes and slots by two
+    // cross-lane permutes instead of a scratch row, the walk's code rides with the state): 80.9 ms; 56 would be a seventh KiB too many:
+    // five workgroups, 87.8 (profiles/r05_pool_sweep.txt).  4^3 bricks (no staging): 64 records at six waves, 13.2 -> 12.0 ms on a 4K /
+    // 1024^3 sparse path trace
+    VRT_POOL_ENTRY(8, 6, 54, 2),
     VRT_POOL_ENTRY(4, 6, 64, 0),
 #ifdef VRT_DEV_VARIANTS
     VRT_POOL_ENTRY(8, 4, 64, 4), VRT_POOL_ENTRY(8, 5, 64, 1), VRT_POOL_ENTRY(8, 6, 56, 1), VRT_POOL_ENTRY(8, 5, 40, 4),
-    VRT_POOL_ENTRY(8, 5, 64, 2), VRT_POOL_ENTRY(4, 5, 64, 0), VRT_POOL_ENTRY(8, 6, 40, 3), VRT_POOL_ENTRY(8, 6, 44, 2), VRT_POOL_ENTRY(8, 6, 32, 4),
+    VRT_POOL_ENTRY(8, 5, 64, 2), VRT_POOL_ENTRY(4, 5, 64, 0), VRT_POOL_ENTRY(8, 6, 56, 2), VRT_POOL_ENTRY(8, 6, 48, 2), VRT_POOL_ENTRY(8, 6, 52, 2), VRT_POOL_ENTRY(8, 6, 40, 3), VRT_POOL_ENTRY(8, 6, 44, 2), VRT_POOL_ENTRY(8, 6, 32, 4),
 #endif
 #ifdef VRT_DEV_VARIANTS
     // DIL 4 (round 3): the counter-free dilated-index walk with the DDA two cells ahead of the test (two requests in flight per lane;

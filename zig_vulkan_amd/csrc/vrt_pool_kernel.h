@@ -9,7 +9,7 @@
 // parameter of that kernel sits on a plateau; what is left is to take the ray OFF the lane.
 //
 // Here a wave owns 128 paths.  64 rays are in the registers of its lanes, the other 64 lie in ray records in the wave's own LDS
-// (21 dwords each, kept by field: dword k of slot j at rec[64 k + j], so that exchanging a lane's ray with a slot's is 21 reads and
+// (20 dwords each — 21 until round 5 —, kept by field: dword k of slot j at rec[S k + j], so that exchanging a lane's ray with a slot's is 21 reads and
 // 21 writes without bank conflicts).  The wave's loop picks a phase — WALK (comp:314-375, the hand-written park loop), BRICK
 // (comp:378-471 for the rays that stand in front of an occupied cell) or TRANSITION (comp:153-265 around GridHit: shade, scatter,
 // shadow ray, next sample, next pixel, ray set-up) — by how many of its 128 rays wait for each; lanes whose ray is in another
@@ -26,7 +26,7 @@
 // to go, and the pools emptied for 12.6 ms of a 113 ms frame, tools/path_profile.py.  With samples as units the drain is one sample long,
 // and the 16 rays of a pixel start side by side in one wave.)
 // No cross-wave communication (no barrier, no atomics but the unit counter): a wave's LDS is its own.
-// LDS per wave: 21 x 256 B records + 256 B slot states + 256 B scratch = 5 888 B, and 4 KiB of staged bricks for a wave in a brick
+// LDS per wave (round 4: 64 slots): 21 x 256 B records + 256 B slot states + 256 B scratch = 5 888 B, and 4 KiB of staged bricks for a wave in a brick
 // round.  With a staging area per wave that is four 256-thread workgroups per CU (156 of the CU's 160 KiB), four waves per SIMD.
 // Measured, the kernel issues one instruction per ~11 cycles per wave whatever the wave count — a wave is one chain of dependent
 // instructions — so occupancy is worth what it is in a latency-bound kernel: the waves of a workgroup SHARE two staging areas
@@ -64,16 +64,14 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
     // (the wave's number through readfirstlane: its LDS and its block of path records are then scalar addresses, not per-lane registers)
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // the workgroup's LDS: 16 lock words | STAGES staging areas of 4 KiB | per wave: records, slot states, scratch
-    constexpr uint32_t S = (uint32_t)SLOTS, kWaveDwords = (kPoolRecDwords + 2u) * S;
+    constexpr uint32_t S = (uint32_t)SLOTS, kWaveDwords = (kPoolRecDwords + 1u) * S;
     uint32_t *const locks = pool_lds;
     // the staging areas for bricks (LDS byte address; layout inside one dictated by global_load_lds: vrt_trace_kernels.h)
     const uint32_t stage0 = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)pool_lds + 64u;
     uint32_t *const rec = pool_lds + 16u + (uint32_t)STAGES * (kPoolStageBytes / 4u) + wave * kWaveDwords; // rec[S k + j]: dword k of the ray in slot j
-    uint32_t *const sstate = rec + kPoolRecDwords * S; // state of the ray in slot j
+    uint32_t *const sstate = rec + kPoolRecDwords * S; // bits 0-7: state of the ray in slot j; bits 8-15: its walk code (GridParkRegs::code)
     // (LDS byte addresses for the exchange's instructions; scalar: the wave's number is)
     const uint32_t rec_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)rec);
-    const uint32_t tmp_lds = rec_lds + (kPoolRecDwords + 1u) * S * 4u;
-    uint32_t *const tmp = sstate + S;
     if (threadIdx.x < 16u) locks[threadIdx.x] = 0u; // (staging locks free; every wave's chunk empty, the counter not yet run out)
     __syncthreads();
     uint32_t *const path = p.pool_paths + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave) * (size_t)(kPoolPaths * kPoolPathDwords);
@@ -112,7 +110,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
     const bool start_is_slot = p.start_is_slot != nullptr && __builtin_amdgcn_readfirstlane((int)*p.start_is_slot) != 0;
     const uint32_t walk_k = max(1u, p.pool_walk_k), brick_thr = p.pool_brick_thr, trans_thr = p.pool_trans_thr, walk_min = p.pool_walk_min;
 
-    // ---- the ray in this lane's registers (the record's 21 dwords) + its state ----
+    // ---- the ray in this lane's registers (the record's 20 dwords) + its state and walk code ----
     f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), inv = mk3(1, 1, 1), sd = mk3(0, 0, 0);
     uint32_t idx = 0u;  // the cell the walk stands on (dilated index; axes walked down mirrored)
     uint32_t cw = 0u;   // kRayWalk: the half-block word of that cell; kRayParked: the occupied cell left behind (dilated index)
@@ -140,42 +138,45 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
 
     // lanes whose ray is not of class X take the ray of a slot that is, as many as there are on either side
     auto exchange = [&](uint32_t X) {
-        const uint32_t sst = lane < S ? sstate[lane] : (uint32_t)kRayExit;
+        const uint32_t sst = lane < S ? (sstate[lane] & 0xFFu) : (uint32_t)kRayExit;
         const unsigned long long offer = __builtin_amdgcn_ballot_w64(pool_class(sst) == X);
         const unsigned long long want = __builtin_amdgcn_ballot_w64(pool_class(st) != X);
-        const uint32_t n = min((uint32_t)__builtin_popcountll(offer), (uint32_t)__builtin_popcountll(want));
+        const uint32_t n_offer = (uint32_t)__builtin_popcountll(offer);
+        const uint32_t n = min(n_offer, (uint32_t)__builtin_popcountll(want));
         const uint32_t q = pool_mbcnt(offer), r = pool_mbcnt(want);
-        if (((offer >> lane) & 1ull) && q < n) tmp[q] = lane;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        // the r-th wanting lane takes the r-th offering slot.  Which slot that is comes through two cross-lane permutes (round 5; until then
+        // through a scratch row in LDS, a dword per slot): first every lane sends its number to its place in "offering lanes first, in
+        // order" — a permutation of the 64 lanes —, then the wanting lane of rank r reads place r.
+        const uint32_t place = ((offer >> lane) & 1ull) ? q : n_offer + (lane - q);
+        const uint32_t by_rank = (uint32_t)__builtin_amdgcn_ds_permute((int)(place << 2), (int)lane);
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(r << 2), (int)by_rank);
         {
-            // the lane's 21 dwords and its state against the slot's, field by field: ds_wrxchg writes the register and returns what was
-            // there into the same register — one LDS instruction per field, nothing copied.  The taking lanes are selected by EXEC inside
-            // the block: to the compiler this is straight-line code on the ray's registers (as a branch it copies all 22 of them to
+            // the lane's 20 dwords and its state + code against the slot's, field by field: ds_wrxchg writes the register and returns what
+            // was there into the same register — one LDS instruction per field, nothing copied.  The taking lanes are selected by EXEC inside
+            // the block: to the compiler this is straight-line code on the ray's registers (as a branch it copies all of them to
             // another set of registers before every exchange: the loaded values are the branch's, the old ones the other path's)
             const unsigned long long take = __builtin_amdgcn_ballot_w64(((want >> lane) & 1ull) && r < n);
-            const uint32_t slot_of = tmp_lds + (r << 2);
+            uint32_t sc = st | (code << 8);
+            uint32_t at = rec_lds + (slot << 2);
             unsigned long long saved;
-            uint32_t at;
 #define VRT_X(k) "ds_wrxchg_rtn_b32 %[f" #k "], %[at], %[f" #k "] offset:%[o" #k "]\n\t"
             asm volatile("s_and_saveexec_b64 %[saved], %[take]\n\t"
-                         "ds_read_b32 %[at], %[slot]\n\t"
-                         "s_waitcnt lgkmcnt(0)\n\t"
-                         "v_lshl_add_u32 %[at], %[at], 2, %[rec]\n\t"
                          VRT_X(0) VRT_X(1) VRT_X(2) VRT_X(3) VRT_X(4) VRT_X(5) VRT_X(6) VRT_X(7) VRT_X(8) VRT_X(9) VRT_X(10) VRT_X(11) VRT_X(12) VRT_X(13)
-                         VRT_X(14) VRT_X(15) VRT_X(16) VRT_X(17) VRT_X(18) VRT_X(19) VRT_X(20) VRT_X(21)
+                         VRT_X(14) VRT_X(15) VRT_X(16) VRT_X(17) VRT_X(18) VRT_X(19) VRT_X(20)
                          "s_waitcnt lgkmcnt(0)\n\t"
                          "s_mov_b64 exec, %[saved]"
                          : [f0] "+v"(ro.x), [f1] "+v"(ro.y), [f2] "+v"(ro.z), [f3] "+v"(rd.x), [f4] "+v"(rd.y), [f5] "+v"(rd.z), [f6] "+v"(inv.x),
                            [f7] "+v"(inv.y), [f8] "+v"(inv.z), [f9] "+v"(sd.x), [f10] "+v"(sd.y), [f11] "+v"(sd.z), [f12] "+v"(idx), [f13] "+v"(cw),
                            [f14] "+v"(t_in), [f15] "+v"(t_out), [f16] "+v"(gtmin), [f17] "+v"(gtmax), [f18] "+v"(ir), [f19] "+v"(fl),
-                           [f20] "+v"(code), [f21] "+v"(st), [at] "=&v"(at), [saved] "=&s"(saved)
-                         : [take] "s"(take), [slot] "v"(slot_of), [rec] "s"(rec_lds), [o0] "n"(0), [o1] "n"(4 * S), [o2] "n"(8 * S), [o3] "n"(12 * S),
+                           [f20] "+v"(sc), [saved] "=&s"(saved)
+                         : [take] "s"(take), [at] "v"(at), [o0] "n"(0), [o1] "n"(4 * S), [o2] "n"(8 * S), [o3] "n"(12 * S),
                            [o4] "n"(16 * S), [o5] "n"(20 * S), [o6] "n"(24 * S), [o7] "n"(28 * S), [o8] "n"(32 * S), [o9] "n"(36 * S), [o10] "n"(40 * S),
                            [o11] "n"(44 * S), [o12] "n"(48 * S), [o13] "n"(52 * S), [o14] "n"(56 * S), [o15] "n"(60 * S), [o16] "n"(64 * S),
-                           [o17] "n"(68 * S), [o18] "n"(72 * S), [o19] "n"(76 * S), [o20] "n"(80 * S), [o21] "n"(84 * S)
+                           [o17] "n"(68 * S), [o18] "n"(72 * S), [o19] "n"(76 * S), [o20] "n"(80 * S)
                          : "memory", "scc");
 #undef VRT_X
+            st = sc & 0xFFu;
+            code = sc >> 8;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
     for (uint32_t round = 0u; round < (1u << 23); round++) {
         // how many of the wave's rays wait for what
         VRT_PROF_BEGIN(tpd);
-        const uint32_t sst = lane < S ? sstate[lane] : (uint32_t)kRayExit;
+        const uint32_t sst = lane < S ? (sstate[lane] & 0xFFu) : (uint32_t)kRayExit;
         const uint32_t n_walk = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kRayWalk)) +
                                 (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sst == kRayWalk));
         const uint32_t n_brick = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kRayParked)) +
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
             }
             // the phase rule's first three lines on fresh counts: neither of the other queues is full, and enough rays are left to walk
             {
-                const uint32_t sst2 = lane < S ? sstate[lane] : (uint32_t)kRayExit;
+                const uint32_t sst2 = lane < S ? (sstate[lane] & 0xFFu) : (uint32_t)kRayExit;
                 const uint32_t w2 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kRayWalk)) +
                                     (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sst2 == kRayWalk));
                 const uint32_t b2 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(st == kRayParked)) +
