@@ -352,7 +352,7 @@ uint32_t vrt_abi_version(void);
  * one sample per pixel would take), as its template-id — the kernel name rocprofv3 reports minus the `void vrt::` prefix and
  * the argument list: "vrt_trace_kernel<8, false, 7, 7, 2, 256>" (B, COUNT, MODE, MIN_WAVES, SHADE, BLOCK),
  * "vrt_path_kernel<8, 5, false, false, false, false, 1>" (B, MIN_WAVES, FILTER, HALF, AHEAD, DIST, DIL) or
- * "vrt_pool_kernel<8, 6, 54, 2>" (B, MIN_WAVES, SLOTS, STAGES).  Inside the multi-GPU pipeline: the kernel of the frame queued last.  On a counting context: the product kernel, not the counting build that
+ * "vrt_pool_kernel<8, 6, 60, 2>" (B, MIN_WAVES, SLOTS, STAGES).  Inside the multi-GPU pipeline: the kernel of the frame queued last.  On a counting context: the product kernel, not the counting build that
  * ran before it.  The name is that of the LAST frame and may change between frames of one context: a context whose bounce frames
  * the persistent kernels trace starts on vrt_path_kernel<..., DIL 1> and moves to vrt_pool_kernel (8^3 bricks) or <..., DIL 2> once the
  * host copy of the occupied cells' box has arrived and says that the box is the grid; frames of other sample / bounce counts take

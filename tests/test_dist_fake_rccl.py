@@ -283,7 +283,7 @@ def test_bounce_frames_go_through_the_pipeline_on_the_persistent_kernels(world, 
     w, grid = _bounce_scene()
     views = ["V0", "V1x", "V0", "V2", "V1x", "V2", "V0", "V1x"]
     ref, single_name = _single_context_frames(w, grid, views, path)
-    assert single_name == "vrt_pool_kernel<8, 6, 54, 2>"
+    assert single_name == "vrt_pool_kernel<8, 6, 60, 2>"
     uid = b"fake-rccl-pool" + bytes([world, frames_in_flight, frames_per_launch]) + os.urandom(16) + bytes(128 - 33)
     ranks = [W.make_renderer(w, grid, kernel_variant=path, shard_rank=r, shard_count=world, shard_root_weight=root_weight) for r in range(world)]
     for r, rt in enumerate(ranks):
@@ -322,7 +322,8 @@ def test_bounce_frames_go_through_the_pipeline_on_the_persistent_kernels(world, 
         assert np.array_equal(frame, ref[v]), f"assembled frame of view {v} differs from the single-context frame"
     for r in range(world):
         assert all(n.startswith(("vrt_path_kernel<8, 5,", "vrt_pool_kernel<8, 6,")) for n in names[r]), names[r]
-        assert names[r][-1] == "vrt_pool_kernel<8, 6, 54, 2>", names[r]
+        if reads[0] < len(views) - 1:     # (a wait before the last frame: the box has reached the host by then; without one it is a race)
+            assert names[r][-1] == "vrt_pool_kernel<8, 6, 60, 2>", names[r]
 
 
 def test_bounce_frames_without_a_sample_buffer_keep_the_lockstep_kernel_in_the_pipeline():

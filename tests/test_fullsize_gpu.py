@@ -62,7 +62,7 @@ def test_cfg4_4k_2048c_sparse_path_trace():
     # the first frame is traced on the dilated cell index with steps-left counters and compared with the oracle; behind it the host
     # knows that the spheres fill the grid, and the second frame — vrt_pool_kernel's (round 4: a pool of 128 rays per wave) — must be the same bytes
     _sampled_parity("cfg4_4k_2048c_b8_sparse", "V1", 3000,
-                    kernels=("vrt_path_kernel<8, 5, false, false, false, false, 1>", "vrt_pool_kernel<8, 6, 54, 2>"))
+                    kernels=("vrt_path_kernel<8, 5, false, false, false, false, 1>", "vrt_pool_kernel<8, 6, 60, 2>"))
 
 
 def _whole_frame_cases():
@@ -113,7 +113,7 @@ def test_whole_frames_of_the_baseline_configurations_are_the_oracles(path):
         assert (u[..., 3] == 255).all() and (f[..., 3] == 1.0).all()
     rt.deinit()
     if str(z["workload"]).startswith("cfg4"):
-        assert names == ["vrt_path_kernel<8, 5, false, false, false, false, 1>", "vrt_pool_kernel<8, 6, 54, 2>"], names
+        assert names == ["vrt_path_kernel<8, 5, false, false, false, false, 1>", "vrt_pool_kernel<8, 6, 60, 2>"], names
 
 
 def test_grid_edits_reach_the_next_dispatch():
@@ -349,7 +349,7 @@ def test_path_kernel_memory_layouts_change_no_pixel():
     base = _frames_with_flags(w, views, 0, kernel_names=names, kernel_variant=path)
     # the spheres reach the grid's faces: the walk ends at the grid's face — round 4: a pool of rays per wave (vrt_pool_kernel);
     # without it vrt_path_kernel's dilated-index walk without steps-left counters; with the second flag, the one with them
-    assert set(names) == {"vrt_pool_kernel<8, 6, 54, 2>"}, names
+    assert set(names) == {"vrt_pool_kernel<8, 6, 60, 2>"}, names
     names = []
     for v, a, b in zip(views, base, _frames_with_flags(w, views, L.TUNE_NO_PATH_POOL, kernel_names=names, kernel_variant=path)):
         assert np.array_equal(a, b), ("a ray per lane", v)

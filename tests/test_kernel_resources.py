@@ -84,7 +84,7 @@ def _scratch_instructions(symbol_part: str) -> int:
 
 
 def test_pool_kernel_holds_6_waves():
-    """vrt_pool_kernel<8, 6, 54, 2> and <4, 6, 64, 0> (round 5: six waves per SIMD): 80 VGPRs, and no scratch: not one
+    """vrt_pool_kernel<8, 6, 60, 2> and <4, 6, 64, 0> (round 5: six waves per SIMD): 80 VGPRs, and no scratch: not one
     scratch instruction in their code (the descriptor may reserve a few bytes — the compiler's emergency slot for saving a register while
     EXEC is rewritten — that no instruction touches)."""
     ks = {n: k for n, k in _kernels().items() if "vrt_pool_kernel" in n}

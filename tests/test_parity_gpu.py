@@ -919,7 +919,7 @@ def test_frames_the_pool_kernel_cannot_take_keep_the_counter_free_path_kernel():
         rt.draw()
         out[variant] = (rt.read_rgba8().copy(), first, rt.kernel_name())
         rt.deinit()
-    assert out[PATH][1] == "vrt_pool_kernel<8, 6, 54, 2>" and out[PATH][2] == "vrt_path_kernel<8, 5, false, false, false, false, 2>", out[PATH][1:]
+    assert out[PATH][1] == "vrt_pool_kernel<8, 6, 60, 2>" and out[PATH][2] == "vrt_path_kernel<8, 5, false, false, false, false, 2>", out[PATH][1:]
     assert out[1 << 21][2].startswith("vrt_trace_kernel<8,")
     assert np.array_equal(out[PATH][0], out[1 << 21][0]) and out[PATH][0].any()
 
@@ -948,7 +948,7 @@ def test_sample_buffers_reserved_up_front_and_kept_when_growth_fails():
         rt.camera.d_camera.samples_per_pixel = 7
         for _ in range(3):
             rt.draw()
-        assert rt.kernel_name() == "vrt_pool_kernel<8, 6, 54, 2>" and np.array_equal(rt.read_rgba8(), want)
+        assert rt.kernel_name() == "vrt_pool_kernel<8, 6, 60, 2>" and np.array_equal(rt.read_rgba8(), want)
         with pytest.raises(L.VrtError):
             rt.reserve_samples(70000)
         big = W.make_renderer(W.Workload("big", 3840, 2160, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000), grid, kernel_variant=PATH)
@@ -958,7 +958,7 @@ def test_sample_buffers_reserved_up_front_and_kept_when_growth_fails():
         big.deinit()
         rt.draw()
         rt.draw()
-        assert rt.kernel_name() == "vrt_pool_kernel<8, 6, 54, 2>" and np.array_equal(rt.read_rgba8(), want)
+        assert rt.kernel_name() == "vrt_pool_kernel<8, 6, 60, 2>" and np.array_equal(rt.read_rgba8(), want)
         rt.deinit()
 
 
@@ -1018,7 +1018,7 @@ def test_pool_kernel_takes_the_material_of_one_material_bricks_from_a_byte_per_c
             W.set_view(rt, v)
             rt.draw()
             out.append((rt.read_rgba32f().copy(), rt.read_rgba8().copy()))
-        assert rt.kernel_name() == "vrt_pool_kernel<8, 6, 54, 2>", rt.kernel_name()
+        assert rt.kernel_name() == "vrt_pool_kernel<8, 6, 60, 2>", rt.kernel_name()
         if edit is not None:
             edit(grid)
             rt.update_grid_delta()
@@ -1028,7 +1028,7 @@ def test_pool_kernel_takes_the_material_of_one_material_bricks_from_a_byte_per_c
             first = (rt.read_rgba32f().copy(), rt.read_rgba8().copy())
             rt.draw()
             out.append((rt.read_rgba32f().copy(), rt.read_rgba8().copy()))
-            assert rt.kernel_name() == "vrt_pool_kernel<8, 6, 54, 2>", rt.kernel_name()
+            assert rt.kernel_name() == "vrt_pool_kernel<8, 6, 60, 2>", rt.kernel_name()
             assert np.array_equal(first[0].view(np.uint32), out[-1][0].view(np.uint32)) and np.array_equal(first[1], out[-1][1])
         pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
         rt.deinit()
@@ -1073,7 +1073,7 @@ def test_pool_kernel_on_bricks_of_4_and_on_a_box_smaller_than_the_grid():
                 frames.append((rt.read_rgba32f().copy(), rt.read_rgba8().copy()))
             out[variant] = (frames, rt.kernel_name(), O.push_constants(rt.camera.blob(), rt.sun.blob()))
             rt.deinit()
-        assert out[PATH][1] == ("vrt_pool_kernel<8, 6, 54, 2>" if w.brick_dimension == 8 else "vrt_pool_kernel<4, 6, 64, 0>"), (w.name, out[PATH][1])
+        assert out[PATH][1] == ("vrt_pool_kernel<8, 6, 60, 2>" if w.brick_dimension == 8 else "vrt_pool_kernel<4, 6, 64, 0>"), (w.name, out[PATH][1])
         assert out[1 << 21][1].startswith("vrt_trace_kernel<"), out[1 << 21][1]
         for v, (fa, ua), (fb, ub) in zip(views, out[PATH][0], out[1 << 21][0]):
             assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)) and np.array_equal(ua, ub) and ua.any(), (w.name, v)

@@ -652,10 +652,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     {
         p.pool_paths = c->lane[0].pool_paths;
         p.pool_cus = (uint32_t)cus;
-        p.pool_walk_k = 12u;
-        p.pool_brick_thr = 48u; // (tools/experiments/pool_sweep.py: a plateau from 48 to 56, walk_min 32 to 40, walk_k 16 to 20)
-        p.pool_trans_thr = 48u;
-        p.pool_walk_min = 32u;
+        p.pool_walk_k = 14u;    // (tools/experiments/pool_sweep.py; round 5, 124 rays per wave: a plateau — walk_k 12 to 16, thresholds 52 to 56, walk_min 36 to 40)
+        p.pool_brick_thr = 52u;
+        p.pool_trans_thr = 52u;
+        p.pool_walk_min = 36u;
         p.path_groups = 8u * (uint32_t)cus; // twice what 4 waves per SIMD hold: late groups find the counter exhausted and leave
         p.path_fin_batch = 32u;
         p.path_brick_lds = (cfg->brick_dimension == 8u && !(cfg->tuning_flags & VRT_TUNE_NO_PATH_BRICK_LDS)) ? 1u : 0u;

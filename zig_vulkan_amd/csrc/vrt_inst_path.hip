@@ -19,13 +19,14 @@ const KernelEntry kEntries[] = {
     // dwords 84.8 -> 82.9 ms (56 records and one area: 106; 40 and three: 93; 44 and two: 85.0 — the pool's size is worth more than the
     // areas: 3.4 % per eight records at five waves per SIMD), then 54 records of 21 dwords (the exchange pairs lanes and slots by two
     // cross-lane permutes instead of a scratch row, the walk's code rides with the state): 80.9 ms; 56 would be a seventh KiB too many:
-    // five workgroups, 87.8 (profiles/r05_pool_sweep.txt).  4^3 bricks (no staging): 64 records at six waves, 13.2 -> 12.0 ms on a 4K /
+    // five workgroups, 87.8; then 60 records of 19 dwords (GridHit's slab distances are formed again by the brick round instead of
+    // carried: + 0.8 % at equal records, 79.8 ms with 60, 79.0 with the phase rule re-tuned) (profiles/r05_pool_sweep.txt).  4^3 bricks (no staging): 64 records at six waves, 13.2 -> 12.0 ms on a 4K /
     // 1024^3 sparse path trace
-    VRT_POOL_ENTRY(8, 6, 54, 2),
+    VRT_POOL_ENTRY(8, 6, 60, 2),
     VRT_POOL_ENTRY(4, 6, 64, 0),
 #ifdef VRT_DEV_VARIANTS
     VRT_POOL_ENTRY(8, 4, 64, 4), VRT_POOL_ENTRY(8, 5, 64, 1), VRT_POOL_ENTRY(8, 6, 56, 1), VRT_POOL_ENTRY(8, 5, 40, 4),
-    VRT_POOL_ENTRY(8, 5, 64, 2), VRT_POOL_ENTRY(4, 5, 64, 0), VRT_POOL_ENTRY(8, 6, 56, 2), VRT_POOL_ENTRY(8, 6, 48, 2), VRT_POOL_ENTRY(8, 6, 52, 2), VRT_POOL_ENTRY(8, 6, 40, 3), VRT_POOL_ENTRY(8, 6, 44, 2), VRT_POOL_ENTRY(8, 6, 32, 4),
+    VRT_POOL_ENTRY(8, 5, 64, 2), VRT_POOL_ENTRY(4, 5, 64, 0), VRT_POOL_ENTRY(8, 6, 56, 2), VRT_POOL_ENTRY(8, 6, 58, 2), VRT_POOL_ENTRY(8, 6, 54, 2), VRT_POOL_ENTRY(8, 6, 40, 3), VRT_POOL_ENTRY(8, 6, 44, 2), VRT_POOL_ENTRY(8, 6, 32, 4),
 #endif
 #ifdef VRT_DEV_VARIANTS
     // DIL 4 (round 3): the counter-free dilated-index walk with the DDA two cells ahead of the test (two requests in flight per lane;

@@ -60,12 +60,12 @@ const KernelEntry *kernel_entry_of(KernelFn fn);
 hipError_t launch_pool_resolve(const TraceParams &p, hipStream_t stream);
 int compiled_kernel_count();
 
-// vrt_pool_kernel (vrt_pool_kernel.h): per wave `slots` ray records of 20 dwords in LDS and a dword of state + walk code per slot (round 5:
-// 23 -> 21 dwords per slot — the exchange pairs lanes and slots by two cross-lane permutes instead of a scratch row, the walk's code rides
-// with the state — which is what lets 56 records per wave fit six workgroups per CU);
+// vrt_pool_kernel (vrt_pool_kernel.h): per wave `slots` ray records of 18 dwords in LDS and a dword of state + walk code per slot (round 5:
+// 23 -> 19 dwords per slot — the exchange pairs lanes and slots by two cross-lane permutes instead of a scratch row, the walk's code rides
+// with the state — GridHit's slab distances are formed again where they are needed — which is what lets 60 records per wave fit six workgroups per CU);
 // per workgroup 16 lock words and `stages` staging areas of 4 KiB for bricks; 64 + slots paths per wave, 16 dwords each in global
 // memory (TraceParams::pool_paths, sized for 128 paths per wave)
-constexpr uint32_t kPoolRecDwords = 20u;
+constexpr uint32_t kPoolRecDwords = 18u;
 constexpr uint32_t kPoolStageBytes = 4096u;
 constexpr uint32_t pool_group_lds_bytes(uint32_t slots, uint32_t stages) { return 64u + stages * kPoolStageBytes + 4u * (kPoolRecDwords + 1u) * 4u * slots; }
 constexpr uint32_t kPoolPaths = 128u;

@@ -9,7 +9,7 @@
 // parameter of that kernel sits on a plateau; what is left is to take the ray OFF the lane.
 //
 // Here a wave owns 128 paths.  64 rays are in the registers of its lanes, the other 64 lie in ray records in the wave's own LDS
-// (20 dwords each — 21 until round 5 —, kept by field: dword k of slot j at rec[S k + j], so that exchanging a lane's ray with a slot's is 21 reads and
+// (18 dwords each — 21 until round 5 —, kept by field: dword k of slot j at rec[S k + j], so that exchanging a lane's ray with a slot's is 21 reads and
 // 21 writes without bank conflicts).  The wave's loop picks a phase — WALK (comp:314-375, the hand-written park loop), BRICK
 // (comp:378-471 for the rays that stand in front of an occupied cell) or TRANSITION (comp:153-265 around GridHit: shade, scatter,
 // shadow ray, next sample, next pixel, ray set-up) — by how many of its 128 rays wait for each; lanes whose ray is in another
@@ -110,13 +110,13 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
     const bool start_is_slot = p.start_is_slot != nullptr && __builtin_amdgcn_readfirstlane((int)*p.start_is_slot) != 0;
     const uint32_t walk_k = max(1u, p.pool_walk_k), brick_thr = p.pool_brick_thr, trans_thr = p.pool_trans_thr, walk_min = p.pool_walk_min;
 
-    // ---- the ray in this lane's registers (the record's 20 dwords) + its state and walk code ----
+    // ---- the ray in this lane's registers (the record's 18 dwords) + its state and walk code ----
     f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), inv = mk3(1, 1, 1), sd = mk3(0, 0, 0);
     uint32_t idx = 0u;  // the cell the walk stands on (dilated index; axes walked down mirrored)
     uint32_t cw = 0u;   // kRayWalk: the half-block word of that cell; kRayParked: the occupied cell left behind (dilated index)
     float t_in = 0.0f;  // crossed distance of the step into the parked cell; kRayHit: hit.t
     float t_out = 0.0f; // crossed distance of the ray's last step; kRayHit: hit.index (bits)
-    float gtmin = 0.0f, gtmax = 0.0f, ir = 1.0f;
+    float ir = 1.0f; // (the slab distances of GridHit, comp:273-286, are not carried: the brick round forms them again from origin and 1 / dir)
     // flags: bits 0-6 the path (slot of `path`), 8-9 / 10-11 / 12-13 ray step x / y / z + 1, 14-17 slab-entry code, 18-19 ignored
     // material type, 20 the step out of the parked cell left the grid, 21-22 kRayHit: the face of the voxel hit, 23 the ray is a shadow ray
     // (RayColor's `kind`, kept with the ray: the transition that finds it finished knows which fields of the path it needs before loading any)
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
     if (lane < S) {
         sstate[lane] = kRayFetch;
 #pragma unroll
-        for (uint32_t k = 0; k < kPoolRecDwords; k++) rec[S * k + lane] = (k == 19u) ? 64u + lane : 0u;
+        for (uint32_t k = 0; k < kPoolRecDwords; k++) rec[S * k + lane] = (k == 17u) ? 64u + lane : 0u;
     }
 
     // tile / tiles_x by the host's reciprocal (TraceParams::pool_tiles_x_magic): the compiler's own would be a per-lane register kept
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
         const uint32_t by_rank = (uint32_t)__builtin_amdgcn_ds_permute((int)(place << 2), (int)lane);
         const uint32_t slot = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(r << 2), (int)by_rank);
         {
-            // the lane's 20 dwords and its state + code against the slot's, field by field: ds_wrxchg writes the register and returns what
+            // the lane's 18 dwords and its state + code against the slot's, field by field: ds_wrxchg writes the register and returns what
             // was there into the same register — one LDS instruction per field, nothing copied.  The taking lanes are selected by EXEC inside
             // the block: to the compiler this is straight-line code on the ray's registers (as a branch it copies all of them to
             // another set of registers before every exchange: the loaded values are the branch's, the old ones the other path's)
@@ -162,17 +162,16 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
 #define VRT_X(k) "ds_wrxchg_rtn_b32 %[f" #k "], %[at], %[f" #k "] offset:%[o" #k "]\n\t"
             asm volatile("s_and_saveexec_b64 %[saved], %[take]\n\t"
                          VRT_X(0) VRT_X(1) VRT_X(2) VRT_X(3) VRT_X(4) VRT_X(5) VRT_X(6) VRT_X(7) VRT_X(8) VRT_X(9) VRT_X(10) VRT_X(11) VRT_X(12) VRT_X(13)
-                         VRT_X(14) VRT_X(15) VRT_X(16) VRT_X(17) VRT_X(18) VRT_X(19) VRT_X(20)
+                         VRT_X(14) VRT_X(15) VRT_X(16) VRT_X(17) VRT_X(18)
                          "s_waitcnt lgkmcnt(0)\n\t"
                          "s_mov_b64 exec, %[saved]"
                          : [f0] "+v"(ro.x), [f1] "+v"(ro.y), [f2] "+v"(ro.z), [f3] "+v"(rd.x), [f4] "+v"(rd.y), [f5] "+v"(rd.z), [f6] "+v"(inv.x),
                            [f7] "+v"(inv.y), [f8] "+v"(inv.z), [f9] "+v"(sd.x), [f10] "+v"(sd.y), [f11] "+v"(sd.z), [f12] "+v"(idx), [f13] "+v"(cw),
-                           [f14] "+v"(t_in), [f15] "+v"(t_out), [f16] "+v"(gtmin), [f17] "+v"(gtmax), [f18] "+v"(ir), [f19] "+v"(fl),
-                           [f20] "+v"(sc), [saved] "=&s"(saved)
+                           [f14] "+v"(t_in), [f15] "+v"(t_out), [f16] "+v"(ir), [f17] "+v"(fl), [f18] "+v"(sc), [saved] "=&s"(saved)
                          : [take] "s"(take), [at] "v"(at), [o0] "n"(0), [o1] "n"(4 * S), [o2] "n"(8 * S), [o3] "n"(12 * S),
                            [o4] "n"(16 * S), [o5] "n"(20 * S), [o6] "n"(24 * S), [o7] "n"(28 * S), [o8] "n"(32 * S), [o9] "n"(36 * S), [o10] "n"(40 * S),
                            [o11] "n"(44 * S), [o12] "n"(48 * S), [o13] "n"(52 * S), [o14] "n"(56 * S), [o15] "n"(60 * S), [o16] "n"(64 * S),
-                           [o17] "n"(68 * S), [o18] "n"(72 * S), [o19] "n"(76 * S), [o20] "n"(80 * S)
+                           [o17] "n"(68 * S), [o18] "n"(72 * S)
                          : "memory", "scc");
 #undef VRT_X
             st = sc & 0xFFu;
@@ -298,7 +297,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 s.inv_dir = inv;
                 s.entry_code = (int)((fl >> 14) & 15u);
                 s.sx = sx_of(fl), s.sy = sy_of(fl), s.sz = sz_of(fl);
-                s.grid_t_min = gtmin, s.grid_t_max = gtmax;
+                s.grid_t_min = 0.0f, s.grid_t_max = 0.0f; // (of the finished ray: not read again)
                 const bool found = st == kRayHit;
                 int ls = (st == kRayFetch) ? kLaneFetch : kLaneDone;
                 // (1) a ray has finished: comp:218-258 from the loop condition's GridHit onwards
@@ -528,7 +527,6 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                     // the ray as the walk and the next transition need it
                     ro = r.origin, rd = r.direction, ir = r.internal_reflection;
                     inv = s.inv_dir;
-                    gtmin = s.grid_t_min, gtmax = s.grid_t_max;
                     fl = ps | ((uint32_t)(s.sx + 1) << 8) | ((uint32_t)(s.sy + 1) << 10) | ((uint32_t)(s.sz + 1) << 12) | (((uint32_t)s.entry_code & 15u) << 14) |
                          ((r.ignore_type_material & 3u) << 18);
                 }
@@ -637,7 +635,19 @@ __global__ __launch_bounds__(256, MIN_WAVES) void vrt_pool_kernel(const TracePar
                 s.inv_dir = inv;
                 s.entry_code = (int)((fl >> 14) & 15u);
                 s.sx = sx, s.sy = sy, s.sz = sz;
-                s.grid_t_min = gtmin, s.grid_t_max = gtmax;
+                {
+                    // GridHit's slab distances (comp:273-286) again, by grid_slab's own operations on the ray's origin and the 1 / dir it
+                    // carries: two words less in every ray record (round 5: room for six more records per wave)
+                    const f3 g_max = mk3(p.grid.max_point_scale[0], p.grid.max_point_scale[1], p.grid.max_point_scale[2]);
+                    const f3 t_lower = (g_min - ro) * inv, t_upper = (g_max - ro) * inv;
+                    const f3 t_mins = mk3(gl_min(t_lower.x, t_upper.x), gl_min(t_lower.y, t_upper.y), gl_min(t_lower.z, t_upper.z));
+                    const f3 t_maxes = mk3(gl_max(t_lower.x, t_upper.x), gl_max(t_lower.y, t_upper.y), gl_max(t_lower.z, t_upper.z));
+                    const bool iy = (t_mins.y > t_mins.x) && (t_mins.y > t_mins.z), iz = (t_mins.z > t_mins.x) && (t_mins.z > t_mins.y);
+                    const float tmin_i = iz ? t_mins.z : (iy ? t_mins.y : t_mins.x);
+                    s.grid_t_min = gl_max(0.00001f, tmin_i);
+                    s.grid_t_max = gl_min(t_max, gl_min(gl_min(t_maxes.x, t_maxes.y), t_maxes.z));
+                }
+                const float gtmin = s.grid_t_min;
                 const f3 brick_min = fma3(mk3((float)cx, (float)cy, (float)cz), splat3(g_scale), g_min); // comp:331
                 const float global_t_value = t_in * g_scale + gtmin + 0.01f * opaque_uniform(g_scale);   // comp:347 (deferred) + comp:332
                 Hit hit;
