@@ -81,13 +81,14 @@ def test_hip_denoise_with_shadows_nan_pattern():
 @pytest.mark.gpu
 @pytest.mark.parametrize("frame, out_size, kw", [
     ((320, 200), (320, 200), dict(samples=20)),                                   # the workgroup's box of texels fits LDS: the staged path
+    ((320, 200), (320, 200), dict(samples=20, inverse_hue_tolerance=7.0)),        # staged, a whole hue exponent other than the default's 20
     ((320, 200), (200, 130), dict(samples=60, pixel_multiplier=6.0)),             # a spiral of 23 texels: taps from global memory, one conditional wrap
     ((320, 200), (640, 400), dict(samples=7, inverse_hue_tolerance=12.5, distribution_bias=0.9)),   # up-scaling; a non-integer hue exponent
     ((24, 16), (96, 64), dict(samples=40, pixel_multiplier=9.0)),                 # the spiral reaches across the whole image: general wrap
     ((320, 200), (320, 200), dict(samples=300)),                                  # more samples than the per-sample table holds
 ])
 def test_hip_denoise_paths_match_oracle(frame, out_size, kw):
-    """vrt_denoise_kernel's three ways to a texel (round 4: a box staged in LDS / global with one conditional wrap / global with the
+    """The present pass's three ways to a texel (round 4: a box staged in LDS — vrt_denoise_tile_kernel, round 5 — / global with one conditional wrap / global with the
     general wrap) and its per-sample table, each against the oracle within the pass's tolerance."""
     w = W.Workload("t", frame[0], frame[1], 64, 4, 2, 2, False, 0.0)
     grid = W.build_grid(w)

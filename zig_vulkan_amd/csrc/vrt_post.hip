@@ -91,8 +91,8 @@ VRT_DI float length_fast(f3 a) { return __builtin_amdgcn_sqrtf(dot3(a, a)); }
 VRT_DI float pow_fast(float a, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(gl_max(a, 0.0f))); }
 
 // The taps of a workgroup's 16 x 16 output pixels fall into a small box of the traced image (25 x 25 texels at the reference's defaults,
-// 1 : 1): with TILED the workgroup converts that box to floats ONCE into LDS (32 x 32 texels, 16 KiB; coordinates wrapped there) and a
-// tap is four ds_read_b128 — no global loads, no unpacking, no wrapping per tap (round 4: 163 -> ~120 us per 1080p frame).  The launcher
+// 1 : 1): vrt_denoise_tile_kernel converts that box to floats ONCE into LDS (32 x 32 texels, 16 KiB; coordinates wrapped there) and a
+// tap is four LDS reads — no global loads, no unpacking, no wrapping per tap (round 4: 163 -> ~120 us per 1080p frame).  The launcher
 // takes it when every workgroup's box fits.
 constexpr int kDenoiseTile = 32;
 VRT_DI f3 sample_bilinear_tile(const float4 *tile, int x0, int y0, int W, int H, float u, float v) {
@@ -107,7 +107,7 @@ VRT_DI f3 sample_bilinear_tile(const float4 *tile, int x0, int y0, int W, int H,
 }
 
 // NEAR: every tap lies within one image width / height of the image (the launcher checks the spiral's radius): one conditional wrap
-template <bool NEAR, bool TILED = false>
+template <bool NEAR>
 __global__ __launch_bounds__(256) void vrt_denoise_kernel(const uchar4 *__restrict__ img, int W, int H, DenoiseParams pc, int out_w, int out_h,
                                                           uint32_t *__restrict__ out_u8, float4 *__restrict__ out_f32) {
     __shared__ float tab_x[kDenoiseTable], tab_y[kDenoiseTable], tab_w[kDenoiseTable];
@@ -131,29 +131,13 @@ __global__ __launch_bounds__(256) void vrt_denoise_kernel(const uchar4 *__restri
         float rx = 0.0f, ry = 1.0f;
         for (int k = 0; k < n && k < kDenoiseTable; k++) spiral(k, rx, ry, tab_x[k], tab_y[k], tab_w[k]);
     }
-    // the box of traced texels this workgroup's taps can touch: from the first pixel's tap furthest left / up to the last pixel's furthest
-    // right / down (s = u W - 0.5 grows with the pixel; `reach` texels of spiral; a texel of slack either side for the roundings)
-    __shared__ float4 tile[TILED ? kDenoiseTile * kDenoiseTile : 1];
-    [[maybe_unused]] int x0 = 0, y0 = 0;
-    if constexpr (TILED) {
-        const float reach = __builtin_fabsf(pc.pixel_multiplier) * sample_radius * 0.5f;
-        x0 = (int)__builtin_floorf(((float)(blockIdx.x * 16u) + 0.5f) / (float)out_w * (float)W - 0.5f - reach) - 1;
-        y0 = (int)__builtin_floorf(((float)(blockIdx.y * 16u) + 0.5f) / (float)out_h * (float)H - 0.5f - reach) - 1;
-        for (int i = (int)threadIdx.x; i < kDenoiseTile * kDenoiseTile; i += 256) {
-            const f3 c = texel_rgb(img, W, wrap_repeat(y0 + i / kDenoiseTile, H), wrap_repeat(x0 + i % kDenoiseTile, W));
-            tile[i] = make_float4(c.x, c.y, c.z, 0.0f);
-        }
-    }
     __syncthreads();
     // 16x16 output pixels per workgroup: neighbouring lanes fetch neighbouring texels
     const int ox = (int)(blockIdx.x * 16u + (threadIdx.x & 15u));
     const int oy = (int)(blockIdx.y * 16u + (threadIdx.x >> 4));
     if (ox >= out_w || oy >= out_h) return;
     const float u = ((float)ox + 0.5f) / (float)out_w, v = ((float)oy + 0.5f) / (float)out_h;
-    auto tap = [&](float tu, float tv) {
-        if constexpr (TILED) return sample_bilinear_tile(tile, x0, y0, W, H, tu, tv);
-        else return sample_bilinear_fast<NEAR>(img, W, H, tu, tv);
-    };
+    auto tap = [&](float tu, float tv) { return sample_bilinear_fast<NEAR>(img, W, H, tu, tv); };
     const f3 center = tap(u, v);
     const f3 center_norm = normalize3(center);
     const float center_sat = length3(center);
@@ -186,6 +170,115 @@ __global__ __launch_bounds__(256) void vrt_denoise_kernel(const uchar4 *__restri
     if (out_f32) out_f32[o] = make_float4(r, g, b, 1.0f);
 }
 
+// Round 5: the staged path of the reference's default hue exponent, written for the vector unit's issue rate — the pass is bound by it
+// (round 4: ~110 vector instructions per tap, 428 cycles per wave-tap measured = 4 x 107).  Per tap, inside the pass's 1e-4 tolerance:
+// the bilinear blend and the running sums as fused multiply-adds, two colour channels per instruction (v_pk_mul_f32 / v_pk_fma_f32 on
+// the register pair ds_read leaves x and y in); one reciprocal square root serves normalize() and length() (length = d * rsq(d));
+// dot(centre_n, normalize(c)) = dot(centre_n, c) * rsq; hue ^ 20 as five multiplications (hue >= -1e-7: its twentieth power is 0 with
+// or without the shader's max(., 0)); the per-sample constants straight from the table (the launcher guarantees it holds them all).
+// What a texel's coordinates are computed from and how — (u + offset) * W - 0.5, floor, fraction — is untouched: that decides WHICH
+// texels a tap blends.  NaN where the shader has NaN: a black tap's rsq(0) = inf poisons its hue, and through it the pixel.
+typedef float f2v __attribute__((ext_vector_type(2)));
+VRT_DI f2v splat2(float a) { return f2v{a, a}; }
+VRT_DI f2v fma2(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
+struct Rgb2 {
+    f2v xy;
+    float z;
+};
+VRT_DI Rgb2 tile_tap(const float4 *tile, int base, float Wf, float Hf, float u, float v) {
+    const float s = u * Wf - 0.5f, t = v * Hf - 0.5f;
+    const float fs = __builtin_floorf(s), ft = __builtin_floorf(t);
+    const float a = s - fs, b = t - ft, ia = 1.0f - a, ib = 1.0f - b;
+    // (the texel's place in the staged box, formed in floats — whole numbers below 2^24, exact — and converted once; inside the box by the
+    // launcher's bound)
+    const float4 *q = tile + ((int)__builtin_fmaf(ft, (float)kDenoiseTile, fs) + base);
+    const float4 p00 = q[0], p10 = q[1], p01 = q[kDenoiseTile], p11 = q[kDenoiseTile + 1];
+    const f2v top = fma2(f2v{p10.x, p10.y}, splat2(a), f2v{p00.x, p00.y} * splat2(ia));
+    const f2v bot = fma2(f2v{p11.x, p11.y}, splat2(a), f2v{p01.x, p01.y} * splat2(ia));
+    const float topz = __builtin_fmaf(p10.z, a, p00.z * ia), botz = __builtin_fmaf(p11.z, a, p01.z * ia);
+    return Rgb2{fma2(bot, splat2(b), top * splat2(ib)), __builtin_fmaf(botz, b, topz * ib)};
+}
+template <int HUE>
+__global__ __launch_bounds__(256) void vrt_denoise_tile_kernel(const uchar4 *__restrict__ img, int W, int H, DenoiseParams pc, int out_w, int out_h,
+                                                               uint32_t *__restrict__ out_u8, float4 *__restrict__ out_f32) {
+    // HUE 20: the reference's default exponent (GraphicsPipeline.zig:38); 0: pc.inverse_hue_tolerance, whatever it is
+    static_assert(HUE == 20 || HUE == 0, "");
+    __shared__ float4 tab[kDenoiseTable]; // per sample: texel offset x, y, the cubed distance weight
+    __shared__ float4 tile[kDenoiseTile * kDenoiseTile];
+    const float cosg = -0.7373688f, sing = 0.6754904f; // cos/sin(GOLDEN_ANGLE), image.frag:25,29
+    const float sample_radius = __builtin_sqrtf((float)pc.samples);
+    const float sample_true_radius = 0.5f / (sample_radius * sample_radius);
+    const float spx = 1.0f / (float)W, spy = 1.0f / (float)H;
+    const int n = pc.samples + 1; // x = 0 .. samples inclusive (image.frag:45)
+    if ((int)threadIdx.x < n) {
+        // sample k by thread k — the same operations in the same order as vrt_denoise_kernel's `spiral` (its rotation is a recurrence:
+        // thread k repeats the k + 1 turns, four operations each; the square root and the pow() are then done side by side instead of
+        // one sample after the other by one thread while its workgroup waits: that was 30 % of the pass)
+        const int k = (int)threadIdx.x;
+        float rx = 0.0f, ry = 1.0f;
+        for (int q = 0; q <= k; q++) {
+            const float nx = rx * cosg + ry * sing, ny = rx * (-sing) + ry * cosg;
+            rx = nx;
+            ry = ny;
+        }
+        const float sq = __builtin_sqrtf((float)k);
+        const float px = ((pc.pixel_multiplier * rx) * sq) * 0.5f, py = ((pc.pixel_multiplier * ry) * sq) * 0.5f;
+        float influence = 1.0f - sample_true_radius * ppow(__builtin_fmaf(py, py, px * px), pc.distribution_bias);
+        influence *= influence * influence;
+        tab[k] = make_float4(px * spx, py * spy, influence, 0.0f);
+    }
+    const float reach = __builtin_fabsf(pc.pixel_multiplier) * sample_radius * 0.5f;
+    const int x0 = (int)__builtin_floorf(((float)(blockIdx.x * 16u) + 0.5f) / (float)out_w * (float)W - 0.5f - reach) - 1;
+    const int y0 = (int)__builtin_floorf(((float)(blockIdx.y * 16u) + 0.5f) / (float)out_h * (float)H - 0.5f - reach) - 1;
+    // (the box starts less than its own size outside the image and the image is at least as large — the launcher's conditions —: a
+    // coordinate wraps by one conditional add / subtract, not by two integer remainders per texel)
+    for (int i = (int)threadIdx.x; i < kDenoiseTile * kDenoiseTile; i += 256) {
+        const f3 c = texel_rgb(img, W, wrap_near(y0 + i / kDenoiseTile, H), wrap_near(x0 + i % kDenoiseTile, W));
+        tile[i] = make_float4(c.x, c.y, c.z, 0.0f);
+    }
+    __syncthreads();
+    const int ox = (int)(blockIdx.x * 16u + (threadIdx.x & 15u));
+    const int oy = (int)(blockIdx.y * 16u + (threadIdx.x >> 4));
+    if (ox >= out_w || oy >= out_h) return;
+    const float u = ((float)ox + 0.5f) / (float)out_w, v = ((float)oy + 0.5f) / (float)out_h;
+    const float Wf = (float)W, Hf = (float)H;
+    const int base = -(y0 * kDenoiseTile + x0);
+    const f3 center = sample_bilinear_tile(tile, x0, y0, W, H, u, v);
+    const f3 cn = normalize3(center);
+    const float center_sat = __builtin_fabsf(length3(center));
+    const f2v cn_xy = f2v{cn.x, cn.y};
+    [[maybe_unused]] const int hue_whole = (pc.inverse_hue_tolerance >= 0.0f && pc.inverse_hue_tolerance <= 64.0f && pc.inverse_hue_tolerance == __builtin_floorf(pc.inverse_hue_tolerance))
+                                               ? (int)pc.inverse_hue_tolerance : -1;
+    f2v acc_xy = splat2(0.0f);
+    float acc_z = 0.0f, influence_sum = 0.0f;
+    for (int k = 0; k < n; k++) {
+        const float4 sk = tab[k];
+        const Rgb2 c = tile_tap(tile, base, Wf, Hf, u + sk.x, v + sk.y);
+        const f2v sq = c.xy * c.xy;
+        const float d = __builtin_fmaf(c.z, c.z, sq.x + sq.y);
+        const float rs = __builtin_amdgcn_rsqf(d);
+        const f2v cd = cn_xy * c.xy;
+        const float hue = __builtin_fmaf(0.5f, __builtin_fmaf(cn.z, c.z, cd.x + cd.y) * rs, 0.5f);
+        float hue_w;
+        if constexpr (HUE == 20) {
+            const float h2 = hue * hue, h4 = h2 * h2, h8 = h4 * h4;
+            hue_w = (h8 * h8) * h4;
+        } else {
+            hue_w = hue_whole >= 0 ? pow_whole(hue, hue_whole) : pow_fast(hue, pc.inverse_hue_tolerance);
+        }
+        const float sat = __builtin_fmaxf(1.0f - __builtin_fabsf(d * rs - center_sat), 0.0f); // (NaN only where hue is NaN already)
+        const float s2 = sat * sat, s4 = s2 * s2;
+        const float influence = (sk.z * hue_w) * (s4 * s4);
+        influence_sum += influence;
+        acc_xy = fma2(c.xy, splat2(influence), acc_xy);
+        acc_z = __builtin_fmaf(c.z, influence, acc_z);
+    }
+    const float r = acc_xy.x / influence_sum, g = acc_xy.y / influence_sum, b = acc_z / influence_sum;
+    const size_t o = (size_t)oy * out_w + ox;
+    out_u8[o] = unorm8p(r) | (unorm8p(g) << 8) | (unorm8p(b) << 16) | (255u << 24);
+    if (out_f32) out_f32[o] = make_float4(r, g, b, 1.0f);
+}
+
 hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias, float mult, float tol, int out_w, int out_h, void *out_u8,
                           void *out_f32, hipStream_t stream) {
     const dim3 grid((out_w + 15) / 16, (out_h + 15) / 16);
@@ -194,8 +287,11 @@ hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias
     const float reach = __builtin_fabsf(mult) * __builtin_sqrtf((float)samples) * 0.5f + 3.0f;
     // the box of a workgroup: 15 output pixels' worth of texels + the spiral both ways + the bilinear footprint and slack (kernel: x0 .. x0 + 31)
     const float span_x = 15.0f * (float)W / (float)out_w + 2.0f * (reach - 3.0f) + 5.0f, span_y = 15.0f * (float)H / (float)out_h + 2.0f * (reach - 3.0f) + 5.0f;
-    if (span_x <= (float)kDenoiseTile && span_y <= (float)kDenoiseTile && samples < kDenoiseTable)
-        hipLaunchKernelGGL((vrt_denoise_kernel<true, true>), grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
+    const bool staged = span_x <= (float)kDenoiseTile && span_y <= (float)kDenoiseTile && samples < kDenoiseTable && W >= 2 * kDenoiseTile && H >= 2 * kDenoiseTile;
+    if (staged && tol == 20.0f)
+        hipLaunchKernelGGL(vrt_denoise_tile_kernel<20>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
+    else if (staged)
+        hipLaunchKernelGGL(vrt_denoise_tile_kernel<0>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
     else if (reach < (float)(W < H ? W : H))
         hipLaunchKernelGGL(vrt_denoise_kernel<true>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
     else
