@@ -474,3 +474,57 @@ def test_a_batch_may_hold_frames_of_several_kernels(order):
         rt.deinit()
     assert np.array_equal(got, ref)
     assert {"vrt_trace_kernel"} < set(names) <= {"vrt_trace_kernel", "vrt_path_kernel", "vrt_pool_kernel"}, names
+
+
+@pytest.mark.parametrize("fixture,world,root_weight,frames_per_launch", [("cfg3_V2", 8, 30, 1), ("cfg3_V2", 4, 0, 8), ("cfg4_V1", 8, 18, 1)])
+def test_sharded_frames_of_the_baseline_configurations_at_full_size_are_the_oracles(fixture, world, root_weight, frames_per_launch):
+    """VERDICT r04 ("the sharded form of configs[3] / [4] has only ever run ... at <= 332 x 210"): BASELINE configs[3] (4K, 1024^3, 4 rays
+    per pixel) and configs[4] (4K, 2048^3 sparse, 16 spp path trace) THROUGH the multi-GPU pipeline at full size — 8 (4) ranks as threads
+    over tests/fake_rccl, each a context with its own replica of the scene, a weighted root share, one collective per frame (and eight
+    frames per collective) — and the frame rank 0 assembles is, byte for byte, the oracle's whole frame (the RGBA8 digest of
+    tests/golden/full/, made by tests/golden/make_full_golden.py).  configs[4]: both frames — traced by vrt_path_kernel<..., DIL 1> until
+    the ranks know the box of the occupied cells, by vrt_pool_kernel behind that."""
+    import hashlib
+    from tests.golden.make_golden import scene_digest
+    from tests.helpers import O
+    if not os.path.exists(FAKE):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full", fixture + ".npz"))
+    w = W.WORKLOADS[str(z["workload"])]
+    grid = W.build_grid(w)
+    assert scene_digest(grid) == str(z["scene_sha256"])
+    ranks = [W.make_renderer(w, grid, shard_rank=r, shard_count=world, shard_root_weight=root_weight) for r in range(world)]
+    uid = b"fake-rccl-full" + bytes([world, frames_per_launch]) + os.urandom(16) + bytes(128 - 32)
+    for r, rt in enumerate(ranks):
+        rt.dist_init(uid, r, world, frames_in_flight=2, rccl_path=FAKE, frames_per_launch=frames_per_launch)
+        W.set_view(rt, str(z["view"]))
+    assert O.push_constants(ranks[0].camera.blob(), ranks[0].sun.blob()).tobytes() == z["push_constants"].tobytes()
+    batches = 2 if w.max_bounce > 0 else 1
+    got, errors, names = [], [], {r: [] for r in range(world)}
+
+    def drive(r):
+        try:
+            rt = ranks[r]
+            for _ in range(batches):
+                for _ in range(frames_per_launch):
+                    rt.dist_frame()
+                names[r].append(rt.kernel_name())
+                rt.dist_wait()            # (a renderer's frames: by the next one the box of the occupied cells has reached the host)
+                if r == 0:
+                    got.append(hashlib.sha256(np.ascontiguousarray(rt.dist_read_frame()).tobytes()).hexdigest())
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    assert not errors, errors
+    for rt in ranks:
+        rt.deinit()
+    assert got == [str(z["rgba8_sha256"])] * batches, (got, str(z["rgba8_sha256"]))
+    if str(z["workload"]).startswith("cfg4"):
+        for r in range(world):
+            assert names[r] == ["vrt_path_kernel<8, 5, false, false, false, false, 1>", "vrt_pool_kernel<8, 6, 60, 2>"], names[r]
