@@ -679,8 +679,14 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
     // samples): -2 % alone and with two frames in flight.  The one-sample kernels at seven waves per SIMD take it in reverse raster only
     // (two frames in flight, frames of more tiles than the schedule takes): headline -0.7 / -1.8 / -0.8 %, 256^3 -0.3 / -4.4 / -6.2 %
     // with two frames in flight; under the cost schedule, one frame at a time, the headline's V2 lost 11 % (tools/experiments/fif_waves_ab.py).
+#ifdef VRT_DEV_PROFILE
+    // (the profile build's phase counters are kept per workgroup, eight words each, in a buffer sized for one workgroup per tile)
+    const bool profiled = p.wave_timeline != nullptr;
+#else
+    const bool profiled = false;
+#endif
     if (const KernelEntry *te = kernel_entry_of(fn); te && te->path == 0 && (te->shade <= 1 || p.tile_order == 3u) && !te->count && p.wave_groups_bounce && !p.wave_groups &&
-                                                       p.block_threads != 512u && !p.split_all && !p.packed_rgb) {
+                                                       p.block_threads != 512u && !p.split_all && !p.packed_rgb && !profiled) {
         TraceParams q = p;
         q.wave_groups = 1u;
         hipLaunchKernelGGL(fn, dim3((q.owned_tiles + (q.tile_order == 5u ? q.sched_units : 0u)) * 4u, frames), dim3(64), lds_bytes, stream, q);
