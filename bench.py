@@ -782,7 +782,7 @@ def main(argv=None) -> None:
                     help="HBM traffic / instruction counters of the roofline object: live = rocprofv3 passes over a child run now; "
                          "profile = the committed profiles/*_pmc.json; auto = live, falling back to profile")
     ap.add_argument("--pmc-frames", type=int, default=None, help="frames per view of a PMC child run; default: up to 24, about 0.6 s")
-    ap.add_argument("--pmc-timeout", type=float, default=240.0)
+    ap.add_argument("--pmc-timeout", type=float, default=90.0, help="seconds per rocprofv3 --pmc pass (a pass takes 5-10 s; one that does not return is killed and the traffic is read from profiles/ instead)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dist", choices=["native", "torch"], default="native",
                     help="N>1 frame gather: native = RCCL send/recv inside libvrt_hip.so (pipelined); torch = torch.distributed.gather (fallback)")
