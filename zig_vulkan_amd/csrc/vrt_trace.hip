@@ -1,6 +1,7 @@
 // vrt_trace.hip — derived-structure builders, tile schedule, root-side un-swizzle, and the launchers / kernel selection
 // called from vrt_api.hip.  The traversal kernels themselves live in vrt_trace_kernels.h and are instantiated by vrt_inst_*.hip.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <climits>
 #include "vrt_internal.h"
 #include "vrt_kernels.h"
@@ -571,7 +572,12 @@ KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t varian
     } else {
         // (the several-samples-per-pixel kernel, shade 1, needs 87 VGPRs left to itself = 5 waves per SIMD; held to 80 it spills
         // 36 bytes outside the loops and runs at 6: 4K / 1024^3 / 4 rays per pixel 1.215 -> 1.183 ms per frame)
-        e = find_trace_kernel(brick_dimension, counters, mode, (shade == 1 && !counters) ? 6 : kDefaultMinWaves, shade, block);
+        int mw1 = 6;
+#ifdef VRT_DEV_VARIANTS
+        if (const char *ev = std::getenv("VRT_DEV_SHADE1_WAVES")) mw1 = std::atoi(ev); // (tuning builds: 5 and 7 for 8^3 bricks)
+#endif
+        e = find_trace_kernel(brick_dimension, counters, mode, (shade == 1 && !counters) ? mw1 : kDefaultMinWaves, shade, block);
+        if (!e && shade == 1 && !counters) e = find_trace_kernel(brick_dimension, counters, mode, 6, shade, block);
     }
     return e ? e->fn : nullptr;
 }
