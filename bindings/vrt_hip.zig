@@ -203,6 +203,9 @@ pub const TUNE_NO_SMALL_FRAME_SPLIT: u32 = 1 << 14;
 pub const TUNE_NO_BOUNCE_WAVE_GROUPS: u32 = 1 << 15;
 pub const TUNE_NO_SAMPLE_UNITS: u32 = 1 << 16;
 pub const TUNE_NO_DEFERRED_MATERIAL: u32 = 1 << 17;
+pub const TUNE_NO_CELL_MATERIAL: u32 = 1 << 18;
+pub const TUNE_GRID_EXIT_ANY_BOX: u32 = 1 << 19;
+pub const TUNE_NO_BOUNCE_AUTOTUNE: u32 = 1 << 20;
 
 pub const GridConfig = extern struct { // Grid.zig:13-20
     brick_alloc: u64 = 0,

@@ -370,6 +370,53 @@ def test_bounce_frames_without_a_sample_buffer_keep_the_lockstep_kernel_in_the_p
         assert np.array_equal(frame, ref[v]), f"assembled frame of view {v} differs from the single-context frame"
 
 
+def test_reserve_samples_on_a_sharded_cache_resident_bounce_context_has_nothing_to_reserve():
+    """a cache-resident power-of-two scene with bounces (the reference app's run in shape) has ONE persistent kernel, the
+    auto-tune's candidate — which contexts of the pipeline never run, so their launch slots have no lanes.  vrt_reserve_samples used to
+    answer VRT_E_OOM there (tools/dist_emulate.py and bench.py's secondary leg call it whenever max_bounce > 0); the header promises
+    VRT_OK for 'nothing to reserve'.  The frames still come out as the single context's, on the lockstep kernel."""
+    if not os.path.exists(FAKE):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
+    w = W.Workload("t", 330, 210, 256, 4, 2, 2, True, 5.0, dims=(64, 32, 64))
+    grid = W.build_grid(w)
+    plain = W.make_renderer(w, grid)
+    W.set_view(plain, "V1")
+    plain.draw()
+    ref = plain.read_rgba8().copy()
+    plain.deinit()
+    world = 2
+    uid = b"fake-rccl-reserve" + os.urandom(16) + bytes(128 - 33)
+    ranks = [W.make_renderer(w, grid, shard_rank=r, shard_count=world) for r in range(world)]
+    for r, rt in enumerate(ranks):
+        rt.dist_init(uid, r, world, frames_in_flight=2, rccl_path=FAKE, frames_per_launch=1)
+        rt.reserve_samples(w.spp)          # (raised VRT_E_OOM before the fix)
+    errors, names = [], []
+
+    def drive(r):
+        try:
+            rt = ranks[r]
+            for _ in range(6):             # (more frames than the auto-tune's four trials: none may be one inside the pipeline)
+                W.set_view(rt, "V1")
+                rt.dist_frame()
+                names.append(rt.kernel_name())
+            rt.dist_wait()
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    assert not errors, errors
+    got = ranks[0].dist_read_frame().copy()
+    for rt in ranks:
+        rt.deinit()
+    assert all(n.startswith("vrt_trace_kernel<4, false,") for n in names), names
+    assert np.array_equal(got, ref)
+
+
 @pytest.mark.parametrize("world,frames_per_launch,bounce", [(2, 1, False), (4, 8, False), (8, 1, False), (2, 1, True)])
 def test_frames_submitted_by_one_call(world, frames_per_launch, bounce):
     """vrt_dist_frames (a C-side multi-frame submit for the pipeline): n cameras, one call across the ABI; the frames

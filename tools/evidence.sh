@@ -10,11 +10,12 @@
 set -u
 TAG=${1:-r05}; shift || true
 PARTS=${*:-"bench driver fly cfg4 soak"}
+FAILED=""
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/evidence_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-WLS="cfg0_256x256_64c_b4 cfg1_1080p_256c_b4 cfg2_1080p_512c_b8 cfg2_1080p_512c_b4 cfg3_4k_1024c_b8 cfg4_4k_2048c_b8_sparse refapp_1024x576_128x64x128_b4"
+WLS=${WLS:-"cfg0_256x256_64c_b4 cfg1_1080p_256c_b4 cfg2_1080p_512c_b8 cfg2_1080p_512c_b4 cfg3_4k_1024c_b8 cfg4_4k_2048c_b8_sparse refapp_1024x576_128x64x128_b4"}
 APP=refapp_1024x576_128x64x128_b4
 for part in $PARTS; do
   case $part in
@@ -25,7 +26,8 @@ for part in $PARTS; do
       echo "$W bench rc=$? $(head -c 200 $OUT/${TAG}_bench_$W.json)"
       mkdir -p $OUT/$W
       rocprofv3 --kernel-trace --stats -d $OUT/$W/stats -o stats -- python $ROOT/bench.py --workload $W --no-cpu-baseline --pmc off > $OUT/$W/bench.json 2> $OUT/$W/stats.log
-      python $ROOT/tools/summarize_prof.py $OUT/$W > $OUT/${TAG}_$W.txt 2>&1
+      python $ROOT/tools/summarize_prof.py $OUT/$W --bench-line $OUT/$W/bench.json --require-phases > $OUT/${TAG}_$W.txt 2>&1 \
+        || { echo "!! $W: summarize_prof.py could not split the launches by bench.py phase (see $OUT/${TAG}_$W.txt)"; cp $OUT/$W/bench.json $OUT/failed_bench_$W.json; cp $OUT/$W/launch_durations.json $OUT/failed_durations_$W.json 2>/dev/null; FAILED="$FAILED $W"; }
       rm -rf $OUT/$W   # the rocpd databases are large; the summary is what is kept
     done ;;
   driver)
@@ -46,3 +48,4 @@ for part in $PARTS; do
   esac
 done
 ls -la $OUT
+if [ -n "$FAILED" ]; then echo "!! summaries WITHOUT the per-phase split:$FAILED"; exit 3; fi

@@ -1,13 +1,27 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 (rocpd sqlite) output dirs — one kernel-trace/stats run plus PMC passes — into a
-small text summary to commit under profiles/.  usage: summarize_prof.py <dir>"""
+small text summary to commit under profiles/.
+usage: summarize_prof.py <dir> [pmc.json] [--bench-line FILE] [--require-phases]
+  the bench line of the profiled command is looked for in FILE, <dir>/bench.json, <dir>/stats.log (first found);
+  --require-phases: exit 2 when the launches of the traversal kernel cannot be split by bench.py phase
+  (no bench line, or a launch count the line does not explain) — a round's summaries must not lose that section silently."""
 import glob
 import os
 import sqlite3
 import sys
 from collections import defaultdict
 
+_args = sys.argv[1:]
+REQUIRE_PHASES = "--require-phases" in _args
+_args = [a for a in _args if a != "--require-phases"]
+BENCH_LINE_FILE = None
+if "--bench-line" in _args:
+    i = _args.index("--bench-line")
+    BENCH_LINE_FILE = _args[i + 1]
+    del _args[i:i + 2]
+sys.argv = [sys.argv[0]] + _args
 out = sys.argv[1]
+phases_done = False
 print(f"# rocprofv3 summary of {os.path.basename(out.rstrip('/'))}")
 for f in sorted(glob.glob(os.path.join(out, "stats", "**", "*.db"), recursive=True)):
     db = sqlite3.connect(f)
@@ -23,13 +37,17 @@ for f in sorted(glob.glob(os.path.join(out, "stats", "**", "*.db"), recursive=Tr
 # The launches of the traversal kernel by bench.py phase.  bench.py's launch sequence of the PRODUCT kernel is fixed:
 # 2 counting contexts x 5 views x 1 frame | 2 probe frames, warm-up, timed region | (single-stream leg) warm-up, timed
 # region | per view: settle, `reps` back to back (-> roofline.kernel_ms_per_view), min(reps, 512) with an event pair each.
-log = os.path.join(out, "stats.log")
-if os.path.exists(log):
-    import json as _json
-    line = None
+import json as _json
+line = None
+for log in [BENCH_LINE_FILE, os.path.join(out, "bench.json"), os.path.join(out, "stats.log")]:
+    if not log or not os.path.exists(log) or line is not None:
+        continue
     for ln in open(log, errors="replace"):
         if ln.startswith("{") and '"roofline"' in ln:
             line = _json.loads(ln)
+if line is None:
+    print("\n## NO bench line found (looked in --bench-line, bench.json, stats.log): launches NOT split by bench.py phase")
+if line is not None:
     for f in sorted(glob.glob(os.path.join(out, "stats", "**", "*.db"), recursive=True)):
         if not line or not line.get("roofline"):
             break
@@ -51,8 +69,12 @@ if os.path.exists(log):
         want = head + len(views) * (settle + reps + timed) + tail
         print(f"\n## {len(d)} launches of the traversal kernel by bench.py phase (us)")
         if len(d) != want:
-            print(f"   (expected {want} launches from the bench line; phase breakdown skipped)")
+            print(f"   (expected {want} launches from the bench line = {2 * len(views)} + 2 + {pre} + {warmup + steps} + {sus_n} + {warmup + steps} + "
+                  f"{len(views)} x ({settle} + {reps} + {timed}) + {tail}; phase breakdown skipped; durations -> launch_durations.json)")
+            with open(os.path.join(out, "launch_durations.json"), "w") as fh:
+                _json.dump({"want": want, "got": len(d), "durations_us": [round(x, 1) for x in d]}, fh)
             continue
+        phases_done = True
         a = 2 * len(views) + 2 + pre
         main = d[a + warmup:a + warmup + steps]
         single = d[a + warmup + steps + sus_n + warmup:a + sus_n + 2 * (warmup + steps)]
@@ -75,6 +97,9 @@ if os.path.exists(log):
                 tot += b2b
         print(f"   roofline leg, views {'/'.join(line['config']['views'])}: avg {sum(tot) / len(tot):.2f}  "
               f"(bench line roofline.kernel_ms_avg by HIP events incl. the schedule kernels between the launches: {line['roofline']['kernel_ms_avg'] * 1e3:.2f})")
+if REQUIRE_PHASES and not phases_done:
+    print("\n## ERROR: --require-phases and no phase split was printed", flush=True)
+    sys.exit(2)
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     if not os.path.isdir(d):
         continue

@@ -228,6 +228,7 @@ struct vrt_ctx {
     // the faster (pool only if it wins by 15 %); a status upload starts the trials again.  Frames are the same bytes either way.
     vrt::KernelFn bounce_auto = nullptr;
     uint32_t auto_next = 0;                // trial frames launched so far (0 .. 4)
+    int32_t auto_spp = 0, auto_bounce = 0; // what trial 0 traced: the other three must trace the same, or the trials start again
     bool auto_decided = false, auto_use_pool = false;
     hipEvent_t auto_ev[4][2] = {};
     float auto_ms[2] = {0.0f, 0.0f};       // what the trials measured: lockstep, pool (vrt_bounce_autotune_ms)

@@ -355,11 +355,15 @@ int dist_order_primary_after_slots(vrt_ctx *ctx) {
     return VRT_OK;
 }
 
+// (a slot has a lane only in contexts whose bounce frames the pipeline gives to a persistent kernel — vrt_dist_init_batched; a slot
+// without one has nothing to reserve: ADVICE r05, a cache-resident scene whose only persistent kernel is the auto-tune's candidate,
+// which the pipeline never runs)
 bool dist_reserve_samples(vrt_ctx *ctx, uint64_t units) {
     bool ok = true;
     for (uint32_t i = 0; i < ctx->dist->nslots; i++) {
         DistSlot &sl = ctx->dist->slots[i];
-        ok = sl.lane.work_counter && lane_samples_ready(ctx, sl.lane, units, sl.stream) && ok;
+        if (!sl.lane.work_counter) continue;
+        ok = lane_samples_ready(ctx, sl.lane, units, sl.stream) && ok;
     }
     return ok;
 }

@@ -227,8 +227,21 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
                 ctx->auto_ms[0] = std::min(ms[0], ms[2]), ctx->auto_ms[1] = std::min(ms[1], ms[3]);
                 ctx->auto_use_pool = done && ctx->auto_ms[1] < 0.85f * ctx->auto_ms[0];
                 ctx->auto_decided = true;
+                if (!ctx->auto_use_pool && !vrt::is_path_kernel(ctx->kernel)) {
+                    // the lockstep kernel stays: the sample buffers the pool trials made serve no frame of this context
+                    for (int l = 0; l < 2; l++) {
+                        if (!ctx->lane[l].samples) continue;
+                        ctx->res.drop(ctx->lane[l].samples); // (the trials' events have completed: nothing in flight reads it)
+                        ctx->lane[l].samples = nullptr;
+                        ctx->lane[l].sample_elems = 0;
+                    }
+                }
             }
         } else if (frames == 1 && !marks && camera && camera->max_bounce > 1 && ctx->box_is_grid && !ctx->status_dirty && !ctx->params.wave_timeline) {
+            // (the four trials must trace the same work: a host that changes the samples per pixel or the bounce count between them
+            // starts the trials again with the new pair — ADVICE r05)
+            if (ctx->auto_next != 0u && (camera->samples_per_pixel != ctx->auto_spp || camera->max_bounce != ctx->auto_bounce)) ctx->auto_next = 0u;
+            if (ctx->auto_next == 0u) ctx->auto_spp = camera->samples_per_pixel, ctx->auto_bounce = camera->max_bounce;
             trial = (int)ctx->auto_next;
             primary_only = true; // (a trial runs alone on the primary stream: its time is the kernel's, not the overlap's)
         }
@@ -448,7 +461,7 @@ int vrt_region_begin(vrt_ctx *ctx) {
     if (!ctx) return VRT_E_INVALID_ARG;
     DeviceGuard dg(ctx->device);
     for (hipEvent_t &e : ctx->ev_region)
-        if (!e) VRT_HIP(ctx, hipEventCreate(&e));
+        if (!e) VRT_HIP(ctx, ctx->res.event(&e)); // (owned by the context's container: released with it)
     VRT_HIP(ctx, hipEventRecord(ctx->ev_region[0], ctx->stream));
     if (ctx->stream_b) VRT_HIP(ctx, hipEventRecord(ctx->ev_region[2], ctx->stream_b));
     return VRT_OK;
@@ -492,6 +505,9 @@ int vrt_trace_wave_timeline(vrt_ctx *ctx, const vrt_camera_device *camera, const
         // the persistent-lane kernel has no wave -> tile map to report: refuse instead of returning zeros
         const vrt::KernelFn would = (camera && camera->max_bounce > 1) ? (ctx->d_counters ? ctx->product[0] : ctx->kernel) : nullptr;
         if (would && vrt::is_path_kernel(would)) return fail(ctx, VRT_E_STATE, "vrt_trace_wave_timeline: frames with bounces run vrt_path_kernel on this context (no per-tile waves)");
+        // (... and so does a context whose auto-tune chose vrt_pool_kernel, or whose next frame would be a pool trial)
+        if (camera && camera->max_bounce > 1 && ctx->bounce_auto && !ctx->dist && ((ctx->auto_decided && ctx->auto_use_pool) || (!ctx->auto_decided && (ctx->auto_next & 1u))))
+            return fail(ctx, VRT_E_STATE, "vrt_trace_wave_timeline: this context's bounce frames run (or are about to try) vrt_pool_kernel (no per-tile waves); VRT_TUNE_NO_BOUNCE_AUTOTUNE keeps the lockstep kernel");
     }
 #endif
     unsigned long long *d = nullptr;
