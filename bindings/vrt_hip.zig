@@ -138,7 +138,7 @@ pub const SunDevice = extern struct { // Sun.Device, Sun.zig:13-18 (32 bytes)
 
 pub const Config = extern struct {
     struct_size: u32 = @sizeOf(Config),
-    abi_version: u32 = 3, // VRT_ABI_VERSION
+    abi_version: u32 = 4, // VRT_ABI_VERSION
     width: u32,
     height: u32,
     brick_dimension: u32 = 4, // State.brick_dimension
@@ -163,6 +163,14 @@ pub const Config = extern struct {
     /// TUNE_* bits, 0 = the library's defaults; every setting renders the same frame (A/B measurements, equivalence tests)
     tuning_flags: u32 = 0,
     _reserved: [4]u32 = [_]u32{0} ** 4,
+};
+
+pub const DistOptions = extern struct { // vrt_dist_options (vrt_dist_init_ex)
+    struct_size: u32 = @sizeOf(DistOptions),
+    frames_in_flight: u32 = 0, // launch slots, 1..16 (0: 4)
+    frames_per_launch: u32 = 0, // 1..8 (0: 1)
+    communicators: u32 = 0, // 0: one per launch slot, at most 8; 1: every slot on the first
+    reserved: [4]u32 = .{ 0, 0, 0, 0 },
 };
 
 pub const ShardInfo = extern struct {
@@ -261,6 +269,10 @@ pub extern fn vrt_assemble_frame(ctx: ?*Ctx, gathered: ?*const anyopaque, dst_fr
 pub extern fn vrt_dist_unique_id(rccl_path: ?[*:0]const u8, out_id128: ?*anyopaque) c_int;
 pub extern fn vrt_dist_init(ctx: ?*Ctx, rccl_path: ?[*:0]const u8, id128: ?*const anyopaque, rank: c_int, world: c_int, frames_in_flight: u32) c_int;
 pub extern fn vrt_dist_init_batched(ctx: ?*Ctx, rccl_path: ?[*:0]const u8, id128: ?*const anyopaque, rank: c_int, world: c_int, frames_in_flight: u32, frames_per_launch: u32) c_int;
+pub extern fn vrt_dist_init_ex(ctx: ?*Ctx, rccl_path: ?[*:0]const u8, id128: ?*const anyopaque, rank: c_int, world: c_int, options: [*c]const DistOptions) c_int;
+pub extern fn vrt_dist_keep_communicators(keep: c_int) c_int;
+pub extern fn vrt_dist_release_communicators() c_int;
+pub extern fn vrt_dist_comm_info(ctx: ?*Ctx, out: *[4]i32) c_int;
 pub extern fn vrt_dist_frame(ctx: ?*Ctx, camera: [*c]const CameraDevice, sun: [*c]const SunDevice) c_int;
 pub extern fn vrt_dist_frames(ctx: ?*Ctx, cameras: [*c]const CameraDevice, suns: [*c]const SunDevice, n: u32, sun_stride: u32) c_int;
 pub extern fn vrt_dist_wait(ctx: ?*Ctx) c_int;
@@ -270,6 +282,7 @@ pub extern fn vrt_dist_info(ctx: ?*Ctx, out: *[4]i32) c_int;
 pub extern fn vrt_dist_profile(ctx: ?*Ctx, enable: u32) c_int;
 pub extern fn vrt_dist_stats(ctx: ?*Ctx, out: *[8]f64) c_int;
 pub extern fn vrt_dist_selftest(ctx: ?*Ctx) c_int;
+pub extern fn vrt_dist_selftest_slots(ctx: ?*Ctx, busy_us: u32, rounds: u32, out: *[4]f64) c_int;
 pub extern fn vrt_last_kernel_ms(ctx: ?*Ctx) f64;
 pub extern fn vrt_region_begin(ctx: ?*Ctx) c_int;
 pub extern fn vrt_region_end(ctx: ?*Ctx, ms: [*c]f64) c_int;

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define VRT_ABI_VERSION 3u /* 3 (round 5): + vrt_dist_frames, vrt_reserve_samples, vrt_bounce_autotune_info; vrt_trace_wave_timeline's capacity rule.  2 (round 4): + vrt_region_begin / _end,
+#define VRT_ABI_VERSION 4u /* 4 (round 6): + vrt_dist_init_ex (a communicator per launch slot), vrt_dist_keep_communicators / _release_communicators, vrt_dist_comm_info, vrt_dist_selftest_slots.  3 (round 5): + vrt_dist_frames, vrt_reserve_samples, vrt_bounce_autotune_info; vrt_trace_wave_timeline's capacity rule.  2 (round 4): + vrt_region_begin / _end,
                              vrt_last_denoise_ms, tuning flags 13-17; the product build refuses development kernel_variants */
 
 /* ---- status codes (replace Zig error unions, e.g. StagingRamp.zig:320-325) */
@@ -281,6 +281,35 @@ int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int ra
  * frames_in_flight counts launches. */
 int vrt_dist_init_batched(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight,
                           uint32_t frames_per_launch);
+/* The general form (round 6).  COMMUNICATORS: RCCL executes the operations of one communicator in the order they were issued, whichever
+ * streams they were issued on, so launch slots that share a communicator have their gathers run one behind the other.  Every launch slot
+ * therefore issues its gather on a communicator of its own — duplicates of the first (ncclCommInitRank from the id) made by
+ * ncclCommSplit; `communicators` = how many (0: one per launch slot, at most 8; 1: the round-5 behaviour, every slot on the first; slot i
+ * uses communicator i % communicators; fewer than asked for where the library has no ncclCommSplit or a split fails — the ranks agree on
+ * the number by one all-reduce, vrt_dist_comm_info reports it).  All ranks issue their launches in the same order and a gather waits only
+ * for operations issued before it, so communicators side by side cannot deadlock.  vrt_dist_init and vrt_dist_init_batched are this call
+ * with communicators = 0. */
+typedef struct vrt_dist_options {
+    uint32_t struct_size;       /* sizeof(vrt_dist_options) */
+    uint32_t frames_in_flight;  /* launch slots, 1..16 (0: 4) */
+    uint32_t frames_per_launch; /* 1..8 (0: 1) */
+    uint32_t communicators;     /* 0..16, see above */
+    uint32_t reserved[4];       /* zero */
+} vrt_dist_options;
+int vrt_dist_init_ex(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, const vrt_dist_options *options);
+/* Communicators are expensive to make (a collective; of the order of a second for eight GPUs) and a host may make contexts often (one
+ * per candidate setting, per workload).  The library keeps them in a per-process pool keyed by (id, rank, world, library): a context
+ * takes the free communicators of its id's set, makes the missing ones, and gives them back at vrt_destroy.  By default a set whose
+ * last context is destroyed is destroyed with it (as before round 6).  vrt_dist_keep_communicators(1): idle sets stay, and a later
+ * vrt_dist_init* with the SAME id (every rank must pass the same id again, and make the same calls in the same order) reuses them
+ * without a collective; returns the previous setting.  vrt_dist_release_communicators destroys every set no context holds and returns
+ * the number of communicators destroyed (call it on every rank at the same point, before the process ends).  A set on which a
+ * collective failed is neither reused nor destroyed. */
+int vrt_dist_keep_communicators(int keep);
+int vrt_dist_release_communicators(void);
+/* out = {communicators this context's launch slots use, how many of them this vrt_dist_init* had to make (the rest came from the pool),
+ * 1 if the library has ncclCommSplit, 1 if the ranks agreed on the number by an all-reduce} */
+int vrt_dist_comm_info(vrt_ctx *ctx, int32_t out[4]);
 int vrt_dist_frame(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_sun_device *sun);
 /* n consecutive vrt_dist_frame calls in one: frame i takes cameras[i] and suns[i * sun_stride] (sun_stride 0: every frame the same
  * sun).  A host that knows its next frames — a scripted fly-through (Benchmark.zig:141-172), a benchmark — submits them without a
@@ -311,6 +340,13 @@ int vrt_dist_profile(vrt_ctx *ctx, uint32_t enable);
 int vrt_dist_stats(vrt_ctx *ctx, double out[8]);
 /* ncclSend + ncclRecv of one shard to this rank itself: checks the RCCL binding on a single GPU */
 int vrt_dist_selftest(vrt_ctx *ctx);
+/* Every launch slot at once against the bound library, on one GPU: `rounds` times, per slot, a kernel that keeps one wave busy for
+ * busy_us microseconds on the slot's stream (the frame's trace kernel) followed by the grouped self send + recv of one shard on the
+ * slot's communicator and stream (the gather).  Fails if an operation fails, a stream faults or bytes differ; a deadlock shows as a call
+ * that does not return (run it under a time limit).  out = {wall ms of the timed rounds (one untimed round precedes them), launches in
+ * them, mean ms from a slot's kernel start to its gather's end in the last round, communicators used}: with every slot on one
+ * communicator the gathers run in issue order, one behind the other; with one per slot they overlap. */
+int vrt_dist_selftest_slots(vrt_ctx *ctx, uint32_t busy_us, uint32_t rounds, double out[4]);
 
 /* ---- measurement ---------------------------------------------------------- */
 /* hipEvent time of the most recent vrt_dispatch / average per frame of the

@@ -28,10 +28,10 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_abi_version():
-    assert L.lib.vrt_abi_version() == L.VRT_ABI_VERSION == 3
+    assert L.lib.vrt_abi_version() == L.VRT_ABI_VERSION == 4
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    assert "#define VRT_ABI_VERSION 3u" in open(os.path.join(root, "include", "vrt_hip.h")).read()
-    assert "abi_version: u32 = 3," in open(os.path.join(root, "bindings", "vrt_hip.zig")).read()   # the Zig host's default
+    assert "#define VRT_ABI_VERSION 4u" in open(os.path.join(root, "include", "vrt_hip.h")).read()
+    assert "abi_version: u32 = 4," in open(os.path.join(root, "bindings", "vrt_hip.zig")).read()   # the Zig host's default
 
 
 def test_struct_layouts_match_reference():

@@ -78,6 +78,149 @@ def test_native_pipeline_with_many_ranks_on_one_gpu(world, frames_in_flight, fra
         assert np.array_equal(frame, ref[v]), f"assembled frame of view {v} differs from the single-context frame"
 
 
+def _fake():
+    import ctypes as C
+    f = C.CDLL(FAKE)
+    f.fake_rccl_set_model.argtypes = [C.c_int, C.c_int]
+    f.fake_rccl_live_communicators.restype = C.c_int
+    return f
+
+
+@pytest.mark.parametrize("world,frames_in_flight,frames_per_launch,communicators,model",
+                         [(8, 8, 1, 0, (1, 2)), (8, 8, 1, 1, (1, 2)), (4, 16, 1, 0, (1, 4)), (4, 6, 2, 3, (1, 1)), (2, 4, 8, 0, (0, 2)), (8, 16, 1, 16, (1, 2)),
+                          (3, 5, 1, 2, (1, 0))])
+def test_a_communicator_per_launch_slot_and_the_stand_ins_cost_model(world, frames_in_flight, frames_per_launch, communicators, model):
+    """Round 6 (VERDICT r05 #2a/b): launch slot i issues its gather on communicator i % n (ncclCommSplit duplicates of the first), n = one
+    per slot up to 8 unless the host says otherwise; and the stand-in now models RCCL's two costs — a communicator's groups execute in
+    issue order, a group is one kernel of k workgroups per operation.  Frames must be the single context's under every combination
+    (the model changes timing, never bytes), and the communicators must all be destroyed with their contexts."""
+    if not os.path.exists(FAKE):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
+    fake = _fake()
+    live_before = fake.fake_rccl_live_communicators()
+    fake.fake_rccl_set_model(*model)
+    try:
+        w = W.Workload("t", 332, 210, 64, 4, 1, 0, True, 0.0)
+        grid = W.build_grid(w)
+        views = ["V0", "V1", "V2", "V1", "V2", "V0", "V0", "V2", "V1", "V1", "V0", "V2", "V0", "V1", "V2", "V0", "V1", "V1", "V2", "V0"]
+        views = views[:max(frames_per_launch, (len(views) // frames_per_launch) * frames_per_launch)]
+        plain = W.make_renderer(w, grid)
+        ref = {}
+        for v in set(views):
+            W.set_view(plain, v)
+            plain.draw()
+            ref[v] = plain.read_rgba8().copy()
+        plain.deinit()
+        uid = b"fake-rccl-comms" + bytes([world, frames_in_flight, communicators]) + os.urandom(16) + bytes(128 - 34)
+        ranks = [W.make_renderer(w, grid, shard_rank=r, shard_count=world) for r in range(world)]
+        for r, rt in enumerate(ranks):
+            rt.dist_init(uid, r, world, frames_in_flight=frames_in_flight, rccl_path=FAKE, frames_per_launch=frames_per_launch, communicators=communicators)
+            info = rt.dist_comm_info()
+            want = min(communicators, frames_in_flight) if communicators else min(frames_in_flight, 8)
+            assert info == {"communicators": want, "made_by_this_init": want, "library_splits": True, "agreed_by_all_reduce": False}, info
+        assert fake.fake_rccl_live_communicators() == live_before + world * want
+        got, errors = [], []
+
+        def drive(r):
+            try:
+                rt = ranks[r]
+                for i, v in enumerate(views):
+                    W.set_view(rt, v)
+                    rt.dist_frame()
+                    if r == 0 and (i + 1) % frames_per_launch == 0 and i % 4 == 3:
+                        got.append((v, rt.dist_read_frame().copy()))
+                rt.dist_wait()
+                if r == 0:
+                    got.append((views[-1], rt.dist_read_frame().copy()))
+            except Exception as e:  # noqa: BLE001
+                errors.append((r, repr(e)))
+
+        threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in threads), "a rank hung"
+        assert not errors, errors
+        for rt in ranks:
+            rt.deinit()
+        for v, frame in got:
+            assert np.array_equal(frame, ref[v]), f"assembled frame of view {v} differs from the single-context frame"
+        assert fake.fake_rccl_live_communicators() == live_before
+    finally:
+        fake.fake_rccl_set_model(0, 0)
+
+
+def test_communicators_kept_in_the_pool_are_reused_by_the_next_context_with_the_same_id():
+    """vrt_dist_keep_communicators(1): a context's communicators outlive it; the next context initialised with the SAME id takes them
+    from the pool (made_by_this_init == 0: no collective), two live contexts of one id get disjoint ones, and
+    vrt_dist_release_communicators destroys what nobody holds.  (bench.py makes a dozen contexts per run — one per root-share candidate
+    and leg — on one id.)"""
+    if not os.path.exists(FAKE):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built (run __graft_entry__.build())")
+    from zig_vulkan_amd import VoxelRT
+    fake = _fake()
+    live_before = fake.fake_rccl_live_communicators()
+    w = W.Workload("t", 330, 210, 64, 4, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    plain = W.make_renderer(w, grid)
+    W.set_view(plain, "V2")
+    plain.draw()
+    ref = plain.read_rgba8().copy()
+    plain.deinit()
+    world = 3
+    uid = b"fake-rccl-pool-keep" + os.urandom(16) + bytes(128 - 35)
+    was = VoxelRT.dist_keep_communicators(True)
+    try:
+        def run(slots, expect_made, hold=None):
+            ranks = [W.make_renderer(w, grid, shard_rank=r, shard_count=world) for r in range(world)]
+            for r, rt in enumerate(ranks):
+                rt.dist_init(uid, r, world, frames_in_flight=slots, rccl_path=FAKE)
+                info = rt.dist_comm_info()
+                assert info["communicators"] == slots and info["made_by_this_init"] == expect_made, info
+            errors = []
+
+            def drive(r):
+                try:
+                    W.set_view(ranks[r], "V2")
+                    for _ in range(2 * slots + 1):
+                        ranks[r].dist_frame()
+                    ranks[r].dist_wait()
+                except Exception as e:  # noqa: BLE001
+                    errors.append((r, repr(e)))
+
+            threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join(timeout=120)
+            assert not any(t.is_alive() for t in threads) and not errors, errors
+            assert np.array_equal(ranks[0].dist_read_frame(), ref)
+            if hold is not None:
+                hold.extend(ranks)
+            else:
+                for rt in ranks:
+                    rt.deinit()
+
+        run(4, 4)                      # makes 4 per rank
+        assert fake.fake_rccl_live_communicators() == live_before + 4 * world      # ... which stay
+        run(3, 0)                      # takes 3 of them: nothing made
+        held = []
+        run(4, 0, hold=held)           # holds all 4 ...
+        run(2, 2)                      # ... so a second live context of the same id makes 2 more (indices 4, 5 on every rank)
+        for rt in held:
+            rt.deinit()
+        run(6, 0)                      # all six from the pool
+        assert fake.fake_rccl_live_communicators() == live_before + 6 * world
+        assert VoxelRT.dist_release_communicators() == 6 * world
+        assert fake.fake_rccl_live_communicators() == live_before
+        run(2, 2)                      # (after a release the same id starts over)
+    finally:
+        VoxelRT.dist_keep_communicators(was)
+        VoxelRT.dist_release_communicators()
+    assert fake.fake_rccl_live_communicators() == live_before
+
+
 @pytest.mark.parametrize("size,world,root_weight,frames_per_launch", [((40, 24), 8, 60, 8), ((16, 16), 4, 50, 2), ((130, 70), 8, 0, 8), ((1, 1), 2, 90, 1)])
 def test_more_ranks_than_tiles_and_tiny_frames(size, world, root_weight, frames_per_launch):
     """Frames with fewer tiles than ranks (some ranks, possibly the root, own nothing), with and without the weighted pattern."""

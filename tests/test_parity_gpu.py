@@ -708,6 +708,41 @@ def test_start_index_shortcut_only_when_the_pattern_holds(variant, bounces):
         assert np.array_equal(frames[name][0].view(np.uint32), fo.view(np.uint32)) and np.array_equal(frames[name][1], uo), name
 
 
+@pytest.mark.parametrize("slots,communicators", [(8, 1), (8, 0), (16, 0), (16, 16)])
+def test_every_launch_slot_at_once_on_real_rccl(slots, communicators):
+    """VERDICT r05 #2a, on the real library (world 1, PyTorch's librccl): every launch slot issues a kernel and its gather — a grouped
+    self send + recv of one shard — on its own stream, 20 rounds, with the slots on ONE communicator (round 5's pipeline) and with a
+    communicator per slot (ncclCommSplit duplicates; the ranks' agreement on their number by ncclAllReduce is exercised too).  Must
+    complete (a deadlock is the test's time limit), deliver the bytes, and report the communicators it used.  The overlap it measures is
+    printed for profiles/r06_rccl_slots_world1.txt (tools/experiments/rccl_slots_probe.py runs the same call at more settings)."""
+    from zig_vulkan_amd import VoxelRT
+    w = W.Workload("t", 1920, 1080, 64, 4, 1, 0, True, 0.0)
+    grid = W.build_grid(w)
+    rt = W.make_renderer(w, grid, shard_rank=0, shard_count=1)
+    rt.dist_init(VoxelRT.dist_unique_id(), 0, 1, frames_in_flight=slots, communicators=communicators)
+    info = rt.dist_comm_info()
+    want = communicators if communicators else min(slots, 8)
+    assert info["library_splits"], "PyTorch's RCCL (2.27) has ncclCommSplit"
+    assert info["communicators"] == want and info["made_by_this_init"] == want, info
+    assert info["agreed_by_all_reduce"] == (want > 1)
+    rt.dist_selftest()
+    st = rt.dist_selftest_slots(busy_us=50, rounds=20)
+    assert st["launches"] == 20 * slots and st["communicators"] == want and st["wall_ms"] > 0
+    print(f"real RCCL, world 1, {slots} slots on {want} communicator(s): {st['us_per_launch']:.1f} us per launch (50 us kernel + self send/recv of "
+          f"{rt.dist_stats()['shard_bytes_per_frame']} B), last round {1e3 * st['last_round_launch_ms']:.1f} us from kernel start to gather end")
+    # ... and the frame loop still reproduces the plain frame on the slots' own communicators (world 1: no peers, but the streams are these)
+    W.set_view(rt, "V1")
+    for _ in range(2 * slots + 1):
+        rt.dist_frame()
+    got = rt.dist_read_frame().copy()
+    rt.deinit()
+    plain = W.make_renderer(w, grid)
+    W.set_view(plain, "V1")
+    plain.draw()
+    assert np.array_equal(got, plain.read_rgba8())
+    plain.deinit()
+
+
 def test_bench_probe_child_runs_the_native_pipeline_on_real_rccl():
     """bench.py --dist-probe, the child process by which the N > 1 bench tries the native RCCL pipeline before it trusts it: here
     with one rank (RCCL refuses two ranks on one device) — communicators from three unique ids: one and eight frames per collective,

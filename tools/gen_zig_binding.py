@@ -19,7 +19,7 @@ END = "// END GENERATED"
 STRUCTS = {"vrt_ctx": "Ctx", "vrt_grid": "Grid", "vrt_vox": "Vox", "vrt_benchmark": "Benchmark", "vrt_config": "Config",
            "vrt_grid_state": "GridState", "vrt_material": "Material", "vrt_camera_device": "CameraDevice", "vrt_sun_device": "SunDevice",
            "vrt_shard_info": "ShardInfo", "vrt_counters": "Counters", "vrt_grid_config": "GridConfig", "vrt_camera_config": "CameraConfig",
-           "vrt_sun_config": "SunConfig", "vrt_denoise_config": "DenoiseConfig", "vrt_vox_xyzi": "VoxXyzi", "vrt_vox_rgba": "VoxRgba"}
+           "vrt_sun_config": "SunConfig", "vrt_denoise_config": "DenoiseConfig", "vrt_vox_xyzi": "VoxXyzi", "vrt_vox_rgba": "VoxRgba", "vrt_dist_options": "DistOptions"}
 OPAQUE = {"Ctx", "Grid", "Vox", "Benchmark"}
 SCALARS = {"int": "c_int", "uint32_t": "u32", "uint64_t": "u64", "int32_t": "i32", "int64_t": "i64", "uint8_t": "u8", "float": "f32",
            "double": "f64", "void": "void", "vrt_buffer_id": "BufferId"}

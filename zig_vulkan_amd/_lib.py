@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (VRT_HIP_LIB: development builds of the same library, e.g. the phase-profile build of tools/experiments/frame_phases.py)
 LIB_PATH = os.environ.get("VRT_HIP_LIB") or os.path.join(_HERE, "libvrt_hip.so")
 
-VRT_ABI_VERSION = 3
+VRT_ABI_VERSION = 4
 
 VRT_OK = 0
 VRT_E_INVALID_ARG = -1
@@ -110,6 +110,11 @@ class Config(C.Structure):  # vrt_config
     ]
 
 
+class DistOptions(C.Structure):  # vrt_dist_options
+    _fields_ = [("struct_size", C.c_uint32), ("frames_in_flight", C.c_uint32), ("frames_per_launch", C.c_uint32), ("communicators", C.c_uint32),
+                ("reserved", C.c_uint32 * 4)]
+
+
 class ShardInfo(C.Structure):
     _fields_ = [("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
                 ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("owned_tiles", C.c_uint32),
@@ -185,6 +190,11 @@ SIGNATURES = {
     "vrt_dist_wait": (C.c_int, [_ctx]),
     "vrt_dist_read_frame": (C.c_int, [_ctx, C.c_void_p, C.c_uint64]),
     "vrt_dist_selftest": (C.c_int, [_ctx]),
+    "vrt_dist_selftest_slots": (C.c_int, [_ctx, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+    "vrt_dist_init_ex": (C.c_int, [_ctx, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(DistOptions)]),
+    "vrt_dist_keep_communicators": (C.c_int, [C.c_int]),
+    "vrt_dist_release_communicators": (C.c_int, []),
+    "vrt_dist_comm_info": (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
     "vrt_dist_profile": (C.c_int, [_ctx, C.c_uint32]),
     "vrt_dist_stats": (C.c_int, [_ctx, _P(C.c_double)]),
     "vrt_dist_broadcast": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_uint64, C.c_int]),

@@ -7,8 +7,11 @@
 #include <rccl/rccl.h> // types and prototypes only: the library is reached through dlopen, not linked
 #include <algorithm>
 #include <cstring>
+#include <ctime>
+#include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 #include "vrt_ctx.h"
 
 using namespace vrt_impl;
@@ -27,6 +30,8 @@ struct RcclApi {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclCommCount) CommCount = nullptr;       // optional (vrt_dist_info)
     decltype(&ncclCommUserRank) CommUserRank = nullptr; // optional
+    decltype(&ncclCommSplit) CommSplit = nullptr;       // optional: one communicator per launch slot (without it every slot shares the first)
+    decltype(&ncclAllReduce) AllReduce = nullptr;       // optional: the ranks agree on how many communicators every one of them got
     bool load(const char *path, std::string &err) {
         lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
         if (!lib) {
@@ -51,11 +56,38 @@ struct RcclApi {
         Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(lib, "ncclBroadcast"));
         CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
         CommUserRank = reinterpret_cast<decltype(CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
+        CommSplit = reinterpret_cast<decltype(CommSplit)>(dlsym(lib, "ncclCommSplit"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
         return true;
     }
 };
 
 constexpr uint32_t kMaxDistSlots = 16;
+constexpr uint32_t kDefaultComms = 8; // communicators a context takes when the host names no number: one per launch slot, at most this many
+
+// ---- the process's communicators ----------------------------------------------------------------------------------------------------
+// RCCL executes the operations of ONE communicator in the order they were issued, whichever streams they were issued on (each launch
+// waits for the communicator's previous one): launch slots that share a communicator have their gathers run one after the other, and a
+// gather cannot start before the one issued before it has ended.  So every launch slot gets a communicator of its own (round 6, VERDICT
+// r05 #2a): duplicates of the first made by ncclCommSplit (color 0, key = rank).  All ranks issue their slots' gathers in the same order
+// and a gather only ever waits for operations issued before it (its own stream's kernel, its peers' gather of the same launch), so
+// communicators side by side cannot deadlock.
+// Making a communicator is a collective that takes RCCL of the order of a second on eight GPUs, and a host makes contexts more often
+// than that is worth (bench.py: one per root-share candidate and leg): the communicators outlive the context that made them, in a pool
+// keyed by (unique id, rank, world, library).  A context takes the free communicators of its key's set in index order and makes the ones
+// that are missing — every rank makes the same vrt_dist_init calls in the same order, so index k is the same communicator everywhere —
+// and gives them back at vrt_destroy.  A host that hands every context the SAME id pays for its communicators once;
+// vrt_dist_release_communicators destroys the ones no context holds.
+struct CommSet {
+    std::string key;
+    void *lib = nullptr; // (the set's own reference on the library: a context's dlopen handle dies with it)
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    std::vector<ncclComm_t> comm; // [0] from ncclCommInitRank, the others split from it
+    std::vector<bool> busy;
+    bool poisoned = false; // a collective on one of them failed: never handed out again, never destroyed (its peers are out of step)
+};
+std::mutex g_comm_mu;
+std::vector<CommSet *> g_comm_sets;
 
 // One launch in flight of the multi-GPU pipeline: its stream carries kernel -> gather -> un-swizzle for a batch of up to
 // `batch` consecutive frames (see Dist).
@@ -76,7 +108,14 @@ struct DistSlot {
 
 struct Dist {
     RcclApi api;
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;   // the first communicator of the set: scene broadcasts, splits, vrt_dist_info; also launch slot 0's
+    CommSet *set = nullptr;      // the pool entry the communicators below were taken from
+    uint32_t ncomms = 0;         // launch slot i issues its gather on comms[i % ncomms]
+    ncclComm_t comms[kMaxDistSlots] = {};
+    uint32_t comm_index[kMaxDistSlots] = {}; // ... its index in the set
+    uint32_t comms_made = 0;     // how many of them this vrt_dist_init had to make (the others were in the pool)
+    bool split_ok = false;       // the library has ncclCommSplit
+    bool agreed = false;         // the ranks agreed on ncomms by an all-reduce (libraries that have ncclAllReduce)
     int rank = 0, world = 1;
     uint32_t nslots = 0;
     DistSlot slots[kMaxDistSlots];
@@ -110,6 +149,101 @@ struct Dist {
         if (r_ != ncclSuccess) return fail(ctx, VRT_E_RCCL, std::string(#call) + ": " + (d)->api.GetErrorString(r_)); \
     } while (0)
 
+// (vrt_dist_selftest_slots: one wave busy for `ticks` of the 100 MHz wall clock)
+__global__ void vrt_spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+namespace {
+double now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+bool g_keep_comms = false; // vrt_dist_keep_communicators: idle sets stay in the pool instead of dying with their last context
+
+void destroy_set(CommSet *set) { // g_comm_mu held; nothing in flight on them (their contexts synchronised their streams before letting go)
+    for (size_t k = set->comm.size(); k-- > 0;)
+        if (set->comm[k] && set->CommDestroy) (void)set->CommDestroy(set->comm[k]);
+    if (set->lib) dlclose(set->lib);
+    delete set;
+}
+
+// `want` communicators for this context: the free ones of its key's set in index order, then new ones (the set's first by
+// ncclCommInitRank, the others split from it) — fewer than `want` where the library cannot split: the slots then share.
+int acquire_comms(vrt_ctx *ctx, Dist *d, const char *rccl_path, const void *id128, uint32_t want) {
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    std::string key(static_cast<const char *>(id128), 128);
+    key += "|" + std::to_string(d->rank) + "/" + std::to_string(d->world) + "|" + rccl_path;
+    d->split_ok = d->api.CommSplit != nullptr;
+    CommSet *set = nullptr;
+    for (CommSet *c : g_comm_sets)
+        if (c->key == key && !c->poisoned) set = c;
+    if (!set) {
+        set = new (std::nothrow) CommSet();
+        if (!set) return fail(ctx, VRT_E_OOM, "host allocation failed");
+        set->key = key;
+        set->lib = dlopen(rccl_path, RTLD_NOW | RTLD_GLOBAL);
+        set->CommDestroy = d->api.CommDestroy;
+        ncclUniqueId id;
+        std::memcpy(&id, id128, sizeof id);
+        ncclComm_t c = nullptr;
+        const ncclResult_t r = d->api.CommInitRank(&c, d->world, id, d->rank);
+        if (r != ncclSuccess) {
+            if (set->lib) dlclose(set->lib);
+            delete set;
+            return fail(ctx, VRT_E_RCCL, std::string("ncclCommInitRank: ") + d->api.GetErrorString(r));
+        }
+        set->comm.push_back(c);
+        set->busy.push_back(false);
+        g_comm_sets.push_back(set);
+        d->comms_made++;
+    }
+    d->set = set;
+    for (uint32_t k = 0; k < set->comm.size() && d->ncomms < want; k++) {
+        if (set->busy[k]) continue;
+        set->busy[k] = true;
+        d->comm_index[d->ncomms] = k;
+        d->comms[d->ncomms++] = set->comm[k];
+    }
+    while (d->ncomms < want && d->api.CommSplit) {
+        ncclComm_t c = nullptr;
+        // (a duplicate: every rank the same color, its own rank as the key; a collective on the set's first communicator, which every
+        // rank's set has at index 0)
+        const ncclResult_t r = d->api.CommSplit(set->comm[0], 0, d->rank, &c, nullptr);
+        if (r != ncclSuccess || !c) break; // (fewer communicators than asked for: launch slots share them)
+        set->comm.push_back(c);
+        set->busy.push_back(true);
+        d->comm_index[d->ncomms] = (uint32_t)set->comm.size() - 1u;
+        d->comms[d->ncomms++] = c;
+        d->comms_made++;
+    }
+    if (d->ncomms == 0) return fail(ctx, VRT_E_RCCL, "no communicator to be had (every one of this id's set is held by another context and the library cannot split)");
+    d->comm = d->comms[0];
+    // The ranks must agree on the number: slot i's gather goes to communicator i % ncomms on EVERY rank.  A split that failed on one
+    // rank only would leave them with different numbers; one tiny all-reduce (minimum) on the first communicator settles it.
+    if (d->api.AllReduce && d->ncomms > 1) {
+        int32_t *dv = nullptr;
+        int32_t hv = (int32_t)d->ncomms;
+        bool ok = hipMalloc(reinterpret_cast<void **>(&dv), sizeof hv) == hipSuccess && hipMemcpyAsync(dv, &hv, sizeof hv, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+        ncclResult_t r = ncclSuccess;
+        if (ok) r = d->api.AllReduce(dv, dv, 1, ncclInt32, ncclMin, d->comm, ctx->stream);
+        ok = ok && r == ncclSuccess && hipMemcpyAsync(&hv, dv, sizeof hv, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+        if (dv) (void)hipFree(dv);
+        if (!ok) return fail(ctx, VRT_E_RCCL, std::string("agreeing on the number of communicators failed") + (r != ncclSuccess ? std::string(": ") + d->api.GetErrorString(r) : std::string()));
+        if (hv < 1) hv = 1;
+        while (d->ncomms > (uint32_t)hv) { // (back to the pool: another rank has fewer)
+            d->ncomms--;
+            set->busy[d->comm_index[d->ncomms]] = false;
+            d->comms[d->ncomms] = nullptr;
+        }
+        d->agreed = true;
+    }
+    return VRT_OK;
+}
+} // namespace
+
 extern "C" {
 
 int vrt_dist_unique_id(const char *rccl_path, void *out_id128) {
@@ -125,9 +259,11 @@ int vrt_dist_unique_id(const char *rccl_path, void *out_id128) {
     return VRT_OK;
 }
 
-int vrt_dist_init_batched(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight,
-                          uint32_t frames_per_launch) {
-    if (!ctx || !rccl_path || !id128) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL argument") : VRT_E_INVALID_ARG;
+int vrt_dist_init_ex(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, const vrt_dist_options *opt) {
+    if (!ctx || !rccl_path || !id128 || !opt) return ctx ? fail(ctx, VRT_E_INVALID_ARG, "NULL argument") : VRT_E_INVALID_ARG;
+    if (opt->struct_size < sizeof(vrt_dist_options)) return fail(ctx, VRT_E_INVALID_ARG, "vrt_dist_options.struct_size");
+    uint32_t frames_in_flight = opt->frames_in_flight, frames_per_launch = opt->frames_per_launch;
+    if (opt->communicators > kMaxDistSlots) return fail(ctx, VRT_E_INVALID_ARG, "at most 16 communicators");
     if (ctx->dist) return fail(ctx, VRT_E_STATE, "vrt_dist_init called twice");
     if (world < 1 || rank < 0 || rank >= world) return fail(ctx, VRT_E_INVALID_ARG, "bad rank / world");
     if ((uint32_t)world != ctx->shard.shard_count || (uint32_t)rank != ctx->shard.shard_rank)
@@ -154,9 +290,10 @@ int vrt_dist_init_batched(vrt_ctx *ctx, const char *rccl_path, const void *id128
     // shards travel as RGB (the alpha of the RGBA8 target is the constant 255): a quarter less for rank 0's links to take in
     d->shard_bytes = (size_t)ctx->shard.tiles_per_rank * vrt::kTileW * vrt::kTileH * 3u;
     ctx->dist = d; // from here free_ctx cleans up
-    ncclUniqueId id;
-    std::memcpy(&id, id128, sizeof id);
-    VRT_NCCL(ctx, d, d->api.CommInitRank(&d->comm, world, id, rank));
+    {
+        const int rca = acquire_comms(ctx, d, rccl_path, id128, opt->communicators ? std::min(opt->communicators, d->nslots) : std::min(d->nslots, kDefaultComms));
+        if (rca != VRT_OK) return rca;
+    }
     const size_t region = d->shard_bytes * d->batch; // one rank's shards of a batch, frame-major
     for (uint32_t i = 0; i < d->nslots; i++) {
         DistSlot &sl = d->slots[i];
@@ -184,8 +321,52 @@ int vrt_dist_init_batched(vrt_ctx *ctx, const char *rccl_path, const void *id128
     return VRT_OK;
 }
 
+int vrt_dist_init_batched(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight,
+                          uint32_t frames_per_launch) {
+    vrt_dist_options o{};
+    o.struct_size = (uint32_t)sizeof o;
+    o.frames_in_flight = frames_in_flight;
+    o.frames_per_launch = frames_per_launch;
+    return vrt_dist_init_ex(ctx, rccl_path, id128, rank, world, &o);
+}
+
 int vrt_dist_init(vrt_ctx *ctx, const char *rccl_path, const void *id128, int rank, int world, uint32_t frames_in_flight) {
     return vrt_dist_init_batched(ctx, rccl_path, id128, rank, world, frames_in_flight, 1);
+}
+
+int vrt_dist_keep_communicators(int keep) {
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    const int was = g_keep_comms ? 1 : 0;
+    g_keep_comms = keep != 0;
+    return was;
+}
+
+int vrt_dist_release_communicators(void) {
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    int n = 0;
+    for (size_t i = 0; i < g_comm_sets.size();) {
+        CommSet *set = g_comm_sets[i];
+        bool idle = !set->poisoned;
+        for (bool b : set->busy) idle = idle && !b;
+        if (!idle) {
+            i++;
+            continue;
+        }
+        n += (int)set->comm.size();
+        destroy_set(set);
+        g_comm_sets.erase(g_comm_sets.begin() + (long)i);
+    }
+    return n;
+}
+
+int vrt_dist_comm_info(vrt_ctx *ctx, int32_t out[4]) {
+    if (!ctx || !ctx->dist || !out) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called / out NULL") : VRT_E_INVALID_ARG;
+    const Dist *d = ctx->dist;
+    out[0] = (int32_t)d->ncomms;
+    out[1] = (int32_t)d->comms_made;
+    out[2] = d->split_ok ? 1 : 0;
+    out[3] = d->agreed ? 1 : 0;
+    return VRT_OK;
 }
 
 // one frame into the pipeline's queue (vrt_dist_frame, vrt_dist_frames)
@@ -313,15 +494,16 @@ int dist_flush(vrt_ctx *ctx) {
     // 2. the one collective of the batch: every rank's shards -> rank 0 (grouped point-to-point = gather)
     const size_t region = d->shard_bytes * d->batch;
     if (d->world > 1) {
+        const ncclComm_t comm = d->comms[(uint32_t)k % d->ncomms]; // this launch slot's communicator (the same index on every rank)
         VRT_NCCL(ctx, d, d->api.GroupStart());
         // a failing Send / Recv must not leave the group open on this rank: close it, then report, and the context
         // stays failed (every later vrt_dist_* call returns VRT_E_RCCL) because its peers are now out of step
         ncclResult_t first_bad = ncclSuccess;
         if (d->rank == 0) {
             for (int r = 1; r < d->world && first_bad == ncclSuccess; r++)
-                first_bad = d->api.Recv(sl.gathered + (size_t)r * region, d->shard_bytes * n, ncclUint8, r, d->comm, sl.stream);
+                first_bad = d->api.Recv(sl.gathered + (size_t)r * region, d->shard_bytes * n, ncclUint8, r, comm, sl.stream);
         } else {
-            first_bad = d->api.Send(sl.shard, d->shard_bytes * n, ncclUint8, 0, d->comm, sl.stream);
+            first_bad = d->api.Send(sl.shard, d->shard_bytes * n, ncclUint8, 0, comm, sl.stream);
         }
         const ncclResult_t end = d->api.GroupEnd();
         if (first_bad != ncclSuccess || end != ncclSuccess) {
@@ -373,7 +555,20 @@ void dist_destroy(vrt_ctx *ctx) {
     if (!d) return;
     for (uint32_t i = 0; i < d->nslots; i++)
         if (d->slots[i].stream) (void)hipStreamSynchronize(d->slots[i].stream);
-    if (d->comm && d->api.CommDestroy) (void)d->api.CommDestroy(d->comm);
+    (void)hipStreamSynchronize(ctx->stream); // (scene broadcasts ride the primary stream)
+    if (d->set) {
+        // the communicators go back to the pool; a set nobody holds any more is destroyed unless the host keeps them (vrt_dist_keep_communicators)
+        std::lock_guard<std::mutex> lk(g_comm_mu);
+        CommSet *set = d->set;
+        for (uint32_t i = 0; i < d->ncomms; i++) set->busy[d->comm_index[i]] = false;
+        if (d->failed) set->poisoned = true; // (peers out of step: neither reused nor destroyed — ncclCommDestroy would wait for them)
+        bool idle = !set->poisoned;
+        for (bool b : set->busy) idle = idle && !b;
+        if (idle && !g_keep_comms) {
+            destroy_set(set);
+            g_comm_sets.erase(std::find(g_comm_sets.begin(), g_comm_sets.end(), set));
+        }
+    }
     delete d;
     ctx->dist = nullptr;
 }
@@ -484,6 +679,76 @@ int vrt_dist_selftest(vrt_ctx *ctx) {
     (void)hipFree(a);
     (void)hipFree(b);
     return rc;
+}
+
+// Every launch slot at once, against the real library on ONE GPU (VERDICT r05 #2a): per round and slot a kernel that keeps one wave
+// busy for busy_us microseconds on the slot's stream — the frame's trace kernel — then the grouped self send + recv of one shard on the
+// slot's communicator and stream — the gather.  Shows (1) that `nslots` streams issuing on `ncomms` communicators complete (no deadlock),
+// (2) the bytes arrive, (3) how far the launches overlap: with the slots on ONE communicator RCCL runs the gathers in issue order, each
+// behind its predecessor; with a communicator per slot they overlap.
+int vrt_dist_selftest_slots(vrt_ctx *ctx, uint32_t busy_us, uint32_t rounds, double out[4]) {
+    if (!ctx || !ctx->dist || !out) return ctx ? fail(ctx, VRT_E_STATE, "vrt_dist_init has not been called / out NULL") : VRT_E_INVALID_ARG;
+    if (rounds == 0 || rounds > 4096u || busy_us > 100000u) return fail(ctx, VRT_E_INVALID_ARG, "vrt_dist_selftest_slots: 1..4096 rounds, at most 100 ms of busy time");
+    Dist *d = ctx->dist;
+    DeviceGuard dg(ctx->device);
+    const size_t n = d->shard_bytes ? d->shard_bytes : 256u;
+    std::vector<uint8_t *> a(d->nslots, nullptr), b(d->nslots, nullptr);
+    std::vector<hipEvent_t> ev(2u * d->nslots, nullptr);
+    std::string host(n, '\0'), back(n, '\0');
+    int rc = VRT_OK;
+    auto cleanup = [&]() {
+        for (uint8_t *p : a) if (p) (void)hipFree(p);
+        for (uint8_t *p : b) if (p) (void)hipFree(p);
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    };
+    for (uint32_t i = 0; i < d->nslots && rc == VRT_OK; i++) {
+        for (size_t j = 0; j < n; j++) host[j] = (char)((j * 131u + 7u + i) & 0xFFu);
+        if (hipMalloc(reinterpret_cast<void **>(&a[i]), n) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&b[i]), n) != hipSuccess ||
+            hipMemcpy(a[i], host.data(), n, hipMemcpyHostToDevice) != hipSuccess || hipMemset(b[i], 0, n) != hipSuccess ||
+            hipEventCreate(&ev[2u * i]) != hipSuccess || hipEventCreate(&ev[2u * i + 1u]) != hipSuccess)
+            rc = fail(ctx, VRT_E_HIP, "selftest allocation failed");
+    }
+    double wall_ms = 0.0, launch_ms = 0.0;
+    if (rc == VRT_OK) {
+        // one untimed round first: RCCL connects a communicator's channels at its first operation
+        for (uint32_t round = 0; round <= rounds && rc == VRT_OK; round++) {
+            if (round == 1u) {
+                for (uint32_t i = 0; i < d->nslots; i++) (void)hipStreamSynchronize(d->slots[i].stream);
+                wall_ms = now_ms();
+            }
+            for (uint32_t i = 0; i < d->nslots && rc == VRT_OK; i++) {
+                hipStream_t st = d->slots[i].stream;
+                const ncclComm_t comm = d->comms[i % d->ncomms];
+                const bool last = round == rounds;
+                if (last) (void)hipEventRecord(ev[2u * i], st);
+                if (busy_us) hipLaunchKernelGGL(vrt_spin_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)busy_us * 100ull);
+                ncclResult_t r = d->api.GroupStart();
+                if (r == ncclSuccess) r = d->api.Send(a[i], n, ncclUint8, d->rank, comm, st);
+                if (r == ncclSuccess) r = d->api.Recv(b[i], n, ncclUint8, d->rank, comm, st);
+                const ncclResult_t r2 = d->api.GroupEnd();
+                if (r == ncclSuccess) r = r2;
+                if (r != ncclSuccess) rc = fail(ctx, VRT_E_RCCL, std::string("self send/recv on slot ") + std::to_string(i) + ": " + d->api.GetErrorString(r));
+                if (last) (void)hipEventRecord(ev[2u * i + 1u], st);
+            }
+        }
+        for (uint32_t i = 0; i < d->nslots; i++)
+            if (hipStreamSynchronize(d->slots[i].stream) != hipSuccess && rc == VRT_OK) rc = fail(ctx, VRT_E_HIP, "selftest: a slot's stream failed");
+        wall_ms = now_ms() - wall_ms;
+    }
+    for (uint32_t i = 0; i < d->nslots && rc == VRT_OK; i++) {
+        for (size_t j = 0; j < n; j++) host[j] = (char)((j * 131u + 7u + i) & 0xFFu);
+        if (hipMemcpy(&back[0], b[i], n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, VRT_E_HIP, "selftest read-back failed");
+        else if (back != host) rc = fail(ctx, VRT_E_RCCL, "self send/recv on slot " + std::to_string(i) + " returned different bytes");
+        float ms = 0.0f;
+        if (rc == VRT_OK && hipEventElapsedTime(&ms, ev[2u * i], ev[2u * i + 1u]) == hipSuccess) launch_ms += (double)ms;
+    }
+    cleanup();
+    if (rc != VRT_OK) return rc;
+    out[0] = wall_ms;                          // the timed rounds, host clock, all slots drained
+    out[1] = (double)rounds * d->nslots;       // launches in them
+    out[2] = launch_ms / d->nslots;            // last round: mean time from a slot's kernel start to its gather's end (events on its stream)
+    out[3] = (double)d->ncomms;
+    return VRT_OK;
 }
 
 // Replica update (delta upload "+ replica broadcast"): one collective per dirty range.

@@ -424,14 +424,37 @@ class VoxelRT:
         return bytes(buf)
 
     def dist_init(self, unique_id: bytes, rank: int, world: int, frames_in_flight: int = 4, rccl_path: Optional[str] = None,
-                  frames_per_launch: int = 1) -> None:
+                  frames_per_launch: int = 1, communicators: int = 0) -> None:
         """frames_in_flight: launches in flight; frames_per_launch: consecutive frames traced by one launch and gathered by
-        one collective (vrt_dist_init_batched).  rccl_path: the library to bind (default: the RCCL PyTorch ships; tests pass
-        a single-process stand-in)."""
+        one collective; communicators: how many RCCL communicators the launch slots issue their gathers on (0: one per slot, at most 8;
+        1: all on one — vrt_dist_init_ex).  rccl_path: the library to bind (default: the RCCL PyTorch ships; tests pass a
+        single-process stand-in)."""
         assert len(unique_id) == 128
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
-        self._check(self._lib.vrt_dist_init_batched(self._h, (rccl_path or L.rccl_library_path()).encode(), buf, rank, world, frames_in_flight,
-                                        frames_per_launch))
+        opt = L.DistOptions()
+        opt.struct_size = C.sizeof(L.DistOptions)
+        opt.frames_in_flight, opt.frames_per_launch, opt.communicators = frames_in_flight, frames_per_launch, communicators
+        self._check(self._lib.vrt_dist_init_ex(self._h, (rccl_path or L.rccl_library_path()).encode(), buf, rank, world, C.byref(opt)))
+
+    def dist_comm_info(self) -> dict:
+        out = (C.c_int32 * 4)()
+        self._check(self._lib.vrt_dist_comm_info(self._h, out))
+        return {"communicators": out[0], "made_by_this_init": out[1], "library_splits": bool(out[2]), "agreed_by_all_reduce": bool(out[3])}
+
+    def dist_selftest_slots(self, busy_us: int = 50, rounds: int = 20) -> dict:
+        """vrt_dist_selftest_slots: every launch slot's kernel + self send / recv at once on the bound library."""
+        out = (C.c_double * 4)()
+        self._check(self._lib.vrt_dist_selftest_slots(self._h, busy_us, rounds, out))
+        return {"wall_ms": out[0], "launches": int(out[1]), "us_per_launch": out[0] * 1e3 / max(1.0, out[1]), "last_round_launch_ms": out[2],
+                "communicators": int(out[3])}
+
+    @staticmethod
+    def dist_keep_communicators(keep: bool = True) -> bool:
+        return bool(lib.vrt_dist_keep_communicators(1 if keep else 0))
+
+    @staticmethod
+    def dist_release_communicators() -> int:
+        return int(lib.vrt_dist_release_communicators())
 
     def dist_frame(self) -> None:
         self._check(self._lib.vrt_dist_frame(self._h, C.byref(self.camera.d_camera), C.byref(self.sun.device_data)))
