@@ -1147,6 +1147,8 @@ def main(argv=None) -> None:
             present = {"kernel": "vrt_denoise_kernel", "from": [w.width, w.height], "to": [pw, ph], "samples": 20, "us_median": p_med * 1e3, "us_min": p_ms[0] * 1e3,
                        "algorithmic_bytes": p_bytes, "bytes_note": "(samples + 2) bilinear taps of 4 texels x 4 B + 4 B written, per output pixel",
                        "achieved_GBps": p_bytes / (p_med * 1e-3) / 1e9, "frac": p_bytes / (p_med * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                       # (frac > 1: the byte model is no bound — the staged kernel reads a texel once into LDS and serves the taps from there)
+                       "frac_model_valid": bool(p_bytes / (p_med * 1e-3) / 1e9 / HBM_PEAK_GBPS <= 1.0), "bound": "issue (taps served from LDS)",
                        "trace_us_median_same_frames": t_ms[len(t_ms) // 2] * 1e3, "frame_trace_plus_present_us": (t_ms[len(t_ms) // 2] + p_med) * 1e3,
                        "note": "view V1, 64 frames, one frame at a time, HIP events around each launch; the source image stays in L2: bound by its gathers and pow(), not by HBM"}
         except Exception as e:  # noqa: BLE001

@@ -717,4 +717,6 @@ def test_sharded_frames_of_the_baseline_configurations_at_full_size_are_the_orac
     assert got == [str(z["rgba8_sha256"])] * batches, (got, str(z["rgba8_sha256"]))
     if str(z["workload"]).startswith("cfg4"):
         for r in range(world):
-            assert names[r] == ["vrt_path_kernel<8, 5, false, false, false, false, 1>", "vrt_pool_kernel<8, 6, 60, 2>"], names[r]
+            # (the first frame: vrt_path_kernel<..., DIL 1> unless the box of the occupied cells has reached the host before it — eight ranks
+            # now initialise their communicators one after the other, which can take that long; the second: the pool kernel)
+            assert names[r][0] in ("vrt_path_kernel<8, 5, false, false, false, false, 1>", "vrt_pool_kernel<8, 6, 60, 2>") and names[r][1] == "vrt_pool_kernel<8, 6, 60, 2>", names[r]
