@@ -6,6 +6,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h> // types and prototypes only: the library is reached through dlopen, not linked
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <mutex>
@@ -486,7 +488,16 @@ int dist_flush(vrt_ctx *ctx) {
         for (uint32_t j = f; j < g; j++) pf.pcs[j - f] = d->pend[j];
         pf.target_rgba8 = sl.shard + (size_t)f * d->shard_bytes;
         // (a launch of g - f frames of this rank's tiles: half-tile workgroups while its waves do not fill the SIMDs twice)
-        pf.split_all = (ctx->split_ok && pf.tile_order == 3u && (uint64_t)ctx->shard.owned_tiles * 4u * (g - f) <= 2ull * ctx->simds) ? 1u : 0u;
+        // Round 6: up to FOUR waves per SIMD (was two).  A rank of eight owns 1 020 of the headline's tiles = 4 080 waves, 4 per SIMD, all
+        // resident at once — the launch order cannot matter, the launch lasts as long as its longest wave, and a wave of 32 lanes has
+        // the shorter chain: rank 1 of 8, one frame per launch, 4 / 8 / 12 / 16 launches in flight 40.7 / 30.8 / 27.7 / 26.0 -> 37.0 /
+        // 28.9 / 26.0 / 24.7 us per frame, the launch 79 -> 72 us (profiles/r06_shard_split_probe.txt).  Not beyond: two frames per launch
+        // (8 waves per SIMD, more than are resident) split lose 17.2 -> 22.2 us per frame; quarters lose everywhere.
+        uint32_t split_factor = 4u, split_level = 1u;
+#ifdef VRT_DEV_VARIANTS
+        if (const char *e = std::getenv("VRT_DEV_SHARD_SPLIT")) (void)std::sscanf(e, "%u:%u", &split_factor, &split_level); // "<waves per SIMD up to which a shard's tiles are split>:<log2 parts>"
+#endif
+        pf.split_all = (ctx->split_ok && pf.tile_order == 3u && (uint64_t)ctx->shard.owned_tiles * 4u * (g - f) <= (uint64_t)split_factor * ctx->simds) ? split_level : 0u;
         VRT_HIP(ctx, vrt::launch_trace(fn, pf, ctx->lds_bytes, sl.stream, g - f));
         f = g;
     }
