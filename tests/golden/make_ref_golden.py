@@ -192,8 +192,61 @@ def main_full(only=()):
         print(f"{name}: {width}x{height}, mean colour {f[:, :, :3].mean(axis=(0, 1))}")
 
 
+# ---- round 6: the kernels BASELINE configs[3] and [4] run, pinned to the reference shader DIRECTLY.  configs[3] / [4]
+# themselves exceed GL's 128 MiB storage-block limit (material_index alone is 1 GiB / 2 GiB), so: the same frame size (3840x2160), the same
+# kind of scene as configs[4] at the largest size that fits (1024^3 voxels, 8^3 bricks, the sparse field, 80 000 brick slots: 128^3 = 2 M
+# cells -> the word-mode kernels, occupied cells reach the grid's faces -> vrt_pool_kernel applies), rendered by the reference shader
+# under llvmpipe with (a) 4 samples, 3 bounces (device value), soft sun — a path trace: vrt_pool_kernel, vrt_path_kernel<DIL 1 / 2>, the
+# lockstep bounce kernel; (b) 2 samples, no bounce, soft sun — configs[3]'s ray mix: vrt_trace_kernel<8, false, 4, 6, 1, 256>.
+BIG = W.WORKLOADS["refbig_4k_1024c_b8_sparse"]
+
+
+def big_cases():
+    return {
+        "big_path_spp4_b3_V1": (BIG, "V1", 4, 2),
+        "big_path_spp4_b3_V0": (BIG, "V0", 4, 2),
+        "big_shadow_spp2_V2": (BIG, "V2", 2, 0),
+        "big_shadow_spp2_V1x": (BIG, "V1x", 2, 0),
+    }
+
+
+def main_big(only=()):
+    import dataclasses
+    import time
+    from tests.golden.make_golden import scene_digest
+    os.makedirs(FULL_OUT, exist_ok=True)
+    info = GlRef().info()
+    check_implementation(info, FULL_OUT)
+    grid = W.build_grid(BIG)
+    scene = oracle_scene_from_grid(grid)
+    ref = ReferenceShader(8)
+    for name, (w0, view, spp, bounce) in big_cases().items():
+        if only and not name.startswith(tuple(only)):
+            continue
+        w = dataclasses.replace(w0, spp=spp, max_bounce=bounce)
+        pc = O.push_constants(W.camera_for(w, view).blob(), W.sun_for(w).blob())
+        t0 = time.time()
+        f, u = ref.render(scene, pc)
+        height, width = f.shape[:2]
+        bands = [hashlib.sha256(np.ascontiguousarray(f[y:y + BAND]).tobytes()).hexdigest() for y in range(0, height, BAND)]
+        origins = crop_origins(width, height)
+        crops = np.stack([f[y:y + CROP, x:x + CROP, :3] for y, x in origins])
+        np.savez_compressed(
+            os.path.join(FULL_OUT, name + ".npz"),
+            provenance=np.array(f"brick_raytracer.comp + rand.comp of /root/reference, OpenGL dialect edits E1-E8 of oracle/ref_gl/recipe.py, {info}"),
+            workload=np.array(w.name), view=np.array(view), size=np.array([width, height]), brick_dimension=np.int32(8),
+            samples_per_pixel=np.int32(spp), max_bounce=np.int32(bounce),
+            push_constants=pc, scene_sha256=np.array(scene_digest(grid)),
+            rgba8_sha256=np.array(hashlib.sha256(u.tobytes()).hexdigest()), float_sha256=np.array(hashlib.sha256(f.tobytes()).hexdigest()),
+            band_rows=np.int32(BAND), band_sha256=np.array(bands), crop_origins=np.array(origins), float_crops=crops,
+            mean_rgb=f[:, :, :3].mean(axis=(0, 1)).astype(np.float64))
+        print(f"{name}: {width}x{height}, {spp} spp, max_bounce {bounce}, {time.time() - t0:.1f} s under llvmpipe, mean colour {f[:, :, :3].mean(axis=(0, 1))}", flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "full":
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        main_big(sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "full":
         main_full(sys.argv[2:])
     else:
         main()

@@ -1754,6 +1754,16 @@ VRT_DI float opaque_uniform(float v) {
 }
 VRT_DI f3 opaque_uniform3(const float (&v)[3]) { return mk3(opaque_uniform(v[0]), opaque_uniform(v[1]), opaque_uniform(v[2])); }
 
+// This lane's index in its wave from the hardware, by an instruction the optimiser may neither hoist nor merge with an earlier
+// copy: what is derived from it (the pixel's place in its tile, its coordinates, its address) is formed again where it is needed
+// instead of staying in registers across the traversal.  (round 6: the several-samples kernel at six waves per SIMD kept eleven such
+// values in scratch — the pixel's coordinates as floats, the jitter's operands, the target offset.)
+VRT_DI uint32_t fresh_lane() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // SHADE: 0 general bounce loop; 1 max_bounce <= 1 (ray_color_single); 2 the same with one sample per
 // pixel (no accumulator kept live across the traversal)
 template <int B, bool COUNT, int MODE, int MIN_WAVES, int SHADE, int BLOCK = 256>
@@ -1782,7 +1792,9 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     // 64 >> s lanes per wave — a frame with fewer waves than the GPU has SIMDs lasts as long as its slowest wave, and a wave walks the
     // bricks its lanes meet one after the other: fewer lanes, a shorter chain
     const uint32_t unit = p.wave_groups ? (blockIdx.x >> 2) : (BLOCK == 512 ? blockIdx.x * 2u + (threadIdx.x >> 8) : (blockIdx.x >> p.split_all));
-    const uint32_t wave = p.wave_groups ? (blockIdx.x & 3u) : ((threadIdx.x >> 6) & 3u);
+    // (SHADE 1: the wave's number in a scalar register — with fresh_lane() below nothing then keeps threadIdx.x alive)
+    const uint32_t wave = p.wave_groups ? (blockIdx.x & 3u)
+                                        : (SHADE == 1 ? ((uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 3u) : ((threadIdx.x >> 6) & 3u));
     if (BLOCK == 512 && unit >= p.owned_tiles) return; // odd tile count: the last workgroup's second half is idle
     uint32_t owned;
     uint32_t split = 0u, half = 0u; // split: this workgroup renders one half of the tile (rows 4*half .. 4*half+3 of each 8x8 block)
@@ -1824,7 +1836,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
     const uint32_t tile_x = tile % p.tiles_x, tile_y = tile / p.tiles_x;
     // lane -> pixel: wave w of the tile covers the 8x8 quadrant (w&1, w>>1)
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = SHADE == 1 ? fresh_lane() : (threadIdx.x & 63u);
     const PushConstants &pc = p.pcs[blockIdx.y]; // frame blockIdx.y of this launch (kernarg segment, scalar loads)
     // A half-tile workgroup of a frame with TWO samples per pixel gives its idle lanes the second sample (round 4): lanes 0-31 trace
     // sample 0 of the wave's 32 pixels, lanes 32-63 sample 1 of the same pixels, and lane l adds lane l + 32's colour to its own —
@@ -1833,10 +1845,15 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     // (a quarter- or eighth-tile workgroup: 16 or 8 pixels per wave, twice as many lanes at work)
     const bool dual = SHADE != 2 && !COUNT && split != 0u && !p.packed_rgb && pc.cam.samples_per_pixel == 2; // (uniform over the workgroup)
     const uint32_t pixels = 64u >> split; // pixels of its 8x8 block this wave renders
-    const uint32_t plane = dual ? (lane & (pixels - 1u)) : lane;
-    const uint32_t in_x = (wave & 1u) * 8u + (plane & 7u);
     const uint32_t rows = 8u >> split; // rows of its 8x8 block this wave renders (split: 4 or 2), from row `half * rows`
-    const uint32_t in_y = (wave >> 1) * 8u + half * rows + ((plane >> 3) & (rows - 1u));
+    // lane -> place in the tile (everything but the lane is uniform over the wave)
+    auto place = [&](uint32_t ln, uint32_t &ix, uint32_t &iy) {
+        const uint32_t pl = dual ? (ln & (pixels - 1u)) : ln;
+        ix = (wave & 1u) * 8u + (pl & 7u);
+        iy = (wave >> 1) * 8u + half * rows + ((pl >> 3) & (rows - 1u));
+    };
+    uint32_t in_x, in_y;
+    place(lane, in_x, in_y);
     const uint32_t px = tile_x * kTileW + in_x;
     const uint32_t py = tile_y * kTileH + in_y;
 
@@ -1853,7 +1870,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     if (inside) {
         f3 color = mk3(0, 0, 0);
         const int spp = (SHADE == 2) ? 1 : pc.cam.samples_per_pixel;
-        const float x = (float)px, y = (float)py;
+        const float x0 = (float)px, y0 = (float)py;
         // CameraGetRay operands, comp:474-477
         const f3 horizontal = mk3(pc.cam.horizontal[0], pc.cam.horizontal[1], pc.cam.horizontal[2]);
         const f3 vertical = mk3(pc.cam.vertical[0], pc.cam.vertical[1], pc.cam.vertical[2]);
@@ -1861,8 +1878,8 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         const f3 origin = mk3(pc.cam.origin[0], pc.cam.origin[1], pc.cam.origin[2]);
         if constexpr (SHADE == 2) {
             // sample 0 is un-jittered: hash12(0) = 0 (comp:167-170)
-            const float u = (x + 0.0f) / (float)(pc.cam.image_width - 1u);
-            const float v = (y + 0.0f) / (float)(pc.cam.image_height - 1u);
+            const float u = (x0 + 0.0f) / (float)(pc.cam.image_width - 1u);
+            const float v = (y0 + 0.0f) / (float)(pc.cam.image_height - 1u);
             const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
             color = mk3(0, 0, 0) + ray_color_single<B, COUNT, MODE>(p, pc, lds_filter, create_ray(origin, ray_dir), c);
         } else {
@@ -1876,6 +1893,12 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
                 const f3 llc = opaque_uniform3(pc.cam.lower_left_corner);
                 const f3 origin = opaque_uniform3(pc.cam.origin);
                 const float flag = (sample_i > 0) ? 1.0f : 0.0f;
+                float x = x0, y = y0;
+                if constexpr (SHADE == 1) { // (the pixel's coordinates formed again from the lane in every trip: not kept across the traversal)
+                    uint32_t sx, sy;
+                    place(fresh_lane(), sx, sy);
+                    x = (float)(tile_x * kTileW + sx), y = (float)(tile_y * kTileH + sy);
+                }
                 const float noise_x = hash_12_jitter(x + (float)sample_i, y, flag);
                 const float u = (x + noise_x) / (float)(pc.cam.image_width - 1u);
                 const float noise_y = hash_12_jitter(x, y + (float)sample_i, flag);
@@ -1888,6 +1911,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         bool writer = true;
         if constexpr (SHADE != 2 && !COUNT) {
             if (dual) { // (both lanes of a pixel are inside the image or neither is: the source lane is active)
+                const uint32_t lane = SHADE == 1 ? fresh_lane() : (threadIdx.x & 63u);
                 const int from = (int)((lane + pixels) & 63u);
                 const f3 second = mk3(__shfl(color.x, from, 64), __shfl(color.y, from, 64), __shfl(color.z, from, 64));
                 color = color + second;
@@ -1898,10 +1922,12 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         color = mk3(__builtin_sqrtf(color.x / fspp), __builtin_sqrtf(color.y / fspp), __builtin_sqrtf(color.z / fspp));
 
         size_t o;
+        uint32_t ox = in_x, oy = in_y;
+        if constexpr (SHADE == 1) place(fresh_lane(), ox, oy);
         if (p.shard_count > 1u || p.packed_tiles) {
-            o = (size_t)owned * (kTileW * kTileH) + in_y * kTileW + in_x; // packed tile-major shard
+            o = (size_t)owned * (kTileW * kTileH) + oy * kTileW + ox; // packed tile-major shard
         } else {
-            o = (size_t)py * p.width + px; // row-major frame
+            o = (size_t)(tile_y * kTileH + oy) * p.width + (tile_x * kTileW + ox); // row-major frame
         }
         rgba = unorm8(color.x) | (unorm8(color.y) << 8) | (unorm8(color.z) << 16) | (255u << 24);
         if (writer) {
@@ -1915,6 +1941,9 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         // RGB shard (multi-GPU pipeline): 16x16 tiles of 3-byte pixels, 768 bytes per tile.  The eight lanes of a row of
         // this wave's 8x8 block hold 24 consecutive bytes = 6 dwords; lane k < 6 of the row assembles dword k from the
         // two pixels it spans (bytes 4k .. 4k+3; pixel = byte / 3) and stores it.
+        const uint32_t lane = SHADE == 1 ? fresh_lane() : (threadIdx.x & 63u);
+        uint32_t in_x, in_y;
+        place(lane, in_x, in_y);
         const uint32_t k = lane & 7u;
         const uint32_t first = k + (k >= 3u ? 1u : 0u); // = 4k / 3 for k < 6
         const int src = (int)((lane & ~7u) + first);
@@ -1929,8 +1958,9 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     __syncthreads();
     if (p.wave_timeline && threadIdx.x < 8) p.wave_timeline[(size_t)blockIdx.x * 8 + threadIdx.x] = vrt_prof[threadIdx.x];
 #else
-    if (p.wave_timeline && lane == 0) {
-        const size_t w_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t lane_end = SHADE == 1 ? fresh_lane() : lane;
+    if (p.wave_timeline && lane_end == 0) {
+        const size_t w_id = (size_t)blockIdx.x * (blockDim.x >> 6) + ((SHADE == 1 && BLOCK != 512) ? (p.wave_groups ? 0u : wave) : (threadIdx.x >> 6));
         p.wave_timeline[2 * w_id] = wall_begin;
         p.wave_timeline[2 * w_id + 1] = wall_clock64();
     }
@@ -1940,7 +1970,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         // atomic add per wave into one word per tile measured 4.5 % of the kernel: the wave's slot is held until the
         // atomic is acknowledged.)
         const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
-        if (lane == 0) p.tile_cost[((size_t)half * p.owned_tiles + owned) * 4u + wave] = (uint32_t)(dt >> 6);
+        if (lane_end == 0) p.tile_cost[((size_t)half * p.owned_tiles + owned) * 4u + wave] = (uint32_t)(dt >> 6);
     }
     if constexpr (COUNT) {
         // wave-level reduction, then one atomic per wave per counter
@@ -1952,7 +1982,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             v[k] = s;
         }
-        if (lane == 0) {
+        if (lane_end == 0) {
             atomicAdd(&p.counters->rays, v[0]);
             atomicAdd(&p.counters->status_loads, v[1]);
             atomicAdd(&p.counters->bricks_entered, v[2]);

@@ -49,6 +49,10 @@ WORKLOADS: Dict[str, Workload] = {
     # the reference app's own default run, grid shape included (src/main.zig:77-81: 128 x 64 x 128 bricks of 4^3, min point
     # (-32, -16, -32), scale 0.5; :23,122-135: 1024x576, 2 samples, max_bounce 2, sun on): the workload a user of the reference sees
     "refapp_1024x576_128x64x128_b4": Workload("refapp_1024x576_128x64x128_b4", 1024, 576, 512, 4, 2, 2, True, 5.0, dims=(128, 64, 128)),
+    # not a BASELINE config (round 6): configs[3] / [4]'s frame size on the largest scene of configs[4]'s kind whose buffers fit GL's 128 MiB
+    # storage-block limit — the scene of the reference-shader fixtures that pin configs[3]'s and [4]'s kernels directly
+    # (tests/golden/make_ref_golden.py big): 128^3 cells -> the word-mode kernels; occupied cells reach the grid's faces -> vrt_pool_kernel
+    "refbig_4k_1024c_b8_sparse": Workload("refbig_4k_1024c_b8_sparse", 3840, 2160, 1024, 8, 4, 2, True, 5.0, "sparse", 0.08, 80_000),
     # not a BASELINE config (round 5): a path trace on 4^3 bricks — the reference's own brick size — at a size the persistent kernels
     # are chosen for themselves... only where bindings 3-5 exceed the caches, which 4^3 bricks reach at 2048^3; used with kernel_variant
     # bit 23 by the A/B of vrt_pool_kernel<4, ...> against vrt_path_kernel<4, ...> (tools/lib_ab.py)
