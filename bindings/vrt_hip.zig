@@ -214,6 +214,7 @@ pub const TUNE_NO_DEFERRED_MATERIAL: u32 = 1 << 17;
 pub const TUNE_NO_CELL_MATERIAL: u32 = 1 << 18;
 pub const TUNE_GRID_EXIT_ANY_BOX: u32 = 1 << 19;
 pub const TUNE_NO_BOUNCE_AUTOTUNE: u32 = 1 << 20;
+pub const TUNE_PRESENT_OWN_STREAM: u32 = 1 << 21;
 
 pub const GridConfig = extern struct { // Grid.zig:13-20
     brick_alloc: u64 = 0,

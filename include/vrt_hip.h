@@ -167,7 +167,8 @@ typedef struct vrt_config {
 #define VRT_TUNE_NO_CELL_MATERIAL     (1u << 18) /* vrt_pool_kernel: always reach a hit's material through brick_index and material_index (comp:337, :422-425), also where all solid voxels of the brick share one material (round 5: a byte per cell says which) */
 #define VRT_TUNE_GRID_EXIT_ANY_BOX    (1u << 19) /* bounce frames of the persistent kernels: the counter-free walk to the grid's face (vrt_pool_kernel, vrt_path_kernel<..., DIL 2>) whatever the box of the occupied cells — by default only where that box is, or nearly is, the grid (a ray that leaves a smaller box walks the empty cells beyond it) */
 #define VRT_TUNE_NO_BOUNCE_AUTOTUNE   (1u << 20) /* bounce frames of scenes that stay in the caches: always the lockstep kernel; by default the library times it against vrt_pool_kernel where both apply (four trial frames) and keeps the faster (round 5) */
-#define VRT_TUNE_ALL                0x1FFFFFu
+#define VRT_TUNE_PRESENT_OWN_STREAM   (1u << 21) /* contexts with two frames in flight: vrt_denoise on a stream of its own behind an event of the frame it reads (the reference's arrangement: graphics queue behind the compute queue's semaphore, Pipeline.zig:494-517).  Measured and NOT the default (round 6): on the stream of the frame it reads the pass already overlaps the next frame's trace, which runs on the other stream; the extra stream costs 3-12 % (profiles/r06_present_overlap.txt) */
+#define VRT_TUNE_ALL                0x3FFFFFu
 
 typedef struct vrt_ctx vrt_ctx;
 

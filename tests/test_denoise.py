@@ -104,3 +104,42 @@ def test_hip_denoise_paths_match_oracle(frame, out_size, kw):
     ok = ~nan_o
     assert ok.any() and np.abs(f[ok] - fo[ok]).max() <= 1e-4
     assert np.abs(u.astype(int) - uo.astype(int))[ok].max() <= 1
+
+
+@pytest.mark.gpu
+def test_present_pass_overlapping_the_next_frames_trace_reads_the_right_frame():
+    """Round 6: with two frames in flight the present pass of frame N overlaps the trace of frame N + 1 (other stream, other
+    target); with VRT_TUNE_PRESENT_OWN_STREAM it runs on a stream of its own behind an event of the frame it reads, and the frame after next
+    waits for the pass before it overwrites that target.  A moving camera, twelve frames submitted without a wait, the presented image
+    read after every frame or only at the end: each must equal the image of the same frame presented one frame at a time."""
+    from zig_vulkan_amd import _lib as L
+    from zig_vulkan_amd import workloads as W
+    w = W.Workload("t", 480, 270, 128, 8, 1, 0, True, 5.0)
+    grid = W.build_grid(w)
+    views = ["V0", "V1", "V2", "V1x", "VG", "V2", "V0", "V1", "V1", "VG", "V0", "V2"]
+    serial = W.make_renderer(w, grid, frames_in_flight=1)
+    want = []
+    for v in views:
+        W.set_view(serial, v)
+        serial.draw()
+        want.append(serial.denoise(640, 360).copy())
+    serial.deinit()
+    for reads, flags in (("every", 0), ("last", 0), ("every", L.TUNE_PRESENT_OWN_STREAM), ("last", L.TUNE_PRESENT_OWN_STREAM)):
+        rt = W.make_renderer(w, grid, frames_in_flight=2, tuning_flags=flags)
+        got = []
+        for i, v in enumerate(views):
+            W.set_view(rt, v)
+            rt.draw()
+            if reads == "every":
+                got.append(rt.denoise(640, 360).copy())
+            else:
+                rt.present(640, 360)
+        if reads == "last":
+            rt.wait()
+            last = np.empty((360, 640, 4), dtype=np.uint8)
+            L.check(L.lib.vrt_read_denoised_rgba8(rt._h, last.ctypes.data, last.nbytes))
+            got = [None] * (len(views) - 1) + [last]
+        rt.deinit()
+        for i, (g, x) in enumerate(zip(got, want)):
+            if g is not None:
+                assert np.array_equal(g, x), f"frame {i} ({views[i]}), reads {reads}: the overlapped present pass read another frame"

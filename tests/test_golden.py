@@ -132,3 +132,32 @@ def test_oracle_and_reference_shader_agree_on_configs1_at_full_size(view):
     assert str(a["float_sha256"]) == str(b["float_sha256"]) and str(a["rgba8_sha256"]) == str(b["rgba8_sha256"])
     assert [str(x) for x in a["band_sha256"]] == [str(x) for x in b["band_sha256"]]
     assert "brick_raytracer.comp" in str(b["provenance"])
+
+
+# ---- round 6: the 4K fixtures of the reference shader on the 1024^3 sparse scene (tests/golden/make_ref_golden.py big) ----
+BIG = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_full", "big_*.npz")))
+
+
+@pytest.mark.parametrize("path", BIG, ids=lambda p: os.path.basename(p)[:-4])
+def test_oracle_reproduces_the_reference_shaders_4k_frames(path):
+    """The oracle against the REFERENCE SHADER's 4K frames that pin configs[3]'s and [4]'s kernels (GPU side:
+    tests/test_reference_parity_gpu.py): the two-sample shadow frames whole (float + RGBA8 hashes, every band), the four-sample
+    three-bounce frames on sixteen bands of sixteen rows spread over the frame (the whole frame is 0.1 G rays: VRT_SLOW_TESTS=1)."""
+    from tests.golden.make_golden import scene_digest
+    z = np.load(path)
+    w = W.WORKLOADS[str(z["workload"])]
+    grid = W.build_grid(w)
+    assert scene_digest(grid) == str(z["scene_sha256"]), "synthetic scene generator drifted"
+    assert "brick_raytracer.comp" in str(z["provenance"])
+    scene = oracle_scene_from_grid(grid)
+    height, band = int(z["size"][1]), int(z["band_rows"])
+    whole = int(z["max_bounce"]) == 0 or bool(os.environ.get("VRT_SLOW_TESTS"))
+    if whole:
+        f, u, _ = O.render(scene, z["push_constants"].copy())
+        assert hashlib.sha256(f.tobytes()).hexdigest() == str(z["float_sha256"]) and hashlib.sha256(u.tobytes()).hexdigest() == str(z["rgba8_sha256"])
+        return
+    nb = (height + band - 1) // band
+    for i in range(2, nb, max(1, nb // 16)):
+        f, _, _ = O.render(scene, z["push_constants"].copy(), rows=(i * band, min(height, (i + 1) * band)))
+        rows = f[i * band:(i + 1) * band] if f.shape[0] == height else f
+        assert hashlib.sha256(np.ascontiguousarray(rows).tobytes()).hexdigest() == str(z["band_sha256"][i]), f"band {i}"

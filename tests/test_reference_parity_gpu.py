@@ -137,7 +137,76 @@ def test_kernels_reproduce_the_reference_shader_at_full_size(path):
     assert hashlib.sha256(u.tobytes()).hexdigest() == str(z["rgba8_sha256"])
 
 
+def _assert_is_full_fixture(f, u, z, name):
+    width, height = (int(v) for v in z["size"])
+    band = int(z["band_rows"])
+    crop = z["float_crops"].shape[1]
+    for (y, x), want in zip(z["crop_origins"], z["float_crops"]):
+        got = f[y:y + crop, x:x + crop, :3]
+        n = int((got.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+        assert n == 0, f"{name}: crop at ({x},{y}): {n} pixels differ from the reference shader's"
+    bad = [i for i, y in enumerate(range(0, height, band))
+           if hashlib.sha256(np.ascontiguousarray(f[y:y + band]).tobytes()).hexdigest() != str(z["band_sha256"][i])]
+    assert not bad, f"{name}: bands of {band} rows that differ from the reference shader's frame: {bad[:20]} ({len(bad)} of {len(z['band_sha256'])})"
+    assert hashlib.sha256(f.tobytes()).hexdigest() == str(z["float_sha256"])
+    assert hashlib.sha256(u.tobytes()).hexdigest() == str(z["rgba8_sha256"])
+
+
+BIG_PATH = [p for p in FULL if "big_path_" in p]
+BIG_SHADOW = [p for p in FULL if "big_shadow_" in p]
+
+
+@pytest.mark.parametrize("path", BIG_PATH, ids=lambda p: os.path.basename(p)[:-4])
+@pytest.mark.parametrize("kernels", ["pool", "dil2", "lockstep"])
+def test_the_kernels_of_configs4_reproduce_the_reference_shader_at_4k(path, kernels):
+    """vrt_pool_kernel — the kernel BASELINE configs[4] settles on — and its neighbours against the REFERENCE SHADER's own
+    frame, not only the oracle's: 3840x2160 on a 1024^3 sparse scene of configs[4]'s kind (the largest whose buffers fit GL's 128 MiB
+    storage blocks), 4 samples, 3 bounces, soft sun, rendered by brick_raytracer.comp under llvmpipe (tests/golden/make_ref_golden.py
+    big).  `pool`: the persistent kernels forced (the scene would stay with the lockstep kernel by size): the first frame by
+    vrt_path_kernel<..., DIL 1>, the second — the box of the occupied cells known — by vrt_pool_kernel<8, 6, 60, 2>; BOTH frames must be
+    the reference's, bit for bit (float and RGBA8, every band).  `dil2`: the pool kernel switched off, vrt_path_kernel<..., DIL 2>.
+    `lockstep`: vrt_trace_kernel<8, false, 4, 4, 0, 256>."""
+    import ctypes as C
+    from tests.golden.make_golden import scene_digest
+    z = np.load(path)
+    w = W.WORKLOADS[str(z["workload"])]
+    grid = _GRIDS.get(w.name)
+    if grid is None:
+        _GRIDS.clear()
+        grid = _GRIDS.setdefault(w.name, W.build_grid(w))
+    assert scene_digest(grid) == str(z["scene_sha256"])
+    cfg = dict(pool=dict(kernel_variant=PATH), dil2=dict(kernel_variant=PATH, tuning_flags=L.TUNE_NO_PATH_POOL), lockstep=dict(kernel_variant=LOCKSTEP))[kernels]
+    rt = W.make_renderer(w, grid, want_float_output=True, **cfg)
+    pc = z["push_constants"].tobytes()
+    C.memmove(C.byref(rt.camera.d_camera), pc[:96], 96)
+    C.memmove(C.byref(rt.sun.device_data), pc[96:], 32)
+    names = []
+    for _ in range(2):
+        rt.draw()
+        f, u = rt.read_rgba32f(), rt.read_rgba8()       # (the read waits: the box of the occupied cells has reached the host by the second frame)
+        names.append(rt.kernel_name())
+        _assert_is_full_fixture(f, u, z, names[-1])
+    rt.deinit()
+    if kernels == "pool":
+        assert names[0] in ("vrt_path_kernel<8, 5, false, false, false, false, 1>", "vrt_pool_kernel<8, 6, 60, 2>") and names[1] == "vrt_pool_kernel<8, 6, 60, 2>", names
+    elif kernels == "dil2":
+        assert names[1] == "vrt_path_kernel<8, 5, false, false, false, false, 2>", names
+    else:
+        assert names == ["vrt_trace_kernel<8, false, 4, 4, 0, 256>"] * 2, names
+
+
+@pytest.mark.parametrize("path", BIG_SHADOW, ids=lambda p: os.path.basename(p)[:-4])
+def test_the_kernel_of_configs3_reproduces_the_reference_shader_at_4k(path):
+    """... and vrt_trace_kernel<8, false, 4, 6, 1, 256> — what BASELINE configs[3] runs (4K, 2 samples x (primary + shadow ray), soft sun;
+    128^3 cells: the status bits by words) — against the reference shader's frame of the same 4K / 1024^3 scene."""
+    z = np.load(path)
+    f, u, name = _full_render(z)
+    assert name == "vrt_trace_kernel<8, false, 4, 6, 1, 256>", name
+    _assert_is_full_fixture(f, u, z, name)
+
+
 def test_full_size_fixtures_exist():
+    assert len(BIG_PATH) == 2 and len(BIG_SHADOW) == 2
     names = set(FULL_IDS)
     assert {f"cfg2_r{r}_{v}" for r in (0, 5) for v in ("V0", "V1", "V2")} <= names
     assert {"refapp_V0", "refapp_256x144_V0", "refapp_256x144_V2"} <= names

@@ -55,10 +55,43 @@ while not done:
     done = bench.update(1.0 / fps)
 kernel = rt.kernel_name()
 rt.deinit()
+# pass 3 (round 6): the same path PIPELINED, as a renderer runs — two frames in flight, nothing waited for until the end; host clock over
+# the whole path.  The present pass on the stream of the frame it reads (the default: the next frame traces on the other stream underneath
+# it), on a stream of its own behind an event of that frame (VRT_TUNE_PRESENT_OWN_STREAM, the reference's two queues joined by a semaphore,
+# Pipeline.zig:494-517), and the trace alone (no present pass) for scale.
+import time  # noqa: E402
+from zig_vulkan_amd import _lib as L  # noqa: E402
+
+
+def pipelined(flags, with_present=True):
+    r = W.make_renderer(w, grid, frames_in_flight=2, tuning_flags=flags)
+    b = r.create_benchmark()
+    for _ in range(8):       # (code objects, buffers, clocks)
+        r.draw()
+        if with_present:
+            r.present(pw, ph)
+    r.wait()
+    n, fin = 0, False
+    t0 = time.perf_counter()
+    while not fin:
+        r.draw()
+        if with_present:
+            r.present(pw, ph)
+        n += 1
+        fin = b.update(1.0 / fps)
+    r.wait()
+    dt = time.perf_counter() - t0
+    r.deinit()
+    return dt / n * 1e3
+
+
+pipe = {"two_in_flight_present_on_the_frames_stream_ms": pipelined(0), "two_in_flight_present_on_its_own_stream_ms": pipelined(L.TUNE_PRESENT_OWN_STREAM),
+        "two_in_flight_trace_only_ms": pipelined(0, with_present=False)}
 frame = [a + b for a, b in zip(trace, present)]
 rec = {"workload": w.name, "protocol": "Benchmark.zig:141-172 scripted path, 60 s at a fixed simulated frame rate; Report = min / max / avg frame ms (Benchmark.zig:109-136)",
        "frames": len(trace), "simulated_fps": fps, "present_size": [pw, ph], "timing": "hipEventElapsedTime around each launch",
        "trace": stats(trace), "present": stats(present), "frame_trace_plus_present": stats(frame),
+       "pipelined_avg_frame_ms": pipe, "pipelined_note": "host clock over the whole path / frames, nothing waited for until the end; the serial figures above are per-frame HIP events, one frame at a time",
        "min_frame_ms": min(trace), "max_frame_ms": max(trace), "avg_frame_ms": sum(trace) / len(trace),
        "rays": rays, "Mrays_per_s_trace": rays / (sum(trace) * 1e-3) / 1e6, "kernel": kernel}
 line = json.dumps(rec)

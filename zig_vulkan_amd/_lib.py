@@ -43,6 +43,7 @@ TUNE_NO_DEFERRED_MATERIAL = 131072
 TUNE_NO_CELL_MATERIAL = 262144
 TUNE_GRID_EXIT_ANY_BOX = 524288
 TUNE_NO_BOUNCE_AUTOTUNE = 1048576
+TUNE_PRESENT_OWN_STREAM = 2097152
 TUNE_NO_PATH_POOL = 8192  # frames with bounces on scenes larger than the caches: vrt_path_kernel (a ray per lane) instead of vrt_pool_kernel
 
 # vrt_buffer_id — shader bindings 1..7

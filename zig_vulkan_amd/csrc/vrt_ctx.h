@@ -209,6 +209,12 @@ struct vrt_ctx {
     uint32_t simds = 1024u;
     hipEvent_t ev_region[4] = {}; // vrt_region_begin / _end: {begin, end} on the primary stream, {begin, end} on the second
     hipEvent_t ev_post_start = nullptr, ev_post_stop = nullptr; // around the most recent present / denoise pass (vrt_last_denoise_ms)
+    // Round 6, VRT_TUNE_PRESENT_OWN_STREAM: contexts with two frames in flight run the present pass on a stream of its own, behind an
+    // event of the frame it reads — the reference's graphics queue behind the compute queue's semaphore (Pipeline.zig:494-517); the frame
+    // after next waits for the pass to have read its target (ev_post_done[slot]).  Not the default: see vrt_denoise.
+    hipStream_t stream_post = nullptr;
+    hipEvent_t ev_post_src[2] = {nullptr, nullptr}, ev_post_done[2] = {nullptr, nullptr};
+    bool post_pending[2] = {false, false};
     bool post_timed = false;
     bool in_flight = false;
     bool timing_valid = false;

@@ -268,6 +268,10 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
     const bool slot_b = b_turn && !sched_changes;
     if (slot_b) {
         // second frame slot: its own stream and target; ordered after every scene write so far
+        if (ctx->post_pending[1]) { // (... and after the present pass that still reads this slot's target, round 6)
+            VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->ev_post_done[1], 0));
+            ctx->post_pending[1] = false;
+        }
         if (ctx->b_seen_upload != ctx->upload_seq) {
             VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->ev_upload, 0));
             ctx->b_seen_upload = ctx->upload_seq;
@@ -303,6 +307,10 @@ static int do_dispatch(vrt_ctx *ctx, const vrt_camera_device *camera, const vrt_
         // timed back-to-back launches: do not let a frame on the other stream run underneath them
         VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_b_done, 0));
         ctx->b_pending = false;
+    }
+    if (ctx->post_pending[0]) { // (the present pass on its own stream may still be reading the primary target, round 6)
+        VRT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_post_done[0], 0));
+        ctx->post_pending[0] = false;
     }
     VRT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     const uint32_t nt = ctx->shard.owned_tiles;
@@ -446,6 +454,10 @@ int vrt_wait(vrt_ctx *ctx) {
     if (ctx->stream_b) {
         VRT_HIP(ctx, wait_stream(ctx->stream_b));
         ctx->b_pending = false;
+    }
+    if (ctx->stream_post) { // (the present passes issued so far)
+        VRT_HIP(ctx, wait_stream(ctx->stream_post));
+        ctx->post_pending[0] = ctx->post_pending[1] = false;
     }
     return VRT_OK;
 }

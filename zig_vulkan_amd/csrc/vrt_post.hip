@@ -313,11 +313,31 @@ int vrt_denoise(vrt_ctx *ctx, const vrt_denoise_config *cfg, uint32_t out_w, uin
     if (cfg) c = *cfg;
     if (c.samples < 0 || c.samples > 4096) return fail(ctx, VRT_E_INVALID_ARG, "samples out of range");
     DeviceGuard dg(ctx->device);
-    // runs on the stream that rendered the most recent frame, so it is ordered after that frame
-    const hipStream_t s = (ctx->last_slot == 1) ? ctx->stream_b : ctx->stream;
+    // On the stream that rendered the most recent frame, so it is ordered after that frame; with two frames in flight the next frame — on
+    // the other stream, into the other target — traces underneath it.  VRT_TUNE_PRESENT_OWN_STREAM: on the present stream, behind an event
+    // of that frame (the reference's arrangement: graphics queue behind the compute queue's semaphore, Pipeline.zig:494-517).
+    const int slot = ctx->last_slot == 1 ? 1 : 0;
+    const hipStream_t frame_stream = slot ? ctx->stream_b : ctx->stream;
+    // (... measured, round 6: the pass on the frame's OWN stream overlaps the next frame's trace just as well — that frame runs on the
+    // other stream — and the present stream's two extra cross-stream waits per frame cost 3-12 %: headline fly-through, two frames in
+    // flight, 0.165 ms per frame on the frame's stream against 0.184 on the present stream (one frame at a time: 0.198); the arrangement
+    // stays behind VRT_TUNE_PRESENT_OWN_STREAM, profiles/r06_present_overlap.txt)
+    const bool overlap = ctx->stream_b && (ctx->cfg.tuning_flags & VRT_TUNE_PRESENT_OWN_STREAM);
+    hipStream_t s = frame_stream;
+    if (overlap) {
+        if (!ctx->stream_post) {
+            VRT_HIP(ctx, ctx->res.stream(&ctx->stream_post));
+            for (int k = 0; k < 2; k++) {
+                VRT_HIP(ctx, ctx->res.event(&ctx->ev_post_src[k], hipEventDisableTiming));
+                VRT_HIP(ctx, ctx->res.event(&ctx->ev_post_done[k], hipEventDisableTiming));
+            }
+        }
+        s = ctx->stream_post;
+    }
     if (ctx->denoised_w != out_w || ctx->denoised_h != out_h || (want_float && !ctx->d_denoised32f)) {
         VRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->stream_b) VRT_HIP(ctx, hipStreamSynchronize(ctx->stream_b));
+        if (ctx->stream_post) VRT_HIP(ctx, hipStreamSynchronize(ctx->stream_post));
         ctx->res.drop(ctx->d_denoised8);
         ctx->res.drop(ctx->d_denoised32f);
         VRT_HIP(ctx, ctx->res.device(&ctx->d_denoised8, (size_t)out_w * out_h * 4u));
@@ -325,11 +345,19 @@ int vrt_denoise(vrt_ctx *ctx, const vrt_denoise_config *cfg, uint32_t out_w, uin
         ctx->denoised_w = out_w;
         ctx->denoised_h = out_h;
     }
-    const void *img = (ctx->last_slot == 1) ? ctx->target8_b : ctx->target8;
+    const void *img = slot ? ctx->target8_b : ctx->target8;
+    if (overlap) {
+        VRT_HIP(ctx, hipEventRecord(ctx->ev_post_src[slot], frame_stream));
+        VRT_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_post_src[slot], 0));
+    }
     VRT_HIP(ctx, hipEventRecord(ctx->ev_post_start, s));
     VRT_HIP(ctx, vrt::launch_denoise(img, (int)ctx->cfg.width, (int)ctx->cfg.height, c.samples, c.distribution_bias, c.pixel_multiplier,
                                      c.inverse_hue_tolerance, (int)out_w, (int)out_h, ctx->d_denoised8, want_float ? ctx->d_denoised32f : nullptr, s));
     VRT_HIP(ctx, hipEventRecord(ctx->ev_post_stop, s));
+    if (overlap) { // (the next frame into this target waits until the pass has read it: do_dispatch)
+        VRT_HIP(ctx, hipEventRecord(ctx->ev_post_done[slot], s));
+        ctx->post_pending[slot] = true;
+    }
     ctx->post_timed = true;
     ctx->denoised_stream = s;
     return VRT_OK;
