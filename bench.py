@@ -403,6 +403,9 @@ class _StubRT:
         return {"rank": int(os.environ.get("RANK", "0")), "world": int(os.environ.get("WORLD_SIZE", "1")), "frames_per_launch": self.batch,
                 "launches_in_flight": 1}
 
+    def dist_comm_info(self):
+        return {"communicators": 1, "made_by_this_init": 1, "library_splits": False, "agreed_by_all_reduce": False}
+
     def dist_stats(self):
         return {"launches_sampled": 4, "frames_sampled": 4 * self.batch, "kernel_ms_per_launch": self.frame_s * 1e3 * self.batch,
                 "collective_ms_per_launch": 0.01, "unswizzle_ms_per_launch": 0.005, "owned_tiles": 10, "shard_bytes_per_frame": 7680,
@@ -489,6 +492,32 @@ class Env:
         self.args, self.torch, self.dist = args, torch, dist
         self.world, self.rank, self.local_rank, self.dev, self.stub, self.use_dist = world, rank, local_rank, dev, stub, use_dist
         self.multi = use_dist and world > 1
+        self._uid = None       # the ONE RCCL unique id of this run: every context's communicators come from the library's pool under it
+
+    def shared_uid(self):
+        """Rank 0 makes the id once, every rank gets it by one broadcast; later contexts pass the same id, and with
+        vrt_dist_keep_communicators(1) the library hands them the communicators earlier contexts made (round 6: a run makes a dozen
+        contexts — one per root-share candidate and leg — and a communicator set costs a collective of the order of a second)."""
+        if self._uid is None:
+            uid = None
+            if self.rank == 0:
+                try:
+                    if self.stub:
+                        uid = b"stub"
+                    else:
+                        from zig_vulkan_amd import VoxelRT
+                        VoxelRT.dist_keep_communicators(True)
+                        uid = VoxelRT.dist_unique_id()
+                except Exception as e:  # noqa: BLE001
+                    print(f"[bench rank 0] no RCCL unique id: {type(e).__name__}: {e}", file=sys.stderr)
+            elif not self.stub:
+                try:
+                    from zig_vulkan_amd import VoxelRT
+                    VoxelRT.dist_keep_communicators(True)
+                except Exception as e:  # noqa: BLE001
+                    print(f"[bench rank {self.rank}] vrt_dist_keep_communicators: {type(e).__name__}: {e}", file=sys.stderr)
+            self._uid = (self.bcast(uid),)    # (a tuple: None — rank 0 failed — is an answer too, and is not asked for again)
+        return self._uid[0]
 
     def sync(self) -> None:
         if not self.stub:
@@ -536,6 +565,7 @@ class Leg:
         import ctypes as C
         self.env, self.W, self.w, self.sharded, self.batch, self.root_share = env, W, w, sharded, batch, root_share
         self.native, self.fg, self.rt, self.dist_info, self.rccl_world = False, None, None, None, None
+        self.comm_info = None
         self.launches_in_flight = None
         self.frame_no = 0
         args, stub, rank, world = env.args, env.stub, env.rank, env.world
@@ -544,17 +574,7 @@ class Leg:
             ok = 1
             # (rank 0 makes the id inside its own guard and every rank executes the broadcast whatever happened: a rank that skipped
             # it would sit in all_min_int's all-reduce while the others sit in the broadcast — ADVICE r03)
-            uid = None
-            if rank == 0:
-                try:
-                    if stub:
-                        uid = b"stub"
-                    else:
-                        from zig_vulkan_amd import VoxelRT
-                        uid = VoxelRT.dist_unique_id()
-                except Exception as e:  # noqa: BLE001
-                    print(f"[bench rank 0] no RCCL unique id: {type(e).__name__}: {e}", file=sys.stderr)
-            uid = env.bcast(uid)
+            uid = env.shared_uid()
             try:
                 if uid is None:
                     raise RuntimeError("rank 0 could not make a RCCL unique id")
@@ -567,10 +587,11 @@ class Leg:
                 # overlap — rank 1 of 8 over the RCCL stand-in: 40.6 us per frame with 4 launches in flight, 30.9 with 8, 26.0 with 16 on the runtime's default 4
                 # hardware queues; 21.2 / 22.8 / 16.2 on 24 queues, tools/experiments/literal_leg_probe.py)
                 self.launches_in_flight = args.dist_frames if (batch > 1 or world == 1) else max(args.dist_frames, min(16, args.literal_launches))
-                self.rt.dist_init(uid, rank, world, self.launches_in_flight, frames_per_launch=(batch if world > 1 else 1))
+                self.rt.dist_init(uid, rank, world, self.launches_in_flight, frames_per_launch=(batch if world > 1 else 1), communicators=args.dist_comms)
                 if world == 1:
                     self.rt.dist_selftest()
                 self.dist_info = self.rt.dist_info()
+                self.comm_info = self.rt.dist_comm_info()
             except Exception as e:  # noqa: BLE001 - any failure means "use the torch path"
                 print(f"[bench rank {rank}] native RCCL pipeline unavailable: {e}", file=sys.stderr)
                 ok = 0
@@ -789,6 +810,9 @@ def main(argv=None) -> None:
     ap.add_argument("--dist-frames", type=int, default=4, help="launches in flight per rank of the native multi-GPU pipeline")
     ap.add_argument("--hw-queues", type=int, default=0, help="N > 1: GPU_MAX_HW_QUEUES of the HIP runtime (0: leave it; the environment wins)")
     ap.add_argument("--literal-launches", type=int, default=8, help="launches in flight per rank of the one-gather-per-frame leg (at most 16)")
+    ap.add_argument("--dist-comms", type=int, default=0,
+                    help="native multi-GPU pipeline: RCCL communicators the launch slots issue their gathers on (0: one per slot, at most 8 — RCCL runs "
+                         "the operations of one communicator in issue order; 1: all on one, the round-5 pipeline)")
     ap.add_argument("--dist-batch", type=int, default=8,
                     help="frames traced by one launch and carried by one collective in the batched leg when world > 1 (every frame is gathered "
                          "once); the north_star-literal leg, one collective per frame, is always timed as well")
@@ -957,6 +981,7 @@ def main(argv=None) -> None:
         legs_out[name] = {"value": rays_of(per_view, args.steps) / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt / args.steps * 1e3,
                           "frames_per_collective": leg.batch, "launches_in_flight": leg.launches_in_flight,
                           "root_share_percent": leg.root_share if leg.native else None,
+                          "communicators": leg.comm_info if leg.native else None,
                           "dist_path": ("native" if leg.native else "torch") if sharded else None,
                           "breakdown": leg.breakdown(2 * args.dist_frames)}
     sustained = None
@@ -1290,6 +1315,12 @@ def main(argv=None) -> None:
                 out["cpu_baseline"] = port
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     leg.close()
+    if sharded and not stub:
+        try:      # (every rank, at the same point: the pooled communicators are destroyed by a collective)
+            from zig_vulkan_amd import VoxelRT
+            VoxelRT.dist_release_communicators()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench rank {rank}] vrt_dist_release_communicators: {type(e).__name__}: {e}", file=sys.stderr)
     if use_dist:
         dist.destroy_process_group()
 

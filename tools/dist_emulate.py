@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--model", default="1:2", help="the stand-in's cost model ORDER:WORKGROUPS_PER_OPERATION (0:0: none)")
     ap.add_argument("--comms", type=int, default=0, help="communicators of the pipeline's launch slots (0: one per slot up to 8; 1: one)")
+    ap.add_argument("--partner-priority", type=int, default=0,
+                    help="stream priority of the OTHER side's operations (the consumer of a peer's shards, the feeder of the root's): they run on the same GPU "
+                         "here and share the runtime's hardware queues with the rank under test; -1: high priority (a queue of their own)")
     args = ap.parse_args()
     model = tuple(int(x) for x in args.model.split(":"))
     w = W.WORKLOADS[args.workload]
@@ -162,7 +165,7 @@ def main():
                 C.memmove(C.byref(u), uid, 128)
                 fam0 = comm_family(u, world, 0, ncomms)
                 sink = torch.zeros(batch * shard_bytes, dtype=torch.uint8, device="cuda")
-                sink_stream = torch.cuda.Stream()
+                sink_stream = torch.cuda.Stream(priority=args.partner_priority)
                 launch_no = [0]
 
                 def consume(frames):
@@ -194,7 +197,7 @@ def main():
                 C.memmove(C.byref(u), uid, 128)
                 fams = [comm_family(u, world, r, ncomms) for r in range(1, world)]
                 dummy = torch.zeros(batch * shard_bytes, dtype=torch.uint8, device="cuda")
-                feeder_stream = torch.cuda.Stream()
+                feeder_stream = torch.cuda.Stream(priority=args.partner_priority)
                 launch_no = [0]
 
                 def feed(frames):
