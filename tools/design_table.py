@@ -38,7 +38,8 @@ for name, label in ROWS:
     print(f"| {label} | {d['value'] / 1e3:.2f} | {d['ms_per_step']:.4f} / {d['ms_per_step_single_stream']:.4f} | "
           + " / ".join(sig(kv[v]) for v in ("V0", "V1", "V2", "V1x", "VG") if v in kv)
           + f" | {frac} | {r['frac_issued']:.2f} | {r.get('lane_util', 0):.2f} | {r['valu_frac']:.2f} | {r['issue_slots_frac']:.2f} | {tr} | "
-          + (f"{pp['us_median']:.0f} µs (frac {pp['frac']:.2f})" if pp else "n/a") + f" | {cpus} | `{r['kernel']}` |")
+          + (f"{pp['us_median']:.0f} µs (issue-bound: byte model void)" if pp and not pp.get("frac_model_valid", True) else (f"{pp['us_median']:.0f} µs (frac {pp['frac']:.2f})" if pp else "n/a"))
+          + f" | {cpus} | `{r['kernel']}` |")
 d = load("bench_driver_protocol_steps20")
 print(f"\ndriver protocol: {d['value'] / 1e3:.1f} Grays/s by the host's clock, {d['value_device_events'] / 1e3:.1f} by device events, "
       f"{d['value_sustained']['value'] / 1e3:.1f} sustained; ms_per_step {d['ms_per_step']:.4f}")
@@ -46,4 +47,5 @@ for name in ("flythrough_refapp", "flythrough_headline"):
     f = load(name)
     t, p, fr = f["trace"], f["present"], f["frame_trace_plus_present"]
     print(f"{name}: trace {t['min_ms']:.3f} / {t['max_ms']:.3f} / {t['avg_ms']:.3f} | present {p['avg_ms']:.3f} | frame {fr['min_ms']:.3f} / {fr['max_ms']:.3f} / "
-          f"{fr['avg_ms']:.3f} | {f['frames']} frames, {f['Mrays_per_s_trace'] / 1e3:.2f} Grays/s over the path")
+          f"{fr['avg_ms']:.3f} | {f['frames']} frames, {f['Mrays_per_s_trace'] / 1e3:.2f} Grays/s over the path"
+          + (f" | pipelined (two frames in flight, host clock): {f['pipelined_avg_frame_ms']}" if f.get("pipelined_avg_frame_ms") else ""))

@@ -6,10 +6,11 @@
 #   part "fly":      the reference's own benchmark protocol (tools/flythrough.py) on the app's run and on the headline workload;
 #   part "cfg4":     the 2048^3 path trace's phase profile (make prof) and its fabric traffic by kernel (tools/pmc_traffic.sh);
 #   part "soak":     determinism soak (tools/soak.py).
+#   part "fuzz":     randomised parity fuzz against the oracle (tools/fuzz_parity.py): general, big frames, pow2, pool.
 # usage: tools/evidence.sh <tag> [part ...]        (default: every part)      -> gpurun_out/evidence_<tag>/
 set -u
 TAG=${1:-r05}; shift || true
-PARTS=${*:-"bench driver fly cfg4 soak"}
+PARTS=${*:-"bench driver fly cfg4 soak fuzz"}
 FAILED=""
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/evidence_$TAG
@@ -45,6 +46,12 @@ for part in $PARTS; do
     cd $ROOT
     { timeout 600 python tools/soak.py 1500; timeout 600 python tools/soak.py 600 $APP 1; timeout 600 python tools/soak.py 600 $APP 2; timeout 600 python tools/soak.py 300 cfg3_4k_1024c_b8 2;
       timeout 900 python tools/soak.py 45 cfg4_4k_2048c_b8_sparse 2; } 2>&1 | grep -v amdgpu > $OUT/${TAG}_soak.txt; cat $OUT/${TAG}_soak.txt | cut -c1-120 ;;
+  fuzz)
+    cd $ROOT
+    { for seed in 6101 6102 6103; do timeout 900 python tools/fuzz_parity.py 1000 $seed 2>&1 | tail -1; done
+      timeout 900 python tools/fuzz_parity.py 400 6201 big 2>&1 | tail -1
+      timeout 900 python tools/fuzz_parity.py 1000 6301 pow2 2>&1 | tail -1
+      for seed in 6401 6402; do timeout 900 python tools/fuzz_parity.py 1000 $seed pool 2>&1 | tail -1; done; } | grep -v amdgpu > $OUT/${TAG}_fuzz.txt; cat $OUT/${TAG}_fuzz.txt | cut -c1-200 ;;
   esac
 done
 ls -la $OUT
