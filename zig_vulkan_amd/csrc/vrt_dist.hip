@@ -576,8 +576,9 @@ void dist_destroy(vrt_ctx *ctx) {
         bool idle = !set->poisoned;
         for (bool b : set->busy) idle = idle && !b;
         if (idle && !g_keep_comms) {
+            const auto it = std::find(g_comm_sets.begin(), g_comm_sets.end(), set);
+            if (it != g_comm_sets.end()) g_comm_sets.erase(it);
             destroy_set(set);
-            g_comm_sets.erase(std::find(g_comm_sets.begin(), g_comm_sets.end(), set));
         }
     }
     delete d;
