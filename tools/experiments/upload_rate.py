@@ -24,3 +24,25 @@ for y in range(40, 200):
 t0 = time.perf_counter(); rt.update_grid_delta(); rt.draw(); rt.wait(); dt = time.perf_counter() - t0
 print(f"delta upload of a 160-voxel edit + one frame: {dt * 1e3:.3f} ms")
 rt.deinit()
+# The other direction (round 6): frames handed back to the host through the boundary's vrt_read_rgba8 (8.3 MB per 1080p frame over PCIe),
+# the hand-off a host WITHOUT device interop uses — never part of bench.py's `value`.
+rt = W.make_renderer(w, grid, frames_in_flight=2)
+rays = {}
+cnt = W.make_renderer(w, grid, enable_counters=True)
+for v in ("V0", "V1", "V2"):
+    W.set_view(cnt, v); cnt.draw(); rays[v] = cnt.counters()["rays"]
+cnt.deinit()
+for _ in range(20):
+    rt.draw(); rt.read_rgba8()
+n, total = 300, 0
+t0 = time.perf_counter()
+for i in range(n):
+    v = ("V0", "V1", "V2")[i % 3]
+    W.set_view(rt, v)
+    rt.draw()
+    rt.read_rgba8()          # waits for the frame, copies it to host memory
+    total += rays[v]
+dt = time.perf_counter() - t0
+print(f"{n} frames each read back to the host (vrt_read_rgba8): {dt / n * 1e3:.3f} ms per frame = {total / dt / 1e9:.2f} Grays/s PCIe-inclusive "
+      f"({w.width * w.height * 4 / (dt / n) / 1e9:.1f} GB/s of pixels)")
+rt.deinit()
