@@ -213,3 +213,18 @@ def test_native_probe_turns_a_failing_or_hanging_child_into_the_torch_path(monke
     assert ok is expect_ok and report["ok"] is expect_ok
     assert expect_text in report["this_rank"]
     assert report["seconds"] < 30
+
+
+def test_profile_summariser_fails_loudly_without_the_per_phase_split(tmp_path):
+    """VERDICT r05 (evidence regression): round 5's summaries lost the "launches by bench.py phase" section silently because the evidence
+    script wrote the bench line where the summariser did not look.  With --require-phases the summariser now exits non-zero when it cannot
+    print that section (no bench line found here: an empty directory), and says so in its output."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "summarize_prof.py"), str(tmp_path), "--require-phases"], capture_output=True, text=True)
+    assert r.returncode == 2 and "NO bench line found" in r.stdout and "no phase split was printed" in r.stdout
+    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "summarize_prof.py"), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "NO bench line found" in r.stdout      # (without the flag: a warning in the summary)
+    sh = open(os.path.join(root, "tools", "evidence.sh")).read()
+    assert "--bench-line $OUT/$W/bench.json --require-phases" in sh and "exit 3" in sh
