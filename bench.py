@@ -282,13 +282,20 @@ def dist_probe_child(args) -> None:
     inside the pipeline — each on its own communicator.  Rank 0 compares every assembled frame with the frame one context renders
     alone.  Exit code 0 = this rank got through.  No torch import; nothing on stdout."""
     import numpy as np
+    from zig_vulkan_amd import VoxelRT
     from zig_vulkan_amd import workloads as W
     uids = bytes.fromhex(args.probe_uid)
     rank, world, device = args.probe_rank, args.probe_world, args.probe_device
-    cases = [(W.Workload("probe", 332, 210, 64, 4, 1, 0, True, 0.0), 0, 1), (W.Workload("probe", 332, 210, 64, 4, 1, 0, True, 0.0), 0, 8),
-             (W.Workload("probe_bounce", 330, 210, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000), 1 << 23, 1)]
-    grids = {}
-    for i, (w, variant, batch) in enumerate(cases):
+    plain_w = W.Workload("probe", 332, 210, 64, 4, 1, 0, True, 0.0)
+    # (workload, kernel_variant, frames per collective, launch slots, which of the three ids, keep the context alive for the next case)
+    # Round 6: the cases go through the communicator pool the way the timed legs do — one id for several contexts
+    # (vrt_dist_keep_communicators), a second context made while the first still holds its communicators (the root-share tune keeps three
+    # alive), a third that takes everything from the pool — so that a hang in that machinery is this child's timeout, not the run's.
+    cases = [(plain_w, 0, 1, 8, 0, True), (plain_w, 0, 8, 4, 0, False), (plain_w, 0, 1, 8, 0, False),
+             (W.Workload("probe_bounce", 330, 210, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000), 1 << 23, 1, 4, 1, False)]
+    VoxelRT.dist_keep_communicators(True)
+    grids, held = {}, []
+    for i, (w, variant, batch, slots, which, hold) in enumerate(cases):
         grid = grids.setdefault(w.name, W.build_grid(w))
         ref = None
         if rank == 0:
@@ -298,7 +305,7 @@ def dist_probe_child(args) -> None:
             ref = plain.read_rgba8().copy()
             plain.deinit()
         rt = W.make_renderer(w, grid, device_id=device, shard_rank=rank, shard_count=world, kernel_variant=variant)
-        rt.dist_init(uids[128 * i:128 * (i + 1)], rank, world, 4, frames_per_launch=batch)
+        rt.dist_init(uids[128 * which:128 * (which + 1)], rank, world, slots, frames_per_launch=batch, communicators=args.dist_comms)
         for v in PROBE_FRAMES:
             W.set_view(rt, v)
             rt.dist_frame()
@@ -306,7 +313,14 @@ def dist_probe_child(args) -> None:
         if rank == 0 and not np.array_equal(rt.dist_read_frame(), ref):
             print(f"[bench probe] case {i} ({w.name}, batch {batch}): the assembled frame differs from the single-context frame", file=sys.stderr)
             sys.exit(3)
-        rt.deinit()
+        if hold:
+            held.append(rt)
+        else:
+            rt.deinit()
+            for h in held:
+                h.deinit()
+            held = []
+    VoxelRT.dist_release_communicators()
     sys.exit(0)
 
 
@@ -325,7 +339,7 @@ def native_probe(env, timeout: float):
     if uids is None:
         return False, {"ok": False, "seconds": 0.0, "this_rank": "rank 0 could not make a RCCL unique id"}
     cmd = [sys.executable, os.path.abspath(__file__), "--dist-probe", "--probe-uid", uids.hex(), "--probe-rank", str(env.rank),
-           "--probe-world", str(env.world), "--probe-device", str(env.local_rank)]
+           "--probe-world", str(env.world), "--probe-device", str(env.local_rank), "--dist-comms", str(env.args.dist_comms)]
     child_env = {k: v for k, v in os.environ.items()
                  if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
                  and not k.startswith("TORCHELASTIC_")}

@@ -745,9 +745,10 @@ def test_every_launch_slot_at_once_on_real_rccl(slots, communicators):
 
 def test_bench_probe_child_runs_the_native_pipeline_on_real_rccl():
     """bench.py --dist-probe, the child process by which the N > 1 bench tries the native RCCL pipeline before it trusts it: here
-    with one rank (RCCL refuses two ranks on one device) — communicators from three unique ids: one and eight frames per collective,
-    and (round 5) a small path trace whose bounce frames the persistent kernels trace inside the pipeline; every assembled frame
-    compared with a single context's."""
+    with one rank (RCCL refuses two ranks on one device) — one and eight frames per collective, and (round 5) a small path trace whose
+    bounce frames the persistent kernels trace inside the pipeline; every assembled frame compared with a single context's.  Round 6:
+    the cases share ONE unique id through the library's communicator pool the way the timed legs do (a context made while another holds
+    its communicators, one that takes everything from the pool), a communicator per launch slot."""
     import subprocess
     import sys
     from zig_vulkan_amd import VoxelRT
