@@ -197,7 +197,7 @@ def main_full(only=()):
 # kind of scene as configs[4] at the largest size that fits (1024^3 voxels, 8^3 bricks, the sparse field, 80 000 brick slots: 128^3 = 2 M
 # cells -> the word-mode kernels, occupied cells reach the grid's faces -> vrt_pool_kernel applies), rendered by the reference shader
 # under llvmpipe with (a) 4 samples, 3 bounces (device value), soft sun — a path trace: vrt_pool_kernel, vrt_path_kernel<DIL 1 / 2>, the
-# lockstep bounce kernel; (b) 2 samples, no bounce, soft sun — configs[3]'s ray mix: vrt_trace_kernel<8, false, 4, 6, 1, 256>.
+# lockstep bounce kernel; (b) 2 samples, no bounce, soft sun — configs[3]'s ray mix: vrt_trace_kernel<8, false, 4, 7, 1, 256> (until round 6's last change: <..., 6, 1, 256>).
 BIG = W.WORKLOADS["refbig_4k_1024c_b8_sparse"]
 
 

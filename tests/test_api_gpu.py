@@ -173,7 +173,7 @@ def test_kernel_name_is_the_symbol_that_ran():
     rt.camera.d_camera.samples_per_pixel = 3
     rt.draw()
     rt.wait()
-    assert rt.kernel_name() == "vrt_trace_kernel<8, false, 7, 6, 1, 256>"      # several samples
+    assert rt.kernel_name() == "vrt_trace_kernel<8, false, 7, 7, 1, 256>"      # several samples
     rt.camera.d_camera.max_bounce = 3
     rt.draw()
     rt.wait()

@@ -197,11 +197,11 @@ def test_the_kernels_of_configs4_reproduce_the_reference_shader_at_4k(path, kern
 
 @pytest.mark.parametrize("path", BIG_SHADOW, ids=lambda p: os.path.basename(p)[:-4])
 def test_the_kernel_of_configs3_reproduces_the_reference_shader_at_4k(path):
-    """... and vrt_trace_kernel<8, false, 4, 6, 1, 256> — what BASELINE configs[3] runs (4K, 2 samples x (primary + shadow ray), soft sun;
+    """... and vrt_trace_kernel<8, false, 4, 7, 1, 256> — what BASELINE configs[3] runs (4K, 2 samples x (primary + shadow ray), soft sun;
     128^3 cells: the status bits by words) — against the reference shader's frame of the same 4K / 1024^3 scene."""
     z = np.load(path)
     f, u, name = _full_render(z)
-    assert name == "vrt_trace_kernel<8, false, 4, 6, 1, 256>", name
+    assert name == "vrt_trace_kernel<8, false, 4, 7, 1, 256>", name
     _assert_is_full_fixture(f, u, z, name)
 
 

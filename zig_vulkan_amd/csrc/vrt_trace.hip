@@ -570,9 +570,11 @@ KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t varian
             if (!e && mw_asked == 5u) e = find_trace_kernel(brick_dimension, false, mode, kDefaultMinWaves, 0, block); // (5 is the path kernel's: product default)
         }
     } else {
-        // (the several-samples-per-pixel kernel, shade 1, needs 87 VGPRs left to itself = 5 waves per SIMD; held to 80 it spills
-        // 36 bytes outside the loops and runs at 6: 4K / 1024^3 / 4 rays per pixel 1.215 -> 1.183 ms per frame)
-        int mw1 = 6;
+        // (the several-samples-per-pixel kernel, shade 1, needs 87 VGPRs left to itself = 5 waves per SIMD; held to 80 it spilled
+        // 36 bytes outside the loops and ran at 6: 4K / 1024^3 / 4 rays per pixel 1.215 -> 1.183 ms per frame.  Round 6: its per-lane
+        // set-up values are formed again from the lane index where they are needed and one hoisted uniform product is kept scalar: 72
+        // VGPRs without a spill = SEVEN waves per SIMD, 5 % faster than six on every view of that workload)
+        int mw1 = 7;
 #ifdef VRT_DEV_VARIANTS
         if (const char *ev = std::getenv("VRT_DEV_SHADE1_WAVES")) mw1 = std::atoi(ev); // (tuning builds: 5 and 7 for 8^3 bricks)
 #endif

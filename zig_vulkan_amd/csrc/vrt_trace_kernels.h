@@ -1281,6 +1281,12 @@ VRT_DI bool skip_to_box(Walk &w, const RaySetup &s, int span_x, int span_y, int 
 #include "vrt_trace_kernels_dev.h"
 #undef VRT_DEV_SECTION
 #endif
+// A wave-uniform float the optimiser may not move out of a loop (empty asm pinned to an SGPR).
+VRT_DI float opaque_uniform(float v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+VRT_DI f3 opaque_uniform3(const float (&v)[3]) { return mk3(opaque_uniform(v[0]), opaque_uniform(v[1]), opaque_uniform(v[2])); }
 // comp:271-376.  t_min = 1e-5, t_max = +inf at every call site (comp:218,247).
 // BATCH (used for frames with bounces, whose secondary rays are incoherent): a lane that reaches an
 // occupied cell does not walk its brick at once but waits (__ballot) until p.brick_batch lanes are waiting or
@@ -1289,7 +1295,9 @@ VRT_DI bool skip_to_box(Walk &w, const RaySetup &s, int span_x, int span_y, int 
 // gives +8.5 % there, larger thresholds stall the moving lanes and lose).  The per-lane
 // sequence of operations is unchanged; only their interleaving across lanes differs.
 
-template <int B, bool COUNT, int MODE, bool BATCH = false>
+// SCALAR_ENTRY: the grid-entry offset 0.0001 * scale (comp:287) formed where it is used (the several-samples kernel; the one-sample
+// kernels measured 0.5 % slower with it and keep the compiler's placement)
+template <int B, bool COUNT, int MODE, bool BATCH = false, bool SCALAR_ENTRY = false>
 VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray &r, Hit &hit, Cnt<COUNT> &c) {
     const float t_min = 0.00001f;
     const float t_max = __builtin_inff();
@@ -1305,7 +1313,9 @@ VRT_DI bool grid_hit(const TraceParams &p, const uint32_t *lds_filter, const Ray
     const float g_scale = p.grid.max_point_scale[3];
     const int dx = (int)p.grid.dim_x, dy = (int)p.grid.dim_y, dz = (int)p.grid.dim_z;
 
-    float global_t_value = s.grid_t_min + 0.0001f * g_scale; // comp:287
+    // (opaque: the product of a uniform is formed where it is used, from its scalar register — hoisted out of the sample loop it was the one
+    // vector register the several-samples kernel spilled at seven waves per SIMD, round 6)
+    float global_t_value = s.grid_t_min + 0.0001f * (SCALAR_ENTRY ? opaque_uniform(g_scale) : g_scale); // comp:287
     const f3 fposition = p.scale_pow2 ? (ray_at(r, global_t_value) - g_min) * p.inv_grid_scale : (ray_at(r, global_t_value) - g_min) / splat3(g_scale);
     Walk w;
     w.side_dist = initial_side_dist(mk3((float)s.sx, (float)s.sy, (float)s.sz), fposition, s.ray_delta());
@@ -1636,14 +1646,14 @@ VRT_DI bool scatter_dielectric(float ir, const Ray &r_in, const Hit &hit, Ray &s
 // comp:203-265 when push_constant.max_bounce <= 1 (Camera.Config.max_bounce = 0: "only primary
 // ray", Camera.zig:74).  The bounce loop then runs at most once, so the scatter functions — whose only
 // products are the next ray and the continue flag — have no observable effect and are not evaluated.
-template <int B, bool COUNT, int MODE>
+template <int B, bool COUNT, int MODE, bool SCALAR_ENTRY = false>
 VRT_DI f3 ray_color_single(const TraceParams &p, const PushConstants &pc, const uint32_t *lds_filter, const Ray &ray, Cnt<COUNT> &c) {
     const bool sun_enabled = pc.sun.enabled > 0;
     const f3 sun_color = mk3(pc.sun.color[0], pc.sun.color[1], pc.sun.color[2]);
     f3 color = mk3(0, 0, 0);
     int loop_count = 0;
     Hit hit;
-    if (pc.cam.max_bounce > 0 && grid_hit<B, COUNT, MODE>(p, lds_filter, ray, hit, c)) {
+    if (pc.cam.max_bounce > 0 && grid_hit<B, COUNT, MODE, false, SCALAR_ENTRY>(p, lds_filter, ray, hit, c)) {
         // (the material record is read AFTER the shadow ray: only its index stays live across the second walk — three registers
         // fewer at the kernel's point of highest pressure; the record sits in the scalar / L1 cache)
         const uint32_t material = hit.index;
@@ -1654,7 +1664,7 @@ VRT_DI f3 ray_color_single(const TraceParams &p, const PushConstants &pc, const 
                                           pc.sun.radius);
             const Ray shadow_ray = create_ray(hit.point, (sun_position + rv) - hit.point);
             Hit shadow_hit;
-            lit = !grid_hit<B, COUNT, MODE>(p, lds_filter, shadow_ray, shadow_hit, c);
+            lit = !grid_hit<B, COUNT, MODE, false, SCALAR_ENTRY>(p, lds_filter, shadow_ray, shadow_hit, c);
         }
         const vrt_material *m = p.materials + material;
         const uint32_t mtype = m->type;
@@ -1747,12 +1757,6 @@ VRT_DI uint32_t xcd_slice_index(uint32_t b, uint32_t n) {
 }
 
 // comp:153-178
-// A wave-uniform float the optimiser may not move out of a loop (empty asm pinned to an SGPR).
-VRT_DI float opaque_uniform(float v) {
-    asm volatile("" : "+s"(v));
-    return v;
-}
-VRT_DI f3 opaque_uniform3(const float (&v)[3]) { return mk3(opaque_uniform(v[0]), opaque_uniform(v[1]), opaque_uniform(v[2])); }
 
 // This lane's index in its wave from the hardware, by an instruction the optimiser may neither hoist nor merge with an earlier
 // copy: what is derived from it (the pixel's place in its tile, its coordinates, its address) is formed again where it is needed
@@ -1904,7 +1908,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
                 const float noise_y = hash_12_jitter(x, y + (float)sample_i, flag);
                 const float v = (y + noise_y) / (float)(pc.cam.image_height - 1u);
                 const f3 ray_dir = fma3(horizontal, splat3(u), llc) + fma3(splat3(v), vertical, -origin);
-                if constexpr (SHADE == 1) color = color + ray_color_single<B, COUNT, MODE>(p, pc, lds_filter, create_ray(origin, ray_dir), c);
+                if constexpr (SHADE == 1) color = color + ray_color_single<B, COUNT, MODE, !COUNT>(p, pc, lds_filter, create_ray(origin, ray_dir), c);
                 else color = color + ray_color<B, COUNT, MODE>(p, pc, lds_filter, create_ray(origin, ray_dir), c);
             }
         }
