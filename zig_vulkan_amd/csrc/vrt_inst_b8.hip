@@ -16,7 +16,7 @@ const KernelEntry kEntries[] = {
     VRT_TRACE_ALL_MODES(8, false, 6, 1),
     VRT_TRACE_ALL_MODES(8, false, 4, 0), VRT_TRACE_ALL_MODES(8, false, 8, 0),
     VRT_TRACE_ENTRY(8, false, 4, 5, 0, 256), VRT_TRACE_ENTRY(8, false, 4, 6, 0, 256),   // (tuning builds of the lockstep bounce kernel)
-    VRT_TRACE_ENTRY(8, false, 4, 7, 1, 256), VRT_TRACE_ENTRY(8, false, 7, 7, 1, 256), VRT_TRACE_ENTRY(8, false, 4, 5, 1, 256),   // (... of the several-samples kernel: 7 is the product's)
+    VRT_TRACE_ENTRY(8, false, 4, 7, 1, 256), VRT_TRACE_ENTRY(8, false, 7, 7, 1, 256), VRT_TRACE_ENTRY(8, false, 4, 5, 1, 256), VRT_TRACE_ENTRY(8, false, 4, 8, 1, 256),   // (... of the several-samples kernel: 7 is the product's)
 #endif
 };
 } // namespace
