@@ -177,7 +177,7 @@ def test_kernel_name_is_the_symbol_that_ran():
     rt.camera.d_camera.max_bounce = 3
     rt.draw()
     rt.wait()
-    assert rt.kernel_name() == "vrt_trace_kernel<8, false, 4, 4, 0, 256>"      # bounces on a small scene: the lockstep kernel on the shader's words
+    assert rt.kernel_name() == "vrt_trace_kernel<8, false, 4, 5, 0, 256>"      # bounces on a small scene: the lockstep kernel on the shader's words
     rt.deinit()
     from zig_vulkan_amd import _lib as L
     # persistent lanes forced; power-of-two grid: the half-block walk on a dilated cell index, or (flag) on the linear one

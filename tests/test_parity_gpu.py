@@ -277,7 +277,7 @@ def test_reference_app_default_scene_shape_non_cubic_grid():
     rt.push_materials(default_materials(256))
     rt.camera.set_origin((0.0, 0.0, 0.0))  # Camera.Config default origin, looking -Z
     rt.draw()
-    assert rt.kernel_name() == "vrt_trace_kernel<4, false, 4, 4, 0, 256>"  # what ran: the lockstep bounce kernel on the shader's words
+    assert rt.kernel_name() == "vrt_trace_kernel<4, false, 4, 5, 0, 256>"  # what ran: the lockstep bounce kernel on the shader's words
     f, u, c = rt.read_rgba32f(), rt.read_rgba8(), rt.counters()
     pc = O.push_constants(rt.camera.blob(), rt.sun.blob())
     rt.deinit()

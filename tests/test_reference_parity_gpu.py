@@ -165,7 +165,7 @@ def test_the_kernels_of_configs4_reproduce_the_reference_shader_at_4k(path, kern
     big).  `pool`: the persistent kernels forced (the scene would stay with the lockstep kernel by size): the first frame by
     vrt_path_kernel<..., DIL 1>, the second — the box of the occupied cells known — by vrt_pool_kernel<8, 6, 60, 2>; BOTH frames must be
     the reference's, bit for bit (float and RGBA8, every band).  `dil2`: the pool kernel switched off, vrt_path_kernel<..., DIL 2>.
-    `lockstep`: vrt_trace_kernel<8, false, 4, 4, 0, 256>."""
+    `lockstep`: vrt_trace_kernel<8, false, 4, 5, 0, 256>."""
     import ctypes as C
     from tests.golden.make_golden import scene_digest
     z = np.load(path)
@@ -192,7 +192,7 @@ def test_the_kernels_of_configs4_reproduce_the_reference_shader_at_4k(path, kern
     elif kernels == "dil2":
         assert names[1] == "vrt_path_kernel<8, 5, false, false, false, false, 2>", names
     else:
-        assert names == ["vrt_trace_kernel<8, false, 4, 4, 0, 256>"] * 2, names
+        assert names == ["vrt_trace_kernel<8, false, 4, 5, 0, 256>"] * 2, names
 
 
 @pytest.mark.parametrize("path", BIG_SHADOW, ids=lambda p: os.path.basename(p)[:-4])

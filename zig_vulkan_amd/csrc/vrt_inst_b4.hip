@@ -9,8 +9,9 @@ const KernelEntry kEntries[] = {
     VRT_TRACE_ENTRY(4, false, 4, 7, 2, 256), VRT_TRACE_ENTRY(4, false, 7, 7, 2, 256),
     // several samples, no bounces: 7 waves per SIMD (round 6: 72 VGPRs without a spill; 6 until then)
     VRT_TRACE_ENTRY(4, false, 4, 7, 1, 256), VRT_TRACE_ENTRY(4, false, 7, 7, 1, 256),
-    // frames with bounces, lockstep: 4 waves (scenes that stay in the caches) and 8 (the multi-GPU pipeline on large scenes)
-    VRT_TRACE_ENTRY(4, false, 4, 4, 0, 256), VRT_TRACE_ENTRY(4, false, 4, 8, 0, 256),
+    // frames with bounces, lockstep: 5 waves (scenes that stay in the caches; round 6: 96 VGPRs, 4 waves / 125 VGPRs until then) and 8
+    // (the multi-GPU pipeline on large scenes)
+    VRT_TRACE_ENTRY(4, false, 4, 5, 0, 256), VRT_TRACE_ENTRY(4, false, 4, 8, 0, 256),
 #else
     VRT_TRACE_ALL_MODES(4, false, 7, 2), VRT_TRACE_ALL_MODES(4, false, 8, 2), VRT_TRACE_ALL_MODES(4, false, 4, 2),
     VRT_TRACE_ALL_MODES(4, false, 6, 1),

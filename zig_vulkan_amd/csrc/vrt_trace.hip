@@ -566,8 +566,10 @@ KernelFn select_trace_kernel(int brick_dimension, bool counters, uint32_t varian
             const bool filter = (variant & kVariantPathFilter) != 0u;
             e = find_path_kernel(brick_dimension, mw == 5u ? 5 : ((mw >= 6u && !filter) ? (int)mw : kDefaultMinWaves), filter, false);
         } else {
-            e = find_trace_kernel(brick_dimension, false, mode, (mw == 8u || mw == 6u || (mw_asked == 5u)) ? (int)(mw_asked == 5u ? 5u : mw) : kDefaultMinWaves, 0, block);
-            if (!e && mw_asked == 5u) e = find_trace_kernel(brick_dimension, false, mode, kDefaultMinWaves, 0, block); // (5 is the path kernel's: product default)
+            // (round 6: with the per-lane set-up values formed again from the lane index the kernel fits 96 VGPRs = FIVE waves per SIMD with
+            // five registers spilled — 33 until then —: the reference app's run 11.6 -> 12.5 Grays/s; 4 asks for the 4-wave build (development))
+            e = find_trace_kernel(brick_dimension, false, mode, (mw == 8u || mw == 6u) ? (int)mw : (mw_asked == 4u ? 4 : 5), 0, block);
+            if (!e) e = find_trace_kernel(brick_dimension, false, mode, mw_asked == 4u ? 5 : kDefaultMinWaves, 0, block);
         }
     } else {
         // (the several-samples-per-pixel kernel, shade 1, needs 87 VGPRs left to itself = 5 waves per SIMD; held to 80 it spilled

@@ -1699,7 +1699,7 @@ VRT_DI f3 ray_color(const TraceParams &p, const PushConstants &pc, const uint32_
     int loop_count = 0;
     f3 color = mk3(0, 0, 0);
 
-    while (loop_count < max_bounce && grid_hit<B, COUNT, MODE, true>(p, lds_filter, current_ray, hit, c)) {
+    while (loop_count < max_bounce && grid_hit<B, COUNT, MODE, true, !COUNT>(p, lds_filter, current_ray, hit, c)) {
         loop_count += 1;
         Ray scattered = current_ray;
         bool result = false;
@@ -1724,7 +1724,7 @@ VRT_DI f3 ray_color(const TraceParams &p, const PushConstants &pc, const uint32_
             // CreateShadowRay, comp:186-190: sun_enabled > 0 here, so the ignore type is MAT_NONE
             Ray shadow_ray = create_ray(hit.point, shadow_ray_dir);
             Hit shadow_hit;
-            if (!grid_hit<B, COUNT, MODE, true>(p, lds_filter, shadow_ray, shadow_hit, c)) {
+            if (!grid_hit<B, COUNT, MODE, true, !COUNT>(p, lds_filter, shadow_ray, shadow_hit, c)) {
                 color = color + attenuation * sun_color;
             }
         } else {
@@ -1798,7 +1798,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const uint32_t unit = p.wave_groups ? (blockIdx.x >> 2) : (BLOCK == 512 ? blockIdx.x * 2u + (threadIdx.x >> 8) : (blockIdx.x >> p.split_all));
     // (SHADE 1: the wave's number in a scalar register — with fresh_lane() below nothing then keeps threadIdx.x alive)
     const uint32_t wave = p.wave_groups ? (blockIdx.x & 3u)
-                                        : (SHADE == 1 ? ((uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 3u) : ((threadIdx.x >> 6) & 3u));
+                                        : ((SHADE <= 1 && !COUNT) ? ((uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 3u) : ((threadIdx.x >> 6) & 3u));
     if (BLOCK == 512 && unit >= p.owned_tiles) return; // odd tile count: the last workgroup's second half is idle
     uint32_t owned;
     uint32_t split = 0u, half = 0u; // split: this workgroup renders one half of the tile (rows 4*half .. 4*half+3 of each 8x8 block)
@@ -1840,7 +1840,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     const uint32_t tile = p.own_period ? (owned / p.own_count) * p.own_period + p.own_slots[owned % p.own_count] : owned * p.shard_count + p.shard_rank;
     const uint32_t tile_x = tile % p.tiles_x, tile_y = tile / p.tiles_x;
     // lane -> pixel: wave w of the tile covers the 8x8 quadrant (w&1, w>>1)
-    const uint32_t lane = SHADE == 1 ? fresh_lane() : (threadIdx.x & 63u);
+    const uint32_t lane = (SHADE <= 1 && !COUNT) ? fresh_lane() : (threadIdx.x & 63u);
     const PushConstants &pc = p.pcs[blockIdx.y]; // frame blockIdx.y of this launch (kernarg segment, scalar loads)
     // A half-tile workgroup of a frame with TWO samples per pixel gives its idle lanes the second sample (round 4): lanes 0-31 trace
     // sample 0 of the wave's 32 pixels, lanes 32-63 sample 1 of the same pixels, and lane l adds lane l + 32's colour to its own —
@@ -1898,7 +1898,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
                 const f3 origin = opaque_uniform3(pc.cam.origin);
                 const float flag = (sample_i > 0) ? 1.0f : 0.0f;
                 float x = x0, y = y0;
-                if constexpr (SHADE == 1) { // (the pixel's coordinates formed again from the lane in every trip: not kept across the traversal)
+                if constexpr ((SHADE <= 1 && !COUNT)) { // (the pixel's coordinates formed again from the lane in every trip: not kept across the traversal)
                     uint32_t sx, sy;
                     place(fresh_lane(), sx, sy);
                     x = (float)(tile_x * kTileW + sx), y = (float)(tile_y * kTileH + sy);
@@ -1915,7 +1915,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         bool writer = true;
         if constexpr (SHADE != 2 && !COUNT) {
             if (dual) { // (both lanes of a pixel are inside the image or neither is: the source lane is active)
-                const uint32_t lane = SHADE == 1 ? fresh_lane() : (threadIdx.x & 63u);
+                const uint32_t lane = (SHADE <= 1 && !COUNT) ? fresh_lane() : (threadIdx.x & 63u);
                 const int from = (int)((lane + pixels) & 63u);
                 const f3 second = mk3(__shfl(color.x, from, 64), __shfl(color.y, from, 64), __shfl(color.z, from, 64));
                 color = color + second;
@@ -1927,7 +1927,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
 
         size_t o;
         uint32_t ox = in_x, oy = in_y;
-        if constexpr (SHADE == 1) place(fresh_lane(), ox, oy);
+        if constexpr ((SHADE <= 1 && !COUNT)) place(fresh_lane(), ox, oy);
         if (p.shard_count > 1u || p.packed_tiles) {
             o = (size_t)owned * (kTileW * kTileH) + oy * kTileW + ox; // packed tile-major shard
         } else {
@@ -1945,7 +1945,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         // RGB shard (multi-GPU pipeline): 16x16 tiles of 3-byte pixels, 768 bytes per tile.  The eight lanes of a row of
         // this wave's 8x8 block hold 24 consecutive bytes = 6 dwords; lane k < 6 of the row assembles dword k from the
         // two pixels it spans (bytes 4k .. 4k+3; pixel = byte / 3) and stores it.
-        const uint32_t lane = SHADE == 1 ? fresh_lane() : (threadIdx.x & 63u);
+        const uint32_t lane = (SHADE <= 1 && !COUNT) ? fresh_lane() : (threadIdx.x & 63u);
         uint32_t in_x, in_y;
         place(lane, in_x, in_y);
         const uint32_t k = lane & 7u;
@@ -1962,9 +1962,9 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
     __syncthreads();
     if (p.wave_timeline && threadIdx.x < 8) p.wave_timeline[(size_t)blockIdx.x * 8 + threadIdx.x] = vrt_prof[threadIdx.x];
 #else
-    const uint32_t lane_end = SHADE == 1 ? fresh_lane() : lane;
+    const uint32_t lane_end = (SHADE <= 1 && !COUNT) ? fresh_lane() : lane;
     if (p.wave_timeline && lane_end == 0) {
-        const size_t w_id = (size_t)blockIdx.x * (blockDim.x >> 6) + ((SHADE == 1 && BLOCK != 512) ? (p.wave_groups ? 0u : wave) : (threadIdx.x >> 6));
+        const size_t w_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (((SHADE <= 1 && !COUNT) && BLOCK != 512) ? (p.wave_groups ? 0u : wave) : (threadIdx.x >> 6));
         p.wave_timeline[2 * w_id] = wall_begin;
         p.wave_timeline[2 * w_id + 1] = wall_clock64();
     }
