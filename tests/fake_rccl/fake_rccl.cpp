@@ -151,13 +151,20 @@ ncclResult_t post_send(const Op &o, CopyJobs &jobs, int &njobs, std::vector<std:
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto &pool = comm->world->pool;
-        for (size_t i = 0; i < pool.size(); i++)
-            if (pool[i].bytes >= o.bytes && hipEventQuery(pool[i].idle) == hipSuccess) {
+        for (size_t i = 0; i < pool.size(); i++) {
+            // (a staging buffer's event may belong to a stream that no longer exists — communicators kept in the library's pool outlive the
+            // contexts whose streams used them, and contexts drain their streams before they go: anything but "not ready" means the copy out
+            // of the buffer is over.  The query's error must not stay behind as the thread's last error: the product's next kernel launch
+            // would report it)
+            const hipError_t q = pool[i].bytes >= o.bytes ? hipEventQuery(pool[i].idle) : hipErrorNotReady;
+            (void)hipGetLastError();
+            if (q != hipErrorNotReady) {
                 s.staging = pool[i].ptr;
                 (void)hipEventDestroy(pool[i].idle);
                 pool.erase(pool.begin() + (long)i);
                 break;
             }
+        }
     }
     if (!s.staging && hipMalloc(&s.staging, o.bytes ? o.bytes : 1) != hipSuccess) return ncclUnhandledCudaError;
     if (g_model_wgs > 0) {

@@ -64,7 +64,7 @@ def test_native_pipeline_with_many_ranks_on_one_gpu(world, frames_in_flight, fra
         except Exception as e:  # noqa: BLE001
             errors.append((r, repr(e)))
 
-    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
@@ -135,7 +135,7 @@ def test_a_communicator_per_launch_slot_and_the_stand_ins_cost_model(world, fram
             except Exception as e:  # noqa: BLE001
                 errors.append((r, repr(e)))
 
-        threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+        threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
         for t in threads:
             t.start()
         for t in threads:
@@ -189,7 +189,7 @@ def test_communicators_kept_in_the_pool_are_reused_by_the_next_context_with_the_
                 except Exception as e:  # noqa: BLE001
                     errors.append((r, repr(e)))
 
-            threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+            threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
             for t in threads:
                 t.start()
             for t in threads:
@@ -250,7 +250,7 @@ def test_more_ranks_than_tiles_and_tiny_frames(size, world, root_weight, frames_
         except Exception as e:  # noqa: BLE001
             errors.append((r, repr(e)))
 
-    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
@@ -316,7 +316,7 @@ def test_edits_made_on_one_rank_reach_every_replica(world, no_broadcast):
         except Exception as e:  # noqa: BLE001
             errors.append((r, repr(e)))
 
-    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
@@ -372,7 +372,7 @@ def test_pipeline_stage_profile(world, frames_per_launch):
         except Exception as e:  # noqa: BLE001
             errors.append((r, repr(e)))
 
-    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
@@ -451,7 +451,7 @@ def test_bounce_frames_go_through_the_pipeline_on_the_persistent_kernels(world, 
         except Exception as e:  # noqa: BLE001
             errors.append((r, repr(e)))
 
-    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
@@ -498,7 +498,7 @@ def test_bounce_frames_without_a_sample_buffer_keep_the_lockstep_kernel_in_the_p
         except Exception as e:  # noqa: BLE001
             errors.append((r, repr(e)))
 
-    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
@@ -546,7 +546,7 @@ def test_reserve_samples_on_a_sharded_cache_resident_bounce_context_has_nothing_
         except Exception as e:  # noqa: BLE001
             errors.append((r, repr(e)))
 
-    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
@@ -596,7 +596,7 @@ def test_frames_submitted_by_one_call(world, frames_per_launch, bounce):
         except Exception as e:  # noqa: BLE001
             errors.append((r, repr(e)))
 
-    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
@@ -653,7 +653,7 @@ def test_a_batch_may_hold_frames_of_several_kernels(order):
         except Exception as e:  # noqa: BLE001
             errors.append((r, repr(e)))
 
-    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
@@ -705,7 +705,7 @@ def test_sharded_frames_of_the_baseline_configurations_at_full_size_are_the_orac
         except Exception as e:  # noqa: BLE001
             errors.append((r, repr(e)))
 
-    threads = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:

@@ -733,7 +733,7 @@ int vrt_dist_selftest_slots(vrt_ctx *ctx, uint32_t busy_us, uint32_t rounds, dou
                 const ncclComm_t comm = d->comms[i % d->ncomms];
                 const bool last = round == rounds;
                 if (last) (void)hipEventRecord(ev[2u * i], st);
-                if (busy_us) hipLaunchKernelGGL(vrt_spin_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)busy_us * 100ull);
+                if (busy_us) VRT_LAUNCH(vrt_spin_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)busy_us * 100ull);
                 ncclResult_t r = d->api.GroupStart();
                 if (r == ncclSuccess) r = d->api.Send(a[i], n, ncclUint8, d->rank, comm, st);
                 if (r == ncclSuccess) r = d->api.Recv(b[i], n, ncclUint8, d->rank, comm, st);

@@ -56,7 +56,7 @@ const KernelEntry kEntries[] = {
 };
 } // namespace
 hipError_t launch_pool_resolve(const TraceParams &p, hipStream_t stream) {
-    hipLaunchKernelGGL(vrt_pool_resolve_kernel, dim3(p.owned_tiles, 1), dim3(256), 0, stream, p);
+    VRT_LAUNCH(vrt_pool_resolve_kernel, dim3(p.owned_tiles, 1), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 KernelTable inst_path() { return KernelTable{kEntries, (int)(sizeof kEntries / sizeof kEntries[0])}; }

@@ -1,6 +1,16 @@
 // vrt_kernels.h — the table of compiled traversal kernels: what the instantiation units (vrt_inst_*.hip) export and what
 // the selection code in vrt_trace.hip searches.
 #pragma once
+// Every kernel launch of the library: the launchers report `hipGetLastError()` behind the launch, and that call returns the calling THREAD's
+// last error whichever runtime call left it — also one that another library tolerated on this thread just before (RCCL's host code runs on
+// the rank's thread between two launches; the test-only RCCL stand-in's hipEventQuery on an event of a destroyed stream left
+// "operation not permitted when stream is capturing" behind, and the next frame's launch reported it: round 6).  So the thread's stale
+// error is read away first; what the launcher then reports is the launch's own.
+#define VRT_LAUNCH(...)                   \
+    do {                                  \
+        (void)hipGetLastError();          \
+        hipLaunchKernelGGL(__VA_ARGS__);  \
+    } while (0)
 #include "vrt_internal.h"
 
 namespace vrt {

@@ -289,13 +289,13 @@ hipError_t launch_denoise(const void *img, int W, int H, int samples, float bias
     const float span_x = 15.0f * (float)W / (float)out_w + 2.0f * (reach - 3.0f) + 5.0f, span_y = 15.0f * (float)H / (float)out_h + 2.0f * (reach - 3.0f) + 5.0f;
     const bool staged = span_x <= (float)kDenoiseTile && span_y <= (float)kDenoiseTile && samples < kDenoiseTable && W >= 2 * kDenoiseTile && H >= 2 * kDenoiseTile;
     if (staged && tol == 20.0f)
-        hipLaunchKernelGGL(vrt_denoise_tile_kernel<20>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
+        VRT_LAUNCH(vrt_denoise_tile_kernel<20>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
     else if (staged)
-        hipLaunchKernelGGL(vrt_denoise_tile_kernel<0>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
+        VRT_LAUNCH(vrt_denoise_tile_kernel<0>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
     else if (reach < (float)(W < H ? W : H))
-        hipLaunchKernelGGL(vrt_denoise_kernel<true>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
+        VRT_LAUNCH(vrt_denoise_kernel<true>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
     else
-        hipLaunchKernelGGL(vrt_denoise_kernel<false>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
+        VRT_LAUNCH(vrt_denoise_kernel<false>, grid, dim3(256), 0, stream, (const uchar4 *)img, W, H, pc, out_w, out_h, (uint32_t *)out_u8, (float4 *)out_f32);
     return hipGetLastError();
 }
 

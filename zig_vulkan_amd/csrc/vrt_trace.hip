@@ -662,7 +662,7 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
         const uint32_t per_group = 4u * (64u + pe->pool_slots), fit = (uint32_t)std::min<uint64_t>((units + per_group - 1u) / per_group, 1u << 30);
         const uint32_t hold = p.pool_cus * pe->min_waves; // (min_waves 256-thread workgroups per CU)
         const uint32_t groups = fit < hold ? (fit ? fit : 1u) : hold;
-        hipLaunchKernelGGL(fn, dim3(groups, 1), dim3(256), pool_group_lds_bytes(pe->pool_slots, pe->pool_stages), stream, p);
+        VRT_LAUNCH(fn, dim3(groups, 1), dim3(256), pool_group_lds_bytes(pe->pool_slots, pe->pool_stages), stream, p);
         e = hipGetLastError();
         return e != hipSuccess ? e : launch_pool_resolve(p, stream);
     }
@@ -678,7 +678,7 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
         // (samples as units of work — vrt_pool_resolve_kernel behind the kernel — for launches of one frame whose context holds the buffer)
         TraceParams q = p;
         if (frames != 1u) q.pool_samples = nullptr;
-        hipLaunchKernelGGL(fn, dim3(groups, frames), dim3(threads), (filter ? p.path_lds_bytes : 0u) + (p.path_brick_lds ? (threads >> 6) * 4096u : 0u), stream, q);
+        VRT_LAUNCH(fn, dim3(groups, frames), dim3(threads), (filter ? p.path_lds_bytes : 0u) + (p.path_brick_lds ? (threads >> 6) * 4096u : 0u), stream, q);
         e = hipGetLastError();
         return (e != hipSuccess || !q.pool_samples) ? e : launch_pool_resolve(q, stream);
     }
@@ -699,21 +699,21 @@ hipError_t launch_trace(KernelFn fn, const TraceParams &p, size_t lds_bytes, hip
                                                        p.block_threads != 512u && !p.split_all && !p.packed_rgb && !profiled) {
         TraceParams q = p;
         q.wave_groups = 1u;
-        hipLaunchKernelGGL(fn, dim3((q.owned_tiles + (q.tile_order == 5u ? q.sched_units : 0u)) * 4u, frames), dim3(64), lds_bytes, stream, q);
+        VRT_LAUNCH(fn, dim3((q.owned_tiles + (q.tile_order == 5u ? q.sched_units : 0u)) * 4u, frames), dim3(64), lds_bytes, stream, q);
         return hipGetLastError();
     }
     // grid.y = the frames of this launch (p.pcs[0 .. frames-1]); workgroups are dispatched x-fastest, so the tiles of
     // frame 0 start first
-    if (p.block_threads == 512u) hipLaunchKernelGGL(fn, dim3((p.owned_tiles + 1u) / 2u, frames), dim3(512), lds_bytes, stream, p);
-    else if (p.wave_groups) hipLaunchKernelGGL(fn, dim3((p.owned_tiles + (p.tile_order == 5u ? p.sched_units : 0u)) * 4u, frames), dim3(64), lds_bytes, stream, p);
-    else if (p.tile_order == 3u && p.split_all) hipLaunchKernelGGL(fn, dim3(p.owned_tiles << p.split_all, frames), dim3(256), lds_bytes, stream, p);
-    else hipLaunchKernelGGL(fn, dim3(p.owned_tiles + (p.tile_order == 5u ? p.sched_units : 0u), frames), dim3(256), lds_bytes, stream, p);
+    if (p.block_threads == 512u) VRT_LAUNCH(fn, dim3((p.owned_tiles + 1u) / 2u, frames), dim3(512), lds_bytes, stream, p);
+    else if (p.wave_groups) VRT_LAUNCH(fn, dim3((p.owned_tiles + (p.tile_order == 5u ? p.sched_units : 0u)) * 4u, frames), dim3(64), lds_bytes, stream, p);
+    else if (p.tile_order == 3u && p.split_all) VRT_LAUNCH(fn, dim3(p.owned_tiles << p.split_all, frames), dim3(256), lds_bytes, stream, p);
+    else VRT_LAUNCH(fn, dim3(p.owned_tiles + (p.tile_order == 5u ? p.sched_units : 0u), frames), dim3(256), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t *prev_order, uint32_t *order, uint32_t n, uint32_t extra_max,
                            uint32_t extra, uint32_t wave_slots, hipStream_t stream) {
-    hipLaunchKernelGGL(vrt_schedule_kernel, dim3(1), dim3(1024), 0, stream, cost, snap, prev_order, order, n, extra_max, extra < extra_max ? extra : extra_max,
+    VRT_LAUNCH(vrt_schedule_kernel, dim3(1), dim3(1024), 0, stream, cost, snap, prev_order, order, n, extra_max, extra < extra_max ? extra : extra_max,
                        wave_slots);
     return hipGetLastError();
 }
@@ -721,7 +721,7 @@ hipError_t launch_schedule(const uint32_t *cost, uint32_t *snap, const uint32_t 
 hipError_t launch_build_status_halfblocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
     if (!p.status_halfblocks) return hipSuccess;
     const uint32_t words = (dim_x >> 2) * (dim_z >> 2) * (dim_y >> 1);
-    hipLaunchKernelGGL(vrt_build_status_halfblocks, dim3((words + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
+    VRT_LAUNCH(vrt_build_status_halfblocks, dim3((words + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
                        const_cast<uint32_t *>(p.status_halfblocks), dim_x, dim_y, dim_z);
     return hipGetLastError();
 }
@@ -733,10 +733,10 @@ hipError_t launch_build_cell_distance(const TraceParams &p, uint32_t dim_x, uint
     return hipErrorNotSupported; // (no kernel of the product build reads the field: vrt_create never allocates it there)
 #else
     uint8_t *d = const_cast<uint8_t *>(p.cell_distance);
-    hipLaunchKernelGGL(vrt_build_distance_seed, dim3((p.status_words + 255u) / 256u), dim3(256), 0, stream, p.brick_status, d, p.status_words, p.status_cells);
+    VRT_LAUNCH(vrt_build_distance_seed, dim3((p.status_words + 255u) / 256u), dim3(256), 0, stream, p.brick_status, d, p.status_words, p.status_cells);
     const uint32_t lines[3] = {dim_z * dim_y, dim_x * dim_y, dim_x * dim_z};
     for (uint32_t axis = 0; axis < 3u; axis++)
-        hipLaunchKernelGGL(vrt_build_distance_sweep, dim3((lines[axis] + 255u) / 256u), dim3(256), 0, stream, d, dim_x, dim_y, dim_z, axis);
+        VRT_LAUNCH(vrt_build_distance_sweep, dim3((lines[axis] + 255u) / 256u), dim3(256), 0, stream, d, dim_x, dim_y, dim_z, axis);
     return hipGetLastError();
 #endif
 }
@@ -753,7 +753,7 @@ hipError_t launch_build_cell_occupancy(const TraceParams &p, uint32_t brick_dime
     const uint64_t scan_lo = any_slot ? 0u : (cell_lo < cell_hi ? cell_lo : 0u), scan_hi = any_slot ? cells : (cell_lo < cell_hi ? cell_hi : 0u);
     if (scan_lo >= scan_hi) return hipSuccess;
     const uint64_t words = (scan_hi - scan_lo) * words8;
-    hipLaunchKernelGGL(vrt_build_cell_occupancy, dim3((uint32_t)((words + 255u) / 256u)), dim3(256), 0, stream, p.brick_status, p.brick_index,
+    VRT_LAUNCH(vrt_build_cell_occupancy, dim3((uint32_t)((words + 255u) / 256u)), dim3(256), 0, stream, p.brick_status, p.brick_index,
                        reinterpret_cast<const uint2 *>(p.brick_occupancy), reinterpret_cast<uint2 *>(const_cast<uint8_t *>(p.cell_occupancy)), scan_lo, scan_hi,
                        words8, brick_alloc, cell_lo, cell_hi, slot_lo, slot_hi);
     return hipGetLastError();
@@ -768,10 +768,10 @@ hipError_t launch_build_cell_material(const TraceParams &p, uint32_t brick_dimen
     const dim3 grid((cells + 255u) / 256u);
     uint8_t *out = const_cast<uint8_t *>(p.cell_material);
     if (brick_dimension == 8u)
-        hipLaunchKernelGGL(vrt_build_cell_material<8>, grid, dim3(256), 0, stream, p.brick_status, p.brick_index, p.brick_occupancy, p.brick_start_index, p.material_index, out,
+        VRT_LAUNCH(vrt_build_cell_material<8>, grid, dim3(256), 0, stream, p.brick_status, p.brick_index, p.brick_occupancy, p.brick_start_index, p.material_index, out,
                            cells, p.status_words, brick_alloc, brick_alloc * bits, cell_lo, cell_hi, slot_lo, slot_hi, mat_lo, mat_hi);
     else
-        hipLaunchKernelGGL(vrt_build_cell_material<4>, grid, dim3(256), 0, stream, p.brick_status, p.brick_index, p.brick_occupancy, p.brick_start_index, p.material_index, out,
+        VRT_LAUNCH(vrt_build_cell_material<4>, grid, dim3(256), 0, stream, p.brick_status, p.brick_index, p.brick_occupancy, p.brick_start_index, p.material_index, out,
                            cells, p.status_words, brick_alloc, brick_alloc * bits, cell_lo, cell_hi, slot_lo, slot_hi, mat_lo, mat_hi);
     return hipGetLastError();
 }
@@ -781,7 +781,7 @@ hipError_t launch_check_start_is_slot(const TraceParams &p, uint32_t brick_dimen
     uint32_t *flag = const_cast<uint32_t *>(p.start_is_slot);
     const hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flag), 1, 1, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(vrt_check_start_is_slot, dim3((uint32_t)((brick_alloc + 255u) / 256u)), dim3(256), 0, stream, p.brick_start_index, flag, brick_alloc,
+    VRT_LAUNCH(vrt_check_start_is_slot, dim3((uint32_t)((brick_alloc + 255u) / 256u)), dim3(256), 0, stream, p.brick_start_index, flag, brick_alloc,
                        brick_dimension * brick_dimension * brick_dimension);
     return hipGetLastError();
 }
@@ -791,7 +791,7 @@ hipError_t launch_check_materials_plain(const TraceParams &p, uint32_t count, hi
     uint32_t *flag = const_cast<uint32_t *>(p.materials_plain);
     const hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flag), 1, 1, stream);
     if (e != hipSuccess) return e;
-    if (count) hipLaunchKernelGGL(vrt_check_materials_plain, dim3((count + 255u) / 256u), dim3(256), 0, stream, p.materials, flag, count);
+    if (count) VRT_LAUNCH(vrt_check_materials_plain, dim3((count + 255u) / 256u), dim3(256), 0, stream, p.materials, flag, count);
     return hipGetLastError();
 }
 
@@ -800,14 +800,14 @@ hipError_t launch_build_cell_bounds(const TraceParams &p, uint32_t dim_x, uint32
     int *bounds = const_cast<int *>(p.cell_bounds);
     hipError_t e = hipMemsetAsync(bounds, 0x80, 6 * sizeof(int), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(vrt_build_cell_bounds, dim3((p.status_words + 255u) / 256u), dim3(256), 0, stream, p.brick_status, bounds, p.status_words,
+    VRT_LAUNCH(vrt_build_cell_bounds, dim3((p.status_words + 255u) / 256u), dim3(256), 0, stream, p.brick_status, bounds, p.status_words,
                        dim_x * dim_y * dim_z, dim_x, dim_z);
     return hipGetLastError();
 }
 
 hipError_t launch_build_status_bytes(const TraceParams &p, hipStream_t stream) {
     if (!p.status_bytes) return hipSuccess;
-    hipLaunchKernelGGL(vrt_build_status_bytes, dim3((p.status_words + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
+    VRT_LAUNCH(vrt_build_status_bytes, dim3((p.status_words + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
                        const_cast<uint8_t *>(p.status_bytes), p.status_words, p.status_cells);
     return hipGetLastError();
 }
@@ -815,7 +815,7 @@ hipError_t launch_build_status_bytes(const TraceParams &p, hipStream_t stream) {
 hipError_t launch_build_status_blocks(const TraceParams &p, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
     if (!p.status_blocks) return hipSuccess;
     const uint32_t nblocks = p.nbx * p.nby * p.nbz;
-    hipLaunchKernelGGL(vrt_build_status_blocks, dim3((nblocks + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
+    VRT_LAUNCH(vrt_build_status_blocks, dim3((nblocks + 255u) / 256u), dim3(256), 0, stream, p.brick_status,
                        const_cast<uint2 *>(p.status_blocks), dim_x, dim_y, dim_z, p.nbx, p.nby, p.nbz);
     return hipGetLastError();
 }
@@ -825,12 +825,12 @@ hipError_t launch_assemble_rgb(const void *gathered, void *frame, uint32_t width
     if (width % 4u == 0u && (reinterpret_cast<uintptr_t>(frame) & 15u) == 0u && (reinterpret_cast<uintptr_t>(gathered) & 3u) == 0u &&
         frame_src_stride_bytes % 4u == 0u) {
         const dim3 grid4((width / 4u + 63u) / 64u, (height + 3u) / 4u, frames);
-        hipLaunchKernelGGL(vrt_assemble_rgb4_kernel, grid4, dim3(256), 0, stream, (const uint8_t *)gathered, (uint32_t *)frame, width, height, tiles_x,
+        VRT_LAUNCH(vrt_assemble_rgb4_kernel, grid4, dim3(256), 0, stream, (const uint8_t *)gathered, (uint32_t *)frame, width, height, tiles_x,
                            shard_count, tiles_per_rank, own, frame_src_stride_bytes);
         return hipGetLastError();
     }
     const dim3 grid((width + 63u) / 64u, (height + 3u) / 4u, frames);
-    hipLaunchKernelGGL(vrt_assemble_rgb_kernel, grid, dim3(256), 0, stream, (const uint8_t *)gathered, (uint32_t *)frame, width, height, tiles_x,
+    VRT_LAUNCH(vrt_assemble_rgb_kernel, grid, dim3(256), 0, stream, (const uint8_t *)gathered, (uint32_t *)frame, width, height, tiles_x,
                        shard_count, tiles_per_rank, own, frame_src_stride_bytes);
     return hipGetLastError();
 }
@@ -840,10 +840,10 @@ hipError_t launch_assemble(const void *gathered, void *frame, uint32_t bytes_per
                            uint32_t frames, uint32_t frame_src_stride_pixels) {
     const dim3 grid((width + 63u) / 64u, (height + 3u) / 4u, frames);
     if (bytes_per_pixel == 4) {
-        hipLaunchKernelGGL(vrt_assemble_kernel<uint32_t>, grid, dim3(256), 0, stream, (const uint32_t *)gathered, (uint32_t *)frame, width,
+        VRT_LAUNCH(vrt_assemble_kernel<uint32_t>, grid, dim3(256), 0, stream, (const uint32_t *)gathered, (uint32_t *)frame, width,
                            height, tiles_x, shard_count, tiles_per_rank, own, frame_src_stride_pixels);
     } else if (bytes_per_pixel == 16) {
-        hipLaunchKernelGGL(vrt_assemble_kernel<float4>, grid, dim3(256), 0, stream, (const float4 *)gathered, (float4 *)frame, width, height,
+        VRT_LAUNCH(vrt_assemble_kernel<float4>, grid, dim3(256), 0, stream, (const float4 *)gathered, (float4 *)frame, width, height,
                            tiles_x, shard_count, tiles_per_rank, own, frame_src_stride_pixels);
     } else {
         return hipErrorInvalidValue;
