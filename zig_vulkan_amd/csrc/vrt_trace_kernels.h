@@ -1957,12 +1957,12 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void vrt_trace_kernel(const Trace
         if (k < 6u && lane < (64u >> split)) // (a half-tile workgroup: the idle half of the wave holds no pixels)
             reinterpret_cast<uint32_t *>(p.target_rgba8 + (size_t)blockIdx.y * p.batch_target_stride)[(size_t)owned * 192u + in_y * 12u + (in_x >> 3) * 6u + k] = dword;
     }
+    const uint32_t lane_end = (SHADE <= 1 && !COUNT) ? fresh_lane() : lane;
 #ifdef VRT_DEV_PROFILE
     VRT_PROF_END(7, tp7);
     __syncthreads();
     if (p.wave_timeline && threadIdx.x < 8) p.wave_timeline[(size_t)blockIdx.x * 8 + threadIdx.x] = vrt_prof[threadIdx.x];
 #else
-    const uint32_t lane_end = (SHADE <= 1 && !COUNT) ? fresh_lane() : lane;
     if (p.wave_timeline && lane_end == 0) {
         const size_t w_id = (size_t)blockIdx.x * (blockDim.x >> 6) + (((SHADE <= 1 && !COUNT) && BLOCK != 512) ? (p.wave_groups ? 0u : wave) : (threadIdx.x >> 6));
         p.wave_timeline[2 * w_id] = wall_begin;
