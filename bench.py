@@ -339,7 +339,7 @@ def native_probe(env, timeout: float):
     if uids is None:
         return False, {"ok": False, "seconds": 0.0, "this_rank": "rank 0 could not make a RCCL unique id"}
     cmd = [sys.executable, os.path.abspath(__file__), "--dist-probe", "--probe-uid", uids.hex(), "--probe-rank", str(env.rank),
-           "--probe-world", str(env.world), "--probe-device", str(env.local_rank), "--dist-comms", str(env.args.dist_comms)]
+           "--probe-world", str(env.world), "--probe-device", str(env.local_rank), "--dist-comms", str(getattr(getattr(env, "args", None), "dist_comms", 0))]
     child_env = {k: v for k, v in os.environ.items()
                  if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
                  and not k.startswith("TORCHELASTIC_")}
