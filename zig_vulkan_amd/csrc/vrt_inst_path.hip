@@ -26,7 +26,7 @@ const KernelEntry kEntries[] = {
     VRT_POOL_ENTRY(4, 6, 64, 0),
 #ifdef VRT_DEV_VARIANTS
     VRT_POOL_ENTRY(8, 4, 64, 4), VRT_POOL_ENTRY(8, 5, 64, 1), VRT_POOL_ENTRY(8, 6, 56, 1), VRT_POOL_ENTRY(8, 5, 40, 4),
-    VRT_POOL_ENTRY(8, 5, 64, 2), VRT_POOL_ENTRY(4, 5, 64, 0), VRT_POOL_ENTRY(8, 6, 56, 2), VRT_POOL_ENTRY(8, 6, 58, 2), VRT_POOL_ENTRY(8, 6, 54, 2), VRT_POOL_ENTRY(8, 6, 40, 3), VRT_POOL_ENTRY(8, 6, 44, 2), VRT_POOL_ENTRY(8, 6, 32, 4),
+    VRT_POOL_ENTRY(8, 5, 64, 2), VRT_POOL_ENTRY(4, 5, 64, 0), VRT_POOL_ENTRY(8, 6, 56, 2), VRT_POOL_ENTRY(8, 6, 58, 2), VRT_POOL_ENTRY(8, 6, 54, 2), VRT_POOL_ENTRY(8, 6, 40, 3), VRT_POOL_ENTRY(8, 6, 44, 2), VRT_POOL_ENTRY(8, 6, 32, 4), VRT_POOL_ENTRY(8, 7, 48, 2),
 #endif
 #ifdef VRT_DEV_VARIANTS
     // DIL 4 (round 3): the counter-free dilated-index walk with the DDA two cells ahead of the test (two requests in flight per lane;
