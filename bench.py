@@ -291,8 +291,9 @@ def dist_probe_child(args) -> None:
     # Round 6: the cases go through the communicator pool the way the timed legs do — one id for several contexts
     # (vrt_dist_keep_communicators), a second context made while the first still holds its communicators (the root-share tune keeps three
     # alive), a third that takes everything from the pool — so that a hang in that machinery is this child's timeout, not the run's.
-    cases = [(plain_w, 0, 1, 8, 0, True), (plain_w, 0, 8, 4, 0, False), (plain_w, 0, 1, 8, 0, False),
-             (W.Workload("probe_bounce", 330, 210, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000), 1 << 23, 1, 4, 1, False)]
+    # (few launch slots per case: every communicator is a collective to make, and the child runs under the parent's time limit)
+    cases = [(plain_w, 0, 1, 4, 0, True), (plain_w, 0, 8, 4, 0, False), (plain_w, 0, 1, 4, 0, False),
+             (W.Workload("probe_bounce", 330, 210, 256, 8, 2, 2, True, 5.0, "sparse", 0.08, 30000), 1 << 23, 1, 2, 1, False)]
     VoxelRT.dist_keep_communicators(True)
     grids, held = {}, []
     for i, (w, variant, batch, slots, which, hold) in enumerate(cases):
@@ -840,7 +841,8 @@ def main(argv=None) -> None:
     ap.add_argument("--force-gather", action="store_true", help="run the shard/gather/assemble path even at world size 1")
     ap.add_argument("--no-native-probe", action="store_true",
                     help="N > 1: skip the child-process probe of the native RCCL pipeline that decides between it and the torch path")
-    ap.add_argument("--probe-timeout", type=float, default=120.0)
+    ap.add_argument("--probe-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the child-process probe of the native pipeline may take (two ncclCommInitRank + ten ncclCommSplit on N GPUs, three small scenes)")
     ap.add_argument("--dist-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe-uid", default="", help=argparse.SUPPRESS)
     ap.add_argument("--probe-rank", type=int, default=0, help=argparse.SUPPRESS)
