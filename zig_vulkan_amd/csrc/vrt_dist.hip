@@ -225,7 +225,8 @@ int acquire_comms(vrt_ctx *ctx, Dist *d, const char *rccl_path, const void *id12
     d->comm = d->comms[0];
     // The ranks must agree on the number: slot i's gather goes to communicator i % ncomms on EVERY rank.  A split that failed on one
     // rank only would leave them with different numbers; one tiny all-reduce (minimum) on the first communicator settles it.
-    if (d->api.AllReduce && d->ncomms > 1) {
+    // (asked of `want`, which every rank passes alike — not of what this rank got: a rank left with one communicator must still take part)
+    if (d->api.AllReduce && want > 1u) {
         int32_t *dv = nullptr;
         int32_t hv = (int32_t)d->ncomms;
         bool ok = hipMalloc(reinterpret_cast<void **>(&dv), sizeof hv) == hipSuccess && hipMemcpyAsync(dv, &hv, sizeof hv, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
