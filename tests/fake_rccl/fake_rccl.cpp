@@ -347,13 +347,16 @@ ncclResult_t ncclGroupStart() {
     t_depth++;
     return ncclSuccess;
 }
-ncclResult_t ncclGroupEnd() {
+// (file-local: ncclBroadcast below must not reach it through the PLT, where the name would bind to the REAL RCCL's ncclGroupEnd if
+// PyTorch's librccl was loaded into the process first — the queued operations would then never run and the ranks would wait for ever)
+static ncclResult_t group_end_impl() {
     if (t_depth <= 0) return ncclInvalidUsage;
     if (--t_depth > 0) return ncclSuccess;
     std::vector<Op> ops;
     ops.swap(t_ops);
     return run_group(ops);
 }
+ncclResult_t ncclGroupEnd() { return group_end_impl(); }
 
 // (the implementations are file-local: a call from ncclBroadcast below must not go through the PLT, where it would bind to the
 // real RCCL's ncclSend / ncclRecv if PyTorch's librccl is already in the process)
@@ -371,7 +374,7 @@ ncclResult_t ncclBroadcast(const void *sendbuff, void *recvbuff, size_t count, n
     ncclResult_t r = ncclSuccess;
     for (int peer = 0; peer < comm->world->nranks && r == ncclSuccess; peer++)
         if (peer != root) r = enqueue(Op{true, const_cast<void *>(sendbuff), count, peer, comm, stream});
-    const ncclResult_t r2 = ncclGroupEnd();
+    const ncclResult_t r2 = group_end_impl();
     if (r == ncclSuccess) r = r2;
     if (r != ncclSuccess) return r;
     if (recvbuff != sendbuff && hipMemcpyAsync(recvbuff, sendbuff, count, hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
